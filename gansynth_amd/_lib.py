@@ -1,0 +1,96 @@
+"""ctypes binding of libgansynth_hip.so (C ABI declared in include/gansynth_hip.h).
+
+Fails loudly: if the shared library has not been built (`python -c 'import __graft_entry__ as g;
+g.build()'` or gansynth_amd/csrc/build.sh) loading raises -- there is no fallback path.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_void_p, POINTER
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgansynth_hip.so")
+
+GS_F32, GS_BF16 = 0, 1
+ACT_NONE, ACT_LRELU, ACT_TANH = 0, 1, 2
+CONV_FWD, CONV_BWD_DATA, CONV_BWD_WEIGHT = 0, 1, 2
+
+P, I, F, L, Z = c_void_p, c_int, c_float, c_int64, c_size_t
+
+# name -> (restype, argtypes); every symbol include/gansynth_hip.h declares
+SIGNATURES = {
+    "gs_last_error": (c_char_p, []),
+    "gs_version": (I, []),
+    "gs_init": (I, []),
+    "gs_prof_enable": (I, [I]),
+    "gs_prof_collect": (I, [POINTER(c_int), POINTER(c_double), POINTER(c_double)]),
+    "gs_conv2d_workspace_bytes": (Z, [I, I, I, I, I, I, I, I, I]),
+    "gs_conv2d_fwd": (I, [P, P, P, I, I, I, I, I, I, I, F, I, P, Z, P]),
+    "gs_conv2d_bwd_data": (I, [P, P, P, I, I, I, I, I, I, I, F, I, P, Z, P]),
+    "gs_conv2d_bwd_weight": (I, [P, P, P, I, I, I, I, I, I, I, F, I, P, Z, P]),
+    "gs_conv2d_transpose_s2_workspace_bytes": (Z, [I, I, I, I, I, I, I]),
+    "gs_conv2d_transpose_s2_fwd": (I, [P, P, P, I, I, I, I, I, F, I, P, Z, P]),
+    "gs_conv2d_transpose_s2_bwd_data": (I, [P, P, P, I, I, I, I, I, F, I, P, Z, P]),
+    "gs_conv2d_transpose_s2_bwd_weight": (I, [P, P, P, I, I, I, I, I, F, I, P, Z, P]),
+    "gs_dense_fwd_workspace_bytes": (Z, [I, I, I]),
+    "gs_dense_fwd": (I, [P, P, P, I, I, I, F, I, P, Z, P]),
+    "gs_dense_bwd_data": (I, [P, P, P, I, I, I, F, I, P]),
+    "gs_dense_bwd_weight": (I, [P, P, P, I, I, I, F, I, P]),
+    "gs_embedding_fwd": (I, [P, P, P, I, I, I, F, I, P]),
+    "gs_embedding_bwd": (I, [P, P, P, I, I, I, F, I, P]),
+    "gs_bias_act_fwd": (I, [P, P, P, L, I, I, I, P]),
+    "gs_act_bwd": (I, [P, P, P, L, I, I, P]),
+    "gs_tanh_bwd_bwd": (I, [P, P, P, P, L, I, P]),
+    "gs_channel_sum_workspace_bytes": (Z, [L, I]),
+    "gs_channel_sum": (I, [P, P, L, I, I, P, Z, P]),
+    "gs_pixel_norm_fwd": (I, [P, P, L, I, F, I, P]),
+    "gs_pixel_norm_bwd": (I, [P, P, P, L, I, F, I, P]),
+    "gs_pixel_norm_bwd_bwd": (I, [P, P, P, P, L, I, F, I, P]),
+    "gs_upscale2d": (I, [P, P, I, I, I, I, I, I, F, I, P]),
+    "gs_blocksum2d": (I, [P, P, I, I, I, I, I, I, F, I, P]),
+    "gs_batch_stddev_fwd": (I, [P, P, I, I, I, F, I, P]),
+    "gs_batch_stddev_bwd": (I, [P, P, P, I, I, I, F, I, P]),
+    "gs_batch_stddev_bwd_bwd": (I, [P, P, P, P, P, I, I, I, F, I, P]),
+    "gs_axpby": (I, [P, P, P, L, F, F, I, P]),
+    "gs_sumsq_rows": (I, [P, P, I, L, I, P]),
+    "gs_row_scale": (I, [P, P, P, I, L, I, P]),
+    "gs_adam_tf_step": (I, [P, P, P, P, L, F, F, F, F, F, P]),
+    "gs_spectral_plan_create": (I, [POINTER(c_void_p), I, I, I, P, P]),
+    "gs_spectral_plan_destroy": (I, [P]),
+    "gs_stft_fwd": (I, [P, P, I, I, I, P, P, P]),
+    "gs_mel_project": (I, [P, P, P, L, P]),
+    "gs_if_unwrap": (I, [P, P, P, I, P]),
+    "gs_stft_mel_if_fwd": (I, [P, P, I, I, I, P, I, P, Z, P]),
+    "gs_stft_mel_if_workspace_bytes": (Z, [P, I]),
+    "gs_mel_if_to_waveform": (I, [P, P, I, I, I, P, I, P, Z, P]),
+    "gs_mel_if_to_waveform_workspace_bytes": (Z, [P, I]),
+}
+
+_lib = None
+
+
+class GansynthHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the library once and attach prototypes.  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GansynthHipError(
+            f"{LIB_PATH} not found: build it with gansynth_amd/csrc/build.sh (or __graft_entry__.build()). "
+            "gansynth_amd has no CPU/torch fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = load().gs_last_error()
+        raise GansynthHipError(f"{what} failed ({code}): {msg.decode() if msg else ''}")

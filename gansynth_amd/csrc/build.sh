@@ -1,0 +1,22 @@
+#!/bin/bash
+# Builds libgansynth_hip.so for gfx950 (cross-compiles without a GPU).  Usage: build.sh [outdir]
+set -e
+cd "$(dirname "$0")"
+OUT=${1:-..}
+mkdir -p obj
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result"
+pids=()
+for f in conv_igemm conv_api elementwise small_ops spectral; do
+  [ -f $f.hip ] || continue
+  if [ ! -f obj/$f.o ] || [ $f.hip -nt obj/$f.o ] || [ gs_common.h -nt obj/$f.o ] || [ conv_shared.h -nt obj/$f.o ] || [ ../../include/gansynth_hip.h -nt obj/$f.o ]; then
+    ( hipcc $FLAGS -c $f.hip -o obj/$f.o ) &
+    pids+=($!)
+  fi
+done
+if [ ! -f obj/core.o ] || [ core.cpp -nt obj/core.o ] || [ gs_common.h -nt obj/core.o ]; then
+  ( hipcc $FLAGS -x hip -c core.cpp -o obj/core.o ) &
+  pids+=($!)
+fi
+for p in "${pids[@]}"; do wait $p; done
+hipcc --offload-arch=gfx950 -shared -fPIC obj/*.o -o $OUT/libgansynth_hip.so
+echo "built $OUT/libgansynth_hip.so"

@@ -1,0 +1,285 @@
+// C-ABI entry points of the conv family + the generic direct (VALU) kernels used for the
+// channel counts the MFMA implicit GEMM does not take: the 2-channel colour 1x1 convs
+// (networks.py:98-105, 233-240) and the 1-channel minibatch-stddev plane (networks.py:174-176).
+#include "conv_shared.h"
+
+namespace gs {
+
+
+// from conv_igemm.hip
+bool igemm_supported(int ic, int oc, int dtype);
+bool wgrad_mfma_supported(int ic, int oc, int dtype);
+size_t igemm_prep_bytes(int ic, int oc, int dtype);
+int run_igemm(int mode, int variant, const void* x, const float* w_hwio, void* y, int N, int Hi, int Wi, int ICk,
+              int OCk, int w_ci, int w_co, int Hb, int Wb, float alpha, int dtype, void* ws, size_t ws_bytes,
+              hipStream_t st);
+size_t wgrad_mfma_bytes(int mode, int N, int Hb, int Wb, int IC, int OC);
+int run_wgrad_mfma(int mode, const void* x, const void* gy, float* gw, int N, int Hi, int Wi, int IC, int OC, int Hb,
+                   int Wb, float alpha, int transpose, void* ws, size_t ws_bytes, hipStream_t st);
+
+// ------------------------------------------------------------------------- direct gather conv
+// y[n][oy][ox][oc0..oc0+OCV) = alpha * sum_{tap,ic} x[n][iy][ix][ic] * wp[tap][oc][ic]   (wp fp32)
+template <typename T, int OCV, int VEC>
+__global__ void conv_direct_kernel(const T* __restrict__ x, const float* __restrict__ wp, T* __restrict__ y, int mode,
+                                   int ks, int N, int Hi, int Wi, int IC, int OC, int Ho, int Wo, float alpha) {
+    const int ngrp = OC / OCV;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)N * Ho * Wo * ngrp;
+    if (idx >= total) return;
+    const int g = idx % ngrp;
+    long pix = idx / ngrp;
+    const int ox = pix % Wo;
+    pix /= Wo;
+    const int oy = pix % Ho;
+    const int n = pix / Ho;
+    const int oc = g * OCV;
+    float acc[OCV];
+#pragma unroll
+    for (int v = 0; v < OCV; ++v) acc[v] = 0.f;
+    for (int ky = 0; ky < ks; ++ky) {
+        int iy;
+        if (mode == MODE_S1) iy = oy + ky - (ks >> 1);
+        else if (mode == MODE_S2) iy = 2 * oy + ky;
+        else { const int d = oy - ky; if (d < 0 || (d & 1)) continue; iy = d >> 1; }
+        if (iy < 0 || iy >= Hi) continue;
+        for (int kx = 0; kx < ks; ++kx) {
+            int ix;
+            if (mode == MODE_S1) ix = ox + kx - (ks >> 1);
+            else if (mode == MODE_S2) ix = 2 * ox + kx;
+            else { const int d = ox - kx; if (d < 0 || (d & 1)) continue; ix = d >> 1; }
+            if (ix < 0 || ix >= Wi) continue;
+            const T* xp = x + (((long)n * Hi + iy) * Wi + ix) * IC;
+            const float* wr = wp + ((long)(ky * ks + kx) * OC + oc) * IC;
+            if (VEC == 4) {
+                for (int ic = 0; ic < IC; ic += 4) {
+                    float xv[4];
+                    ld4(xp + ic, xv);
+#pragma unroll
+                    for (int v = 0; v < OCV; ++v) {
+                        const float4 wv = *reinterpret_cast<const float4*>(wr + (long)v * IC + ic);
+                        acc[v] += xv[0] * wv.x + xv[1] * wv.y + xv[2] * wv.z + xv[3] * wv.w;
+                    }
+                }
+            } else {
+                for (int ic = 0; ic < IC; ++ic) {
+                    const float xv = DT<T>::ld(xp + ic);
+#pragma unroll
+                    for (int v = 0; v < OCV; ++v) acc[v] += xv * wr[(long)v * IC + ic];
+                }
+            }
+        }
+    }
+    T* yp = y + (((long)n * Ho + oy) * Wo + ox) * OC + oc;
+    if (OCV == 4) {
+        float o[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) o[v] = acc[v < OCV ? v : 0] * alpha;
+        st4(yp, o);
+    } else {
+#pragma unroll
+        for (int v = 0; v < OCV; ++v) DT<T>::st(yp + v, acc[v] * alpha);
+    }
+}
+
+template <typename T>
+static int launch_direct(const T* x, const float* wp, T* y, int mode, int ks, int N, int Hi, int Wi, int IC, int OC,
+                         int Ho, int Wo, float alpha, hipStream_t st) {
+    const int ocv = OC % 4 == 0 ? 4 : (OC % 2 == 0 ? 2 : 1);
+    const int vec = IC % 4 == 0 ? 4 : 1;
+    const long total = (long)N * Ho * Wo * (OC / ocv);
+    dim3 grid(cdiv(total, 256)), block(256);
+#define GS_DL(OCVV, VECV)                                                                                              \
+    hipLaunchKernelGGL((conv_direct_kernel<T, OCVV, VECV>), grid, block, 0, st, x, wp, y, mode, ks, N, Hi, Wi, IC, OC, Ho, \
+                       Wo, alpha)
+    if (ocv == 4 && vec == 4) GS_DL(4, 4);
+    else if (ocv == 4) GS_DL(4, 1);
+    else if (ocv == 2 && vec == 4) GS_DL(2, 4);
+    else if (ocv == 2) GS_DL(2, 1);
+    else if (vec == 4) GS_DL(1, 4);
+    else GS_DL(1, 1);
+#undef GS_DL
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+// direct conv through the fp32 prepped weights living in ws
+static int run_direct(int mode, int ks, int variant, const void* x, const float* w_hwio, void* y, int N, int Hi, int Wi,
+                      int ICk, int OCk, int w_ci, int w_co, int Ho, int Wo, float alpha, int dtype, void* ws,
+                      size_t ws_bytes, hipStream_t st) {
+    const long total = (long)ks * ks * w_ci * w_co;
+    if (ws_bytes < (size_t)total * 4) return fail(GS_ERR_WORKSPACE, "conv direct: workspace %zu < %zu", ws_bytes, (size_t)total * 4);
+    float* wp = reinterpret_cast<float*>(ws);
+    hipLaunchKernelGGL((weight_prep_kernel<float>), dim3(cdiv(total, 256)), dim3(256), 0, st, w_hwio, wp, ks * ks, w_ci, w_co, variant);
+    GS_CHECK_LAUNCH();
+    GS_DISPATCH_DTYPE(dtype, return launch_direct<T>(reinterpret_cast<const T*>(x), wp, reinterpret_cast<T*>(y), mode, ks,
+                                                     N, Hi, Wi, ICk, OCk, Ho, Wo, alpha, st));
+}
+
+// ------------------------------------------------------------------ direct weight gradient
+// part[slice][t][ic][oc] = sum over the slice's output pixels of x[in(p,t)][ic] * gy[p][oc]
+template <typename T>
+__global__ __launch_bounds__(256) void conv_wgrad_direct_kernel(const T* __restrict__ x, const T* __restrict__ gy,
+                                                                float* __restrict__ part, int mode, int ks, int N, int Hi,
+                                                                int Wi, int IC, int OC, int Hb, int Wb, long E, long npix,
+                                                                long pps) {
+    __shared__ float red[256];
+    const int tid = threadIdx.x;
+    const long e = (long)blockIdx.x * 64 + (tid & 63);
+    const int sub = tid >> 6;
+    const int slice = blockIdx.y;
+    float acc = 0.f;
+    if (e < E) {
+        const int oc = e % OC;
+        const int ic = (e / OC) % IC;
+        const int t = e / ((long)IC * OC);
+        const int ky = t / ks, kx = t % ks;
+        const long p0 = (long)slice * pps;
+        long p1 = p0 + pps;
+        if (p1 > npix) p1 = npix;
+        for (long p = p0 + sub; p < p1; p += 4) {
+            const int px = p % Wb;
+            const long q = p / Wb;
+            const int py = q % Hb;
+            const int n = q / Hb;
+            int iy, ix;
+            if (mode == MODE_S1) { iy = py + ky - (ks >> 1); ix = px + kx - (ks >> 1); }
+            else { iy = 2 * py + ky; ix = 2 * px + kx; }
+            if (iy < 0 || iy >= Hi || ix < 0 || ix >= Wi) continue;
+            acc += DT<T>::ld(x + (((long)n * Hi + iy) * Wi + ix) * IC + ic) * DT<T>::ld(gy + p * OC + oc);
+        }
+    }
+    red[tid] = acc;
+    __syncthreads();
+    if (sub == 0 && e < E) part[(long)slice * E + e] = red[tid] + red[tid + 64] + red[tid + 128] + red[tid + 192];
+}
+
+static void wgrad_direct_geometry(long npix, long* nslices, long* pps) {
+    long ns = (npix + 1023) / 1024;
+    if (ns > 1024) ns = 1024;
+    if (ns < 1) ns = 1;
+    *pps = (npix + ns - 1) / ns;
+    *nslices = (npix + *pps - 1) / *pps;
+}
+
+static size_t wgrad_direct_bytes(int ks, int N, int Hb, int Wb, int IC, int OC) {
+    long ns, pps;
+    wgrad_direct_geometry((long)N * Hb * Wb, &ns, &pps);
+    return align256((size_t)ns * ks * ks * IC * OC * 4);
+}
+
+static int run_wgrad_direct(int mode, int ks, const void* x, const void* gy, float* gw, int N, int Hi, int Wi, int IC,
+                            int OC, int Hb, int Wb, float alpha, int transpose, int dtype, void* ws, size_t ws_bytes,
+                            hipStream_t st) {
+    long ns, pps;
+    const long npix = (long)N * Hb * Wb;
+    wgrad_direct_geometry(npix, &ns, &pps);
+    const long E = (long)ks * ks * IC * OC;
+    if (ws_bytes < (size_t)ns * E * 4) return fail(GS_ERR_WORKSPACE, "conv wgrad direct: workspace %zu < %zu", ws_bytes, (size_t)ns * E * 4);
+    float* part = reinterpret_cast<float*>(ws);
+    dim3 grid(cdiv(E, 64), (unsigned)ns);
+    GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((conv_wgrad_direct_kernel<T>), grid, dim3(256), 0, st,
+                                                reinterpret_cast<const T*>(x), reinterpret_cast<const T*>(gy), part, mode,
+                                                ks, N, Hi, Wi, IC, OC, Hb, Wb, E, npix, pps));
+    GS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(E, 256)), dim3(256), 0, st, part, gw, (int)ns, ks * ks, IC, OC, alpha, transpose);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+static int check_conv_args(int n, int h, int w, int ci, int co, int ksize, int stride, int dtype) {
+    GS_CHECK_ARG(n > 0 && h > 0 && w > 0 && ci > 0 && co > 0, "conv2d: non-positive dim");
+    GS_CHECK_ARG(ksize == 1 || ksize == 3, "conv2d: ksize %d not in {1,3}", ksize);
+    GS_CHECK_ARG(stride == 1 || (stride == 2 && ksize == 3), "conv2d: stride %d unsupported with ksize %d", stride, ksize);
+    GS_CHECK_ARG(stride == 1 || (h % 2 == 0 && w % 2 == 0), "conv2d: stride 2 needs even h,w (got %d,%d)", h, w);
+    GS_CHECK_ARG(dtype == GS_F32 || dtype == GS_BF16, "conv2d: bad dtype %d", dtype);
+    return 0;
+}
+
+}  // namespace gs
+
+using namespace gs;
+
+extern "C" size_t gs_conv2d_workspace_bytes(int which, int n, int h, int w, int ci, int co, int ksize, int stride, int dtype) {
+    const int hb = h / stride, wb = w / stride;
+    if (which == GS_CONV_BWD_WEIGHT) {
+        if (ksize == 3 && wgrad_mfma_supported(ci, co, dtype)) return wgrad_mfma_bytes(stride == 2 ? MODE_S2 : MODE_S1, n, hb, wb, ci, co);
+        return wgrad_direct_bytes(ksize, n, hb, wb, ci, co);
+    }
+    return align256((size_t)ksize * ksize * ci * co * 4);
+}
+
+extern "C" int gs_conv2d_fwd(const void* x, const float* w_hwio, void* y, int n, int h, int w, int ci, int co, int ksize,
+                             int stride, float alpha, int dtype, void* ws, size_t ws_bytes, void* stream) {
+    if (int e = check_conv_args(n, h, w, ci, co, ksize, stride, dtype)) return e;
+    hipStream_t st = as_stream(stream);
+    const int hb = h / stride, wb = w / stride;
+    const int mode = stride == 2 ? MODE_S2 : MODE_S1;
+    if (ksize == 3 && igemm_supported(ci, co, dtype))
+        return run_igemm(mode, 0, x, w_hwio, y, n, h, w, ci, co, ci, co, hb, wb, alpha, dtype, ws, ws_bytes, st);
+    return run_direct(mode, ksize, 0, x, w_hwio, y, n, h, w, ci, co, ci, co, hb, wb, alpha, dtype, ws, ws_bytes, st);
+}
+
+extern "C" int gs_conv2d_bwd_data(const void* gy, const float* w_hwio, void* gx, int n, int h, int w, int ci, int co,
+                                  int ksize, int stride, float alpha, int dtype, void* ws, size_t ws_bytes, void* stream) {
+    if (int e = check_conv_args(n, h, w, ci, co, ksize, stride, dtype)) return e;
+    hipStream_t st = as_stream(stream);
+    const int hb = h / stride, wb = w / stride;
+    if (stride == 1) {  // flipped taps, roles of ci/co swapped
+        if (ksize == 3 && igemm_supported(co, ci, dtype))
+            return run_igemm(MODE_S1, 1, gy, w_hwio, gx, n, h, w, co, ci, ci, co, h, w, alpha, dtype, ws, ws_bytes, st);
+        return run_direct(MODE_S1, ksize, 1, gy, w_hwio, gx, n, h, w, co, ci, ci, co, h, w, alpha, dtype, ws, ws_bytes, st);
+    }
+    if (igemm_supported(co, ci, dtype))
+        return run_igemm(MODE_T2, 2, gy, w_hwio, gx, n, hb, wb, co, ci, ci, co, hb, wb, alpha, dtype, ws, ws_bytes, st);
+    return run_direct(MODE_T2, 3, 2, gy, w_hwio, gx, n, hb, wb, co, ci, ci, co, h, w, alpha, dtype, ws, ws_bytes, st);
+}
+
+extern "C" int gs_conv2d_bwd_weight(const void* x, const void* gy, float* gw_hwio, int n, int h, int w, int ci, int co,
+                                    int ksize, int stride, float alpha, int dtype, void* ws, size_t ws_bytes, void* stream) {
+    if (int e = check_conv_args(n, h, w, ci, co, ksize, stride, dtype)) return e;
+    hipStream_t st = as_stream(stream);
+    const int hb = h / stride, wb = w / stride;
+    const int mode = stride == 2 ? MODE_S2 : MODE_S1;
+    if (ksize == 3 && wgrad_mfma_supported(ci, co, dtype))
+        return run_wgrad_mfma(mode, x, gy, gw_hwio, n, h, w, ci, co, hb, wb, alpha, 0, ws, ws_bytes, st);
+    return run_wgrad_direct(mode, ksize, x, gy, gw_hwio, n, h, w, ci, co, hb, wb, alpha, 0, dtype, ws, ws_bytes, st);
+}
+
+// ---- conv2d_transpose 3x3 stride 2: re-labelings of the stride-2 maps (see include/gansynth_hip.h)
+extern "C" size_t gs_conv2d_transpose_s2_workspace_bytes(int which, int n, int h, int w, int ci, int co, int dtype) {
+    if (which == GS_CONV_BWD_WEIGHT) {
+        if (wgrad_mfma_supported(co, ci, dtype)) return wgrad_mfma_bytes(MODE_S2, n, h, w, co, ci);
+        return wgrad_direct_bytes(3, n, h, w, co, ci);
+    }
+    return align256((size_t)9 * ci * co * 4);
+}
+
+extern "C" int gs_conv2d_transpose_s2_fwd(const void* x, const float* w_hwio, void* y, int n, int h, int w, int ci, int co,
+                                          float alpha, int dtype, void* ws, size_t ws_bytes, void* stream) {
+    if (int e = check_conv_args(n, 2 * h, 2 * w, co, ci, 3, 2, dtype)) return e;
+    hipStream_t st = as_stream(stream);
+    // out[2i+k][co] += x[i][ci] * w[k][ci][co]: kernel roles ICk = ci, OCk = co, Wp[t][co][ci] (variant 0)
+    if (igemm_supported(ci, co, dtype))
+        return run_igemm(MODE_T2, 0, x, w_hwio, y, n, h, w, ci, co, ci, co, h, w, alpha, dtype, ws, ws_bytes, st);
+    return run_direct(MODE_T2, 3, 0, x, w_hwio, y, n, h, w, ci, co, ci, co, 2 * h, 2 * w, alpha, dtype, ws, ws_bytes, st);
+}
+
+extern "C" int gs_conv2d_transpose_s2_bwd_data(const void* gy, const float* w_hwio, void* gx, int n, int h, int w, int ci,
+                                               int co, float alpha, int dtype, void* ws, size_t ws_bytes, void* stream) {
+    if (int e = check_conv_args(n, 2 * h, 2 * w, co, ci, 3, 2, dtype)) return e;
+    hipStream_t st = as_stream(stream);
+    // gx[i][ci] = sum gy[2i+k][co] * w[k][ci][co]: stride-2 conv, roles ICk = co, OCk = ci, Wp[t][ci][co] (variant 2)
+    if (igemm_supported(co, ci, dtype))
+        return run_igemm(MODE_S2, 2, gy, w_hwio, gx, n, 2 * h, 2 * w, co, ci, ci, co, h, w, alpha, dtype, ws, ws_bytes, st);
+    return run_direct(MODE_S2, 3, 2, gy, w_hwio, gx, n, 2 * h, 2 * w, co, ci, ci, co, h, w, alpha, dtype, ws, ws_bytes, st);
+}
+
+extern "C" int gs_conv2d_transpose_s2_bwd_weight(const void* x, const void* gy, float* gw_hwio, int n, int h, int w, int ci,
+                                                 int co, float alpha, int dtype, void* ws, size_t ws_bytes, void* stream) {
+    if (int e = check_conv_args(n, 2 * h, 2 * w, co, ci, 3, 2, dtype)) return e;
+    hipStream_t st = as_stream(stream);
+    // gw[k][ci][co] = sum x[i][ci] * gy[2i+k][co]: stride-2 wgrad with (input side = gy, output side = x), transposed
+    if (wgrad_mfma_supported(co, ci, dtype))
+        return run_wgrad_mfma(MODE_S2, gy, x, gw_hwio, n, 2 * h, 2 * w, co, ci, h, w, alpha, 1, ws, ws_bytes, st);
+    return run_wgrad_direct(MODE_S2, 3, gy, x, gw_hwio, n, 2 * h, 2 * w, co, ci, h, w, alpha, 1, dtype, ws, ws_bytes, st);
+}

@@ -1,0 +1,56 @@
+// Kernels and constants shared by conv_igemm.hip and conv_api.hip (each TU gets its own copy).
+#pragma once
+#include "gs_common.h"
+
+namespace gs {
+
+enum { MODE_S1 = 0, MODE_S2 = 1, MODE_T2 = 2 };
+
+static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+// ------------------------------------------------------------------------------ weight prep
+// Re-lays the fp32 HWIO master weight into the kernel operand Wp[tap][OCk][ICk] (ICk contiguous,
+// storage type T, no scaling -- alpha is applied to the fp32 accumulators).
+//   variant 0 (fwd)        : Wp[t][co][ci]       = w[t][ci][co]      (OCk = co, ICk = ci)
+//   variant 1 (bwd-data S1): Wp[taps-1-t][ci][co] = w[t][ci][co]     (OCk = ci, ICk = co; taps flipped)
+//   variant 2 (bwd-data T2): Wp[t][ci][co]       = w[t][ci][co]      (OCk = ci, ICk = co)
+template <typename T>
+__global__ void weight_prep_kernel(const float* __restrict__ w, T* __restrict__ wp, int taps, int ci, int co, int variant) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long total = (long)taps * ci * co;
+    if (idx >= total) return;
+    if (variant == 0) {
+        int c_i = idx % ci;
+        int c_o = (idx / ci) % co;
+        int t = idx / ((long)ci * co);
+        DT<T>::st(wp + idx, w[((long)t * ci + c_i) * co + c_o]);
+    } else {
+        int t = idx / ((long)ci * co);
+        long rem = idx % ((long)ci * co);
+        int tt = variant == 1 ? taps - 1 - t : t;
+        DT<T>::st(wp + (long)tt * ci * co + rem, w[idx]);
+    }
+}
+
+// gw[e] = alpha * sum_s part[s][e]; `transpose` swaps the last two dims on output
+// (used by conv2d_transpose's weight gradient, whose stored variable is [k][k][Cin_T][Cout_T]).
+static __global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ gw, int nslices,
+                                    int taps, int ic, int oc, float alpha, int transpose) {
+    const long total = (long)taps * ic * oc;
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    float s = 0.f;
+    for (int k = 0; k < nslices; ++k) s += part[(long)k * total + e];
+    s *= alpha;
+    if (!transpose) {
+        gw[e] = s;
+    } else {
+        const int o = e % oc;
+        const int i = (e / oc) % ic;
+        const int t = e / ((long)ic * oc);
+        gw[((long)t * oc + o) * ic + i] = s;
+    }
+}
+
+
+}  // namespace gs

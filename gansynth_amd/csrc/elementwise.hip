@@ -1,0 +1,518 @@
+// HBM-bound elementwise / row-reduction kernels of the PGGAN hot path (channels-last).
+//   bias + leaky_relu / tanh          ops.py:244-246, networks.py:55,66,80,91,106,184,194,216,227,241
+//   pixel_normalization (+1st/2nd order gradients)          ops.py:330-333
+//   upscale2d / downscale2d                                  ops.py:283-305
+//   lerp                                                     networks.py:10-11
+//   R1 penalty reductions                                    models.py:47-49
+//   TF-form Adam                                             models.py:67-89
+// All are one-read/one-write streaming kernels with 16-byte (f32) / 8-byte (bf16) accesses and
+// wave64 shuffle reductions; none goes near the MFMA.
+#include "gs_common.h"
+
+namespace gs {
+
+static inline int ew_grid(long nvec) {
+    long g = (nvec + 255) / 256;
+    if (g > 8192) g = 8192;  // grid-stride the rest (256 CUs x 8 blocks x 4)
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+// ------------------------------------------------------------------ bias + activation
+template <typename T, int ACT, bool BIAS>
+__global__ void bias_act_kernel(const T* __restrict__ x, const float* __restrict__ bias, T* __restrict__ y, long nvec, int cvec) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+        float v[4];
+        ld4(x + i * 4, v);
+        if (BIAS) {
+            const float4 b = *reinterpret_cast<const float4*>(bias + (i % cvec) * 4);
+            v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (ACT == GS_ACT_LRELU) v[e] = v[e] > 0.f ? v[e] : 0.2f * v[e];
+            if (ACT == GS_ACT_TANH) v[e] = tanhf(v[e]);
+        }
+        st4(y + i * 4, v);
+    }
+}
+// scalar fallback (c not a multiple of 4: the 2-channel images)
+template <typename T>
+__global__ void bias_act_scalar_kernel(const T* __restrict__ x, const float* __restrict__ bias, T* __restrict__ y, long n, int c, int act) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float v = DT<T>::ld(x + i);
+        if (bias) v += bias[i % c];
+        if (act == GS_ACT_LRELU) v = v > 0.f ? v : 0.2f * v;
+        if (act == GS_ACT_TANH) v = tanhf(v);
+        DT<T>::st(y + i, v);
+    }
+}
+
+// gx = g * act'(y) through the activation output y
+template <typename T, int ACT>
+__global__ void act_bwd_kernel(const T* __restrict__ g, const T* __restrict__ y, T* __restrict__ gx, long n) {
+    const long nvec = n >> 2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+        float gv[4], yv[4];
+        ld4(g + i * 4, gv);
+        ld4(y + i * 4, yv);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (ACT == GS_ACT_LRELU) gv[e] = yv[e] > 0.f ? gv[e] : 0.2f * gv[e];
+            if (ACT == GS_ACT_TANH) gv[e] = gv[e] * (1.f - yv[e] * yv[e]);
+        }
+        st4(gx + i * 4, gv);
+    }
+    // tail
+    const long t = nvec * 4 + (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) {
+        float gv = DT<T>::ld(g + t), yv = DT<T>::ld(y + t);
+        if (ACT == GS_ACT_LRELU) gv = yv > 0.f ? gv : 0.2f * gv;
+        if (ACT == GS_ACT_TANH) gv = gv * (1.f - yv * yv);
+        DT<T>::st(gx + t, gv);
+    }
+}
+
+template <typename T>
+__global__ void tanh_bwd_bwd_kernel(const T* __restrict__ gg, const T* __restrict__ g, const T* __restrict__ y, T* __restrict__ out, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        DT<T>::st(out + i, -2.f * DT<T>::ld(y + i) * DT<T>::ld(g + i) * DT<T>::ld(gg + i));
+}
+
+// out = ca*a + cb*b
+template <typename T>
+__global__ void axpby_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out, long n, float ca, float cb) {
+    const long nvec = n >> 2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+        float av[4], bv[4];
+        ld4(a + i * 4, av);
+        ld4(b + i * 4, bv);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) av[e] = ca * av[e] + cb * bv[e];
+        st4(out + i * 4, av);
+    }
+    const long t = nvec * 4 + (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) DT<T>::st(out + t, ca * DT<T>::ld(a + t) + cb * DT<T>::ld(b + t));
+}
+
+// ------------------------------------------------------------------------ channel sum
+// out[c] = sum_p g[p][c].  Pass 1: block b sums rows b, b+G, ... into part[b][c]; pass 2 sums parts.
+template <typename T>
+__global__ __launch_bounds__(256) void channel_sum_kernel(const T* __restrict__ g, float* __restrict__ part, long p, int c) {
+    // thread handles channel quad q = tid % (c/4) (or single channels when c%4 != 0), row lane r = tid / quads
+    __shared__ float red[256 * 4];
+    const int tid = threadIdx.x;
+    if ((c & 3) == 0 && c <= 1024) {
+        const int quads = c >> 2;
+        const int rl = 256 / quads > 0 ? 256 / quads : 1;  // row lanes per block
+        const int q = tid % quads, r = tid / quads;
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+        if (r < rl && quads <= 256) {
+            for (long row = (long)blockIdx.x * rl + r; row < p; row += (long)gridDim.x * rl) {
+                float v[4];
+                ld4(g + row * c + q * 4, v);
+                a[0] += v[0]; a[1] += v[1]; a[2] += v[2]; a[3] += v[3];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[tid * 4 + e] = a[e];
+        __syncthreads();
+        if (tid < quads) {
+            float s[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int k = 0; k < rl; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s[e] += red[(k * quads + tid) * 4 + e];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) part[(long)blockIdx.x * c + tid * 4 + e] = s[e];
+        }
+    } else {
+        // generic: thread per (channel, row lane)
+        const int cl = c < 256 ? c : 256;
+        const int rl = 256 / cl;
+        const int ch = tid % cl, r = tid / cl;
+        for (int c0 = 0; c0 < c; c0 += cl) {
+            float a = 0.f;
+            if (r < rl && c0 + ch < c)
+                for (long row = (long)blockIdx.x * rl + r; row < p; row += (long)gridDim.x * rl) a += DT<T>::ld(g + row * c + c0 + ch);
+            __syncthreads();
+            red[tid] = a;
+            __syncthreads();
+            if (tid < cl && c0 + tid < c) {
+                float s = 0.f;
+                for (int k = 0; k < rl; ++k) s += red[k * cl + tid];
+                part[(long)blockIdx.x * c + c0 + tid] = s;
+            }
+        }
+    }
+}
+static __global__ void channel_sum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int nparts, int c) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    float s = 0.f;
+    for (int k = 0; k < nparts; ++k) s += part[(long)k * c + ch];
+    out[ch] = s;
+}
+static int channel_sum_parts(long p, int c) {
+    long rows_per_block = 256 / (c >= 4 ? ((c & 3) == 0 ? c / 4 : (c < 256 ? c : 256)) : c);
+    if (rows_per_block < 1) rows_per_block = 1;
+    long nb = (p + rows_per_block * 16 - 1) / (rows_per_block * 16);
+    if (nb > 1024) nb = 1024;
+    if (nb < 1) nb = 1;
+    return (int)nb;
+}
+
+// ------------------------------------------------------------------------- pixel norm
+// Row p of C channels is owned by L = min(64, C/4) lanes (4 channels per lane per pass).
+// MODE 0: y = x*r ; MODE 1: gx = r*(g - y*mean(y*g)) ; MODE 2: second-order term (see header).
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void pixel_norm_kernel(const T* __restrict__ a0, const T* __restrict__ a1, const T* __restrict__ a2,
+                                                         T* __restrict__ out, long p, int c, float eps) {
+    // a0 = x (MODE 0) | g (MODE 1) | gg (MODE 2);  a1 = x (MODE 1) | g (MODE 2);  a2 = x (MODE 2)
+    const int quads = c >> 2;
+    const int L = quads < 64 ? quads : 64;       // lanes per row (power of two)
+    const int passes = quads / L;                // 1, 2 (c=512) ...
+    const int rows_per_wave = 64 / L;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane % L;
+    const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+    const float invc = 1.f / (float)c;
+    for (long row0 = wave * rows_per_wave; row0 < p; row0 += nwaves * rows_per_wave) {
+        const long row = row0 + lane / L;
+        const bool ok = row < p;
+        const T* xr = (MODE == 0 ? a0 : (MODE == 1 ? a1 : a2)) + row * c;
+        float xv[4][4], s = 0.f;  // up to 4 passes (c <= 1024)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k < passes) {
+                if (ok) ld4(xr + (k * L + sub) * 4, xv[k]);
+                else xv[k][0] = xv[k][1] = xv[k][2] = xv[k][3] = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s += xv[k][e] * xv[k][e];
+            }
+        }
+        for (int o = L >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        const float r = rsqrtf(s * invc + eps);
+        if (MODE == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k < passes && ok) {
+                    float o4[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o4[e] = xv[k][e] * r;
+                    st4(out + row * c + (k * L + sub) * 4, o4);
+                }
+        } else if (MODE == 1) {
+            float gv[4][4], q = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k < passes) {
+                    if (ok) ld4(a0 + row * c + (k * L + sub) * 4, gv[k]);
+                    else gv[k][0] = gv[k][1] = gv[k][2] = gv[k][3] = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) q += xv[k][e] * r * gv[k][e];
+                }
+            for (int o = L >> 1; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+            q *= invc;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k < passes && ok) {
+                    float o4[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o4[e] = r * (gv[k][e] - xv[k][e] * r * q);
+                    st4(out + row * c + (k * L + sub) * 4, o4);
+                }
+        } else {
+            float ggv[4][4], gv[4][4], sa = 0.f, sp = 0.f, sq = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k < passes) {
+                    if (ok) { ld4(a0 + row * c + (k * L + sub) * 4, ggv[k]); ld4(a1 + row * c + (k * L + sub) * 4, gv[k]); }
+                    else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) ggv[k][e] = gv[k][e] = 0.f;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float yv = xv[k][e] * r;
+                        sa += ggv[k][e] * gv[k][e];
+                        sp += yv * ggv[k][e];
+                        sq += yv * gv[k][e];
+                    }
+                }
+            for (int o = L >> 1; o > 0; o >>= 1) {
+                sa += __shfl_xor(sa, o, 64);
+                sp += __shfl_xor(sp, o, 64);
+                sq += __shfl_xor(sq, o, 64);
+            }
+            const float k0 = r * r * invc;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k < passes && ok) {
+                    float o4[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float yv = xv[k][e] * r;
+                        o4[e] = k0 * (-sa * yv - sq * ggv[k][e] - sp * gv[k][e] + 3.f * sp * sq * yv * invc);
+                    }
+                    st4(out + row * c + (k * L + sub) * 4, o4);
+                }
+        }
+    }
+}
+
+// ----------------------------------------------------------------- upscale / block sum
+template <typename T>
+__global__ void upscale_kernel(const T* __restrict__ x, T* __restrict__ y, int n, int h, int w, int c, int fy, int fx, float scale) {
+    const long total = (long)n * h * fy * w * fx * c;
+    const int wo = w * fx, ho = h * fy;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ch = i % c;
+        long r = i / c;
+        const int ox = r % wo;
+        r /= wo;
+        const int oy = r % ho;
+        const int b = r / ho;
+        const float v = DT<T>::ld(x + (((long)b * h + oy / fy) * w + ox / fx) * c + ch);
+        DT<T>::st(y + i, scale == 1.f ? v : v * scale);
+    }
+}
+// one wave per output element group: y[b][oy][ox][ch] = scale * sum_{fy,fx} x
+template <typename T>
+__global__ __launch_bounds__(256) void blocksum_kernel(const T* __restrict__ x, T* __restrict__ y, int n, int h, int w, int c, int fy, int fx, float scale) {
+    const int ho = h / fy, wo = w / fx;
+    const long total = (long)n * ho * wo * c;
+    const int lane = threadIdx.x & 63;
+    const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+    const int blk = fy * fx;
+    for (long o = wave; o < total; o += nwaves) {
+        const int ch = o % c;
+        long r = o / c;
+        const int ox = r % wo;
+        r /= wo;
+        const int oy = r % ho;
+        const int b = r / ho;
+        float s = 0.f;
+        for (int k = lane; k < blk; k += 64) {
+            const int dy = k / fx, dx = k % fx;
+            s += DT<T>::ld(x + (((long)b * h + oy * fy + dy) * w + ox * fx + dx) * c + ch);
+        }
+        s = wave_sum(s);
+        if (lane == 0) DT<T>::st(y + o, s * scale);
+    }
+}
+// small blocks: one thread per output element
+template <typename T>
+__global__ void blocksum_small_kernel(const T* __restrict__ x, T* __restrict__ y, int n, int h, int w, int c, int fy, int fx, float scale) {
+    const int ho = h / fy, wo = w / fx;
+    const long total = (long)n * ho * wo * c;
+    for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
+        const int ch = o % c;
+        long r = o / c;
+        const int ox = r % wo;
+        r /= wo;
+        const int oy = r % ho;
+        const int b = r / ho;
+        float s = 0.f;
+        for (int dy = 0; dy < fy; ++dy)
+            for (int dx = 0; dx < fx; ++dx) s += DT<T>::ld(x + (((long)b * h + oy * fy + dy) * w + ox * fx + dx) * c + ch);
+        DT<T>::st(y + o, s * scale);
+    }
+}
+
+// --------------------------------------------------------------------- row reductions
+// out[r] = sum_j x[r][j]^2, one block per row (deterministic order).
+template <typename T>
+__global__ __launch_bounds__(256) void sumsq_rows_kernel(const T* __restrict__ x, float* __restrict__ out, long cols) {
+    __shared__ float red[4];
+    const int r = blockIdx.x;
+    const T* xr = x + (long)r * cols;
+    float s = 0.f;
+    const long nvec = cols >> 2;
+    for (long i = threadIdx.x; i < nvec; i += 256) {
+        float v[4];
+        ld4(xr + i * 4, v);
+        s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    for (long i = nvec * 4 + threadIdx.x; i < cols; i += 256) { const float v = DT<T>::ld(xr + i); s += v * v; }
+    s = block_sum<256>(s, red);
+    if (threadIdx.x == 0) out[r] = s;
+}
+template <typename T>
+__global__ void row_scale_kernel(const T* __restrict__ x, const float* __restrict__ s, T* __restrict__ out, int rows, long cols) {
+    const long nvec = ((long)rows * cols) >> 2;  // cols % 4 == 0 checked by the caller
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+        const float f = s[(i * 4) / cols];
+        float v[4];
+        ld4(x + i * 4, v);
+        v[0] *= f; v[1] *= f; v[2] *= f; v[3] *= f;
+        st4(out + i * 4, v);
+    }
+}
+
+// -------------------------------------------------------------------------------- Adam
+static __global__ void adam_tf_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                      long n, float lr_t, float b1, float b2, float eps, float gs) {
+    const long nvec = n >> 2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+        float4 pv = reinterpret_cast<float4*>(p)[i];
+        const float4 gv0 = reinterpret_cast<const float4*>(g)[i];
+        float4 mv = reinterpret_cast<float4*>(m)[i];
+        float4 vv = reinterpret_cast<float4*>(v)[i];
+        float* pp = &pv.x; float* mm = &mv.x; float* vp = &vv.x; const float* gg = &gv0.x;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float gr = gg[e] * gs;
+            mm[e] = b1 * mm[e] + (1.f - b1) * gr;
+            vp[e] = b2 * vp[e] + (1.f - b2) * gr * gr;
+            pp[e] -= lr_t * mm[e] / (sqrtf(vp[e]) + eps);
+        }
+        reinterpret_cast<float4*>(p)[i] = pv;
+        reinterpret_cast<float4*>(m)[i] = mv;
+        reinterpret_cast<float4*>(v)[i] = vv;
+    }
+    const long t = nvec * 4 + (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) {
+        const float gr = g[t] * gs;
+        m[t] = b1 * m[t] + (1.f - b1) * gr;
+        v[t] = b2 * v[t] + (1.f - b2) * gr * gr;
+        p[t] -= lr_t * m[t] / (sqrtf(v[t]) + eps);
+    }
+}
+
+}  // namespace gs
+
+using namespace gs;
+
+extern "C" int gs_bias_act_fwd(const void* x, const float* bias, void* y, int64_t p, int c, int act, int dtype, void* stream) {
+    GS_CHECK_ARG(p > 0 && c > 0 && act >= 0 && act <= 2, "bias_act: bad args");
+    hipStream_t st = as_stream(stream);
+    const long n = (long)p * c;
+    if ((c & 3) == 0) {
+        const long nvec = n >> 2;
+        dim3 grid(ew_grid(nvec));
+#define GS_BA(ACT, B) hipLaunchKernelGGL((bias_act_kernel<T, ACT, B>), grid, dim3(256), 0, st, (const T*)x, bias, (T*)y, nvec, c >> 2)
+        GS_DISPATCH_DTYPE(dtype, {
+            if (bias) { if (act == 0) GS_BA(0, true); else if (act == 1) GS_BA(1, true); else GS_BA(2, true); }
+            else { if (act == 0) GS_BA(0, false); else if (act == 1) GS_BA(1, false); else GS_BA(2, false); }
+        });
+#undef GS_BA
+    } else {
+        GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bias_act_scalar_kernel<T>), dim3(ew_grid(n)), dim3(256), 0, st, (const T*)x, bias, (T*)y, n, c, act));
+    }
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gs_act_bwd(const void* g, const void* y, void* gx, int64_t numel, int act, int dtype, void* stream) {
+    GS_CHECK_ARG(numel > 0 && (act == 1 || act == 2), "act_bwd: bad args");
+    hipStream_t st = as_stream(stream);
+    dim3 grid(ew_grid((numel >> 2) + 4));
+    GS_DISPATCH_DTYPE(dtype, {
+        if (act == 1) hipLaunchKernelGGL((act_bwd_kernel<T, 1>), grid, dim3(256), 0, st, (const T*)g, (const T*)y, (T*)gx, (long)numel);
+        else hipLaunchKernelGGL((act_bwd_kernel<T, 2>), grid, dim3(256), 0, st, (const T*)g, (const T*)y, (T*)gx, (long)numel);
+    });
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gs_tanh_bwd_bwd(const void* gg, const void* g, const void* y, void* out, int64_t numel, int dtype, void* stream) {
+    GS_CHECK_ARG(numel > 0, "tanh_bwd_bwd: bad args");
+    GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((tanh_bwd_bwd_kernel<T>), dim3(ew_grid(numel)), dim3(256), 0, as_stream(stream),
+                                                (const T*)gg, (const T*)g, (const T*)y, (T*)out, (long)numel));
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gs_axpby(const void* a, const void* b, void* out, int64_t numel, float ca, float cb, int dtype, void* stream) {
+    GS_CHECK_ARG(numel > 0, "axpby: bad args");
+    GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((axpby_kernel<T>), dim3(ew_grid((numel >> 2) + 4)), dim3(256), 0, as_stream(stream),
+                                                (const T*)a, (const T*)b, (T*)out, (long)numel, ca, cb));
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" size_t gs_channel_sum_workspace_bytes(int64_t p, int c) { return (size_t)channel_sum_parts(p, c) * c * sizeof(float); }
+
+extern "C" int gs_channel_sum(const void* g, float* out, int64_t p, int c, int dtype, void* ws, size_t ws_bytes, void* stream) {
+    GS_CHECK_ARG(p > 0 && c > 0, "channel_sum: bad args");
+    const int nparts = channel_sum_parts(p, c);
+    if (ws_bytes < (size_t)nparts * c * sizeof(float)) return fail(GS_ERR_WORKSPACE, "channel_sum: workspace too small");
+    hipStream_t st = as_stream(stream);
+    float* part = (float*)ws;
+    GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((channel_sum_kernel<T>), dim3(nparts), dim3(256), 0, st, (const T*)g, part, (long)p, c));
+    GS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(channel_sum_final_kernel, dim3(cdiv(c, 256)), dim3(256), 0, st, part, out, nparts, c);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+static int pixel_norm_launch(int mode, const void* a0, const void* a1, const void* a2, void* out, int64_t p, int c, float eps, int dtype, void* stream) {
+    GS_CHECK_ARG(p > 0 && c >= 4 && c <= 1024 && (c & (c - 1)) == 0, "pixel_norm: c=%d must be a power of two in [4,1024]", c);
+    const int L = (c >> 2) < 64 ? (c >> 2) : 64;
+    const long rows_per_block = 4 * (64 / L);
+    dim3 grid(ew_grid(((long)p + rows_per_block - 1) / rows_per_block * 256));
+    hipStream_t st = as_stream(stream);
+    GS_DISPATCH_DTYPE(dtype, {
+        if (mode == 0) hipLaunchKernelGGL((pixel_norm_kernel<T, 0>), grid, dim3(256), 0, st, (const T*)a0, (const T*)a1, (const T*)a2, (T*)out, (long)p, c, eps);
+        else if (mode == 1) hipLaunchKernelGGL((pixel_norm_kernel<T, 1>), grid, dim3(256), 0, st, (const T*)a0, (const T*)a1, (const T*)a2, (T*)out, (long)p, c, eps);
+        else hipLaunchKernelGGL((pixel_norm_kernel<T, 2>), grid, dim3(256), 0, st, (const T*)a0, (const T*)a1, (const T*)a2, (T*)out, (long)p, c, eps);
+    });
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int gs_pixel_norm_fwd(const void* x, void* y, int64_t p, int c, float eps, int dtype, void* stream) {
+    return pixel_norm_launch(0, x, nullptr, nullptr, y, p, c, eps, dtype, stream);
+}
+extern "C" int gs_pixel_norm_bwd(const void* g, const void* x, void* gx, int64_t p, int c, float eps, int dtype, void* stream) {
+    return pixel_norm_launch(1, g, x, nullptr, gx, p, c, eps, dtype, stream);
+}
+extern "C" int gs_pixel_norm_bwd_bwd(const void* gg, const void* g, const void* x, void* out, int64_t p, int c, float eps, int dtype, void* stream) {
+    return pixel_norm_launch(2, gg, g, x, out, p, c, eps, dtype, stream);
+}
+
+extern "C" int gs_upscale2d(const void* x, void* y, int n, int h, int w, int c, int fy, int fx, float scale, int dtype, void* stream) {
+    GS_CHECK_ARG(n > 0 && h > 0 && w > 0 && c > 0 && fy > 0 && fx > 0, "upscale2d: bad args");
+    const long total = (long)n * h * fy * w * fx * c;
+    GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((upscale_kernel<T>), dim3(ew_grid(total)), dim3(256), 0, as_stream(stream),
+                                                (const T*)x, (T*)y, n, h, w, c, fy, fx, scale));
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gs_blocksum2d(const void* x, void* y, int n, int h, int w, int c, int fy, int fx, float scale, int dtype, void* stream) {
+    GS_CHECK_ARG(n > 0 && c > 0 && fy > 0 && fx > 0 && h % fy == 0 && w % fx == 0, "blocksum2d: bad args");
+    const long total = (long)n * (h / fy) * (w / fx) * c;
+    hipStream_t st = as_stream(stream);
+    if (fy * fx >= 32) {
+        GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((blocksum_kernel<T>), dim3(ew_grid(total * 64)), dim3(256), 0, st, (const T*)x, (T*)y, n, h, w, c, fy, fx, scale));
+    } else {
+        GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((blocksum_small_kernel<T>), dim3(ew_grid(total)), dim3(256), 0, st, (const T*)x, (T*)y, n, h, w, c, fy, fx, scale));
+    }
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gs_sumsq_rows(const void* x, float* out, int rows, int64_t cols, int dtype, void* stream) {
+    GS_CHECK_ARG(rows > 0 && cols > 0, "sumsq_rows: bad args");
+    GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((sumsq_rows_kernel<T>), dim3(rows), dim3(256), 0, as_stream(stream), (const T*)x, out, (long)cols));
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gs_row_scale(const void* x, const float* s, void* out, int rows, int64_t cols, int dtype, void* stream) {
+    GS_CHECK_ARG(rows > 0 && cols > 0 && cols % 4 == 0, "row_scale: cols must be a multiple of 4");
+    const long nvec = ((long)rows * cols) >> 2;
+    GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((row_scale_kernel<T>), dim3(ew_grid(nvec)), dim3(256), 0, as_stream(stream), (const T*)x, s, (T*)out, rows, (long)cols));
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gs_adam_tf_step(float* p, const float* g, float* m, float* v, int64_t numel, float lr_t, float beta1, float beta2,
+                               float eps, float grad_scale, void* stream) {
+    GS_CHECK_ARG(numel > 0, "adam: bad args");
+    hipLaunchKernelGGL(adam_tf_kernel, dim3(ew_grid((numel >> 2) + 4)), dim3(256), 0, as_stream(stream), p, g, m, v, (long)numel, lr_t, beta1, beta2, eps, grad_scale);
+    GS_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,112 @@
+// Shared device/host helpers for libgansynth_hip.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/gansynth_hip.h"
+
+namespace gs {
+
+// ------------------------------------------------------------------ error reporting
+extern thread_local char g_err[512];
+int fail(int code, const char* fmt, ...);
+
+#define GS_CHECK_ARG(cond, ...)                         \
+    do {                                                \
+        if (!(cond)) return gs::fail(GS_ERR_ARG, __VA_ARGS__); \
+    } while (0)
+
+#define GS_CHECK_LAUNCH()                                                             \
+    do {                                                                              \
+        hipError_t e__ = hipGetLastError();                                           \
+        if (e__ != hipSuccess) return gs::fail(GS_ERR_HIP, "%s:%d launch failed: %s", \
+                                               __FILE__, __LINE__, hipGetErrorString(e__)); \
+    } while (0)
+
+// ---------------------------------------------------------------------- bf16 storage
+struct bf16_t {
+    unsigned short v;
+};
+
+__device__ __host__ inline float bf16_to_f32(bf16_t h) {
+    union { unsigned int u; float f; } c;
+    c.u = ((unsigned int)h.v) << 16;
+    return c.f;
+}
+__device__ __host__ inline bf16_t f32_to_bf16(float f) {  // round-to-nearest-even
+    union { unsigned int u; float f; } c;
+    c.f = f;
+    unsigned int u = c.u;
+    bf16_t r;
+    if ((u & 0x7fffffffu) > 0x7f800000u) { r.v = (unsigned short)((u >> 16) | 0x40); return r; }  // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    r.v = (unsigned short)(u >> 16);
+    return r;
+}
+
+template <typename T> struct DT;
+template <> struct DT<float> {
+    static constexpr int id = GS_F32;
+    __device__ static inline float ld(const float* p) { return *p; }
+    __device__ static inline void st(float* p, float v) { *p = v; }
+};
+template <> struct DT<bf16_t> {
+    static constexpr int id = GS_BF16;
+    __device__ static inline float ld(const bf16_t* p) { return bf16_to_f32(*p); }
+    __device__ static inline void st(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+};
+
+// 4-element vector access (16 B for f32, 8 B for bf16); pointers must be aligned.
+__device__ inline void ld4(const float* p, float (&o)[4]) {
+    float4 v = *reinterpret_cast<const float4*>(p);
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+}
+__device__ inline void st4(float* p, const float (&o)[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
+}
+__device__ inline void ld4(const bf16_t* p, float (&o)[4]) {
+    uint2 v = *reinterpret_cast<const uint2*>(p);
+    o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+    o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+}
+__device__ inline void st4(bf16_t* p, const float (&o)[4]) {
+    uint2 v;
+    v.x = (unsigned int)f32_to_bf16(o[0]).v | ((unsigned int)f32_to_bf16(o[1]).v << 16);
+    v.y = (unsigned int)f32_to_bf16(o[2]).v | ((unsigned int)f32_to_bf16(o[3]).v << 16);
+    *reinterpret_cast<uint2*>(p) = v;
+}
+
+// ------------------------------------------------------------- wave64 / block reductions
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// Sum over a block of NT threads (NT multiple of 64, <= 1024); result valid in every thread.
+template <int NT>
+__device__ inline float block_sum(float v, float* smem /* >= NT/64 floats */) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) smem[w] = v;
+    __syncthreads();
+    float r = 0.f;
+#pragma unroll
+    for (int i = 0; i < NT / 64; ++i) r += smem[i];
+    return r;
+}
+
+inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// dispatch on dtype id
+#define GS_DISPATCH_DTYPE(dtype, ...)                                   \
+    do {                                                                \
+        if ((dtype) == GS_F32) { using T = float; __VA_ARGS__; }        \
+        else if ((dtype) == GS_BF16) { using T = gs::bf16_t; __VA_ARGS__; } \
+        else return gs::fail(GS_ERR_ARG, "bad dtype %d", (int)(dtype)); \
+    } while (0)
+
+}  // namespace gs

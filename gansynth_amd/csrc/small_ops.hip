@@ -1,0 +1,296 @@
+// Small-tensor kernels of the PGGAN hot path: dense (ops.py:183-201), embedding (ops.py:204-218)
+// and minibatch stddev (ops.py:336-348) with their first/second-order gradients.  These are
+// weight-bandwidth-bound (dense: 16.8 MB of fp32 weights for 8 rows) or tiny; none is MFMA work.
+#include "gs_common.h"
+
+namespace gs {
+
+constexpr int DENSE_BT = 16;  // batch rows held in registers per pass
+
+// ---------------------------------------------------------------------------- dense fwd
+// y[b][o] = alpha * sum_i x[b][i] * w[i][o].  Block = 64 output columns x 4 i-lanes; grid.y
+// splits the reduction so that (out/64)*ksplit blocks cover the chip; partial sums go through
+// `part[ks][b][o]` and a finalize pass (deterministic).
+template <typename T>
+__global__ __launch_bounds__(256) void dense_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w, float* __restrict__ part,
+                                                        int b0, int nb, int in, int out, int b_total, int ipb) {
+    __shared__ float red[4][DENSE_BT][64];
+    const int tid = threadIdx.x;
+    const int col = blockIdx.x * 64 + (tid & 63);
+    const int sub = tid >> 6;
+    const int ks = blockIdx.y;
+    const int i0 = ks * ipb;
+    int i1 = i0 + ipb;
+    if (i1 > in) i1 = in;
+    float acc[DENSE_BT];
+#pragma unroll
+    for (int b = 0; b < DENSE_BT; ++b) acc[b] = 0.f;
+    if (col < out) {
+        for (int i = i0 + sub; i < i1; i += 4) {
+            const float wv = w[(long)i * out + col];
+#pragma unroll
+            for (int b = 0; b < DENSE_BT; ++b)
+                if (b < nb) acc[b] += DT<T>::ld(x + (long)(b0 + b) * in + i) * wv;
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < DENSE_BT; ++b) red[sub][b][tid & 63] = acc[b];
+    __syncthreads();
+    if (sub == 0 && col < out) {
+        for (int b = 0; b < nb; ++b)
+            part[((long)ks * b_total + b0 + b) * out + col] = red[0][b][tid] + red[1][b][tid] + red[2][b][tid] + red[3][b][tid];
+    }
+}
+template <typename T>
+__global__ void dense_finalize_kernel(const float* __restrict__ part, T* __restrict__ y, long n, int ksplit, float alpha) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int k = 0; k < ksplit; ++k) s += part[(long)k * n + i];
+    DT<T>::st(y + i, s * alpha);
+}
+
+// ------------------------------------------------------------------------ dense bwd data
+// gx[b][i] = alpha * sum_o gy[b][o] * w[i][o] : one wave per weight row i (coalesced along o).
+template <typename T>
+__global__ __launch_bounds__(256) void dense_bwd_data_kernel(const T* __restrict__ gy, const float* __restrict__ w, T* __restrict__ gx,
+                                                             int b0, int nb, int in, int out, float alpha) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= in) return;
+    float acc[DENSE_BT];
+#pragma unroll
+    for (int b = 0; b < DENSE_BT; ++b) acc[b] = 0.f;
+    const float* wr = w + (long)i * out;
+    for (int o = lane; o < out; o += 64) {
+        const float wv = wr[o];
+#pragma unroll
+        for (int b = 0; b < DENSE_BT; ++b)
+            if (b < nb) acc[b] += DT<T>::ld(gy + (long)(b0 + b) * out + o) * wv;
+    }
+#pragma unroll
+    for (int b = 0; b < DENSE_BT; ++b) {
+        if (b < nb) {
+            const float s = wave_sum(acc[b]);
+            if (lane == 0) DT<T>::st(gx + (long)(b0 + b) * in + i, s * alpha);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------- dense bwd weight
+// gw[i][o] = alpha * sum_b x[b][i] * gy[b][o]
+template <typename T>
+__global__ void dense_bwd_weight_kernel(const T* __restrict__ x, const T* __restrict__ gy, float* __restrict__ gw, int b, int in, int out, float alpha) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long)in * out) return;
+    const int o = e % out;
+    const int i = e / out;
+    float s = 0.f;
+    for (int k = 0; k < b; ++k) s += DT<T>::ld(x + (long)k * in + i) * DT<T>::ld(gy + (long)k * out + o);
+    gw[e] = s * alpha;
+}
+
+static void dense_split(int in, int out, int* ksplit, int* ipb) {
+    const int tiles = cdiv(out, 64);
+    int ks = 1024 / tiles;
+    if (ks < 1) ks = 1;
+    int maxks = in / 32;
+    if (maxks < 1) maxks = 1;
+    if (ks > maxks) ks = maxks;
+    *ipb = cdiv(in, ks);
+    *ksplit = cdiv(in, *ipb);
+}
+
+// ------------------------------------------------------------------------------ embedding
+template <typename T>
+__global__ void embedding_fwd_kernel(const int64_t* __restrict__ idx, const float* __restrict__ w, T* __restrict__ y, int b, int rows, int units, float alpha) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= b * units) return;
+    const int r = e / units, u = e % units;
+    long k = idx[r];
+    if (k < 0) k = 0;
+    if (k >= rows) k = rows - 1;
+    DT<T>::st(y + e, w[k * units + u] * alpha);
+}
+// gw[row][u] = alpha * sum_{b: idx[b]==row} gy[b][u]  (gather form: deterministic, no atomics)
+template <typename T>
+__global__ void embedding_bwd_kernel(const int64_t* __restrict__ idx, const T* __restrict__ gy, float* __restrict__ gw, int b, int rows, int units, float alpha) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= rows * units) return;
+    const int r = e / units, u = e % units;
+    float s = 0.f;
+    for (int k = 0; k < b; ++k)
+        if (idx[k] == r) s += DT<T>::ld(gy + (long)k * units + u);
+    gw[e] = s * alpha;
+}
+
+// -------------------------------------------------------------------------- batch stddev
+// x [b][hw][c] (channels-last), groups of 4: column j in [0, M=b/4) holds samples j, j+M, j+2M, j+3M.
+// One block per column j.
+template <typename T>
+__device__ inline void bs_load(const T* x, int M, int j, long pos, long npos, float (&v)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = DT<T>::ld(x + ((long)(i * M + j)) * npos + pos);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void batch_stddev_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int M, int hw, int c, float eps) {
+    __shared__ float red[4];
+    const int j = blockIdx.x;
+    const long npos = (long)hw * c;
+    float s = 0.f;
+    for (long pos = threadIdx.x; pos < npos; pos += 256) {
+        float v[4];
+        bs_load(x, M, j, pos, npos, v);
+        const float mu = 0.25f * (v[0] + v[1] + v[2] + v[3]);
+        float var = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) var += (v[i] - mu) * (v[i] - mu);
+        s += sqrtf(0.25f * var + eps);
+    }
+    s = block_sum<256>(s, red) / (float)npos;
+    for (int k = threadIdx.x; k < 4 * hw; k += 256) {
+        const int i = k / hw, p = k % hw;
+        DT<T>::st(y + (long)(i * M + j) * hw + p, s);
+    }
+}
+
+// gx_i = gs_j * d_i / (4 sigma N),  gs_j = sum over members/pixels of gy
+template <typename T>
+__global__ __launch_bounds__(256) void batch_stddev_bwd_kernel(const T* __restrict__ gy, const T* __restrict__ x, T* __restrict__ gx,
+                                                               int M, int hw, int c, float eps) {
+    __shared__ float red[4];
+    const int j = blockIdx.x;
+    const long npos = (long)hw * c;
+    float g = 0.f;
+    for (int k = threadIdx.x; k < 4 * hw; k += 256) g += DT<T>::ld(gy + (long)((k / hw) * M + j) * hw + (k % hw));
+    g = block_sum<256>(g, red);
+    const float coef = g / (4.f * (float)npos);
+    for (long pos = threadIdx.x; pos < npos; pos += 256) {
+        float v[4];
+        bs_load(x, M, j, pos, npos, v);
+        const float mu = 0.25f * (v[0] + v[1] + v[2] + v[3]);
+        float var = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) var += (v[i] - mu) * (v[i] - mu);
+        const float inv = coef / sqrtf(0.25f * var + eps);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) DT<T>::st(gx + ((long)(i * M + j)) * npos + pos, (v[i] - mu) * inv);
+    }
+}
+
+// F = sum_pos gs_j/(4N) * S/sigma,  S = sum_i ggx_i d_i
+//   ggy (every member / pixel of column j) = sum_pos S / (4 sigma N)
+//   gx2_k = gs_j/(4N) * [ (ggx_k - mean_i ggx_i)/sigma - S d_k / (4 sigma^3) ]
+template <typename T>
+__global__ __launch_bounds__(256) void batch_stddev_bwd_bwd_kernel(const T* __restrict__ ggx, const T* __restrict__ gy, const T* __restrict__ x,
+                                                                   T* __restrict__ ggy, T* __restrict__ gx2, int M, int hw, int c, float eps) {
+    __shared__ float red[4];
+    const int j = blockIdx.x;
+    const long npos = (long)hw * c;
+    float g = 0.f;
+    for (int k = threadIdx.x; k < 4 * hw; k += 256) g += DT<T>::ld(gy + (long)((k / hw) * M + j) * hw + (k % hw));
+    g = block_sum<256>(g, red);
+    const float coef = g / (4.f * (float)npos);
+    float t = 0.f;
+    for (long pos = threadIdx.x; pos < npos; pos += 256) {
+        float v[4], gg[4];
+        bs_load(x, M, j, pos, npos, v);
+        bs_load(ggx, M, j, pos, npos, gg);
+        const float mu = 0.25f * (v[0] + v[1] + v[2] + v[3]);
+        const float gm = 0.25f * (gg[0] + gg[1] + gg[2] + gg[3]);
+        float var = 0.f, S = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { var += (v[i] - mu) * (v[i] - mu); S += gg[i] * (v[i] - mu); }
+        const float sig = sqrtf(0.25f * var + eps);
+        t += S / sig;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            DT<T>::st(gx2 + ((long)(i * M + j)) * npos + pos, coef * ((gg[i] - gm) / sig - S * (v[i] - mu) / (4.f * sig * sig * sig)));
+    }
+    t = block_sum<256>(t, red) / (4.f * (float)npos);
+    for (int k = threadIdx.x; k < 4 * hw; k += 256) DT<T>::st(ggy + (long)((k / hw) * M + j) * hw + (k % hw), t);
+}
+
+}  // namespace gs
+
+using namespace gs;
+
+extern "C" size_t gs_dense_fwd_workspace_bytes(int b, int in, int out) {
+    int ks, ipb;
+    dense_split(in, out, &ks, &ipb);
+    return (size_t)ks * b * out * sizeof(float);
+}
+
+extern "C" int gs_dense_fwd(const void* x, const float* w, void* y, int b, int in, int out, float alpha, int dtype,
+                            void* ws, size_t ws_bytes, void* stream) {
+    GS_CHECK_ARG(b > 0 && in > 0 && out > 0, "dense_fwd: bad args");
+    int ks, ipb;
+    dense_split(in, out, &ks, &ipb);
+    if (ws_bytes < (size_t)ks * b * out * sizeof(float)) return fail(GS_ERR_WORKSPACE, "dense_fwd: workspace too small");
+    hipStream_t st = as_stream(stream);
+    float* part = (float*)ws;
+    for (int b0 = 0; b0 < b; b0 += DENSE_BT) {
+        const int nb = b - b0 < DENSE_BT ? b - b0 : DENSE_BT;
+        GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dense_fwd_kernel<T>), dim3(cdiv(out, 64), ks), dim3(256), 0, st, (const T*)x, w, part, b0, nb, in, out, b, ipb));
+        GS_CHECK_LAUNCH();
+    }
+    const long n = (long)b * out;
+    GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dense_finalize_kernel<T>), dim3(cdiv(n, 256)), dim3(256), 0, st, part, (T*)y, n, ks, alpha));
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gs_dense_bwd_data(const void* gy, const float* w, void* gx, int b, int in, int out, float alpha, int dtype, void* stream) {
+    GS_CHECK_ARG(b > 0 && in > 0 && out > 0, "dense_bwd_data: bad args");
+    hipStream_t st = as_stream(stream);
+    for (int b0 = 0; b0 < b; b0 += DENSE_BT) {
+        const int nb = b - b0 < DENSE_BT ? b - b0 : DENSE_BT;
+        GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dense_bwd_data_kernel<T>), dim3(cdiv(in, 4)), dim3(256), 0, st, (const T*)gy, w, (T*)gx, b0, nb, in, out, alpha));
+        GS_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
+extern "C" int gs_dense_bwd_weight(const void* x, const void* gy, float* gw, int b, int in, int out, float alpha, int dtype, void* stream) {
+    GS_CHECK_ARG(b > 0 && in > 0 && out > 0, "dense_bwd_weight: bad args");
+    const long n = (long)in * out;
+    GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dense_bwd_weight_kernel<T>), dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), (const T*)x, (const T*)gy, gw, b, in, out, alpha));
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gs_embedding_fwd(const int64_t* idx, const float* w, void* y, int b, int rows, int units, float alpha, int dtype, void* stream) {
+    GS_CHECK_ARG(b > 0 && rows > 0 && units > 0, "embedding_fwd: bad args");
+    GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((embedding_fwd_kernel<T>), dim3(cdiv((long)b * units, 256)), dim3(256), 0, as_stream(stream), idx, w, (T*)y, b, rows, units, alpha));
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gs_embedding_bwd(const int64_t* idx, const void* gy, float* gw, int b, int rows, int units, float alpha, int dtype, void* stream) {
+    GS_CHECK_ARG(b > 0 && rows > 0 && units > 0, "embedding_bwd: bad args");
+    GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((embedding_bwd_kernel<T>), dim3(cdiv((long)rows * units, 256)), dim3(256), 0, as_stream(stream), idx, (const T*)gy, gw, b, rows, units, alpha));
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gs_batch_stddev_fwd(const void* x, void* y, int b, int hw, int c, float eps, int dtype, void* stream) {
+    GS_CHECK_ARG(b > 0 && b % 4 == 0 && hw > 0 && c > 0, "batch_stddev: batch %d must be a positive multiple of 4 (ops.py:341)", b);
+    GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((batch_stddev_fwd_kernel<T>), dim3(b / 4), dim3(256), 0, as_stream(stream), (const T*)x, (T*)y, b / 4, hw, c, eps));
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gs_batch_stddev_bwd(const void* gy, const void* x, void* gx, int b, int hw, int c, float eps, int dtype, void* stream) {
+    GS_CHECK_ARG(b > 0 && b % 4 == 0 && hw > 0 && c > 0, "batch_stddev_bwd: bad args");
+    GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((batch_stddev_bwd_kernel<T>), dim3(b / 4), dim3(256), 0, as_stream(stream), (const T*)gy, (const T*)x, (T*)gx, b / 4, hw, c, eps));
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gs_batch_stddev_bwd_bwd(const void* ggx, const void* gy, const void* x, void* ggy, void* gx2, int b, int hw, int c, float eps, int dtype, void* stream) {
+    GS_CHECK_ARG(b > 0 && b % 4 == 0 && hw > 0 && c > 0, "batch_stddev_bwd_bwd: bad args");
+    GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((batch_stddev_bwd_bwd_kernel<T>), dim3(b / 4), dim3(256), 0, as_stream(stream), (const T*)ggx, (const T*)gy, (const T*)x, (T*)ggy, (T*)gx2, b / 4, hw, c, eps));
+    GS_CHECK_LAUNCH();
+    return 0;
+}

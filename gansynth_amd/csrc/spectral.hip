@@ -1,0 +1,412 @@
+// waveform <-> (log-mel magnitude, instantaneous frequency) for gfx950
+// (reference spectral_ops.py:8-149; TF ops replaced: tf.signal.stft / inverse_stft, tf.abs,
+// tf.angle, tf.tensordot with the mel matrix and its tfp.math.pinv, unwrap/diff/cumsum).
+//
+//  stft_kernel     one workgroup per (frame, example): front-pad + framing + periodic Hann fused
+//                  into the load, a 2048-point real FFT done as a 1024-point complex radix-2 FFT
+//                  in LDS (packed even/odd trick), |.| and atan2 in the epilogue, and -- fused
+//                  variant -- the mel projection straight out of LDS.  The mel matrix is 0.2 %
+//                  dense (<= 6 non-zeros per column), so it is applied as an ELL gather, not a GEMM.
+//  if kernels      threads across mel bins (coalesced), 128 sequential time steps per thread.
+//  inverse         exp / cumsum prep, dense pinv(mel) contraction on fp32 MFMA (this one IS a
+//                  dense GEMM), packed inverse FFT, windowed overlap-add.
+#include "gs_common.h"
+
+#include <math.h>
+#include <vector>
+
+struct gs_spectral_plan {
+    int frame_length, frame_step, time_steps, nbins, log2h, maxnz;
+    float* hann;        // [frame_length]
+    float2* tw;         // [nbins/2]  exp(-2 pi i k / nbins)
+    float2* twp;        // [nbins+1]  exp(-2 pi i k / frame_length)
+    int* mel_idx;       // [nbins][maxnz] ELL by mel column
+    float* mel_val;     // [nbins][maxnz]
+    float* pinv;        // [nbins][nbins] or nullptr
+    float* inv_window;  // [frame_length]
+};
+
+namespace gs {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ inline float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+
+// in-place radix-2 DIT FFT of H points held bit-reversed in LDS; INV conjugates the twiddles
+template <bool INV>
+__device__ inline void fft_lds(float2* z, const float2* __restrict__ tw, int H, int log2h) {
+    for (int s = 1; s <= log2h; ++s) {
+        const int half = 1 << (s - 1);
+        const int tstep = (H >> 1) >> (s - 1);
+        for (int bf = threadIdx.x; bf < (H >> 1); bf += blockDim.x) {
+            const int pos = bf & (half - 1);
+            const int i = ((bf >> (s - 1)) << s) + pos;
+            float2 w = tw[pos * tstep];
+            if (INV) w.y = -w.y;
+            const float2 u = z[i];
+            const float2 v = cmul(w, z[i + half]);
+            z[i] = make_float2(u.x + v.x, u.y + v.y);
+            z[i + half] = make_float2(u.x - v.x, u.y - v.y);
+        }
+        __syncthreads();
+    }
+}
+
+__device__ inline int bitrev(int v, int bits) { return (int)(__brev((unsigned)v) >> (32 - bits)); }
+
+// MODE 0: write magnitude/phase [b][T][H] (DC dropped).
+// MODE 1: fused mel: images[b][T][H][2] channel 0 = (log(mel_mag + 1e-6) + 3.76)/10.05 ; mel_phase[b][T][H] fp32
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void stft_kernel(gs_spectral_plan p, const float* __restrict__ wave, int wave_len, int front_pad,
+                                                   float* __restrict__ o0, float* __restrict__ o1, T* __restrict__ images) {
+    __shared__ float2 z[1024];
+    __shared__ float smag[MODE == 1 ? 1024 : 1];
+    __shared__ float sph[MODE == 1 ? 1024 : 1];
+    const int H = p.nbins, step = p.frame_step;
+    const int t = blockIdx.x, b = blockIdx.y;
+    const float* wv = wave + (long)b * wave_len;
+    for (int n = threadIdx.x; n < H; n += blockDim.x) {
+        const int s0 = t * step + 2 * n - front_pad;
+        const float x0 = (s0 >= 0 && s0 < wave_len) ? wv[s0] * p.hann[2 * n] : 0.f;
+        const float x1 = (s0 + 1 >= 0 && s0 + 1 < wave_len) ? wv[s0 + 1] * p.hann[2 * n + 1] : 0.f;
+        z[bitrev(n, p.log2h)] = make_float2(x0, x1);
+    }
+    __syncthreads();
+    fft_lds<false>(z, p.tw, H, p.log2h);
+    const long row = ((long)b * p.time_steps + t) * H;
+    for (int k = threadIdx.x + 1; k <= H; k += blockDim.x) {
+        const float2 zk = z[k & (H - 1)];
+        const float2 zc = z[(H - k) & (H - 1)];  // conj applied below
+        const float2 e = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y));   // (Zk + conj(Zc))/2
+        const float2 o = make_float2(0.5f * (zk.y + zc.y), -0.5f * (zk.x - zc.x));  // (Zk - conj(Zc))/(2i)
+        const float2 wo = cmul(p.twp[k], o);
+        const float re = e.x + wo.x, im = e.y + wo.y;
+        const float mg = hypotf(re, im);
+        const float ph = (re == 0.f && im == 0.f) ? 0.f : atan2f(im, re);
+        if (MODE == 0) {
+            o0[row + k - 1] = mg;
+            o1[row + k - 1] = ph;
+        } else {
+            smag[k - 1] = mg;
+            sph[k - 1] = ph;
+        }
+    }
+    if (MODE == 1) {
+        __syncthreads();
+        for (int m = threadIdx.x; m < H; m += blockDim.x) {
+            float am = 0.f, ap = 0.f;
+            for (int j = 0; j < p.maxnz; ++j) {
+                const int f = p.mel_idx[m * p.maxnz + j];
+                const float w = p.mel_val[m * p.maxnz + j];
+                am += smag[f] * w;
+                ap += sph[f] * w;
+            }
+            DT<T>::st(images + (row + m) * 2, (logf(am + 1.0e-6f) + 3.76f) / 10.05f);
+            o0[row + m] = ap;
+        }
+    }
+}
+
+// out[row][m] = sum_j in[row][idx[m][j]] * val[m][j]
+static __global__ void mel_project_kernel(gs_spectral_plan p, const float* __restrict__ in, float* __restrict__ out, long rows) {
+    const int H = p.nbins;
+    const long total = rows * H;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int m = i % H;
+        const float* r = in + (i / H) * H;
+        float a = 0.f;
+        for (int j = 0; j < p.maxnz; ++j) a += r[p.mel_idx[m * p.maxnz + j]] * p.mel_val[m * p.maxnz + j];
+        out[i] = a;
+    }
+}
+
+// spectral_ops.py:21-44 along time: d = p[t]-p[t-1]; m = floormod(d+pi, 2pi)-pi; m = pi where (m==-pi & d>0);
+// unwrapped = p + cumsum(m-d); IF = [unwrapped[0], diff(unwrapped)]/pi.  One thread per (example, mel bin).
+template <typename T, int MODE>  // MODE 0: out fp32 [b][T][H]; MODE 1: images[b][T][H][2] channel 1
+__global__ void if_unwrap_kernel(gs_spectral_plan p, const float* __restrict__ mel_phase, float* __restrict__ out, T* __restrict__ images, int batch) {
+    const int H = p.nbins, TT = p.time_steps;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= batch * H) return;
+    const int b = i / H, m = i % H;
+    const float pi = 3.14159274101257324f;  // float32(np.pi)
+    const float two_pi = pi * 2.0f;
+    float prev_p = 0.f, prev_u = 0.f, cum = 0.f;
+    for (int t = 0; t < TT; ++t) {
+        const long o = ((long)b * TT + t) * H + m;
+        const float ph = mel_phase[o];
+        float v;
+        if (t == 0) {
+            prev_u = ph;
+            v = ph / pi;
+        } else {
+            const float d = ph - prev_p;
+            float md = fmodf(d + pi, two_pi);
+            if (md < 0.f) md += two_pi;
+            md -= pi;
+            if (md == -pi && d > 0.f) md = pi;
+            cum += md - d;
+            const float u = ph + cum;
+            v = (u - prev_u) / pi;
+            prev_u = u;
+        }
+        prev_p = ph;
+        if (MODE == 0) out[o] = v;
+        else DT<T>::st(images + o * 2 + 1, v);
+    }
+}
+
+// ------------------------------------------------------------------------------ inverse
+// images -> mel_mag = exp(lm*10.05 - 3.76), mel_phase = cumsum(IF*pi) over time (spectral_ops.py:107-111)
+template <typename T>
+__global__ void inv_prep_kernel(gs_spectral_plan p, const T* __restrict__ images, float* __restrict__ mel_mag, float* __restrict__ mel_phase, int batch) {
+    const int H = p.nbins, TT = p.time_steps;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= batch * H) return;
+    const int b = i / H, m = i % H;
+    const float pi = 3.14159274101257324f;
+    float cum = 0.f;
+    for (int t = 0; t < TT; ++t) {
+        const long o = ((long)b * TT + t) * H + m;
+        const float lm = DT<T>::ld(images + o * 2) * 10.05f + (-3.76f);
+        const float fi = DT<T>::ld(images + o * 2 + 1) * 1.0f + 0.0f;
+        cum += fi * pi;
+        mel_mag[o] = expf(lm);
+        mel_phase[o] = cum;
+    }
+}
+
+// C[M][N] = A[M][K] @ B[K][N], fp32 MFMA (32x32x2), 64x64 block tile, 4 waves (2x2), K step 16.
+static __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int M, int N, int K) {
+    __shared__ float As[64][17];
+    __shared__ float Bs[16][64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, hi = lane >> 5, l31 = lane & 31;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int wm = (wv >> 1) * 32, wn = (wv & 1) * 32;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        __syncthreads();
+        for (int c = tid; c < 64 * 16; c += 256) {
+            const int r = c >> 4, k = c & 15;
+            As[r][k] = (m0 + r < M && k0 + k < K) ? A[(long)(m0 + r) * K + k0 + k] : 0.f;
+        }
+        for (int c = tid; c < 16 * 64; c += 256) {
+            const int k = c >> 6, j = c & 63;
+            Bs[k][j] = (k0 + k < K && n0 + j < N) ? B[(long)(k0 + k) * N + n0 + j] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; kk += 2)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[wm + l31][kk + hi], Bs[kk + hi][wn + l31], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int i = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        const int j = n0 + wn + l31;
+        if (i < M && j < N) C[(long)i * N + j] = acc[r];
+    }
+}
+
+// one workgroup per (frame, example): spectrum from (mag, phase), DC = 0 (spectral_ops.py:128-131), packed inverse
+// real FFT, multiply by the inverse window; frames[b][T][L]
+static __global__ __launch_bounds__(256) void istft_kernel(gs_spectral_plan p, const float* __restrict__ mag, const float* __restrict__ phase, float* __restrict__ frames) {
+    __shared__ float2 x[1025];
+    __shared__ float2 z[1024];
+    const int H = p.nbins, L = p.frame_length;
+    const int t = blockIdx.x, b = blockIdx.y;
+    const long row = ((long)b * p.time_steps + t) * H;
+    for (int k = threadIdx.x; k <= H; k += blockDim.x) {
+        if (k == 0) x[0] = make_float2(0.f, 0.f);
+        else {
+            const float mg = mag[row + k - 1], ph = phase[row + k - 1];
+            float sn, cs;
+            sincosf(ph, &sn, &cs);
+            x[k] = make_float2(mg * cs, mg * sn);
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < H; k += blockDim.x) {
+        float2 xk = x[k];
+        float2 xc = x[H - k];
+        if (k == 0) { xk.y = 0.f; xc.y = 0.f; }  // irfft uses only the real parts of DC and Nyquist
+        const float2 e = make_float2(0.5f * (xk.x + xc.x), 0.5f * (xk.y - xc.y));  // (Xk + conj(X[H-k]))/2
+        const float2 d = make_float2(0.5f * (xk.x - xc.x), 0.5f * (xk.y + xc.y));  // (Xk - conj(X[H-k]))/2
+        float2 w = p.twp[k];
+        w.y = -w.y;  // e^{+2 pi i k / N}
+        const float2 o = cmul(w, d);
+        // Z = Xe + i*Xo
+        z[bitrev(k, p.log2h)] = make_float2(e.x - o.y, e.y + o.x);
+    }
+    __syncthreads();
+    fft_lds<true>(z, p.tw, H, p.log2h);
+    const float sc = 1.0f / (float)H;
+    float* fr = frames + ((long)b * p.time_steps + t) * L;
+    for (int n = threadIdx.x; n < H; n += blockDim.x) {
+        fr[2 * n] = z[n].x * sc * p.inv_window[2 * n];
+        fr[2 * n + 1] = z[n].y * sc * p.inv_window[2 * n + 1];
+    }
+}
+
+// overlap-add (gather form) + drop the front padding: wave[b][s] = sum_f frames[b][f][s + front_pad - f*step]
+static __global__ void overlap_add_kernel(gs_spectral_plan p, const float* __restrict__ frames, float* __restrict__ wave, int batch, int wave_len, int front_pad) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)batch * wave_len) return;
+    const int b = i / wave_len;
+    const int s = (int)(i % wave_len) + front_pad;
+    const int L = p.frame_length, step = p.frame_step;
+    int f1 = s / step;
+    if (f1 > p.time_steps - 1) f1 = p.time_steps - 1;
+    int f0 = (s - L + step) / step;
+    if (s - L + 1 <= 0) f0 = 0;
+    if (f0 < 0) f0 = 0;
+    float a = 0.f;
+    for (int f = f0; f <= f1; ++f) {
+        const int off = s - f * step;
+        if (off >= 0 && off < L) a += frames[((long)b * p.time_steps + f) * L + off];
+    }
+    wave[i] = a;
+}
+
+}  // namespace gs
+
+using namespace gs;
+
+#define GS_HIP_OK(expr)                                                                        \
+    do {                                                                                       \
+        hipError_t e__ = (expr);                                                               \
+        if (e__ != hipSuccess) return gs::fail(GS_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e__)); \
+    } while (0)
+
+extern "C" int gs_spectral_plan_create(gs_spectral_plan** out, int frame_length, int frame_step, int time_steps,
+                                       const float* mel_dense, const float* mel_pinv) {
+    GS_CHECK_ARG(out && mel_dense, "plan_create: null argument");
+    const int H = frame_length / 2;
+    int log2h = 0;
+    while ((1 << log2h) < H) ++log2h;
+    GS_CHECK_ARG((1 << log2h) == H && H >= 64 && H <= 1024 && frame_length == 2 * H, "plan_create: frame_length %d must be 2*2^k, 128..2048", frame_length);
+    GS_CHECK_ARG(frame_step > 0 && time_steps > 0, "plan_create: bad frame_step/time_steps");
+    gs_spectral_plan* p = new gs_spectral_plan();
+    memset(p, 0, sizeof(*p));
+    p->frame_length = frame_length; p->frame_step = frame_step; p->time_steps = time_steps; p->nbins = H; p->log2h = log2h;
+    std::vector<float> hann(frame_length), invw(frame_length);
+    for (int n = 0; n < frame_length; ++n) hann[n] = (float)(0.5 - 0.5 * cos(2.0 * M_PI * n / frame_length));
+    {  // tf.signal.inverse_stft_window_fn: w / sum over overlaps of w^2
+        const int overlaps = (frame_length + frame_step - 1) / frame_step;
+        std::vector<double> den(overlaps * frame_step, 0.0), w2(overlaps * frame_step, 0.0);
+        for (int n = 0; n < frame_length; ++n) { const double w = 0.5 - 0.5 * cos(2.0 * M_PI * n / frame_length); w2[n] = w * w; }
+        for (int r = 0; r < frame_step; ++r) { double s = 0; for (int o = 0; o < overlaps; ++o) s += w2[o * frame_step + r]; for (int o = 0; o < overlaps; ++o) den[o * frame_step + r] = s; }
+        for (int n = 0; n < frame_length; ++n) invw[n] = (float)((0.5 - 0.5 * cos(2.0 * M_PI * n / frame_length)) / den[n]);
+    }
+    std::vector<float2> tw(H / 2), twp(H + 1);
+    for (int k = 0; k < H / 2; ++k) tw[k] = make_float2((float)cos(-2.0 * M_PI * k / H), (float)sin(-2.0 * M_PI * k / H));
+    for (int k = 0; k <= H; ++k) twp[k] = make_float2((float)cos(-2.0 * M_PI * k / frame_length), (float)sin(-2.0 * M_PI * k / frame_length));
+    int maxnz = 1;
+    for (int m = 0; m < H; ++m) { int c = 0; for (int f = 0; f < H; ++f) if (mel_dense[(long)f * H + m] != 0.f) ++c; if (c > maxnz) maxnz = c; }
+    std::vector<int> idx((long)H * maxnz, 0);
+    std::vector<float> val((long)H * maxnz, 0.f);
+    for (int m = 0; m < H; ++m) { int c = 0; for (int f = 0; f < H; ++f) { const float w = mel_dense[(long)f * H + m]; if (w != 0.f) { idx[(long)m * maxnz + c] = f; val[(long)m * maxnz + c] = w; ++c; } } }
+    p->maxnz = maxnz;
+    GS_HIP_OK(hipMalloc(&p->hann, frame_length * sizeof(float)));
+    GS_HIP_OK(hipMalloc(&p->inv_window, frame_length * sizeof(float)));
+    GS_HIP_OK(hipMalloc(&p->tw, (H / 2) * sizeof(float2)));
+    GS_HIP_OK(hipMalloc(&p->twp, (H + 1) * sizeof(float2)));
+    GS_HIP_OK(hipMalloc(&p->mel_idx, idx.size() * sizeof(int)));
+    GS_HIP_OK(hipMalloc(&p->mel_val, val.size() * sizeof(float)));
+    GS_HIP_OK(hipMemcpy(p->hann, hann.data(), frame_length * sizeof(float), hipMemcpyHostToDevice));
+    GS_HIP_OK(hipMemcpy(p->inv_window, invw.data(), frame_length * sizeof(float), hipMemcpyHostToDevice));
+    GS_HIP_OK(hipMemcpy(p->tw, tw.data(), (H / 2) * sizeof(float2), hipMemcpyHostToDevice));
+    GS_HIP_OK(hipMemcpy(p->twp, twp.data(), (H + 1) * sizeof(float2), hipMemcpyHostToDevice));
+    GS_HIP_OK(hipMemcpy(p->mel_idx, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice));
+    GS_HIP_OK(hipMemcpy(p->mel_val, val.data(), val.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (mel_pinv) {
+        GS_HIP_OK(hipMalloc(&p->pinv, (size_t)H * H * sizeof(float)));
+        GS_HIP_OK(hipMemcpy(p->pinv, mel_pinv, (size_t)H * H * sizeof(float), hipMemcpyHostToDevice));
+    }
+    *out = p;
+    return 0;
+}
+
+extern "C" int gs_spectral_plan_destroy(gs_spectral_plan* p) {
+    if (!p) return 0;
+    hipFree(p->hann); hipFree(p->inv_window); hipFree(p->tw); hipFree(p->twp); hipFree(p->mel_idx); hipFree(p->mel_val);
+    if (p->pinv) hipFree(p->pinv);
+    delete p;
+    return 0;
+}
+
+extern "C" int gs_stft_fwd(const gs_spectral_plan* p, const float* wave, int batch, int wave_len, int front_pad, float* magnitude,
+                           float* phase, void* stream) {
+    GS_CHECK_ARG(p && batch > 0 && wave_len > 0, "stft_fwd: bad args");
+    hipLaunchKernelGGL((stft_kernel<float, 0>), dim3(p->time_steps, batch), dim3(256), 0, as_stream(stream), *p, wave, wave_len, front_pad,
+                       magnitude, phase, (float*)nullptr);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gs_mel_project(const gs_spectral_plan* p, const float* in, float* out, int64_t rows, void* stream) {
+    GS_CHECK_ARG(p && rows > 0, "mel_project: bad args");
+    long g = ((long)rows * p->nbins + 255) / 256;
+    if (g > 16384) g = 16384;
+    hipLaunchKernelGGL(mel_project_kernel, dim3((unsigned)g), dim3(256), 0, as_stream(stream), *p, in, out, (long)rows);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gs_if_unwrap(const gs_spectral_plan* p, const float* mel_phase, float* mel_if, int batch, void* stream) {
+    GS_CHECK_ARG(p && batch > 0, "if_unwrap: bad args");
+    hipLaunchKernelGGL((if_unwrap_kernel<float, 0>), dim3(cdiv((long)batch * p->nbins, 256)), dim3(256), 0, as_stream(stream), *p, mel_phase, mel_if,
+                       (float*)nullptr, batch);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" size_t gs_stft_mel_if_workspace_bytes(const gs_spectral_plan* p, int batch) {
+    return p ? (size_t)batch * p->time_steps * p->nbins * sizeof(float) : 0;
+}
+
+extern "C" int gs_stft_mel_if_fwd(const gs_spectral_plan* p, const float* wave, int batch, int wave_len, int front_pad, void* images,
+                                  int dtype, void* ws, size_t ws_bytes, void* stream) {
+    GS_CHECK_ARG(p && batch > 0 && wave_len > 0, "stft_mel_if_fwd: bad args");
+    if (ws_bytes < gs_stft_mel_if_workspace_bytes(p, batch)) return fail(GS_ERR_WORKSPACE, "stft_mel_if_fwd: workspace too small");
+    hipStream_t st = as_stream(stream);
+    float* mel_phase = (float*)ws;
+    GS_DISPATCH_DTYPE(dtype, {
+        hipLaunchKernelGGL((stft_kernel<T, 1>), dim3(p->time_steps, batch), dim3(256), 0, st, *p, wave, wave_len, front_pad, mel_phase, (float*)nullptr, (T*)images);
+        hipLaunchKernelGGL((if_unwrap_kernel<T, 1>), dim3(cdiv((long)batch * p->nbins, 256)), dim3(256), 0, st, *p, mel_phase, (float*)nullptr, (T*)images, batch);
+    });
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" size_t gs_mel_if_to_waveform_workspace_bytes(const gs_spectral_plan* p, int batch) {
+    if (!p) return 0;
+    const size_t rows = (size_t)batch * p->time_steps;
+    return (4 * rows * p->nbins + rows * p->frame_length) * sizeof(float);
+}
+
+extern "C" int gs_mel_if_to_waveform(const gs_spectral_plan* p, const void* images, int batch, int wave_len, int front_pad, float* wave,
+                                     int dtype, void* ws, size_t ws_bytes, void* stream) {
+    GS_CHECK_ARG(p && batch > 0 && wave_len > 0, "mel_if_to_waveform: bad args");
+    GS_CHECK_ARG(p->pinv != nullptr, "mel_if_to_waveform: the plan was created without mel_pinv");
+    if (ws_bytes < gs_mel_if_to_waveform_workspace_bytes(p, batch)) return fail(GS_ERR_WORKSPACE, "mel_if_to_waveform: workspace too small");
+    hipStream_t st = as_stream(stream);
+    const long rows = (long)batch * p->time_steps;
+    const int H = p->nbins;
+    float* mel_mag = (float*)ws;
+    float* mel_ph = mel_mag + rows * H;
+    float* mag = mel_ph + rows * H;
+    float* ph = mag + rows * H;
+    float* frames = ph + rows * H;
+    GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((inv_prep_kernel<T>), dim3(cdiv((long)batch * H, 256)), dim3(256), 0, st, *p, (const T*)images, mel_mag, mel_ph, batch));
+    GS_CHECK_LAUNCH();
+    dim3 gg(cdiv(H, 64), cdiv(rows, 64));
+    hipLaunchKernelGGL(gemm_f32_kernel, gg, dim3(256), 0, st, mel_mag, p->pinv, mag, (int)rows, H, H);
+    hipLaunchKernelGGL(gemm_f32_kernel, gg, dim3(256), 0, st, mel_ph, p->pinv, ph, (int)rows, H, H);
+    GS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(istft_kernel, dim3(p->time_steps, batch), dim3(256), 0, st, *p, mag, ph, frames);
+    GS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(overlap_add_kernel, dim3(cdiv((long)batch * wave_len, 256)), dim3(256), 0, st, *p, frames, wave, batch, wave_len, front_pad);
+    GS_CHECK_LAUNCH();
+    return 0;
+}

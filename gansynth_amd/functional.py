@@ -1,0 +1,370 @@
+"""Differentiable (to second order) wrappers around the HIP kernels.
+
+The reference obtains its R1 penalty and mode-seeking loss from nested tf.gradients
+(models.py:47,60), i.e. it differentiates through the backward pass.  Each op here is a
+torch.autograd.Function whose backward is itself expressed with Functions, so
+`torch.autograd.grad(..., create_graph=True)` composes exactly like tf.gradients does:
+
+  conv / conv-transpose / dense : the three bilinear maps (fwd, bwd-data, bwd-weight) are closed
+                                  under differentiation -- each one's gradients are the other two;
+  bias+activation, pixel-norm, tanh, batch-stddev : explicit first- and second-order kernels;
+  upscale / block-sum : adjoint pair.
+
+torch is only the tape; every tensor operation is a kernel from libgansynth_hip.so.
+"""
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import kernels
+from ._lib import ACT_LRELU, ACT_NONE, ACT_TANH
+
+
+def _K():
+    return kernels.get()
+
+
+# ------------------------------------------------------------------ bilinear map families
+class _ConvKind(object):
+    """tf.nn.conv2d SAME (ops.py:237-243), ksize in {1,3}, stride in {1,2}."""
+
+    def __init__(self, ksize, stride):
+        self.ksize, self.stride = ksize, stride
+
+    def fwd(self, x, w, alpha):
+        return _K().conv2d_fwd(x, w, self.ksize, self.stride, alpha)
+
+    def bwd_data(self, gy, w, x_shape, alpha):
+        return _K().conv2d_bwd_data(gy, w, x_shape, self.ksize, self.stride, alpha)
+
+    def bwd_weight(self, x, gy, alpha):
+        return _K().conv2d_bwd_weight(x, gy, self.ksize, self.stride, alpha)
+
+
+class _ConvTransposeKind(object):
+    """tf.nn.conv2d_transpose 3x3 stride 2 SAME (ops.py:266-276)."""
+
+    def fwd(self, x, w, alpha):
+        return _K().conv2d_transpose_fwd(x, w, alpha)
+
+    def bwd_data(self, gy, w, x_shape, alpha):
+        return _K().conv2d_transpose_bwd_data(gy, w, alpha)
+
+    def bwd_weight(self, x, gy, alpha):
+        return _K().conv2d_transpose_bwd_weight(x, gy, alpha)
+
+
+class _DenseKind(object):
+    """tf.matmul (ops.py:197)."""
+
+    def fwd(self, x, w, alpha):
+        return _K().dense_fwd(x, w, alpha)
+
+    def bwd_data(self, gy, w, x_shape, alpha):
+        return _K().dense_bwd_data(gy, w, alpha)
+
+    def bwd_weight(self, x, gy, alpha):
+        return _K().dense_bwd_weight(x, gy, alpha)
+
+
+_KINDS = {}
+
+
+def _kind(key):
+    if key not in _KINDS:
+        if key[0] == "conv":
+            _KINDS[key] = _ConvKind(key[1], key[2])
+        elif key[0] == "convT":
+            _KINDS[key] = _ConvTransposeKind()
+        else:
+            _KINDS[key] = _DenseKind()
+    return _KINDS[key]
+
+
+class _Bilinear(Function):
+    """y = alpha * B(x, w)."""
+
+    @staticmethod
+    def forward(ctx, x, w, kind, alpha):
+        ctx.kind, ctx.alpha = kind, alpha
+        ctx.save_for_backward(x, w)
+        return kind.fwd(x, w, alpha)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gx = _BilinearBwdData.apply(gy, w, x.shape, ctx.kind, ctx.alpha) if ctx.needs_input_grad[0] else None
+        gw = _BilinearBwdWeight.apply(x, gy, ctx.kind, ctx.alpha).to(w.dtype) if ctx.needs_input_grad[1] else None
+        return gx, gw, None, None
+
+
+class _BilinearBwdData(Function):
+    """gx = alpha * d<gy, B(x,w)>/dx   (linear in gy and in w)."""
+
+    @staticmethod
+    def forward(ctx, gy, w, x_shape, kind, alpha):
+        ctx.kind, ctx.alpha = kind, alpha
+        ctx.save_for_backward(gy, w)
+        return kind.bwd_data(gy, w, x_shape, alpha)
+
+    @staticmethod
+    def backward(ctx, ggx):
+        gy, w = ctx.saved_tensors
+        g_gy = _Bilinear.apply(ggx, w, ctx.kind, ctx.alpha) if ctx.needs_input_grad[0] else None
+        g_w = _BilinearBwdWeight.apply(ggx, gy, ctx.kind, ctx.alpha).to(w.dtype) if ctx.needs_input_grad[1] else None
+        return g_gy, g_w, None, None, None
+
+
+class _BilinearBwdWeight(Function):
+    """gw = alpha * d<gy, B(x,w)>/dw   (linear in x and in gy); fp32 out."""
+
+    @staticmethod
+    def forward(ctx, x, gy, kind, alpha):
+        ctx.kind, ctx.alpha = kind, alpha
+        ctx.save_for_backward(x, gy)
+        return kind.bwd_weight(x, gy, alpha)
+
+    @staticmethod
+    def backward(ctx, ggw):
+        x, gy = ctx.saved_tensors
+        g_x = _BilinearBwdData.apply(gy, ggw, x.shape, ctx.kind, ctx.alpha) if ctx.needs_input_grad[0] else None
+        g_gy = _Bilinear.apply(x, ggw, ctx.kind, ctx.alpha) if ctx.needs_input_grad[1] else None
+        return g_x, g_gy, None, None
+
+
+def conv2d(x, w, ksize, stride, alpha):
+    return _Bilinear.apply(x, w, _kind(("conv", ksize, stride)), alpha)
+
+
+def conv2d_transpose(x, w, alpha):
+    return _Bilinear.apply(x, w, _kind(("convT",)), alpha)
+
+
+def dense(x, w, alpha):
+    return _Bilinear.apply(x, w, _kind(("dense",)), alpha)
+
+
+# --------------------------------------------------------------------------- embedding
+class _Embedding(Function):
+    @staticmethod
+    def forward(ctx, idx, w, alpha, dtype):
+        ctx.alpha, ctx.rows = alpha, w.shape[0]
+        ctx.save_for_backward(idx)
+        return _K().embedding_fwd(idx, w, alpha, dtype)
+
+    @staticmethod
+    def backward(ctx, gy):
+        (idx,) = ctx.saved_tensors
+        return None, _EmbeddingBwd.apply(idx, gy, ctx.rows, ctx.alpha), None, None
+
+
+class _EmbeddingBwd(Function):
+    @staticmethod
+    def forward(ctx, idx, gy, rows, alpha):
+        ctx.alpha, ctx.dtype = alpha, gy.dtype
+        ctx.save_for_backward(idx)
+        return _K().embedding_bwd(idx, gy, rows, alpha)
+
+    @staticmethod
+    def backward(ctx, ggw):
+        (idx,) = ctx.saved_tensors
+        return None, _Embedding.apply(idx, ggw, ctx.alpha, ctx.dtype), None, None
+
+
+def embedding(idx, w, alpha, dtype):
+    return _Embedding.apply(idx, w, alpha, dtype)
+
+
+# ------------------------------------------------------------------- bias + activation
+class _ChannelSum(Function):
+    @staticmethod
+    def forward(ctx, g):
+        ctx.shape, ctx.dtype = g.shape, g.dtype
+        return _K().channel_sum(g)
+
+    @staticmethod
+    def backward(ctx, gs):
+        view = (1, -1, 1, 1) if len(ctx.shape) == 4 else (1, -1)
+        return gs.to(ctx.dtype).view(view).expand(ctx.shape)
+
+
+class _BiasAct(Function):
+    """z = act(x + bias[c])."""
+
+    @staticmethod
+    def forward(ctx, x, bias, act):
+        z = _K().bias_act_fwd(x, bias, act)
+        ctx.act = act
+        ctx.has_bias = bias is not None
+        if act != ACT_NONE:
+            ctx.save_for_backward(z)
+        return z
+
+    @staticmethod
+    def backward(ctx, gz):
+        if ctx.act != ACT_NONE:
+            (z,) = ctx.saved_tensors
+            gx = _ActBwd.apply(gz, z, ctx.act)
+        else:
+            gx = gz
+        gb = _ChannelSum.apply(gx) if (ctx.has_bias and ctx.needs_input_grad[1]) else None
+        return (gx if ctx.needs_input_grad[0] else None), gb, None
+
+
+class _ActBwd(Function):
+    """gx = g * act'(.) written through the activation output z."""
+
+    @staticmethod
+    def forward(ctx, g, z, act):
+        ctx.act = act
+        ctx.save_for_backward(g, z)
+        return _K().act_bwd(g, z, act)
+
+    @staticmethod
+    def backward(ctx, ggx):
+        g, z = ctx.saved_tensors
+        g_g = _ActBwd.apply(ggx, z, ctx.act) if ctx.needs_input_grad[0] else None
+        g_z = None
+        if ctx.act == ACT_TANH and ctx.needs_input_grad[1]:
+            g_z = _K().tanh_bwd_bwd(ggx, g, z)  # leaky_relu is piecewise linear: no term
+        return g_g, g_z, None
+
+
+def bias_act(x, bias, act):
+    return _BiasAct.apply(x, bias, act)
+
+
+# ------------------------------------------------------------------------- pixel norm
+class _PixelNorm(Function):
+    @staticmethod
+    def forward(ctx, x, eps):
+        ctx.eps = eps
+        ctx.save_for_backward(x)
+        return _K().pixel_norm_fwd(x, eps)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return _PixelNormBwd.apply(g, x, ctx.eps), None
+
+
+class _PixelNormBwd(Function):
+    @staticmethod
+    def forward(ctx, g, x, eps):
+        ctx.eps = eps
+        ctx.save_for_backward(g, x)
+        return _K().pixel_norm_bwd(g, x, eps)
+
+    @staticmethod
+    def backward(ctx, gg):
+        g, x = ctx.saved_tensors
+        g_g = _PixelNormBwd.apply(gg, x, ctx.eps) if ctx.needs_input_grad[0] else None  # symmetric Jacobian
+        g_x = _K().pixel_norm_bwd_bwd(gg, g, x, ctx.eps) if ctx.needs_input_grad[1] else None
+        return g_g, g_x, None
+
+
+def pixel_norm(x, eps):
+    return _PixelNorm.apply(x, eps)
+
+
+# ------------------------------------------------------------------ upscale / block sum
+class _Upscale(Function):
+    @staticmethod
+    def forward(ctx, x, fy, fx, scale):
+        ctx.f = (fy, fx, scale)
+        return _K().upscale2d(x, fy, fx, scale)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _BlockSum.apply(g, *ctx.f), None, None, None
+
+
+class _BlockSum(Function):
+    @staticmethod
+    def forward(ctx, x, fy, fx, scale):
+        ctx.f = (fy, fx, scale)
+        return _K().blocksum2d(x, fy, fx, scale)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _Upscale.apply(g, *ctx.f), None, None, None
+
+
+def upscale(x, fy, fx):
+    return _Upscale.apply(x, fy, fx, 1.0)
+
+
+def avg_pool(x, fy, fx):
+    return _BlockSum.apply(x, fy, fx, 1.0 / float(fy * fx))
+
+
+# ------------------------------------------------------------------------ batch stddev
+class _BatchStddev(Function):
+    @staticmethod
+    def forward(ctx, x, eps):
+        ctx.eps = eps
+        ctx.save_for_backward(x)
+        return _K().batch_stddev_fwd(x, eps)
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        return _BatchStddevBwd.apply(gy, x, ctx.eps), None
+
+
+class _BatchStddevBwd(Function):
+    @staticmethod
+    def forward(ctx, gy, x, eps):
+        ctx.eps = eps
+        ctx.save_for_backward(gy, x)
+        return _K().batch_stddev_bwd(gy, x, eps)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, ggx):
+        gy, x = ctx.saved_tensors
+        ggy, gx2 = _K().batch_stddev_bwd_bwd(ggx, gy, x, ctx.eps)
+        return ggy, gx2, None
+
+
+def batch_stddev(x, eps):
+    return _BatchStddev.apply(x, eps)
+
+
+# --------------------------------------------------------------------------------- lerp
+class _Axpby(Function):
+    @staticmethod
+    def forward(ctx, a, b, ca, cb):
+        ctx.c = (ca, cb)
+        return _K().axpby(a, b, ca, cb)
+
+    @staticmethod
+    def backward(ctx, g):
+        ca, cb = ctx.c
+        ga = _Axpby.apply(g, g, ca, 0.0) if ctx.needs_input_grad[0] else None
+        gb = _Axpby.apply(g, g, 0.0, cb) if ctx.needs_input_grad[1] else None
+        return ga, gb, None, None
+
+
+def axpby(a, b, ca, cb):
+    return _Axpby.apply(a, b, ca, cb)
+
+
+# ----------------------------------------------------------------- R1 penalty reduction
+class _SumSqRows(Function):
+    """out[b] = sum_j x[b][...]^2  (models.py:48)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return _K().sumsq_rows(x)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return _K().row_scale(x, 2.0 * g)
+
+
+def sumsq_rows(x):
+    return _SumSqRows.apply(x)

@@ -1,0 +1,350 @@
+"""Tensor-level wrappers over the C ABI (one method per kernel entry point).
+
+Inputs/outputs are torch CUDA(HIP) tensors; torch only supplies device memory and the
+current stream.  4-D activations are logical NCHW with channels-last strides, which is the
+[n][h][w][c] layout the kernels expect.  Every method launches HIP kernels from
+libgansynth_hip.so -- nothing here computes with torch ops.
+
+The autograd layer (functional.py) talks to the module-level `K` object; tests may swap it for
+an emulation to check the autograd algebra on CPU, the product never does.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import GS_BF16, GS_F32
+
+CL = torch.channels_last
+
+
+def _dt(t):
+    if t.dtype == torch.float32:
+        return GS_F32
+    if t.dtype == torch.bfloat16:
+        return GS_BF16
+    raise TypeError(f"unsupported activation dtype {t.dtype}")
+
+
+def _act(x):
+    """Make an activation tensor kernel-ready (channels-last for 4-D, contiguous otherwise)."""
+    if x.dim() == 4:
+        return x if x.is_contiguous(memory_format=CL) else x.contiguous(memory_format=CL)
+    return x if x.is_contiguous() else x.contiguous()
+
+
+def _f32c(t):
+    t = t if t.dtype == torch.float32 else t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _empty_like_act(shape, ref):
+    if len(shape) == 4:
+        return torch.empty(shape, dtype=ref.dtype, device=ref.device, memory_format=CL)
+    return torch.empty(shape, dtype=ref.dtype, device=ref.device)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def _rows_cols(x):
+    """(rows, channels) of a channels-last activation: rows = n*h*w for 4-D, b for 2-D."""
+    if x.dim() == 4:
+        n, c, h, w = x.shape
+        return n * h * w, c
+    return x.shape[0], x.shape[1]
+
+
+class HipKernels(object):
+    def __init__(self):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.GansynthHipError("gansynth_amd needs a HIP device (torch.cuda.is_available() is False)")
+        _lib.check(self.lib.gs_init(), "gs_init")
+
+    # ------------------------------------------------------------------------------- conv
+    def conv2d_fwd(self, x, w, ksize, stride, alpha):
+        x, w = _act(x), _f32c(w)
+        n, ci, h, wd = x.shape
+        co = w.shape[3]
+        y = _empty_like_act((n, co, h // stride, wd // stride), x)
+        nb = self.lib.gs_conv2d_workspace_bytes(_lib.CONV_FWD, n, h, wd, ci, co, ksize, stride, _dt(x))
+        ws = _ws(nb, x.device)
+        _lib.check(self.lib.gs_conv2d_fwd(x.data_ptr(), w.data_ptr(), y.data_ptr(), n, h, wd, ci, co, ksize, stride,
+                                          float(alpha), _dt(x), ws.data_ptr(), ws.numel(), _stream()), "gs_conv2d_fwd")
+        return y
+
+    def conv2d_bwd_data(self, gy, w, x_shape, ksize, stride, alpha):
+        gy, w = _act(gy), _f32c(w)
+        n, ci, h, wd = x_shape
+        co = w.shape[3]
+        gx = _empty_like_act((n, ci, h, wd), gy)
+        nb = self.lib.gs_conv2d_workspace_bytes(_lib.CONV_BWD_DATA, n, h, wd, ci, co, ksize, stride, _dt(gy))
+        ws = _ws(nb, gy.device)
+        _lib.check(self.lib.gs_conv2d_bwd_data(gy.data_ptr(), w.data_ptr(), gx.data_ptr(), n, h, wd, ci, co, ksize, stride,
+                                               float(alpha), _dt(gy), ws.data_ptr(), ws.numel(), _stream()), "gs_conv2d_bwd_data")
+        return gx
+
+    def conv2d_bwd_weight(self, x, gy, ksize, stride, alpha):
+        x, gy = _act(x), _act(gy)
+        n, ci, h, wd = x.shape
+        co = gy.shape[1]
+        gw = torch.empty((ksize, ksize, ci, co), dtype=torch.float32, device=x.device)
+        nb = self.lib.gs_conv2d_workspace_bytes(_lib.CONV_BWD_WEIGHT, n, h, wd, ci, co, ksize, stride, _dt(x))
+        ws = _ws(nb, x.device)
+        _lib.check(self.lib.gs_conv2d_bwd_weight(x.data_ptr(), gy.data_ptr(), gw.data_ptr(), n, h, wd, ci, co, ksize, stride,
+                                                 float(alpha), _dt(x), ws.data_ptr(), ws.numel(), _stream()), "gs_conv2d_bwd_weight")
+        return gw
+
+    def conv2d_transpose_fwd(self, x, w, alpha):
+        x, w = _act(x), _f32c(w)
+        n, ci, h, wd = x.shape
+        co = w.shape[3]
+        y = _empty_like_act((n, co, 2 * h, 2 * wd), x)
+        nb = self.lib.gs_conv2d_transpose_s2_workspace_bytes(_lib.CONV_FWD, n, h, wd, ci, co, _dt(x))
+        ws = _ws(nb, x.device)
+        _lib.check(self.lib.gs_conv2d_transpose_s2_fwd(x.data_ptr(), w.data_ptr(), y.data_ptr(), n, h, wd, ci, co, float(alpha),
+                                                       _dt(x), ws.data_ptr(), ws.numel(), _stream()), "gs_conv2d_transpose_s2_fwd")
+        return y
+
+    def conv2d_transpose_bwd_data(self, gy, w, alpha):
+        gy, w = _act(gy), _f32c(w)
+        n, co, h2, w2 = gy.shape
+        ci = w.shape[2]
+        h, wd = h2 // 2, w2 // 2
+        gx = _empty_like_act((n, ci, h, wd), gy)
+        nb = self.lib.gs_conv2d_transpose_s2_workspace_bytes(_lib.CONV_BWD_DATA, n, h, wd, ci, co, _dt(gy))
+        ws = _ws(nb, gy.device)
+        _lib.check(self.lib.gs_conv2d_transpose_s2_bwd_data(gy.data_ptr(), w.data_ptr(), gx.data_ptr(), n, h, wd, ci, co, float(alpha),
+                                                            _dt(gy), ws.data_ptr(), ws.numel(), _stream()), "gs_conv2d_transpose_s2_bwd_data")
+        return gx
+
+    def conv2d_transpose_bwd_weight(self, x, gy, alpha):
+        x, gy = _act(x), _act(gy)
+        n, ci, h, wd = x.shape
+        co = gy.shape[1]
+        gw = torch.empty((3, 3, ci, co), dtype=torch.float32, device=x.device)
+        nb = self.lib.gs_conv2d_transpose_s2_workspace_bytes(_lib.CONV_BWD_WEIGHT, n, h, wd, ci, co, _dt(x))
+        ws = _ws(nb, x.device)
+        _lib.check(self.lib.gs_conv2d_transpose_s2_bwd_weight(x.data_ptr(), gy.data_ptr(), gw.data_ptr(), n, h, wd, ci, co, float(alpha),
+                                                              _dt(x), ws.data_ptr(), ws.numel(), _stream()), "gs_conv2d_transpose_s2_bwd_weight")
+        return gw
+
+    # ------------------------------------------------------------------------------ dense
+    def dense_fwd(self, x, w, alpha):
+        x, w = _act(x), _f32c(w)
+        b, i = x.shape
+        o = w.shape[1]
+        y = torch.empty((b, o), dtype=x.dtype, device=x.device)
+        ws = _ws(self.lib.gs_dense_fwd_workspace_bytes(b, i, o), x.device)
+        _lib.check(self.lib.gs_dense_fwd(x.data_ptr(), w.data_ptr(), y.data_ptr(), b, i, o, float(alpha), _dt(x),
+                                         ws.data_ptr(), ws.numel(), _stream()), "gs_dense_fwd")
+        return y
+
+    def dense_bwd_data(self, gy, w, alpha):
+        gy, w = _act(gy), _f32c(w)
+        b, o = gy.shape
+        i = w.shape[0]
+        gx = torch.empty((b, i), dtype=gy.dtype, device=gy.device)
+        _lib.check(self.lib.gs_dense_bwd_data(gy.data_ptr(), w.data_ptr(), gx.data_ptr(), b, i, o, float(alpha), _dt(gy), _stream()),
+                   "gs_dense_bwd_data")
+        return gx
+
+    def dense_bwd_weight(self, x, gy, alpha):
+        x, gy = _act(x), _act(gy)
+        b, i = x.shape
+        o = gy.shape[1]
+        gw = torch.empty((i, o), dtype=torch.float32, device=x.device)
+        _lib.check(self.lib.gs_dense_bwd_weight(x.data_ptr(), gy.data_ptr(), gw.data_ptr(), b, i, o, float(alpha), _dt(x), _stream()),
+                   "gs_dense_bwd_weight")
+        return gw
+
+    def embedding_fwd(self, idx, w, alpha, dtype):
+        w = _f32c(w)
+        idx = idx.contiguous()
+        b = idx.shape[0]
+        rows, units = w.shape
+        y = torch.empty((b, units), dtype=dtype, device=w.device)
+        _lib.check(self.lib.gs_embedding_fwd(idx.data_ptr(), w.data_ptr(), y.data_ptr(), b, rows, units, float(alpha), _dt(y), _stream()),
+                   "gs_embedding_fwd")
+        return y
+
+    def embedding_bwd(self, idx, gy, rows, alpha):
+        gy = _act(gy)
+        idx = idx.contiguous()
+        b, units = gy.shape
+        gw = torch.empty((rows, units), dtype=torch.float32, device=gy.device)
+        _lib.check(self.lib.gs_embedding_bwd(idx.data_ptr(), gy.data_ptr(), gw.data_ptr(), b, rows, units, float(alpha), _dt(gy), _stream()),
+                   "gs_embedding_bwd")
+        return gw
+
+    # ------------------------------------------------------------------ bias / activations
+    def bias_act_fwd(self, x, bias, act):
+        x = _act(x)
+        p, c = _rows_cols(x)
+        y = torch.empty_like(x)
+        bp = None
+        if bias is not None:
+            bias = _f32c(bias)
+            bp = bias.data_ptr()
+        _lib.check(self.lib.gs_bias_act_fwd(x.data_ptr(), bp, y.data_ptr(), p, c, act, _dt(x), _stream()), "gs_bias_act_fwd")
+        return y
+
+    def act_bwd(self, g, y, act):
+        y = _act(y)
+        g = _match(g, y)
+        gx = torch.empty_like(y)
+        _lib.check(self.lib.gs_act_bwd(g.data_ptr(), y.data_ptr(), gx.data_ptr(), y.numel(), act, _dt(y), _stream()), "gs_act_bwd")
+        return gx
+
+    def tanh_bwd_bwd(self, gg, g, y):
+        y = _act(y)
+        gg, g = _match(gg, y), _match(g, y)
+        out = torch.empty_like(y)
+        _lib.check(self.lib.gs_tanh_bwd_bwd(gg.data_ptr(), g.data_ptr(), y.data_ptr(), out.data_ptr(), y.numel(), _dt(y), _stream()),
+                   "gs_tanh_bwd_bwd")
+        return out
+
+    def channel_sum(self, g):
+        g = _act(g)
+        p, c = _rows_cols(g)
+        out = torch.empty((c,), dtype=torch.float32, device=g.device)
+        ws = _ws(self.lib.gs_channel_sum_workspace_bytes(p, c), g.device)
+        _lib.check(self.lib.gs_channel_sum(g.data_ptr(), out.data_ptr(), p, c, _dt(g), ws.data_ptr(), ws.numel(), _stream()), "gs_channel_sum")
+        return out
+
+    def pixel_norm_fwd(self, x, eps):
+        x = _act(x)
+        p, c = _rows_cols(x)
+        y = torch.empty_like(x)
+        _lib.check(self.lib.gs_pixel_norm_fwd(x.data_ptr(), y.data_ptr(), p, c, float(eps), _dt(x), _stream()), "gs_pixel_norm_fwd")
+        return y
+
+    def pixel_norm_bwd(self, g, x, eps):
+        x = _act(x)
+        g = _match(g, x)
+        p, c = _rows_cols(x)
+        gx = torch.empty_like(x)
+        _lib.check(self.lib.gs_pixel_norm_bwd(g.data_ptr(), x.data_ptr(), gx.data_ptr(), p, c, float(eps), _dt(x), _stream()), "gs_pixel_norm_bwd")
+        return gx
+
+    def pixel_norm_bwd_bwd(self, gg, g, x, eps):
+        x = _act(x)
+        gg, g = _match(gg, x), _match(g, x)
+        p, c = _rows_cols(x)
+        out = torch.empty_like(x)
+        _lib.check(self.lib.gs_pixel_norm_bwd_bwd(gg.data_ptr(), g.data_ptr(), x.data_ptr(), out.data_ptr(), p, c, float(eps), _dt(x), _stream()),
+                   "gs_pixel_norm_bwd_bwd")
+        return out
+
+    # --------------------------------------------------------------------- up / down scale
+    def upscale2d(self, x, fy, fx, scale):
+        x = _act(x)
+        n, c, h, w = x.shape
+        y = _empty_like_act((n, c, h * fy, w * fx), x)
+        _lib.check(self.lib.gs_upscale2d(x.data_ptr(), y.data_ptr(), n, h, w, c, fy, fx, float(scale), _dt(x), _stream()), "gs_upscale2d")
+        return y
+
+    def blocksum2d(self, x, fy, fx, scale):
+        x = _act(x)
+        n, c, h, w = x.shape
+        y = _empty_like_act((n, c, h // fy, w // fx), x)
+        _lib.check(self.lib.gs_blocksum2d(x.data_ptr(), y.data_ptr(), n, h, w, c, fy, fx, float(scale), _dt(x), _stream()), "gs_blocksum2d")
+        return y
+
+    # ------------------------------------------------------------------------ batch stddev
+    def batch_stddev_fwd(self, x, eps):
+        x = _act(x)
+        n, c, h, w = x.shape
+        y = _empty_like_act((n, 1, h, w), x)
+        _lib.check(self.lib.gs_batch_stddev_fwd(x.data_ptr(), y.data_ptr(), n, h * w, c, float(eps), _dt(x), _stream()), "gs_batch_stddev_fwd")
+        return y
+
+    def batch_stddev_bwd(self, gy, x, eps):
+        x = _act(x)
+        n, c, h, w = x.shape
+        gy = _act(gy.to(x.dtype))
+        gx = torch.empty_like(x)
+        _lib.check(self.lib.gs_batch_stddev_bwd(gy.data_ptr(), x.data_ptr(), gx.data_ptr(), n, h * w, c, float(eps), _dt(x), _stream()),
+                   "gs_batch_stddev_bwd")
+        return gx
+
+    def batch_stddev_bwd_bwd(self, ggx, gy, x, eps):
+        x = _act(x)
+        n, c, h, w = x.shape
+        ggx = _match(ggx, x)
+        gy = _act(gy.to(x.dtype))
+        ggy = torch.empty_like(gy)
+        gx2 = torch.empty_like(x)
+        _lib.check(self.lib.gs_batch_stddev_bwd_bwd(ggx.data_ptr(), gy.data_ptr(), x.data_ptr(), ggy.data_ptr(), gx2.data_ptr(),
+                                                    n, h * w, c, float(eps), _dt(x), _stream()), "gs_batch_stddev_bwd_bwd")
+        return ggy, gx2
+
+    # ------------------------------------------------------------------- misc elementwise
+    def axpby(self, a, b, ca, cb):
+        a = _act(a)
+        b = _match(b, a)
+        out = torch.empty_like(a)
+        _lib.check(self.lib.gs_axpby(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), float(ca), float(cb), _dt(a), _stream()), "gs_axpby")
+        return out
+
+    def sumsq_rows(self, x):
+        x = _act(x)
+        rows = x.shape[0]
+        out = torch.empty((rows,), dtype=torch.float32, device=x.device)
+        _lib.check(self.lib.gs_sumsq_rows(x.data_ptr(), out.data_ptr(), rows, x.numel() // rows, _dt(x), _stream()), "gs_sumsq_rows")
+        return out
+
+    def row_scale(self, x, s):
+        x = _act(x)
+        s = _f32c(s)
+        rows = x.shape[0]
+        out = torch.empty_like(x)
+        _lib.check(self.lib.gs_row_scale(x.data_ptr(), s.data_ptr(), out.data_ptr(), rows, x.numel() // rows, _dt(x), _stream()), "gs_row_scale")
+        return out
+
+    def adam_tf_step(self, p, g, m, v, lr_t, beta1, beta2, eps, grad_scale=1.0):
+        for t in (p, g, m, v):
+            assert t.dtype == torch.float32 and t.is_contiguous()
+        _lib.check(self.lib.gs_adam_tf_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), float(lr_t), float(beta1),
+                                            float(beta2), float(eps), float(grad_scale), _stream()), "gs_adam_tf_step")
+
+    # --------------------------------------------------------------------------- profiling
+    def prof_enable(self, on):
+        self.lib.gs_prof_enable(1 if on else 0)
+
+    def prof_collect(self):
+        n, ms, fl = ctypes.c_int(0), ctypes.c_double(0.0), ctypes.c_double(0.0)
+        self.lib.gs_prof_collect(ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl))
+        return n.value, ms.value, fl.value
+
+
+def _match(t, ref):
+    """Bring a gradient tensor to the dtype/layout of the activation it pairs with."""
+    if t.dtype != ref.dtype:
+        t = t.to(ref.dtype)
+    if t.shape != ref.shape:
+        t = t.expand(ref.shape)
+    return _act(t)
+
+
+_K = None
+
+
+def get():
+    """The process-wide kernel object (created on first use; raises without the library / a GPU)."""
+    global _K
+    if _K is None:
+        _K = HipKernels()
+    return _K
+
+
+def set_backend(obj):
+    """Test hook: install an object with the HipKernels interface (CPU emulation for autograd tests)."""
+    global _K
+    _K = obj

@@ -1,0 +1,204 @@
+"""GANSynth trainer step on the HIP path (reference models.py:8-108, train loop :189-194).
+
+Same constructor as the reference's GANSynth (generator / discriminator callables, input fns,
+spectral_params, hyper_params).  One iteration = a discriminator update then a generator update,
+each on its own fresh batch, exactly like the two session.run calls of models.py:191-192:
+
+  D run: L_D = mean(softplus(-r) + softplus(f) + w_r1 * sum((d sum(r) / d x_real)^2))   :39-49,65
+  G run: L_G = mean(softplus(-f) + w_ms / (sum((d sum(G(z)) / d z)^2) + 1e-6))            :57-64
+  both with tf.train.AdamOptimizer (TF form), only the G run bumps global_step            :67-89
+
+Parameters, gradients and Adam slots of each network live in one flat fp32 buffer (one fused
+Adam launch, one all-reduce payload).  Data parallelism (new -- the reference is single GPU):
+one process per GPU, gradients summed with torch.distributed all_reduce (backend "nccl" = RCCL
+over xGMI) and averaged inside the Adam kernel.
+"""
+import math
+from collections import OrderedDict
+
+import torch
+import torch.nn.functional as TF
+
+from . import functional as F
+from . import kernels
+from . import spectral_ops
+from . import variables
+
+_PAD = 64  # floats; keeps every parameter view 256-byte aligned inside the flat buffer
+
+
+class _FlatParams(object):
+    """All trainable variables of one scope re-homed into one flat fp32 buffer (+grad, m, v)."""
+
+    def __init__(self, named_params):
+        self.named = OrderedDict(named_params)
+        sizes = [p.numel() for p in self.named.values()]
+        offs, total = [], 0
+        for n in sizes:
+            offs.append(total)
+            total += (n + _PAD - 1) // _PAD * _PAD
+        dev = next(iter(self.named.values())).device
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros_like(self.flat)
+        self.m = torch.zeros_like(self.flat)
+        self.v = torch.zeros_like(self.flat)
+        self.numel = sum(sizes)
+        for (name, p), off, n in zip(self.named.items(), offs, sizes):
+            self.flat[off:off + n].copy_(p.data.reshape(-1))
+            p.data = self.flat[off:off + n].view(p.shape)
+            p.grad = self.grad[off:off + n].view(p.shape)
+        self.t = 0
+
+    def requires_grad_(self, flag):
+        for p in self.named.values():
+            p.requires_grad_(flag)
+
+    def zero_grad(self):
+        self.grad.zero_()
+        for p in self.named.values():
+            if p.grad is None or p.grad.data_ptr() < self.grad.data_ptr():
+                raise RuntimeError("parameter lost its flat gradient view")
+
+
+class GANSynth(object):
+
+    def __init__(self, generator, discriminator, real_input_fn, fake_input_fn, spectral_params, hyper_params,
+                 dtype=torch.float32, store=None, distributed=False):
+        self.generator, self.discriminator = generator, discriminator
+        self.real_input_fn, self.fake_input_fn = real_input_fn, fake_input_fn
+        self.spectral_params, self.hyper_params = spectral_params, hyper_params
+        self.dtype = dtype
+        self.store = store if store is not None else variables.default_store()
+        self.distributed = bool(distributed)
+        self.world = torch.distributed.get_world_size() if self.distributed else 1
+        self.global_step = 0
+        self.g_params = None
+        self.d_params = None
+        self.generator_loss = None
+        self.discriminator_loss = None
+
+    # ----------------------------------------------------------------------------- build
+    def _build(self, latents, labels):
+        """Create every variable (the reference's graph owns all of them from step 0), then flatten."""
+        owner = getattr(self.generator, "__self__", None)
+        with torch.no_grad():
+            if owner is not None and hasattr(owner, "_g_variables"):
+                with variables.variable_scope("generator"):
+                    owner._g_variables(latents.shape[1], labels.shape[1])
+                with variables.variable_scope("discriminator"):
+                    owner._d_variables(labels.shape[1])
+            else:
+                images = self.generator(latents, labels)
+                self.discriminator(images, labels)
+        self.g_params = _FlatParams(self.store.trainable_variables("generator"))
+        self.d_params = _FlatParams(self.store.trainable_variables("discriminator"))
+        if self.distributed:  # identical weights on every rank
+            torch.distributed.broadcast(self.g_params.flat, 0)
+            torch.distributed.broadcast(self.d_params.flat, 0)
+
+    def _ensure_built(self, latents, labels):
+        if self.g_params is None:
+            self._build(latents, labels)
+
+    # -------------------------------------------------------------------------- inputs
+    def _real_batch(self):
+        """real_input_fn() -> (waveforms [B,L] | images [B,2,T,F], labels [B,61])."""
+        data, labels = self.real_input_fn()
+        if data.dim() == 2:  # waveforms: models.py:27-28
+            images = spectral_ops.convert_to_images(data, **self.spectral_params, dtype=self.dtype)
+        else:
+            images = data
+        return images.to(self.dtype), labels.to(self.dtype)
+
+    # --------------------------------------------------------------------------- losses
+    @staticmethod
+    def _label_logits(logits, labels):
+        """tf.gather_nd(logits, tf.where(labels)) for one-hot labels (models.py:39-40)."""
+        return (logits.float() * labels.float()).sum(dim=1)
+
+    def discriminator_losses(self, latents, labels, real_images):
+        hp = self.hyper_params
+        with torch.no_grad():  # var_list is the discriminator's only: no generator backward (models.py:86-89)
+            fake_images = self.generator(latents, labels)
+        real_images = real_images.detach().requires_grad_(True)
+        _, real_logits = self.discriminator(real_images, labels)
+        _, fake_logits = self.discriminator(fake_images, labels)
+        real_logits = self._label_logits(real_logits, labels)
+        fake_logits = self._label_logits(fake_logits, labels)
+        losses = TF.softplus(-real_logits) + TF.softplus(fake_logits)
+        if hp.real_gradient_penalty_weight:
+            (real_gradients,) = torch.autograd.grad(real_logits.sum(), real_images, create_graph=True)
+            losses = losses + F.sumsq_rows(real_gradients) * hp.real_gradient_penalty_weight
+        if hp.get("fake_gradient_penalty_weight", 0.0):
+            raise NotImplementedError("fake_gradient_penalty_weight is 0 in the reference configuration (gan_synth_main.py:87)")
+        return losses
+
+    def generator_losses(self, latents, labels):
+        hp = self.hyper_params
+        latents = latents.detach().requires_grad_(True)
+        fake_images = self.generator(latents, labels)
+        _, fake_logits = self.discriminator(fake_images, labels)
+        fake_logits = self._label_logits(fake_logits, labels)
+        losses = TF.softplus(-fake_logits)
+        if hp.mode_seeking_loss_weight:
+            ones = torch.ones_like(fake_images)  # tf.gradients(ys) sums ys
+            (latent_gradients,) = torch.autograd.grad(fake_images, latents, grad_outputs=ones, create_graph=True)
+            mode_seeking = 1.0 / (latent_gradients.float().pow(2).sum(dim=1) + 1.0e-6)
+            losses = losses + mode_seeking * hp.mode_seeking_loss_weight
+        return losses
+
+    # ------------------------------------------------------------------------- updates
+    def _apply(self, params, lr, beta1, beta2):
+        if self.distributed:
+            torch.distributed.all_reduce(params.grad)
+        params.t += 1
+        lr_t = lr * math.sqrt(1.0 - beta2 ** params.t) / (1.0 - beta1 ** params.t)
+        kernels.get().adam_tf_step(params.flat, params.grad, params.m, params.v, lr_t, beta1, beta2, 1.0e-8,
+                                   1.0 / self.world)
+
+    def discriminator_step(self, latents, labels, real_images):
+        self._ensure_built(latents, labels)
+        hp = self.hyper_params
+        self.g_params.requires_grad_(False)
+        self.d_params.requires_grad_(True)
+        self.d_params.zero_grad()
+        loss = self.discriminator_losses(latents, labels, real_images).mean()
+        loss.backward()
+        self._apply(self.d_params, hp.discriminator_learning_rate, hp.discriminator_beta1, hp.discriminator_beta2)
+        self.discriminator_loss = loss.detach()
+        return self.discriminator_loss
+
+    def generator_step(self, latents, labels):
+        self._ensure_built(latents, labels)
+        hp = self.hyper_params
+        self.g_params.requires_grad_(True)
+        self.d_params.requires_grad_(False)
+        self.g_params.zero_grad()
+        loss = self.generator_losses(latents, labels).mean()
+        loss.backward()
+        self._apply(self.g_params, hp.generator_learning_rate, hp.generator_beta1, hp.generator_beta2)
+        self.global_step += 1  # models.py:84
+        self.generator_loss = loss.detach()
+        return self.generator_loss
+
+    def train_step(self):
+        """models.py:191-192: one discriminator run then one generator run, fresh inputs for each."""
+        real_images, labels = self._real_batch()
+        d_loss = self.discriminator_step(self.fake_input_fn().to(self.dtype), labels, real_images)
+        _, labels = self._real_batch()
+        g_loss = self.generator_step(self.fake_input_fn().to(self.dtype), labels)
+        return d_loss, g_loss
+
+    def train(self, total_steps, log_tensor_steps=100, log=print):
+        """models.py:110-194 without the TF hooks: loop until global_step reaches total_steps."""
+        while self.global_step < total_steps:
+            d_loss, g_loss = self.train_step()
+            if log is not None and self.global_step % log_tensor_steps == 0:
+                log(f"global_step = {self.global_step}, generator_loss = {float(g_loss):.6f}, "
+                    f"discriminator_loss = {float(d_loss):.6f}")
+
+    def generate(self, latents, labels):
+        """models.py:232-250: fake waveforms for a batch."""
+        with torch.no_grad():
+            images = self.generator(latents.to(self.dtype), labels.to(self.dtype))
+        return spectral_ops.convert_images_to_waveform(images, **self.spectral_params)

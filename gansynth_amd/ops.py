@@ -1,0 +1,124 @@
+"""The reference's ops.py call surface on HIP kernels.
+
+Function names, keyword arguments and defaults follow reference ops.py:149-348 (dense,
+embedding, conv2d, conv2d_transpose, upscale2d, downscale2d, pixel_normalization,
+batch_stddev, get_weight, get_bias); tensors are eager torch tensors of logical shape NCHW
+(physically channels-last) instead of graph tensors, parameters live in variables.VariableStore
+under the reference's scope names.  Two documented extensions keep the HBM traffic down:
+  * get_weight returns (variable, runtime_scale): the equalized-LR multiply of ops.py:154-160 is
+    folded into the consuming kernel as `alpha` instead of materialising weight*scale;
+  * conv2d / conv2d_transpose / dense take `activation=None|"leaky_relu"|"tanh"`, fusing the
+    tf.nn.leaky_relu / tf.nn.tanh the reference applies right after them (networks.py:55,66,80,
+    91,106,184,194,216,227,241) into the bias pass.  With the default None they behave exactly
+    like the reference functions.
+"""
+import numpy as np
+import torch
+
+from . import functional as F
+from . import variables
+from ._lib import ACT_LRELU, ACT_NONE, ACT_TANH
+
+_ACT = {None: ACT_NONE, "leaky_relu": ACT_LRELU, "tanh": ACT_TANH}
+
+
+def get_weight(shape, variance_scale=2.0, scale_weight=False):
+    """ops.py:149-171.  Returns (variable, alpha): alpha = sqrt(variance_scale / prod(shape[:-1]))
+    when scale_weight (variable ~ truncN(0,1)), else 1 (variable ~ truncN(0, stddev))."""
+    stddev = float(np.sqrt(variance_scale / np.prod(shape[:-1])))
+    store = variables.default_store()
+    if scale_weight:
+        return store.get_variable("weight", shape, variables.truncated_normal(0.0, 1.0)), stddev
+    return store.get_variable("weight", shape, variables.truncated_normal(0.0, stddev)), 1.0
+
+
+def get_bias(shape):
+    """ops.py:174-180."""
+    return variables.default_store().get_variable("bias", shape, variables.zeros())
+
+
+def dense(inputs, units, use_bias=True, variance_scale=2.0, scale_weight=False, activation=None):
+    """ops.py:183-201."""
+    weight, alpha = get_weight([inputs.shape[1], units], variance_scale, scale_weight)
+    outputs = F.dense(inputs, weight, alpha)
+    bias = get_bias([units]) if use_bias else None
+    if bias is not None or activation is not None:
+        outputs = F.bias_act(outputs, bias, _ACT[activation])
+    return outputs
+
+
+def embedding(inputs, units, variance_scale=2.0, scale_weight=False):
+    """ops.py:204-218: row gather by argmax of the (one-hot) inputs."""
+    weight, alpha = get_weight([inputs.shape[1], units], variance_scale, scale_weight)
+    return F.embedding(torch.argmax(inputs, dim=1), weight, alpha, inputs.dtype)
+
+
+def conv2d(inputs, filters, kernel_size, strides=[1, 1], use_bias=True, variance_scale=2.0, scale_weight=False,
+           activation=None):
+    """ops.py:221-247 (NCHW, SAME)."""
+    kernel_size, strides = list(kernel_size), list(strides)
+    if kernel_size[0] != kernel_size[1] or strides[0] != strides[1]:
+        raise ValueError("conv2d: only square kernels / isotropic strides are on the hot path")
+    weight, alpha = get_weight([*kernel_size, inputs.shape[1], filters], variance_scale, scale_weight)
+    outputs = F.conv2d(inputs, weight, kernel_size[0], strides[0], alpha)
+    bias = get_bias([filters]) if use_bias else None
+    if bias is not None or activation is not None:
+        outputs = F.bias_act(outputs, bias, _ACT[activation])
+    return outputs
+
+
+def conv2d_transpose(inputs, filters, kernel_size, strides=[1, 1], use_bias=True, variance_scale=2.0, scale_weight=False,
+                     activation=None):
+    """ops.py:250-280 (NCHW, SAME, output = input * strides); 3x3 / stride 2 is the hot-path case."""
+    if list(kernel_size) != [3, 3] or list(strides) != [2, 2]:
+        raise ValueError("conv2d_transpose: the hot path is kernel 3x3, strides 2x2 (networks.py:71-79)")
+    weight, alpha = get_weight([*kernel_size, inputs.shape[1], filters], variance_scale, scale_weight)
+    outputs = F.conv2d_transpose(inputs, weight, alpha)
+    bias = get_bias([filters]) if use_bias else None
+    if bias is not None or activation is not None:
+        outputs = F.bias_act(outputs, bias, _ACT[activation])
+    return outputs
+
+
+def upscale2d(inputs, factors=[2, 2]):
+    """ops.py:283-291."""
+    factors = np.asanyarray(factors)
+    if (factors == 1).all():
+        return inputs
+    return F.upscale(inputs, int(factors[0]), int(factors[1]))
+
+
+def downscale2d(inputs, factors=[2, 2]):
+    """ops.py:294-305."""
+    factors = np.asanyarray(factors)
+    if (factors == 1).all():
+        return inputs
+    return F.avg_pool(inputs, int(factors[0]), int(factors[1]))
+
+
+def pixel_normalization(inputs, epsilon=1.0e-12):
+    """ops.py:330-333 (axis 1, also for the 2-D latent)."""
+    return F.pixel_norm(inputs, epsilon)
+
+
+def batch_stddev(inputs, groups=4, epsilon=1.0e-12):
+    """ops.py:336-348."""
+    if groups != 4:
+        raise ValueError("batch_stddev: the reference graph uses groups=4 (networks.py:174)")
+    if inputs.shape[0] % groups:
+        raise ValueError(f"batch_stddev: batch {inputs.shape[0]} is not a multiple of groups={groups} (ops.py:341)")
+    return F.batch_stddev(inputs, epsilon)
+
+
+def leaky_relu(inputs):
+    """tf.nn.leaky_relu (alpha 0.2)."""
+    return F.bias_act(inputs, None, ACT_LRELU)
+
+
+def tanh(inputs):
+    return F.bias_act(inputs, None, ACT_TANH)
+
+
+def lerp(a, b, t):
+    """networks.py:10-11."""
+    return F.axpby(a, b, float(t), 1.0 - float(t))

@@ -1,0 +1,172 @@
+/* libgansynth_hip.so -- C ABI of the MI355X (gfx950) GANSynth hot path.
+ *
+ * The reference (skmhrk1209/GANSynth) has no FFI layer: its boundary is the Python call
+ * surface of ops.py / networks.py / spectral_ops.py / models.py, whose arithmetic runs inside
+ * TensorFlow kernels.  Each entry point below replaces the TF kernel(s) behind one of those
+ * reference call sites (cited as file:line relative to the reference tree); the Python host in
+ * gansynth_amd/ re-exposes the reference's own function names on top of them.
+ *
+ * Conventions
+ *  - every function returns 0 on success, a negative GS_ERR_* code otherwise;
+ *    gs_last_error() returns a thread-local message for the last failure;
+ *  - all pointers are DEVICE pointers owned by the caller (torch); the library never allocates,
+ *    frees or synchronises on the hot path and is hipGraph-capture safe; scratch space is passed
+ *    in as `ws` and sized by the matching *_workspace_bytes query;
+ *  - activations are channels-last: a logical NCHW tensor [n,c,h,w] is stored [n][h][w][c]
+ *    ("NHWC"); 2-D tensors are [rows][cols] row-major.  `dtype` is the storage type of
+ *    activations (GS_F32 or GS_BF16); accumulation is always fp32;
+ *  - parameters (weights, biases), their gradients and optimizer state are always fp32 in the
+ *    reference's own layouts: conv HWIO [kh][kw][Cin][Cout], dense [in][out];
+ *  - `alpha` is the equalized-learning-rate runtime scale sqrt(variance_scale / fan_in) of
+ *    ops.py:154-160, applied inside the kernel;
+ *  - `stream` is a hipStream_t passed as void*.
+ */
+#ifndef GANSYNTH_HIP_H
+#define GANSYNTH_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { GS_F32 = 0, GS_BF16 = 1 };
+enum { GS_OK = 0, GS_ERR_ARG = -1, GS_ERR_HIP = -2, GS_ERR_UNSUPPORTED = -3, GS_ERR_WORKSPACE = -4 };
+enum { GS_ACT_NONE = 0, GS_ACT_LRELU = 1, GS_ACT_TANH = 2 };
+/* which of the three bilinear conv maps a workspace query is for */
+enum { GS_CONV_FWD = 0, GS_CONV_BWD_DATA = 1, GS_CONV_BWD_WEIGHT = 2 };
+
+const char* gs_last_error(void);
+int gs_version(void);
+/* number of CUs etc. are queried lazily; this forces it (and checks the device is gfx950) */
+int gs_init(void);
+
+/* ---------------------------------------------------------------- profiling hooks (bench.py)
+ * When enabled, every launch of the MFMA implicit-GEMM conv kernels is bracketed by a pair of
+ * HIP events on its own stream.  gs_prof_collect synchronises those events and returns the number
+ * of launches, their summed duration (ms) and summed algorithmic FLOPs. */
+int gs_prof_enable(int on);
+int gs_prof_collect(int* launches, double* total_ms, double* total_flops);
+
+/* ------------------------------------------------------------------------------- conv2d
+ * tf.nn.conv2d NCHW/HWIO padding=SAME (ops.py:237-243) with ksize in {1,3}, stride in {1,2}
+ * (stride 2 only with ksize 3; TF SAME on an even input pads 0 before / 1 after).
+ *   x [n][h][w][ci]  w [k][k][ci][co] fp32  y [n][h/stride][w/stride][co]
+ *   y = alpha * conv(x, w)                       (bias / activation are separate entry points)
+ * The three maps are closed under differentiation (each one's gradient is another one), which is
+ * how the Python host gets the second-order terms of models.py:47,60.
+ *   bwd_data  : gx[n][h][w][ci] = alpha * d<gy, conv(x,w)>/dx
+ *   bwd_weight: gw[k][k][ci][co] = alpha * d<gy, conv(x,w)>/dw   (fp32 out)
+ * (n,h,w) are always the dims of x (the conv INPUT side), for all three. */
+size_t gs_conv2d_workspace_bytes(int which, int n, int h, int w, int ci, int co, int ksize, int stride, int dtype);
+int gs_conv2d_fwd(const void* x, const float* w_hwio, void* y, int n, int h, int w, int ci, int co,
+                  int ksize, int stride, float alpha, int dtype, void* ws, size_t ws_bytes, void* stream);
+int gs_conv2d_bwd_data(const void* gy, const float* w_hwio, void* gx, int n, int h, int w, int ci, int co,
+                       int ksize, int stride, float alpha, int dtype, void* ws, size_t ws_bytes, void* stream);
+int gs_conv2d_bwd_weight(const void* x, const void* gy, float* gw_hwio, int n, int h, int w, int ci, int co,
+                         int ksize, int stride, float alpha, int dtype, void* ws, size_t ws_bytes, void* stream);
+
+/* tf.nn.conv2d_transpose NCHW, 3x3, stride 2, SAME, output = 2h x 2w (ops.py:266-276): the
+ * gradient-of-conv definition out[2i+k] += x[i] * w[k][ci][co], cropped at the end.
+ *   x [n][h][w][ci]  w [3][3][ci][co] fp32 (the STORED variable of ops.py:259-265)  y [n][2h][2w][co]
+ * These are thin re-labelings of the stride-2 conv2d maps above (same kernels):
+ *   transpose_fwd(x,w)        = conv2d_bwd_data (gy:=x, w^T)     with conv input side = y
+ *   transpose_bwd_data(gy,w)  = conv2d_fwd      (x:=gy, w^T)
+ *   transpose_bwd_weight(x,gy)= conv2d_bwd_weight(x:=gy, gy:=x)^T
+ * (n,h,w) are the dims of x (the LOW resolution side). */
+size_t gs_conv2d_transpose_s2_workspace_bytes(int which, int n, int h, int w, int ci, int co, int dtype);
+int gs_conv2d_transpose_s2_fwd(const void* x, const float* w_hwio, void* y, int n, int h, int w, int ci, int co,
+                               float alpha, int dtype, void* ws, size_t ws_bytes, void* stream);
+int gs_conv2d_transpose_s2_bwd_data(const void* gy, const float* w_hwio, void* gx, int n, int h, int w, int ci, int co,
+                                    float alpha, int dtype, void* ws, size_t ws_bytes, void* stream);
+int gs_conv2d_transpose_s2_bwd_weight(const void* x, const void* gy, float* gw_hwio, int n, int h, int w, int ci, int co,
+                                      float alpha, int dtype, void* ws, size_t ws_bytes, void* stream);
+
+/* -------------------------------------------------------------------------------- dense
+ * tf.matmul (ops.py:197): y[b][out] = alpha * x[b][in] @ w[in][out] (split-K partials live in ws).
+ * bwd_data: gx = alpha * gy @ w^T ; bwd_weight: gw = alpha * x^T @ gy (fp32). */
+size_t gs_dense_fwd_workspace_bytes(int b, int in, int out);
+int gs_dense_fwd(const void* x, const float* w, void* y, int b, int in, int out, float alpha, int dtype,
+                 void* ws, size_t ws_bytes, void* stream);
+int gs_dense_bwd_data(const void* gy, const float* w, void* gx, int b, int in, int out, float alpha, int dtype, void* stream);
+int gs_dense_bwd_weight(const void* x, const void* gy, float* gw, int b, int in, int out, float alpha, int dtype, void* stream);
+
+/* tf.nn.embedding_lookup(w*alpha, argmax(labels,1)) (ops.py:217): idx[b] are the argmax indices.
+ * fwd: y[b][units] = alpha * w[idx[b]][:]  ; bwd: gw[rows][units] = alpha * scatter_add(gy) (gw zero-filled here). */
+int gs_embedding_fwd(const int64_t* idx, const float* w, void* y, int b, int rows, int units, float alpha, int dtype, void* stream);
+int gs_embedding_bwd(const int64_t* idx, const void* gy, float* gw, int b, int rows, int units, float alpha, int dtype, void* stream);
+
+/* ----------------------------------------------------- bias / activations (channels-last)
+ * tf.nn.bias_add + tf.nn.leaky_relu(alpha=0.2) / tf.nn.tanh (ops.py:244-246, networks.py:55,66,106 ...).
+ *   y[p][c] = act(x[p][c] + bias[c])        (bias may be NULL)
+ *   act_bwd : gx = g * act'(.) expressed through the activation OUTPUT y
+ *   tanh_bwd_bwd: second-order term d/dy [g*(1-y^2)] . gg = -2*y*g*gg  (lrelu has none)
+ *   channel_sum: out[c] = sum_p g[p][c] (bias gradient, fp32 out) */
+int gs_bias_act_fwd(const void* x, const float* bias, void* y, int64_t p, int c, int act, int dtype, void* stream);
+int gs_act_bwd(const void* g, const void* y, void* gx, int64_t numel, int act, int dtype, void* stream);
+int gs_tanh_bwd_bwd(const void* gg, const void* g, const void* y, void* out, int64_t numel, int dtype, void* stream);
+size_t gs_channel_sum_workspace_bytes(int64_t p, int c);
+int gs_channel_sum(const void* g, float* out, int64_t p, int c, int dtype, void* ws, size_t ws_bytes, void* stream);
+
+/* pixel_normalization (ops.py:330-333): y = x / sqrt(mean_c(x^2) + eps), per row p over c.
+ *   bwd      : gx = r*(g - y*mean_c(y*g)),  r = rsqrt(mean_c(x^2)+eps)
+ *   bwd_bwd_x: d<gg, bwd(g,x)>/dx = (r^2/C) * (-(gg.g) y - (y.g) gg - (y.gg) g + 3 (y.gg)(y.g) y / C)
+ *   (d<gg, bwd(g,x)>/dg = bwd(gg, x): the Jacobian is symmetric) */
+int gs_pixel_norm_fwd(const void* x, void* y, int64_t p, int c, float eps, int dtype, void* stream);
+int gs_pixel_norm_bwd(const void* g, const void* x, void* gx, int64_t p, int c, float eps, int dtype, void* stream);
+int gs_pixel_norm_bwd_bwd(const void* gg, const void* g, const void* x, void* out, int64_t p, int c, float eps, int dtype, void* stream);
+
+/* upscale2d / downscale2d (ops.py:283-305).
+ *   upscale : y[n][h*fy][w*fx][c] = x[n][h][w][c]                       (bit-exact copy)
+ *   blocksum: y[n][h/fy][w/fx][c] = scale * sum_{fy x fx block} x        (scale = 1/(fy*fx) is avg_pool;
+ *             scale = 1 is the adjoint of upscale) */
+int gs_upscale2d(const void* x, void* y, int n, int h, int w, int c, int fy, int fx, float scale, int dtype, void* stream);
+int gs_blocksum2d(const void* x, void* y, int n, int h, int w, int c, int fy, int fx, float scale, int dtype, void* stream);
+
+/* batch_stddev (ops.py:336-348), groups = 4: x [b][h][w][c] -> y [b][h][w][1], b % 4 == 0.
+ *   bwd: gx from gy ; bwd_bwd: (ggy, gx2) = gradients of <ggx, bwd(gy, x)> w.r.t. gy and x. */
+int gs_batch_stddev_fwd(const void* x, void* y, int b, int hw, int c, float eps, int dtype, void* stream);
+int gs_batch_stddev_bwd(const void* gy, const void* x, void* gx, int b, int hw, int c, float eps, int dtype, void* stream);
+int gs_batch_stddev_bwd_bwd(const void* ggx, const void* gy, const void* x, void* ggy, void* gx2,
+                            int b, int hw, int c, float eps, int dtype, void* stream);
+
+/* lerp (networks.py:10-11) and generic fused axpby: out = ca*a + cb*b. */
+int gs_axpby(const void* a, const void* b, void* out, int64_t numel, float ca, float cb, int dtype, void* stream);
+
+/* per-sample sum of squares (the R1 penalty reduction, models.py:48): out[r] = sum_j x[r][j]^2 (fp32 out);
+ * row_scale: out[r][j] = s[r] * x[r][j]  (its gradient, s fp32). */
+int gs_sumsq_rows(const void* x, float* out, int rows, int64_t cols, int dtype, void* stream);
+int gs_row_scale(const void* x, const float* s, void* out, int rows, int64_t cols, int dtype, void* stream);
+
+/* tf.train.AdamOptimizer step (models.py:67-89), TF form, fused over one flat fp32 buffer:
+ *   m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g*g ; p -= lr_t * m / (sqrt(v) + eps),
+ *   lr_t = lr*sqrt(1-b2^t)/(1-b1^t) computed by the caller; grad_scale multiplies g first (1/world). */
+int gs_adam_tf_step(float* p, const float* g, float* m, float* v, int64_t numel, float lr_t, float beta1,
+                    float beta2, float eps, float grad_scale, void* stream);
+
+/* ------------------------------------------------------------------------------ spectral
+ * spectral_ops.py:45-94.  Plan = immutable per-device tables (Hann window, twiddles, CSR mel matrix
+ * supplied by the caller as built by linear_to_mel_weight_matrix, dense pinv for the inverse). */
+typedef struct gs_spectral_plan gs_spectral_plan;
+int gs_spectral_plan_create(gs_spectral_plan** plan, int frame_length, int frame_step, int time_steps,
+                            const float* mel_dense /* host [nbins][nbins] */, const float* mel_pinv /* host, may be NULL */);
+int gs_spectral_plan_destroy(gs_spectral_plan* plan);
+/* stage-wise entry points (parity tests) */
+int gs_stft_fwd(const gs_spectral_plan* plan, const float* wave, int batch, int wave_len, int front_pad,
+                float* magnitude, float* phase, void* stream);           /* [b][T][nbins] each, DC dropped */
+int gs_mel_project(const gs_spectral_plan* plan, const float* in, float* out, int64_t rows, void* stream);
+int gs_if_unwrap(const gs_spectral_plan* plan, const float* mel_phase, float* mel_if, int batch, void* stream);
+/* fused: waveform -> (log-mel, IF) written as one channels-last image [b][T][nbins][2] */
+int gs_stft_mel_if_fwd(const gs_spectral_plan* plan, const float* wave, int batch, int wave_len, int front_pad,
+                       void* images, int dtype, void* ws, size_t ws_bytes, void* stream);
+size_t gs_stft_mel_if_workspace_bytes(const gs_spectral_plan* plan, int batch);
+/* inverse (spectral_ops.py:97-149): images [b][T][nbins][2] -> wave [b][wave_len] */
+int gs_mel_if_to_waveform(const gs_spectral_plan* plan, const void* images, int batch, int wave_len, int front_pad,
+                          float* wave, int dtype, void* ws, size_t ws_bytes, void* stream);
+size_t gs_mel_if_to_waveform_workspace_bytes(const gs_spectral_plan* plan, int batch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GANSYNTH_HIP_H */
