@@ -1,0 +1,162 @@
+"""Headline benchmark: G+D training step images/sec at 128x1024x2 (log-mel + IF), fully grown.
+
+    python bench.py --gpus N --steps K --warmup W            (N=1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W     (N>1, one rank per GPU, RCCL)
+
+One step = one reference iteration (models.py:191-192): a discriminator update then a generator
+update, each on its own synthetic batch of `--batch` (default 8) examples per GPU, inputs already
+resident in HBM.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOPS_PER_IMAGE = 268.1e9  # 7*F_G + 11*F_D, SURVEY.md 8(d)
+PEAK = {"f32": 157.3, "bf16": 2500.0}  # dense MFMA TFLOP/s, MI355X_MICROARCH.md
+
+
+def synthetic_pool(batch, rank, dtype, n=4):
+    """SURVEY.md 8(d) synthetic inputs, generated once and kept in HBM."""
+    pool = []
+    for i in range(n):
+        g = torch.Generator().manual_seed(1000 + rank + 97 * i)
+        lat = torch.randn(batch, 256, generator=g)
+        g = torch.Generator().manual_seed(2000 + rank + 97 * i)
+        lab = torch.nn.functional.one_hot(torch.randint(0, 61, (batch,), generator=g), 61).float()
+        g = torch.Generator().manual_seed(3000 + rank + 97 * i)
+        real = torch.randn(batch, 2, 128, 1024, generator=g)
+        real[:, 0] = real[:, 0] * 0.6 - 0.2
+        real[:, 1] = real[:, 1] * 0.4
+        real = real.clamp_(-1, 1)
+        pool.append((lat.cuda().to(dtype), lab.cuda().to(dtype),
+                     real.cuda().to(dtype).contiguous(memory_format=torch.channels_last)))
+    return pool
+
+
+def cpu_baseline():
+    """The CPU oracle (torch-CPU fp32 restatement of the reference graph) timed on this host's cores,
+    on a bounded sample: ONE iteration (D update + G update) at batch 4, fully grown 128x1024."""
+    from oracle import torch_ref as R
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    pg = R.PGGAN([2, 16], [128, 1024], 32, 256, 1.0)
+    gp, dp = pg.init_params(seed=0)
+    tr = R.Trainer(pg, gp, dp)
+    lat, lab, real = R.synthetic_batch(4)
+    t0 = time.time()
+    tr.d_step(lat, lab, real)
+    tr.g_step(lat, lab)
+    dt = time.time() - t0
+    return {"value": 4.0 / dt, "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": "1 iteration (D update + G update incl. R1 + mode-seeking double-backward, TF-Adam) at batch 4, "
+                      "fully grown 128x1024x2, fp32, torch-CPU oracle (oracle/torch_ref.py)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=8, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default=os.environ.get("GS_BENCH_DTYPE", "f32"))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+
+    from gansynth_amd import kernels, variables
+    from gansynth_amd.models import GANSynth
+    from gansynth_amd.networks import PGGAN
+    from gansynth_amd.utils import Dict
+
+    dtype = torch.float32 if args.dtype == "f32" else torch.bfloat16
+    variables.set_default_store(variables.VariableStore(device="cuda", seed=0))
+    pggan = PGGAN(min_resolution=[2, 16], max_resolution=[128, 1024], min_channels=32, max_channels=256, growing_level=1.0)
+    global_batch = args.batch * world
+    hyper = Dict(generator_learning_rate=8e-4 * global_batch / 8, generator_beta1=0.0, generator_beta2=0.99,
+                 discriminator_learning_rate=8e-4 * global_batch / 8, discriminator_beta1=0.0, discriminator_beta2=0.99,
+                 mode_seeking_loss_weight=0.1, real_gradient_penalty_weight=5.0, fake_gradient_penalty_weight=0.0)
+    pool = synthetic_pool(args.batch, rank, dtype)
+    cursor = [0]
+
+    def real_input_fn():
+        lat, lab, real = pool[cursor[0] % len(pool)]
+        return real, lab
+
+    def fake_input_fn():
+        lat, _, _ = pool[cursor[0] % len(pool)]
+        cursor[0] += 1
+        return lat
+
+    model = GANSynth(pggan.generator, pggan.discriminator, real_input_fn, fake_input_fn, None, hyper, dtype=dtype,
+                     distributed=distributed)
+    K = kernels.get()
+
+    def barrier():
+        if distributed:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        model.train_step()
+    barrier()
+    K.prof_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        d_loss, g_loss = model.train_step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    launches, conv_ms, conv_flops = K.prof_collect()
+    K.prof_enable(False)
+    if distributed:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if not (torch.isfinite(d_loss) and torch.isfinite(g_loss)):
+        raise SystemExit(f"non-finite losses: {float(d_loss)} {float(g_loss)}")
+
+    if rank == 0:
+        value = global_batch * args.steps / elapsed
+        achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        out = {
+            "metric": "G+D step images/sec at 128x1024x2 mel+IF",
+            "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1]: fully grown PGGAN 128x1024x2 G+D iteration (D update + G update, "
+                                   "R1 + mode-seeking), per-GPU batch %d, random-init weights" % args.batch,
+                       "global_batch": global_batch, "parallelism": "dp%d" % world},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK[args.dtype], "unit": "TFLOP/s",
+                         "frac": achieved / PEAK[args.dtype], "traffic": None,
+                         "kernel": "conv_igemm_kernel + conv_wgrad_kernel (MFMA 3x3 conv family)",
+                         "launches": launches, "avg_launch_ms": conv_ms / max(launches, 1),
+                         "time_share": conv_ms / (elapsed * 1e3)},
+            "model_flops_utilization": value * FLOPS_PER_IMAGE / 1e12 / PEAK[args.dtype] / world,
+            "losses": {"discriminator": float(d_loss), "generator": float(g_loss)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if distributed:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,207 @@
+"""GPU: every HIP entry point (called through the C ABI via gansynth_amd.kernels) against an
+independent torch-CPU computation of the same primitive (tests/cpu_kernels.py, which is built on the
+oracle's restatements).  Tolerance: 1e-3 relative (BASELINE.json north_star) on the tensor scale;
+index/copy ops are bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def K():
+    from gansynth_amd import kernels
+    return kernels.HipKernels()
+
+
+@pytest.fixture(scope="module")
+def E():
+    from tests.cpu_kernels import CpuEmuKernels
+    return CpuEmuKernels()
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def dev(t, dtype=torch.float32):
+    t = t.to("cuda", dtype)
+    return t.contiguous(memory_format=torch.channels_last) if t.dim() == 4 else t
+
+
+def close(got, ref, rel=1e-3, name=""):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float()
+    assert got.shape == ref.shape, f"{name}: shape {tuple(got.shape)} vs {tuple(ref.shape)}"
+    scale = float(ref.abs().max()) + 1e-30
+    err = float((got - ref).abs().max()) / scale
+    assert err <= rel, f"{name}: max err / max|ref| = {err:.3e} > {rel:.1e}"
+
+
+# (n, ci, co, h, w, ksize, stride) -- covers every MFMA tile configuration + the direct kernels
+CONV_CASES = [
+    (2, 32, 32, 8, 128, 3, 1),    # S1 A1 B2 TW64 TG9 (top-level shape class)
+    (2, 32, 32, 4, 32, 3, 1),     # S1 A1 B1 TW32
+    (1, 64, 64, 8, 64, 3, 1),     # S1 A2 B2 TW64
+    (2, 64, 64, 4, 32, 3, 1),     # S1 A2 B1 TW32
+    (4, 64, 64, 2, 16, 3, 1),     # S1 A2 B1 TW16 (tile taller than the image)
+    (1, 128, 128, 8, 32, 3, 1),   # S1 A4 B1 TW32
+    (4, 256, 256, 2, 16, 3, 1),   # S1 A4 B1 TW16, two oc tiles (the 2x16 stage)
+    (2, 64, 32, 6, 40, 3, 1),     # ragged spatial tile edges, ci != co
+    (2, 32, 64, 8, 128, 3, 2),    # S2 A2 B1 TW32  (D downscale 32->64)
+    (2, 64, 128, 8, 64, 3, 2),    # S2 A4 B1 TW32
+    (4, 256, 256, 4, 32, 3, 2),   # S2 A4 TW16 (4x32 -> 2x16)
+    (2, 64, 32, 8, 64, 3, 2),     # S2 A1 (oc 32); its bwd-data is T2 with 64 outputs
+    (2, 32, 32, 12, 72, 3, 2),    # ragged stride-2
+    (2, 32, 2, 8, 64, 1, 1),      # G colour block 32->2 (direct)
+    (2, 2, 32, 8, 64, 1, 1),      # D colour block 2->32 (direct)
+    (4, 1, 16, 2, 16, 3, 1),      # minibatch-stddev plane (direct, ci=1)
+    (2, 16, 2, 4, 32, 1, 1),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_three_maps(K, E, case):
+    n, ci, co, h, w, ks, st = case
+    x = rnd(n, ci, h, w, seed=1)
+    wt = rnd(ks, ks, ci, co, seed=2)
+    alpha = float(np.sqrt(2.0 / (ks * ks * ci)))
+    y_ref = E.conv2d_fwd(x, wt, ks, st, alpha)
+    close(K.conv2d_fwd(dev(x), dev(wt), ks, st, alpha), y_ref, name="fwd")
+    gy = rnd(*y_ref.shape, seed=3)
+    close(K.conv2d_bwd_data(dev(gy), dev(wt), x.shape, ks, st, alpha), E.conv2d_bwd_data(gy, wt, x.shape, ks, st, alpha), name="bwd_data")
+    close(K.conv2d_bwd_weight(dev(x), dev(gy), ks, st, alpha), E.conv2d_bwd_weight(x, gy, ks, st, alpha), name="bwd_weight")
+
+
+CONVT_CASES = [
+    (2, 64, 32, 8, 64),    # T2 A1 B2 TW64 (top level 64->32)
+    (2, 64, 32, 4, 32),    # T2 A1 B1 TW32
+    (1, 128, 64, 8, 32),   # T2 A2 B1 TW32
+    (4, 256, 256, 2, 16),  # T2 A2 B1 TW16, 4 oc tiles (2x16 -> 4x32)
+    (2, 32, 64, 5, 24),    # ragged, ci < co
+]
+
+
+@pytest.mark.parametrize("case", CONVT_CASES)
+def test_conv2d_transpose_three_maps(K, E, case):
+    n, ci, co, h, w = case
+    x = rnd(n, ci, h, w, seed=4)
+    wt = rnd(3, 3, ci, co, seed=5)
+    alpha = float(np.sqrt(2.0 / (9 * ci)))
+    y_ref = E.conv2d_transpose_fwd(x, wt, alpha)
+    assert y_ref.shape == (n, co, 2 * h, 2 * w)
+    close(K.conv2d_transpose_fwd(dev(x), dev(wt), alpha), y_ref, name="fwd")
+    gy = rnd(*y_ref.shape, seed=6)
+    close(K.conv2d_transpose_bwd_data(dev(gy), dev(wt), alpha), E.conv2d_transpose_bwd_data(gy, wt, alpha), name="bwd_data")
+    close(K.conv2d_transpose_bwd_weight(dev(x), dev(gy), alpha), E.conv2d_transpose_bwd_weight(x, gy, alpha), name="bwd_weight")
+
+
+@pytest.mark.parametrize("b,i,o", [(8, 512, 8192), (8, 8192, 256), (8, 256, 61), (4, 32, 40), (20, 100, 70)])
+def test_dense(K, E, b, i, o):
+    x, w, gy = rnd(b, i, seed=1), rnd(i, o, seed=2), rnd(b, o, seed=3)
+    alpha = float(np.sqrt(2.0 / i))
+    close(K.dense_fwd(dev(x), dev(w), alpha), E.dense_fwd(x, w, alpha), name="fwd")
+    close(K.dense_bwd_data(dev(gy), dev(w), alpha), E.dense_bwd_data(gy, w, alpha), name="bwd_data")
+    close(K.dense_bwd_weight(dev(x), dev(gy), alpha), E.dense_bwd_weight(x, gy, alpha), name="bwd_weight")
+
+
+def test_embedding_exact(K, E):
+    w = rnd(61, 256, seed=1)
+    idx = torch.tensor([3, 60, 0, 3, 17, 3, 59, 1])
+    got = K.embedding_fwd(idx.cuda(), dev(w), 0.5, torch.float32).cpu()
+    assert torch.equal(got, E.embedding_fwd(idx, w, 0.5, torch.float32))  # one multiply per element: bit-exact
+    gy = rnd(8, 256, seed=2)
+    close(K.embedding_bwd(idx.cuda(), dev(gy), 61, 0.5), E.embedding_bwd(idx, gy, 61, 0.5), rel=1e-6, name="bwd")
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 8, 64), (4, 256, 2, 16), (2, 2, 16, 128), (8, 8192), (8, 61), (3, 64, 5, 7)])
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_bias_act_and_grads(K, E, shape, act):
+    x, g, gg = rnd(*shape, seed=1), rnd(*shape, seed=2), rnd(*shape, seed=3)
+    bias = rnd(shape[1], seed=4)
+    y_ref = E.bias_act_fwd(x, bias, act)
+    y = K.bias_act_fwd(dev(x), dev(bias), act)
+    close(y, y_ref, rel=1e-5, name="fwd")
+    close(K.bias_act_fwd(dev(x), None, act), E.bias_act_fwd(x, None, act), rel=1e-5, name="fwd_nobias")
+    if act:
+        close(K.act_bwd(dev(g), dev(y_ref), act), E.act_bwd(g, y_ref, act), rel=1e-5, name="act_bwd")
+    if act == 2:
+        close(K.tanh_bwd_bwd(dev(gg), dev(g), dev(y_ref)), E.tanh_bwd_bwd(gg, g, y_ref), rel=1e-5, name="tanh_bwd_bwd")
+    close(K.channel_sum(dev(g)), E.channel_sum(g), rel=1e-5, name="channel_sum")
+
+
+def test_channel_sum_large(K, E):
+    g = rnd(2, 32, 128, 256, seed=5)
+    close(K.channel_sum(dev(g)), E.channel_sum(g), rel=1e-5)
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 8, 64), (4, 256, 2, 16), (3, 64, 5, 9), (2, 128, 4, 16), (8, 512), (4, 8, 3, 5)])
+def test_pixel_norm_all_orders(K, E, shape):
+    x, g, gg = rnd(*shape, seed=1), rnd(*shape, seed=2), rnd(*shape, seed=3)
+    eps = 1e-12
+    close(K.pixel_norm_fwd(dev(x), eps), E.pixel_norm_fwd(x, eps), rel=1e-5, name="fwd")
+    close(K.pixel_norm_bwd(dev(g), dev(x), eps), E.pixel_norm_bwd(g, x, eps), rel=1e-4, name="bwd")
+    close(K.pixel_norm_bwd_bwd(dev(gg), dev(g), dev(x), eps), E.pixel_norm_bwd_bwd(gg, g, x, eps), rel=1e-4, name="bwd_bwd")
+
+
+@pytest.mark.parametrize("n,c,h,w,fy,fx", [(2, 2, 2, 16, 64, 64), (2, 2, 8, 64, 16, 16), (2, 2, 64, 512, 2, 2), (1, 4, 4, 4, 3, 2), (2, 32, 4, 8, 2, 2)])
+def test_upscale_exact_and_blocksum(K, E, n, c, h, w, fy, fx):
+    x = rnd(n, c, h, w, seed=1)
+    up = K.upscale2d(dev(x), fy, fx, 1.0).cpu()
+    assert torch.equal(up, E.upscale2d(x, fy, fx, 1.0))  # index op: bit-exact
+    big = rnd(n, c, h * fy, w * fx, seed=2)
+    close(K.blocksum2d(dev(big), fy, fx, 1.0 / (fy * fx)), E.blocksum2d(big, fy, fx, 1.0 / (fy * fx)), rel=1e-5, name="avgpool")
+    close(K.blocksum2d(dev(big), fy, fx, 1.0), E.blocksum2d(big, fy, fx, 1.0), rel=1e-5, name="blocksum")
+
+
+@pytest.mark.parametrize("b,c,h,w", [(4, 256, 2, 16), (8, 256, 2, 16), (8, 16, 3, 5)])
+def test_batch_stddev_all_orders(K, E, b, c, h, w):
+    x = rnd(b, c, h, w, seed=1)
+    gy = rnd(b, 1, h, w, seed=2)
+    ggx = rnd(b, c, h, w, seed=3)
+    eps = 1e-12
+    close(K.batch_stddev_fwd(dev(x), eps), E.batch_stddev_fwd(x, eps), rel=1e-5, name="fwd")
+    close(K.batch_stddev_bwd(dev(gy), dev(x), eps), E.batch_stddev_bwd(gy, x, eps), rel=1e-4, name="bwd")
+    ggy, gx2 = K.batch_stddev_bwd_bwd(dev(ggx), dev(gy), dev(x), eps)
+    rggy, rgx2 = E.batch_stddev_bwd_bwd(ggx, gy, x, eps)
+    close(ggy, rggy, rel=1e-4, name="bwd_bwd.ggy")
+    close(gx2, rgx2, rel=1e-4, name="bwd_bwd.gx")
+
+
+def test_axpby_sumsq_rowscale(K, E):
+    a, b = rnd(2, 2, 16, 128, seed=1), rnd(2, 2, 16, 128, seed=2)
+    close(K.axpby(dev(a), dev(b), 0.3, 0.7), E.axpby(a, b, 0.3, 0.7), rel=1e-6)
+    close(K.axpby(dev(a[:, :, :3, :5]), dev(b[:, :, :3, :5]), -1.0, 2.0), E.axpby(a[:, :, :3, :5], b[:, :, :3, :5], -1.0, 2.0), rel=1e-6)
+    x = rnd(8, 2, 32, 64, seed=3)
+    close(K.sumsq_rows(dev(x)), E.sumsq_rows(x), rel=1e-5)
+    s = rnd(8, seed=4)
+    close(K.row_scale(dev(x), dev(s)), E.row_scale(x, s), rel=1e-6)
+
+
+def test_adam_tf_step(K, E):
+    n = 100003
+    p, g = rnd(n, seed=1), rnd(n, seed=2)
+    m, v = rnd(n, seed=3).abs() * 0.1, rnd(n, seed=4).abs() * 0.1
+    rp, rm, rv = p.clone(), m.clone(), v.clone()
+    E.adam_tf_step(rp, g, rm, rv, 1e-3, 0.0, 0.99, 1e-8, 0.5)
+    dp, dg, dm, dv = p.cuda(), g.cuda(), m.cuda(), v.cuda()
+    K.adam_tf_step(dp, dg, dm, dv, 1e-3, 0.0, 0.99, 1e-8, 0.5)
+    close(dp, rp, rel=1e-6)
+    close(dm, rm, rel=1e-6)
+    close(dv, rv, rel=1e-6)
+
+
+@pytest.mark.parametrize("case", [(2, 32, 32, 8, 128, 3, 1), (2, 64, 64, 4, 32, 3, 1), (2, 32, 64, 8, 128, 3, 2), (4, 256, 256, 2, 16, 3, 1)])
+def test_conv2d_bf16_forward_and_data_grad(K, E, case):
+    """bf16 storage / fp32 accumulate path of the MFMA kernels against the fp32 reference on bf16-rounded inputs."""
+    n, ci, co, h, w, ks, st = case
+    x = rnd(n, ci, h, w, seed=1).bfloat16().float()
+    wt = rnd(ks, ks, ci, co, seed=2)
+    wt_r = wt.bfloat16().float()
+    alpha = float(np.sqrt(2.0 / (ks * ks * ci)))
+    y_ref = E.conv2d_fwd(x, wt_r, ks, st, alpha)
+    close(K.conv2d_fwd(dev(x, torch.bfloat16), dev(wt), ks, st, alpha), y_ref, rel=1e-2, name="fwd")
+    gy = rnd(*y_ref.shape, seed=3).bfloat16().float()
+    close(K.conv2d_bwd_data(dev(gy, torch.bfloat16), dev(wt), x.shape, ks, st, alpha), E.conv2d_bwd_data(gy, wt_r, x.shape, ks, st, alpha), rel=1e-2, name="bwd_data")

@@ -1,0 +1,130 @@
+"""GPU: the PGGAN G+D path end to end on the HIP kernels vs the oracle (fp32, 1e-3 relative) --
+forward, both losses (R1 + mode-seeking double-backward), every parameter gradient and one
+TF-Adam update; config[0] of BASELINE.json (2x16 stage, batch 4 -- SURVEY.md D1/D2) against the
+committed golden fixture; fade-in regimes; fully grown full-size forward."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import torch_ref as R
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def relerr(got, ref):
+    got, ref = got.detach().float().cpu(), ref.detach().float()
+    return float((got - ref).abs().max()) / (float(ref.abs().max()) + 1e-30)
+
+
+def make(level, store, full=True, dtype=torch.float32):
+    from gansynth_amd.networks import PGGAN
+    from gansynth_amd.models import GANSynth
+    from gansynth_amd.utils import Dict
+    kw = dict(min_resolution=[2, 16], max_resolution=[128, 1024], min_channels=32, max_channels=256) if full else \
+        dict(min_resolution=[2, 16], max_resolution=[16, 128], min_channels=32, max_channels=64)
+    pg, opg = PGGAN(growing_level=level, **kw), R.PGGAN(growing_level=level, **kw)
+    model = GANSynth(pg.generator, pg.discriminator, None, None, None, Dict(R.DEFAULT_HYPER), dtype=dtype)
+    return pg, opg, model
+
+
+def cuda(t):
+    return t.cuda().contiguous(memory_format=torch.channels_last) if t.dim() == 4 else t.cuda()
+
+
+def run_step_parity(pg, opg, model, store, batch, res, tol=1e-3):
+    lat, lab, real = R.synthetic_batch(batch, rank=0, image_shape=(2, *res))
+    lat2, lab2, _ = R.synthetic_batch(batch, rank=1, image_shape=(2, *res))
+    gp, dp = opg.init_params(seed=0, bias_std=0.1)
+    model._build(cuda(lat), cuda(lab))
+    store.load_state_dict({**gp, **dp})
+    tr = R.Trainer(opg, gp, dp)
+    # forward
+    with torch.no_grad():
+        fake = pg.generator(cuda(lat), cuda(lab))
+        feats, logits = pg.discriminator(cuda(real), cuda(lab))
+        ofake = opg.generator(gp, lat, lab)
+        ofeats, ologits = opg.discriminator(dp, real, lab)
+    assert relerr(fake, ofake) < tol, f"generator images {relerr(fake, ofake):.2e}"
+    assert relerr(feats, ofeats) < tol and relerr(logits, ologits) < tol
+    # D run
+    d_loss = model.discriminator_step(cuda(lat), cuda(lab), cuda(real))
+    d_grads = {k: p.grad.clone() for k, p in model.d_params.named.items()}
+    od_loss, od_grads = tr.d_step(lat, lab, real)
+    assert abs(float(d_loss) - float(od_loss)) <= tol * max(1.0, abs(float(od_loss))), (float(d_loss), float(od_loss))
+    bad = {k: relerr(d_grads[k], od_grads[k]) for k in od_grads if float(od_grads[k].abs().max()) > 0}
+    assert max(bad.values()) < 5 * tol, sorted(bad.items(), key=lambda kv: -kv[1])[:5]
+    zero = [k for k in od_grads if float(od_grads[k].abs().max()) == 0]
+    assert all(float(d_grads[k].abs().max()) == 0 for k in zero)  # untaken branches: exactly zero gradient
+    # G run
+    g_loss = model.generator_step(cuda(lat2), cuda(lab2))
+    g_grads = {k: p.grad.clone() for k, p in model.g_params.named.items()}
+    og_loss, og_grads = tr.g_step(lat2, lab2)
+    assert abs(float(g_loss) - float(og_loss)) <= tol * max(1.0, abs(float(og_loss))), (float(g_loss), float(og_loss))
+    bad = {k: relerr(g_grads[k], og_grads[k]) for k in og_grads if float(og_grads[k].abs().max()) > 0}
+    assert max(bad.values()) < 5 * tol, sorted(bad.items(), key=lambda kv: -kv[1])[:5]
+    # TF-Adam updated parameters
+    for k, p in list(model.d_params.named.items()) + list(model.g_params.named.items()):
+        ref = tr.d[k] if k in tr.d else tr.g[k]
+        assert relerr(p.data, ref.data) < tol, k
+    assert model.global_step == 1
+    return fake, feats, logits, d_loss, g_loss, d_grads, g_grads
+
+
+def test_config0_2x16_stage_batch4_vs_oracle_and_golden(gpu_store):
+    pg, opg, model = make(0.0, gpu_store)
+    fake, feats, logits, d_loss, g_loss, d_grads, g_grads = run_step_parity(pg, opg, model, gpu_store, 4, (128, 1024))
+    gold = np.load(os.path.join(GOLD, "pggan_2x16_b4.npz"))
+    up = fake.float().cpu()
+    assert torch.equal(up[:, :, ::64, ::64].repeat_interleave(64, 2).repeat_interleave(64, 3), up)  # nearest upscale: bit-exact blocks
+    assert relerr(up[:, :, ::64, ::64], torch.from_numpy(gold["fake_2x16"])) < 1e-3
+    assert relerr(feats, torch.from_numpy(gold["features"])) < 1e-3
+    assert relerr(logits, torch.from_numpy(gold["logits"])) < 1e-3
+    assert abs(float(d_loss) - float(gold["d_loss"])) < 1e-3 * max(1.0, abs(float(gold["d_loss"])))
+    assert abs(float(g_loss) - float(gold["g_loss"])) < 1e-3 * max(1.0, abs(float(gold["g_loss"])))
+    for k, g in list(d_grads.items()) + list(g_grads.items()):
+        ref = float(gold["gradnorm/" + k])
+        assert abs(float(g.double().norm()) - ref) <= 5e-3 * ref + 1e-12, k
+
+
+@pytest.mark.parametrize("level", [0.12, 0.25, 0.6, 1.0])
+def test_fade_regimes_reduced_pggan(gpu_store, level):
+    """2x16 .. 16x128 PGGAN (depth 3): level 0.12 -> depth 1 fade, 0.25 -> 2, 0.6 -> 3, 1.0 fully grown."""
+    pg, opg, model = make(level, gpu_store, full=False)
+    run_step_parity(pg, opg, model, gpu_store, 4, (16, 128))
+
+
+def test_fully_grown_full_size_forward(gpu_store):
+    """BASELINE.json configs[1] shape (128x1024x2, fully grown), forward of both networks, batch 4."""
+    pg, opg, model = make(1.0, gpu_store)
+    lat, lab, real = R.synthetic_batch(4, rank=0)
+    gp, dp = opg.init_params(seed=0, bias_std=0.1)
+    model._build(cuda(lat), cuda(lab))
+    gpu_store.load_state_dict({**gp, **dp})
+    with torch.no_grad():
+        fake = pg.generator(cuda(lat), cuda(lab))
+        feats, logits = pg.discriminator(cuda(real), cuda(lab))
+        ofake = opg.generator(gp, lat, lab)
+        ofeats, ologits = opg.discriminator(dp, real, lab)
+    assert fake.shape == (4, 2, 128, 1024)
+    assert relerr(fake, ofake) < 1e-3
+    assert relerr(feats, ofeats) < 1e-3 and relerr(logits, ologits) < 1e-3
+
+
+def test_full_size_step_runs_and_is_finite(gpu_store):
+    """Full G+D iteration at the headline shape (batch 8, fully grown): finite losses, every active
+    parameter moves, inactive colour blocks do not (zero gradient, zero Adam update with m=v=0)."""
+    pg, opg, model = make(1.0, gpu_store)
+    lat, lab, real = R.synthetic_batch(8, rank=0)
+    d0 = None
+    d_loss = model.discriminator_step(cuda(lat), cuda(lab), cuda(real))
+    g_loss = model.generator_step(cuda(lat), cuda(lab))
+    assert np.isfinite(float(d_loss)) and np.isfinite(float(g_loss))
+    for k, p in model.g_params.named.items():
+        g = float(p.grad.abs().max())
+        assert np.isfinite(g)
+        if "color_block" in k and "128x1024" not in k:
+            assert g == 0.0, k
+    assert float(model.g_params.named["generator/conv_block_128x1024/conv/weight"].grad.abs().max()) > 0
