@@ -56,7 +56,7 @@ class _FlatParams(object):
     def zero_grad(self):
         self.grad.zero_()
         for p in self.named.values():
-            if p.grad is None or p.grad.data_ptr() < self.grad.data_ptr():
+            if p.grad is None:
                 raise RuntimeError("parameter lost its flat gradient view")
 
 
@@ -185,8 +185,8 @@ class GANSynth(object):
         """models.py:191-192: one discriminator run then one generator run, fresh inputs for each."""
         real_images, labels = self._real_batch()
         d_loss = self.discriminator_step(self.fake_input_fn().to(self.dtype), labels, real_images)
-        _, labels = self._real_batch()
-        g_loss = self.generator_step(self.fake_input_fn().to(self.dtype), labels)
+        _, labels = self.real_input_fn()  # the G run only consumes the labels of its batch (waveform branch is pruned)
+        g_loss = self.generator_step(self.fake_input_fn().to(self.dtype), labels.to(self.dtype))
         return d_loss, g_loss
 
     def train(self, total_steps, log_tensor_steps=100, log=print):

@@ -46,21 +46,37 @@ def test_stagewise_vs_oracle():
 
 
 def test_fused_vs_oracle_and_golden():
+    """Conditioning: log(mel + 1e-6) amplifies fp32 FFT round-off without bound where a bin is (numerically)
+    silent -- the oracle's own float32 and float64 evaluations of the pure tone differ by 0.09 there -- and the
+    phase of a silent bin is noise.  So: the noise example (dense spectrum) is compared everywhere at 1e-3;
+    the tone example is compared in the linear mel domain everywhere (relative to the frame maximum) and in
+    the log / IF domain on the bins that carry signal (> 1e-3 of the maximum)."""
     from gansynth_amd import spectral_ops as G
     w = waves()
     st = S.convert_to_spectrogram_stages(w, **P)
+    st64 = S.convert_to_spectrogram_stages(w, **P, dtype=np.float64)
     lm, mi = G.convert_to_spectrogram(torch.from_numpy(w).cuda(), **P)
     lm, mi = lm.cpu().numpy(), mi.cpu().numpy()
     assert lm.shape == mi.shape == (2, 128, 1024)
-    assert np.abs(lm - st["log_mel"]).max() < 1e-3
-    d = np.abs(wrap2(mi - st["mel_if"]))
-    # the mel-projected phase mixes up to 6 raw phases; elements fed by near-silent bins are ill-conditioned
-    assert np.mean(d < 1e-3) > 0.995, np.mean(d < 1e-3)
+    # noise: everywhere
+    assert np.abs(lm[1] - st["log_mel"][1]).max() < 1e-3
+    assert np.abs(lm[1] - st64["log_mel"][1]).max() < 1e-3
+    assert np.abs(wrap2(mi[1] - st["mel_if"][1])).max() < 1e-3
+    # tone: linear domain everywhere, log/IF where there is signal
+    mel_lin = np.exp(lm * 10.05 - 3.76) - 1e-6
+    for i in range(2):
+        ref = st64["mel_magnitude"][i]
+        assert np.abs(mel_lin[i] - ref).max() <= 3e-4 * ref.max()
+        loud = ref > 1e-3 * ref.max()
+        assert np.abs(lm[i] - st64["log_mel"][i])[loud].max() < 1e-3
+        assert np.abs(wrap2(mi[i] - st64["mel_if"][i]))[loud].max() < 1e-3
     assert np.allclose(lm[:, :3], (np.log(1e-6) + 3.76) / 10.05, atol=1e-6) and np.all(mi[:, :3] == 0)
     gold = np.load(os.path.join(GOLD, "spectral_tone_noise.npz"))
     fr = gold["frames"]
-    assert np.abs(lm[:, fr] - gold["log_mel"]).max() < 1e-3
-    assert np.mean(np.abs(wrap2(mi[:, fr] - gold["mel_if"])) < 1e-3) > 0.995
+    assert np.abs(lm[1][fr] - gold["log_mel"][1]).max() < 1e-3
+    assert np.abs(wrap2(mi[1][fr] - gold["mel_if"][1])).max() < 1e-3
+    loud = gold["mel_magnitude"][0] > 1e-3 * gold["mel_magnitude"][0].max()
+    assert np.abs(lm[0][fr] - gold["log_mel"][0])[loud].max() < 1e-3
 
 
 def test_inverse_vs_oracle():
