@@ -45,7 +45,7 @@ def cpu_baseline():
     """The CPU oracle (torch-CPU fp32 restatement of the reference graph) timed on this host's cores,
     on a bounded sample: ONE iteration (D update + G update) at batch 4, fully grown 128x1024."""
     from oracle import torch_ref as R
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 32)  # beyond ~32 threads torch-CPU conv backward stops scaling (256-thread run: 40x slower)
     torch.set_num_threads(cores)
     pg = R.PGGAN([2, 16], [128, 1024], 32, 256, 1.0)
     gp, dp = pg.init_params(seed=0)

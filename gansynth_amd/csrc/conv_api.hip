@@ -15,7 +15,7 @@ int run_igemm(int mode, int variant, const void* x, const float* w_hwio, void* y
               hipStream_t st);
 size_t wgrad_mfma_bytes(int mode, int N, int Hb, int Wb, int IC, int OC);
 int run_wgrad_mfma(int mode, const void* x, const void* gy, float* gw, int N, int Hi, int Wi, int IC, int OC, int Hb,
-                   int Wb, float alpha, int transpose, void* ws, size_t ws_bytes, hipStream_t st);
+                   int Wb, float alpha, int transpose, int dtype, void* ws, size_t ws_bytes, hipStream_t st);
 
 // ------------------------------------------------------------------------- direct gather conv
 // y[n][oy][ox][oc0..oc0+OCV) = alpha * sum_{tap,ic} x[n][iy][ix][ic] * wp[tap][oc][ic]   (wp fp32)
@@ -181,7 +181,7 @@ static int run_wgrad_direct(int mode, int ks, const void* x, const void* gy, flo
                                                 reinterpret_cast<const T*>(x), reinterpret_cast<const T*>(gy), part, mode,
                                                 ks, N, Hi, Wi, IC, OC, Hb, Wb, E, npix, pps));
     GS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(E, 256)), dim3(256), 0, st, part, gw, (int)ns, ks * ks, IC, OC, alpha, transpose);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(E, 64)), dim3(256), 0, st, part, gw, (int)ns, ks * ks, IC, OC, alpha, transpose);
     GS_CHECK_LAUNCH();
     return 0;
 }
@@ -241,7 +241,7 @@ extern "C" int gs_conv2d_bwd_weight(const void* x, const void* gy, float* gw_hwi
     const int hb = h / stride, wb = w / stride;
     const int mode = stride == 2 ? MODE_S2 : MODE_S1;
     if (ksize == 3 && wgrad_mfma_supported(ci, co, dtype))
-        return run_wgrad_mfma(mode, x, gy, gw_hwio, n, h, w, ci, co, hb, wb, alpha, 0, ws, ws_bytes, st);
+        return run_wgrad_mfma(mode, x, gy, gw_hwio, n, h, w, ci, co, hb, wb, alpha, 0, dtype, ws, ws_bytes, st);
     return run_wgrad_direct(mode, ksize, x, gy, gw_hwio, n, h, w, ci, co, hb, wb, alpha, 0, dtype, ws, ws_bytes, st);
 }
 
@@ -280,6 +280,6 @@ extern "C" int gs_conv2d_transpose_s2_bwd_weight(const void* x, const void* gy, 
     hipStream_t st = as_stream(stream);
     // gw[k][ci][co] = sum x[i][ci] * gy[2i+k][co]: stride-2 wgrad with (input side = gy, output side = x), transposed
     if (wgrad_mfma_supported(co, ci, dtype))
-        return run_wgrad_mfma(MODE_S2, gy, x, gw_hwio, n, 2 * h, 2 * w, co, ci, h, w, alpha, 1, ws, ws_bytes, st);
+        return run_wgrad_mfma(MODE_S2, gy, x, gw_hwio, n, 2 * h, 2 * w, co, ci, h, w, alpha, 1, dtype, ws, ws_bytes, st);
     return run_wgrad_direct(MODE_S2, 3, gy, x, gw_hwio, n, 2 * h, 2 * w, co, ci, h, w, alpha, 1, dtype, ws, ws_bytes, st);
 }

@@ -239,7 +239,7 @@ template <typename T, int MODE, int TW>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(
     const T* __restrict__ x, const T* __restrict__ gy, float* __restrict__ part,
     int N, int Hi, int Wi, int IC, int OC, int Hb, int Wb, int tiles_x, int tiles_y, int ntiles, int nslices) {
-    static_assert(sizeof(T) == 4, "bf16 wgrad uses conv_wgrad_bf16_kernel");
+    // T = bf16: operands are widened to fp32 while staging (exact), the contraction runs on the fp32 MFMA.
     constexpr int NP = MODE == MODE_S2 ? 64 : 128;
     constexpr int TH = NP / TW;
     constexpr int PH = patch_dim<MODE>(TH), PW = patch_dim<MODE>(TW);
@@ -277,18 +277,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
             const int pix = c >> 3, part = c & 7;
             const int ly = pix / PW, lx = pix % PW;
             const int iy = oy0 + ly, ix = ox0 + lx;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (iy >= 0 && iy < Hi && ix >= 0 && ix < Wi)
-                v = *reinterpret_cast<const float4*>(x + (((long)n * Hi + iy) * Wi + ix) * IC + ic0 + part * 4);
-            *reinterpret_cast<float4*>(lp + pix * ROWF + part * 4) = v;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (iy >= 0 && iy < Hi && ix >= 0 && ix < Wi) ld4(x + (((long)n * Hi + iy) * Wi + ix) * IC + ic0 + part * 4, v);
+            *reinterpret_cast<float4*>(lp + pix * ROWF + part * 4) = make_float4(v[0], v[1], v[2], v[3]);
         }
         for (int c = tid; c < NP * 8; c += 256) {
             const int pix = c >> 3, part = c & 7;
             const int gy_ = by + pix / TW, gx_ = bx + pix % TW;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gy_ < Hb && gx_ < Wb)
-                v = *reinterpret_cast<const float4*>(gy + (((long)n * Hb + gy_) * Wb + gx_) * OC + oc0 + part * 4);
-            *reinterpret_cast<float4*>(lg + pix * ROWF + part * 4) = v;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (gy_ < Hb && gx_ < Wb) ld4(gy + (((long)n * Hb + gy_) * Wb + gx_) * OC + oc0 + part * 4, v);
+            *reinterpret_cast<float4*>(lg + pix * ROWF + part * 4) = make_float4(v[0], v[1], v[2], v[3]);
         }
         __syncthreads();
 #pragma unroll 2
@@ -375,7 +373,7 @@ bool igemm_supported(int ic, int oc, int dtype) {
     const int bk = dtype == GS_F32 ? 16 : 32;
     return ic % bk == 0 && oc % 32 == 0;
 }
-bool wgrad_mfma_supported(int ic, int oc, int dtype) { return dtype == GS_F32 && ic % 32 == 0 && oc % 32 == 0; }
+bool wgrad_mfma_supported(int ic, int oc, int dtype) { return (dtype == GS_F32 || dtype == GS_BF16) && ic % 32 == 0 && oc % 32 == 0; }
 
 size_t igemm_prep_bytes(int ic, int oc, int dtype) {
     return align256((size_t)9 * ic * oc * (dtype == GS_F32 ? 4 : 2));
@@ -417,7 +415,7 @@ static void wgrad_geometry(int mode, int N, int Hb, int Wb, int IC, int OC, int*
     *tiles_y = cdiv(Hb, th);
     *ntiles = N * *tiles_x * *tiles_y;
     const int pairs = (IC / 32) * (OC / 32);
-    int ns = 1024 / pairs;
+    int ns = 512 / pairs;
     if (ns < 1) ns = 1;
     if (ns > *ntiles) ns = *ntiles;
     *nslices = ns;
@@ -431,27 +429,30 @@ size_t wgrad_mfma_bytes(int mode, int N, int Hb, int Wb, int IC, int OC) {
 
 // x: conv input side [N][Hi][Wi][IC]; gy: [N][Hb][Wb][OC]; gw[9][IC][OC] (or transposed)
 int run_wgrad_mfma(int mode, const void* x, const void* gy, float* gw, int N, int Hi, int Wi, int IC, int OC, int Hb,
-                   int Wb, float alpha, int transpose, void* ws, size_t ws_bytes, hipStream_t st) {
+                   int Wb, float alpha, int transpose, int dtype, void* ws, size_t ws_bytes, hipStream_t st) {
     int tw, tiles_x, tiles_y, ntiles, nslices;
     wgrad_geometry(mode, N, Hb, Wb, IC, OC, &tw, &tiles_x, &tiles_y, &ntiles, &nslices);
     const size_t need = (size_t)nslices * 9 * IC * OC * sizeof(float);
     if (ws_bytes < need) return fail(GS_ERR_WORKSPACE, "conv wgrad: workspace %zu < %zu", ws_bytes, need);
     float* part = reinterpret_cast<float*>(ws);
     dim3 grid((IC / 32) * (OC / 32), nslices);
-    const float* xx = reinterpret_cast<const float*>(x);
-    const float* gg = reinterpret_cast<const float*>(gy);
     {
         ProfScope ps(st, 2.0 * 9.0 * (double)N * Hb * Wb * IC * OC);
-#define GS_WG(M, TWV)                                                                                            \
-    hipLaunchKernelGGL((conv_wgrad_kernel<float, M, TWV>), grid, dim3(256), 0, st, xx, gg, part, N, Hi, Wi, IC, OC, Hb, \
-                       Wb, tiles_x, tiles_y, ntiles, nslices)
-        if (mode == MODE_S1) { if (tw == 32) GS_WG(MODE_S1, 32); else GS_WG(MODE_S1, 16); }
-        else { if (tw == 32) GS_WG(MODE_S2, 32); else GS_WG(MODE_S2, 16); }
+#define GS_WG(TT, M, TWV)                                                                                              \
+    hipLaunchKernelGGL((conv_wgrad_kernel<TT, M, TWV>), grid, dim3(256), 0, st, reinterpret_cast<const TT*>(x),        \
+                       reinterpret_cast<const TT*>(gy), part, N, Hi, Wi, IC, OC, Hb, Wb, tiles_x, tiles_y, ntiles, nslices)
+#define GS_WG_ALL(TT)                                                                       \
+    do {                                                                                    \
+        if (mode == MODE_S1) { if (tw == 32) GS_WG(TT, MODE_S1, 32); else GS_WG(TT, MODE_S1, 16); } \
+        else { if (tw == 32) GS_WG(TT, MODE_S2, 32); else GS_WG(TT, MODE_S2, 16); }          \
+    } while (0)
+        if (dtype == GS_F32) GS_WG_ALL(float); else GS_WG_ALL(bf16_t);
+#undef GS_WG_ALL
 #undef GS_WG
     }
     GS_CHECK_LAUNCH();
     const long total = 9L * IC * OC;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, part, gw, nslices, 9, IC, OC, alpha, transpose);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 64)), dim3(256), 0, st, part, gw, nslices, 9, IC, OC, alpha, transpose);
     GS_CHECK_LAUNCH();
     return 0;
 }

@@ -34,23 +34,35 @@ __global__ void weight_prep_kernel(const float* __restrict__ w, T* __restrict__ 
 
 // gw[e] = alpha * sum_s part[s][e]; `transpose` swaps the last two dims on output
 // (used by conv2d_transpose's weight gradient, whose stored variable is [k][k][Cin_T][Cout_T]).
-static __global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ gw, int nslices,
-                                    int taps, int ic, int oc, float alpha, int transpose) {
+// Block = 64 consecutive elements x 4 slice lanes (fixed summation order -> deterministic).
+static __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ gw, int nslices,
+                                                                  int taps, int ic, int oc, float alpha, int transpose) {
+    __shared__ float red[256];
     const long total = (long)taps * ic * oc;
-    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= total) return;
-    float s = 0.f;
-    for (int k = 0; k < nslices; ++k) s += part[(long)k * total + e];
-    s *= alpha;
-    if (!transpose) {
-        gw[e] = s;
-    } else {
-        const int o = e % oc;
-        const int i = (e / oc) % ic;
-        const int t = e / ((long)ic * oc);
-        gw[((long)t * oc + o) * ic + i] = s;
+    const long e = (long)blockIdx.x * 64 + (threadIdx.x & 63);
+    const int sl = threadIdx.x >> 6;
+    float s0 = 0.f, s1 = 0.f;
+    if (e < total) {
+        int k = sl;
+        for (; k + 4 < nslices; k += 8) {
+            s0 += part[(long)k * total + e];
+            s1 += part[(long)(k + 4) * total + e];
+        }
+        if (k < nslices) s0 += part[(long)k * total + e];
+    }
+    red[threadIdx.x] = s0 + s1;
+    __syncthreads();
+    if (sl == 0 && e < total) {
+        const float s = (red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] + red[threadIdx.x + 192]) * alpha;
+        if (!transpose) {
+            gw[e] = s;
+        } else {
+            const int o = e % oc;
+            const int i = (e / oc) % ic;
+            const int t = e / ((long)ic * oc);
+            gw[((long)t * oc + o) * ic + i] = s;
+        }
     }
 }
-
 
 }  // namespace gs

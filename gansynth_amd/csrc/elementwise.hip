@@ -145,18 +145,28 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const T* __restrict__ 
         }
     }
 }
-static __global__ void channel_sum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int nparts, int c) {
-    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ch >= c) return;
+// out[ch] = sum_k part[k][ch]: block = 32 channels x 8 part lanes
+static __global__ __launch_bounds__(256) void channel_sum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int nparts, int c) {
+    __shared__ float red[256];
+    const int ch = blockIdx.x * 32 + (threadIdx.x & 31);
+    const int pl = threadIdx.x >> 5;
     float s = 0.f;
-    for (int k = 0; k < nparts; ++k) s += part[(long)k * c + ch];
-    out[ch] = s;
+    if (ch < c)
+        for (int k = pl; k < nparts; k += 8) s += part[(long)k * c + ch];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (pl == 0 && ch < c) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[k * 32 + threadIdx.x];
+        out[ch] = t;
+    }
 }
 static int channel_sum_parts(long p, int c) {
     long rows_per_block = 256 / (c >= 4 ? ((c & 3) == 0 ? c / 4 : (c < 256 ? c : 256)) : c);
     if (rows_per_block < 1) rows_per_block = 1;
     long nb = (p + rows_per_block * 16 - 1) / (rows_per_block * 16);
-    if (nb > 1024) nb = 1024;
+    if (nb > 512) nb = 512;
     if (nb < 1) nb = 1;
     return (int)nb;
 }
@@ -443,7 +453,7 @@ extern "C" int gs_channel_sum(const void* g, float* out, int64_t p, int c, int d
     float* part = (float*)ws;
     GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((channel_sum_kernel<T>), dim3(nparts), dim3(256), 0, st, (const T*)g, part, (long)p, c));
     GS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(channel_sum_final_kernel, dim3(cdiv(c, 256)), dim3(256), 0, st, part, out, nparts, c);
+    hipLaunchKernelGGL(channel_sum_final_kernel, dim3(cdiv(c, 32)), dim3(256), 0, st, part, out, nparts, c);
     GS_CHECK_LAUNCH();
     return 0;
 }

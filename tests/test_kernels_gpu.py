@@ -205,3 +205,22 @@ def test_conv2d_bf16_forward_and_data_grad(K, E, case):
     close(K.conv2d_fwd(dev(x, torch.bfloat16), dev(wt), ks, st, alpha), y_ref, rel=1e-2, name="fwd")
     gy = rnd(*y_ref.shape, seed=3).bfloat16().float()
     close(K.conv2d_bwd_data(dev(gy, torch.bfloat16), dev(wt), x.shape, ks, st, alpha), E.conv2d_bwd_data(gy, wt_r, x.shape, ks, st, alpha), rel=1e-2, name="bwd_data")
+
+
+@pytest.mark.parametrize("case", [(2, 32, 32, 8, 128, 3, 1), (2, 32, 64, 8, 128, 3, 2), (4, 256, 256, 2, 16, 3, 1)])
+def test_conv2d_bf16_weight_grad(K, E, case):
+    n, ci, co, h, w, ks, st = case
+    x = rnd(n, ci, h, w, seed=1).bfloat16().float()
+    gy = rnd(n, co, h // st, w // st, seed=3).bfloat16().float()
+    alpha = float(np.sqrt(2.0 / (ks * ks * ci)))
+    close(K.conv2d_bwd_weight(dev(x, torch.bfloat16), dev(gy, torch.bfloat16), ks, st, alpha), E.conv2d_bwd_weight(x, gy, ks, st, alpha), rel=1e-4, name="bwd_weight")
+
+
+def test_conv2d_transpose_bf16(K, E):
+    n, ci, co, h, w = 2, 64, 32, 8, 64
+    x = rnd(n, ci, h, w, seed=4).bfloat16().float()
+    wt = rnd(3, 3, ci, co, seed=5)
+    alpha = float(np.sqrt(2.0 / (9 * ci)))
+    close(K.conv2d_transpose_fwd(dev(x, torch.bfloat16), dev(wt), alpha), E.conv2d_transpose_fwd(x, wt.bfloat16().float(), alpha), rel=1e-2, name="fwd")
+    gy = rnd(n, co, 2 * h, 2 * w, seed=6).bfloat16().float()
+    close(K.conv2d_transpose_bwd_weight(dev(x, torch.bfloat16), dev(gy, torch.bfloat16), alpha), E.conv2d_transpose_bwd_weight(x, gy, alpha), rel=1e-4, name="bwd_weight")

@@ -137,3 +137,37 @@ def test_full_size_step_runs_and_is_finite(gpu_store):
         if "color_block" in k and "128x1024" not in k:
             assert g == 0.0, k
     assert float(model.g_params.named["generator/conv_block_128x1024/conv/weight"].grad.abs().max()) > 0
+
+
+def test_bf16_path_tracks_fp32(gpu_store):
+    """bf16 storage / fp32 accumulate (BASELINE.json configs[1] dtype): the same step as fp32 within bf16 rounding.
+    Forward outputs within 3 % of the tensor scale, both losses within 3 %, gradient direction (cosine) > 0.98
+    for the large tensors."""
+    from gansynth_amd import variables
+    lat, lab, real = R.synthetic_batch(4, rank=0, image_shape=(2, 16, 128))
+    res = {}
+    for dtype in (torch.float32, torch.bfloat16):
+        variables.set_default_store(variables.VariableStore(device="cuda"))
+        pg, opg, model = make(1.0, variables.default_store(), full=False, dtype=dtype)
+        gp, dp = opg.init_params(seed=0, bias_std=0.1)
+        model._build(cuda(lat), cuda(lab))
+        variables.default_store().load_state_dict({**gp, **dp})
+        c = lambda t: cuda(t).to(dtype)
+        with torch.no_grad():
+            fake = pg.generator(c(lat), c(lab))
+            _, logits = pg.discriminator(c(real), c(lab))
+        d_loss = model.discriminator_step(c(lat), c(lab), c(real))
+        d_grads = {k: p.grad.clone() for k, p in model.d_params.named.items()}
+        g_loss = model.generator_step(c(lat), c(lab))
+        g_grads = {k: p.grad.clone() for k, p in model.g_params.named.items()}
+        res[dtype] = (fake.float(), logits.float(), float(d_loss), float(g_loss), d_grads, g_grads)
+    f32, b16 = res[torch.float32], res[torch.bfloat16]
+    assert b16[0].dtype == torch.float32 and relerr(b16[0].cpu(), f32[0].cpu()) < 3e-2
+    assert relerr(b16[1].cpu(), f32[1].cpu()) < 3e-2
+    assert abs(b16[2] - f32[2]) < 3e-2 * max(1.0, abs(f32[2])) and abs(b16[3] - f32[3]) < 3e-2 * max(1.0, abs(f32[3]))
+    for grads_b, grads_f in ((b16[4], f32[4]), (b16[5], f32[5])):
+        for k in grads_f:
+            a, b = grads_b[k].flatten().double(), grads_f[k].flatten().double()
+            if b.numel() >= 4096 and float(b.norm()) > 0:
+                cos = float((a @ b) / (a.norm() * b.norm() + 1e-30))
+                assert cos > 0.98, (k, cos)
