@@ -13,7 +13,7 @@ size_t igemm_prep_bytes(int ic, int oc, int dtype);
 int run_igemm(int mode, int variant, const void* x, const float* w_hwio, void* y, int N, int Hi, int Wi, int ICk,
               int OCk, int w_ci, int w_co, int Hb, int Wb, float alpha, int dtype, void* ws, size_t ws_bytes,
               hipStream_t st);
-size_t wgrad_mfma_bytes(int mode, int N, int Hb, int Wb, int IC, int OC);
+size_t wgrad_mfma_bytes(int mode, int dtype, int N, int Hb, int Wb, int IC, int OC);
 int run_wgrad_mfma(int mode, const void* x, const void* gy, float* gw, int N, int Hi, int Wi, int IC, int OC, int Hb,
                    int Wb, float alpha, int transpose, int dtype, void* ws, size_t ws_bytes, hipStream_t st);
 
@@ -202,7 +202,7 @@ using namespace gs;
 extern "C" size_t gs_conv2d_workspace_bytes(int which, int n, int h, int w, int ci, int co, int ksize, int stride, int dtype) {
     const int hb = h / stride, wb = w / stride;
     if (which == GS_CONV_BWD_WEIGHT) {
-        if (ksize == 3 && wgrad_mfma_supported(ci, co, dtype)) return wgrad_mfma_bytes(stride == 2 ? MODE_S2 : MODE_S1, n, hb, wb, ci, co);
+        if (ksize == 3 && wgrad_mfma_supported(ci, co, dtype)) return wgrad_mfma_bytes(stride == 2 ? MODE_S2 : MODE_S1, dtype, n, hb, wb, ci, co);
         return wgrad_direct_bytes(ksize, n, hb, wb, ci, co);
     }
     return align256((size_t)ksize * ksize * ci * co * 4);
@@ -248,7 +248,7 @@ extern "C" int gs_conv2d_bwd_weight(const void* x, const void* gy, float* gw_hwi
 // ---- conv2d_transpose 3x3 stride 2: re-labelings of the stride-2 maps (see include/gansynth_hip.h)
 extern "C" size_t gs_conv2d_transpose_s2_workspace_bytes(int which, int n, int h, int w, int ci, int co, int dtype) {
     if (which == GS_CONV_BWD_WEIGHT) {
-        if (wgrad_mfma_supported(co, ci, dtype)) return wgrad_mfma_bytes(MODE_S2, n, h, w, co, ci);
+        if (wgrad_mfma_supported(co, ci, dtype)) return wgrad_mfma_bytes(MODE_S2, dtype, n, h, w, co, ci);
         return wgrad_direct_bytes(3, n, h, w, co, ci);
     }
     return align256((size_t)9 * ci * co * 4);

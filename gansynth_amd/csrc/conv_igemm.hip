@@ -322,6 +322,128 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
     }
 }
 
+// bf16 weight gradient on the bf16 MFMA (32x32x16, K = 16 pixels per instruction).
+// The contraction index is the PIXEL, but channels-last tiles keep channels contiguous, so each
+// lane's 8 k-values live in 8 different LDS rows: they are fetched as 16-bit LDS reads and packed
+// in registers.  The three horizontal taps of a kernel row read overlapping pixel windows
+// (p+kx .. p+kx+7), so one row costs 10 reads (stride 1) / 17 reads (stride 2) for 3 MFMAs and the
+// shifted fragments are rebuilt with v_alignbit -- 38 (59) LDS reads per 9 MFMAs, which balances
+// the LDS pipe against the matrix pipe.
+__device__ inline unsigned int pk16(unsigned short lo, unsigned short hi) { return (unsigned int)lo | ((unsigned int)hi << 16); }
+__device__ inline unsigned int shr16(unsigned int hi, unsigned int lo) { return __builtin_amdgcn_alignbit(hi, lo, 16); }
+__device__ inline bf16x8 mk_frag(unsigned int a, unsigned int b, unsigned int c, unsigned int d) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 v = {a, b, c, d};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int MODE, int TW>
+__global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(
+    const bf16_t* __restrict__ x, const bf16_t* __restrict__ gy, float* __restrict__ part,
+    int N, int Hi, int Wi, int IC, int OC, int Hb, int Wb, int tiles_x, int tiles_y, int ntiles, int nslices) {
+    constexpr int NP = MODE == MODE_S2 ? 128 : 256;
+    constexpr int TH = NP / TW;
+    constexpr int PH = patch_dim<MODE>(TH), PW = patch_dim<MODE>(TW);
+    constexpr int S = MODE == MODE_S2 ? 2 : 1;
+    constexpr int ROW = 32;  // bf16 per LDS row (32 channels = 64 B)
+    constexpr int LDS_MAIN = (PH * PW + NP) * ROW * 2;
+    constexpr int LDS_RED = 4 * 1024 * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_MAIN > LDS_RED ? LDS_MAIN : LDS_RED];
+    unsigned short* lp = reinterpret_cast<unsigned short*>(lds_raw);
+    unsigned short* lg = lp + PH * PW * ROW;
+    float* lred = reinterpret_cast<float*>(lds_raw);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6, hi = lane >> 5, l31 = lane & 31;
+    const int n_ict = IC / 32;
+    const int ic0 = (blockIdx.x % n_ict) * 32, oc0 = (blockIdx.x / n_ict) * 32;
+    const int slice = blockIdx.y;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    for (int tile = slice; tile < ntiles; tile += nslices) {
+        int b = tile;
+        const int tile_x = b % tiles_x;
+        b /= tiles_x;
+        const int tile_y = b % tiles_y;
+        const int n = b / tiles_y;
+        const int by = tile_y * TH, bx = tile_x * TW;
+        const int oy0 = MODE == MODE_S2 ? 2 * by : by - 1;
+        const int ox0 = MODE == MODE_S2 ? 2 * bx : bx - 1;
+        __syncthreads();
+        for (int c = tid; c < PH * PW * 4; c += 256) {
+            const int pix = c >> 2, part4 = c & 3;
+            const int ly = pix / PW, lx = pix % PW;
+            const int iy = oy0 + ly, ix = ox0 + lx;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (iy >= 0 && iy < Hi && ix >= 0 && ix < Wi)
+                v = *reinterpret_cast<const uint4*>(x + (((long)n * Hi + iy) * Wi + ix) * IC + ic0 + part4 * 8);
+            *reinterpret_cast<uint4*>(lp + pix * ROW + part4 * 8) = v;
+        }
+        for (int c = tid; c < NP * 4; c += 256) {
+            const int pix = c >> 2, part4 = c & 3;
+            const int gy_ = by + pix / TW, gx_ = bx + pix % TW;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (gy_ < Hb && gx_ < Wb)
+                v = *reinterpret_cast<const uint4*>(gy + (((long)n * Hb + gy_) * Wb + gx_) * OC + oc0 + part4 * 8);
+            *reinterpret_cast<uint4*>(lg + pix * ROW + part4 * 8) = v;
+        }
+        __syncthreads();
+        for (int g = wv; g < NP / 16; g += 4) {
+            const int ty = (g * 16) / TW, tx0 = (g * 16) % TW + 8 * hi;
+            const unsigned short* gb = lg + (ty * TW + tx0) * ROW + l31;
+            const bf16x8 bfrag = mk_frag(pk16(gb[0], gb[ROW]), pk16(gb[2 * ROW], gb[3 * ROW]), pk16(gb[4 * ROW], gb[5 * ROW]),
+                                         pk16(gb[6 * ROW], gb[7 * ROW]));
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const unsigned short* pb = lp + ((ty * S + ky) * PW + tx0 * S) * ROW + l31;
+                if (MODE == MODE_S2) {
+                    unsigned int E[5], O[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        E[q] = pk16(pb[(4 * q) * ROW], pb[(4 * q + 2) * ROW]);
+                        O[q] = pk16(pb[(4 * q + 1) * ROW], pb[(4 * q + 3) * ROW]);
+                    }
+                    E[4] = pb[16 * ROW];
+                    acc[ky * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk_frag(E[0], E[1], E[2], E[3]), bfrag, acc[ky * 3 + 0], 0, 0, 0);
+                    acc[ky * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk_frag(O[0], O[1], O[2], O[3]), bfrag, acc[ky * 3 + 1], 0, 0, 0);
+                    acc[ky * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                        mk_frag(shr16(E[1], E[0]), shr16(E[2], E[1]), shr16(E[3], E[2]), shr16(E[4], E[3])), bfrag, acc[ky * 3 + 2], 0, 0, 0);
+                } else {
+                    unsigned int R[5];
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) R[q] = pk16(pb[(2 * q) * ROW], pb[(2 * q + 1) * ROW]);
+                    acc[ky * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk_frag(R[0], R[1], R[2], R[3]), bfrag, acc[ky * 3 + 0], 0, 0, 0);
+                    acc[ky * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                        mk_frag(shr16(R[1], R[0]), shr16(R[2], R[1]), shr16(R[3], R[2]), shr16(R[4], R[3])), bfrag, acc[ky * 3 + 1], 0, 0, 0);
+                    acc[ky * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk_frag(R[1], R[2], R[3], R[4]), bfrag, acc[ky * 3 + 2], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
+            lred[wv * 1024 + i * 32 + l31] = acc[t][r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int e = tid + 256 * k;
+            const float s = lred[e] + lred[1024 + e] + lred[2048 + e] + lred[3072 + e];
+            const int i = e >> 5, j = e & 31;
+            part[(((long)slice * 9 + t) * IC + ic0 + i) * OC + oc0 + j] = s;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------ dispatch
 
 template <typename T, int MODE, int A, int B, int TW, int TG>
@@ -406,9 +528,9 @@ int run_igemm(int mode, int variant, const void* x, const float* w_hwio, void* y
 }
 
 // ---- weight gradient (fp32 MFMA path)
-static void wgrad_geometry(int mode, int N, int Hb, int Wb, int IC, int OC, int* tw, int* tiles_x, int* tiles_y,
+static void wgrad_geometry(int mode, int dtype, int N, int Hb, int Wb, int IC, int OC, int* tw, int* tiles_x, int* tiles_y,
                            int* ntiles, int* nslices) {
-    const int np = mode == MODE_S2 ? 64 : 128;
+    const int np = (mode == MODE_S2 ? 64 : 128) * (dtype == GS_BF16 ? 2 : 1);
     *tw = Wb >= 32 ? 32 : 16;
     const int th = np / *tw;
     *tiles_x = cdiv(Wb, *tw);
@@ -421,9 +543,9 @@ static void wgrad_geometry(int mode, int N, int Hb, int Wb, int IC, int OC, int*
     *nslices = ns;
 }
 
-size_t wgrad_mfma_bytes(int mode, int N, int Hb, int Wb, int IC, int OC) {
+size_t wgrad_mfma_bytes(int mode, int dtype, int N, int Hb, int Wb, int IC, int OC) {
     int tw, tx, ty, nt, ns;
-    wgrad_geometry(mode, N, Hb, Wb, IC, OC, &tw, &tx, &ty, &nt, &ns);
+    wgrad_geometry(mode, dtype, N, Hb, Wb, IC, OC, &tw, &tx, &ty, &nt, &ns);
     return align256((size_t)ns * 9 * IC * OC * sizeof(float));
 }
 
@@ -431,7 +553,7 @@ size_t wgrad_mfma_bytes(int mode, int N, int Hb, int Wb, int IC, int OC) {
 int run_wgrad_mfma(int mode, const void* x, const void* gy, float* gw, int N, int Hi, int Wi, int IC, int OC, int Hb,
                    int Wb, float alpha, int transpose, int dtype, void* ws, size_t ws_bytes, hipStream_t st) {
     int tw, tiles_x, tiles_y, ntiles, nslices;
-    wgrad_geometry(mode, N, Hb, Wb, IC, OC, &tw, &tiles_x, &tiles_y, &ntiles, &nslices);
+    wgrad_geometry(mode, dtype, N, Hb, Wb, IC, OC, &tw, &tiles_x, &tiles_y, &ntiles, &nslices);
     const size_t need = (size_t)nslices * 9 * IC * OC * sizeof(float);
     if (ws_bytes < need) return fail(GS_ERR_WORKSPACE, "conv wgrad: workspace %zu < %zu", ws_bytes, need);
     float* part = reinterpret_cast<float*>(ws);
@@ -446,7 +568,16 @@ int run_wgrad_mfma(int mode, const void* x, const void* gy, float* gw, int N, in
         if (mode == MODE_S1) { if (tw == 32) GS_WG(TT, MODE_S1, 32); else GS_WG(TT, MODE_S1, 16); } \
         else { if (tw == 32) GS_WG(TT, MODE_S2, 32); else GS_WG(TT, MODE_S2, 16); }          \
     } while (0)
-        if (dtype == GS_F32) GS_WG_ALL(float); else GS_WG_ALL(bf16_t);
+        if (dtype == GS_F32) {
+            GS_WG_ALL(float);
+        } else {
+#define GS_WGB(M, TWV)                                                                                                  \
+    hipLaunchKernelGGL((conv_wgrad_bf16_kernel<M, TWV>), grid, dim3(256), 0, st, reinterpret_cast<const bf16_t*>(x),    \
+                       reinterpret_cast<const bf16_t*>(gy), part, N, Hi, Wi, IC, OC, Hb, Wb, tiles_x, tiles_y, ntiles, nslices)
+            if (mode == MODE_S1) { if (tw == 32) GS_WGB(MODE_S1, 32); else GS_WGB(MODE_S1, 16); }
+            else { if (tw == 32) GS_WGB(MODE_S2, 32); else GS_WGB(MODE_S2, 16); }
+#undef GS_WGB
+        }
 #undef GS_WG_ALL
 #undef GS_WG
     }
