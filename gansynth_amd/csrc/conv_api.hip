@@ -11,8 +11,8 @@ bool igemm_supported(int ic, int oc, int dtype);
 bool wgrad_mfma_supported(int ic, int oc, int dtype);
 size_t igemm_prep_bytes(int ic, int oc, int dtype);
 int run_igemm(int mode, int variant, const void* x, const float* w_hwio, void* y, int N, int Hi, int Wi, int ICk,
-              int OCk, int w_ci, int w_co, int Hb, int Wb, float alpha, int dtype, void* ws, size_t ws_bytes,
-              hipStream_t st);
+              int OCk, int w_ci, int w_co, int Hb, int Wb, float alpha, const float* bias, int act, int dtype, void* ws,
+              size_t ws_bytes, hipStream_t st);
 size_t wgrad_mfma_bytes(int mode, int dtype, int N, int Hb, int Wb, int IC, int OC);
 int run_wgrad_mfma(int mode, const void* x, const void* gy, float* gw, int N, int Hi, int Wi, int IC, int OC, int Hb,
                    int Wb, float alpha, int transpose, int dtype, void* ws, size_t ws_bytes, hipStream_t st);
@@ -215,7 +215,7 @@ extern "C" int gs_conv2d_fwd(const void* x, const float* w_hwio, void* y, int n,
     const int hb = h / stride, wb = w / stride;
     const int mode = stride == 2 ? MODE_S2 : MODE_S1;
     if (ksize == 3 && igemm_supported(ci, co, dtype))
-        return run_igemm(mode, 0, x, w_hwio, y, n, h, w, ci, co, ci, co, hb, wb, alpha, dtype, ws, ws_bytes, st);
+        return run_igemm(mode, 0, x, w_hwio, y, n, h, w, ci, co, ci, co, hb, wb, alpha, nullptr, 0, dtype, ws, ws_bytes, st);
     return run_direct(mode, ksize, 0, x, w_hwio, y, n, h, w, ci, co, ci, co, hb, wb, alpha, dtype, ws, ws_bytes, st);
 }
 
@@ -226,11 +226,11 @@ extern "C" int gs_conv2d_bwd_data(const void* gy, const float* w_hwio, void* gx,
     const int hb = h / stride, wb = w / stride;
     if (stride == 1) {  // flipped taps, roles of ci/co swapped
         if (ksize == 3 && igemm_supported(co, ci, dtype))
-            return run_igemm(MODE_S1, 1, gy, w_hwio, gx, n, h, w, co, ci, ci, co, h, w, alpha, dtype, ws, ws_bytes, st);
+            return run_igemm(MODE_S1, 1, gy, w_hwio, gx, n, h, w, co, ci, ci, co, h, w, alpha, nullptr, 0, dtype, ws, ws_bytes, st);
         return run_direct(MODE_S1, ksize, 1, gy, w_hwio, gx, n, h, w, co, ci, ci, co, h, w, alpha, dtype, ws, ws_bytes, st);
     }
     if (igemm_supported(co, ci, dtype))
-        return run_igemm(MODE_T2, 2, gy, w_hwio, gx, n, hb, wb, co, ci, ci, co, hb, wb, alpha, dtype, ws, ws_bytes, st);
+        return run_igemm(MODE_T2, 2, gy, w_hwio, gx, n, hb, wb, co, ci, ci, co, hb, wb, alpha, nullptr, 0, dtype, ws, ws_bytes, st);
     return run_direct(MODE_T2, 3, 2, gy, w_hwio, gx, n, hb, wb, co, ci, ci, co, h, w, alpha, dtype, ws, ws_bytes, st);
 }
 
@@ -260,7 +260,7 @@ extern "C" int gs_conv2d_transpose_s2_fwd(const void* x, const float* w_hwio, vo
     hipStream_t st = as_stream(stream);
     // out[2i+k][co] += x[i][ci] * w[k][ci][co]: kernel roles ICk = ci, OCk = co, Wp[t][co][ci] (variant 0)
     if (igemm_supported(ci, co, dtype))
-        return run_igemm(MODE_T2, 0, x, w_hwio, y, n, h, w, ci, co, ci, co, h, w, alpha, dtype, ws, ws_bytes, st);
+        return run_igemm(MODE_T2, 0, x, w_hwio, y, n, h, w, ci, co, ci, co, h, w, alpha, nullptr, 0, dtype, ws, ws_bytes, st);
     return run_direct(MODE_T2, 3, 0, x, w_hwio, y, n, h, w, ci, co, ci, co, 2 * h, 2 * w, alpha, dtype, ws, ws_bytes, st);
 }
 
@@ -270,7 +270,7 @@ extern "C" int gs_conv2d_transpose_s2_bwd_data(const void* gy, const float* w_hw
     hipStream_t st = as_stream(stream);
     // gx[i][ci] = sum gy[2i+k][co] * w[k][ci][co]: stride-2 conv, roles ICk = co, OCk = ci, Wp[t][ci][co] (variant 2)
     if (igemm_supported(co, ci, dtype))
-        return run_igemm(MODE_S2, 2, gy, w_hwio, gx, n, 2 * h, 2 * w, co, ci, ci, co, h, w, alpha, dtype, ws, ws_bytes, st);
+        return run_igemm(MODE_S2, 2, gy, w_hwio, gx, n, 2 * h, 2 * w, co, ci, ci, co, h, w, alpha, nullptr, 0, dtype, ws, ws_bytes, st);
     return run_direct(MODE_S2, 3, 2, gy, w_hwio, gx, n, 2 * h, 2 * w, co, ci, ci, co, h, w, alpha, dtype, ws, ws_bytes, st);
 }
 

@@ -90,143 +90,288 @@ template <int MODE> __host__ __device__ constexpr int tap_off(int k) {  // patch
 }
 
 // ------------------------------------------------------------------------- implicit GEMM
-// Block = 256 threads = 4 waves, every wave owns all 32*A output channels of the block and
-// 32*B of its 128*B base pixels.  K loop: input-channel chunks of 64 bytes (16 f32 / 32 bf16),
-// the halo'd input patch of a chunk is staged once and reused by all 9 taps.
+// Persistent, software-pipelined kernel.  Block = 256 threads = 4 waves; every wave owns all
+// 32*A output channels of the block and 32*B of its 128*B base pixels.  A block walks a list of
+// work items (spatial tile x output-channel tile; the list of an XCD is contiguous so that
+// neighbouring tiles share halo rows in that XCD's L2).  The K loop runs over input-channel chunks of
+// 64 bytes (16 f32 / 32 bf16) x tap groups; while the MFMAs of one stage run, the global loads of the
+// next stage (next tap group / next chunk / next ITEM) are already in flight into registers, and are
+// written to the other half of a double-buffered LDS ring after the MFMAs -- one barrier per stage.
+// LDS rows are 64 bytes, the four 16-byte slots of a row are XOR-swizzled with bits 2..3 of the row
+// index, which makes the 16-lane ds_read_b128 groups conflict-free without padding.
+// TG == 9 is the "resident weights" mode for the thin top-of-pyramid layers (32 output channels):
+// all taps of all chunks stay in LDS for the life of the block and only the input patch streams.
+struct ConvP {
+    const void* x;
+    const void* wp;
+    void* y;
+    const float* bias;  // optional fused epilogue: y = act(alpha * conv + bias)
+    int act;
+    int N, Hi, Wi, IC, OC, Hb, Wb, tiles_x, tiles_y, nsp, noct, nch;
+    float alpha;
+};
+
 template <typename T, int MODE, int A, int B, int TW, int TG>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(
-    const T* __restrict__ x, const T* __restrict__ wp, T* __restrict__ y,
-    int N, int Hi, int Wi, int IC, int OC, int Hb, int Wb, int tiles_x, int tiles_y, float alpha) {
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
     constexpr int NP = 128 * B;
     constexpr int TH = NP / TW;
     constexpr int PH = patch_dim<MODE>(TH), PW = patch_dim<MODE>(TW);
     constexpr int S = MODE == MODE_S2 ? 2 : 1;
     constexpr int NPH = MODE == MODE_T2 ? 4 : 1;
-    constexpr int BKB = 64;
-    constexpr int BK = BKB / (int)sizeof(T);
-    constexpr int ROWB = BKB + 16;
-    constexpr int CPP = BKB / 16;
+    constexpr int BK = 64 / (int)sizeof(T);
     constexpr int OCT = 32 * A;
+    constexpr int NTG = 9 / TG;
+    constexpr bool RESIDENT = TG == 9;
+    constexpr int PCH = PH * PW * 4;    // 16-byte slots of a patch chunk
+    constexpr int WCH = TG * OCT * 4;   // 16-byte slots of one weight stage
+    constexpr int PREG = (PCH + 255) / 256, WREG = (WCH + 255) / 256;
+    constexpr int PBYTES = PH * PW * 64, WBYTES = TG * OCT * 64;
     typedef typename Mma<T>::frag_t frag_t;
 
-    __shared__ __attribute__((aligned(16))) unsigned char lds[PH * PW * ROWB + TG * OCT * ROWB];
-    unsigned char* lp = lds;
-    unsigned char* lw = lds + PH * PW * ROWB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    unsigned char* const lpatch = lds;                // 2 x PBYTES
+    unsigned char* const lwgt = lds + 2 * PBYTES;     // streamed: 2 x WBYTES ; resident: nch x WBYTES
+
+    const T* __restrict__ x = reinterpret_cast<const T*>(p.x);
+    const T* __restrict__ wp = reinterpret_cast<const T*>(p.wp);
+    T* __restrict__ y = reinterpret_cast<T*>(p.y);
+    const int Hi = p.Hi, Wi = p.Wi, IC = p.IC, OC = p.OC, Hb = p.Hb, Wb = p.Wb, NCH = p.nch;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6, hi = lane >> 5, l31 = lane & 31;
-    int bid = blockIdx.x;
-    const int tile_x = bid % tiles_x;
-    bid /= tiles_x;
-    const int tile_y = bid % tiles_y;
-    const int n = bid / tiles_y;
-    const int oc0 = blockIdx.y * OCT;
-    const int by = tile_y * TH, bx = tile_x * TW;
-    const int oy0 = MODE == MODE_S2 ? 2 * by : by - 1;
-    const int ox0 = MODE == MODE_S2 ? 2 * bx : bx - 1;
 
-    f32x16 acc[NPH][A][B];
-#pragma unroll
-    for (int p = 0; p < NPH; ++p)
-#pragma unroll
-        for (int a = 0; a < A; ++a)
-#pragma unroll
-            for (int b = 0; b < B; ++b)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[p][a][b][r] = 0.f;
-
-    int pixoff[B];
-#pragma unroll
-    for (int b = 0; b < B; ++b) {
-        const int p = (wv * B + b) * 32 + l31;
-        const int ty = p / TW, tx = p % TW;
-        pixoff[b] = ((ty * S) * PW + tx * S) * ROWB + hi * 16;
+    // ---- this block's item list (XCD-contiguous when the grid is a multiple of 8)
+    const int total = p.nsp * p.noct;
+    int first, stride, count;
+    if ((gridDim.x & 7) == 0) {
+        const int per_xcd = (total + 7) >> 3, gx = gridDim.x >> 3;
+        const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+        first = xcd * per_xcd + loc;
+        stride = gx;
+        int end = (xcd + 1) * per_xcd;
+        if (end > total) end = total;
+        count = first < end ? (end - first + gx - 1) / gx : 0;
+    } else {
+        first = blockIdx.x;
+        stride = gridDim.x;
+        count = first < total ? (total - first + stride - 1) / stride : 0;
     }
-    const int arow = l31 * ROWB + hi * 16;
+    if (count == 0) return;
 
-    for (int ic0 = 0; ic0 < IC; ic0 += BK) {
-        __syncthreads();
-        // ---- stage the input patch chunk (zero outside the image)
-        for (int c = tid; c < PH * PW * CPP; c += 256) {
-            const int pix = c / CPP, part = c % CPP;
-            const int ly = pix / PW, lx = pix % PW;
-            const int iy = oy0 + ly, ix = ox0 + lx;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (iy >= 0 && iy < Hi && ix >= 0 && ix < Wi) {
-                const T* src = x + (((long)n * Hi + iy) * Wi + ix) * IC + ic0;
-                v = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(src) + part * 16);
-            }
-            *reinterpret_cast<uint4*>(lp + pix * ROWB + part * 16) = v;
-        }
+    uint4 preg[PREG], wreg[WREG];
+
+    auto item_coords = [&](int item, int& n, int& by, int& bx, int& oc0) {
+        const int sp = item / p.noct;
+        oc0 = (item - sp * p.noct) * OCT;
+        const int tile_x = sp % p.tiles_x;
+        const int r = sp / p.tiles_x;
+        by = (r % p.tiles_y) * TH;
+        bx = tile_x * TW;
+        n = r / p.tiles_y;
+    };
+    auto load_patch = [&](int item, int ch) {
+        int n, by, bx, oc0;
+        item_coords(item, n, by, bx, oc0);
+        const int oy0 = MODE == MODE_S2 ? 2 * by : by - 1;
+        const int ox0 = MODE == MODE_S2 ? 2 * bx : bx - 1;
+        const T* xb = x + (long)n * Hi * Wi * IC + ch * BK;
 #pragma unroll
-        for (int tg = 0; tg < 9; tg += TG) {
-            if (tg > 0) __syncthreads();
-            // ---- stage the weight rows of TG taps for this chunk
-            for (int c = tid; c < TG * OCT * CPP; c += 256) {
-                const int part = c % CPP;
-                const int row = (c / CPP) % OCT;
-                const int tt = c / (CPP * OCT);
-                const int i = tg + tt;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (i < 9 && oc0 + row < OC) {
+        for (int r = 0; r < PREG; ++r) {
+            const int c = tid + 256 * r;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (c < PCH) {
+                const int pix = c >> 2, part = c & 3;
+                const int ly = pix / PW, lx = pix - ly * PW;
+                const int iy = oy0 + ly, ix = ox0 + lx;
+                if (iy >= 0 && iy < Hi && ix >= 0 && ix < Wi)
+                    v = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(xb + ((long)iy * Wi + ix) * IC) + part * 16);
+            }
+            preg[r] = v;
+        }
+    };
+    auto store_patch = [&](int buf) {
+        unsigned char* dst = lpatch + buf * PBYTES;
+#pragma unroll
+        for (int r = 0; r < PREG; ++r) {
+            const int c = tid + 256 * r;
+            if (c < PCH) {
+                const int pix = c >> 2, part = c & 3;
+                *reinterpret_cast<uint4*>(dst + pix * 64 + ((part ^ ((pix >> 2) & 3)) << 4)) = preg[r];
+            }
+        }
+    };
+    auto load_weights = [&](int oc0, int ch, int tg) {
+#pragma unroll
+        for (int r = 0; r < WREG; ++r) {
+            const int c = tid + 256 * r;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (c < WCH) {
+                const int part = c & 3;
+                const int row = (c >> 2) % OCT;
+                const int i = tg * TG + (c >> 2) / OCT;
+                if (oc0 + row < OC) {
                     const int wt = tap_ky<MODE>(i) * 3 + tap_kx<MODE>(i);
-                    const T* src = wp + ((long)wt * OC + oc0 + row) * IC + ic0;
+                    const T* src = wp + ((long)wt * OC + oc0 + row) * IC + ch * BK;
                     v = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(src) + part * 16);
                 }
-                *reinterpret_cast<uint4*>(lw + (tt * OCT + row) * ROWB + part * 16) = v;
             }
-            __syncthreads();
+            wreg[r] = v;
+        }
+    };
+    auto store_weights = [&](unsigned char* dst) {
 #pragma unroll
-            for (int tt = 0; tt < TG; ++tt) {
-                const int i = tg + tt;
-                if (i < 9) {
+        for (int r = 0; r < WREG; ++r) {
+            const int c = tid + 256 * r;
+            if (c < WCH) {
+                const int R = c >> 2, part = c & 3;
+                *reinterpret_cast<uint4*>(dst + R * 64 + ((part ^ ((R >> 2) & 3)) << 4)) = wreg[r];
+            }
+        }
+    };
+
+    f32x16 acc[NPH][A][B];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int ph = 0; ph < NPH; ++ph)
+#pragma unroll
+            for (int a = 0; a < A; ++a)
+#pragma unroll
+                for (int b = 0; b < B; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[ph][a][b][r] = 0.f;
+    };
+
+    int pixbase[B];  // patch pixel index of this lane's base pixel (tap offset added per tap)
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+        const int q = (wv * B + b) * 32 + l31;
+        pixbase[b] = ((q / TW) * S) * PW + (q % TW) * S;
+    }
+    const int aswz = (l31 >> 2) & 3;
+
+    // ---- prologue
+    int item = first, done = 0;
+    {
+        int n, by, bx, oc0;
+        item_coords(item, n, by, bx, oc0);
+        load_patch(item, 0);
+        store_patch(0);
+        if (RESIDENT) {
+            for (int ch = 0; ch < NCH; ++ch) {
+                load_weights(oc0, ch, 0);
+                store_weights(lwgt + ch * WBYTES);
+            }
+        } else {
+            load_weights(oc0, 0, 0);
+            store_weights(lwgt);
+        }
+    }
+    __syncthreads();
+    zero_acc();
+    int pb = 0, wb = 0;
+
+    while (true) {
+        int n, by, bx, oc0;
+        item_coords(item, n, by, bx, oc0);
+        for (int ch = 0; ch < NCH; ++ch) {
+#pragma unroll
+            for (int tg = 0; tg < NTG; ++tg) {
+                // ---- what comes next, and its global loads (in flight during the MFMAs below)
+                const bool last_tg = tg == NTG - 1;
+                const bool last_ch = ch == NCH - 1;
+                const bool has_next_item = done + 1 < count;
+                const bool need_patch = last_tg && (!last_ch || has_next_item);
+                const bool need_w = !RESIDENT && (!last_tg || !last_ch || has_next_item);
+                if (need_patch) {
+                    if (!last_ch) load_patch(item, ch + 1);
+                    else load_patch(item + stride, 0);
+                }
+                if (need_w) {
+                    if (!last_tg) load_weights(oc0, ch, tg + 1);
+                    else if (!last_ch) load_weights(oc0, ch + 1, 0);
+                    else {
+                        const int nit = item + stride;
+                        load_weights((nit - (nit / p.noct) * p.noct) * OCT, 0, 0);
+                    }
+                }
+                // ---- MFMAs of this stage
+                const unsigned char* lp = lpatch + pb * PBYTES;
+                const unsigned char* lw = RESIDENT ? lwgt + ch * WBYTES : lwgt + wb * WBYTES;
+#pragma unroll
+                for (int tt = 0; tt < TG; ++tt) {
+                    const int i = tg * TG + tt;
                     const int ph = tap_phase<MODE>(i);
-                    const int toff = (tap_off<MODE>(tap_ky<MODE>(i)) * PW + tap_off<MODE>(tap_kx<MODE>(i))) * ROWB;
+                    const int toff = tap_off<MODE>(tap_ky<MODE>(i)) * PW + tap_off<MODE>(tap_kx<MODE>(i));
+                    int boff[B], bswz[B];
 #pragma unroll
-                    for (int ks = 0; ks < BKB / 32; ++ks) {
+                    for (int b = 0; b < B; ++b) {
+                        const int pidx = pixbase[b] + toff;
+                        boff[b] = pidx * 64;
+                        bswz[b] = (pidx >> 2) & 3;
+                    }
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
                         frag_t af[A], bf[B];
 #pragma unroll
                         for (int a = 0; a < A; ++a)
-                            af[a] = *reinterpret_cast<const frag_t*>(lw + (tt * OCT + a * 32) * ROWB + arow + ks * 32);
+                            af[a] = *reinterpret_cast<const frag_t*>(lw + (tt * OCT + a * 32 + l31) * 64 + (((ks * 2 + hi) ^ aswz) << 4));
 #pragma unroll
                         for (int b = 0; b < B; ++b)
-                            bf[b] = *reinterpret_cast<const frag_t*>(lp + pixoff[b] + toff + ks * 32);
+                            bf[b] = *reinterpret_cast<const frag_t*>(lp + boff[b] + (((ks * 2 + hi) ^ bswz[b]) << 4));
 #pragma unroll
                         for (int a = 0; a < A; ++a)
 #pragma unroll
                             for (int b = 0; b < B; ++b) Mma<T>::mma(af[a], bf[b], acc[ph][a][b]);
                     }
                 }
-            }
-        }
-    }
-
-    // ---- epilogue: D[oc][pixel]; lane holds oc = 8q + 4hi + (0..3) of pixel l31 per accumulator quad
-    const int Ho = MODE == MODE_T2 ? 2 * Hb : Hb, Wo = MODE == MODE_T2 ? 2 * Wb : Wb;
+                // ---- epilogue of the item: D[oc][pixel]; a lane holds oc = 8q + 4hi + (0..3) of pixel l31 per quad
+                if (last_tg && last_ch) {
+                    const int Ho = MODE == MODE_T2 ? 2 * Hb : Hb, Wo = MODE == MODE_T2 ? 2 * Wb : Wb;
 #pragma unroll
-    for (int b = 0; b < B; ++b) {
-        const int p = (wv * B + b) * 32 + l31;
-        const int gy = by + p / TW, gx = bx + p % TW;
-        if (gy < Hb && gx < Wb) {
+                    for (int b = 0; b < B; ++b) {
+                        const int q = (wv * B + b) * 32 + l31;
+                        const int gy = by + q / TW, gx = bx + q % TW;
+                        if (gy < Hb && gx < Wb) {
 #pragma unroll
-            for (int ph = 0; ph < NPH; ++ph) {
-                const int oy = MODE == MODE_T2 ? 2 * gy + (ph >> 1) : gy;
-                const int ox = MODE == MODE_T2 ? 2 * gx + (ph & 1) : gx;
-                T* yp = y + (((long)n * Ho + oy) * Wo + ox) * OC + oc0;
+                            for (int ph = 0; ph < NPH; ++ph) {
+                                const int oy = MODE == MODE_T2 ? 2 * gy + (ph >> 1) : gy;
+                                const int ox = MODE == MODE_T2 ? 2 * gx + (ph & 1) : gx;
+                                T* yp = y + (((long)n * Ho + oy) * Wo + ox) * OC + oc0;
 #pragma unroll
-                for (int a = 0; a < A; ++a) {
-                    if (oc0 + a * 32 < OC) {
+                                for (int a = 0; a < A; ++a) {
+                                    if (oc0 + a * 32 < OC) {
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            float o[4];
+                                        for (int qd = 0; qd < 4; ++qd) {
+                                            float o[4];
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) o[e] = acc[ph][a][b][q * 4 + e] * alpha;
-                            st4(yp + a * 32 + q * 8 + hi * 4, o);
+                                            for (int e = 0; e < 4; ++e) o[e] = acc[ph][a][b][qd * 4 + e] * p.alpha;
+                                            if (p.bias) {
+                                                const float4 bv = *reinterpret_cast<const float4*>(p.bias + oc0 + a * 32 + qd * 8 + hi * 4);
+                                                o[0] += bv.x; o[1] += bv.y; o[2] += bv.z; o[3] += bv.w;
+                                            }
+                                            if (p.act == GS_ACT_LRELU) {
+#pragma unroll
+                                                for (int e = 0; e < 4; ++e) o[e] = o[e] > 0.f ? o[e] : 0.2f * o[e];
+                                            }
+                                            st4(yp + a * 32 + qd * 8 + hi * 4, o);
+                                        }
+                                    }
+                                }
+                            }
                         }
                     }
+                    zero_acc();
                 }
+                // ---- publish the prefetched stage into the other LDS buffers
+                if (need_patch) store_patch(pb ^ 1);
+                if (need_w) store_weights(lwgt + (wb ^ 1) * WBYTES);
+                if (need_patch || need_w) __syncthreads();
+                if (need_patch) pb ^= 1;
+                if (need_w) wb ^= 1;
             }
         }
+        if (++done >= count) break;
+        item += stride;
     }
 }
 
@@ -446,48 +591,87 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(
 
 // ------------------------------------------------------------------------------ dispatch
 
+static int g_num_cus = 0;
+static int num_cus() {
+    if (g_num_cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+            g_num_cus = n;
+        else
+            g_num_cus = 256;
+    }
+    return g_num_cus;
+}
+
 template <typename T, int MODE, int A, int B, int TW, int TG>
-static int launch_igemm(const T* x, const T* wp, T* y, int N, int Hi, int Wi, int IC, int OC, int Hb, int Wb,
-                        float alpha, hipStream_t st) {
+static int launch_igemm(ConvP p, hipStream_t st) {
     constexpr int NP = 128 * B;
     constexpr int TH = NP / TW;
-    const int tiles_x = cdiv(Wb, TW), tiles_y = cdiv(Hb, TH);
-    dim3 grid((unsigned)((long)N * tiles_x * tiles_y), (unsigned)cdiv(OC, 32 * A));
-    const double flops = 2.0 * 9.0 * (double)N * Hb * Wb * IC * OC * (MODE == MODE_T2 ? 1.0 : 1.0);
+    constexpr int PH = patch_dim<MODE>(TH), PW = patch_dim<MODE>(TW);
+    constexpr int OCT = 32 * A;
+    constexpr int BK = 64 / (int)sizeof(T);
+    p.tiles_x = cdiv(p.Wb, TW);
+    p.tiles_y = cdiv(p.Hb, TH);
+    p.nsp = p.N * p.tiles_x * p.tiles_y;
+    p.noct = cdiv(p.OC, OCT);
+    p.nch = p.IC / BK;
+    const int wbufs = TG == 9 ? p.nch : 2;
+    const size_t lds = (size_t)2 * PH * PW * 64 + (size_t)wbufs * TG * OCT * 64;
+    if (lds > 160 * 1024) return fail(GS_ERR_UNSUPPORTED, "conv igemm: %zu bytes of LDS needed", lds);
+    auto kern = conv_igemm_kernel<T, MODE, A, B, TW, TG>;
+    static size_t max_set = 0;  // per template instantiation
+    if (lds > max_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return fail(GS_ERR_HIP, "conv igemm: cannot reserve %zu bytes of dynamic LDS", lds);
+        max_set = lds;
+    }
+    // resident blocks per CU: LDS-limited, and at most 2 (accumulator-heavy kernels hold 1-2 waves per SIMD)
+    int per_cu = (int)((160 * 1024) / lds);
+    if (per_cu > 2) per_cu = 2;
+    if (per_cu < 1) per_cu = 1;
+    const long total = (long)p.nsp * p.noct;
+    long grid = (long)per_cu * num_cus();
+    if (grid > total) grid = total;
+    if (grid >= 8) grid &= ~7L;
+    const double flops = 2.0 * 9.0 * (double)p.N * p.Hb * p.Wb * p.IC * p.OC;
     ProfScope ps(st, flops);
-    hipLaunchKernelGGL((conv_igemm_kernel<T, MODE, A, B, TW, TG>), grid, dim3(256), 0, st, x, wp, y, N, Hi, Wi, IC, OC,
-                       Hb, Wb, tiles_x, tiles_y, alpha);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, p);
     return 0;
 }
 
-// choose the tile configuration from (OC, Wb)
+// choose the tile configuration from (OC, Wb, problem size)
 template <typename T, int MODE>
-static int dispatch_igemm(const T* x, const T* wp, T* y, int N, int Hi, int Wi, int IC, int OC, int Hb, int Wb,
-                          float alpha, hipStream_t st) {
+static int dispatch_igemm(ConvP p, hipStream_t st) {
+    constexpr int BK = 64 / (int)sizeof(T);
+    const int OC = p.OC, Wb = p.Wb;
+    const int nch = p.IC / BK;
+    const bool resident_ok = OC == 32 && nch <= 2;
+    // number of 128-pixel tiles: prefer 128-wide oc tiles only when they still give >= 2 blocks per CU
+    const long tiles128 = (long)p.N * cdiv(p.Hb, Wb >= 32 ? 4 : 8) * cdiv(Wb, Wb >= 32 ? 32 : 16);
+    const bool wide = OC % 128 == 0 && tiles128 * (OC / 128) >= 2L * num_cus();
     if constexpr (MODE == MODE_T2) {
-        if (OC == 32 && Wb >= 64) return launch_igemm<T, MODE, 1, 2, 64, 9>(x, wp, y, N, Hi, Wi, IC, OC, Hb, Wb, alpha, st);
-        if (OC == 32) return launch_igemm<T, MODE, 1, 1, 32, 9>(x, wp, y, N, Hi, Wi, IC, OC, Hb, Wb, alpha, st);
-        if (Wb >= 32) return launch_igemm<T, MODE, 2, 1, 32, 3>(x, wp, y, N, Hi, Wi, IC, OC, Hb, Wb, alpha, st);
-        return launch_igemm<T, MODE, 2, 1, 16, 3>(x, wp, y, N, Hi, Wi, IC, OC, Hb, Wb, alpha, st);
+        if (resident_ok && Wb >= 64) return launch_igemm<T, MODE, 1, 2, 64, 9>(p, st);
+        if (OC == 32) return launch_igemm<T, MODE, 1, 1, 32, 3>(p, st);
+        if (Wb >= 32) return launch_igemm<T, MODE, 2, 1, 32, 3>(p, st);
+        return launch_igemm<T, MODE, 2, 1, 16, 3>(p, st);
     } else if constexpr (MODE == MODE_S2) {
-        if (OC == 32) return launch_igemm<T, MODE, 1, 1, 32, 9>(x, wp, y, N, Hi, Wi, IC, OC, Hb, Wb, alpha, st);
-        if (OC == 64 || OC % 128 != 0) {
-            if (Wb >= 32) return launch_igemm<T, MODE, 2, 1, 32, 3>(x, wp, y, N, Hi, Wi, IC, OC, Hb, Wb, alpha, st);
-            return launch_igemm<T, MODE, 2, 1, 16, 3>(x, wp, y, N, Hi, Wi, IC, OC, Hb, Wb, alpha, st);
+        if (OC == 32) return launch_igemm<T, MODE, 1, 1, 32, 3>(p, st);
+        if (!wide) {
+            if (Wb >= 32) return launch_igemm<T, MODE, 2, 1, 32, 3>(p, st);
+            return launch_igemm<T, MODE, 2, 1, 16, 3>(p, st);
         }
-        if (Wb >= 32) return launch_igemm<T, MODE, 4, 1, 32, 3>(x, wp, y, N, Hi, Wi, IC, OC, Hb, Wb, alpha, st);
-        return launch_igemm<T, MODE, 4, 1, 16, 3>(x, wp, y, N, Hi, Wi, IC, OC, Hb, Wb, alpha, st);
+        if (Wb >= 32) return launch_igemm<T, MODE, 4, 1, 32, 3>(p, st);
+        return launch_igemm<T, MODE, 4, 1, 16, 3>(p, st);
     } else {
-    // MODE_S1
-    if (OC == 32 && Wb >= 64) return launch_igemm<T, MODE, 1, 2, 64, 9>(x, wp, y, N, Hi, Wi, IC, OC, Hb, Wb, alpha, st);
-    if (OC == 32) return launch_igemm<T, MODE, 1, 1, 32, 9>(x, wp, y, N, Hi, Wi, IC, OC, Hb, Wb, alpha, st);
-    if ((OC == 64 || OC % 128 != 0) && Wb >= 64) return launch_igemm<T, MODE, 2, 2, 64, 3>(x, wp, y, N, Hi, Wi, IC, OC, Hb, Wb, alpha, st);
-    if (OC == 64 || OC % 128 != 0) {
-        if (Wb >= 32) return launch_igemm<T, MODE, 2, 1, 32, 3>(x, wp, y, N, Hi, Wi, IC, OC, Hb, Wb, alpha, st);
-        return launch_igemm<T, MODE, 2, 1, 16, 3>(x, wp, y, N, Hi, Wi, IC, OC, Hb, Wb, alpha, st);
-    }
-    if (Wb >= 32) return launch_igemm<T, MODE, 4, 1, 32, 3>(x, wp, y, N, Hi, Wi, IC, OC, Hb, Wb, alpha, st);
-    return launch_igemm<T, MODE, 4, 1, 16, 3>(x, wp, y, N, Hi, Wi, IC, OC, Hb, Wb, alpha, st);
+        if (resident_ok && Wb >= 64) return launch_igemm<T, MODE, 1, 2, 64, 9>(p, st);
+        if (OC == 32) return launch_igemm<T, MODE, 1, 1, 32, 3>(p, st);
+        if (!wide && Wb >= 64 && OC == 64) return launch_igemm<T, MODE, 2, 2, 64, 3>(p, st);
+        if (!wide) {
+            if (Wb >= 32) return launch_igemm<T, MODE, 2, 1, 32, 3>(p, st);
+            return launch_igemm<T, MODE, 2, 1, 16, 3>(p, st);
+        }
+        if (Wb >= 32) return launch_igemm<T, MODE, 4, 1, 32, 3>(p, st);
+        return launch_igemm<T, MODE, 4, 1, 16, 3>(p, st);
     }
 }
 
@@ -504,27 +688,31 @@ size_t igemm_prep_bytes(int ic, int oc, int dtype) {
 // mode: MODE_*; variant: weight_prep variant; (ICk, OCk) are the kernel-role channel counts
 template <typename T>
 static int run_igemm_t(int mode, int variant, const void* x, const float* w_hwio, void* y, int N, int Hi, int Wi,
-                       int ICk, int OCk, int w_ci, int w_co, int Hb, int Wb, float alpha, void* ws, size_t ws_bytes,
-                       hipStream_t st) {
+                       int ICk, int OCk, int w_ci, int w_co, int Hb, int Wb, float alpha, const float* bias, int act,
+                       void* ws, size_t ws_bytes, hipStream_t st) {
     const size_t need = (size_t)9 * w_ci * w_co * sizeof(T);
     if (ws_bytes < need) return fail(GS_ERR_WORKSPACE, "conv igemm: workspace %zu < %zu", ws_bytes, need);
     T* wp = reinterpret_cast<T*>(ws);
     const long total = 9L * w_ci * w_co;
     hipLaunchKernelGGL((weight_prep_kernel<T>), dim3(cdiv(total, 256)), dim3(256), 0, st, w_hwio, wp, 9, w_ci, w_co, variant);
-    const T* xx = reinterpret_cast<const T*>(x);
-    T* yy = reinterpret_cast<T*>(y);
-    if (mode == MODE_S1) dispatch_igemm<T, MODE_S1>(xx, wp, yy, N, Hi, Wi, ICk, OCk, Hb, Wb, alpha, st);
-    else if (mode == MODE_S2) dispatch_igemm<T, MODE_S2>(xx, wp, yy, N, Hi, Wi, ICk, OCk, Hb, Wb, alpha, st);
-    else dispatch_igemm<T, MODE_T2>(xx, wp, yy, N, Hi, Wi, ICk, OCk, Hb, Wb, alpha, st);
+    ConvP p;
+    memset(&p, 0, sizeof(p));
+    p.x = x; p.wp = wp; p.y = y; p.bias = bias; p.act = act;
+    p.N = N; p.Hi = Hi; p.Wi = Wi; p.IC = ICk; p.OC = OCk; p.Hb = Hb; p.Wb = Wb; p.alpha = alpha;
+    int rc;
+    if (mode == MODE_S1) rc = dispatch_igemm<T, MODE_S1>(p, st);
+    else if (mode == MODE_S2) rc = dispatch_igemm<T, MODE_S2>(p, st);
+    else rc = dispatch_igemm<T, MODE_T2>(p, st);
+    if (rc) return rc;
     GS_CHECK_LAUNCH();
     return 0;
 }
 
 int run_igemm(int mode, int variant, const void* x, const float* w_hwio, void* y, int N, int Hi, int Wi, int ICk,
-              int OCk, int w_ci, int w_co, int Hb, int Wb, float alpha, int dtype, void* ws, size_t ws_bytes,
-              hipStream_t st) {
+              int OCk, int w_ci, int w_co, int Hb, int Wb, float alpha, const float* bias, int act, int dtype, void* ws,
+              size_t ws_bytes, hipStream_t st) {
     GS_DISPATCH_DTYPE(dtype, return (run_igemm_t<T>(mode, variant, x, w_hwio, y, N, Hi, Wi, ICk, OCk, w_ci, w_co, Hb,
-                                                    Wb, alpha, ws, ws_bytes, st)));
+                                                    Wb, alpha, bias, act, ws, ws_bytes, st)));
 }
 
 // ---- weight gradient (fp32 MFMA path)
