@@ -66,7 +66,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=8, help="per-GPU batch (weak scaling)")
-    ap.add_argument("--dtype", choices=["f32", "bf16"], default=os.environ.get("GS_BENCH_DTYPE", "f32"))
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default=os.environ.get("GS_BENCH_DTYPE", "bf16"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

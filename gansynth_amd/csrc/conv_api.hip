@@ -153,6 +153,62 @@ __global__ __launch_bounds__(256) void conv_wgrad_direct_kernel(const T* __restr
     if (sub == 0 && e < E) part[(long)slice * E + e] = red[tid] + red[tid + 64] + red[tid + 128] + red[tid + 192];
 }
 
+// ------------------------------------------------------------- thin 1x1 weight gradient
+// The colour convs have 2 channels on one side: gw = sum_p wide[p][C] (x) thin[p][2].  One streaming pass:
+// C/4 lanes per pixel hold 4 wide channels x 2 thin values = 8 accumulators, pixel lanes reduce through LDS.
+// WIDE_IS_X: x is the wide tensor (gw[c][j], Cout = 2), else gy is (gw[j][c], Cin = 2).
+template <typename T, bool WIDE_IS_X>
+__global__ __launch_bounds__(256) void thin_wgrad_kernel(const T* __restrict__ wide, const T* __restrict__ thin, float* __restrict__ part,
+                                                         int C, long npix, long pps) {
+    __shared__ float red[256 * 8];
+    const int quads = C >> 2;
+    const int rpi = 256 / quads;  // pixel lanes per iteration
+    const int q = threadIdx.x % quads, r = threadIdx.x / quads;
+    const long p0 = (long)blockIdx.x * pps;
+    long p1 = p0 + pps;
+    if (p1 > npix) p1 = npix;
+    float acc[4][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+    if (r < rpi) {
+        for (long p = p0 + r; p < p1; p += rpi) {
+            float w4[4];
+            ld4(wide + p * C + q * 4, w4);
+            const float t0 = DT<T>::ld(thin + p * 2), t1 = DT<T>::ld(thin + p * 2 + 1);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { acc[e][0] += w4[e] * t0; acc[e][1] += w4[e] * t1; }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[threadIdx.x * 8 + e * 2] = acc[e][0]; red[threadIdx.x * 8 + e * 2 + 1] = acc[e][1]; }
+    __syncthreads();
+    if (threadIdx.x < quads) {
+        float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < rpi; ++k)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s[e] += red[(k * quads + threadIdx.x) * 8 + e];
+        float* out = part + (long)blockIdx.x * C * 2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = threadIdx.x * 4 + e;
+            if (WIDE_IS_X) { out[c * 2] = s[e * 2]; out[c * 2 + 1] = s[e * 2 + 1]; }
+            else { out[c] = s[e * 2]; out[C + c] = s[e * 2 + 1]; }
+        }
+    }
+}
+
+static bool thin_wgrad_ok(int ks, int ci, int co) {
+    if (ks != 1) return false;
+    const int c = ci == 2 ? co : (co == 2 ? ci : 0);
+    return c >= 4 && c <= 1024 && (c & 3) == 0 && 256 % (c >> 2) == 0 && !(ci == 2 && co == 2);
+}
+static void thin_wgrad_geometry(long npix, int c, long* nslices, long* pps) {
+    const long rpi = 256 / (c >> 2);
+    long ns = (npix + rpi * 32 - 1) / (rpi * 32);
+    if (ns > 1024) ns = 1024;
+    if (ns < 1) ns = 1;
+    *pps = (npix + ns - 1) / ns;
+    *nslices = (npix + *pps - 1) / *pps;
+}
+
 static void wgrad_direct_geometry(long npix, long* nslices, long* pps) {
     long ns = (npix + 1023) / 1024;
     if (ns > 1024) ns = 1024;
@@ -164,6 +220,11 @@ static void wgrad_direct_geometry(long npix, long* nslices, long* pps) {
 static size_t wgrad_direct_bytes(int ks, int N, int Hb, int Wb, int IC, int OC) {
     long ns, pps;
     wgrad_direct_geometry((long)N * Hb * Wb, &ns, &pps);
+    if (thin_wgrad_ok(ks, IC, OC)) {
+        long tns, tpps;
+        thin_wgrad_geometry((long)N * Hb * Wb, IC == 2 ? OC : IC, &tns, &tpps);
+        if (tns > ns) ns = tns;
+    }
     return align256((size_t)ns * ks * ks * IC * OC * 4);
 }
 
@@ -172,8 +233,25 @@ static int run_wgrad_direct(int mode, int ks, const void* x, const void* gy, flo
                             hipStream_t st) {
     long ns, pps;
     const long npix = (long)N * Hb * Wb;
-    wgrad_direct_geometry(npix, &ns, &pps);
     const long E = (long)ks * ks * IC * OC;
+    if (thin_wgrad_ok(ks, IC, OC) && mode == MODE_S1) {
+        const int C = IC == 2 ? OC : IC;
+        thin_wgrad_geometry(npix, C, &ns, &pps);
+        if (ws_bytes < (size_t)ns * E * 4) return fail(GS_ERR_WORKSPACE, "conv wgrad thin: workspace %zu < %zu", ws_bytes, (size_t)ns * E * 4);
+        float* tpart = reinterpret_cast<float*>(ws);
+        if (IC == 2) {
+            GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((thin_wgrad_kernel<T, false>), dim3((unsigned)ns), dim3(256), 0, st,
+                                                        reinterpret_cast<const T*>(gy), reinterpret_cast<const T*>(x), tpart, C, npix, pps));
+        } else {
+            GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((thin_wgrad_kernel<T, true>), dim3((unsigned)ns), dim3(256), 0, st,
+                                                        reinterpret_cast<const T*>(x), reinterpret_cast<const T*>(gy), tpart, C, npix, pps));
+        }
+        GS_CHECK_LAUNCH();
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(E, 64)), dim3(256), 0, st, tpart, gw, (int)ns, 1, IC, OC, alpha, transpose);
+        GS_CHECK_LAUNCH();
+        return 0;
+    }
+    wgrad_direct_geometry(npix, &ns, &pps);
     if (ws_bytes < (size_t)ns * E * 4) return fail(GS_ERR_WORKSPACE, "conv wgrad direct: workspace %zu < %zu", ws_bytes, (size_t)ns * E * 4);
     float* part = reinterpret_cast<float*>(ws);
     dim3 grid(cdiv(E, 64), (unsigned)ns);

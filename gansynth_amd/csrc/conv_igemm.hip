@@ -483,7 +483,7 @@ __device__ inline bf16x8 mk_frag(unsigned int a, unsigned int b, unsigned int c,
 }
 
 template <int MODE, int TW>
-__global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(
+__global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(
     const bf16_t* __restrict__ x, const bf16_t* __restrict__ gy, float* __restrict__ part,
     int N, int Hi, int Wi, int IC, int OC, int Hb, int Wb, int tiles_x, int tiles_y, int ntiles, int nslices) {
     constexpr int NP = MODE == MODE_S2 ? 128 : 256;
@@ -665,7 +665,6 @@ static int dispatch_igemm(ConvP p, hipStream_t st) {
     } else {
         if (resident_ok && Wb >= 64) return launch_igemm<T, MODE, 1, 2, 64, 9>(p, st);
         if (OC == 32) return launch_igemm<T, MODE, 1, 1, 32, 3>(p, st);
-        if (!wide && Wb >= 64 && OC == 64) return launch_igemm<T, MODE, 2, 2, 64, 3>(p, st);
         if (!wide) {
             if (Wb >= 32) return launch_igemm<T, MODE, 2, 1, 32, 3>(p, st);
             return launch_igemm<T, MODE, 2, 1, 16, 3>(p, st);

@@ -90,6 +90,31 @@ __global__ void dense_bwd_weight_kernel(const T* __restrict__ x, const T* __rest
     gw[e] = s * alpha;
 }
 
+// wide rows (out >= 2048, e.g. the generator's 512 -> 8192 dense): one block per weight row
+template <typename T>
+__global__ __launch_bounds__(256) void dense_bwd_data_wide_kernel(const T* __restrict__ gy, const float* __restrict__ w, T* __restrict__ gx,
+                                                                  int b0, int nb, int in, int out, float alpha) {
+    __shared__ float red[4];
+    const int i = blockIdx.x;
+    float acc[DENSE_BT];
+#pragma unroll
+    for (int b = 0; b < DENSE_BT; ++b) acc[b] = 0.f;
+    const float* wr = w + (long)i * out;
+    for (int o = threadIdx.x; o < out; o += 256) {
+        const float wv = wr[o];
+#pragma unroll
+        for (int b = 0; b < DENSE_BT; ++b)
+            if (b < nb) acc[b] += DT<T>::ld(gy + (long)(b0 + b) * out + o) * wv;
+    }
+#pragma unroll
+    for (int b = 0; b < DENSE_BT; ++b) {
+        if (b < nb) {
+            const float s = block_sum<256>(acc[b], red);
+            if (threadIdx.x == 0) DT<T>::st(gx + (long)(b0 + b) * in + i, s * alpha);
+        }
+    }
+}
+
 static void dense_split(int in, int out, int* ksplit, int* ipb) {
     const int tiles = cdiv(out, 64);
     int ks = 1024 / tiles;
@@ -246,7 +271,11 @@ extern "C" int gs_dense_bwd_data(const void* gy, const float* w, void* gx, int b
     hipStream_t st = as_stream(stream);
     for (int b0 = 0; b0 < b; b0 += DENSE_BT) {
         const int nb = b - b0 < DENSE_BT ? b - b0 : DENSE_BT;
-        GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dense_bwd_data_kernel<T>), dim3(cdiv(in, 4)), dim3(256), 0, st, (const T*)gy, w, (T*)gx, b0, nb, in, out, alpha));
+        if (out >= 2048) {
+            GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dense_bwd_data_wide_kernel<T>), dim3(in), dim3(256), 0, st, (const T*)gy, w, (T*)gx, b0, nb, in, out, alpha));
+        } else {
+            GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dense_bwd_data_kernel<T>), dim3(cdiv(in, 4)), dim3(256), 0, st, (const T*)gy, w, (T*)gx, b0, nb, in, out, alpha));
+        }
         GS_CHECK_LAUNCH();
     }
     return 0;

@@ -224,3 +224,11 @@ def test_conv2d_transpose_bf16(K, E):
     close(K.conv2d_transpose_fwd(dev(x, torch.bfloat16), dev(wt), alpha), E.conv2d_transpose_fwd(x, wt.bfloat16().float(), alpha), rel=1e-2, name="fwd")
     gy = rnd(n, co, 2 * h, 2 * w, seed=6).bfloat16().float()
     close(K.conv2d_transpose_bwd_weight(dev(x, torch.bfloat16), dev(gy, torch.bfloat16), alpha), E.conv2d_transpose_bwd_weight(x, gy, alpha), rel=1e-4, name="bwd_weight")
+
+
+@pytest.mark.parametrize("n,ci,co,h,w", [(2, 32, 2, 64, 256), (2, 2, 32, 64, 256), (4, 256, 2, 2, 16), (4, 2, 256, 2, 16), (3, 64, 2, 7, 9)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_thin_colour_weight_grad(K, E, n, ci, co, h, w, dtype):
+    x = rnd(n, ci, h, w, seed=1).to(dtype).float()
+    gy = rnd(n, co, h, w, seed=3).to(dtype).float()
+    close(K.conv2d_bwd_weight(dev(x, dtype), dev(gy, dtype), 1, 1, 0.25), E.conv2d_bwd_weight(x, gy, 1, 1, 0.25), rel=1e-4, name="thin wgrad")
