@@ -145,7 +145,7 @@ def main():
                        "global_batch": global_batch, "parallelism": "dp%d" % world},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK[args.dtype], "unit": "TFLOP/s",
                          "frac": achieved / PEAK[args.dtype], "traffic": None,
-                         "kernel": "conv_igemm_kernel + conv_wgrad_kernel (MFMA 3x3 conv family)",
+                         "kernel": "conv_igemm_kernel<*> (MFMA implicit-GEMM 3x3 conv: fwd, bwd-data, transposed conv; all instantiations)",
                          "launches": launches, "avg_launch_ms": conv_ms / max(launches, 1),
                          "time_share": conv_ms / (elapsed * 1e3)},
             "model_flops_utilization": value * FLOPS_PER_IMAGE / 1e12 / PEAK[args.dtype] / world,

@@ -111,7 +111,7 @@ struct ConvP {
     float alpha;
 };
 
-template <typename T, int MODE, int A, int B, int TW, int TG>
+template <typename T, int MODE, int A, int B, int TW, int TG, bool RESIDENT>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
     constexpr int NP = 128 * B;
     constexpr int TH = NP / TW;
@@ -121,7 +121,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
     constexpr int BK = 64 / (int)sizeof(T);
     constexpr int OCT = 32 * A;
     constexpr int NTG = 9 / TG;
-    constexpr bool RESIDENT = TG == 9;
     constexpr int PCH = PH * PW * 4;    // 16-byte slots of a patch chunk
     constexpr int WCH = TG * OCT * 4;   // 16-byte slots of one weight stage
     constexpr int PREG = (PCH + 255) / 256, WREG = (WCH + 255) / 256;
@@ -468,34 +467,44 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
 }
 
 // bf16 weight gradient on the bf16 MFMA (32x32x16, K = 16 pixels per instruction).
-// The contraction index is the PIXEL, but channels-last tiles keep channels contiguous, so each
-// lane's 8 k-values live in 8 different LDS rows: they are fetched as 16-bit LDS reads and packed
-// in registers.  The three horizontal taps of a kernel row read overlapping pixel windows
-// (p+kx .. p+kx+7), so one row costs 10 reads (stride 1) / 17 reads (stride 2) for 3 MFMAs and the
-// shifted fragments are rebuilt with v_alignbit -- 38 (59) LDS reads per 9 MFMAs, which balances
-// the LDS pipe against the matrix pipe.
-__device__ inline unsigned int pk16(unsigned short lo, unsigned short hi) { return (unsigned int)lo | ((unsigned int)hi << 16); }
+// The contraction index is the PIXEL, while channels-last global tiles keep channels contiguous, so the
+// tiles are TRANSPOSED while they are staged: LDS holds [channel][row][pixel] planes (pixel contiguous).
+// A lane's 8 k-values are then one aligned ds_read_b128, and the three horizontal taps of a kernel
+// row come from one 10-pixel window (b128 + b32) shifted with v_alignbit: 7 LDS reads + 12 VALU per
+// 9 MFMAs (stride 2: even/odd column planes, 13 reads).  Staging: a thread takes 2 (4) adjacent pixels x 8
+// channels, transposes 16-bit pairs with v_perm and issues 32-bit LDS writes; channel planes are pitched
+// an odd multiple of 16 bytes apart so that the 16-lane read groups hit 16 distinct bank slots.
+__device__ inline unsigned int perm_lo(unsigned int hi_src, unsigned int lo_src) { return __builtin_amdgcn_perm(hi_src, lo_src, 0x05040100u); }  // (lo_src.lo | hi_src.lo << 16)
+__device__ inline unsigned int perm_hi(unsigned int hi_src, unsigned int lo_src) { return __builtin_amdgcn_perm(hi_src, lo_src, 0x07060302u); }  // (lo_src.hi | hi_src.hi << 16)
 __device__ inline unsigned int shr16(unsigned int hi, unsigned int lo) { return __builtin_amdgcn_alignbit(hi, lo, 16); }
 __device__ inline bf16x8 mk_frag(unsigned int a, unsigned int b, unsigned int c, unsigned int d) {
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     u32x4 v = {a, b, c, d};
     return __builtin_bit_cast(bf16x8, v);
 }
+__host__ __device__ constexpr int odd16(int bytes) { return ((bytes + 15) / 16) % 2 ? ((bytes + 15) / 16) * 16 : ((bytes + 15) / 16 + 1) * 16; }
 
 template <int MODE, int TW>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(
     const bf16_t* __restrict__ x, const bf16_t* __restrict__ gy, float* __restrict__ part,
     int N, int Hi, int Wi, int IC, int OC, int Hb, int Wb, int tiles_x, int tiles_y, int ntiles, int nslices) {
-    constexpr int NP = MODE == MODE_S2 ? 128 : 256;
+    constexpr bool S2 = MODE == MODE_S2;
+    constexpr int NP = S2 ? 128 : 256;
     constexpr int TH = NP / TW;
     constexpr int PH = patch_dim<MODE>(TH), PW = patch_dim<MODE>(TW);
-    constexpr int S = MODE == MODE_S2 ? 2 : 1;
-    constexpr int ROW = 32;  // bf16 per LDS row (32 channels = 64 B)
-    constexpr int LDS_MAIN = (PH * PW + NP) * ROW * 2;
+    constexpr int XP = S2 ? TW + 8 : ((TW + 2 + 7) / 8) * 8;  // entries per row of the (even) x plane
+    constexpr int OP = TW;                                     // entries per row of the odd plane (stride 2 only)
+    constexpr int XCP = odd16((PH * XP + (S2 ? PH * OP : 0)) * 2);  // bytes between channel planes of x
+    constexpr int GCP = odd16(NP * 2);                               // bytes between channel planes of gy
+    constexpr int LDS_MAIN = 32 * XCP + 32 * GCP;
     constexpr int LDS_RED = 4 * 1024 * 4;
+    constexpr int PPT = S2 ? 4 : 2;                 // pixels handled per staging work item
+    constexpr int XG = (PW + PPT - 1) / PPT;        // pixel groups per patch row
+    constexpr int XITEMS = PH * XG * 4;             // x 4 channel groups of 8
+    constexpr int GITEMS = (NP / 2) * 4;
     __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_MAIN > LDS_RED ? LDS_MAIN : LDS_RED];
-    unsigned short* lp = reinterpret_cast<unsigned short*>(lds_raw);
-    unsigned short* lg = lp + PH * PW * ROW;
+    unsigned char* const lx_ = lds_raw;
+    unsigned char* const lg_ = lds_raw + 32 * XCP;
     float* lred = reinterpret_cast<float*>(lds_raw);
 
     const int tid = threadIdx.x;
@@ -503,6 +512,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(
     const int n_ict = IC / 32;
     const int ic0 = (blockIdx.x % n_ict) * 32, oc0 = (blockIdx.x / n_ict) * 32;
     const int slice = blockIdx.y;
+    // staging lane map inside a wave: 16 pixel groups x 4 channel groups (cg slow) -> coalesced 64-byte global
+    // segments per pixel and at most 2-way (free) conflicts on the 32-bit LDS writes
+    const int s_pg = lane & 15, s_cg = lane >> 4;
 
     f32x16 acc[9];
 #pragma unroll
@@ -517,55 +529,100 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(
         const int tile_y = b % tiles_y;
         const int n = b / tiles_y;
         const int by = tile_y * TH, bx = tile_x * TW;
-        const int oy0 = MODE == MODE_S2 ? 2 * by : by - 1;
-        const int ox0 = MODE == MODE_S2 ? 2 * bx : bx - 1;
+        const int oy0 = S2 ? 2 * by : by - 1;
+        const int ox0 = S2 ? 2 * bx : bx - 1;
         __syncthreads();
-        for (int c = tid; c < PH * PW * 4; c += 256) {
-            const int pix = c >> 2, part4 = c & 3;
-            const int ly = pix / PW, lx = pix % PW;
-            const int iy = oy0 + ly, ix = ox0 + lx;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (iy >= 0 && iy < Hi && ix >= 0 && ix < Wi)
-                v = *reinterpret_cast<const uint4*>(x + (((long)n * Hi + iy) * Wi + ix) * IC + ic0 + part4 * 8);
-            *reinterpret_cast<uint4*>(lp + pix * ROW + part4 * 8) = v;
+        // ---- x patch: transpose into [ic][row][pixel]
+        for (int base = wv * 16; base < PH * XG; base += 64) {
+            const int g = base + s_pg;
+            if (g < PH * XG) {
+                const int ly = g / XG, lx = (g - ly * XG) * PPT;
+                const int iy = oy0 + ly;
+                uint4 v[PPT];
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) {
+                    const int ix = ox0 + lx + k;
+                    v[k] = make_uint4(0, 0, 0, 0);
+                    if (iy >= 0 && iy < Hi && ix >= 0 && ix < Wi && lx + k < PW)
+                        v[k] = *reinterpret_cast<const uint4*>(x + (((long)n * Hi + iy) * Wi + ix) * IC + ic0 + s_cg * 8);
+                }
+                unsigned char* dst = lx_ + (s_cg * 8) * XCP;
+                if (!S2) {
+                    const unsigned int* a = reinterpret_cast<const unsigned int*>(&v[0]);
+                    const unsigned int* c = reinterpret_cast<const unsigned int*>(&v[PPT - 1]);
+                    unsigned char* d = dst + (ly * XP + lx) * 2;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        *reinterpret_cast<unsigned int*>(d + (2 * j) * XCP) = perm_lo(c[j], a[j]);
+                        *reinterpret_cast<unsigned int*>(d + (2 * j + 1) * XCP) = perm_hi(c[j], a[j]);
+                    }
+                } else {
+                    const unsigned int* p0 = reinterpret_cast<const unsigned int*>(&v[0]);
+                    const unsigned int* p1 = reinterpret_cast<const unsigned int*>(&v[1]);
+                    const unsigned int* p2 = reinterpret_cast<const unsigned int*>(&v[2]);
+                    const unsigned int* p3 = reinterpret_cast<const unsigned int*>(&v[3]);
+                    unsigned char* de = dst + (ly * XP + (lx >> 1)) * 2;            // even columns lx, lx+2
+                    unsigned char* dq = dst + (PH * XP + ly * OP + (lx >> 1)) * 2;  // odd columns lx+1, lx+3
+                    const bool odd_ok = (lx >> 1) + 1 < OP + 1 && (lx >> 1) < OP;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        *reinterpret_cast<unsigned int*>(de + (2 * j) * XCP) = perm_lo(p2[j], p0[j]);
+                        *reinterpret_cast<unsigned int*>(de + (2 * j + 1) * XCP) = perm_hi(p2[j], p0[j]);
+                        if (odd_ok) {
+                            *reinterpret_cast<unsigned int*>(dq + (2 * j) * XCP) = perm_lo(p3[j], p1[j]);
+                            *reinterpret_cast<unsigned int*>(dq + (2 * j + 1) * XCP) = perm_hi(p3[j], p1[j]);
+                        }
+                    }
+                }
+            }
         }
-        for (int c = tid; c < NP * 4; c += 256) {
-            const int pix = c >> 2, part4 = c & 3;
-            const int gy_ = by + pix / TW, gx_ = bx + pix % TW;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (gy_ < Hb && gx_ < Wb)
-                v = *reinterpret_cast<const uint4*>(gy + (((long)n * Hb + gy_) * Wb + gx_) * OC + oc0 + part4 * 8);
-            *reinterpret_cast<uint4*>(lg + pix * ROW + part4 * 8) = v;
+        // ---- gy tile: transpose into [oc][pixel]
+        for (int base = wv * 16; base < NP / 2; base += 64) {
+            const int pp = base + s_pg;  // pixel pair
+            const int p0 = pp * 2;
+            const int gy_ = by + p0 / TW, gx_ = bx + p0 % TW;
+            uint4 v0 = make_uint4(0, 0, 0, 0), v1 = make_uint4(0, 0, 0, 0);
+            if (gy_ < Hb) {
+                const bf16_t* src = gy + (((long)n * Hb + gy_) * Wb + gx_) * OC + oc0 + s_cg * 8;
+                if (gx_ < Wb) v0 = *reinterpret_cast<const uint4*>(src);
+                if (gx_ + 1 < Wb) v1 = *reinterpret_cast<const uint4*>(src + OC);
+            }
+            const unsigned int* a = reinterpret_cast<const unsigned int*>(&v0);
+            const unsigned int* c = reinterpret_cast<const unsigned int*>(&v1);
+            unsigned char* d = lg_ + (s_cg * 8) * GCP + p0 * 2;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                *reinterpret_cast<unsigned int*>(d + (2 * j) * GCP) = perm_lo(c[j], a[j]);
+                *reinterpret_cast<unsigned int*>(d + (2 * j + 1) * GCP) = perm_hi(c[j], a[j]);
+            }
         }
         __syncthreads();
+        // ---- MFMAs: wave wv takes pixel groups wv, wv+4, ...
         for (int g = wv; g < NP / 16; g += 4) {
             const int ty = (g * 16) / TW, tx0 = (g * 16) % TW + 8 * hi;
-            const unsigned short* gb = lg + (ty * TW + tx0) * ROW + l31;
-            const bf16x8 bfrag = mk_frag(pk16(gb[0], gb[ROW]), pk16(gb[2 * ROW], gb[3 * ROW]), pk16(gb[4 * ROW], gb[5 * ROW]),
-                                         pk16(gb[6 * ROW], gb[7 * ROW]));
+            const bf16x8 bfrag = *reinterpret_cast<const bf16x8*>(lg_ + l31 * GCP + (ty * TW + tx0) * 2);
+            const unsigned char* xb = lx_ + l31 * XCP;
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
-                const unsigned short* pb = lp + ((ty * S + ky) * PW + tx0 * S) * ROW + l31;
-                if (MODE == MODE_S2) {
-                    unsigned int E[5], O[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        E[q] = pk16(pb[(4 * q) * ROW], pb[(4 * q + 2) * ROW]);
-                        O[q] = pk16(pb[(4 * q + 1) * ROW], pb[(4 * q + 3) * ROW]);
-                    }
-                    E[4] = pb[16 * ROW];
-                    acc[ky * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk_frag(E[0], E[1], E[2], E[3]), bfrag, acc[ky * 3 + 0], 0, 0, 0);
-                    acc[ky * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk_frag(O[0], O[1], O[2], O[3]), bfrag, acc[ky * 3 + 1], 0, 0, 0);
-                    acc[ky * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                        mk_frag(shr16(E[1], E[0]), shr16(E[2], E[1]), shr16(E[3], E[2]), shr16(E[4], E[3])), bfrag, acc[ky * 3 + 2], 0, 0, 0);
-                } else {
-                    unsigned int R[5];
-#pragma unroll
-                    for (int q = 0; q < 5; ++q) R[q] = pk16(pb[(2 * q) * ROW], pb[(2 * q + 1) * ROW]);
-                    acc[ky * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk_frag(R[0], R[1], R[2], R[3]), bfrag, acc[ky * 3 + 0], 0, 0, 0);
+                if (!S2) {
+                    const unsigned char* rp = xb + ((ty + ky) * XP + tx0) * 2;
+                    const uint4 d = *reinterpret_cast<const uint4*>(rp);
+                    const unsigned int d4 = *reinterpret_cast<const unsigned int*>(rp + 16);
+                    acc[ky * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk_frag(d.x, d.y, d.z, d.w), bfrag, acc[ky * 3 + 0], 0, 0, 0);
                     acc[ky * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                        mk_frag(shr16(R[1], R[0]), shr16(R[2], R[1]), shr16(R[3], R[2]), shr16(R[4], R[3])), bfrag, acc[ky * 3 + 1], 0, 0, 0);
-                    acc[ky * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk_frag(R[1], R[2], R[3], R[4]), bfrag, acc[ky * 3 + 2], 0, 0, 0);
+                        mk_frag(shr16(d.y, d.x), shr16(d.z, d.y), shr16(d.w, d.z), shr16(d4, d.w)), bfrag, acc[ky * 3 + 1], 0, 0, 0);
+                    acc[ky * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk_frag(d.y, d.z, d.w, d4), bfrag, acc[ky * 3 + 2], 0, 0, 0);
+                } else {
+                    const int r = 2 * ty + ky;
+                    const unsigned char* ep = xb + (r * XP + tx0) * 2;
+                    const unsigned char* op = xb + (PH * XP + r * OP + tx0) * 2;
+                    const uint4 e = *reinterpret_cast<const uint4*>(ep);
+                    const unsigned int e4 = *reinterpret_cast<const unsigned int*>(ep + 16);
+                    const uint4 o = *reinterpret_cast<const uint4*>(op);
+                    acc[ky * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk_frag(e.x, e.y, e.z, e.w), bfrag, acc[ky * 3 + 0], 0, 0, 0);
+                    acc[ky * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk_frag(o.x, o.y, o.z, o.w), bfrag, acc[ky * 3 + 1], 0, 0, 0);
+                    acc[ky * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                        mk_frag(shr16(e.y, e.x), shr16(e.z, e.y), shr16(e.w, e.z), shr16(e4, e.w)), bfrag, acc[ky * 3 + 2], 0, 0, 0);
                 }
             }
         }
@@ -603,7 +660,7 @@ static int num_cus() {
     return g_num_cus;
 }
 
-template <typename T, int MODE, int A, int B, int TW, int TG>
+template <typename T, int MODE, int A, int B, int TW, int TG, bool RESIDENT = false>
 static int launch_igemm(ConvP p, hipStream_t st) {
     constexpr int NP = 128 * B;
     constexpr int TH = NP / TW;
@@ -615,10 +672,10 @@ static int launch_igemm(ConvP p, hipStream_t st) {
     p.nsp = p.N * p.tiles_x * p.tiles_y;
     p.noct = cdiv(p.OC, OCT);
     p.nch = p.IC / BK;
-    const int wbufs = TG == 9 ? p.nch : 2;
+    const int wbufs = RESIDENT ? p.nch : 2;
     const size_t lds = (size_t)2 * PH * PW * 64 + (size_t)wbufs * TG * OCT * 64;
     if (lds > 160 * 1024) return fail(GS_ERR_UNSUPPORTED, "conv igemm: %zu bytes of LDS needed", lds);
-    auto kern = conv_igemm_kernel<T, MODE, A, B, TW, TG>;
+    auto kern = conv_igemm_kernel<T, MODE, A, B, TW, TG, RESIDENT>;
     static size_t max_set = 0;  // per template instantiation
     if (lds > max_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -650,7 +707,7 @@ static int dispatch_igemm(ConvP p, hipStream_t st) {
     const long tiles128 = (long)p.N * cdiv(p.Hb, Wb >= 32 ? 4 : 8) * cdiv(Wb, Wb >= 32 ? 32 : 16);
     const bool wide = OC % 128 == 0 && tiles128 * (OC / 128) >= 2L * num_cus();
     if constexpr (MODE == MODE_T2) {
-        if (resident_ok && Wb >= 64) return launch_igemm<T, MODE, 1, 2, 64, 9>(p, st);
+        if (resident_ok && Wb >= 64) return launch_igemm<T, MODE, 1, 2, 64, 9, true>(p, st);
         if (OC == 32) return launch_igemm<T, MODE, 1, 1, 32, 3>(p, st);
         if (Wb >= 32) return launch_igemm<T, MODE, 2, 1, 32, 3>(p, st);
         return launch_igemm<T, MODE, 2, 1, 16, 3>(p, st);
@@ -663,8 +720,10 @@ static int dispatch_igemm(ConvP p, hipStream_t st) {
         if (Wb >= 32) return launch_igemm<T, MODE, 4, 1, 32, 3>(p, st);
         return launch_igemm<T, MODE, 4, 1, 16, 3>(p, st);
     } else {
-        if (resident_ok && Wb >= 64) return launch_igemm<T, MODE, 1, 2, 64, 9>(p, st);
+        if (resident_ok && Wb >= 64) return launch_igemm<T, MODE, 1, 2, 64, 9, true>(p, st);
         if (OC == 32) return launch_igemm<T, MODE, 1, 1, 32, 3>(p, st);
+        if (OC % 64 == 0 && Wb >= 32 && (long)p.N * cdiv(p.Hb, 8) * cdiv(Wb, 32) * (OC / 64) >= num_cus() / 2)
+            return launch_igemm<T, MODE, 2, 2, 32, 9>(p, st);
         if (!wide) {
             if (Wb >= 32) return launch_igemm<T, MODE, 2, 1, 32, 3>(p, st);
             return launch_igemm<T, MODE, 2, 1, 16, 3>(p, st);
@@ -746,7 +805,6 @@ int run_wgrad_mfma(int mode, const void* x, const void* gy, float* gw, int N, in
     float* part = reinterpret_cast<float*>(ws);
     dim3 grid((IC / 32) * (OC / 32), nslices);
     {
-        ProfScope ps(st, 2.0 * 9.0 * (double)N * Hb * Wb * IC * OC);
 #define GS_WG(TT, M, TWV)                                                                                              \
     hipLaunchKernelGGL((conv_wgrad_kernel<TT, M, TWV>), grid, dim3(256), 0, st, reinterpret_cast<const TT*>(x),        \
                        reinterpret_cast<const TT*>(gy), part, N, Hi, Wi, IC, OC, Hb, Wb, tiles_x, tiles_y, ntiles, nslices)

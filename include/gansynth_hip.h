@@ -43,7 +43,7 @@ int gs_version(void);
 int gs_init(void);
 
 /* ---------------------------------------------------------------- profiling hooks (bench.py)
- * When enabled, every launch of the MFMA implicit-GEMM conv kernels is bracketed by a pair of
+ * When enabled, every launch of conv_igemm_kernel (the MFMA implicit-GEMM conv) is bracketed by a pair of
  * HIP events on its own stream.  gs_prof_collect synchronises those events and returns the number
  * of launches, their summed duration (ms) and summed algorithmic FLOPs. */
 int gs_prof_enable(int on);
