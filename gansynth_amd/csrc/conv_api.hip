@@ -11,8 +11,8 @@ bool igemm_supported(int ic, int oc, int dtype);
 bool wgrad_mfma_supported(int ic, int oc, int dtype);
 size_t igemm_prep_bytes(int ic, int oc, int dtype);
 int run_igemm(int mode, int variant, const void* x, const float* w_hwio, void* y, int N, int Hi, int Wi, int ICk,
-              int OCk, int w_ci, int w_co, int Hb, int Wb, float alpha, const float* bias, int act, int dtype, void* ws,
-              size_t ws_bytes, hipStream_t st);
+              int OCk, int w_ci, int w_co, int Hb, int Wb, float alpha, const float* bias, int act, int dtype, int w_prepared,
+              void* ws, size_t ws_bytes, hipStream_t st);
 size_t wgrad_mfma_bytes(int mode, int dtype, int N, int Hb, int Wb, int IC, int OC);
 int run_wgrad_mfma(int mode, const void* x, const void* gy, float* gw, int N, int Hi, int Wi, int IC, int OC, int Hb,
                    int Wb, float alpha, int transpose, int dtype, void* ws, size_t ws_bytes, hipStream_t st);
@@ -104,13 +104,15 @@ static int launch_direct(const T* x, const float* wp, T* y, int mode, int ks, in
 
 // direct conv through the fp32 prepped weights living in ws
 static int run_direct(int mode, int ks, int variant, const void* x, const float* w_hwio, void* y, int N, int Hi, int Wi,
-                      int ICk, int OCk, int w_ci, int w_co, int Ho, int Wo, float alpha, int dtype, void* ws,
+                      int ICk, int OCk, int w_ci, int w_co, int Ho, int Wo, float alpha, int dtype, int w_prepared, void* ws,
                       size_t ws_bytes, hipStream_t st) {
     const long total = (long)ks * ks * w_ci * w_co;
     if (ws_bytes < (size_t)total * 4) return fail(GS_ERR_WORKSPACE, "conv direct: workspace %zu < %zu", ws_bytes, (size_t)total * 4);
     float* wp = reinterpret_cast<float*>(ws);
-    hipLaunchKernelGGL((weight_prep_kernel<float>), dim3(cdiv(total, 256)), dim3(256), 0, st, w_hwio, wp, ks * ks, w_ci, w_co, variant);
-    GS_CHECK_LAUNCH();
+    if (!w_prepared) {
+        hipLaunchKernelGGL((weight_prep_kernel<float>), dim3(cdiv(total, 256)), dim3(256), 0, st, w_hwio, wp, ks * ks, w_ci, w_co, variant);
+        GS_CHECK_LAUNCH();
+    }
     GS_DISPATCH_DTYPE(dtype, return launch_direct<T>(reinterpret_cast<const T*>(x), wp, reinterpret_cast<T*>(y), mode, ks,
                                                      N, Hi, Wi, ICk, OCk, Ho, Wo, alpha, st));
 }
@@ -286,30 +288,49 @@ extern "C" size_t gs_conv2d_workspace_bytes(int which, int n, int h, int w, int 
     return align256((size_t)ksize * ksize * ci * co * 4);
 }
 
-extern "C" int gs_conv2d_fwd(const void* x, const float* w_hwio, void* y, int n, int h, int w, int ci, int co, int ksize,
-                             int stride, float alpha, int dtype, void* ws, size_t ws_bytes, void* stream) {
+// the bias/activation epilogue for the shapes that do not go through the MFMA kernel
+extern "C" int gs_bias_act_fwd(const void* x, const float* bias, void* y, int64_t p, int c, int act, int dtype, void* stream);
+
+static int conv2d_fwd_impl(const void* x, const float* w_hwio, const float* bias, int act, void* y, int n, int h, int w, int ci, int co, int ksize,
+                           int stride, float alpha, int dtype, int w_prepared, void* ws, size_t ws_bytes, void* stream) {
     if (int e = check_conv_args(n, h, w, ci, co, ksize, stride, dtype)) return e;
+    GS_CHECK_ARG(act == GS_ACT_NONE || act == GS_ACT_LRELU || act == GS_ACT_TANH, "conv2d: bad activation %d", act);
     hipStream_t st = as_stream(stream);
     const int hb = h / stride, wb = w / stride;
     const int mode = stride == 2 ? MODE_S2 : MODE_S1;
-    if (ksize == 3 && igemm_supported(ci, co, dtype))
-        return run_igemm(mode, 0, x, w_hwio, y, n, h, w, ci, co, ci, co, hb, wb, alpha, nullptr, 0, dtype, ws, ws_bytes, st);
-    return run_direct(mode, ksize, 0, x, w_hwio, y, n, h, w, ci, co, ci, co, hb, wb, alpha, dtype, ws, ws_bytes, st);
+    if (ksize == 3 && igemm_supported(ci, co, dtype) && act != GS_ACT_TANH)
+        return run_igemm(mode, 0, x, w_hwio, y, n, h, w, ci, co, ci, co, hb, wb, alpha, bias, act, dtype, w_prepared, ws, ws_bytes, st);
+    if (int e = run_direct(mode, ksize, 0, x, w_hwio, y, n, h, w, ci, co, ci, co, hb, wb, alpha, dtype, w_prepared, ws, ws_bytes, st)) return e;
+    if (bias || act != GS_ACT_NONE) return gs_bias_act_fwd(y, bias, y, (int64_t)n * hb * wb, co, act, dtype, stream);
+    return 0;
+}
+
+extern "C" int gs_conv2d_fwd(const void* x, const float* w_hwio, void* y, int n, int h, int w, int ci, int co, int ksize,
+                             int stride, float alpha, int dtype, int w_prepared, void* ws, size_t ws_bytes, void* stream) {
+    return conv2d_fwd_impl(x, w_hwio, nullptr, GS_ACT_NONE, y, n, h, w, ci, co, ksize, stride, alpha, dtype, w_prepared, ws, ws_bytes, stream);
+}
+
+extern "C" int gs_conv2d_fwd_bias_act(const void* x, const float* w_hwio, const float* bias, void* y, int n, int h, int w, int ci, int co,
+                                      int ksize, int stride, float alpha, int act, int dtype, int w_prepared, void* ws, size_t ws_bytes,
+                                      void* stream) {
+    return conv2d_fwd_impl(x, w_hwio, bias, act, y, n, h, w, ci, co, ksize, stride, alpha, dtype, w_prepared, ws, ws_bytes, stream);
 }
 
 extern "C" int gs_conv2d_bwd_data(const void* gy, const float* w_hwio, void* gx, int n, int h, int w, int ci, int co,
-                                  int ksize, int stride, float alpha, int dtype, void* ws, size_t ws_bytes, void* stream) {
+                                  int ksize, int stride, float alpha, int dtype, int w_prepared, void* ws, size_t ws_bytes, void* stream) {
     if (int e = check_conv_args(n, h, w, ci, co, ksize, stride, dtype)) return e;
+    const float* bias = nullptr;
+    const int act = GS_ACT_NONE;
     hipStream_t st = as_stream(stream);
     const int hb = h / stride, wb = w / stride;
     if (stride == 1) {  // flipped taps, roles of ci/co swapped
         if (ksize == 3 && igemm_supported(co, ci, dtype))
-            return run_igemm(MODE_S1, 1, gy, w_hwio, gx, n, h, w, co, ci, ci, co, h, w, alpha, nullptr, 0, dtype, ws, ws_bytes, st);
-        return run_direct(MODE_S1, ksize, 1, gy, w_hwio, gx, n, h, w, co, ci, ci, co, h, w, alpha, dtype, ws, ws_bytes, st);
+            return run_igemm(MODE_S1, 1, gy, w_hwio, gx, n, h, w, co, ci, ci, co, h, w, alpha, bias, act, dtype, w_prepared, ws, ws_bytes, st);
+        return run_direct(MODE_S1, ksize, 1, gy, w_hwio, gx, n, h, w, co, ci, ci, co, h, w, alpha, dtype, w_prepared, ws, ws_bytes, st);
     }
     if (igemm_supported(co, ci, dtype))
-        return run_igemm(MODE_T2, 2, gy, w_hwio, gx, n, hb, wb, co, ci, ci, co, hb, wb, alpha, nullptr, 0, dtype, ws, ws_bytes, st);
-    return run_direct(MODE_T2, 3, 2, gy, w_hwio, gx, n, hb, wb, co, ci, ci, co, h, w, alpha, dtype, ws, ws_bytes, st);
+        return run_igemm(MODE_T2, 2, gy, w_hwio, gx, n, hb, wb, co, ci, ci, co, hb, wb, alpha, bias, act, dtype, w_prepared, ws, ws_bytes, st);
+    return run_direct(MODE_T2, 3, 2, gy, w_hwio, gx, n, hb, wb, co, ci, ci, co, h, w, alpha, dtype, w_prepared, ws, ws_bytes, st);
 }
 
 extern "C" int gs_conv2d_bwd_weight(const void* x, const void* gy, float* gw_hwio, int n, int h, int w, int ci, int co,
@@ -332,24 +353,39 @@ extern "C" size_t gs_conv2d_transpose_s2_workspace_bytes(int which, int n, int h
     return align256((size_t)9 * ci * co * 4);
 }
 
-extern "C" int gs_conv2d_transpose_s2_fwd(const void* x, const float* w_hwio, void* y, int n, int h, int w, int ci, int co,
-                                          float alpha, int dtype, void* ws, size_t ws_bytes, void* stream) {
+static int conv2d_transpose_fwd_impl(const void* x, const float* w_hwio, const float* bias, int act, void* y, int n, int h, int w, int ci,
+                                     int co, float alpha, int dtype, int w_prepared, void* ws, size_t ws_bytes, void* stream) {
     if (int e = check_conv_args(n, 2 * h, 2 * w, co, ci, 3, 2, dtype)) return e;
     hipStream_t st = as_stream(stream);
     // out[2i+k][co] += x[i][ci] * w[k][ci][co]: kernel roles ICk = ci, OCk = co, Wp[t][co][ci] (variant 0)
-    if (igemm_supported(ci, co, dtype))
-        return run_igemm(MODE_T2, 0, x, w_hwio, y, n, h, w, ci, co, ci, co, h, w, alpha, nullptr, 0, dtype, ws, ws_bytes, st);
-    return run_direct(MODE_T2, 3, 0, x, w_hwio, y, n, h, w, ci, co, ci, co, 2 * h, 2 * w, alpha, dtype, ws, ws_bytes, st);
+    if (igemm_supported(ci, co, dtype) && act != GS_ACT_TANH)
+        return run_igemm(MODE_T2, 0, x, w_hwio, y, n, h, w, ci, co, ci, co, h, w, alpha, bias, act, dtype, w_prepared, ws, ws_bytes, st);
+    if (int e = run_direct(MODE_T2, 3, 0, x, w_hwio, y, n, h, w, ci, co, ci, co, 2 * h, 2 * w, alpha, dtype, w_prepared, ws, ws_bytes, st)) return e;
+    if (bias || act != GS_ACT_NONE) return gs_bias_act_fwd(y, bias, y, (int64_t)n * 4 * h * w, co, act, dtype, stream);
+    return 0;
+}
+
+extern "C" int gs_conv2d_transpose_s2_fwd(const void* x, const float* w_hwio, void* y, int n, int h, int w, int ci, int co,
+                                          float alpha, int dtype, int w_prepared, void* ws, size_t ws_bytes, void* stream) {
+    return conv2d_transpose_fwd_impl(x, w_hwio, nullptr, GS_ACT_NONE, y, n, h, w, ci, co, alpha, dtype, w_prepared, ws, ws_bytes, stream);
+}
+
+extern "C" int gs_conv2d_transpose_s2_fwd_bias_act(const void* x, const float* w_hwio, const float* bias, void* y, int n, int h, int w, int ci,
+                                                   int co, float alpha, int act, int dtype, int w_prepared, void* ws, size_t ws_bytes,
+                                                   void* stream) {
+    return conv2d_transpose_fwd_impl(x, w_hwio, bias, act, y, n, h, w, ci, co, alpha, dtype, w_prepared, ws, ws_bytes, stream);
 }
 
 extern "C" int gs_conv2d_transpose_s2_bwd_data(const void* gy, const float* w_hwio, void* gx, int n, int h, int w, int ci,
-                                               int co, float alpha, int dtype, void* ws, size_t ws_bytes, void* stream) {
+                                               int co, float alpha, int dtype, int w_prepared, void* ws, size_t ws_bytes, void* stream) {
     if (int e = check_conv_args(n, 2 * h, 2 * w, co, ci, 3, 2, dtype)) return e;
+    const float* bias = nullptr;
+    const int act = GS_ACT_NONE;
     hipStream_t st = as_stream(stream);
     // gx[i][ci] = sum gy[2i+k][co] * w[k][ci][co]: stride-2 conv, roles ICk = co, OCk = ci, Wp[t][ci][co] (variant 2)
     if (igemm_supported(co, ci, dtype))
-        return run_igemm(MODE_S2, 2, gy, w_hwio, gx, n, 2 * h, 2 * w, co, ci, ci, co, h, w, alpha, nullptr, 0, dtype, ws, ws_bytes, st);
-    return run_direct(MODE_S2, 3, 2, gy, w_hwio, gx, n, 2 * h, 2 * w, co, ci, ci, co, h, w, alpha, dtype, ws, ws_bytes, st);
+        return run_igemm(MODE_S2, 2, gy, w_hwio, gx, n, 2 * h, 2 * w, co, ci, ci, co, h, w, alpha, bias, act, dtype, w_prepared, ws, ws_bytes, st);
+    return run_direct(MODE_S2, 3, 2, gy, w_hwio, gx, n, 2 * h, 2 * w, co, ci, ci, co, h, w, alpha, dtype, w_prepared, ws, ws_bytes, st);
 }
 
 extern "C" int gs_conv2d_transpose_s2_bwd_weight(const void* x, const void* gy, float* gw_hwio, int n, int h, int w, int ci,

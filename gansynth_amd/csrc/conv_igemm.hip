@@ -159,6 +159,31 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
 
     uint4 preg[PREG], wreg[WREG];
 
+    // ---- per-thread staging descriptors, constant for the life of the block (keeps the per-stage address
+    //      arithmetic down to one add + two unsigned compares per 16-byte slot)
+    int p_ll[PREG], p_off[PREG], p_lds[PREG];
+#pragma unroll
+    for (int r = 0; r < PREG; ++r) {
+        const int c = tid + 256 * r;
+        const int pix = c >> 2, part = c & 3;
+        const int ly = pix / PW, lx = pix - ly * PW;
+        const bool ok = c < PCH;
+        p_ll[r] = ok ? ((ly << 16) | lx) : 0x7fff0000;
+        p_off[r] = ((ly * Wi + lx) * IC) * (int)sizeof(T) + part * 16;
+        p_lds[r] = ok ? pix * 64 + ((part ^ ((lx >> 2) & 3)) << 4) : -1;
+    }
+    int w_off[WREG], w_lds[WREG];
+#pragma unroll
+    for (int r = 0; r < WREG; ++r) {
+        const int c = tid + 256 * r;
+        const int R = c >> 2, part = c & 3;
+        const int row = R % OCT, tt = R / OCT;
+        const bool ok = c < WCH;
+        if (MODE == MODE_T2) w_off[r] = ok ? ((tt << 16) | row) : -1;  // tap order is a permutation: resolved per stage
+        else w_off[r] = ok ? (tt * OC + row) * IC * (int)sizeof(T) + part * 16 : -1;
+        w_lds[r] = ok ? R * 64 + ((part ^ ((R >> 2) & 3)) << 4) : -1;
+    }
+
     auto item_coords = [&](int item, int& n, int& by, int& bx, int& oc0) {
         const int sp = item / p.noct;
         oc0 = (item - sp * p.noct) * OCT;
@@ -173,59 +198,50 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
         item_coords(item, n, by, bx, oc0);
         const int oy0 = MODE == MODE_S2 ? 2 * by : by - 1;
         const int ox0 = MODE == MODE_S2 ? 2 * bx : bx - 1;
-        const T* xb = x + (long)n * Hi * Wi * IC + ch * BK;
+        const unsigned char* xb = reinterpret_cast<const unsigned char*>(x) +
+                                  ((((long)n * Hi + oy0) * Wi + ox0) * IC + ch * BK) * (long)sizeof(T);
 #pragma unroll
         for (int r = 0; r < PREG; ++r) {
-            const int c = tid + 256 * r;
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (c < PCH) {
-                const int pix = c >> 2, part = c & 3;
-                const int ly = pix / PW, lx = pix - ly * PW;
-                const int iy = oy0 + ly, ix = ox0 + lx;
-                if (iy >= 0 && iy < Hi && ix >= 0 && ix < Wi)
-                    v = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(xb + ((long)iy * Wi + ix) * IC) + part * 16);
-            }
+            if ((unsigned)(oy0 + (p_ll[r] >> 16)) < (unsigned)Hi && (unsigned)(ox0 + (p_ll[r] & 0xffff)) < (unsigned)Wi)
+                v = *reinterpret_cast<const uint4*>(xb + p_off[r]);
             preg[r] = v;
         }
     };
     auto store_patch = [&](int buf) {
         unsigned char* dst = lpatch + buf * PBYTES;
 #pragma unroll
-        for (int r = 0; r < PREG; ++r) {
-            const int c = tid + 256 * r;
-            if (c < PCH) {
-                const int pix = c >> 2, part = c & 3;
-                *reinterpret_cast<uint4*>(dst + pix * 64 + ((part ^ ((pix >> 2) & 3)) << 4)) = preg[r];
-            }
-        }
+        for (int r = 0; r < PREG; ++r)
+            if (p_lds[r] >= 0) *reinterpret_cast<uint4*>(dst + p_lds[r]) = preg[r];
     };
     auto load_weights = [&](int oc0, int ch, int tg) {
+        if (MODE != MODE_T2) {
+            const unsigned char* wb = reinterpret_cast<const unsigned char*>(wp) +
+                                      (((long)tg * TG * OC + oc0) * IC + ch * BK) * (long)sizeof(T);
 #pragma unroll
-        for (int r = 0; r < WREG; ++r) {
-            const int c = tid + 256 * r;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (c < WCH) {
-                const int part = c & 3;
-                const int row = (c >> 2) % OCT;
-                const int i = tg * TG + (c >> 2) / OCT;
-                if (oc0 + row < OC) {
+            for (int r = 0; r < WREG; ++r) {
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (w_off[r] >= 0) v = *reinterpret_cast<const uint4*>(wb + w_off[r]);
+                wreg[r] = v;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < WREG; ++r) {
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (w_off[r] >= 0) {
+                    const int i = tg * TG + (w_off[r] >> 16), row = w_off[r] & 0xffff;
                     const int wt = tap_ky<MODE>(i) * 3 + tap_kx<MODE>(i);
                     const T* src = wp + ((long)wt * OC + oc0 + row) * IC + ch * BK;
-                    v = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(src) + part * 16);
+                    v = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(src) + ((tid + 256 * r) & 3) * 16);
                 }
+                wreg[r] = v;
             }
-            wreg[r] = v;
         }
     };
     auto store_weights = [&](unsigned char* dst) {
 #pragma unroll
-        for (int r = 0; r < WREG; ++r) {
-            const int c = tid + 256 * r;
-            if (c < WCH) {
-                const int R = c >> 2, part = c & 3;
-                *reinterpret_cast<uint4*>(dst + R * 64 + ((part ^ ((R >> 2) & 3)) << 4)) = wreg[r];
-            }
-        }
+        for (int r = 0; r < WREG; ++r)
+            if (w_lds[r] >= 0) *reinterpret_cast<uint4*>(dst + w_lds[r]) = wreg[r];
     };
 
     f32x16 acc[NPH][A][B];
@@ -240,13 +256,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
                     for (int r = 0; r < 16; ++r) acc[ph][a][b][r] = 0.f;
     };
 
-    int pixbase[B];  // patch pixel index of this lane's base pixel (tap offset added per tap)
+    // fragment byte offsets with the slot swizzle folded in: B side per (pixel group, horizontal tap offset, k step),
+    // A side per k step; the vertical tap offset and the tap / channel-tile row are compile-time immediates
+    int b_off[B][3][2], a_off[2];
 #pragma unroll
     for (int b = 0; b < B; ++b) {
         const int q = (wv * B + b) * 32 + l31;
-        pixbase[b] = ((q / TW) * S) * PW + (q % TW) * S;
+        const int pb0 = ((q / TW) * S) * PW + (q % TW) * S;
+#pragma unroll
+        for (int ox = 0; ox < 3; ++ox) {
+            const int key = (((q % TW) * S + ox) >> 2) & 3;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) b_off[b][ox][ks] = (pb0 + ox) * 64 + (((ks * 2 + hi) ^ key) << 4);
+        }
     }
-    const int aswz = (l31 >> 2) & 3;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) a_off[ks] = l31 * 64 + (((ks * 2 + hi) ^ ((l31 >> 2) & 3)) << 4);
 
     // ---- prologue
     int item = first, done = 0;
@@ -300,23 +325,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
                 for (int tt = 0; tt < TG; ++tt) {
                     const int i = tg * TG + tt;
                     const int ph = tap_phase<MODE>(i);
-                    const int toff = tap_off<MODE>(tap_ky<MODE>(i)) * PW + tap_off<MODE>(tap_kx<MODE>(i));
-                    int boff[B], bswz[B];
-#pragma unroll
-                    for (int b = 0; b < B; ++b) {
-                        const int pidx = pixbase[b] + toff;
-                        boff[b] = pidx * 64;
-                        bswz[b] = (pidx >> 2) & 3;
-                    }
+                    const int oyv = tap_off<MODE>(tap_ky<MODE>(i)), oxv = tap_off<MODE>(tap_kx<MODE>(i));
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks) {
                         frag_t af[A], bf[B];
 #pragma unroll
                         for (int a = 0; a < A; ++a)
-                            af[a] = *reinterpret_cast<const frag_t*>(lw + (tt * OCT + a * 32 + l31) * 64 + (((ks * 2 + hi) ^ aswz) << 4));
+                            af[a] = *reinterpret_cast<const frag_t*>(lw + (tt * OCT + a * 32) * 64 + a_off[ks]);
 #pragma unroll
                         for (int b = 0; b < B; ++b)
-                            bf[b] = *reinterpret_cast<const frag_t*>(lp + boff[b] + (((ks * 2 + hi) ^ bswz[b]) << 4));
+                            bf[b] = *reinterpret_cast<const frag_t*>(lp + oyv * PW * 64 + b_off[b][oxv][ks]);
 #pragma unroll
                         for (int a = 0; a < A; ++a)
 #pragma unroll
@@ -467,58 +485,56 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
 }
 
 // bf16 weight gradient on the bf16 MFMA (32x32x16, K = 16 pixels per instruction).
-// The contraction index is the PIXEL, while channels-last global tiles keep channels contiguous, so the
-// tiles are TRANSPOSED while they are staged: LDS holds [channel][row][pixel] planes (pixel contiguous).
-// A lane's 8 k-values are then one aligned ds_read_b128, and the three horizontal taps of a kernel
-// row come from one 10-pixel window (b128 + b32) shifted with v_alignbit: 7 LDS reads + 12 VALU per
-// 9 MFMAs (stride 2: even/odd column planes, 13 reads).  Staging: a thread takes 2 (4) adjacent pixels x 8
-// channels, transposes 16-bit pairs with v_perm and issues 32-bit LDS writes; channel planes are pitched
-// an odd multiple of 16 bytes apart so that the 16-lane read groups hit 16 distinct bank slots.
-__device__ inline unsigned int perm_lo(unsigned int hi_src, unsigned int lo_src) { return __builtin_amdgcn_perm(hi_src, lo_src, 0x05040100u); }  // (lo_src.lo | hi_src.lo << 16)
-__device__ inline unsigned int perm_hi(unsigned int hi_src, unsigned int lo_src) { return __builtin_amdgcn_perm(hi_src, lo_src, 0x07060302u); }  // (lo_src.hi | hi_src.hi << 16)
+// The contraction index is the PIXEL while channels-last tiles keep channels contiguous, i.e. the operands
+// sit K-major in LDS ([pixel][32 channels], 64-byte rows, staged with plain 16-byte copies).  gfx950's
+// transposing LDS read ds_read_b64_tr_b16 turns that into K-contiguous fragments for free.  Measured
+// semantics (scripts/probe/tr_probe.hip): inside each 16-lane group, lane s supplies the address of 4
+// consecutive b16 (8 bytes); lane i = 4m + pos receives, for j = 0..3, element `pos` of the data supplied
+// by lane 4j + m.  With lane s pointing at (pixel row k0 + (s >> 2), channels 4(s & 3)..+3) every lane gets
+// 4 consecutive pixels of its own channel; two reads = one MFMA operand.  The three horizontal taps of a
+// kernel row use overlapping pixel windows, so 3 reads (12 pixels) + 4 v_alignbit feed 3 MFMAs.
+// Block = 192 threads = 3 waves; wave w owns kernel row ky = w (3 taps, 48 fp32 accumulators) over all pixels
+// of the tile: no cross-wave reduction, small register footprint, 3 blocks per CU.
 __device__ inline unsigned int shr16(unsigned int hi, unsigned int lo) { return __builtin_amdgcn_alignbit(hi, lo, 16); }
 __device__ inline bf16x8 mk_frag(unsigned int a, unsigned int b, unsigned int c, unsigned int d) {
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     u32x4 v = {a, b, c, d};
     return __builtin_bit_cast(bf16x8, v);
 }
-__host__ __device__ constexpr int odd16(int bytes) { return ((bytes + 15) / 16) % 2 ? ((bytes + 15) / 16) * 16 : ((bytes + 15) / 16 + 1) * 16; }
+__device__ inline uint2 lds_tr16(const unsigned char* p) {
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (s16x4 __attribute__((address_space(3)))*)(reinterpret_cast<const s16x4*>(p)));
+    return __builtin_bit_cast(uint2, v);
+}
 
 template <int MODE, int TW>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(
+__global__ __launch_bounds__(192) void conv_wgrad_bf16_kernel(
     const bf16_t* __restrict__ x, const bf16_t* __restrict__ gy, float* __restrict__ part,
     int N, int Hi, int Wi, int IC, int OC, int Hb, int Wb, int tiles_x, int tiles_y, int ntiles, int nslices) {
     constexpr bool S2 = MODE == MODE_S2;
     constexpr int NP = S2 ? 128 : 256;
     constexpr int TH = NP / TW;
     constexpr int PH = patch_dim<MODE>(TH), PW = patch_dim<MODE>(TW);
-    constexpr int XP = S2 ? TW + 8 : ((TW + 2 + 7) / 8) * 8;  // entries per row of the (even) x plane
-    constexpr int OP = TW;                                     // entries per row of the odd plane (stride 2 only)
-    constexpr int XCP = odd16((PH * XP + (S2 ? PH * OP : 0)) * 2);  // bytes between channel planes of x
-    constexpr int GCP = odd16(NP * 2);                               // bytes between channel planes of gy
-    constexpr int LDS_MAIN = 32 * XCP + 32 * GCP;
-    constexpr int LDS_RED = 4 * 1024 * 4;
-    constexpr int PPT = S2 ? 4 : 2;                 // pixels handled per staging work item
-    constexpr int XG = (PW + PPT - 1) / PPT;        // pixel groups per patch row
-    constexpr int XITEMS = PH * XG * 4;             // x 4 channel groups of 8
-    constexpr int GITEMS = (NP / 2) * 4;
-    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_MAIN > LDS_RED ? LDS_MAIN : LDS_RED];
+    constexpr int S = S2 ? 2 : 1;
+    constexpr int XCH = PH * PW * 4, GCH = NP * 4;          // 16-byte chunks to stage
+    constexpr int XIT = (XCH + 191) / 192, GIT = (GCH + 191) / 192;
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[(PH * PW + NP) * 64];
     unsigned char* const lx_ = lds_raw;
-    unsigned char* const lg_ = lds_raw + 32 * XCP;
-    float* lred = reinterpret_cast<float*>(lds_raw);
+    unsigned char* const lg_ = lds_raw + PH * PW * 64;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6, hi = lane >> 5, l31 = lane & 31;
     const int n_ict = IC / 32;
     const int ic0 = (blockIdx.x % n_ict) * 32, oc0 = (blockIdx.x / n_ict) * 32;
     const int slice = blockIdx.y;
-    // staging lane map inside a wave: 16 pixel groups x 4 channel groups (cg slow) -> coalesced 64-byte global
-    // segments per pixel and at most 2-way (free) conflicts on the 32-bit LDS writes
-    const int s_pg = lane & 15, s_cg = lane >> 4;
+    // transposing-read supplier role of this lane: pixel row (lane & 15) >> 2 of the 4-row block, channel quad
+    const int t_row = (lane & 15) >> 2;
+    const int t_col = (((lane >> 4) & 1) * 16 + (lane & 3) * 4) * 2;  // byte offset inside the 64-byte row
 
-    f32x16 acc[9];
+    f32x16 acc[3];
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < 3; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
@@ -531,118 +547,67 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(
         const int by = tile_y * TH, bx = tile_x * TW;
         const int oy0 = S2 ? 2 * by : by - 1;
         const int ox0 = S2 ? 2 * bx : bx - 1;
-        __syncthreads();
-        // ---- x patch: transpose into [ic][row][pixel]
-        for (int base = wv * 16; base < PH * XG; base += 64) {
-            const int g = base + s_pg;
-            if (g < PH * XG) {
-                const int ly = g / XG, lx = (g - ly * XG) * PPT;
-                const int iy = oy0 + ly;
-                uint4 v[PPT];
+        uint4 xv[XIT], gv[GIT];
 #pragma unroll
-                for (int k = 0; k < PPT; ++k) {
-                    const int ix = ox0 + lx + k;
-                    v[k] = make_uint4(0, 0, 0, 0);
-                    if (iy >= 0 && iy < Hi && ix >= 0 && ix < Wi && lx + k < PW)
-                        v[k] = *reinterpret_cast<const uint4*>(x + (((long)n * Hi + iy) * Wi + ix) * IC + ic0 + s_cg * 8);
-                }
-                unsigned char* dst = lx_ + (s_cg * 8) * XCP;
-                if (!S2) {
-                    const unsigned int* a = reinterpret_cast<const unsigned int*>(&v[0]);
-                    const unsigned int* c = reinterpret_cast<const unsigned int*>(&v[PPT - 1]);
-                    unsigned char* d = dst + (ly * XP + lx) * 2;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        *reinterpret_cast<unsigned int*>(d + (2 * j) * XCP) = perm_lo(c[j], a[j]);
-                        *reinterpret_cast<unsigned int*>(d + (2 * j + 1) * XCP) = perm_hi(c[j], a[j]);
-                    }
-                } else {
-                    const unsigned int* p0 = reinterpret_cast<const unsigned int*>(&v[0]);
-                    const unsigned int* p1 = reinterpret_cast<const unsigned int*>(&v[1]);
-                    const unsigned int* p2 = reinterpret_cast<const unsigned int*>(&v[2]);
-                    const unsigned int* p3 = reinterpret_cast<const unsigned int*>(&v[3]);
-                    unsigned char* de = dst + (ly * XP + (lx >> 1)) * 2;            // even columns lx, lx+2
-                    unsigned char* dq = dst + (PH * XP + ly * OP + (lx >> 1)) * 2;  // odd columns lx+1, lx+3
-                    const bool odd_ok = (lx >> 1) + 1 < OP + 1 && (lx >> 1) < OP;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        *reinterpret_cast<unsigned int*>(de + (2 * j) * XCP) = perm_lo(p2[j], p0[j]);
-                        *reinterpret_cast<unsigned int*>(de + (2 * j + 1) * XCP) = perm_hi(p2[j], p0[j]);
-                        if (odd_ok) {
-                            *reinterpret_cast<unsigned int*>(dq + (2 * j) * XCP) = perm_lo(p3[j], p1[j]);
-                            *reinterpret_cast<unsigned int*>(dq + (2 * j + 1) * XCP) = perm_hi(p3[j], p1[j]);
-                        }
-                    }
-                }
-            }
+        for (int it = 0; it < XIT; ++it) {
+            const int c = tid + 192 * it;
+            const int pix = c >> 2, part4 = c & 3;
+            const int ly = pix / PW, lx = pix - ly * PW;
+            const int iy = oy0 + ly, ix = ox0 + lx;
+            xv[it] = make_uint4(0, 0, 0, 0);
+            if (c < XCH && iy >= 0 && iy < Hi && ix >= 0 && ix < Wi)
+                xv[it] = *reinterpret_cast<const uint4*>(x + (((long)n * Hi + iy) * Wi + ix) * IC + ic0 + part4 * 8);
         }
-        // ---- gy tile: transpose into [oc][pixel]
-        for (int base = wv * 16; base < NP / 2; base += 64) {
-            const int pp = base + s_pg;  // pixel pair
-            const int p0 = pp * 2;
-            const int gy_ = by + p0 / TW, gx_ = bx + p0 % TW;
-            uint4 v0 = make_uint4(0, 0, 0, 0), v1 = make_uint4(0, 0, 0, 0);
-            if (gy_ < Hb) {
-                const bf16_t* src = gy + (((long)n * Hb + gy_) * Wb + gx_) * OC + oc0 + s_cg * 8;
-                if (gx_ < Wb) v0 = *reinterpret_cast<const uint4*>(src);
-                if (gx_ + 1 < Wb) v1 = *reinterpret_cast<const uint4*>(src + OC);
-            }
-            const unsigned int* a = reinterpret_cast<const unsigned int*>(&v0);
-            const unsigned int* c = reinterpret_cast<const unsigned int*>(&v1);
-            unsigned char* d = lg_ + (s_cg * 8) * GCP + p0 * 2;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                *reinterpret_cast<unsigned int*>(d + (2 * j) * GCP) = perm_lo(c[j], a[j]);
-                *reinterpret_cast<unsigned int*>(d + (2 * j + 1) * GCP) = perm_hi(c[j], a[j]);
-            }
+        for (int it = 0; it < GIT; ++it) {
+            const int c = tid + 192 * it;
+            const int pix = c >> 2, part4 = c & 3;
+            const int gy_ = by + pix / TW, gx_ = bx + pix % TW;
+            gv[it] = make_uint4(0, 0, 0, 0);
+            if (c < GCH && gy_ < Hb && gx_ < Wb)
+                gv[it] = *reinterpret_cast<const uint4*>(gy + (((long)n * Hb + gy_) * Wb + gx_) * OC + oc0 + part4 * 8);
+        }
+        __syncthreads();  // every wave is done reading the previous tile
+#pragma unroll
+        for (int it = 0; it < XIT; ++it) {
+            const int c = tid + 192 * it;
+            if (c < XCH) *reinterpret_cast<uint4*>(lx_ + c * 16) = xv[it];
+        }
+#pragma unroll
+        for (int it = 0; it < GIT; ++it) {
+            const int c = tid + 192 * it;
+            if (c < GCH) *reinterpret_cast<uint4*>(lg_ + c * 16) = gv[it];
         }
         __syncthreads();
-        // ---- MFMAs: wave wv takes pixel groups wv, wv+4, ...
-        for (int g = wv; g < NP / 16; g += 4) {
+        // ---- MFMAs: this wave's kernel row (ky = wv) over every 16-pixel group of the tile
+#pragma unroll 2
+        for (int g = 0; g < NP / 16; ++g) {
             const int ty = (g * 16) / TW, tx0 = (g * 16) % TW + 8 * hi;
-            const bf16x8 bfrag = *reinterpret_cast<const bf16x8*>(lg_ + l31 * GCP + (ty * TW + tx0) * 2);
-            const unsigned char* xb = lx_ + l31 * XCP;
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                if (!S2) {
-                    const unsigned char* rp = xb + ((ty + ky) * XP + tx0) * 2;
-                    const uint4 d = *reinterpret_cast<const uint4*>(rp);
-                    const unsigned int d4 = *reinterpret_cast<const unsigned int*>(rp + 16);
-                    acc[ky * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk_frag(d.x, d.y, d.z, d.w), bfrag, acc[ky * 3 + 0], 0, 0, 0);
-                    acc[ky * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                        mk_frag(shr16(d.y, d.x), shr16(d.z, d.y), shr16(d.w, d.z), shr16(d4, d.w)), bfrag, acc[ky * 3 + 1], 0, 0, 0);
-                    acc[ky * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk_frag(d.y, d.z, d.w, d4), bfrag, acc[ky * 3 + 2], 0, 0, 0);
-                } else {
-                    const int r = 2 * ty + ky;
-                    const unsigned char* ep = xb + (r * XP + tx0) * 2;
-                    const unsigned char* op = xb + (PH * XP + r * OP + tx0) * 2;
-                    const uint4 e = *reinterpret_cast<const uint4*>(ep);
-                    const unsigned int e4 = *reinterpret_cast<const unsigned int*>(ep + 16);
-                    const uint4 o = *reinterpret_cast<const uint4*>(op);
-                    acc[ky * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk_frag(e.x, e.y, e.z, e.w), bfrag, acc[ky * 3 + 0], 0, 0, 0);
-                    acc[ky * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk_frag(o.x, o.y, o.z, o.w), bfrag, acc[ky * 3 + 1], 0, 0, 0);
-                    acc[ky * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                        mk_frag(shr16(e.y, e.x), shr16(e.z, e.y), shr16(e.w, e.z), shr16(e4, e.w)), bfrag, acc[ky * 3 + 2], 0, 0, 0);
-                }
+            const unsigned char* gp = lg_ + (ty * TW + tx0 + t_row) * 64 + t_col;
+            const uint2 b0 = lds_tr16(gp), b1 = lds_tr16(gp + 4 * 64);
+            const bf16x8 bfrag = mk_frag(b0.x, b0.y, b1.x, b1.y);
+            const unsigned char* xp = lx_ + (((ty * S + wv) * PW + tx0 * S) + t_row * S) * 64 + t_col;
+            if (!S2) {
+                const uint2 d0 = lds_tr16(xp), d1 = lds_tr16(xp + 4 * 64), d2 = lds_tr16(xp + 8 * 64);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk_frag(d0.x, d0.y, d1.x, d1.y), bfrag, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk_frag(shr16(d0.y, d0.x), shr16(d1.x, d0.y), shr16(d1.y, d1.x), shr16(d2.x, d1.y)), bfrag, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk_frag(d0.y, d1.x, d1.y, d2.x), bfrag, acc[2], 0, 0, 0);
+            } else {
+                // even columns 2(p)+0 / +2 share a 9-pixel window; odd columns 2(p)+1 are their own 8-pixel window
+                const uint2 e0 = lds_tr16(xp), e1 = lds_tr16(xp + 8 * 64), e2 = lds_tr16(xp + 16 * 64);
+                const uint2 o0 = lds_tr16(xp + 64), o1 = lds_tr16(xp + 9 * 64);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk_frag(e0.x, e0.y, e1.x, e1.y), bfrag, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk_frag(o0.x, o0.y, o1.x, o1.y), bfrag, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk_frag(shr16(e0.y, e0.x), shr16(e1.x, e0.y), shr16(e1.y, e1.x), shr16(e2.x, e1.y)), bfrag, acc[2], 0, 0, 0);
             }
         }
     }
+    // ---- each wave owns its 3 taps: D[ic i][oc j], lane = (j = l31, i = (r&3) + 8(r>>2) + 4hi)
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        __syncthreads();
+    for (int kx = 0; kx < 3; ++kx) {
+        float* dst = part + (((long)slice * 9 + wv * 3 + kx) * IC + ic0) * OC + oc0 + l31;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
-            lred[wv * 1024 + i * 32 + l31] = acc[t][r];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int e = tid + 256 * k;
-            const float s = lred[e] + lred[1024 + e] + lred[2048 + e] + lred[3072 + e];
-            const int i = e >> 5, j = e & 31;
-            part[(((long)slice * 9 + t) * IC + ic0 + i) * OC + oc0 + j] = s;
-        }
+        for (int r = 0; r < 16; ++r) dst[(long)((r & 3) + 8 * (r >> 2) + 4 * hi) * OC] = acc[kx][r];
     }
 }
 
@@ -747,12 +712,13 @@ size_t igemm_prep_bytes(int ic, int oc, int dtype) {
 template <typename T>
 static int run_igemm_t(int mode, int variant, const void* x, const float* w_hwio, void* y, int N, int Hi, int Wi,
                        int ICk, int OCk, int w_ci, int w_co, int Hb, int Wb, float alpha, const float* bias, int act,
-                       void* ws, size_t ws_bytes, hipStream_t st) {
+                       int w_prepared, void* ws, size_t ws_bytes, hipStream_t st) {
     const size_t need = (size_t)9 * w_ci * w_co * sizeof(T);
     if (ws_bytes < need) return fail(GS_ERR_WORKSPACE, "conv igemm: workspace %zu < %zu", ws_bytes, need);
     T* wp = reinterpret_cast<T*>(ws);
     const long total = 9L * w_ci * w_co;
-    hipLaunchKernelGGL((weight_prep_kernel<T>), dim3(cdiv(total, 256)), dim3(256), 0, st, w_hwio, wp, 9, w_ci, w_co, variant);
+    if (!w_prepared)
+        hipLaunchKernelGGL((weight_prep_kernel<T>), dim3(cdiv(total, 256)), dim3(256), 0, st, w_hwio, wp, 9, w_ci, w_co, variant);
     ConvP p;
     memset(&p, 0, sizeof(p));
     p.x = x; p.wp = wp; p.y = y; p.bias = bias; p.act = act;
@@ -767,10 +733,10 @@ static int run_igemm_t(int mode, int variant, const void* x, const float* w_hwio
 }
 
 int run_igemm(int mode, int variant, const void* x, const float* w_hwio, void* y, int N, int Hi, int Wi, int ICk,
-              int OCk, int w_ci, int w_co, int Hb, int Wb, float alpha, const float* bias, int act, int dtype, void* ws,
-              size_t ws_bytes, hipStream_t st) {
+              int OCk, int w_ci, int w_co, int Hb, int Wb, float alpha, const float* bias, int act, int dtype, int w_prepared,
+              void* ws, size_t ws_bytes, hipStream_t st) {
     GS_DISPATCH_DTYPE(dtype, return (run_igemm_t<T>(mode, variant, x, w_hwio, y, N, Hi, Wi, ICk, OCk, w_ci, w_co, Hb,
-                                                    Wb, alpha, bias, act, ws, ws_bytes, st)));
+                                                    Wb, alpha, bias, act, w_prepared, ws, ws_bytes, st)));
 }
 
 // ---- weight gradient (fp32 MFMA path)
@@ -783,7 +749,7 @@ static void wgrad_geometry(int mode, int dtype, int N, int Hb, int Wb, int IC, i
     *tiles_y = cdiv(Hb, th);
     *ntiles = N * *tiles_x * *tiles_y;
     const int pairs = (IC / 32) * (OC / 32);
-    int ns = 512 / pairs;
+    int ns = (dtype == GS_BF16 ? 768 : 512) / pairs;
     if (ns < 1) ns = 1;
     if (ns > *ntiles) ns = *ntiles;
     *nslices = ns;
@@ -817,7 +783,7 @@ int run_wgrad_mfma(int mode, const void* x, const void* gy, float* gw, int N, in
             GS_WG_ALL(float);
         } else {
 #define GS_WGB(M, TWV)                                                                                                  \
-    hipLaunchKernelGGL((conv_wgrad_bf16_kernel<M, TWV>), grid, dim3(256), 0, st, reinterpret_cast<const bf16_t*>(x),    \
+    hipLaunchKernelGGL((conv_wgrad_bf16_kernel<M, TWV>), grid, dim3(192), 0, st, reinterpret_cast<const bf16_t*>(x),    \
                        reinterpret_cast<const bf16_t*>(gy), part, N, Hi, Wi, IC, OC, Hb, Wb, tiles_x, tiles_y, ntiles, nslices)
             if (mode == MODE_S1) { if (tw == 32) GS_WGB(MODE_S1, 32); else GS_WGB(MODE_S1, 16); }
             else { if (tw == 32) GS_WGB(MODE_S2, 32); else GS_WGB(MODE_S2, 16); }

@@ -145,6 +145,44 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const T* __restrict__ 
         }
     }
 }
+// fused backward of (bias + activation): gx = g * act'(y) AND part[block][c] = sum over the block's rows of gx
+// (one pass over g and y instead of two; c % 4 == 0, c <= 1024)
+template <typename T, int ACT>
+__global__ __launch_bounds__(256) void act_bwd_sum_kernel(const T* __restrict__ g, const T* __restrict__ y, T* __restrict__ gx,
+                                                          float* __restrict__ part, long p, int c) {
+    __shared__ float red[256 * 4];
+    const int tid = threadIdx.x;
+    const int quads = c >> 2;
+    const int rl = 256 / quads > 0 ? 256 / quads : 1;
+    const int q = tid % quads, r = tid / quads;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    if (r < rl) {
+        for (long row = (long)blockIdx.x * rl + r; row < p; row += (long)gridDim.x * rl) {
+            float gv[4], yv[4];
+            ld4(g + row * c + q * 4, gv);
+            ld4(y + row * c + q * 4, yv);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (ACT == GS_ACT_LRELU) gv[e] = yv[e] > 0.f ? gv[e] : 0.2f * gv[e];
+                if (ACT == GS_ACT_TANH) gv[e] = gv[e] * (1.f - yv[e] * yv[e]);
+                a[e] += gv[e];
+            }
+            st4(gx + row * c + q * 4, gv);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[tid * 4 + e] = a[e];
+    __syncthreads();
+    if (tid < quads) {
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < rl; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[e] += red[(k * quads + tid) * 4 + e];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) part[(long)blockIdx.x * c + tid * 4 + e] = s[e];
+    }
+}
+
 // out[ch] = sum_k part[k][ch]: block = 32 channels x 8 part lanes
 static __global__ __launch_bounds__(256) void channel_sum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int nparts, int c) {
     __shared__ float red[256];
@@ -165,8 +203,8 @@ static __global__ __launch_bounds__(256) void channel_sum_final_kernel(const flo
 static int channel_sum_parts(long p, int c) {
     long rows_per_block = 256 / (c >= 4 ? ((c & 3) == 0 ? c / 4 : (c < 256 ? c : 256)) : c);
     if (rows_per_block < 1) rows_per_block = 1;
-    long nb = (p + rows_per_block * 16 - 1) / (rows_per_block * 16);
-    if (nb > 512) nb = 512;
+    long nb = (p + rows_per_block * 8 - 1) / (rows_per_block * 8);
+    if (nb > 2048) nb = 2048;
     if (nb < 1) nb = 1;
     return (int)nb;
 }
@@ -454,6 +492,29 @@ extern "C" int gs_channel_sum(const void* g, float* out, int64_t p, int c, int d
     GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((channel_sum_kernel<T>), dim3(nparts), dim3(256), 0, st, (const T*)g, part, (long)p, c));
     GS_CHECK_LAUNCH();
     hipLaunchKernelGGL(channel_sum_final_kernel, dim3(cdiv(c, 32)), dim3(256), 0, st, part, out, nparts, c);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gs_act_bwd(const void* g, const void* y, void* gx, int64_t numel, int act, int dtype, void* stream);
+
+extern "C" int gs_act_bwd_bias(const void* g, const void* y, void* gx, float* gb, int64_t p, int c, int act, int dtype, void* ws,
+                               size_t ws_bytes, void* stream) {
+    GS_CHECK_ARG(p > 0 && c > 0 && (act == 1 || act == 2), "act_bwd_bias: bad args");
+    if ((c & 3) != 0 || c > 1024 || 256 % (c >> 2) != 0) {  // generic shapes: two passes
+        if (int e = gs_act_bwd(g, y, gx, p * c, act, dtype, stream)) return e;
+        return gs_channel_sum(gx, gb, p, c, dtype, ws, ws_bytes, stream);
+    }
+    const int nparts = channel_sum_parts(p, c);
+    if (ws_bytes < (size_t)nparts * c * sizeof(float)) return fail(GS_ERR_WORKSPACE, "act_bwd_bias: workspace too small");
+    hipStream_t st = as_stream(stream);
+    float* part = (float*)ws;
+    GS_DISPATCH_DTYPE(dtype, {
+        if (act == 1) hipLaunchKernelGGL((act_bwd_sum_kernel<T, 1>), dim3(nparts), dim3(256), 0, st, (const T*)g, (const T*)y, (T*)gx, part, (long)p, c);
+        else hipLaunchKernelGGL((act_bwd_sum_kernel<T, 2>), dim3(nparts), dim3(256), 0, st, (const T*)g, (const T*)y, (T*)gx, part, (long)p, c);
+    });
+    GS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(channel_sum_final_kernel, dim3(cdiv(c, 32)), dim3(256), 0, st, part, gb, nparts, c);
     GS_CHECK_LAUNCH();
     return 0;
 }

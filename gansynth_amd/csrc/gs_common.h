@@ -71,10 +71,17 @@ __device__ inline void ld4(const bf16_t* p, float (&o)[4]) {
     o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
     o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
 }
+// two floats -> packed bf16 pair, round-to-nearest-even: one v_cvt_pk_bf16_f32 on gfx950
+__device__ inline unsigned int pack_bf16x2(float lo, float hi) {
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf16x2_t));
+}
 __device__ inline void st4(bf16_t* p, const float (&o)[4]) {
     uint2 v;
-    v.x = (unsigned int)f32_to_bf16(o[0]).v | ((unsigned int)f32_to_bf16(o[1]).v << 16);
-    v.y = (unsigned int)f32_to_bf16(o[2]).v | ((unsigned int)f32_to_bf16(o[3]).v << 16);
+    v.x = pack_bf16x2(o[0], o[1]);
+    v.y = pack_bf16x2(o[2], o[3]);
     *reinterpret_cast<uint2*>(p) = v;
 }
 

@@ -34,6 +34,9 @@ class _ConvKind(object):
     def fwd(self, x, w, alpha):
         return _K().conv2d_fwd(x, w, self.ksize, self.stride, alpha)
 
+    def fwd_bias_act(self, x, w, bias, alpha, act):
+        return _K().conv2d_fwd_bias_act(x, w, bias, self.ksize, self.stride, alpha, act)
+
     def bwd_data(self, gy, w, x_shape, alpha):
         return _K().conv2d_bwd_data(gy, w, x_shape, self.ksize, self.stride, alpha)
 
@@ -46,6 +49,9 @@ class _ConvTransposeKind(object):
 
     def fwd(self, x, w, alpha):
         return _K().conv2d_transpose_fwd(x, w, alpha)
+
+    def fwd_bias_act(self, x, w, bias, alpha, act):
+        return _K().conv2d_transpose_fwd_bias_act(x, w, bias, alpha, act)
 
     def bwd_data(self, gy, w, x_shape, alpha):
         return _K().conv2d_transpose_bwd_data(gy, w, alpha)
@@ -132,8 +138,45 @@ class _BilinearBwdWeight(Function):
         return g_x, g_gy, None, None
 
 
+class _ConvBiasAct(Function):
+    """z = act(alpha * B(x, w) + bias) with the bias / activation fused into the GEMM epilogue."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, kind, alpha, act):
+        ctx.kind, ctx.alpha, ctx.act, ctx.has_bias = kind, alpha, act, bias is not None
+        z = kind.fwd_bias_act(x, w, bias, alpha, act)
+        ctx.save_for_backward(x, w, z)
+        return z
+
+    @staticmethod
+    def backward(ctx, gz):
+        x, w, z = ctx.saved_tensors
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
+        gb = None
+        if ctx.act != ACT_NONE:
+            if want_b and not torch.is_grad_enabled():   # plain backward: one fused pass
+                gy, gb = _K().act_bwd_bias(gz, z, ctx.act)
+            else:                                        # under create_graph: differentiable pieces
+                gy = _ActBwd.apply(gz, z, ctx.act)
+                gb = _ChannelSum.apply(gy) if want_b else None
+        else:
+            gy = gz
+            gb = _ChannelSum.apply(gy) if want_b else None
+        gx = _BilinearBwdData.apply(gy, w, x.shape, ctx.kind, ctx.alpha) if ctx.needs_input_grad[0] else None
+        gw = _BilinearBwdWeight.apply(x, gy, ctx.kind, ctx.alpha).to(w.dtype) if ctx.needs_input_grad[1] else None
+        return gx, gw, gb, None, None, None
+
+
 def conv2d(x, w, ksize, stride, alpha):
     return _Bilinear.apply(x, w, _kind(("conv", ksize, stride)), alpha)
+
+
+def conv2d_bias_act(x, w, bias, ksize, stride, alpha, act):
+    return _ConvBiasAct.apply(x, w, bias, _kind(("conv", ksize, stride)), alpha, act)
+
+
+def conv2d_transpose_bias_act(x, w, bias, alpha, act):
+    return _ConvBiasAct.apply(x, w, bias, _kind(("convT",)), alpha, act)
 
 
 def conv2d_transpose(x, w, alpha):
@@ -202,12 +245,18 @@ class _BiasAct(Function):
 
     @staticmethod
     def backward(ctx, gz):
+        want_b = ctx.has_bias and ctx.needs_input_grad[1]
+        gb = None
         if ctx.act != ACT_NONE:
             (z,) = ctx.saved_tensors
-            gx = _ActBwd.apply(gz, z, ctx.act)
+            if want_b and not torch.is_grad_enabled():
+                gx, gb = _K().act_bwd_bias(gz, z, ctx.act)
+            else:
+                gx = _ActBwd.apply(gz, z, ctx.act)
+                gb = _ChannelSum.apply(gx) if want_b else None
         else:
             gx = gz
-        gb = _ChannelSum.apply(gx) if (ctx.has_bias and ctx.needs_input_grad[1]) else None
+            gb = _ChannelSum.apply(gx) if want_b else None
         return (gx if ctx.needs_input_grad[0] else None), gb, None
 
 

@@ -66,17 +66,53 @@ class HipKernels(object):
         if not torch.cuda.is_available():
             raise _lib.GansynthHipError("gansynth_amd needs a HIP device (torch.cuda.is_available() is False)")
         _lib.check(self.lib.gs_init(), "gs_init")
+        self._param_ranges = []   # (ptr, nbytes) of registered flat parameter buffers
+        self._wcache = {}         # (weight ptr, map tag) -> (persistent workspace holding the re-laid operand, stamp)
+        self._epoch = 0           # bumped whenever parameter values change (Adam step, explicit invalidation)
+
+    # --------------------------------------------------------- prepared-weight workspaces
+    def register_param_buffer(self, flat):
+        """Weights living in `flat` may keep their kernel operand (re-laid, storage dtype) between calls."""
+        self._param_ranges.append((flat.data_ptr(), flat.numel() * flat.element_size()))
+
+    def invalidate_weights(self):
+        self._epoch += 1
+
+    def _weight_ws(self, w, tag, nbytes):
+        """-> (workspace, w_prepared).  A registered parameter gets one persistent workspace per conv map, reused
+        (w_prepared = 1) until the parameter values change; anything else gets a transient workspace."""
+        ptr = w.data_ptr()
+        if not any(lo <= ptr < lo + n for lo, n in self._param_ranges):
+            return _ws(nbytes, w.device), 0
+        key, stamp = (ptr, tag), (self._epoch, w._version)
+        ent = self._wcache.get(key)
+        if ent is not None and ent[0].numel() >= nbytes:
+            if ent[1] == stamp:
+                return ent[0], 1
+            self._wcache[key] = (ent[0], stamp)
+            return ent[0], 0
+        buf = _ws(nbytes, w.device)
+        self._wcache[key] = (buf, stamp)
+        return buf, 0
 
     # ------------------------------------------------------------------------------- conv
     def conv2d_fwd(self, x, w, ksize, stride, alpha):
+        return self.conv2d_fwd_bias_act(x, w, None, ksize, stride, alpha, _lib.ACT_NONE)
+
+    def conv2d_fwd_bias_act(self, x, w, bias, ksize, stride, alpha, act):
         x, w = _act(x), _f32c(w)
         n, ci, h, wd = x.shape
         co = w.shape[3]
         y = _empty_like_act((n, co, h // stride, wd // stride), x)
         nb = self.lib.gs_conv2d_workspace_bytes(_lib.CONV_FWD, n, h, wd, ci, co, ksize, stride, _dt(x))
-        ws = _ws(nb, x.device)
-        _lib.check(self.lib.gs_conv2d_fwd(x.data_ptr(), w.data_ptr(), y.data_ptr(), n, h, wd, ci, co, ksize, stride,
-                                          float(alpha), _dt(x), ws.data_ptr(), ws.numel(), _stream()), "gs_conv2d_fwd")
+        ws, prepared = self._weight_ws(w, ("fwd", ksize, stride, _dt(x)), nb)
+        bp = None
+        if bias is not None:
+            bias = _f32c(bias)
+            bp = bias.data_ptr()
+        _lib.check(self.lib.gs_conv2d_fwd_bias_act(x.data_ptr(), w.data_ptr(), bp, y.data_ptr(), n, h, wd, ci, co, ksize, stride,
+                                                   float(alpha), act, _dt(x), prepared, ws.data_ptr(), ws.numel(), _stream()),
+                   "gs_conv2d_fwd_bias_act")
         return y
 
     def conv2d_bwd_data(self, gy, w, x_shape, ksize, stride, alpha):
@@ -85,9 +121,9 @@ class HipKernels(object):
         co = w.shape[3]
         gx = _empty_like_act((n, ci, h, wd), gy)
         nb = self.lib.gs_conv2d_workspace_bytes(_lib.CONV_BWD_DATA, n, h, wd, ci, co, ksize, stride, _dt(gy))
-        ws = _ws(nb, gy.device)
+        ws, prepared = self._weight_ws(w, ("bwd_data", ksize, stride, _dt(gy)), nb)
         _lib.check(self.lib.gs_conv2d_bwd_data(gy.data_ptr(), w.data_ptr(), gx.data_ptr(), n, h, wd, ci, co, ksize, stride,
-                                               float(alpha), _dt(gy), ws.data_ptr(), ws.numel(), _stream()), "gs_conv2d_bwd_data")
+                                               float(alpha), _dt(gy), prepared, ws.data_ptr(), ws.numel(), _stream()), "gs_conv2d_bwd_data")
         return gx
 
     def conv2d_bwd_weight(self, x, gy, ksize, stride, alpha):
@@ -102,14 +138,22 @@ class HipKernels(object):
         return gw
 
     def conv2d_transpose_fwd(self, x, w, alpha):
+        return self.conv2d_transpose_fwd_bias_act(x, w, None, alpha, _lib.ACT_NONE)
+
+    def conv2d_transpose_fwd_bias_act(self, x, w, bias, alpha, act):
         x, w = _act(x), _f32c(w)
         n, ci, h, wd = x.shape
         co = w.shape[3]
         y = _empty_like_act((n, co, 2 * h, 2 * wd), x)
         nb = self.lib.gs_conv2d_transpose_s2_workspace_bytes(_lib.CONV_FWD, n, h, wd, ci, co, _dt(x))
-        ws = _ws(nb, x.device)
-        _lib.check(self.lib.gs_conv2d_transpose_s2_fwd(x.data_ptr(), w.data_ptr(), y.data_ptr(), n, h, wd, ci, co, float(alpha),
-                                                       _dt(x), ws.data_ptr(), ws.numel(), _stream()), "gs_conv2d_transpose_s2_fwd")
+        ws, prepared = self._weight_ws(w, ("t_fwd", _dt(x)), nb)
+        bp = None
+        if bias is not None:
+            bias = _f32c(bias)
+            bp = bias.data_ptr()
+        _lib.check(self.lib.gs_conv2d_transpose_s2_fwd_bias_act(x.data_ptr(), w.data_ptr(), bp, y.data_ptr(), n, h, wd, ci, co,
+                                                                float(alpha), act, _dt(x), prepared, ws.data_ptr(), ws.numel(), _stream()),
+                   "gs_conv2d_transpose_s2_fwd_bias_act")
         return y
 
     def conv2d_transpose_bwd_data(self, gy, w, alpha):
@@ -119,9 +163,9 @@ class HipKernels(object):
         h, wd = h2 // 2, w2 // 2
         gx = _empty_like_act((n, ci, h, wd), gy)
         nb = self.lib.gs_conv2d_transpose_s2_workspace_bytes(_lib.CONV_BWD_DATA, n, h, wd, ci, co, _dt(gy))
-        ws = _ws(nb, gy.device)
+        ws, prepared = self._weight_ws(w, ("t_bwd_data", _dt(gy)), nb)
         _lib.check(self.lib.gs_conv2d_transpose_s2_bwd_data(gy.data_ptr(), w.data_ptr(), gx.data_ptr(), n, h, wd, ci, co, float(alpha),
-                                                            _dt(gy), ws.data_ptr(), ws.numel(), _stream()), "gs_conv2d_transpose_s2_bwd_data")
+                                                            _dt(gy), prepared, ws.data_ptr(), ws.numel(), _stream()), "gs_conv2d_transpose_s2_bwd_data")
         return gx
 
     def conv2d_transpose_bwd_weight(self, x, gy, alpha):
@@ -201,6 +245,18 @@ class HipKernels(object):
         gx = torch.empty_like(y)
         _lib.check(self.lib.gs_act_bwd(g.data_ptr(), y.data_ptr(), gx.data_ptr(), y.numel(), act, _dt(y), _stream()), "gs_act_bwd")
         return gx
+
+    def act_bwd_bias(self, g, y, act):
+        """(gx, gb): activation backward and the bias gradient in one pass."""
+        y = _act(y)
+        g = _match(g, y)
+        p, c = _rows_cols(y)
+        gx = torch.empty_like(y)
+        gb = torch.empty((c,), dtype=torch.float32, device=y.device)
+        ws = _ws(self.lib.gs_channel_sum_workspace_bytes(p, c), y.device)
+        _lib.check(self.lib.gs_act_bwd_bias(g.data_ptr(), y.data_ptr(), gx.data_ptr(), gb.data_ptr(), p, c, act, _dt(y),
+                                            ws.data_ptr(), ws.numel(), _stream()), "gs_act_bwd_bias")
+        return gx, gb
 
     def tanh_bwd_bwd(self, gg, g, y):
         y = _act(y)
@@ -313,6 +369,7 @@ class HipKernels(object):
             assert t.dtype == torch.float32 and t.is_contiguous()
         _lib.check(self.lib.gs_adam_tf_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), float(lr_t), float(beta1),
                                             float(beta2), float(eps), float(grad_scale), _stream()), "gs_adam_tf_step")
+        self._epoch += 1  # parameter values changed: cached kernel operands are stale
 
     # --------------------------------------------------------------------------- profiling
     def prof_enable(self, on):

@@ -95,6 +95,11 @@ class GANSynth(object):
         if self.distributed:  # identical weights on every rank
             torch.distributed.broadcast(self.g_params.flat, 0)
             torch.distributed.broadcast(self.d_params.flat, 0)
+        K = kernels.get()
+        if hasattr(K, "register_param_buffer"):  # lets the conv kernels keep their re-laid weight operands between calls
+            K.register_param_buffer(self.g_params.flat)
+            K.register_param_buffer(self.d_params.flat)
+            K.invalidate_weights()
 
     def _ensure_built(self, latents, labels):
         if self.g_params is None:

@@ -60,11 +60,10 @@ def conv2d(inputs, filters, kernel_size, strides=[1, 1], use_bias=True, variance
     if kernel_size[0] != kernel_size[1] or strides[0] != strides[1]:
         raise ValueError("conv2d: only square kernels / isotropic strides are on the hot path")
     weight, alpha = get_weight([*kernel_size, inputs.shape[1], filters], variance_scale, scale_weight)
-    outputs = F.conv2d(inputs, weight, kernel_size[0], strides[0], alpha)
     bias = get_bias([filters]) if use_bias else None
     if bias is not None or activation is not None:
-        outputs = F.bias_act(outputs, bias, _ACT[activation])
-    return outputs
+        return F.conv2d_bias_act(inputs, weight, bias, kernel_size[0], strides[0], alpha, _ACT[activation])
+    return F.conv2d(inputs, weight, kernel_size[0], strides[0], alpha)
 
 
 def conv2d_transpose(inputs, filters, kernel_size, strides=[1, 1], use_bias=True, variance_scale=2.0, scale_weight=False,
@@ -73,11 +72,10 @@ def conv2d_transpose(inputs, filters, kernel_size, strides=[1, 1], use_bias=True
     if list(kernel_size) != [3, 3] or list(strides) != [2, 2]:
         raise ValueError("conv2d_transpose: the hot path is kernel 3x3, strides 2x2 (networks.py:71-79)")
     weight, alpha = get_weight([*kernel_size, inputs.shape[1], filters], variance_scale, scale_weight)
-    outputs = F.conv2d_transpose(inputs, weight, alpha)
     bias = get_bias([filters]) if use_bias else None
     if bias is not None or activation is not None:
-        outputs = F.bias_act(outputs, bias, _ACT[activation])
-    return outputs
+        return F.conv2d_transpose_bias_act(inputs, weight, bias, alpha, _ACT[activation])
+    return F.conv2d_transpose(inputs, weight, alpha)
 
 
 def upscale2d(inputs, factors=[2, 2]):

@@ -63,6 +63,9 @@ class VariableStore(object):
                     self.variables[k].copy_(torch.as_tensor(t).to(self.variables[k]))
                 elif strict:
                     raise KeyError(f"unknown variable {k}")
+        from . import kernels
+        if kernels._K is not None and hasattr(kernels._K, "invalidate_weights"):
+            kernels._K.invalidate_weights()
         missing = [k for k in self.variables if k not in state]
         if strict and missing:
             raise KeyError(f"state is missing {missing[:4]}...")

@@ -58,12 +58,20 @@ int gs_prof_collect(int* launches, double* total_ms, double* total_flops);
  * how the Python host gets the second-order terms of models.py:47,60.
  *   bwd_data  : gx[n][h][w][ci] = alpha * d<gy, conv(x,w)>/dx
  *   bwd_weight: gw[k][k][ci][co] = alpha * d<gy, conv(x,w)>/dw   (fp32 out)
- * (n,h,w) are always the dims of x (the conv INPUT side), for all three. */
+ * (n,h,w) are always the dims of x (the conv INPUT side), for all three.
+ * fwd / bwd_data first re-lay the weight into the kernel operand at the start of `ws`; `w_prepared` != 0 says that
+ * `ws` still holds that operand from an earlier call with the same weight values (same map, dtype), so the
+ * re-layout is skipped -- the caller keeps one persistent ws per (weight, map) between optimizer steps. */
 size_t gs_conv2d_workspace_bytes(int which, int n, int h, int w, int ci, int co, int ksize, int stride, int dtype);
 int gs_conv2d_fwd(const void* x, const float* w_hwio, void* y, int n, int h, int w, int ci, int co,
-                  int ksize, int stride, float alpha, int dtype, void* ws, size_t ws_bytes, void* stream);
+                  int ksize, int stride, float alpha, int dtype, int w_prepared, void* ws, size_t ws_bytes, void* stream);
+/* same with the bias add + activation the reference applies right after (ops.py:244-246 + tf.nn.leaky_relu /
+ * tf.nn.tanh in networks.py) fused into the GEMM epilogue: y = act(alpha * conv(x, w) + bias); bias may be NULL */
+int gs_conv2d_fwd_bias_act(const void* x, const float* w_hwio, const float* bias, void* y, int n, int h, int w, int ci, int co,
+                           int ksize, int stride, float alpha, int act, int dtype, int w_prepared, void* ws, size_t ws_bytes,
+                           void* stream);
 int gs_conv2d_bwd_data(const void* gy, const float* w_hwio, void* gx, int n, int h, int w, int ci, int co,
-                       int ksize, int stride, float alpha, int dtype, void* ws, size_t ws_bytes, void* stream);
+                       int ksize, int stride, float alpha, int dtype, int w_prepared, void* ws, size_t ws_bytes, void* stream);
 int gs_conv2d_bwd_weight(const void* x, const void* gy, float* gw_hwio, int n, int h, int w, int ci, int co,
                          int ksize, int stride, float alpha, int dtype, void* ws, size_t ws_bytes, void* stream);
 
@@ -77,9 +85,12 @@ int gs_conv2d_bwd_weight(const void* x, const void* gy, float* gw_hwio, int n, i
  * (n,h,w) are the dims of x (the LOW resolution side). */
 size_t gs_conv2d_transpose_s2_workspace_bytes(int which, int n, int h, int w, int ci, int co, int dtype);
 int gs_conv2d_transpose_s2_fwd(const void* x, const float* w_hwio, void* y, int n, int h, int w, int ci, int co,
-                               float alpha, int dtype, void* ws, size_t ws_bytes, void* stream);
+                               float alpha, int dtype, int w_prepared, void* ws, size_t ws_bytes, void* stream);
+int gs_conv2d_transpose_s2_fwd_bias_act(const void* x, const float* w_hwio, const float* bias, void* y, int n, int h, int w,
+                                        int ci, int co, float alpha, int act, int dtype, int w_prepared, void* ws,
+                                        size_t ws_bytes, void* stream);
 int gs_conv2d_transpose_s2_bwd_data(const void* gy, const float* w_hwio, void* gx, int n, int h, int w, int ci, int co,
-                                    float alpha, int dtype, void* ws, size_t ws_bytes, void* stream);
+                                    float alpha, int dtype, int w_prepared, void* ws, size_t ws_bytes, void* stream);
 int gs_conv2d_transpose_s2_bwd_weight(const void* x, const void* gy, float* gw_hwio, int n, int h, int w, int ci, int co,
                                       float alpha, int dtype, void* ws, size_t ws_bytes, void* stream);
 
@@ -105,6 +116,9 @@ int gs_embedding_bwd(const int64_t* idx, const void* gy, float* gw, int b, int r
  *   channel_sum: out[c] = sum_p g[p][c] (bias gradient, fp32 out) */
 int gs_bias_act_fwd(const void* x, const float* bias, void* y, int64_t p, int c, int act, int dtype, void* stream);
 int gs_act_bwd(const void* g, const void* y, void* gx, int64_t numel, int act, int dtype, void* stream);
+/* act_bwd and the bias gradient in one pass: gx = g*act'(y), gb[c] = sum_p gx[p][c] (ws: gs_channel_sum_workspace_bytes) */
+int gs_act_bwd_bias(const void* g, const void* y, void* gx, float* gb, int64_t p, int c, int act, int dtype, void* ws,
+                    size_t ws_bytes, void* stream);
 int gs_tanh_bwd_bwd(const void* gg, const void* g, const void* y, void* out, int64_t numel, int dtype, void* stream);
 size_t gs_channel_sum_workspace_bytes(int64_t p, int c);
 int gs_channel_sum(const void* g, float* out, int64_t p, int c, int dtype, void* ws, size_t ws_bytes, void* stream);

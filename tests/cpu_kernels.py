@@ -30,6 +30,16 @@ class CpuEmuKernels(object):
         scale = alpha / R.weight_scale(w.shape, 1.0)
         return (R.conv2d(x.detach(), w, zero, (stride, stride), 1.0) * scale).detach()
 
+    def conv2d_fwd_bias_act(self, x, w, bias, ksize, stride, alpha, act):
+        return self.bias_act_fwd(self.conv2d_fwd(x, w, ksize, stride, alpha), bias, act)
+
+    def conv2d_transpose_fwd_bias_act(self, x, w, bias, alpha, act):
+        return self.bias_act_fwd(self.conv2d_transpose_fwd(x, w, alpha), bias, act)
+
+    def act_bwd_bias(self, g, y, act):
+        gx = self.act_bwd(g, y, act)
+        return gx, self.channel_sum(gx)
+
     def conv2d_bwd_data(self, gy, w, x_shape, ksize, stride, alpha):
         return _lin_grad(lambda z: self_conv(z, w, stride, alpha), tuple(x_shape), gy, gy.detach()).detach()
 

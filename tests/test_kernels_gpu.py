@@ -232,3 +232,62 @@ def test_thin_colour_weight_grad(K, E, n, ci, co, h, w, dtype):
     x = rnd(n, ci, h, w, seed=1).to(dtype).float()
     gy = rnd(n, co, h, w, seed=3).to(dtype).float()
     close(K.conv2d_bwd_weight(dev(x, dtype), dev(gy, dtype), 1, 1, 0.25), E.conv2d_bwd_weight(x, gy, 1, 1, 0.25), rel=1e-4, name="thin wgrad")
+
+
+@pytest.mark.parametrize("case", [(2, 32, 32, 8, 128, 3, 1), (2, 64, 64, 4, 32, 3, 1), (2, 32, 64, 8, 128, 3, 2), (2, 32, 2, 8, 64, 1, 1), (4, 256, 256, 2, 16, 3, 1)])
+@pytest.mark.parametrize("act", [0, 1, 2])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv2d_fused_bias_act_epilogue(K, E, case, act, dtype):
+    n, ci, co, h, w, ks, st = case
+    x = rnd(n, ci, h, w, seed=1).to(dtype).float()
+    wt = rnd(ks, ks, ci, co, seed=2)
+    wr = wt.to(dtype).float() if (dtype == torch.bfloat16 and ks == 3) else wt
+    bias = rnd(co, seed=7)
+    alpha = float(np.sqrt(2.0 / (ks * ks * ci)))
+    ref = E.conv2d_fwd_bias_act(x, wr, bias, ks, st, alpha, act)
+    tol = 1e-3 if dtype == torch.float32 else 2e-2
+    close(K.conv2d_fwd_bias_act(dev(x, dtype), dev(wt), dev(bias), ks, st, alpha, act), ref, rel=tol, name="fused fwd")
+    close(K.conv2d_fwd_bias_act(dev(x, dtype), dev(wt), None, ks, st, alpha, act), E.conv2d_fwd_bias_act(x, wr, None, ks, st, alpha, act), rel=tol, name="fused fwd nobias")
+
+
+@pytest.mark.parametrize("act", [0, 1])
+def test_conv2d_transpose_fused_bias_act(K, E, act):
+    n, ci, co, h, w = 2, 64, 32, 8, 64
+    x, wt, bias = rnd(n, ci, h, w, seed=4), rnd(3, 3, ci, co, seed=5), rnd(co, seed=6)
+    close(K.conv2d_transpose_fwd_bias_act(dev(x), dev(wt), dev(bias), 0.1, act), E.conv2d_transpose_fwd_bias_act(x, wt, bias, 0.1, act), name="convT fused")
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 64, 256), (4, 256, 2, 16), (2, 2, 16, 128), (8, 8192), (3, 64, 5, 7), (8, 61)])
+@pytest.mark.parametrize("act", [1, 2])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_act_bwd_bias_fused(K, E, shape, act, dtype):
+    g = rnd(*shape, seed=2).to(dtype).float()
+    y = E.bias_act_fwd(rnd(*shape, seed=1), None, act).to(dtype).float()
+    gx_ref, gb_ref = E.act_bwd_bias(g, y, act)
+    gx, gb = K.act_bwd_bias(dev(g, dtype), dev(y, dtype), act)
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    close(gx, gx_ref, rel=tol, name="gx")
+    # the sum is taken over the unrounded fp32 values in registers: compare against the exact sum
+    close(gb, gb_ref, rel=1e-4 if dtype == torch.float32 else 2e-2, name="gb")
+
+
+def test_prepared_weight_operand_cache(K, E):
+    """A registered parameter keeps its re-laid operand between calls until its values change."""
+    flat = torch.randn(9 * 32 * 32 + 64, device="cuda")
+    K.register_param_buffer(flat)
+    w = flat[:9 * 32 * 32].view(3, 3, 32, 32)
+    x = rnd(2, 32, 8, 64, seed=1)
+    ref1 = E.conv2d_fwd(x, w.cpu(), 3, 1, 0.1)
+    close(K.conv2d_fwd(dev(x), w, 3, 1, 0.1), ref1, name="first call (prepares)")
+    close(K.conv2d_fwd(dev(x), w, 3, 1, 0.1), ref1, name="second call (reuses)")
+    close(K.conv2d_bwd_data(dev(ref1), w, x.shape, 3, 1, 0.1), E.conv2d_bwd_data(ref1, w.cpu(), x.shape, 3, 1, 0.1), name="bwd_data")
+    assert any(k[0] == w.data_ptr() for k in K._wcache)
+    # raw-pointer update (what the Adam kernel does) + explicit invalidation
+    K.adam_tf_step(flat, torch.ones_like(flat), torch.zeros_like(flat), torch.zeros_like(flat), 0.5, 0.0, 0.99, 1e-8, 1.0)
+    ref2 = E.conv2d_fwd(x, w.cpu(), 3, 1, 0.1)
+    assert float((ref2 - ref1).abs().max()) > 1e-3
+    close(K.conv2d_fwd(dev(x), w, 3, 1, 0.1), ref2, name="after the parameter changed")
+    # in-place torch update bumps the tensor version
+    with torch.no_grad():
+        w.mul_(0.5)
+    close(K.conv2d_fwd(dev(x), w, 3, 1, 0.1), E.conv2d_fwd(x, w.cpu(), 3, 1, 0.1), name="after an in-place torch update")
