@@ -227,7 +227,7 @@ static size_t wgrad_direct_bytes(int ks, int N, int Hb, int Wb, int IC, int OC) 
         thin_wgrad_geometry((long)N * Hb * Wb, IC == 2 ? OC : IC, &tns, &tpps);
         if (tns > ns) ns = tns;
     }
-    return align256((size_t)ns * ks * ks * IC * OC * 4);
+    return align256(((size_t)ns * ks * ks * IC * OC + wgrad_reduce_extra(ns, (long)ks * ks * IC * OC)) * 4);
 }
 
 static int run_wgrad_direct(int mode, int ks, const void* x, const void* gy, float* gw, int N, int Hi, int Wi, int IC,
@@ -239,7 +239,7 @@ static int run_wgrad_direct(int mode, int ks, const void* x, const void* gy, flo
     if (thin_wgrad_ok(ks, IC, OC) && mode == MODE_S1) {
         const int C = IC == 2 ? OC : IC;
         thin_wgrad_geometry(npix, C, &ns, &pps);
-        if (ws_bytes < (size_t)ns * E * 4) return fail(GS_ERR_WORKSPACE, "conv wgrad thin: workspace %zu < %zu", ws_bytes, (size_t)ns * E * 4);
+        if (ws_bytes < ((size_t)ns * E + wgrad_reduce_extra(ns, E)) * 4) return fail(GS_ERR_WORKSPACE, "conv wgrad thin: workspace too small (%zu)", ws_bytes);
         float* tpart = reinterpret_cast<float*>(ws);
         if (IC == 2) {
             GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((thin_wgrad_kernel<T, false>), dim3((unsigned)ns), dim3(256), 0, st,
@@ -249,19 +249,19 @@ static int run_wgrad_direct(int mode, int ks, const void* x, const void* gy, flo
                                                         reinterpret_cast<const T*>(x), reinterpret_cast<const T*>(gy), tpart, C, npix, pps));
         }
         GS_CHECK_LAUNCH();
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(E, 64)), dim3(256), 0, st, tpart, gw, (int)ns, 1, IC, OC, alpha, transpose);
+        wgrad_reduce_launch(tpart, gw, (int)ns, 1, IC, OC, alpha, transpose, st);
         GS_CHECK_LAUNCH();
         return 0;
     }
     wgrad_direct_geometry(npix, &ns, &pps);
-    if (ws_bytes < (size_t)ns * E * 4) return fail(GS_ERR_WORKSPACE, "conv wgrad direct: workspace %zu < %zu", ws_bytes, (size_t)ns * E * 4);
+    if (ws_bytes < ((size_t)ns * E + wgrad_reduce_extra(ns, E)) * 4) return fail(GS_ERR_WORKSPACE, "conv wgrad direct: workspace too small (%zu)", ws_bytes);
     float* part = reinterpret_cast<float*>(ws);
     dim3 grid(cdiv(E, 64), (unsigned)ns);
     GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((conv_wgrad_direct_kernel<T>), grid, dim3(256), 0, st,
                                                 reinterpret_cast<const T*>(x), reinterpret_cast<const T*>(gy), part, mode,
                                                 ks, N, Hi, Wi, IC, OC, Hb, Wb, E, npix, pps));
     GS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(E, 64)), dim3(256), 0, st, part, gw, (int)ns, ks * ks, IC, OC, alpha, transpose);
+    wgrad_reduce_launch(part, gw, (int)ns, ks * ks, IC, OC, alpha, transpose, st);
     GS_CHECK_LAUNCH();
     return 0;
 }

@@ -758,7 +758,7 @@ static void wgrad_geometry(int mode, int dtype, int N, int Hb, int Wb, int IC, i
 size_t wgrad_mfma_bytes(int mode, int dtype, int N, int Hb, int Wb, int IC, int OC) {
     int tw, tx, ty, nt, ns;
     wgrad_geometry(mode, dtype, N, Hb, Wb, IC, OC, &tw, &tx, &ty, &nt, &ns);
-    return align256((size_t)ns * 9 * IC * OC * sizeof(float));
+    return align256(((size_t)ns * 9 * IC * OC + wgrad_reduce_extra(ns, 9L * IC * OC)) * sizeof(float));
 }
 
 // x: conv input side [N][Hi][Wi][IC]; gy: [N][Hb][Wb][OC]; gw[9][IC][OC] (or transposed)
@@ -766,7 +766,7 @@ int run_wgrad_mfma(int mode, const void* x, const void* gy, float* gw, int N, in
                    int Wb, float alpha, int transpose, int dtype, void* ws, size_t ws_bytes, hipStream_t st) {
     int tw, tiles_x, tiles_y, ntiles, nslices;
     wgrad_geometry(mode, dtype, N, Hb, Wb, IC, OC, &tw, &tiles_x, &tiles_y, &ntiles, &nslices);
-    const size_t need = (size_t)nslices * 9 * IC * OC * sizeof(float);
+    const size_t need = ((size_t)nslices * 9 * IC * OC + wgrad_reduce_extra(nslices, 9L * IC * OC)) * sizeof(float);
     if (ws_bytes < need) return fail(GS_ERR_WORKSPACE, "conv wgrad: workspace %zu < %zu", ws_bytes, need);
     float* part = reinterpret_cast<float*>(ws);
     dim3 grid((IC / 32) * (OC / 32), nslices);
@@ -793,8 +793,7 @@ int run_wgrad_mfma(int mode, const void* x, const void* gy, float* gw, int N, in
 #undef GS_WG
     }
     GS_CHECK_LAUNCH();
-    const long total = 9L * IC * OC;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 64)), dim3(256), 0, st, part, gw, nslices, 9, IC, OC, alpha, transpose);
+    wgrad_reduce_launch(part, gw, nslices, 9, IC, OC, alpha, transpose, st);
     GS_CHECK_LAUNCH();
     return 0;
 }

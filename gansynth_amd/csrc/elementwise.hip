@@ -183,22 +183,39 @@ __global__ __launch_bounds__(256) void act_bwd_sum_kernel(const T* __restrict__ 
     }
 }
 
-// out[ch] = sum_k part[k][ch]: block = 32 channels x 8 part lanes
-static __global__ __launch_bounds__(256) void channel_sum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int nparts, int c) {
+// out[s][ch] = sum over the s-th slab of `per` parts of part[k][ch]: block = 32 channels x 8 part lanes.
+// Called once (nsplit = 1) or twice (first level writes nsplit rows, second level sums them): fixed order.
+static __global__ __launch_bounds__(256) void channel_sum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int nparts, int c, int per) {
     __shared__ float red[256];
     const int ch = blockIdx.x * 32 + (threadIdx.x & 31);
     const int pl = threadIdx.x >> 5;
+    const int k0 = blockIdx.y * per;
+    int k1 = k0 + per;
+    if (k1 > nparts) k1 = nparts;
     float s = 0.f;
     if (ch < c)
-        for (int k = pl; k < nparts; k += 8) s += part[(long)k * c + ch];
+        for (int k = k0 + pl; k < k1; k += 8) s += part[(long)k * c + ch];
     red[threadIdx.x] = s;
     __syncthreads();
     if (pl == 0 && ch < c) {
         float t = 0.f;
 #pragma unroll
         for (int k = 0; k < 8; ++k) t += red[k * 32 + threadIdx.x];
-        out[ch] = t;
+        out[(long)blockIdx.y * c + ch] = t;
     }
+}
+constexpr int CS_SLAB = 64;  // parts per first-level block
+static int channel_sum_finalize(float* part, float* out, int nparts, int c, hipStream_t st) {
+    if (nparts <= CS_SLAB) {
+        hipLaunchKernelGGL(channel_sum_final_kernel, dim3(cdiv(c, 32), 1), dim3(256), 0, st, part, out, nparts, c, nparts);
+    } else {
+        const int nsplit = cdiv(nparts, CS_SLAB);
+        float* part2 = part + (long)nparts * c;
+        hipLaunchKernelGGL(channel_sum_final_kernel, dim3(cdiv(c, 32), nsplit), dim3(256), 0, st, part, part2, nparts, c, CS_SLAB);
+        hipLaunchKernelGGL(channel_sum_final_kernel, dim3(cdiv(c, 32), 1), dim3(256), 0, st, part2, out, nsplit, c, nsplit);
+    }
+    GS_CHECK_LAUNCH();
+    return 0;
 }
 static int channel_sum_parts(long p, int c) {
     long rows_per_block = 256 / (c >= 4 ? ((c & 3) == 0 ? c / 4 : (c < 256 ? c : 256)) : c);
@@ -481,22 +498,24 @@ extern "C" int gs_axpby(const void* a, const void* b, void* out, int64_t numel, 
     return 0;
 }
 
-extern "C" size_t gs_channel_sum_workspace_bytes(int64_t p, int c) { return (size_t)channel_sum_parts(p, c) * c * sizeof(float); }
+extern "C" size_t gs_channel_sum_workspace_bytes(int64_t p, int c) {
+    const int np = channel_sum_parts(p, c);
+    return (size_t)(np + cdiv(np, CS_SLAB)) * c * sizeof(float);
+}
 
 extern "C" int gs_channel_sum(const void* g, float* out, int64_t p, int c, int dtype, void* ws, size_t ws_bytes, void* stream) {
     GS_CHECK_ARG(p > 0 && c > 0, "channel_sum: bad args");
     const int nparts = channel_sum_parts(p, c);
-    if (ws_bytes < (size_t)nparts * c * sizeof(float)) return fail(GS_ERR_WORKSPACE, "channel_sum: workspace too small");
+    if (ws_bytes < gs_channel_sum_workspace_bytes(p, c)) return fail(GS_ERR_WORKSPACE, "channel_sum: workspace too small");
     hipStream_t st = as_stream(stream);
     float* part = (float*)ws;
     GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((channel_sum_kernel<T>), dim3(nparts), dim3(256), 0, st, (const T*)g, part, (long)p, c));
     GS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(channel_sum_final_kernel, dim3(cdiv(c, 32)), dim3(256), 0, st, part, out, nparts, c);
-    GS_CHECK_LAUNCH();
-    return 0;
+    return channel_sum_finalize(part, out, nparts, c, st);
 }
 
 extern "C" int gs_act_bwd(const void* g, const void* y, void* gx, int64_t numel, int act, int dtype, void* stream);
+extern "C" size_t gs_channel_sum_workspace_bytes(int64_t p, int c);
 
 extern "C" int gs_act_bwd_bias(const void* g, const void* y, void* gx, float* gb, int64_t p, int c, int act, int dtype, void* ws,
                                size_t ws_bytes, void* stream) {
@@ -506,7 +525,7 @@ extern "C" int gs_act_bwd_bias(const void* g, const void* y, void* gx, float* gb
         return gs_channel_sum(gx, gb, p, c, dtype, ws, ws_bytes, stream);
     }
     const int nparts = channel_sum_parts(p, c);
-    if (ws_bytes < (size_t)nparts * c * sizeof(float)) return fail(GS_ERR_WORKSPACE, "act_bwd_bias: workspace too small");
+    if (ws_bytes < gs_channel_sum_workspace_bytes(p, c)) return fail(GS_ERR_WORKSPACE, "act_bwd_bias: workspace too small");
     hipStream_t st = as_stream(stream);
     float* part = (float*)ws;
     GS_DISPATCH_DTYPE(dtype, {
@@ -514,9 +533,7 @@ extern "C" int gs_act_bwd_bias(const void* g, const void* y, void* gx, float* gb
         else hipLaunchKernelGGL((act_bwd_sum_kernel<T, 2>), dim3(nparts), dim3(256), 0, st, (const T*)g, (const T*)y, (T*)gx, part, (long)p, c);
     });
     GS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(channel_sum_final_kernel, dim3(cdiv(c, 32)), dim3(256), 0, st, part, gb, nparts, c);
-    GS_CHECK_LAUNCH();
-    return 0;
+    return channel_sum_finalize(part, gb, nparts, c, st);
 }
 
 static int pixel_norm_launch(int mode, const void* a0, const void* a1, const void* a2, void* out, int64_t p, int c, float eps, int dtype, void* stream) {

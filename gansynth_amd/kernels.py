@@ -73,18 +73,23 @@ class HipKernels(object):
     # --------------------------------------------------------- prepared-weight workspaces
     def register_param_buffer(self, flat):
         """Weights living in `flat` may keep their kernel operand (re-laid, storage dtype) between calls."""
-        self._param_ranges.append((flat.data_ptr(), flat.numel() * flat.element_size()))
+        self._param_ranges.append([flat.data_ptr(), flat.numel() * flat.element_size(), 0])
 
-    def invalidate_weights(self):
-        self._epoch += 1
+    def invalidate_weights(self, flat=None):
+        """Parameter values changed (all registered buffers, or only the one `flat` lives in)."""
+        ptr = None if flat is None else flat.data_ptr()
+        for rng in self._param_ranges:
+            if ptr is None or rng[0] <= ptr < rng[0] + rng[1]:
+                rng[2] += 1
 
     def _weight_ws(self, w, tag, nbytes):
         """-> (workspace, w_prepared).  A registered parameter gets one persistent workspace per conv map, reused
         (w_prepared = 1) until the parameter values change; anything else gets a transient workspace."""
         ptr = w.data_ptr()
-        if not any(lo <= ptr < lo + n for lo, n in self._param_ranges):
+        rng = next((r for r in self._param_ranges if r[0] <= ptr < r[0] + r[1]), None)
+        if rng is None:
             return _ws(nbytes, w.device), 0
-        key, stamp = (ptr, tag), (self._epoch, w._version)
+        key, stamp = (ptr, tag), (rng[2], w._version)
         ent = self._wcache.get(key)
         if ent is not None and ent[0].numel() >= nbytes:
             if ent[1] == stamp:
@@ -369,7 +374,7 @@ class HipKernels(object):
             assert t.dtype == torch.float32 and t.is_contiguous()
         _lib.check(self.lib.gs_adam_tf_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), float(lr_t), float(beta1),
                                             float(beta2), float(eps), float(grad_scale), _stream()), "gs_adam_tf_step")
-        self._epoch += 1  # parameter values changed: cached kernel operands are stale
+        self.invalidate_weights(p)  # parameter values changed: cached kernel operands of that buffer are stale
 
     # --------------------------------------------------------------------------- profiling
     def prof_enable(self, on):
