@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="per-GPU batch (weak scaling)")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default=os.environ.get("GS_BENCH_DTYPE", "bf16"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graphs", action="store_true", help="launch every kernel eagerly instead of replaying hipGraphs")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -106,7 +107,7 @@ def main():
         return lat
 
     model = GANSynth(pggan.generator, pggan.discriminator, real_input_fn, fake_input_fn, None, hyper, dtype=dtype,
-                     distributed=distributed)
+                     distributed=distributed, use_graphs=not args.no_graphs)
     K = kernels.get()
 
     def barrier():
@@ -114,15 +115,24 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 1)):
         model.train_step()
     barrier()
-    K.prof_enable(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         d_loss, g_loss = model.train_step()
     barrier()
     elapsed = time.perf_counter() - t0
+    # per-kernel roofline: the same iteration launched eagerly with a HIP event pair around every
+    # conv_igemm_kernel launch on its own stream (events cannot bracket kernels inside a replayed hipGraph)
+    prof_steps = min(args.steps, 5)
+    model.use_graphs = False
+    model.train_step()
+    barrier()
+    K.prof_enable(True)
+    for _ in range(prof_steps):
+        model.train_step()
+    barrier()
     launches, conv_ms, conv_flops = K.prof_collect()
     K.prof_enable(False)
     if distributed:
@@ -142,12 +152,14 @@ def main():
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[1]: fully grown PGGAN 128x1024x2 G+D iteration (D update + G update, "
                                    "R1 + mode-seeking), per-GPU batch %d, random-init weights" % args.batch,
-                       "global_batch": global_batch, "parallelism": "dp%d" % world},
+                       "global_batch": global_batch, "parallelism": "dp%d" % world,
+                       "launch": "eager" if args.no_graphs else "hipGraph replay of fwd+bwd per run; all-reduce + Adam eager"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK[args.dtype], "unit": "TFLOP/s",
                          "frac": achieved / PEAK[args.dtype], "traffic": None,
                          "kernel": "conv_igemm_kernel<*> (MFMA implicit-GEMM 3x3 conv: fwd, bwd-data, transposed conv; all instantiations)",
                          "launches": launches, "avg_launch_ms": conv_ms / max(launches, 1),
-                         "time_share": conv_ms / (elapsed * 1e3)},
+                         "time_share": (conv_ms / prof_steps) / (elapsed * 1e3 / args.steps),
+                         "measured_over": "%d eager iterations after the timed region (same build, same inputs)" % prof_steps},
             "model_flops_utilization": value * FLOPS_PER_IMAGE / 1e12 / PEAK[args.dtype] / world,
             "losses": {"discriminator": float(d_loss), "generator": float(g_loss)},
         }

@@ -63,7 +63,7 @@ class _FlatParams(object):
 class GANSynth(object):
 
     def __init__(self, generator, discriminator, real_input_fn, fake_input_fn, spectral_params, hyper_params,
-                 dtype=torch.float32, store=None, distributed=False):
+                 dtype=torch.float32, store=None, distributed=False, use_graphs=False):
         self.generator, self.discriminator = generator, discriminator
         self.real_input_fn, self.fake_input_fn = real_input_fn, fake_input_fn
         self.spectral_params, self.hyper_params = spectral_params, hyper_params
@@ -76,6 +76,11 @@ class GANSynth(object):
         self.d_params = None
         self.generator_loss = None
         self.discriminator_loss = None
+        # hipGraph replay of the forward+backward of each run (launch-bound otherwise: ~600 kernels per run).
+        # Only valid while the network structure and every by-value kernel scalar are step-invariant, i.e. in the
+        # fully grown regime (no fade coefficient); the optimizer update and the all-reduce stay outside the graph.
+        self.use_graphs = bool(use_graphs)
+        self._graphs = {}
 
     # ----------------------------------------------------------------------------- build
     def _build(self, latents, labels):
@@ -161,29 +166,69 @@ class GANSynth(object):
         kernels.get().adam_tf_step(params.flat, params.grad, params.m, params.v, lr_t, beta1, beta2, 1.0e-8,
                                    1.0 / self.world)
 
+    def _forward_backward(self, which, *inputs):
+        """Gradients of one run into the flat gradient buffer; returns the (detached) mean loss."""
+        if which == "d":
+            self.g_params.requires_grad_(False)
+            self.d_params.requires_grad_(True)
+            self.d_params.zero_grad()
+            loss = self.discriminator_losses(*inputs).mean()
+        else:
+            self.g_params.requires_grad_(True)
+            self.d_params.requires_grad_(False)
+            self.g_params.zero_grad()
+            loss = self.generator_losses(*inputs).mean()
+        loss.backward()
+        return loss.detach()
+
+    def _graphable(self):
+        owner = getattr(self.generator, "__self__", None)
+        if not self.use_graphs or owner is None or not hasattr(owner, "_head_depth"):
+            return False
+        head, fade = owner._head_depth(owner.growing_depth)
+        return fade is None and head == owner.max_depth
+
+    def _run(self, which, *inputs):
+        if not self._graphable():
+            self._graphs.clear()
+            return self._forward_backward(which, *inputs)
+        entry = self._graphs.get(which)
+        if entry is None or any(a.shape != b.shape or a.dtype != b.dtype for a, b in zip(entry[1], inputs)):
+            static = [t.detach().clone() for t in inputs]
+            K = kernels.get()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):  # one eager pass on a side stream (allocator / lazy-init warm-up)
+                self._forward_backward(which, *static)
+            torch.cuda.current_stream().wait_stream(side)
+            K.invalidate_weights()  # every weight operand must be (re)built INSIDE the captured graph
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                loss = self._forward_backward(which, *static)
+            K.invalidate_weights()
+            entry = (graph, static, loss)
+            self._graphs[which] = entry
+        graph, static, loss = entry
+        for dst, src in zip(static, inputs):
+            dst.copy_(src)
+        graph.replay()
+        return loss
+
     def discriminator_step(self, latents, labels, real_images):
         self._ensure_built(latents, labels)
         hp = self.hyper_params
-        self.g_params.requires_grad_(False)
-        self.d_params.requires_grad_(True)
-        self.d_params.zero_grad()
-        loss = self.discriminator_losses(latents, labels, real_images).mean()
-        loss.backward()
+        loss = self._run("d", latents, labels, real_images)
         self._apply(self.d_params, hp.discriminator_learning_rate, hp.discriminator_beta1, hp.discriminator_beta2)
-        self.discriminator_loss = loss.detach()
+        self.discriminator_loss = loss
         return self.discriminator_loss
 
     def generator_step(self, latents, labels):
         self._ensure_built(latents, labels)
         hp = self.hyper_params
-        self.g_params.requires_grad_(True)
-        self.d_params.requires_grad_(False)
-        self.g_params.zero_grad()
-        loss = self.generator_losses(latents, labels).mean()
-        loss.backward()
+        loss = self._run("g", latents, labels)
         self._apply(self.g_params, hp.generator_learning_rate, hp.generator_beta1, hp.generator_beta2)
         self.global_step += 1  # models.py:84
-        self.generator_loss = loss.detach()
+        self.generator_loss = loss
         return self.generator_loss
 
     def train_step(self):

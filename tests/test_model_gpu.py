@@ -173,3 +173,27 @@ def test_bf16_path_tracks_fp32(gpu_store):
             if b.numel() >= 4096 and float(b.norm()) > 0:
                 cos = float((a @ b) / (a.norm() * b.norm() + 1e-30))
                 assert cos > 0.95, (k, cos)
+
+
+def test_hipgraph_replay_equals_eager(gpu_store):
+    """Fully grown regime: replaying the captured forward+backward gives the same losses / parameters as eager launches."""
+    from gansynth_amd import variables
+    out = {}
+    for graphs in (False, True):
+        variables.set_default_store(variables.VariableStore(device="cuda"))
+        pg, opg, model = make(1.0, variables.default_store(), full=False)
+        model.use_graphs = graphs
+        gp, dp = opg.init_params(seed=0, bias_std=0.1)
+        losses = []
+        for step in range(3):
+            lat, lab, real = R.synthetic_batch(4, rank=step, image_shape=(2, 16, 128))
+            if step == 0:
+                model._build(cuda(lat), cuda(lab))
+                variables.default_store().load_state_dict({**gp, **dp})
+            losses.append(float(model.discriminator_step(cuda(lat), cuda(lab), cuda(real))))
+            losses.append(float(model.generator_step(cuda(lat), cuda(lab))))
+        out[graphs] = (losses, model.d_params.flat.clone(), model.g_params.flat.clone())
+        if graphs:
+            assert set(model._graphs) == {"d", "g"}
+    assert out[False][0] == out[True][0], (out[False][0], out[True][0])
+    assert torch.equal(out[False][1], out[True][1]) and torch.equal(out[False][2], out[True][2])
