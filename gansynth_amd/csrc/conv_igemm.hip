@@ -130,6 +130,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char* const lpatch = lds;                // 2 x PBYTES
     unsigned char* const lwgt = lds + 2 * PBYTES;     // streamed: 2 x WBYTES ; resident: nch x WBYTES
+    float* const lbias = reinterpret_cast<float*>(lwgt + (RESIDENT ? p.nch : 2) * WBYTES);  // OC floats (zeros without a bias)
 
     const T* __restrict__ x = reinterpret_cast<const T*>(p.x);
     const T* __restrict__ wp = reinterpret_cast<const T*>(p.wp);
@@ -157,7 +158,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
     }
     if (count == 0) return;
 
-    uint4 preg[PREG], wreg[WREG];
+    uint4 preg[PREG], wreg[WREG];  // (zero-initialised: conditionally-assigned struct arrays otherwise end up in scratch)
+#pragma unroll
+    for (int r = 0; r < WREG; ++r) wreg[r] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < PREG; ++r) preg[r] = make_uint4(0, 0, 0, 0);
+    unsigned int pmask = 0;  // which patch slots of the prefetched stage lie inside the image
 
     // ---- per-thread staging descriptors, constant for the life of the block (keeps the per-stage address
     //      arithmetic down to one add + two unsigned compares per 16-byte slot)
@@ -184,7 +190,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
         w_lds[r] = ok ? R * 64 + ((part ^ ((R >> 2) & 3)) << 4) : -1;
     }
 
-    auto item_coords = [&](int item, int& n, int& by, int& bx, int& oc0) {
+    auto item_coords = [&](int item, int& n, int& by, int& bx, int& oc0) __attribute__((always_inline)) {
         const int sp = item / p.noct;
         oc0 = (item - sp * p.noct) * OCT;
         const int tile_x = sp % p.tiles_x;
@@ -193,59 +199,59 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
         bx = tile_x * TW;
         n = r / p.tiles_y;
     };
-    auto load_patch = [&](int item, int ch) {
+    auto load_patch = [&](int item, int ch) __attribute__((always_inline)) {
         int n, by, bx, oc0;
         item_coords(item, n, by, bx, oc0);
         const int oy0 = MODE == MODE_S2 ? 2 * by : by - 1;
         const int ox0 = MODE == MODE_S2 ? 2 * bx : bx - 1;
         const unsigned char* xb = reinterpret_cast<const unsigned char*>(x) +
                                   ((((long)n * Hi + oy0) * Wi + ox0) * IC + ch * BK) * (long)sizeof(T);
+        // NOTE: every load is unconditional (out-of-image slots read the tensor base and are zeroed when they are
+        // written to LDS).  A per-slot `if (inside) load` makes hipcc branch around each load and drain vmcnt(0)
+        // per slot, which serialises the whole prefetch into dependent L2 round trips.
+        pmask = 0;
 #pragma unroll
         for (int r = 0; r < PREG; ++r) {
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if ((unsigned)(oy0 + (p_ll[r] >> 16)) < (unsigned)Hi && (unsigned)(ox0 + (p_ll[r] & 0xffff)) < (unsigned)Wi)
-                v = *reinterpret_cast<const uint4*>(xb + p_off[r]);
-            preg[r] = v;
+            const bool ok = (unsigned)(oy0 + (p_ll[r] >> 16)) < (unsigned)Hi && (unsigned)(ox0 + (p_ll[r] & 0xffff)) < (unsigned)Wi;
+            pmask |= ok ? (1u << r) : 0u;
+            const unsigned char* src = ok ? xb + p_off[r] : reinterpret_cast<const unsigned char*>(x);
+            preg[r] = *reinterpret_cast<const uint4*>(src);
         }
     };
-    auto store_patch = [&](int buf) {
+    auto store_patch = [&](int buf) __attribute__((always_inline)) {
         unsigned char* dst = lpatch + buf * PBYTES;
 #pragma unroll
-        for (int r = 0; r < PREG; ++r)
-            if (p_lds[r] >= 0) *reinterpret_cast<uint4*>(dst + p_lds[r]) = preg[r];
+        for (int r = 0; r < PREG; ++r) {
+            const uint4 v = (pmask >> r) & 1u ? preg[r] : make_uint4(0, 0, 0, 0);
+            if (PCH % 256 == 0 || r < PREG - 1 || p_lds[r] >= 0) *reinterpret_cast<uint4*>(dst + (p_lds[r] >= 0 ? p_lds[r] : 0)) = v;
+        }
     };
-    auto load_weights = [&](int oc0, int ch, int tg) {
+    auto load_weights = [&](int oc0, int ch, int tg) __attribute__((always_inline)) {
         if (MODE != MODE_T2) {
             const unsigned char* wb = reinterpret_cast<const unsigned char*>(wp) +
                                       (((long)tg * TG * OC + oc0) * IC + ch * BK) * (long)sizeof(T);
 #pragma unroll
-            for (int r = 0; r < WREG; ++r) {
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (w_off[r] >= 0) v = *reinterpret_cast<const uint4*>(wb + w_off[r]);
-                wreg[r] = v;
-            }
+            for (int r = 0; r < WREG; ++r)  // unconditional (slots past the end re-read slot 0 and are not stored)
+                wreg[r] = *reinterpret_cast<const uint4*>(wb + (w_off[r] >= 0 ? w_off[r] : 0));
         } else {
 #pragma unroll
             for (int r = 0; r < WREG; ++r) {
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (w_off[r] >= 0) {
-                    const int i = tg * TG + (w_off[r] >> 16), row = w_off[r] & 0xffff;
-                    const int wt = tap_ky<MODE>(i) * 3 + tap_kx<MODE>(i);
-                    const T* src = wp + ((long)wt * OC + oc0 + row) * IC + ch * BK;
-                    v = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(src) + ((tid + 256 * r) & 3) * 16);
-                }
-                wreg[r] = v;
+                const int wo = w_off[r] >= 0 ? w_off[r] : 0;
+                const int i = tg * TG + (wo >> 16), row = wo & 0xffff;
+                const int wt = tap_ky<MODE>(i) * 3 + tap_kx<MODE>(i);
+                const T* src = wp + ((long)wt * OC + oc0 + row) * IC + ch * BK;
+                wreg[r] = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(src) + ((tid + 256 * r) & 3) * 16);
             }
         }
     };
-    auto store_weights = [&](unsigned char* dst) {
+    auto store_weights = [&](unsigned char* dst) __attribute__((always_inline)) {
 #pragma unroll
         for (int r = 0; r < WREG; ++r)
-            if (w_lds[r] >= 0) *reinterpret_cast<uint4*>(dst + w_lds[r]) = wreg[r];
+            if (WCH % 256 == 0 || r < WREG - 1 || w_lds[r] >= 0) *reinterpret_cast<uint4*>(dst + (w_lds[r] >= 0 ? w_lds[r] : 0)) = wreg[r];
     };
 
     f32x16 acc[NPH][A][B];
-    auto zero_acc = [&]() {
+    auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int ph = 0; ph < NPH; ++ph)
 #pragma unroll
@@ -272,6 +278,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
     }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) a_off[ks] = l31 * 64 + (((ks * 2 + hi) ^ ((l31 >> 2) & 3)) << 4);
+
+    for (int c = tid; c < OC; c += 256) lbias[c] = p.bias ? p.bias[c] : 0.f;
 
     // ---- prologue
     int item = first, done = 0;
@@ -362,10 +370,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
                                             float o[4];
 #pragma unroll
                                             for (int e = 0; e < 4; ++e) o[e] = acc[ph][a][b][qd * 4 + e] * p.alpha;
-                                            if (p.bias) {
-                                                const float4 bv = *reinterpret_cast<const float4*>(p.bias + oc0 + a * 32 + qd * 8 + hi * 4);
-                                                o[0] += bv.x; o[1] += bv.y; o[2] += bv.z; o[3] += bv.w;
-                                            }
+                                            const float4 bv = *reinterpret_cast<const float4*>(lbias + oc0 + a * 32 + qd * 8 + hi * 4);
+                                            o[0] += bv.x; o[1] += bv.y; o[2] += bv.z; o[3] += bv.w;
                                             if (p.act == GS_ACT_LRELU) {
 #pragma unroll
                                                 for (int e = 0; e < 4; ++e) o[e] = o[e] > 0.f ? o[e] : 0.2f * o[e];
@@ -439,16 +445,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
             const int pix = c >> 3, part = c & 7;
             const int ly = pix / PW, lx = pix % PW;
             const int iy = oy0 + ly, ix = ox0 + lx;
-            float v[4] = {0.f, 0.f, 0.f, 0.f};
-            if (iy >= 0 && iy < Hi && ix >= 0 && ix < Wi) ld4(x + (((long)n * Hi + iy) * Wi + ix) * IC + ic0 + part * 4, v);
-            *reinterpret_cast<float4*>(lp + pix * ROWF + part * 4) = make_float4(v[0], v[1], v[2], v[3]);
+            float v[4];
+            const bool ok = iy >= 0 && iy < Hi && ix >= 0 && ix < Wi;
+            ld4(ok ? x + (((long)n * Hi + iy) * Wi + ix) * IC + ic0 + part * 4 : x, v);  // unconditional load, zero-select after
+            *reinterpret_cast<float4*>(lp + pix * ROWF + part * 4) = ok ? make_float4(v[0], v[1], v[2], v[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         for (int c = tid; c < NP * 8; c += 256) {
             const int pix = c >> 3, part = c & 7;
             const int gy_ = by + pix / TW, gx_ = bx + pix % TW;
-            float v[4] = {0.f, 0.f, 0.f, 0.f};
-            if (gy_ < Hb && gx_ < Wb) ld4(gy + (((long)n * Hb + gy_) * Wb + gx_) * OC + oc0 + part * 4, v);
-            *reinterpret_cast<float4*>(lg + pix * ROWF + part * 4) = make_float4(v[0], v[1], v[2], v[3]);
+            float v[4];
+            const bool ok = gy_ < Hb && gx_ < Wb;
+            ld4(ok ? gy + (((long)n * Hb + gy_) * Wb + gx_) * OC + oc0 + part * 4 : gy, v);
+            *reinterpret_cast<float4*>(lg + pix * ROWF + part * 4) = ok ? make_float4(v[0], v[1], v[2], v[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         __syncthreads();
 #pragma unroll 2
@@ -548,35 +556,36 @@ __global__ __launch_bounds__(192) void conv_wgrad_bf16_kernel(
         const int oy0 = S2 ? 2 * by : by - 1;
         const int ox0 = S2 ? 2 * bx : bx - 1;
         uint4 xv[XIT], gv[GIT];
+        unsigned int xok = 0, gok = 0;
 #pragma unroll
         for (int it = 0; it < XIT; ++it) {
             const int c = tid + 192 * it;
             const int pix = c >> 2, part4 = c & 3;
             const int ly = pix / PW, lx = pix - ly * PW;
             const int iy = oy0 + ly, ix = ox0 + lx;
-            xv[it] = make_uint4(0, 0, 0, 0);
-            if (c < XCH && iy >= 0 && iy < Hi && ix >= 0 && ix < Wi)
-                xv[it] = *reinterpret_cast<const uint4*>(x + (((long)n * Hi + iy) * Wi + ix) * IC + ic0 + part4 * 8);
+            const bool ok = c < XCH && (unsigned)iy < (unsigned)Hi && (unsigned)ix < (unsigned)Wi;
+            xok |= ok ? (1u << it) : 0u;   // loads are unconditional; out-of-image slots are zeroed at the LDS store
+            xv[it] = *reinterpret_cast<const uint4*>(ok ? x + (((long)n * Hi + iy) * Wi + ix) * IC + ic0 + part4 * 8 : x);
         }
 #pragma unroll
         for (int it = 0; it < GIT; ++it) {
             const int c = tid + 192 * it;
             const int pix = c >> 2, part4 = c & 3;
             const int gy_ = by + pix / TW, gx_ = bx + pix % TW;
-            gv[it] = make_uint4(0, 0, 0, 0);
-            if (c < GCH && gy_ < Hb && gx_ < Wb)
-                gv[it] = *reinterpret_cast<const uint4*>(gy + (((long)n * Hb + gy_) * Wb + gx_) * OC + oc0 + part4 * 8);
+            const bool ok = c < GCH && gy_ < Hb && gx_ < Wb;
+            gok |= ok ? (1u << it) : 0u;
+            gv[it] = *reinterpret_cast<const uint4*>(ok ? gy + (((long)n * Hb + gy_) * Wb + gx_) * OC + oc0 + part4 * 8 : gy);
         }
         __syncthreads();  // every wave is done reading the previous tile
 #pragma unroll
         for (int it = 0; it < XIT; ++it) {
             const int c = tid + 192 * it;
-            if (c < XCH) *reinterpret_cast<uint4*>(lx_ + c * 16) = xv[it];
+            if (c < XCH) *reinterpret_cast<uint4*>(lx_ + c * 16) = (xok >> it) & 1u ? xv[it] : make_uint4(0, 0, 0, 0);
         }
 #pragma unroll
         for (int it = 0; it < GIT; ++it) {
             const int c = tid + 192 * it;
-            if (c < GCH) *reinterpret_cast<uint4*>(lg_ + c * 16) = gv[it];
+            if (c < GCH) *reinterpret_cast<uint4*>(lg_ + c * 16) = (gok >> it) & 1u ? gv[it] : make_uint4(0, 0, 0, 0);
         }
         __syncthreads();
         // ---- MFMAs: this wave's kernel row (ky = wv) over every 16-pixel group of the tile
@@ -638,7 +647,7 @@ static int launch_igemm(ConvP p, hipStream_t st) {
     p.noct = cdiv(p.OC, OCT);
     p.nch = p.IC / BK;
     const int wbufs = RESIDENT ? p.nch : 2;
-    const size_t lds = (size_t)2 * PH * PW * 64 + (size_t)wbufs * TG * OCT * 64;
+    const size_t lds = (size_t)2 * PH * PW * 64 + (size_t)wbufs * TG * OCT * 64 + (size_t)((p.OC + 3) / 4) * 16;
     if (lds > 160 * 1024) return fail(GS_ERR_UNSUPPORTED, "conv igemm: %zu bytes of LDS needed", lds);
     auto kern = conv_igemm_kernel<T, MODE, A, B, TW, TG, RESIDENT>;
     static size_t max_set = 0;  // per template instantiation
