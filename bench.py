@@ -145,6 +145,10 @@ def main():
     if rank == 0:
         value = global_batch * args.steps / elapsed
         achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        traffic = None  # HBM bytes per launch of the same kernel from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE)
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_igemm_traffic.json")
+        if args.dtype == "bf16" and args.batch == 8 and os.path.exists(pmc):
+            traffic = json.load(open(pmc))["avg_hbm_bytes_per_launch"]
         out = {
             "metric": "G+D step images/sec at 128x1024x2 mel+IF",
             "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -155,7 +159,8 @@ def main():
                        "global_batch": global_batch, "parallelism": "dp%d" % world,
                        "launch": "eager" if args.no_graphs else "hipGraph replay of fwd+bwd per run; all-reduce + Adam eager"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK[args.dtype], "unit": "TFLOP/s",
-                         "frac": achieved / PEAK[args.dtype], "traffic": None,
+                         "frac": achieved / PEAK[args.dtype], "traffic": traffic,
+                         "algorithmic_flops_per_launch": conv_flops / max(launches, 1),
                          "kernel": "conv_igemm_kernel<*> (MFMA implicit-GEMM 3x3 conv: fwd, bwd-data, transposed conv; all instantiations)",
                          "launches": launches, "avg_launch_ms": conv_ms / max(launches, 1),
                          "time_share": (conv_ms / prof_steps) / (elapsed * 1e3 / args.steps),
