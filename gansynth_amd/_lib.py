@@ -27,24 +27,24 @@ SIGNATURES = {
     "gs_conv2d_fwd": (I, [P, P, P, I, I, I, I, I, I, I, F, I, I, P, Z, P]),
     "gs_conv2d_fwd_bias_act": (I, [P, P, P, P, I, I, I, I, I, I, I, F, I, I, I, P, Z, P]),
     "gs_conv2d_bwd_data": (I, [P, P, P, I, I, I, I, I, I, I, F, I, I, P, Z, P]),
-    "gs_conv2d_bwd_weight": (I, [P, P, P, I, I, I, I, I, I, I, F, I, P, Z, P]),
+    "gs_conv2d_bwd_weight": (I, [P, P, P, I, I, I, I, I, I, I, F, I, I, P, Z, P]),
     "gs_conv2d_transpose_s2_workspace_bytes": (Z, [I, I, I, I, I, I, I]),
     "gs_conv2d_transpose_s2_fwd": (I, [P, P, P, I, I, I, I, I, F, I, I, P, Z, P]),
     "gs_conv2d_transpose_s2_fwd_bias_act": (I, [P, P, P, P, I, I, I, I, I, F, I, I, I, P, Z, P]),
     "gs_conv2d_transpose_s2_bwd_data": (I, [P, P, P, I, I, I, I, I, F, I, I, P, Z, P]),
-    "gs_conv2d_transpose_s2_bwd_weight": (I, [P, P, P, I, I, I, I, I, F, I, P, Z, P]),
+    "gs_conv2d_transpose_s2_bwd_weight": (I, [P, P, P, I, I, I, I, I, F, I, I, P, Z, P]),
     "gs_dense_fwd_workspace_bytes": (Z, [I, I, I]),
     "gs_dense_fwd": (I, [P, P, P, I, I, I, F, I, P, Z, P]),
     "gs_dense_bwd_data": (I, [P, P, P, I, I, I, F, I, P]),
-    "gs_dense_bwd_weight": (I, [P, P, P, I, I, I, F, I, P]),
+    "gs_dense_bwd_weight": (I, [P, P, P, I, I, I, F, I, I, P]),
     "gs_embedding_fwd": (I, [P, P, P, I, I, I, F, I, P]),
     "gs_embedding_bwd": (I, [P, P, P, I, I, I, F, I, P]),
     "gs_bias_act_fwd": (I, [P, P, P, L, I, I, I, P]),
     "gs_act_bwd": (I, [P, P, P, L, I, I, P]),
-    "gs_act_bwd_bias": (I, [P, P, P, P, L, I, I, I, P, Z, P]),
+    "gs_act_bwd_bias": (I, [P, P, P, P, L, I, I, I, I, P, Z, P]),
     "gs_tanh_bwd_bwd": (I, [P, P, P, P, L, I, P]),
     "gs_channel_sum_workspace_bytes": (Z, [L, I]),
-    "gs_channel_sum": (I, [P, P, L, I, I, P, Z, P]),
+    "gs_channel_sum": (I, [P, P, L, I, I, I, P, Z, P]),
     "gs_pixel_norm_fwd": (I, [P, P, L, I, F, I, P]),
     "gs_pixel_norm_bwd": (I, [P, P, P, L, I, F, I, P]),
     "gs_pixel_norm_bwd_bwd": (I, [P, P, P, P, L, I, F, I, P]),

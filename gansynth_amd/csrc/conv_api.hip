@@ -15,7 +15,7 @@ int run_igemm(int mode, int variant, const void* x, const float* w_hwio, void* y
               void* ws, size_t ws_bytes, hipStream_t st);
 size_t wgrad_mfma_bytes(int mode, int dtype, int N, int Hb, int Wb, int IC, int OC);
 int run_wgrad_mfma(int mode, const void* x, const void* gy, float* gw, int N, int Hi, int Wi, int IC, int OC, int Hb,
-                   int Wb, float alpha, int transpose, int dtype, void* ws, size_t ws_bytes, hipStream_t st);
+                   int Wb, float alpha, int transpose, int accumulate, int dtype, void* ws, size_t ws_bytes, hipStream_t st);
 
 // ------------------------------------------------------------------------- direct gather conv
 // y[n][oy][ox][oc0..oc0+OCV) = alpha * sum_{tap,ic} x[n][iy][ix][ic] * wp[tap][oc][ic]   (wp fp32)
@@ -231,7 +231,7 @@ static size_t wgrad_direct_bytes(int ks, int N, int Hb, int Wb, int IC, int OC) 
 }
 
 static int run_wgrad_direct(int mode, int ks, const void* x, const void* gy, float* gw, int N, int Hi, int Wi, int IC,
-                            int OC, int Hb, int Wb, float alpha, int transpose, int dtype, void* ws, size_t ws_bytes,
+                            int OC, int Hb, int Wb, float alpha, int transpose, int accumulate, int dtype, void* ws, size_t ws_bytes,
                             hipStream_t st) {
     long ns, pps;
     const long npix = (long)N * Hb * Wb;
@@ -249,7 +249,7 @@ static int run_wgrad_direct(int mode, int ks, const void* x, const void* gy, flo
                                                         reinterpret_cast<const T*>(x), reinterpret_cast<const T*>(gy), tpart, C, npix, pps));
         }
         GS_CHECK_LAUNCH();
-        wgrad_reduce_launch(tpart, gw, (int)ns, 1, IC, OC, alpha, transpose, st);
+        wgrad_reduce_launch(tpart, gw, (int)ns, 1, IC, OC, alpha, transpose, accumulate, st);
         GS_CHECK_LAUNCH();
         return 0;
     }
@@ -261,7 +261,7 @@ static int run_wgrad_direct(int mode, int ks, const void* x, const void* gy, flo
                                                 reinterpret_cast<const T*>(x), reinterpret_cast<const T*>(gy), part, mode,
                                                 ks, N, Hi, Wi, IC, OC, Hb, Wb, E, npix, pps));
     GS_CHECK_LAUNCH();
-    wgrad_reduce_launch(part, gw, (int)ns, ks * ks, IC, OC, alpha, transpose, st);
+    wgrad_reduce_launch(part, gw, (int)ns, ks * ks, IC, OC, alpha, transpose, accumulate, st);
     GS_CHECK_LAUNCH();
     return 0;
 }
@@ -334,14 +334,14 @@ extern "C" int gs_conv2d_bwd_data(const void* gy, const float* w_hwio, void* gx,
 }
 
 extern "C" int gs_conv2d_bwd_weight(const void* x, const void* gy, float* gw_hwio, int n, int h, int w, int ci, int co,
-                                    int ksize, int stride, float alpha, int dtype, void* ws, size_t ws_bytes, void* stream) {
+                                    int ksize, int stride, float alpha, int accumulate, int dtype, void* ws, size_t ws_bytes, void* stream) {
     if (int e = check_conv_args(n, h, w, ci, co, ksize, stride, dtype)) return e;
     hipStream_t st = as_stream(stream);
     const int hb = h / stride, wb = w / stride;
     const int mode = stride == 2 ? MODE_S2 : MODE_S1;
     if (ksize == 3 && wgrad_mfma_supported(ci, co, dtype))
-        return run_wgrad_mfma(mode, x, gy, gw_hwio, n, h, w, ci, co, hb, wb, alpha, 0, dtype, ws, ws_bytes, st);
-    return run_wgrad_direct(mode, ksize, x, gy, gw_hwio, n, h, w, ci, co, hb, wb, alpha, 0, dtype, ws, ws_bytes, st);
+        return run_wgrad_mfma(mode, x, gy, gw_hwio, n, h, w, ci, co, hb, wb, alpha, 0, accumulate, dtype, ws, ws_bytes, st);
+    return run_wgrad_direct(mode, ksize, x, gy, gw_hwio, n, h, w, ci, co, hb, wb, alpha, 0, accumulate, dtype, ws, ws_bytes, st);
 }
 
 // ---- conv2d_transpose 3x3 stride 2: re-labelings of the stride-2 maps (see include/gansynth_hip.h)
@@ -389,11 +389,11 @@ extern "C" int gs_conv2d_transpose_s2_bwd_data(const void* gy, const float* w_hw
 }
 
 extern "C" int gs_conv2d_transpose_s2_bwd_weight(const void* x, const void* gy, float* gw_hwio, int n, int h, int w, int ci,
-                                                 int co, float alpha, int dtype, void* ws, size_t ws_bytes, void* stream) {
+                                                 int co, float alpha, int accumulate, int dtype, void* ws, size_t ws_bytes, void* stream) {
     if (int e = check_conv_args(n, 2 * h, 2 * w, co, ci, 3, 2, dtype)) return e;
     hipStream_t st = as_stream(stream);
     // gw[k][ci][co] = sum x[i][ci] * gy[2i+k][co]: stride-2 wgrad with (input side = gy, output side = x), transposed
     if (wgrad_mfma_supported(co, ci, dtype))
-        return run_wgrad_mfma(MODE_S2, gy, x, gw_hwio, n, 2 * h, 2 * w, co, ci, h, w, alpha, 1, dtype, ws, ws_bytes, st);
-    return run_wgrad_direct(MODE_S2, 3, gy, x, gw_hwio, n, 2 * h, 2 * w, co, ci, h, w, alpha, 1, dtype, ws, ws_bytes, st);
+        return run_wgrad_mfma(MODE_S2, gy, x, gw_hwio, n, 2 * h, 2 * w, co, ci, h, w, alpha, 1, accumulate, dtype, ws, ws_bytes, st);
+    return run_wgrad_direct(MODE_S2, 3, gy, x, gw_hwio, n, 2 * h, 2 * w, co, ci, h, w, alpha, 1, accumulate, dtype, ws, ws_bytes, st);
 }

@@ -329,24 +329,30 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
                 // ---- MFMAs of this stage
                 const unsigned char* lp = lpatch + pb * PBYTES;
                 const unsigned char* lw = RESIDENT ? lwgt + ch * WBYTES : lwgt + wb * WBYTES;
-#pragma unroll
-                for (int tt = 0; tt < TG; ++tt) {
-                    const int i = tg * TG + tt;
-                    const int ph = tap_phase<MODE>(i);
-                    const int oyv = tap_off<MODE>(tap_ky<MODE>(i)), oxv = tap_off<MODE>(tap_kx<MODE>(i));
-#pragma unroll
-                    for (int ks = 0; ks < 2; ++ks) {
-                        frag_t af[A], bf[B];
+                // fragment reads are software-pipelined one (tap, k-step) ahead of the MFMAs that consume them: with one
+                // or two waves per SIMD nothing else hides the LDS latency (the compiler issues them just-in-time)
+                {
+                    frag_t af[2][A], bf[2][B];
+                    auto load_frags = [&](int step, int buf) __attribute__((always_inline)) {
+                        const int tt = step >> 1, ks = step & 1;
+                        const int i = tg * TG + tt;
+                        const int oyv = tap_off<MODE>(tap_ky<MODE>(i)), oxv = tap_off<MODE>(tap_kx<MODE>(i));
 #pragma unroll
                         for (int a = 0; a < A; ++a)
-                            af[a] = *reinterpret_cast<const frag_t*>(lw + (tt * OCT + a * 32) * 64 + a_off[ks]);
+                            af[buf][a] = *reinterpret_cast<const frag_t*>(lw + (tt * OCT + a * 32) * 64 + a_off[ks]);
 #pragma unroll
                         for (int b = 0; b < B; ++b)
-                            bf[b] = *reinterpret_cast<const frag_t*>(lp + oyv * PW * 64 + b_off[b][oxv][ks]);
+                            bf[buf][b] = *reinterpret_cast<const frag_t*>(lp + oyv * PW * 64 + b_off[b][oxv][ks]);
+                    };
+                    load_frags(0, 0);
+#pragma unroll
+                    for (int step = 0; step < 2 * TG; ++step) {
+                        if (step + 1 < 2 * TG) load_frags(step + 1, (step + 1) & 1);
+                        const int ph = tap_phase<MODE>(tg * TG + (step >> 1));
 #pragma unroll
                         for (int a = 0; a < A; ++a)
 #pragma unroll
-                            for (int b = 0; b < B; ++b) Mma<T>::mma(af[a], bf[b], acc[ph][a][b]);
+                            for (int b = 0; b < B; ++b) Mma<T>::mma(af[step & 1][a], bf[step & 1][b], acc[ph][a][b]);
                     }
                 }
                 // ---- epilogue of the item: D[oc][pixel]; a lane holds oc = 8q + 4hi + (0..3) of pixel l31 per quad
@@ -772,7 +778,7 @@ size_t wgrad_mfma_bytes(int mode, int dtype, int N, int Hb, int Wb, int IC, int 
 
 // x: conv input side [N][Hi][Wi][IC]; gy: [N][Hb][Wb][OC]; gw[9][IC][OC] (or transposed)
 int run_wgrad_mfma(int mode, const void* x, const void* gy, float* gw, int N, int Hi, int Wi, int IC, int OC, int Hb,
-                   int Wb, float alpha, int transpose, int dtype, void* ws, size_t ws_bytes, hipStream_t st) {
+                   int Wb, float alpha, int transpose, int accumulate, int dtype, void* ws, size_t ws_bytes, hipStream_t st) {
     int tw, tiles_x, tiles_y, ntiles, nslices;
     wgrad_geometry(mode, dtype, N, Hb, Wb, IC, OC, &tw, &tiles_x, &tiles_y, &ntiles, &nslices);
     const size_t need = ((size_t)nslices * 9 * IC * OC + wgrad_reduce_extra(nslices, 9L * IC * OC)) * sizeof(float);
@@ -802,7 +808,7 @@ int run_wgrad_mfma(int mode, const void* x, const void* gy, float* gw, int N, in
 #undef GS_WG
     }
     GS_CHECK_LAUNCH();
-    wgrad_reduce_launch(part, gw, nslices, 9, IC, OC, alpha, transpose, st);
+    wgrad_reduce_launch(part, gw, nslices, 9, IC, OC, alpha, transpose, accumulate, st);
     GS_CHECK_LAUNCH();
     return 0;
 }

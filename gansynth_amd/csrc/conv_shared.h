@@ -38,7 +38,7 @@ __global__ void weight_prep_kernel(const float* __restrict__ w, T* __restrict__ 
 // summation order -> deterministic.  With `raw` the slab sum is written un-scaled to out[blockIdx.y][e]
 // (first level of a two-level reduction when there are many slices).
 static __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ gw, int nslices,
-                                                                  int taps, int ic, int oc, float alpha, int transpose, int per, int raw) {
+                                                                  int taps, int ic, int oc, float alpha, int transpose, int per, int raw, int accumulate) {
     __shared__ float red[256];
     const long total = (long)taps * ic * oc;
     const long e = (long)blockIdx.x * 64 + (threadIdx.x & 63);
@@ -64,30 +64,30 @@ static __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* _
             return;
         }
         s *= alpha;
-        if (!transpose) {
-            gw[e] = s;
-        } else {
+        long dst = e;
+        if (transpose) {
             const int o = e % oc;
             const int i = (e / oc) % ic;
             const int t = e / ((long)ic * oc);
-            gw[((long)t * oc + o) * ic + i] = s;
+            dst = ((long)t * oc + o) * ic + i;
         }
+        gw[dst] = accumulate ? gw[dst] + s : s;
     }
 }
 
 constexpr int WG_SLAB = 64;  // slices per first-level block
 // extra fp32 elements the partial buffer needs behind its nslices*total partials
 static inline size_t wgrad_reduce_extra(long nslices, long total) { return nslices > WG_SLAB ? (size_t)((nslices + WG_SLAB - 1) / WG_SLAB) * total : 0; }
-static inline void wgrad_reduce_launch(float* part, float* gw, int nslices, int taps, int ic, int oc, float alpha, int transpose, hipStream_t st) {
+static inline void wgrad_reduce_launch(float* part, float* gw, int nslices, int taps, int ic, int oc, float alpha, int transpose, int accumulate, hipStream_t st) {
     const long total = (long)taps * ic * oc;
     const unsigned gx = (unsigned)((total + 63) / 64);
     if (nslices <= WG_SLAB) {
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(gx, 1), dim3(256), 0, st, part, gw, nslices, taps, ic, oc, alpha, transpose, nslices, 0);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(gx, 1), dim3(256), 0, st, part, gw, nslices, taps, ic, oc, alpha, transpose, nslices, 0, accumulate);
     } else {
         const int nsplit = (nslices + WG_SLAB - 1) / WG_SLAB;
         float* part2 = part + (long)nslices * total;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(gx, nsplit), dim3(256), 0, st, part, part2, nslices, taps, ic, oc, 1.f, 0, WG_SLAB, 1);
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(gx, 1), dim3(256), 0, st, part2, gw, nsplit, taps, ic, oc, alpha, transpose, nsplit, 0);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(gx, nsplit), dim3(256), 0, st, part, part2, nslices, taps, ic, oc, 1.f, 0, WG_SLAB, 1, 0);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(gx, 1), dim3(256), 0, st, part2, gw, nsplit, taps, ic, oc, alpha, transpose, nsplit, 0, accumulate);
     }
 }
 

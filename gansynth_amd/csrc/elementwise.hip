@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void act_bwd_sum_kernel(const T* __restrict__ 
 
 // out[s][ch] = sum over the s-th slab of `per` parts of part[k][ch]: block = 32 channels x 8 part lanes.
 // Called once (nsplit = 1) or twice (first level writes nsplit rows, second level sums them): fixed order.
-static __global__ __launch_bounds__(256) void channel_sum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int nparts, int c, int per) {
+static __global__ __launch_bounds__(256) void channel_sum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int nparts, int c, int per, int accumulate) {
     __shared__ float red[256];
     const int ch = blockIdx.x * 32 + (threadIdx.x & 31);
     const int pl = threadIdx.x >> 5;
@@ -201,18 +201,19 @@ static __global__ __launch_bounds__(256) void channel_sum_final_kernel(const flo
         float t = 0.f;
 #pragma unroll
         for (int k = 0; k < 8; ++k) t += red[k * 32 + threadIdx.x];
-        out[(long)blockIdx.y * c + ch] = t;
+        float* o = out + (long)blockIdx.y * c + ch;
+        *o = accumulate ? *o + t : t;
     }
 }
 constexpr int CS_SLAB = 64;  // parts per first-level block
-static int channel_sum_finalize(float* part, float* out, int nparts, int c, hipStream_t st) {
+static int channel_sum_finalize(float* part, float* out, int nparts, int c, int accumulate, hipStream_t st) {
     if (nparts <= CS_SLAB) {
-        hipLaunchKernelGGL(channel_sum_final_kernel, dim3(cdiv(c, 32), 1), dim3(256), 0, st, part, out, nparts, c, nparts);
+        hipLaunchKernelGGL(channel_sum_final_kernel, dim3(cdiv(c, 32), 1), dim3(256), 0, st, part, out, nparts, c, nparts, accumulate);
     } else {
         const int nsplit = cdiv(nparts, CS_SLAB);
         float* part2 = part + (long)nparts * c;
-        hipLaunchKernelGGL(channel_sum_final_kernel, dim3(cdiv(c, 32), nsplit), dim3(256), 0, st, part, part2, nparts, c, CS_SLAB);
-        hipLaunchKernelGGL(channel_sum_final_kernel, dim3(cdiv(c, 32), 1), dim3(256), 0, st, part2, out, nsplit, c, nsplit);
+        hipLaunchKernelGGL(channel_sum_final_kernel, dim3(cdiv(c, 32), nsplit), dim3(256), 0, st, part, part2, nparts, c, CS_SLAB, 0);
+        hipLaunchKernelGGL(channel_sum_final_kernel, dim3(cdiv(c, 32), 1), dim3(256), 0, st, part2, out, nsplit, c, nsplit, accumulate);
     }
     GS_CHECK_LAUNCH();
     return 0;
@@ -503,7 +504,7 @@ extern "C" size_t gs_channel_sum_workspace_bytes(int64_t p, int c) {
     return (size_t)(np + cdiv(np, CS_SLAB)) * c * sizeof(float);
 }
 
-extern "C" int gs_channel_sum(const void* g, float* out, int64_t p, int c, int dtype, void* ws, size_t ws_bytes, void* stream) {
+extern "C" int gs_channel_sum(const void* g, float* out, int64_t p, int c, int accumulate, int dtype, void* ws, size_t ws_bytes, void* stream) {
     GS_CHECK_ARG(p > 0 && c > 0, "channel_sum: bad args");
     const int nparts = channel_sum_parts(p, c);
     if (ws_bytes < gs_channel_sum_workspace_bytes(p, c)) return fail(GS_ERR_WORKSPACE, "channel_sum: workspace too small");
@@ -511,18 +512,18 @@ extern "C" int gs_channel_sum(const void* g, float* out, int64_t p, int c, int d
     float* part = (float*)ws;
     GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((channel_sum_kernel<T>), dim3(nparts), dim3(256), 0, st, (const T*)g, part, (long)p, c));
     GS_CHECK_LAUNCH();
-    return channel_sum_finalize(part, out, nparts, c, st);
+    return channel_sum_finalize(part, out, nparts, c, accumulate, st);
 }
 
 extern "C" int gs_act_bwd(const void* g, const void* y, void* gx, int64_t numel, int act, int dtype, void* stream);
 extern "C" size_t gs_channel_sum_workspace_bytes(int64_t p, int c);
 
-extern "C" int gs_act_bwd_bias(const void* g, const void* y, void* gx, float* gb, int64_t p, int c, int act, int dtype, void* ws,
-                               size_t ws_bytes, void* stream) {
+extern "C" int gs_act_bwd_bias(const void* g, const void* y, void* gx, float* gb, int64_t p, int c, int act, int accumulate, int dtype,
+                               void* ws, size_t ws_bytes, void* stream) {
     GS_CHECK_ARG(p > 0 && c > 0 && (act == 1 || act == 2), "act_bwd_bias: bad args");
     if ((c & 3) != 0 || c > 1024 || 256 % (c >> 2) != 0) {  // generic shapes: two passes
         if (int e = gs_act_bwd(g, y, gx, p * c, act, dtype, stream)) return e;
-        return gs_channel_sum(gx, gb, p, c, dtype, ws, ws_bytes, stream);
+        return gs_channel_sum(gx, gb, p, c, accumulate, dtype, ws, ws_bytes, stream);
     }
     const int nparts = channel_sum_parts(p, c);
     if (ws_bytes < gs_channel_sum_workspace_bytes(p, c)) return fail(GS_ERR_WORKSPACE, "act_bwd_bias: workspace too small");
@@ -533,7 +534,7 @@ extern "C" int gs_act_bwd_bias(const void* g, const void* y, void* gx, float* gb
         else hipLaunchKernelGGL((act_bwd_sum_kernel<T, 2>), dim3(nparts), dim3(256), 0, st, (const T*)g, (const T*)y, (T*)gx, part, (long)p, c);
     });
     GS_CHECK_LAUNCH();
-    return channel_sum_finalize(part, gb, nparts, c, st);
+    return channel_sum_finalize(part, gb, nparts, c, accumulate, st);
 }
 
 static int pixel_norm_launch(int mode, const void* a0, const void* a1, const void* a2, void* out, int64_t p, int c, float eps, int dtype, void* stream) {

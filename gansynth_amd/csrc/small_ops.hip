@@ -80,14 +80,14 @@ __global__ __launch_bounds__(256) void dense_bwd_data_kernel(const T* __restrict
 // ---------------------------------------------------------------------- dense bwd weight
 // gw[i][o] = alpha * sum_b x[b][i] * gy[b][o]
 template <typename T>
-__global__ void dense_bwd_weight_kernel(const T* __restrict__ x, const T* __restrict__ gy, float* __restrict__ gw, int b, int in, int out, float alpha) {
+__global__ void dense_bwd_weight_kernel(const T* __restrict__ x, const T* __restrict__ gy, float* __restrict__ gw, int b, int in, int out, float alpha, int accumulate) {
     const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (long)in * out) return;
     const int o = e % out;
     const int i = e / out;
     float s = 0.f;
     for (int k = 0; k < b; ++k) s += DT<T>::ld(x + (long)k * in + i) * DT<T>::ld(gy + (long)k * out + o);
-    gw[e] = s * alpha;
+    gw[e] = accumulate ? gw[e] + s * alpha : s * alpha;
 }
 
 // wide rows (out >= 2048, e.g. the generator's 512 -> 8192 dense): one block per weight row
@@ -281,10 +281,10 @@ extern "C" int gs_dense_bwd_data(const void* gy, const float* w, void* gx, int b
     return 0;
 }
 
-extern "C" int gs_dense_bwd_weight(const void* x, const void* gy, float* gw, int b, int in, int out, float alpha, int dtype, void* stream) {
+extern "C" int gs_dense_bwd_weight(const void* x, const void* gy, float* gw, int b, int in, int out, float alpha, int accumulate, int dtype, void* stream) {
     GS_CHECK_ARG(b > 0 && in > 0 && out > 0, "dense_bwd_weight: bad args");
     const long n = (long)in * out;
-    GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dense_bwd_weight_kernel<T>), dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), (const T*)x, (const T*)gy, gw, b, in, out, alpha));
+    GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dense_bwd_weight_kernel<T>), dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), (const T*)x, (const T*)gy, gw, b, in, out, alpha, accumulate));
     GS_CHECK_LAUNCH();
     return 0;
 }

@@ -40,8 +40,8 @@ class _ConvKind(object):
     def bwd_data(self, gy, w, x_shape, alpha):
         return _K().conv2d_bwd_data(gy, w, x_shape, self.ksize, self.stride, alpha)
 
-    def bwd_weight(self, x, gy, alpha):
-        return _K().conv2d_bwd_weight(x, gy, self.ksize, self.stride, alpha)
+    def bwd_weight(self, x, gy, alpha, out=None):
+        return _K().conv2d_bwd_weight(x, gy, self.ksize, self.stride, alpha, out=out)
 
 
 class _ConvTransposeKind(object):
@@ -56,8 +56,8 @@ class _ConvTransposeKind(object):
     def bwd_data(self, gy, w, x_shape, alpha):
         return _K().conv2d_transpose_bwd_data(gy, w, alpha)
 
-    def bwd_weight(self, x, gy, alpha):
-        return _K().conv2d_transpose_bwd_weight(x, gy, alpha)
+    def bwd_weight(self, x, gy, alpha, out=None):
+        return _K().conv2d_transpose_bwd_weight(x, gy, alpha, out=out)
 
 
 class _DenseKind(object):
@@ -69,8 +69,22 @@ class _DenseKind(object):
     def bwd_data(self, gy, w, x_shape, alpha):
         return _K().dense_bwd_data(gy, w, alpha)
 
-    def bwd_weight(self, x, gy, alpha):
-        return _K().dense_bwd_weight(x, gy, alpha)
+    def bwd_weight(self, x, gy, alpha, out=None):
+        return _K().dense_bwd_weight(x, gy, alpha, out=out)
+
+
+def _accum_target(param):
+    """Where a parameter gradient may be ADDED in place by the producing kernel instead of being returned to autograd
+    (which would allocate it and add it into .grad with one more pass): plain backward only (under create_graph the
+    gradient must stay a differentiable tensor), leaf parameter with a pre-allocated contiguous fp32 .grad."""
+    if param is None or torch.is_grad_enabled():
+        return None
+    if not (param.is_leaf and param.requires_grad):
+        return None
+    g = param.grad
+    if g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.shape != param.shape:
+        return None
+    return g
 
 
 _KINDS = {}
@@ -92,7 +106,7 @@ class _Bilinear(Function):
 
     @staticmethod
     def forward(ctx, x, w, kind, alpha):
-        ctx.kind, ctx.alpha = kind, alpha
+        ctx.kind, ctx.alpha, ctx.wref = kind, alpha, w
         ctx.save_for_backward(x, w)
         return kind.fwd(x, w, alpha)
 
@@ -100,7 +114,13 @@ class _Bilinear(Function):
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
         gx = _BilinearBwdData.apply(gy, w, x.shape, ctx.kind, ctx.alpha) if ctx.needs_input_grad[0] else None
-        gw = _BilinearBwdWeight.apply(x, gy, ctx.kind, ctx.alpha).to(w.dtype) if ctx.needs_input_grad[1] else None
+        gw = None
+        if ctx.needs_input_grad[1]:
+            tgt = _accum_target(ctx.wref)
+            if tgt is not None:
+                ctx.kind.bwd_weight(x, gy, ctx.alpha, out=tgt)
+            else:
+                gw = _BilinearBwdWeight.apply(x, gy, ctx.kind, ctx.alpha).to(w.dtype)
         return gx, gw, None, None
 
 
@@ -109,7 +129,7 @@ class _BilinearBwdData(Function):
 
     @staticmethod
     def forward(ctx, gy, w, x_shape, kind, alpha):
-        ctx.kind, ctx.alpha = kind, alpha
+        ctx.kind, ctx.alpha, ctx.wref = kind, alpha, w
         ctx.save_for_backward(gy, w)
         return kind.bwd_data(gy, w, x_shape, alpha)
 
@@ -117,7 +137,13 @@ class _BilinearBwdData(Function):
     def backward(ctx, ggx):
         gy, w = ctx.saved_tensors
         g_gy = _Bilinear.apply(ggx, w, ctx.kind, ctx.alpha) if ctx.needs_input_grad[0] else None
-        g_w = _BilinearBwdWeight.apply(ggx, gy, ctx.kind, ctx.alpha).to(w.dtype) if ctx.needs_input_grad[1] else None
+        g_w = None
+        if ctx.needs_input_grad[1]:
+            tgt = _accum_target(ctx.wref)
+            if tgt is not None:   # second-order term of the penalty, added straight into w.grad
+                ctx.kind.bwd_weight(ggx, gy, ctx.alpha, out=tgt)
+            else:
+                g_w = _BilinearBwdWeight.apply(ggx, gy, ctx.kind, ctx.alpha).to(w.dtype)
         return g_gy, g_w, None, None, None
 
 
@@ -138,12 +164,30 @@ class _BilinearBwdWeight(Function):
         return g_x, g_gy, None, None
 
 
+def _bias_act_backward(gz, z, act, bias_param, want_b):
+    """Backward of z = act(y + bias): (gy, gb).  Plain backward: one fused pass, the bias gradient added straight into
+    bias.grad when possible (gb = None then).  Under create_graph: differentiable Functions."""
+    plain = not torch.is_grad_enabled()
+    tgt = _accum_target(bias_param) if want_b else None
+    if act != ACT_NONE:
+        if want_b and plain:
+            gy, gb = _K().act_bwd_bias(gz, z, act, out=tgt)
+            return gy, (None if tgt is not None else gb)
+        gy = _ActBwd.apply(gz, z, act)
+        return gy, (_ChannelSum.apply(gy) if want_b else None)
+    if want_b and tgt is not None:
+        _K().channel_sum(gz, out=tgt)
+        return gz, None
+    return gz, (_ChannelSum.apply(gz) if want_b else None)
+
+
 class _ConvBiasAct(Function):
     """z = act(alpha * B(x, w) + bias) with the bias / activation fused into the GEMM epilogue."""
 
     @staticmethod
     def forward(ctx, x, w, bias, kind, alpha, act):
         ctx.kind, ctx.alpha, ctx.act, ctx.has_bias = kind, alpha, act, bias is not None
+        ctx.wref, ctx.bref = w, bias
         z = kind.fwd_bias_act(x, w, bias, alpha, act)
         ctx.save_for_backward(x, w, z)
         return z
@@ -152,18 +196,15 @@ class _ConvBiasAct(Function):
     def backward(ctx, gz):
         x, w, z = ctx.saved_tensors
         want_b = ctx.has_bias and ctx.needs_input_grad[2]
-        gb = None
-        if ctx.act != ACT_NONE:
-            if want_b and not torch.is_grad_enabled():   # plain backward: one fused pass
-                gy, gb = _K().act_bwd_bias(gz, z, ctx.act)
-            else:                                        # under create_graph: differentiable pieces
-                gy = _ActBwd.apply(gz, z, ctx.act)
-                gb = _ChannelSum.apply(gy) if want_b else None
-        else:
-            gy = gz
-            gb = _ChannelSum.apply(gy) if want_b else None
+        gy, gb = _bias_act_backward(gz, z if ctx.act != ACT_NONE else None, ctx.act, ctx.bref if want_b else None, want_b)
         gx = _BilinearBwdData.apply(gy, w, x.shape, ctx.kind, ctx.alpha) if ctx.needs_input_grad[0] else None
-        gw = _BilinearBwdWeight.apply(x, gy, ctx.kind, ctx.alpha).to(w.dtype) if ctx.needs_input_grad[1] else None
+        gw = None
+        if ctx.needs_input_grad[1]:
+            tgt = _accum_target(ctx.wref)
+            if tgt is not None:
+                ctx.kind.bwd_weight(x, gy, ctx.alpha, out=tgt)
+            else:
+                gw = _BilinearBwdWeight.apply(x, gy, ctx.kind, ctx.alpha).to(w.dtype)
         return gx, gw, gb, None, None, None
 
 
@@ -239,6 +280,7 @@ class _BiasAct(Function):
         z = _K().bias_act_fwd(x, bias, act)
         ctx.act = act
         ctx.has_bias = bias is not None
+        ctx.bref = bias
         if act != ACT_NONE:
             ctx.save_for_backward(z)
         return z
@@ -246,17 +288,8 @@ class _BiasAct(Function):
     @staticmethod
     def backward(ctx, gz):
         want_b = ctx.has_bias and ctx.needs_input_grad[1]
-        gb = None
-        if ctx.act != ACT_NONE:
-            (z,) = ctx.saved_tensors
-            if want_b and not torch.is_grad_enabled():
-                gx, gb = _K().act_bwd_bias(gz, z, ctx.act)
-            else:
-                gx = _ActBwd.apply(gz, z, ctx.act)
-                gb = _ChannelSum.apply(gx) if want_b else None
-        else:
-            gx = gz
-            gb = _ChannelSum.apply(gx) if want_b else None
+        z = ctx.saved_tensors[0] if ctx.act != ACT_NONE else None
+        gx, gb = _bias_act_backward(gz, z, ctx.act, ctx.bref if want_b else None, want_b)
         return (gx if ctx.needs_input_grad[0] else None), gb, None
 
 

@@ -131,15 +131,17 @@ class HipKernels(object):
                                                float(alpha), _dt(gy), prepared, ws.data_ptr(), ws.numel(), _stream()), "gs_conv2d_bwd_data")
         return gx
 
-    def conv2d_bwd_weight(self, x, gy, ksize, stride, alpha):
+    def conv2d_bwd_weight(self, x, gy, ksize, stride, alpha, out=None):
+        """gw (new tensor), or with `out` (fp32, contiguous) the gradient is ADDED into it inside the kernel."""
         x, gy = _act(x), _act(gy)
         n, ci, h, wd = x.shape
         co = gy.shape[1]
-        gw = torch.empty((ksize, ksize, ci, co), dtype=torch.float32, device=x.device)
+        gw = torch.empty((ksize, ksize, ci, co), dtype=torch.float32, device=x.device) if out is None else out
         nb = self.lib.gs_conv2d_workspace_bytes(_lib.CONV_BWD_WEIGHT, n, h, wd, ci, co, ksize, stride, _dt(x))
         ws = _ws(nb, x.device)
         _lib.check(self.lib.gs_conv2d_bwd_weight(x.data_ptr(), gy.data_ptr(), gw.data_ptr(), n, h, wd, ci, co, ksize, stride,
-                                                 float(alpha), _dt(x), ws.data_ptr(), ws.numel(), _stream()), "gs_conv2d_bwd_weight")
+                                                 float(alpha), 0 if out is None else 1, _dt(x), ws.data_ptr(), ws.numel(), _stream()),
+                   "gs_conv2d_bwd_weight")
         return gw
 
     def conv2d_transpose_fwd(self, x, w, alpha):
@@ -173,15 +175,16 @@ class HipKernels(object):
                                                             _dt(gy), prepared, ws.data_ptr(), ws.numel(), _stream()), "gs_conv2d_transpose_s2_bwd_data")
         return gx
 
-    def conv2d_transpose_bwd_weight(self, x, gy, alpha):
+    def conv2d_transpose_bwd_weight(self, x, gy, alpha, out=None):
         x, gy = _act(x), _act(gy)
         n, ci, h, wd = x.shape
         co = gy.shape[1]
-        gw = torch.empty((3, 3, ci, co), dtype=torch.float32, device=x.device)
+        gw = torch.empty((3, 3, ci, co), dtype=torch.float32, device=x.device) if out is None else out
         nb = self.lib.gs_conv2d_transpose_s2_workspace_bytes(_lib.CONV_BWD_WEIGHT, n, h, wd, ci, co, _dt(x))
         ws = _ws(nb, x.device)
         _lib.check(self.lib.gs_conv2d_transpose_s2_bwd_weight(x.data_ptr(), gy.data_ptr(), gw.data_ptr(), n, h, wd, ci, co, float(alpha),
-                                                              _dt(x), ws.data_ptr(), ws.numel(), _stream()), "gs_conv2d_transpose_s2_bwd_weight")
+                                                              0 if out is None else 1, _dt(x), ws.data_ptr(), ws.numel(), _stream()),
+                   "gs_conv2d_transpose_s2_bwd_weight")
         return gw
 
     # ------------------------------------------------------------------------------ dense
@@ -204,13 +207,13 @@ class HipKernels(object):
                    "gs_dense_bwd_data")
         return gx
 
-    def dense_bwd_weight(self, x, gy, alpha):
+    def dense_bwd_weight(self, x, gy, alpha, out=None):
         x, gy = _act(x), _act(gy)
         b, i = x.shape
         o = gy.shape[1]
-        gw = torch.empty((i, o), dtype=torch.float32, device=x.device)
-        _lib.check(self.lib.gs_dense_bwd_weight(x.data_ptr(), gy.data_ptr(), gw.data_ptr(), b, i, o, float(alpha), _dt(x), _stream()),
-                   "gs_dense_bwd_weight")
+        gw = torch.empty((i, o), dtype=torch.float32, device=x.device) if out is None else out
+        _lib.check(self.lib.gs_dense_bwd_weight(x.data_ptr(), gy.data_ptr(), gw.data_ptr(), b, i, o, float(alpha),
+                                                0 if out is None else 1, _dt(x), _stream()), "gs_dense_bwd_weight")
         return gw
 
     def embedding_fwd(self, idx, w, alpha, dtype):
@@ -251,16 +254,16 @@ class HipKernels(object):
         _lib.check(self.lib.gs_act_bwd(g.data_ptr(), y.data_ptr(), gx.data_ptr(), y.numel(), act, _dt(y), _stream()), "gs_act_bwd")
         return gx
 
-    def act_bwd_bias(self, g, y, act):
-        """(gx, gb): activation backward and the bias gradient in one pass."""
+    def act_bwd_bias(self, g, y, act, out=None):
+        """(gx, gb): activation backward and the bias gradient in one pass (gb added into `out` when given)."""
         y = _act(y)
         g = _match(g, y)
         p, c = _rows_cols(y)
         gx = torch.empty_like(y)
-        gb = torch.empty((c,), dtype=torch.float32, device=y.device)
+        gb = torch.empty((c,), dtype=torch.float32, device=y.device) if out is None else out
         ws = _ws(self.lib.gs_channel_sum_workspace_bytes(p, c), y.device)
-        _lib.check(self.lib.gs_act_bwd_bias(g.data_ptr(), y.data_ptr(), gx.data_ptr(), gb.data_ptr(), p, c, act, _dt(y),
-                                            ws.data_ptr(), ws.numel(), _stream()), "gs_act_bwd_bias")
+        _lib.check(self.lib.gs_act_bwd_bias(g.data_ptr(), y.data_ptr(), gx.data_ptr(), gb.data_ptr(), p, c, act, 0 if out is None else 1,
+                                            _dt(y), ws.data_ptr(), ws.numel(), _stream()), "gs_act_bwd_bias")
         return gx, gb
 
     def tanh_bwd_bwd(self, gg, g, y):
@@ -271,13 +274,14 @@ class HipKernels(object):
                    "gs_tanh_bwd_bwd")
         return out
 
-    def channel_sum(self, g):
+    def channel_sum(self, g, out=None):
         g = _act(g)
         p, c = _rows_cols(g)
-        out = torch.empty((c,), dtype=torch.float32, device=g.device)
+        res = torch.empty((c,), dtype=torch.float32, device=g.device) if out is None else out
         ws = _ws(self.lib.gs_channel_sum_workspace_bytes(p, c), g.device)
-        _lib.check(self.lib.gs_channel_sum(g.data_ptr(), out.data_ptr(), p, c, _dt(g), ws.data_ptr(), ws.numel(), _stream()), "gs_channel_sum")
-        return out
+        _lib.check(self.lib.gs_channel_sum(g.data_ptr(), res.data_ptr(), p, c, 0 if out is None else 1, _dt(g), ws.data_ptr(), ws.numel(),
+                                           _stream()), "gs_channel_sum")
+        return res
 
     def pixel_norm_fwd(self, x, eps):
         x = _act(x)

@@ -61,7 +61,10 @@ int gs_prof_collect(int* launches, double* total_ms, double* total_flops);
  * (n,h,w) are always the dims of x (the conv INPUT side), for all three.
  * fwd / bwd_data first re-lay the weight into the kernel operand at the start of `ws`; `w_prepared` != 0 says that
  * `ws` still holds that operand from an earlier call with the same weight values (same map, dtype), so the
- * re-layout is skipped -- the caller keeps one persistent ws per (weight, map) between optimizer steps. */
+ * re-layout is skipped -- the caller keeps one persistent ws per (weight, map) between optimizer steps.
+ * Every gradient-of-a-parameter entry point (bwd_weight, dense_bwd_weight, channel_sum, act_bwd_bias) takes
+ * `accumulate`: 0 overwrites the output, 1 adds into it (tf.gradients sums the contributions of a variable used
+ * several times; accumulating in the producing kernel replaces one read-modify-write pass per contribution). */
 size_t gs_conv2d_workspace_bytes(int which, int n, int h, int w, int ci, int co, int ksize, int stride, int dtype);
 int gs_conv2d_fwd(const void* x, const float* w_hwio, void* y, int n, int h, int w, int ci, int co,
                   int ksize, int stride, float alpha, int dtype, int w_prepared, void* ws, size_t ws_bytes, void* stream);
@@ -73,7 +76,7 @@ int gs_conv2d_fwd_bias_act(const void* x, const float* w_hwio, const float* bias
 int gs_conv2d_bwd_data(const void* gy, const float* w_hwio, void* gx, int n, int h, int w, int ci, int co,
                        int ksize, int stride, float alpha, int dtype, int w_prepared, void* ws, size_t ws_bytes, void* stream);
 int gs_conv2d_bwd_weight(const void* x, const void* gy, float* gw_hwio, int n, int h, int w, int ci, int co,
-                         int ksize, int stride, float alpha, int dtype, void* ws, size_t ws_bytes, void* stream);
+                         int ksize, int stride, float alpha, int accumulate, int dtype, void* ws, size_t ws_bytes, void* stream);
 
 /* tf.nn.conv2d_transpose NCHW, 3x3, stride 2, SAME, output = 2h x 2w (ops.py:266-276): the
  * gradient-of-conv definition out[2i+k] += x[i] * w[k][ci][co], cropped at the end.
@@ -92,7 +95,7 @@ int gs_conv2d_transpose_s2_fwd_bias_act(const void* x, const float* w_hwio, cons
 int gs_conv2d_transpose_s2_bwd_data(const void* gy, const float* w_hwio, void* gx, int n, int h, int w, int ci, int co,
                                     float alpha, int dtype, int w_prepared, void* ws, size_t ws_bytes, void* stream);
 int gs_conv2d_transpose_s2_bwd_weight(const void* x, const void* gy, float* gw_hwio, int n, int h, int w, int ci, int co,
-                                      float alpha, int dtype, void* ws, size_t ws_bytes, void* stream);
+                                      float alpha, int accumulate, int dtype, void* ws, size_t ws_bytes, void* stream);
 
 /* -------------------------------------------------------------------------------- dense
  * tf.matmul (ops.py:197): y[b][out] = alpha * x[b][in] @ w[in][out] (split-K partials live in ws).
@@ -101,7 +104,8 @@ size_t gs_dense_fwd_workspace_bytes(int b, int in, int out);
 int gs_dense_fwd(const void* x, const float* w, void* y, int b, int in, int out, float alpha, int dtype,
                  void* ws, size_t ws_bytes, void* stream);
 int gs_dense_bwd_data(const void* gy, const float* w, void* gx, int b, int in, int out, float alpha, int dtype, void* stream);
-int gs_dense_bwd_weight(const void* x, const void* gy, float* gw, int b, int in, int out, float alpha, int dtype, void* stream);
+int gs_dense_bwd_weight(const void* x, const void* gy, float* gw, int b, int in, int out, float alpha, int accumulate, int dtype,
+                        void* stream);
 
 /* tf.nn.embedding_lookup(w*alpha, argmax(labels,1)) (ops.py:217): idx[b] are the argmax indices.
  * fwd: y[b][units] = alpha * w[idx[b]][:]  ; bwd: gw[rows][units] = alpha * scatter_add(gy) (gw zero-filled here). */
@@ -117,11 +121,11 @@ int gs_embedding_bwd(const int64_t* idx, const void* gy, float* gw, int b, int r
 int gs_bias_act_fwd(const void* x, const float* bias, void* y, int64_t p, int c, int act, int dtype, void* stream);
 int gs_act_bwd(const void* g, const void* y, void* gx, int64_t numel, int act, int dtype, void* stream);
 /* act_bwd and the bias gradient in one pass: gx = g*act'(y), gb[c] = sum_p gx[p][c] (ws: gs_channel_sum_workspace_bytes) */
-int gs_act_bwd_bias(const void* g, const void* y, void* gx, float* gb, int64_t p, int c, int act, int dtype, void* ws,
-                    size_t ws_bytes, void* stream);
+int gs_act_bwd_bias(const void* g, const void* y, void* gx, float* gb, int64_t p, int c, int act, int accumulate, int dtype,
+                    void* ws, size_t ws_bytes, void* stream);
 int gs_tanh_bwd_bwd(const void* gg, const void* g, const void* y, void* out, int64_t numel, int dtype, void* stream);
 size_t gs_channel_sum_workspace_bytes(int64_t p, int c);
-int gs_channel_sum(const void* g, float* out, int64_t p, int c, int dtype, void* ws, size_t ws_bytes, void* stream);
+int gs_channel_sum(const void* g, float* out, int64_t p, int c, int accumulate, int dtype, void* ws, size_t ws_bytes, void* stream);
 
 /* pixel_normalization (ops.py:330-333): y = x / sqrt(mean_c(x^2) + eps), per row p over c.
  *   bwd      : gx = r*(g - y*mean_c(y*g)),  r = rsqrt(mean_c(x^2)+eps)

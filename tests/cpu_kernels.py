@@ -36,18 +36,26 @@ class CpuEmuKernels(object):
     def conv2d_transpose_fwd_bias_act(self, x, w, bias, alpha, act):
         return self.bias_act_fwd(self.conv2d_transpose_fwd(x, w, alpha), bias, act)
 
-    def act_bwd_bias(self, g, y, act):
+    def act_bwd_bias(self, g, y, act, out=None):
         gx = self.act_bwd(g, y, act)
-        return gx, self.channel_sum(gx)
+        return gx, self.channel_sum(gx, out=out)
 
     def conv2d_bwd_data(self, gy, w, x_shape, ksize, stride, alpha):
         return _lin_grad(lambda z: self_conv(z, w, stride, alpha), tuple(x_shape), gy, gy.detach()).detach()
 
-    def conv2d_bwd_weight(self, x, gy, ksize, stride, alpha):
+    @staticmethod
+    def _out(val, out):
+        if out is None:
+            return val
+        with torch.no_grad():
+            out.add_(val.to(out.dtype))
+        return out
+
+    def conv2d_bwd_weight(self, x, gy, ksize, stride, alpha, out=None):
         ci, co = x.shape[1], gy.shape[1]
         shape = (ksize, ksize, ci, co)
         g = _lin_grad(lambda z: self_conv(x.detach(), z, stride, alpha), shape, gy, gy.detach())
-        return g.float().detach()
+        return self._out(g.float().detach(), out)
 
     def conv2d_transpose_fwd(self, x, w, alpha):
         return self_convT(x.detach(), w.detach().to(x.dtype), alpha).detach()
@@ -57,9 +65,9 @@ class CpuEmuKernels(object):
         ci = w.shape[2]
         return _lin_grad(lambda z: self_convT(z, w.detach().to(gy.dtype), alpha), (n, ci, h2 // 2, w2 // 2), gy, gy.detach()).detach()
 
-    def conv2d_transpose_bwd_weight(self, x, gy, alpha):
+    def conv2d_transpose_bwd_weight(self, x, gy, alpha, out=None):
         shape = (3, 3, x.shape[1], gy.shape[1])
-        return _lin_grad(lambda z: self_convT(x.detach(), z, alpha), shape, gy, gy.detach()).float().detach()
+        return self._out(_lin_grad(lambda z: self_convT(x.detach(), z, alpha), shape, gy, gy.detach()).float().detach(), out)
 
     def dense_fwd(self, x, w, alpha):
         return (x.detach() @ w.detach().to(x.dtype)) * alpha
@@ -67,8 +75,8 @@ class CpuEmuKernels(object):
     def dense_bwd_data(self, gy, w, alpha):
         return (gy.detach() @ w.detach().to(gy.dtype).t()) * alpha
 
-    def dense_bwd_weight(self, x, gy, alpha):
-        return ((x.detach().t() @ gy.detach()) * alpha).float()
+    def dense_bwd_weight(self, x, gy, alpha, out=None):
+        return self._out(((x.detach().t() @ gy.detach()) * alpha).float(), out)
 
     def embedding_fwd(self, idx, w, alpha, dtype):
         return (w.detach()[idx] * alpha).to(dtype)
@@ -98,9 +106,9 @@ class CpuEmuKernels(object):
     def tanh_bwd_bwd(self, gg, g, y):
         return -2.0 * y.detach() * g.detach() * gg.detach()
 
-    def channel_sum(self, g):
+    def channel_sum(self, g, out=None):
         g = g.detach().float()
-        return g.sum(dim=(0, 2, 3)) if g.dim() == 4 else g.sum(dim=0)
+        return self._out(g.sum(dim=(0, 2, 3)) if g.dim() == 4 else g.sum(dim=0), out)
 
     def pixel_norm_fwd(self, x, eps):
         return R.pixel_normalization(x.detach(), eps)

@@ -291,3 +291,36 @@ def test_prepared_weight_operand_cache(K, E):
     with torch.no_grad():
         w.mul_(0.5)
     close(K.conv2d_fwd(dev(x), w, 3, 1, 0.1), E.conv2d_fwd(x, w.cpu(), 3, 1, 0.1), name="after an in-place torch update")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_parameter_gradients_accumulate_in_kernel(K, E, dtype):
+    """`out=`: the gradient is added into an existing fp32 buffer by the reducing kernel itself (accumulate=1 in the
+    C ABI) -- what functional.py uses to write straight into the flat gradient buffer."""
+    tol = 1e-4
+    for (n, ci, co, h, w, ks, st) in [(2, 32, 32, 8, 128, 3, 1), (2, 32, 64, 8, 128, 3, 2), (2, 32, 2, 8, 64, 1, 1), (4, 1, 16, 2, 16, 3, 1)]:
+        x = rnd(n, ci, h, w, seed=1).to(dtype).float()
+        gy = rnd(n, co, h // st, w // st, seed=2).to(dtype).float()
+        base = rnd(ks, ks, ci, co, seed=3)
+        acc = dev(base).contiguous()
+        got = K.conv2d_bwd_weight(dev(x, dtype), dev(gy, dtype), ks, st, 0.2, out=acc)
+        assert got.data_ptr() == acc.data_ptr()
+        close(acc, base + E.conv2d_bwd_weight(x, gy, ks, st, 0.2), rel=tol, name=f"conv wgrad += {ci}->{co} k{ks} s{st}")
+    x, gy, base = rnd(2, 64, 8, 64, seed=4).to(dtype).float(), rnd(2, 32, 16, 128, seed=5).to(dtype).float(), rnd(3, 3, 64, 32, seed=6)
+    acc = dev(base).contiguous()
+    K.conv2d_transpose_bwd_weight(dev(x, dtype), dev(gy, dtype), 0.1, out=acc)
+    close(acc, base + E.conv2d_transpose_bwd_weight(x, gy, 0.1), rel=tol, name="convT wgrad +=")
+    x, gy, base = rnd(8, 512, seed=7).to(dtype).float(), rnd(8, 256, seed=8).to(dtype).float(), rnd(512, 256, seed=9)
+    acc = dev(base)
+    K.dense_bwd_weight(dev(x, dtype), dev(gy, dtype), 0.3, out=acc)
+    close(acc, base + E.dense_bwd_weight(x, gy, 0.3), rel=tol, name="dense wgrad +=")
+    for shape in [(2, 32, 64, 256), (8, 8192), (3, 64, 5, 7)]:
+        g = rnd(*shape, seed=2).to(dtype).float()
+        y = E.bias_act_fwd(rnd(*shape, seed=1), None, 1).to(dtype).float()
+        base = rnd(shape[1], seed=3)
+        acc = dev(base)
+        K.channel_sum(dev(g, dtype), out=acc)
+        close(acc, base + E.channel_sum(g), rel=tol, name="channel_sum +=")
+        acc = dev(base)
+        K.act_bwd_bias(dev(g, dtype), dev(y, dtype), 1, out=acc)
+        close(acc, base + E.act_bwd_bias(g, y, 1)[1], rel=1e-4 if dtype == torch.float32 else 2e-2, name="act_bwd_bias +=")
