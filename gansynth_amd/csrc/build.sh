@@ -9,7 +9,10 @@ pids=()
 for f in conv_igemm conv_api elementwise small_ops spectral; do
   [ -f $f.hip ] || continue
   if [ ! -f obj/$f.o ] || [ $f.hip -nt obj/$f.o ] || [ gs_common.h -nt obj/$f.o ] || [ conv_shared.h -nt obj/$f.o ] || [ ../../include/gansynth_hip.h -nt obj/$f.o ]; then
-    ( hipcc $FLAGS -c $f.hip -o obj/$f.o ) &
+    EXTRA=""
+    # MFMA accumulators in VGPRs (hipcc otherwise parks them in AGPRs and every epilogue value costs a v_accvgpr_read)
+    [ $f = conv_igemm ] && EXTRA="-mllvm -amdgpu-mfma-vgpr-form"
+    ( hipcc $FLAGS $EXTRA -c $f.hip -o obj/$f.o ) &
     pids+=($!)
   fi
 done

@@ -90,17 +90,26 @@ template <int MODE> __host__ __device__ constexpr int tap_off(int k) {  // patch
 }
 
 // ------------------------------------------------------------------------- implicit GEMM
-// Persistent, software-pipelined kernel.  Block = 256 threads = 4 waves; every wave owns all
-// 32*A output channels of the block and 32*B of its 128*B base pixels.  A block walks a list of
-// work items (spatial tile x output-channel tile; the list of an XCD is contiguous so that
-// neighbouring tiles share halo rows in that XCD's L2).  The K loop runs over input-channel chunks of
-// 64 bytes (16 f32 / 32 bf16) x tap groups; while the MFMAs of one stage run, the global loads of the
-// next stage (next tap group / next chunk / next ITEM) are already in flight into registers, and are
-// written to the other half of a double-buffered LDS ring after the MFMAs -- one barrier per stage.
-// LDS rows are 64 bytes, the four 16-byte slots of a row are XOR-swizzled with bits 2..3 of the row
-// index, which makes the 16-lane ds_read_b128 groups conflict-free without padding.
-// TG == 9 is the "resident weights" mode for the thin top-of-pyramid layers (32 output channels):
-// all taps of all chunks stay in LDS for the life of the block and only the input patch streams.
+// Persistent kernel fed by LDS-DMA.  Block = 256 threads = 4 waves; every wave owns all 32*A output
+// channels of the block and 32*B of its 128*B base pixels.  A block walks a list of work items (spatial
+// tile x output-channel tile; the list of an XCD is contiguous so that neighbouring tiles share halo rows
+// in that XCD's L2).  The K loop runs over stages = input-channel chunks of 64 bytes (16 f32 / 32 bf16)
+// x tap groups.
+//
+// Staging: nothing passes through registers.  Every operand row is 64 bytes = four 16-byte slots, and a
+// `buffer_load_dwordx4 ... lds` wave-instruction deposits 64 slots (1 KiB, 16 rows) at M0 + 16*lane while
+// each lane supplies its own source offset -- so the XOR slot swizzle that makes the 16-lane ds_read_b128
+// groups conflict-free is applied on the SOURCE side (lane at slot position p fetches part p ^ key(row)).
+// Out-of-image patch rows are free: the descriptor covers exactly one image, rows above / below it fall
+// outside [0, num_records) and the hardware writes zeros (measured, scripts/probe/dma_probe.hip); columns
+// left / right of the image are forced out of range per lane.
+// The stages of the next D iterations are always in flight (ring of D+1 weight buffers, 1+ceil(D/NTG) patch
+// buffers); a wave waits with a COUNTED s_waitcnt vmcnt(n) -- n = its DMA pieces of the stages that may
+// still be in flight -- and one raw s_barrier per stage publishes the landed stage to the other waves.
+// hipcc knows nothing about these loads (inline asm), so it adds no vmcnt(0) of its own; the main loop has
+// no ordinary global loads (the bias lives in LDS), only the epilogue stores.
+// TG == 9 with RESIDENT keeps all taps of all chunks in LDS for the life of the block (thin layers: 32 or
+// 64 output channels) and only the input patches stream.
 struct ConvP {
     const void* x;
     const void* wp;
@@ -109,36 +118,95 @@ struct ConvP {
     int act;
     int N, Hi, Wi, IC, OC, Hb, Wb, tiles_x, tiles_y, nsp, noct, nch;
     float alpha;
+#ifdef GS_IGEMM_TRACE
+    unsigned long long* trace;  // [block][64] shader-clock stamps of wave 0 (scripts/probe/igemm_trace.hip)
+#endif
 };
+#ifdef GS_IGEMM_TRACE
+#define GS_TR(slot)                                                                                              \
+    do {                                                                                                         \
+        if (p.trace && threadIdx.x == 0 && (slot) < 64) p.trace[blockIdx.x * 64 + (slot)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define GS_TR(slot) do { } while (0)
+#endif
 
-template <typename T, int MODE, int A, int B, int TW, int TG, bool RESIDENT>
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// one LDS-DMA piece: 64 lanes x 16 bytes -> LDS[lds_addr + 16*lane].  M0 is written and consumed inside the statement and
+// not restored: nothing else in these kernels uses M0 (gfx9 LDS instructions do not), which the build checks in the ISA.
+__device__ __forceinline__ void lds_dma16(unsigned lds_addr, unsigned voff, i32x4 rs) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                 :
+                 : "s"(lds_addr), "v"(voff), "s"(rs)
+                 : "memory");
+}
+// raw buffer descriptor over [base, base + bytes): stride 0, 32-bit data format (gfx950)
+__device__ __forceinline__ i32x4 make_rsrc(const void* base, unsigned bytes) {
+    const unsigned long long b = reinterpret_cast<unsigned long long>(base);
+    i32x4 rs;
+    rs[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)b);
+    rs[1] = __builtin_amdgcn_readfirstlane((int)((b >> 32) & 0xffffu));
+    rs[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+    rs[3] = 0x00020000;
+    return rs;
+}
+// s_waitcnt vmcnt(n) with n known only after unrolling (the asm immediate must be a literal)
+__device__ __forceinline__ void wait_vmcnt(int n) {
+#define GS_VM(K) case K: asm volatile("s_waitcnt vmcnt(" #K ")" ::: "memory"); break;
+    switch (n) {
+        GS_VM(0) GS_VM(1) GS_VM(2) GS_VM(3) GS_VM(4) GS_VM(5) GS_VM(6) GS_VM(7) GS_VM(8) GS_VM(9) GS_VM(10) GS_VM(11)
+        GS_VM(12) GS_VM(13) GS_VM(14) GS_VM(15) GS_VM(16) GS_VM(17) GS_VM(18) GS_VM(19) GS_VM(20) GS_VM(21) GS_VM(22)
+        GS_VM(23) GS_VM(24) GS_VM(25) GS_VM(26) GS_VM(27) GS_VM(28) GS_VM(29) GS_VM(30) GS_VM(31) GS_VM(32)
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+#undef GS_VM
+}
+__device__ __forceinline__ void block_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+template <typename T, int MODE, int A, int B, int TW, int TG, bool RESIDENT, int D>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
     constexpr int NP = 128 * B;
     constexpr int TH = NP / TW;
     constexpr int PH = patch_dim<MODE>(TH), PW = patch_dim<MODE>(TW);
     constexpr int S = MODE == MODE_S2 ? 2 : 1;
     constexpr int NPH = MODE == MODE_T2 ? 4 : 1;
-    constexpr int BK = 64 / (int)sizeof(T);
+    constexpr int SZ = (int)sizeof(T);
+    constexpr int BK = 64 / SZ;
     constexpr int OCT = 32 * A;
     constexpr int NTG = 9 / TG;
-    constexpr int PCH = PH * PW * 4;    // 16-byte slots of a patch chunk
-    constexpr int WCH = TG * OCT * 4;   // 16-byte slots of one weight stage
-    constexpr int PREG = (PCH + 255) / 256, WREG = (WCH + 255) / 256;
-    constexpr int PBYTES = PH * PW * 64, WBYTES = TG * OCT * 64;
+    constexpr int PCH = PH * PW * 4;          // 16-byte slots of a patch chunk
+    constexpr int NPP = (PCH + 63) / 64;      // its 1 KiB DMA pieces ...
+    constexpr int PP = (NPP + 3) / 4;         // ... per wave
+    constexpr int PBUF = PP * 4096;           // bytes of one patch buffer (whole pieces for every wave; the excess is zero-filled)
+    constexpr int WBYTES = TG * OCT * 64;     // bytes of one weight stage
+    constexpr int NWP = WBYTES / 1024;
+    constexpr int WP = (NWP + 3) / 4;
+    constexpr int WBUF = WP * 4096;           // bytes of one weight buffer
+    constexpr int NPB = 1 + (D + NTG - 1) / NTG;  // patch ring
+    constexpr int NWB = D + 1;                    // weight ring
+    constexpr int NSTEP = 2 * TG;                 // (tap, k-step) MFMA steps of a stage
     typedef typename Mma<T>::frag_t frag_t;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    unsigned char* const lpatch = lds;                // 2 x PBYTES
-    unsigned char* const lwgt = lds + 2 * PBYTES;     // streamed: 2 x WBYTES ; resident: nch x WBYTES
-    float* const lbias = reinterpret_cast<float*>(lwgt + (RESIDENT ? p.nch : 2) * WBYTES);  // OC floats (zeros without a bias)
+    unsigned char* const lpatch = lds;                // NPB x PBUF
+    unsigned char* const lwgt = lds + NPB * PBUF;     // streamed: NWB x WBUF ; resident: nch x WBUF
+    float* const lbias = reinterpret_cast<float*>(lwgt + (RESIDENT ? p.nch : NWB) * WBUF);  // OC floats (zeros without a bias)
+    unsigned char* const lstage = reinterpret_cast<unsigned char*>(lbias) + ((p.OC + 3) / 4) * 16;  // 4 x 32 rows of 32 channels + pad
+    const unsigned a_patch = (unsigned)(uintptr_t)lds;  // low 32 bits of a flat LDS address = the LDS byte address
+    const unsigned a_wgt = a_patch + NPB * PBUF;
 
-    const T* __restrict__ x = reinterpret_cast<const T*>(p.x);
     const T* __restrict__ wp = reinterpret_cast<const T*>(p.wp);
     T* __restrict__ y = reinterpret_cast<T*>(p.y);
     const int Hi = p.Hi, Wi = p.Wi, IC = p.IC, OC = p.OC, Hb = p.Hb, Wb = p.Wb, NCH = p.nch;
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wv = tid >> 6, hi = lane >> 5, l31 = lane & 31;
+    const int lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     // ---- this block's item list (XCD-contiguous when the grid is a multiple of 8)
     const int total = p.nsp * p.noct;
@@ -157,38 +225,35 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
         count = first < total ? (total - first + stride - 1) / stride : 0;
     }
     if (count == 0) return;
+    GS_TR(0);
 
-    uint4 preg[PREG], wreg[WREG];  // (zero-initialised: conditionally-assigned struct arrays otherwise end up in scratch)
+    // ---- per-lane DMA source descriptors, constant for the life of the block
+    int p_voff[PP], p_lx[PP];
 #pragma unroll
-    for (int r = 0; r < WREG; ++r) wreg[r] = make_uint4(0, 0, 0, 0);
-#pragma unroll
-    for (int r = 0; r < PREG; ++r) preg[r] = make_uint4(0, 0, 0, 0);
-    unsigned int pmask = 0;  // which patch slots of the prefetched stage lie inside the image
-
-    // ---- per-thread staging descriptors, constant for the life of the block (keeps the per-stage address
-    //      arithmetic down to one add + two unsigned compares per 16-byte slot)
-    int p_ll[PREG], p_off[PREG], p_lds[PREG];
-#pragma unroll
-    for (int r = 0; r < PREG; ++r) {
-        const int c = tid + 256 * r;
-        const int pix = c >> 2, part = c & 3;
-        const int ly = pix / PW, lx = pix - ly * PW;
-        const bool ok = c < PCH;
-        p_ll[r] = ok ? ((ly << 16) | lx) : 0x7fff0000;
-        p_off[r] = ((ly * Wi + lx) * IC) * (int)sizeof(T) + part * 16;
-        p_lds[r] = ok ? pix * 64 + ((part ^ ((lx >> 2) & 3)) << 4) : -1;
+    for (int k = 0; k < PP; ++k) {
+        const int slot = (wv + 4 * k) * 64 + lane;
+        const int row = slot >> 2, pos = slot & 3;
+        const int ly = row / PW, lx = row - ly * PW;
+        p_voff[k] = ((ly * Wi + lx) * IC) * SZ + ((pos ^ ((lx >> 2) & 3)) << 4);
+        p_lx[k] = slot < PCH ? lx : 0x40000000;  // never inside the image
     }
-    int w_off[WREG], w_lds[WREG];
+    const int w_lane = ((lane >> 2) * IC) * SZ + (((lane & 3) ^ ((lane >> 4) & 3)) << 4);
+    // block-constant scalar part of every weight piece: rows [tap tt][16*sub ..] of the stage (T2 walks the taps phase by phase)
+    int w_soff[NTG][WP];
 #pragma unroll
-    for (int r = 0; r < WREG; ++r) {
-        const int c = tid + 256 * r;
-        const int R = c >> 2, part = c & 3;
-        const int row = R % OCT, tt = R / OCT;
-        const bool ok = c < WCH;
-        if (MODE == MODE_T2) w_off[r] = ok ? ((tt << 16) | row) : -1;  // tap order is a permutation: resolved per stage
-        else w_off[r] = ok ? (tt * OC + row) * IC * (int)sizeof(T) + part * 16 : -1;
-        w_lds[r] = ok ? R * 64 + ((part ^ ((R >> 2) & 3)) << 4) : -1;
-    }
+    for (int tg = 0; tg < NTG; ++tg)
+#pragma unroll
+        for (int k = 0; k < WP; ++k) {
+            const int j = wv + 4 * k;
+            const int tt = j / (2 * A), sub = j % (2 * A);
+            const int i = tg * TG + tt;
+            const int wt = MODE == MODE_T2 ? (int)((0x453718620ULL >> (4 * (i < 9 ? i : 0))) & 15) : i;
+            w_soff[tg][k] = (NWP % 4 == 0 || j < NWP) ? ((wt * OC + sub * 16) * IC) * SZ : (int)0x80000000;
+        }
+    const unsigned img_bytes = (unsigned)Hi * Wi * IC * SZ;
+    const unsigned w_bytes = 9u * IC * OC * SZ;
+    i32x4 rs_w = make_rsrc(wp, w_bytes);
+    const unsigned a_wave = wv * 1024;
 
     auto item_coords = [&](int item, int& n, int& by, int& bx, int& oc0) __attribute__((always_inline)) {
         const int sp = item / p.noct;
@@ -199,55 +264,58 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
         bx = tile_x * TW;
         n = r / p.tiles_y;
     };
-    auto load_patch = [&](int item, int ch) __attribute__((always_inline)) {
-        int n, by, bx, oc0;
-        item_coords(item, n, by, bx, oc0);
-        const int oy0 = MODE == MODE_S2 ? 2 * by : by - 1;
-        const int ox0 = MODE == MODE_S2 ? 2 * bx : bx - 1;
-        const unsigned char* xb = reinterpret_cast<const unsigned char*>(x) +
-                                  ((((long)n * Hi + oy0) * Wi + ox0) * IC + ch * BK) * (long)sizeof(T);
-        // NOTE: every load is unconditional (out-of-image slots read the tensor base and are zeroed when they are
-        // written to LDS).  A per-slot `if (inside) load` makes hipcc branch around each load and drain vmcnt(0)
-        // per slot, which serialises the whole prefetch into dependent L2 round trips.
-        pmask = 0;
-#pragma unroll
-        for (int r = 0; r < PREG; ++r) {
-            const bool ok = (unsigned)(oy0 + (p_ll[r] >> 16)) < (unsigned)Hi && (unsigned)(ox0 + (p_ll[r] & 0xffff)) < (unsigned)Wi;
-            pmask |= ok ? (1u << r) : 0u;
-            const unsigned char* src = ok ? xb + p_off[r] : reinterpret_cast<const unsigned char*>(x);
-            preg[r] = *reinterpret_cast<const uint4*>(src);
+
+    // ---- issue side: cursor over (item, chunk); the tap group is a compile-time value at every call site
+    int i_item = first, i_left = count, i_ch = 0, i_pb = 0, i_wb = 0;
+    int i_n, i_by, i_bx, i_oc0;
+    item_coords(i_item, i_n, i_by, i_bx, i_oc0);
+    int i_oy0 = 0, i_ox0 = 0, i_org = 0;
+    i32x4 rs_x = make_rsrc(p.x, img_bytes);
+
+    // Past the end of the item list the stages are still "issued" (the counted waits stay static) but against empty
+    // descriptors: every lane is out of range, nothing is fetched, zeros land in ring slots nobody reads again.
+    int i_wbase = 0;
+    auto issue_setup = [&](int tg) __attribute__((always_inline)) {  // scalars of the stage about to be issued
+        const bool more = i_left > 0;
+        if (tg == 0) {
+            i_oy0 = MODE == MODE_S2 ? 2 * i_by : i_by - 1;
+            i_ox0 = MODE == MODE_S2 ? 2 * i_bx : i_bx - 1;
+            i_org = ((i_oy0 * Wi + i_ox0) * IC + i_ch * BK) * SZ;
+            rs_x = make_rsrc(reinterpret_cast<const unsigned char*>(p.x) + (size_t)(more ? i_n : 0) * img_bytes, more ? img_bytes : 0u);
+        }
+        if (!RESIDENT) {
+            rs_w[2] = more ? (int)w_bytes : 0;
+            i_wbase = (i_oc0 * IC + i_ch * BK) * SZ;
         }
     };
-    auto store_patch = [&](int buf) __attribute__((always_inline)) {
-        unsigned char* dst = lpatch + buf * PBYTES;
-#pragma unroll
-        for (int r = 0; r < PREG; ++r) {
-            const uint4 v = (pmask >> r) & 1u ? preg[r] : make_uint4(0, 0, 0, 0);
-            if (PCH % 256 == 0 || r < PREG - 1 || p_lds[r] >= 0) *reinterpret_cast<uint4*>(dst + (p_lds[r] >= 0 ? p_lds[r] : 0)) = v;
-        }
+    auto issue_patch_piece = [&](int k) __attribute__((always_inline)) {
+        const unsigned voff = (unsigned)(i_ox0 + p_lx[k]) < (unsigned)Wi ? (unsigned)(i_org + p_voff[k]) : 0x80000000u;
+        lds_dma16(a_patch + a_wave + i_pb * PBUF + k * 4096, voff, rs_x);
     };
-    auto load_weights = [&](int oc0, int ch, int tg) __attribute__((always_inline)) {
-        if (MODE != MODE_T2) {
-            const unsigned char* wb = reinterpret_cast<const unsigned char*>(wp) +
-                                      (((long)tg * TG * OC + oc0) * IC + ch * BK) * (long)sizeof(T);
-#pragma unroll
-            for (int r = 0; r < WREG; ++r)  // unconditional (slots past the end re-read slot 0 and are not stored)
-                wreg[r] = *reinterpret_cast<const uint4*>(wb + (w_off[r] >= 0 ? w_off[r] : 0));
-        } else {
-#pragma unroll
-            for (int r = 0; r < WREG; ++r) {
-                const int wo = w_off[r] >= 0 ? w_off[r] : 0;
-                const int i = tg * TG + (wo >> 16), row = wo & 0xffff;
-                const int wt = tap_ky<MODE>(i) * 3 + tap_kx<MODE>(i);
-                const T* src = wp + ((long)wt * OC + oc0 + row) * IC + ch * BK;
-                wreg[r] = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(src) + ((tid + 256 * r) & 3) * 16);
+    auto issue_weight_piece = [&](int k, int tg, int wbase, unsigned dst_base) __attribute__((always_inline)) {
+        // (pieces past the end of the stage carry 0x80000000: out of range for any descriptor)
+        lds_dma16(dst_base + a_wave + k * 4096, (unsigned)(w_lane + (w_soff[tg][k] + wbase)), rs_w);
+    };
+    constexpr int NPW = RESIDENT ? 0 : WP;
+    auto stage_pieces = [](int tg) { return (tg == 0 ? PP : 0) + NPW; };  // DMA pieces a wave issues for a stage
+    // piece q of the stage being issued (patch pieces first)
+    auto issue_piece = [&](int q, int tg) __attribute__((always_inline)) {
+        const int np = tg == 0 ? PP : 0;
+        if (q < np) issue_patch_piece(q);
+        else issue_weight_piece(q - np, tg, i_wbase, a_wgt + i_wb * WBUF);
+    };
+    auto issue_advance = [&](int tg) __attribute__((always_inline)) {
+        if (tg == 0) i_pb = i_pb + 1 == NPB ? 0 : i_pb + 1;
+        if (!RESIDENT) i_wb = i_wb + 1 == NWB ? 0 : i_wb + 1;
+        if (tg == NTG - 1) {
+            if (++i_ch == NCH) {
+                i_ch = 0;
+                --i_left;
+                i_item += stride;
+                if (i_left > 0) item_coords(i_item, i_n, i_by, i_bx, i_oc0);
+                else i_left = 0;
             }
         }
-    };
-    auto store_weights = [&](unsigned char* dst) __attribute__((always_inline)) {
-#pragma unroll
-        for (int r = 0; r < WREG; ++r)
-            if (WCH % 256 == 0 || r < WREG - 1 || w_lds[r] >= 0) *reinterpret_cast<uint4*>(dst + (w_lds[r] >= 0 ? w_lds[r] : 0)) = wreg[r];
     };
 
     f32x16 acc[NPH][A][B];
@@ -280,110 +348,150 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
     for (int ks = 0; ks < 2; ++ks) a_off[ks] = l31 * 64 + (((ks * 2 + hi) ^ ((l31 >> 2) & 3)) << 4);
 
     for (int c = tid; c < OC; c += 256) lbias[c] = p.bias ? p.bias[c] : 0.f;
+    block_barrier();  // (also drains hipcc's own loads above before the first DMA is issued)
+    GS_TR(1);
 
-    // ---- prologue
-    int item = first, done = 0;
-    {
-        int n, by, bx, oc0;
-        item_coords(item, n, by, bx, oc0);
-        load_patch(item, 0);
-        store_patch(0);
-        if (RESIDENT) {
-            for (int ch = 0; ch < NCH; ++ch) {
-                load_weights(oc0, ch, 0);
-                store_weights(lwgt + ch * WBYTES);
-            }
-        } else {
-            load_weights(oc0, 0, 0);
-            store_weights(lwgt);
-        }
+    // ---- prologue: resident weights, then the first D stages
+    if (RESIDENT) {
+        for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+            for (int k = 0; k < WP; ++k) issue_weight_piece(k, 0, (i_oc0 * IC + ch * BK) * SZ, a_wgt + ch * WBUF);
     }
-    __syncthreads();
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        issue_setup(d % NTG);
+#pragma unroll
+        for (int q = 0; q < stage_pieces(d % NTG); ++q) issue_piece(q, d % NTG);
+        issue_advance(d % NTG);
+    }
+    GS_TR(2);
+    wait_vmcnt(0);
+    block_barrier();
+    GS_TR(3);
     zero_acc();
-    int pb = 0, wb = 0;
+#ifdef GS_IGEMM_TRACE
+    int tr_stage = 0;
+#endif
 
+    int item = first, done = 0, c_pb = 0, c_wb = 0;
     while (true) {
         int n, by, bx, oc0;
         item_coords(item, n, by, bx, oc0);
         for (int ch = 0; ch < NCH; ++ch) {
 #pragma unroll
             for (int tg = 0; tg < NTG; ++tg) {
-                // ---- what comes next, and its global loads (in flight during the MFMAs below)
-                const bool last_tg = tg == NTG - 1;
-                const bool last_ch = ch == NCH - 1;
-                const bool has_next_item = done + 1 < count;
-                const bool need_patch = last_tg && (!last_ch || has_next_item);
-                const bool need_w = !RESIDENT && (!last_tg || !last_ch || has_next_item);
-                if (need_patch) {
-                    if (!last_ch) load_patch(item, ch + 1);
-                    else load_patch(item + stride, 0);
-                }
-                if (need_w) {
-                    if (!last_tg) load_weights(oc0, ch, tg + 1);
-                    else if (!last_ch) load_weights(oc0, ch + 1, 0);
-                    else {
-                        const int nit = item + stride;
-                        load_weights((nit - (nit / p.noct) * p.noct) * OCT, 0, 0);
-                    }
-                }
-                // ---- MFMAs of this stage
-                const unsigned char* lp = lpatch + pb * PBYTES;
-                const unsigned char* lw = RESIDENT ? lwgt + ch * WBYTES : lwgt + wb * WBYTES;
-                // fragment reads are software-pipelined one (tap, k-step) ahead of the MFMAs that consume them: with one
-                // or two waves per SIMD nothing else hides the LDS latency (the compiler issues them just-in-time)
+                const int itg = (tg + D) % NTG;            // tap group of the stage issued during this one
+                const int npiece = stage_pieces(itg);
+                issue_setup(itg);
+                // ---- MFMAs of this stage; fragment reads run one (tap, k-step) ahead, the DMA pieces of stage +D are
+                //      spread over the steps
+                const unsigned char* lp = lpatch + c_pb * PBUF;
+                const unsigned char* lw = RESIDENT ? lwgt + ch * WBUF : lwgt + c_wb * WBUF;
                 {
-                    frag_t af[2][A], bf[2][B];
-                    auto load_frags = [&](int step, int buf) __attribute__((always_inline)) {
-                        const int tt = step >> 1, ks = step & 1;
+                    constexpr int PF = NSTEP >= 6 ? 2 : 1;   // fragment reads run PF steps ahead of their MFMAs (LDS latency with 4
+                                                             // waves on the pipe exceeds one step of 2-4 MFMAs)
+                    frag_t af[PF + 1][A], bf[PF + 1][B];
+                    // one fragment read of (step, r): r < A -> weight rows of channel tile r, else pixel group r - A
+                    auto load_frag = [&](int step, int r) __attribute__((always_inline)) {
+                        const int tt = step >> 1, ks = step & 1, buf = step % (PF + 1);
                         const int i = tg * TG + tt;
                         const int oyv = tap_off<MODE>(tap_ky<MODE>(i)), oxv = tap_off<MODE>(tap_kx<MODE>(i));
-#pragma unroll
-                        for (int a = 0; a < A; ++a)
-                            af[buf][a] = *reinterpret_cast<const frag_t*>(lw + (tt * OCT + a * 32) * 64 + a_off[ks]);
-#pragma unroll
-                        for (int b = 0; b < B; ++b)
-                            bf[buf][b] = *reinterpret_cast<const frag_t*>(lp + oyv * PW * 64 + b_off[b][oxv][ks]);
+                        if (r < A) af[buf][r] = *reinterpret_cast<const frag_t*>(lw + (tt * OCT + r * 32) * 64 + a_off[ks]);
+                        else bf[buf][r - A] = *reinterpret_cast<const frag_t*>(lp + oyv * PW * 64 + b_off[r - A][oxv][ks]);
                     };
-                    load_frags(0, 0);
+#if !defined(GS_ABL_NOMMA)
 #pragma unroll
-                    for (int step = 0; step < 2 * TG; ++step) {
-                        if (step + 1 < 2 * TG) load_frags(step + 1, (step + 1) & 1);
+                    for (int st0 = 0; st0 < PF; ++st0)
+#pragma unroll
+                        for (int r = 0; r < A + B; ++r) load_frag(st0, r);
+#endif
+                    // Every MFMA is followed by its share of the other work of the step -- the fragment reads of step+1 and
+                    // the DMA pieces of stage +D -- and the order is pinned: with one wave per SIMD only what is issued
+                    // inside an MFMA's 32-cycle shadow is free, and left alone hipcc sinks the reads next to their consumers.
+                    constexpr int NMMA = A * B;
+                    constexpr int RPM = (A + B + NMMA - 1) / NMMA;            // reads per MFMA slot
+                    const int ppm = (npiece + NSTEP * NMMA - 1) / (NSTEP * NMMA);  // DMA pieces per MFMA slot
+#pragma unroll
+                    for (int step = 0; step < NSTEP; ++step) {
                         const int ph = tap_phase<MODE>(tg * TG + (step >> 1));
 #pragma unroll
-                        for (int a = 0; a < A; ++a)
+                        for (int m = 0; m < NMMA; ++m) {
+#ifndef GS_ABL_NOMMA
+                            Mma<T>::mma(af[step % (PF + 1)][m / B], bf[step % (PF + 1)][m % B], acc[ph][m / B][m % B]);
+#if !defined(GS_ABL_NOFRAG)
+                            if (step + PF < NSTEP) {
 #pragma unroll
-                            for (int b = 0; b < B; ++b) Mma<T>::mma(af[step & 1][a], bf[step & 1][b], acc[ph][a][b]);
+                                for (int r = m * RPM; r < (m + 1) * RPM && r < A + B; ++r) load_frag(step + PF, r);
+                            }
+#endif
+#endif
+#ifndef GS_ABL_NODMA
+                            {
+                                const int slot = step * NMMA + m;
+#pragma unroll
+                                for (int q = slot * ppm; q < (slot + 1) * ppm && q < npiece; ++q) issue_piece(q, itg);
+                            }
+#endif
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
                     }
                 }
-                // ---- epilogue of the item: D[oc][pixel]; a lane holds oc = 8q + 4hi + (0..3) of pixel l31 per quad
-                if (last_tg && last_ch) {
+                issue_advance(itg);
+                // ---- the next stage must have landed before the barrier below: leave only the younger stages in flight
+                {
+                    int younger = 0;
+#pragma unroll
+                    for (int d = 2; d <= D; ++d) younger += stage_pieces((tg + d) % NTG);
+#ifndef GS_ABL_NODMA
+                    wait_vmcnt(younger);
+#endif
+                }
+                // ---- epilogue of the item.  D[oc][pixel]: a lane holds oc = 8q + 4hi + (0..3) of pixel l31 per accumulator quad,
+                //      i.e. 8 / 16 bytes per pixel row -- stored directly that is 64 separate small write requests per
+                //      instruction and the store path, not HBM, bounds the kernel.  So each 32-pixel x 32-channel tile takes a
+                //      detour through a wave-private LDS tile and leaves as 16-byte-per-lane stores whose lane quads cover
+                //      whole 64-byte runs of a pixel row.
+#ifndef GS_ABL_NOEPI
+                if (tg == NTG - 1 && ch == NCH - 1) {
                     const int Ho = MODE == MODE_T2 ? 2 * Hb : Hb, Wo = MODE == MODE_T2 ? 2 * Wb : Wb;
+                    constexpr int RB = 32 * SZ + 16;       // staged row: 32 channels + pad (conflict-free quad writes)
+                    constexpr int LPR = 32 * SZ / 16;      // lanes per staged row when reading 16 bytes each
+                    constexpr int RPI = 64 / LPR;          // rows per read instruction
+                    unsigned char* const sw = lstage + wv * (32 * RB);
+                    const int r_row = lane / LPR, r_seg = lane % LPR;
+                    const float slope = p.act == GS_ACT_LRELU ? 0.2f : 1.f;
 #pragma unroll
                     for (int b = 0; b < B; ++b) {
-                        const int q = (wv * B + b) * 32 + l31;
-                        const int gy = by + q / TW, gx = bx + q % TW;
-                        if (gy < Hb && gx < Wb) {
 #pragma unroll
-                            for (int ph = 0; ph < NPH; ++ph) {
-                                const int oy = MODE == MODE_T2 ? 2 * gy + (ph >> 1) : gy;
-                                const int ox = MODE == MODE_T2 ? 2 * gx + (ph & 1) : gx;
-                                T* yp = y + (((long)n * Ho + oy) * Wo + ox) * OC + oc0;
+                        for (int ph = 0; ph < NPH; ++ph) {
 #pragma unroll
-                                for (int a = 0; a < A; ++a) {
-                                    if (oc0 + a * 32 < OC) {
+                            for (int a = 0; a < A; ++a) {
 #pragma unroll
-                                        for (int qd = 0; qd < 4; ++qd) {
-                                            float o[4];
+                                for (int qd = 0; qd < 4; ++qd) {
+                                    float o[4];
 #pragma unroll
-                                            for (int e = 0; e < 4; ++e) o[e] = acc[ph][a][b][qd * 4 + e] * p.alpha;
-                                            const float4 bv = *reinterpret_cast<const float4*>(lbias + oc0 + a * 32 + qd * 8 + hi * 4);
-                                            o[0] += bv.x; o[1] += bv.y; o[2] += bv.z; o[3] += bv.w;
-                                            if (p.act == GS_ACT_LRELU) {
+                                    for (int e = 0; e < 4; ++e) o[e] = acc[ph][a][b][qd * 4 + e] * p.alpha;
+                                    const float4 bv = *reinterpret_cast<const float4*>(lbias + oc0 + a * 32 + qd * 8 + hi * 4);
+                                    o[0] += bv.x; o[1] += bv.y; o[2] += bv.z; o[3] += bv.w;
 #pragma unroll
-                                                for (int e = 0; e < 4; ++e) o[e] = o[e] > 0.f ? o[e] : 0.2f * o[e];
-                                            }
-                                            st4(yp + a * 32 + qd * 8 + hi * 4, o);
-                                        }
+                                    for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], slope * o[e]);  // leaky relu (slope 1: identity)
+                                    st4(reinterpret_cast<T*>(sw + l31 * RB) + qd * 8 + hi * 4, o);
+                                }
+#pragma unroll
+                                for (int it = 0; it < 32 / RPI; ++it) {
+                                    const int row = it * RPI + r_row;
+                                    const int q = (wv * B + b) * 32 + row;
+                                    const int gy = by + q / TW, gx = bx + q % TW;
+                                    const uint4 v = *reinterpret_cast<const uint4*>(sw + row * RB + r_seg * 16);
+#ifdef GS_ABL_NOSTORE
+                                    if (gy < -1000) {   // never (keeps the epilogue arithmetic alive)
+#else
+                                    if (gy < Hb && gx < Wb) {
+#endif
+                                        const int oy = MODE == MODE_T2 ? 2 * gy + (ph >> 1) : gy;
+                                        const int ox = MODE == MODE_T2 ? 2 * gx + (ph & 1) : gx;
+                                        T* yp = y + (((long)n * Ho + oy) * Wo + ox) * OC + oc0 + a * 32 + r_seg * (16 / SZ);
+                                        *reinterpret_cast<uint4*>(yp) = v;
                                     }
                                 }
                             }
@@ -391,17 +499,21 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
                     }
                     zero_acc();
                 }
-                // ---- publish the prefetched stage into the other LDS buffers
-                if (need_patch) store_patch(pb ^ 1);
-                if (need_w) store_weights(lwgt + (wb ^ 1) * WBYTES);
-                if (need_patch || need_w) __syncthreads();
-                if (need_patch) pb ^= 1;
-                if (need_w) wb ^= 1;
+#endif
+                block_barrier();
+#ifdef GS_IGEMM_TRACE
+                GS_TR(4 + tr_stage);
+                ++tr_stage;
+#endif
+                if (tg == NTG - 1) c_pb = c_pb + 1 == NPB ? 0 : c_pb + 1;
+                if (!RESIDENT) c_wb = c_wb + 1 == NWB ? 0 : c_wb + 1;
             }
         }
         if (++done >= count) break;
         item += stride;
     }
+    GS_TR(63);
+    wait_vmcnt(0);  // the (empty) stages issued past the end must have retired before this block's LDS is handed on
 }
 
 // --------------------------------------------------------------------- weight gradient
@@ -640,22 +752,28 @@ static int num_cus() {
     return g_num_cus;
 }
 
-template <typename T, int MODE, int A, int B, int TW, int TG, bool RESIDENT = false>
+template <typename T, int MODE, int A, int B, int TW, int TG, bool RESIDENT = false, int D = 2>
 static int launch_igemm(ConvP p, hipStream_t st) {
     constexpr int NP = 128 * B;
     constexpr int TH = NP / TW;
     constexpr int PH = patch_dim<MODE>(TH), PW = patch_dim<MODE>(TW);
     constexpr int OCT = 32 * A;
     constexpr int BK = 64 / (int)sizeof(T);
+    constexpr int NTG = 9 / TG;
+    constexpr int PBUF = ((PH * PW * 4 + 255) / 256) * 4096;
+    constexpr int WBUF = ((TG * OCT * 64 + 4095) / 4096) * 4096;
+    constexpr int NPB = 1 + (D + NTG - 1) / NTG, NWB = D + 1;
     p.tiles_x = cdiv(p.Wb, TW);
     p.tiles_y = cdiv(p.Hb, TH);
     p.nsp = p.N * p.tiles_x * p.tiles_y;
     p.noct = cdiv(p.OC, OCT);
     p.nch = p.IC / BK;
-    const int wbufs = RESIDENT ? p.nch : 2;
-    const size_t lds = (size_t)2 * PH * PW * 64 + (size_t)wbufs * TG * OCT * 64 + (size_t)((p.OC + 3) / 4) * 16;
+    const int wbufs = RESIDENT ? p.nch : NWB;
+    const size_t lds = (size_t)NPB * PBUF + (size_t)wbufs * WBUF + (size_t)((p.OC + 3) / 4) * 16 + 4 * 32 * (32 * sizeof(T) + 16);
+    if (p.OC % OCT != 0) return fail(GS_ERR_UNSUPPORTED, "conv igemm: %d output channels with %d-wide tiles", p.OC, OCT);
+    if ((size_t)p.Hi * p.Wi * p.IC * sizeof(T) >= (1ull << 31)) return fail(GS_ERR_UNSUPPORTED, "conv igemm: one image exceeds 2 GiB");
     if (lds > 160 * 1024) return fail(GS_ERR_UNSUPPORTED, "conv igemm: %zu bytes of LDS needed", lds);
-    auto kern = conv_igemm_kernel<T, MODE, A, B, TW, TG, RESIDENT>;
+    auto kern = conv_igemm_kernel<T, MODE, A, B, TW, TG, RESIDENT, D>;
     static size_t max_set = 0;  // per template instantiation
     if (lds > max_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -683,33 +801,29 @@ static int dispatch_igemm(ConvP p, hipStream_t st) {
     const int OC = p.OC, Wb = p.Wb;
     const int nch = p.IC / BK;
     const bool resident_ok = OC == 32 && nch <= 2;
-    // number of 128-pixel tiles: prefer 128-wide oc tiles only when they still give >= 2 blocks per CU
-    const long tiles128 = (long)p.N * cdiv(p.Hb, Wb >= 32 ? 4 : 8) * cdiv(Wb, Wb >= 32 ? 32 : 16);
-    const bool wide = OC % 128 == 0 && tiles128 * (OC / 128) >= 2L * num_cus();
+    const bool resident64_ok = OC == 64 && nch <= 2;   // 9 taps x 64 x (<= 64 channels) <= 72 KiB stay in LDS
+    const int a2 = OC % 64 == 0;
+    // blocks the layer gives with 128*B-pixel x 64-channel tiles (TW = 32)
+    auto items64 = [&](int B_) { return (long)p.N * cdiv(p.Hb, 4 * B_) * cdiv(Wb, 32) * (OC / 64); };
     if constexpr (MODE == MODE_T2) {
         if (resident_ok && Wb >= 64) return launch_igemm<T, MODE, 1, 2, 64, 9, true>(p, st);
-        if (OC == 32) return launch_igemm<T, MODE, 1, 1, 32, 3>(p, st);
+        if (!a2) return launch_igemm<T, MODE, 1, 1, 32, 3>(p, st);
         if (Wb >= 32) return launch_igemm<T, MODE, 2, 1, 32, 3>(p, st);
         return launch_igemm<T, MODE, 2, 1, 16, 3>(p, st);
     } else if constexpr (MODE == MODE_S2) {
-        if (OC == 32) return launch_igemm<T, MODE, 1, 1, 32, 3>(p, st);
-        if (!wide) {
-            if (Wb >= 32) return launch_igemm<T, MODE, 2, 1, 32, 3>(p, st);
-            return launch_igemm<T, MODE, 2, 1, 16, 3>(p, st);
-        }
-        if (Wb >= 32) return launch_igemm<T, MODE, 4, 1, 32, 3>(p, st);
-        return launch_igemm<T, MODE, 4, 1, 16, 3>(p, st);
+        if (!a2) return launch_igemm<T, MODE, 1, 1, 32, 3>(p, st);
+        if (Wb >= 32) return launch_igemm<T, MODE, 2, 1, 32, 3>(p, st);
+        return launch_igemm<T, MODE, 2, 1, 16, 3>(p, st);
     } else {
         if (resident_ok && Wb >= 64) return launch_igemm<T, MODE, 1, 2, 64, 9, true>(p, st);
-        if (OC == 32) return launch_igemm<T, MODE, 1, 1, 32, 3>(p, st);
-        if (OC % 64 == 0 && Wb >= 32 && (long)p.N * cdiv(p.Hb, 8) * cdiv(Wb, 32) * (OC / 64) >= num_cus() / 2)
-            return launch_igemm<T, MODE, 2, 2, 32, 9>(p, st);
-        if (!wide) {
-            if (Wb >= 32) return launch_igemm<T, MODE, 2, 1, 32, 3>(p, st);
-            return launch_igemm<T, MODE, 2, 1, 16, 3>(p, st);
-        }
-        if (Wb >= 32) return launch_igemm<T, MODE, 4, 1, 32, 3>(p, st);
-        return launch_igemm<T, MODE, 4, 1, 16, 3>(p, st);
+        if (!a2) return launch_igemm<T, MODE, 1, 1, 32, 3>(p, st);
+        if (resident64_ok && Wb >= 32 && items64(2) >= num_cus() / 2) return launch_igemm<T, MODE, 2, 2, 32, 9, true>(p, st);
+        // every block re-streams its 64 x IC x 9 weight slab from L2: the more pixels a block owns the smaller that
+        // stream is per MFMA -- take the largest pixel tile that still gives every CU a block
+        if (Wb >= 32 && items64(4) >= num_cus()) return launch_igemm<T, MODE, 2, 4, 32, 3>(p, st);
+        if (Wb >= 32 && items64(2) >= num_cus()) return launch_igemm<T, MODE, 2, 2, 32, 3>(p, st);
+        if (Wb >= 32) return launch_igemm<T, MODE, 2, 1, 32, 3>(p, st);
+        return launch_igemm<T, MODE, 2, 1, 16, 3>(p, st);
     }
 }
 

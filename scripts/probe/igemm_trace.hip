@@ -1,0 +1,70 @@
+// In-kernel timeline of the implicit-GEMM conv: compiles the production kernel with GS_IGEMM_TRACE and prints, averaged over
+// blocks, the shader-clock stamps of wave 0 (start, bias staged, prologue issued, first stage landed, every stage, end).
+// usage: igemm_trace <mode 0|1|2> <N> <Hin> <Win> <IC> <OC> [reps]
+#define GS_IGEMM_TRACE 1
+#include "../../gansynth_amd/csrc/conv_igemm.hip"
+#include "../../gansynth_amd/csrc/core.cpp"
+#include <stdlib.h>
+#include <vector>
+
+int main(int argc, char** argv) {
+    using namespace gs;
+    const int mode = atoi(argv[1]), N = atoi(argv[2]), Hi = atoi(argv[3]), Wi = atoi(argv[4]), IC = atoi(argv[5]), OC = atoi(argv[6]);
+    const int reps = argc > 7 ? atoi(argv[7]) : 5;
+    const int Hb = mode == MODE_S2 ? Hi / 2 : Hi, Wb = mode == MODE_S2 ? Wi / 2 : Wi;
+    const int Ho = mode == MODE_T2 ? 2 * Hi : Hb, Wo = mode == MODE_T2 ? 2 * Wi : Wb;
+    const size_t nx = (size_t)N * Hi * Wi * IC, ny = (size_t)N * Ho * Wo * OC, nw = (size_t)9 * IC * OC;
+    std::vector<unsigned short> hx(nx), hw(nw);
+    for (auto& v : hx) v = 0x3c00 + (rand() & 0x3ff);  // bf16 in [0.0078, 0.0156): finite, non-trivial
+    for (auto& v : hw) v = 0x3c00 + (rand() & 0x3ff);
+    void *x, *w, *y;
+    unsigned long long* tr;
+    hipMalloc(&x, nx * 2); hipMalloc(&w, nw * 2); hipMalloc(&y, ny * 2); hipMalloc(&tr, 4096 * 64 * 8);
+    hipMemcpy(x, hx.data(), nx * 2, hipMemcpyHostToDevice);
+    hipMemcpy(w, hw.data(), nw * 2, hipMemcpyHostToDevice);
+    ConvP p;
+    memset(&p, 0, sizeof(p));
+    p.x = x; p.wp = w; p.y = y; p.N = N; p.Hi = Hi; p.Wi = Wi; p.IC = IC; p.OC = OC; p.Hb = Hb; p.Wb = Wb; p.alpha = 1.f; p.trace = tr;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e9f;
+    for (int r = 0; r < reps; ++r) {
+        hipMemset(tr, 0, 4096 * 64 * 8);
+        hipEventRecord(e0, 0);
+        int rc = mode == 0 ? dispatch_igemm<bf16_t, MODE_S1>(p, 0) : (mode == 1 ? dispatch_igemm<bf16_t, MODE_S2>(p, 0) : dispatch_igemm<bf16_t, MODE_T2>(p, 0));
+        hipEventRecord(e1, 0);
+        hipEventSynchronize(e1);
+        if (rc) { printf("launch failed: %s\n", g_err); return 1; }
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best) best = ms;
+    }
+    std::vector<unsigned long long> h(4096 * 64);
+    hipMemcpy(h.data(), tr, h.size() * 8, hipMemcpyDeviceToHost);
+    int nb = 0;
+    double sum[64] = {0};
+    unsigned long long t0min = ~0ull, t1max = 0;
+    for (int b = 0; b < 4096; ++b) {
+        if (!h[b * 64]) continue;
+        ++nb;
+        if (h[b * 64] < t0min) t0min = h[b * 64];
+        if (h[b * 64 + 63] > t1max) t1max = h[b * 64 + 63];
+        for (int s = 0; s < 64; ++s) sum[s] += h[b * 64 + s] ? (double)(h[b * 64 + s] - h[b * 64]) : 0.0;
+    }
+    printf("event time %.1f us; %d blocks traced; first start -> last end %.0f ticks\n", best * 1e3, nb, (double)(t1max - t0min));
+    const char* names[4] = {"start", "bias staged", "prologue issued", "stage 0 landed"};
+    double prev = 0;
+    for (int s = 0; s < 64; ++s) {
+        if (s > 0 && sum[s] == 0) continue;
+        const double v = sum[s] / nb;
+        if (s < 4) printf("  %-18s %9.0f  (+%.0f)\n", names[s], v, v - prev);
+        else if (s == 63) printf("  %-18s %9.0f  (+%.0f)\n", "end", v, v - prev);
+        else printf("  stage %2d done      %9.0f  (+%.0f)\n", s - 4, v, v - prev);
+        prev = v;
+    }
+    // start skew across blocks
+    double skew = 0;
+    for (int b = 0; b < 4096; ++b) if (h[b * 64]) skew += (double)(h[b * 64] - t0min);
+    printf("  mean block start after the first block: %.0f ticks\n", skew / nb);
+    return 0;
+}
