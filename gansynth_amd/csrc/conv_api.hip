@@ -102,16 +102,185 @@ static int launch_direct(const T* x, const float* wp, T* y, int mode, int ks, in
     return 0;
 }
 
-// direct conv through the fp32 prepped weights living in ws
+
+// ------------------------------------------------------------------ thin 1x1 convolutions
+// The colour blocks (ops.py:237-243 with a [1,1,C,2] / [1,1,2,C] kernel) are pure streaming: 64 bytes in and 4 out per
+// pixel, or the reverse.  One lane per 16 bytes of the wide side keeps every access coalesced; the bias / activation
+// epilogue of the block is applied in the same pass.
+__device__ inline float thin_act(float v, int act) {
+    if (act == GS_ACT_LRELU) return fmaxf(v, 0.2f * v);
+    if (act == GS_ACT_TANH) return tanhf(v);
+    return v;
+}
+template <typename T> struct Wide;   // 16 bytes of T
+template <> struct Wide<float> { static constexpr int N = 4; };
+template <> struct Wide<bf16_t> { static constexpr int N = 8; };
+template <typename T> __device__ inline void ld_wide(const T* p, float* o);
+template <> __device__ inline void ld_wide<float>(const float* p, float* o) { ld4(p, *reinterpret_cast<float(*)[4]>(o)); }
+template <> __device__ inline void ld_wide<bf16_t>(const bf16_t* p, float* o) {
+    const uint4 v = *reinterpret_cast<const uint4*>(p);
+    const unsigned int w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { o[2 * i] = __uint_as_float(w[i] << 16); o[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+}
+template <typename T> __device__ inline void st_wide(T* p, const float* o);
+template <> __device__ inline void st_wide<float>(float* p, const float* o) { *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]); }
+template <> __device__ inline void st_wide<bf16_t>(bf16_t* p, const float* o) {
+    uint4 v;
+    v.x = pack_bf16x2(o[0], o[1]); v.y = pack_bf16x2(o[2], o[3]); v.z = pack_bf16x2(o[4], o[5]); v.w = pack_bf16x2(o[6], o[7]);
+    *reinterpret_cast<uint4*>(p) = v;
+}
+
+// few -> many channels: y[p][oc] = act(alpha * sum_ic x[p][ic] wp[oc][ic] + bias[oc]),  IC <= 4, OC % Wide::N == 0, 256 % (OC / N) == 0.
+// A thread keeps its Wide::N output channels (weights + bias in registers) and strides over pixels.
+template <typename T, int IC>
+__global__ __launch_bounds__(256) void thin_expand_kernel(const T* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
+                                                          T* __restrict__ y, long P, int OC, float alpha, int act) {
+    constexpr int WN = Wide<T>::N;
+    const int groups = OC / WN;
+    const int oc0 = (threadIdx.x % groups) * WN;
+    float wr[WN][IC], br[WN];
+#pragma unroll
+    for (int v = 0; v < WN; ++v) {
+        br[v] = bias ? bias[oc0 + v] : 0.f;
+#pragma unroll
+        for (int i = 0; i < IC; ++i) wr[v][i] = wp[(oc0 + v) * IC + i] * alpha;
+    }
+    const long ppb = 256 / groups;  // pixels per block pass
+    for (long pix = (long)blockIdx.x * ppb + threadIdx.x / groups; pix < P; pix += (long)gridDim.x * ppb) {
+        float xv[IC];
+#pragma unroll
+        for (int i = 0; i < IC; ++i) xv[i] = DT<T>::ld(x + pix * IC + i);
+        float o[WN];
+#pragma unroll
+        for (int v = 0; v < WN; ++v) {
+            float a = br[v];
+#pragma unroll
+            for (int i = 0; i < IC; ++i) a += xv[i] * wr[v][i];
+            o[v] = thin_act(a, act);
+        }
+        st_wide<T>(y + pix * OC + oc0, o);
+    }
+}
+
+// many -> few channels: a pixel is read by L = IC / Wide::N lanes (a power of two <= 64), partial dots are folded with
+// xor-shuffles, lane 0 of the group writes the OC <= 4 results.  Weights stay in registers across the pixel loop.
+template <typename T, int OC>
+__global__ __launch_bounds__(256) void thin_reduce_kernel(const T* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
+                                                          T* __restrict__ y, long P, int IC, float alpha, int act) {
+    constexpr int WN = Wide<T>::N;
+    const int L = IC / WN;
+    const int l = threadIdx.x % L;
+    float wr[OC][WN];
+#pragma unroll
+    for (int v = 0; v < OC; ++v)
+#pragma unroll
+        for (int i = 0; i < WN; ++i) wr[v][i] = wp[v * IC + l * WN + i] * alpha;
+    const long ppb = 256 / L;
+    const long npass = (P + (long)gridDim.x * ppb - 1) / ((long)gridDim.x * ppb);  // same trip count for every lane (shuffles)
+    for (long k = 0; k < npass; ++k) {
+        const long pix = (k * gridDim.x + blockIdx.x) * ppb + threadIdx.x / L;
+        float a[OC];
+#pragma unroll
+        for (int v = 0; v < OC; ++v) a[v] = 0.f;
+        if (pix < P) {
+            float xv[WN];
+            ld_wide<T>(x + pix * IC + l * WN, xv);
+#pragma unroll
+            for (int v = 0; v < OC; ++v)
+#pragma unroll
+                for (int i = 0; i < WN; ++i) a[v] += xv[i] * wr[v][i];
+        }
+        for (int o = L >> 1; o > 0; o >>= 1)
+#pragma unroll
+            for (int v = 0; v < OC; ++v) a[v] += __shfl_xor(a[v], o, 64);
+        if (pix < P && l == 0) {
+#pragma unroll
+            for (int v = 0; v < OC; ++v) DT<T>::st(y + pix * OC + v, thin_act(a[v] + (bias ? bias[v] : 0.f), act));
+        }
+    }
+}
+
+// one output channel, many input channels, any tap geometry (the data gradient of the minibatch-stddev plane of the last
+// discriminator block): a wave per output pixel, lanes over the input channels.
+template <typename T>
+__global__ __launch_bounds__(256) void thin_single_kernel(const T* __restrict__ x, const float* __restrict__ wp, T* __restrict__ y, int mode,
+                                                          int ks, int N, int Hi, int Wi, int IC, int Ho, int Wo, float alpha) {
+    const long pix = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (pix >= (long)N * Ho * Wo) return;
+    const int ox = pix % Wo;
+    const int oy = (pix / Wo) % Ho;
+    const int n = pix / ((long)Wo * Ho);
+    float a = 0.f;
+    for (int ky = 0; ky < ks; ++ky) {
+        int iy;
+        if (mode == MODE_S1) iy = oy + ky - (ks >> 1);
+        else if (mode == MODE_S2) iy = 2 * oy + ky;
+        else { const int d = oy - ky; if (d < 0 || (d & 1)) continue; iy = d >> 1; }
+        if (iy < 0 || iy >= Hi) continue;
+        for (int kx = 0; kx < ks; ++kx) {
+            int ix;
+            if (mode == MODE_S1) ix = ox + kx - (ks >> 1);
+            else if (mode == MODE_S2) ix = 2 * ox + kx;
+            else { const int d = ox - kx; if (d < 0 || (d & 1)) continue; ix = d >> 1; }
+            if (ix < 0 || ix >= Wi) continue;
+            const T* xp = x + (((long)n * Hi + iy) * Wi + ix) * IC;
+            const float* wr = wp + (long)(ky * ks + kx) * IC;
+            for (int ic = lane; ic < IC; ic += 64) a += DT<T>::ld(xp + ic) * wr[ic];
+        }
+    }
+    a = wave_sum(a);
+    if (lane == 0) DT<T>::st(y + pix, a * alpha);
+}
+
+// direct conv through the fp32 prepped weights living in ws; *fused is set when bias / act went into the same pass
 static int run_direct(int mode, int ks, int variant, const void* x, const float* w_hwio, void* y, int N, int Hi, int Wi,
                       int ICk, int OCk, int w_ci, int w_co, int Ho, int Wo, float alpha, int dtype, int w_prepared, void* ws,
-                      size_t ws_bytes, hipStream_t st) {
+                      size_t ws_bytes, hipStream_t st, const float* bias = nullptr, int act = GS_ACT_NONE, bool* fused = nullptr) {
     const long total = (long)ks * ks * w_ci * w_co;
     if (ws_bytes < (size_t)total * 4) return fail(GS_ERR_WORKSPACE, "conv direct: workspace %zu < %zu", ws_bytes, (size_t)total * 4);
     float* wp = reinterpret_cast<float*>(ws);
     if (!w_prepared) {
         hipLaunchKernelGGL((weight_prep_kernel<float>), dim3(cdiv(total, 256)), dim3(256), 0, st, w_hwio, wp, ks * ks, w_ci, w_co, variant);
         GS_CHECK_LAUNCH();
+    }
+    if (fused) *fused = false;
+    const long P = (long)N * Ho * Wo;
+    const int wn = dtype == GS_F32 ? 4 : 8;
+    if (ks == 1 && mode == MODE_S1 && ICk <= 4 && OCk % wn == 0 && 256 % (OCk / wn) == 0) {   // colour -> features
+        long nb = cdiv(P * (OCk / wn), 256);
+        if (nb > 4096) nb = 4096;
+        const unsigned grid = (unsigned)nb;
+#define GS_TE(TT, ICV) hipLaunchKernelGGL((thin_expand_kernel<TT, ICV>), dim3(grid), dim3(256), 0, st, (const TT*)x, wp, bias, (TT*)y, P, OCk, alpha, act)
+#define GS_TE_ALL(TT) do { if (ICk == 1) GS_TE(TT, 1); else if (ICk == 2) GS_TE(TT, 2); else if (ICk == 3) GS_TE(TT, 3); else GS_TE(TT, 4); } while (0)
+        GS_DISPATCH_DTYPE(dtype, GS_TE_ALL(T));
+#undef GS_TE_ALL
+#undef GS_TE
+        GS_CHECK_LAUNCH();
+        if (fused) *fused = true;
+        else if (bias || act != GS_ACT_NONE) return fail(GS_ERR_ARG, "conv direct: epilogue requested without a fused flag");
+        return 0;
+    }
+    const int lanes = ICk / wn;
+    if (ks == 1 && mode == MODE_S1 && OCk <= 4 && ICk % wn == 0 && lanes <= 64 && (lanes & (lanes - 1)) == 0) {  // features -> colour
+        long nb = cdiv(P * lanes, 256);
+        if (nb > 4096) nb = 4096;
+        const unsigned grid = (unsigned)nb;
+#define GS_TR(TT, OCV) hipLaunchKernelGGL((thin_reduce_kernel<TT, OCV>), dim3(grid), dim3(256), 0, st, (const TT*)x, wp, bias, (TT*)y, P, ICk, alpha, act)
+#define GS_TR_ALL(TT) do { if (OCk == 1) GS_TR(TT, 1); else if (OCk == 2) GS_TR(TT, 2); else if (OCk == 3) GS_TR(TT, 3); else GS_TR(TT, 4); } while (0)
+        GS_DISPATCH_DTYPE(dtype, GS_TR_ALL(T));
+#undef GS_TR_ALL
+#undef GS_TR
+        GS_CHECK_LAUNCH();
+        if (fused) *fused = true;
+        return 0;
+    }
+    if (OCk == 1 && ICk >= 64) {
+        GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((thin_single_kernel<T>), dim3((unsigned)cdiv(P, 4)), dim3(256), 0, st, (const T*)x, wp, (T*)y, mode,
+                                                    ks, N, Hi, Wi, ICk, Ho, Wo, alpha));
+        GS_CHECK_LAUNCH();
+        return 0;
     }
     GS_DISPATCH_DTYPE(dtype, return launch_direct<T>(reinterpret_cast<const T*>(x), wp, reinterpret_cast<T*>(y), mode, ks,
                                                      N, Hi, Wi, ICk, OCk, Ho, Wo, alpha, st));
@@ -300,8 +469,9 @@ static int conv2d_fwd_impl(const void* x, const float* w_hwio, const float* bias
     const int mode = stride == 2 ? MODE_S2 : MODE_S1;
     if (ksize == 3 && igemm_supported(ci, co, dtype) && act != GS_ACT_TANH)
         return run_igemm(mode, 0, x, w_hwio, y, n, h, w, ci, co, ci, co, hb, wb, alpha, bias, act, dtype, w_prepared, ws, ws_bytes, st);
-    if (int e = run_direct(mode, ksize, 0, x, w_hwio, y, n, h, w, ci, co, ci, co, hb, wb, alpha, dtype, w_prepared, ws, ws_bytes, st)) return e;
-    if (bias || act != GS_ACT_NONE) return gs_bias_act_fwd(y, bias, y, (int64_t)n * hb * wb, co, act, dtype, stream);
+    bool fused = false;
+    if (int e = run_direct(mode, ksize, 0, x, w_hwio, y, n, h, w, ci, co, ci, co, hb, wb, alpha, dtype, w_prepared, ws, ws_bytes, st, bias, act, &fused)) return e;
+    if (!fused && (bias || act != GS_ACT_NONE)) return gs_bias_act_fwd(y, bias, y, (int64_t)n * hb * wb, co, act, dtype, stream);
     return 0;
 }
 
