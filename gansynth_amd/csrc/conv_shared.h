@@ -34,35 +34,31 @@ __global__ void weight_prep_kernel(const float* __restrict__ w, T* __restrict__ 
 
 // gw[e] = alpha * sum_s part[s][e]; `transpose` swaps the last two dims on output
 // (used by conv2d_transpose's weight gradient, whose stored variable is [k][k][Cin_T][Cout_T]).
-// Block = 64 consecutive elements x 4 slice lanes over the slab [blockIdx.y*per, +per) of slices; fixed
-// summation order -> deterministic.  With `raw` the slab sum is written un-scaled to out[blockIdx.y][e]
-// (first level of a two-level reduction when there are many slices).
+// Block = (256 / L) consecutive elements x L slice lanes; one launch whatever the slice count (L = 4 for a few slices,
+// 16 for the hundreds of slices of the thin top-of-pyramid layers); fixed summation order -> deterministic.
+template <int L>
 static __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ gw, int nslices,
-                                                                  int taps, int ic, int oc, float alpha, int transpose, int per, int raw, int accumulate) {
+                                                                  int taps, int ic, int oc, float alpha, int transpose, int accumulate) {
+    constexpr int EPB = 256 / L;
     __shared__ float red[256];
     const long total = (long)taps * ic * oc;
-    const long e = (long)blockIdx.x * 64 + (threadIdx.x & 63);
-    const int sl = threadIdx.x >> 6;
-    const int k0 = blockIdx.y * per;
-    int k1 = k0 + per;
-    if (k1 > nslices) k1 = nslices;
+    const long e = (long)blockIdx.x * EPB + (threadIdx.x % EPB);
+    const int sl = threadIdx.x / EPB;
     float s0 = 0.f, s1 = 0.f;
     if (e < total) {
-        int k = k0 + sl;
-        for (; k + 4 < k1; k += 8) {
+        int k = sl;
+        for (; k + L < nslices; k += 2 * L) {
             s0 += part[(long)k * total + e];
-            s1 += part[(long)(k + 4) * total + e];
+            s1 += part[(long)(k + L) * total + e];
         }
-        if (k < k1) s0 += part[(long)k * total + e];
+        if (k < nslices) s0 += part[(long)k * total + e];
     }
     red[threadIdx.x] = s0 + s1;
     __syncthreads();
     if (sl == 0 && e < total) {
-        float s = red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] + red[threadIdx.x + 192];
-        if (raw) {
-            gw[(long)blockIdx.y * total + e] = s;
-            return;
-        }
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < L; ++j) s += red[threadIdx.x + j * EPB];
         s *= alpha;
         long dst = e;
         if (transpose) {
@@ -75,19 +71,14 @@ static __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* _
     }
 }
 
-constexpr int WG_SLAB = 64;  // slices per first-level block
-// extra fp32 elements the partial buffer needs behind its nslices*total partials
-static inline size_t wgrad_reduce_extra(long nslices, long total) { return nslices > WG_SLAB ? (size_t)((nslices + WG_SLAB - 1) / WG_SLAB) * total : 0; }
+// extra fp32 elements the partial buffer needs behind its nslices*total partials (none any more; kept for the ABI size query)
+static inline size_t wgrad_reduce_extra(long nslices, long total) { (void)nslices; (void)total; return 0; }
 static inline void wgrad_reduce_launch(float* part, float* gw, int nslices, int taps, int ic, int oc, float alpha, int transpose, int accumulate, hipStream_t st) {
     const long total = (long)taps * ic * oc;
-    const unsigned gx = (unsigned)((total + 63) / 64);
-    if (nslices <= WG_SLAB) {
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(gx, 1), dim3(256), 0, st, part, gw, nslices, taps, ic, oc, alpha, transpose, nslices, 0, accumulate);
+    if (nslices <= 32) {
+        hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, part, gw, nslices, taps, ic, oc, alpha, transpose, accumulate);
     } else {
-        const int nsplit = (nslices + WG_SLAB - 1) / WG_SLAB;
-        float* part2 = part + (long)nslices * total;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(gx, nsplit), dim3(256), 0, st, part, part2, nslices, taps, ic, oc, 1.f, 0, WG_SLAB, 1, 0);
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(gx, 1), dim3(256), 0, st, part2, gw, nsplit, taps, ic, oc, alpha, transpose, nsplit, 0, accumulate);
+        hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, st, part, gw, nslices, taps, ic, oc, alpha, transpose, accumulate);
     }
 }
 

@@ -115,7 +115,158 @@ __global__ __launch_bounds__(256) void dense_bwd_data_wide_kernel(const T* __res
     }
 }
 
+
+// ---- fast paths (vector loads; the generic kernels above remain for odd shapes) ------------------------------------
+// y[b][o] = alpha * sum_i x[b][i] w[i][o], in % 4 == 0, out % 32 == 0.  Block = 8 column threads (float4: 32 columns) x 32 row
+// lanes; a row lane takes 4 consecutive rows per pass (one 8/16-byte load of x per batch row).  Row lanes are folded with
+// xor-shuffles inside a wave and through LDS across the 4 waves; with ksplit == 1 the result is written directly.
+template <typename T>
+__global__ __launch_bounds__(256) void dense_fwd_fast_kernel(const T* __restrict__ x, const float* __restrict__ w, float* __restrict__ part,
+                                                             T* __restrict__ y, int b0, int nb, int in, int out, int b_total, int ipb, float alpha) {
+    __shared__ float red[4][DENSE_BT][32];
+    const int tid = threadIdx.x;
+    const int c = tid & 7, r = tid >> 3;           // column thread, row lane (0..31)
+    const int col = blockIdx.x * 32 + c * 4;
+    const int i0 = blockIdx.y * ipb;
+    int i1 = i0 + ipb;
+    if (i1 > in) i1 = in;
+    float acc[DENSE_BT][4];
+#pragma unroll
+    for (int b = 0; b < DENSE_BT; ++b)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[b][e] = 0.f;
+    for (int i = i0 + 4 * r; i < i1; i += 128) {
+        float4 wv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) wv[k] = *reinterpret_cast<const float4*>(w + (long)(i + k) * out + col);
+#pragma unroll
+        for (int b = 0; b < DENSE_BT; ++b) {
+            if (b < nb) {
+                float xv[4];
+                ld4(x + (long)(b0 + b) * in + i, xv);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    acc[b][0] += xv[k] * wv[k].x; acc[b][1] += xv[k] * wv[k].y; acc[b][2] += xv[k] * wv[k].z; acc[b][3] += xv[k] * wv[k].w;
+                }
+            }
+        }
+    }
+    // fold the 8 row lanes of the wave (lane = r_local * 8 + c)
+#pragma unroll
+    for (int b = 0; b < DENSE_BT; ++b) {
+        if (b < nb) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = acc[b][e];
+                v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+                acc[b][e] = v;
+            }
+        }
+    }
+    const int wv_ = tid >> 6;
+    if ((tid & 63) < 8) {
+#pragma unroll
+        for (int b = 0; b < DENSE_BT; ++b)
+            if (b < nb) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) red[wv_][b][c * 4 + e] = acc[b][e];
+            }
+    }
+    __syncthreads();
+    for (int k = tid; k < nb * 32; k += 256) {
+        const int b = k >> 5, cc = k & 31;
+        const float s = red[0][b][cc] + red[1][b][cc] + red[2][b][cc] + red[3][b][cc];
+        const int o = blockIdx.x * 32 + cc;
+        if (part) part[((long)blockIdx.y * b_total + b0 + b) * out + o] = s;
+        else DT<T>::st(y + (long)(b0 + b) * out + o, s * alpha);
+    }
+}
+
+// gx[b][i] = alpha * sum_o gy[b][o] w[i][o], out % 256 == 0: one wave per weight row, 16 bytes of w per lane per pass.
+template <typename T>
+__global__ __launch_bounds__(256) void dense_bwd_data_fast_kernel(const T* __restrict__ gy, const float* __restrict__ w, T* __restrict__ gx,
+                                                                  int b0, int nb, int in, int out, float alpha) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= in) return;
+    float acc[DENSE_BT];
+#pragma unroll
+    for (int b = 0; b < DENSE_BT; ++b) acc[b] = 0.f;
+    const float* wr = w + (long)i * out;
+    for (int o = lane * 4; o < out; o += 256) {
+        const float4 wv = *reinterpret_cast<const float4*>(wr + o);
+#pragma unroll
+        for (int b = 0; b < DENSE_BT; ++b) {
+            if (b < nb) {
+                float gv[4];
+                ld4(gy + (long)(b0 + b) * out + o, gv);
+                acc[b] += gv[0] * wv.x + gv[1] * wv.y + gv[2] * wv.z + gv[3] * wv.w;
+            }
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < DENSE_BT; ++b) {
+        if (b < nb) {
+            const float sum = wave_sum(acc[b]);
+            if (lane == 0) DT<T>::st(gx + (long)(b0 + b) * in + i, sum * alpha);
+        }
+    }
+}
+
+// gw[i][o] (+)= alpha * sum_b x[b][i] gy[b][o], out % 256 == 0, b <= DENSE_BT: a thread keeps its 4 columns of gy for every
+// batch row in registers and walks DENSE_WR rows of the weight matrix (16-byte stores).
+constexpr int DENSE_WR = 16;
+template <typename T>
+__global__ __launch_bounds__(256) void dense_bwd_weight_fast_kernel(const T* __restrict__ x, const T* __restrict__ gy, float* __restrict__ gw,
+                                                                    int b, int in, int out, float alpha, int accumulate) {
+    __shared__ float xs[DENSE_BT][DENSE_WR];
+    const int tid = threadIdx.x;
+    const int ct = tid & 63, rl = tid >> 6;
+    const int col = blockIdx.x * 256 + ct * 4;
+    const int r0 = blockIdx.y * DENSE_WR;
+    for (int k = tid; k < b * DENSE_WR; k += 256) {
+        const int bb = k / DENSE_WR, rr = k % DENSE_WR;
+        xs[bb][rr] = r0 + rr < in ? DT<T>::ld(x + (long)bb * in + r0 + rr) * alpha : 0.f;
+    }
+    float g[DENSE_BT][4];
+#pragma unroll
+    for (int bb = 0; bb < DENSE_BT; ++bb) {
+        if (bb < b) ld4(gy + (long)bb * out + col, g[bb]);
+        else { g[bb][0] = g[bb][1] = g[bb][2] = g[bb][3] = 0.f; }
+    }
+    __syncthreads();
+    for (int rr = rl; rr < DENSE_WR && r0 + rr < in; rr += 4) {
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int bb = 0; bb < DENSE_BT; ++bb) {
+            if (bb < b) {
+                const float xv = xs[bb][rr];
+                o[0] += xv * g[bb][0]; o[1] += xv * g[bb][1]; o[2] += xv * g[bb][2]; o[3] += xv * g[bb][3];
+            }
+        }
+        float4* dst = reinterpret_cast<float4*>(gw + (long)(r0 + rr) * out + col);
+        if (accumulate) {
+            const float4 old = *dst;
+            o[0] += old.x; o[1] += old.y; o[2] += old.z; o[3] += old.w;
+        }
+        *dst = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+static bool dense_fwd_fast_ok(int in, int out) { return in % 4 == 0 && out % 32 == 0; }
 static void dense_split(int in, int out, int* ksplit, int* ipb) {
+    if (dense_fwd_fast_ok(in, out)) {   // (out/32) x ksplit blocks should cover the chip twice; a split handles >= 128 rows
+        const int tiles = out / 32;
+        int ks = (512 + tiles - 1) / tiles;
+        const int maxks = in / 128 > 0 ? in / 128 : 1;
+        if (ks > maxks) ks = maxks;
+        if (ks < 1) ks = 1;
+        int per = (in + ks - 1) / ks;
+        per = (per + 3) & ~3;
+        *ipb = per;
+        *ksplit = (in + per - 1) / per;
+        return;
+    }
     const int tiles = cdiv(out, 64);
     int ks = 1024 / tiles;
     if (ks < 1) ks = 1;
@@ -255,11 +406,18 @@ extern "C" int gs_dense_fwd(const void* x, const float* w, void* y, int b, int i
     if (ws_bytes < (size_t)ks * b * out * sizeof(float)) return fail(GS_ERR_WORKSPACE, "dense_fwd: workspace too small");
     hipStream_t st = as_stream(stream);
     float* part = (float*)ws;
+    const bool fast = dense_fwd_fast_ok(in, out);
     for (int b0 = 0; b0 < b; b0 += DENSE_BT) {
         const int nb = b - b0 < DENSE_BT ? b - b0 : DENSE_BT;
-        GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dense_fwd_kernel<T>), dim3(cdiv(out, 64), ks), dim3(256), 0, st, (const T*)x, w, part, b0, nb, in, out, b, ipb));
+        if (fast) {
+            GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dense_fwd_fast_kernel<T>), dim3(out / 32, ks), dim3(256), 0, st, (const T*)x, w,
+                                                        ks > 1 ? part : nullptr, (T*)y, b0, nb, in, out, b, ipb, alpha));
+        } else {
+            GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dense_fwd_kernel<T>), dim3(cdiv(out, 64), ks), dim3(256), 0, st, (const T*)x, w, part, b0, nb, in, out, b, ipb));
+        }
         GS_CHECK_LAUNCH();
     }
+    if (fast && ks == 1) return 0;
     const long n = (long)b * out;
     GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dense_finalize_kernel<T>), dim3(cdiv(n, 256)), dim3(256), 0, st, part, (T*)y, n, ks, alpha));
     GS_CHECK_LAUNCH();
@@ -271,7 +429,9 @@ extern "C" int gs_dense_bwd_data(const void* gy, const float* w, void* gx, int b
     hipStream_t st = as_stream(stream);
     for (int b0 = 0; b0 < b; b0 += DENSE_BT) {
         const int nb = b - b0 < DENSE_BT ? b - b0 : DENSE_BT;
-        if (out >= 2048) {
+        if (out % 256 == 0) {
+            GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dense_bwd_data_fast_kernel<T>), dim3(cdiv(in, 4)), dim3(256), 0, st, (const T*)gy, w, (T*)gx, b0, nb, in, out, alpha));
+        } else if (out >= 2048) {
             GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dense_bwd_data_wide_kernel<T>), dim3(in), dim3(256), 0, st, (const T*)gy, w, (T*)gx, b0, nb, in, out, alpha));
         } else {
             GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dense_bwd_data_kernel<T>), dim3(cdiv(in, 4)), dim3(256), 0, st, (const T*)gy, w, (T*)gx, b0, nb, in, out, alpha));
@@ -284,6 +444,12 @@ extern "C" int gs_dense_bwd_data(const void* gy, const float* w, void* gx, int b
 extern "C" int gs_dense_bwd_weight(const void* x, const void* gy, float* gw, int b, int in, int out, float alpha, int accumulate, int dtype, void* stream) {
     GS_CHECK_ARG(b > 0 && in > 0 && out > 0, "dense_bwd_weight: bad args");
     const long n = (long)in * out;
+    if (out % 256 == 0 && b <= DENSE_BT) {
+        GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dense_bwd_weight_fast_kernel<T>), dim3(out / 256, cdiv(in, DENSE_WR)), dim3(256), 0, as_stream(stream),
+                                                    (const T*)x, (const T*)gy, gw, b, in, out, alpha, accumulate));
+        GS_CHECK_LAUNCH();
+        return 0;
+    }
     GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dense_bwd_weight_kernel<T>), dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), (const T*)x, (const T*)gy, gw, b, in, out, alpha, accumulate));
     GS_CHECK_LAUNCH();
     return 0;
