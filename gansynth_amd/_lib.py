@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libgansynth_hip.so")
 
 GS_F32, GS_BF16 = 0, 1
 ACT_NONE, ACT_LRELU, ACT_TANH = 0, 1, 2
+PREP_CONV_FWD, PREP_CONV_BWD_DATA, PREP_CONVT_FWD, PREP_CONVT_BWD_DATA = 0, 1, 2, 3
 CONV_FWD, CONV_BWD_DATA, CONV_BWD_WEIGHT = 0, 1, 2
 
 P, I, F, L, Z = c_void_p, c_int, c_float, c_int64, c_size_t
@@ -56,6 +57,7 @@ SIGNATURES = {
     "gs_axpby": (I, [P, P, P, L, F, F, I, P]),
     "gs_sumsq_rows": (I, [P, P, I, L, I, P]),
     "gs_row_scale": (I, [P, P, P, I, L, I, P]),
+    "gs_weight_prep_batch": (I, [P, I, P]),
     "gs_adam_tf_step": (I, [P, P, P, P, L, F, F, F, F, F, P]),
     "gs_spectral_plan_create": (I, [POINTER(c_void_p), I, I, I, P, P]),
     "gs_spectral_plan_destroy": (I, [P]),

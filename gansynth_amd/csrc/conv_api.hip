@@ -286,6 +286,59 @@ static int run_direct(int mode, int ks, int variant, const void* x, const float*
                                                      N, Hi, Wi, ICk, OCk, Ho, Wo, alpha, st));
 }
 
+// ------------------------------------------------------------------ batched weight re-layout
+// which operand a map's entry point builds: (variant of weight_prep_kernel, fp32 storage for the direct kernels / T for MFMA)
+__device__ __host__ inline void prep_plan(int map, int ci, int co, int ksize, int dtype, int* variant, bool* store_f32) {
+    const int bk = dtype == GS_F32 ? 16 : 32;
+    bool mfma;
+    if (map == GS_PREP_CONV_FWD || map == GS_PREP_CONVT_FWD) {
+        *variant = 0;
+        mfma = ksize == 3 && ci % bk == 0 && co % 32 == 0;
+    } else if (map == GS_PREP_CONV_BWD_DATA) {   // stride 1: flipped taps; stride 2: transposed-conv walk (set by the caller)
+        *variant = 1;
+        mfma = ksize == 3 && co % bk == 0 && ci % 32 == 0;
+    } else {
+        *variant = 2;
+        mfma = co % bk == 0 && ci % 32 == 0;
+    }
+    *store_f32 = !mfma || dtype == GS_F32;
+}
+static __global__ __launch_bounds__(256) void weight_prep_batch_kernel(const GsPrepDesc* __restrict__ descs) {
+    const GsPrepDesc d = descs[blockIdx.y];
+    int variant;
+    bool f32;
+    prep_plan(d.map, d.ci, d.co, d.ksize, d.dtype, &variant, &f32);
+    if (d.map == GS_PREP_CONV_BWD_DATA && d.stride == 2) variant = 2;
+    const int taps = d.ksize * d.ksize, ci = d.ci, co = d.co;
+    const long total = (long)taps * ci * co;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        long dst;
+        float v;
+        if (variant == 0) {
+            const int c_i = idx % ci;
+            const int c_o = (idx / ci) % co;
+            const int t = idx / ((long)ci * co);
+            dst = idx;
+            v = d.w_hwio[((long)t * ci + c_i) * co + c_o];
+        } else {
+            const int t = idx / ((long)ci * co);
+            const long rem = idx % ((long)ci * co);
+            const int tt = variant == 1 ? taps - 1 - t : t;
+            dst = (long)tt * ci * co + rem;
+            v = d.w_hwio[idx];
+        }
+        if (f32) reinterpret_cast<float*>(d.ws)[dst] = v;
+        else reinterpret_cast<bf16_t*>(d.ws)[dst] = f32_to_bf16(v);
+    }
+}
+
+extern "C" int gs_weight_prep_batch(const GsPrepDesc* descs, int n, void* stream) {
+    GS_CHECK_ARG(descs != nullptr && n > 0 && n <= 65535, "weight_prep_batch: bad args");
+    hipLaunchKernelGGL(weight_prep_batch_kernel, dim3(64, n), dim3(256), 0, as_stream(stream), descs);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
 // ------------------------------------------------------------------ direct weight gradient
 // part[slice][t][ic][oc] = sum over the slice's output pixels of x[in(p,t)][ic] * gy[p][oc]
 template <typename T>

@@ -10,6 +10,7 @@ an emulation to check the autograd algebra on CPU, the product never does.
 """
 import ctypes
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -68,7 +69,7 @@ class HipKernels(object):
         _lib.check(self.lib.gs_init(), "gs_init")
         self._param_ranges = []   # (ptr, nbytes) of registered flat parameter buffers
         self._wcache = {}         # (weight ptr, map tag) -> (persistent workspace holding the re-laid operand, stamp)
-        self._epoch = 0           # bumped whenever parameter values change (Adam step, explicit invalidation)
+        self._prep_tables = {}    # tuple of cache keys -> device table of GsPrepDesc rows (refresh_weights)
 
     # --------------------------------------------------------- prepared-weight workspaces
     def register_param_buffer(self, flat):
@@ -82,9 +83,10 @@ class HipKernels(object):
             if ptr is None or rng[0] <= ptr < rng[0] + rng[1]:
                 rng[2] += 1
 
-    def _weight_ws(self, w, tag, nbytes):
+    def _weight_ws(self, w, tag, nbytes, plan=None):
         """-> (workspace, w_prepared).  A registered parameter gets one persistent workspace per conv map, reused
-        (w_prepared = 1) until the parameter values change; anything else gets a transient workspace."""
+        (w_prepared = 1) until the parameter values change; anything else gets a transient workspace.
+        `plan` = (GS_PREP_* map, ci, co, ksize, stride, dtype id) lets refresh_weights() rebuild the operand in a batch."""
         ptr = w.data_ptr()
         rng = next((r for r in self._param_ranges if r[0] <= ptr < r[0] + r[1]), None)
         if rng is None:
@@ -94,11 +96,35 @@ class HipKernels(object):
         if ent is not None and ent[0].numel() >= nbytes:
             if ent[1] == stamp:
                 return ent[0], 1
-            self._wcache[key] = (ent[0], stamp)
+            ent[1] = stamp
             return ent[0], 0
-        buf = _ws(nbytes, w.device)
-        self._wcache[key] = (buf, stamp)
-        return buf, 0
+        self._wcache[key] = [_ws(nbytes, w.device), stamp, w, plan, rng]
+        self._prep_tables.clear()
+        return self._wcache[key][0], 0
+
+    def refresh_weights(self, flat=None):
+        """Rebuild, in ONE launch, every stale prepared operand of the parameters living in `flat` (all registered
+        buffers when None) -- called after an optimizer step instead of letting each conv re-lay its weight."""
+        ptr = None if flat is None else flat.data_ptr()
+        stale = [k for k, e in self._wcache.items()
+                 if e[3] is not None and (ptr is None or e[4][0] <= ptr < e[4][0] + e[4][1]) and e[1] != (e[4][2], e[2]._version)]
+        if not stale:
+            return 0
+        tkey = tuple(stale)
+        table = self._prep_tables.get(tkey)
+        if table is None:
+            rows = np.zeros((len(stale), 5), dtype=np.int64)   # GsPrepDesc: 2 pointers + 6 int32 = 40 bytes
+            for i, k in enumerate(stale):
+                buf, _, w, plan, _ = self._wcache[k]
+                rows[i, 0], rows[i, 1] = w.data_ptr(), buf.data_ptr()
+                rows[i, 2:5] = np.array(plan, dtype=np.int32).view(np.int64)
+            table = torch.from_numpy(rows).to(self._wcache[stale[0]][0].device)
+            self._prep_tables[tkey] = table
+        _lib.check(self.lib.gs_weight_prep_batch(table.data_ptr(), len(stale), _stream()), "gs_weight_prep_batch")
+        for k in stale:
+            e = self._wcache[k]
+            e[1] = (e[4][2], e[2]._version)
+        return len(stale)
 
     # ------------------------------------------------------------------------------- conv
     def conv2d_fwd(self, x, w, ksize, stride, alpha):
@@ -110,7 +136,7 @@ class HipKernels(object):
         co = w.shape[3]
         y = _empty_like_act((n, co, h // stride, wd // stride), x)
         nb = self.lib.gs_conv2d_workspace_bytes(_lib.CONV_FWD, n, h, wd, ci, co, ksize, stride, _dt(x))
-        ws, prepared = self._weight_ws(w, ("fwd", ksize, stride, _dt(x)), nb)
+        ws, prepared = self._weight_ws(w, ("fwd", ksize, stride, _dt(x)), nb, (_lib.PREP_CONV_FWD, ci, co, ksize, stride, _dt(x)))
         bp = None
         if bias is not None:
             bias = _f32c(bias)
@@ -126,7 +152,7 @@ class HipKernels(object):
         co = w.shape[3]
         gx = _empty_like_act((n, ci, h, wd), gy)
         nb = self.lib.gs_conv2d_workspace_bytes(_lib.CONV_BWD_DATA, n, h, wd, ci, co, ksize, stride, _dt(gy))
-        ws, prepared = self._weight_ws(w, ("bwd_data", ksize, stride, _dt(gy)), nb)
+        ws, prepared = self._weight_ws(w, ("bwd_data", ksize, stride, _dt(gy)), nb, (_lib.PREP_CONV_BWD_DATA, ci, co, ksize, stride, _dt(gy)))
         _lib.check(self.lib.gs_conv2d_bwd_data(gy.data_ptr(), w.data_ptr(), gx.data_ptr(), n, h, wd, ci, co, ksize, stride,
                                                float(alpha), _dt(gy), prepared, ws.data_ptr(), ws.numel(), _stream()), "gs_conv2d_bwd_data")
         return gx
@@ -153,7 +179,7 @@ class HipKernels(object):
         co = w.shape[3]
         y = _empty_like_act((n, co, 2 * h, 2 * wd), x)
         nb = self.lib.gs_conv2d_transpose_s2_workspace_bytes(_lib.CONV_FWD, n, h, wd, ci, co, _dt(x))
-        ws, prepared = self._weight_ws(w, ("t_fwd", _dt(x)), nb)
+        ws, prepared = self._weight_ws(w, ("t_fwd", _dt(x)), nb, (_lib.PREP_CONVT_FWD, ci, co, 3, 2, _dt(x)))
         bp = None
         if bias is not None:
             bias = _f32c(bias)
@@ -170,7 +196,7 @@ class HipKernels(object):
         h, wd = h2 // 2, w2 // 2
         gx = _empty_like_act((n, ci, h, wd), gy)
         nb = self.lib.gs_conv2d_transpose_s2_workspace_bytes(_lib.CONV_BWD_DATA, n, h, wd, ci, co, _dt(gy))
-        ws, prepared = self._weight_ws(w, ("t_bwd_data", _dt(gy)), nb)
+        ws, prepared = self._weight_ws(w, ("t_bwd_data", _dt(gy)), nb, (_lib.PREP_CONVT_BWD_DATA, ci, co, 3, 2, _dt(gy)))
         _lib.check(self.lib.gs_conv2d_transpose_s2_bwd_data(gy.data_ptr(), w.data_ptr(), gx.data_ptr(), n, h, wd, ci, co, float(alpha),
                                                             _dt(gy), prepared, ws.data_ptr(), ws.numel(), _stream()), "gs_conv2d_transpose_s2_bwd_data")
         return gx
@@ -378,7 +404,8 @@ class HipKernels(object):
             assert t.dtype == torch.float32 and t.is_contiguous()
         _lib.check(self.lib.gs_adam_tf_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), float(lr_t), float(beta1),
                                             float(beta2), float(eps), float(grad_scale), _stream()), "gs_adam_tf_step")
-        self.invalidate_weights(p)  # parameter values changed: cached kernel operands of that buffer are stale
+        self.invalidate_weights(p)  # parameter values changed: cached kernel operands of that buffer are stale ...
+        self.refresh_weights(p)     # ... and are rebuilt here in one launch
 
     # --------------------------------------------------------------------------- profiling
     def prof_enable(self, on):

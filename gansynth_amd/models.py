@@ -201,11 +201,12 @@ class GANSynth(object):
             with torch.cuda.stream(side):  # one eager pass on a side stream (allocator / lazy-init warm-up)
                 self._forward_backward(which, *static)
             torch.cuda.current_stream().wait_stream(side)
-            K.invalidate_weights()  # every weight operand must be (re)built INSIDE the captured graph
+            # the prepared weight operands live in persistent workspaces that the optimizer step refreshes eagerly
+            # (kernels.adam_tf_step): bring them up to date now so that the captured graph holds no re-layout launches
+            K.refresh_weights()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 loss = self._forward_backward(which, *static)
-            K.invalidate_weights()
             entry = (graph, static, loss)
             self._graphs[which] = entry
         graph, static, loss = entry

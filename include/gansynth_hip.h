@@ -97,6 +97,19 @@ int gs_conv2d_transpose_s2_bwd_data(const void* gy, const float* w_hwio, void* g
 int gs_conv2d_transpose_s2_bwd_weight(const void* x, const void* gy, float* gw_hwio, int n, int h, int w, int ci, int co,
                                       float alpha, int accumulate, int dtype, void* ws, size_t ws_bytes, void* stream);
 
+/* Refreshing many prepared weight operands in one launch (after an optimizer step: ~60 conv maps, one kernel instead of
+ * one re-layout launch in front of each conv).  A descriptor names the fp32 HWIO master weight, the persistent workspace
+ * of one (weight, map) pair and the map: GS_PREP_* below, (ci, co, ksize, stride) of the variable, activation dtype.
+ * gs_weight_prep_batch writes exactly what the map's entry point would write with w_prepared = 0, so the next call of that
+ * entry point may pass w_prepared = 1.  `descs` lives in DEVICE memory (n descriptors). */
+enum { GS_PREP_CONV_FWD = 0, GS_PREP_CONV_BWD_DATA = 1, GS_PREP_CONVT_FWD = 2, GS_PREP_CONVT_BWD_DATA = 3 };
+typedef struct GsPrepDesc {
+    const float* w_hwio; /* master weight [k][k][ci][co] */
+    void* ws;            /* the map's workspace (operand at its start) */
+    int32_t map, ci, co, ksize, stride, dtype;
+} GsPrepDesc;
+int gs_weight_prep_batch(const GsPrepDesc* descs, int n, void* stream);
+
 /* -------------------------------------------------------------------------------- dense
  * tf.matmul (ops.py:197): y[b][out] = alpha * x[b][in] @ w[in][out] (split-K partials live in ws).
  * bwd_data: gx = alpha * gy @ w^T ; bwd_weight: gw = alpha * x^T @ gy (fp32). */
