@@ -738,6 +738,135 @@ __global__ __launch_bounds__(192) void conv_wgrad_bf16_kernel(
     }
 }
 
+// 64 x 64 (input x output channel) tiles per block for layers with >= 64 channels on both sides: the four 32 x 32 pairs of
+// the tile share ONE staged copy of the input patch and of the gradient tile (a 32 x 32 block re-stages the patch for every
+// output tile and the gradients for every input tile: twice the L2 -> LDS stream per MFMA, and that stream is what bounds the
+// kernel).  Block = 256 threads = 4 waves, wave w owns the pair (input tile w >> 1, output tile w & 1) for all 9 taps
+// (144 fp32 accumulators); operands sit in LDS as two 32-channel planes per side so that the transposing reads keep their
+// conflict-free 64-byte rows.
+template <int MODE, int TW>
+__global__ __launch_bounds__(256) void conv_wgrad_bf16_2x2_kernel(
+    const bf16_t* __restrict__ x, const bf16_t* __restrict__ gy, float* __restrict__ part,
+    int N, int Hi, int Wi, int IC, int OC, int Hb, int Wb, int tiles_x, int tiles_y, int ntiles, int nslices) {
+    constexpr bool S2 = MODE == MODE_S2;
+    constexpr int NP = S2 ? 64 : 256;   // stride 2: the patch is 4-5x the tile, 64 output pixels keep two staged tiles in LDS
+    constexpr int TH = NP / TW;
+    constexpr int PH = patch_dim<MODE>(TH), PW = patch_dim<MODE>(TW);
+    constexpr int S = S2 ? 2 : 1;
+    constexpr int XRG = (PH * PW + 15) / 16;          // 16-row groups (= 1 KiB LDS-DMA pieces) of a patch plane
+    constexpr int GRG = NP / 16;
+    constexpr int XK = (XRG + 3) / 4, GK = GRG / 4;   // row groups per wave (every wave issues the same number of pieces)
+    constexpr int XPL = XK * 4096, GPL = NP * 64;     // bytes of one 32-channel plane
+    constexpr int BUF = 2 * XPL + 2 * GPL;            // one staged tile; two of them: the DMA of tile t+1 runs under the MFMAs of tile t
+    constexpr int NPIECE = 2 * XK + 2 * GK;           // DMA pieces a wave issues per tile
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const unsigned a_base = (unsigned)(uintptr_t)lds_raw;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_ict = IC / 64;
+    const int ic0 = (blockIdx.x % n_ict) * 64, oc0 = (blockIdx.x / n_ict) * 64;
+    const int it = wv >> 1, ot = wv & 1;
+    const int slice = blockIdx.y;
+    const int t_row = (lane & 15) >> 2;
+    const int t_col = (((lane >> 4) & 1) * 16 + (lane & 3) * 4) * 2;
+
+    // staging = LDS-DMA (no registers, see the implicit-GEMM kernel): a piece is 16 rows x 64 bytes of one channel plane; rows
+    // above / below the image fall outside the per-image descriptor (zero fill), columns outside are forced out of range.
+    int x_voff[XK], x_lx[XK];
+#pragma unroll
+    for (int k = 0; k < XK; ++k) {
+        const int row = (wv + 4 * k) * 16 + (lane >> 2);
+        const int ly = row / PW, lx = row - ly * PW;
+        x_voff[k] = ((ly * Wi + lx) * IC) * 2 + (lane & 3) * 16;
+        x_lx[k] = row < PH * PW ? lx : 0x40000000;
+    }
+    const unsigned ximg = (unsigned)Hi * Wi * IC * 2, gimg = (unsigned)Hb * Wb * OC * 2;
+
+    auto issue_tile = [&](int tile, int buf) __attribute__((always_inline)) {
+        int b = tile;
+        const int tile_x = b % tiles_x;
+        b /= tiles_x;
+        const int tile_y = b % tiles_y;
+        const int n = b / tiles_y;
+        const int by = tile_y * TH, bx = tile_x * TW;
+        const int oy0 = S2 ? 2 * by : by - 1;
+        const int ox0 = S2 ? 2 * bx : bx - 1;
+        const i32x4 rs_x = make_rsrc(reinterpret_cast<const unsigned char*>(x) + (size_t)n * ximg, ximg);
+        const i32x4 rs_g = make_rsrc(reinterpret_cast<const unsigned char*>(gy) + (size_t)n * gimg, gimg);
+        const int xorg = ((oy0 * Wi + ox0) * IC + ic0) * 2;
+        const unsigned a_x = a_base + buf * BUF, a_g = a_x + 2 * XPL;
+#pragma unroll
+        for (int k = 0; k < XK; ++k) {
+            const unsigned v = (unsigned)(ox0 + x_lx[k]) < (unsigned)Wi ? (unsigned)(xorg + x_voff[k]) : 0x80000000u;
+            lds_dma16(a_x + (wv + 4 * k) * 1024, v, rs_x);
+            lds_dma16(a_x + XPL + (wv + 4 * k) * 1024, v == 0x80000000u ? v : v + 64, rs_x);
+        }
+#pragma unroll
+        for (int k = 0; k < GK; ++k) {
+            const int pix = (wv + 4 * k) * 16 + (lane >> 2);
+            const int gy_ = by + pix / TW, gx_ = bx + pix % TW;
+            const unsigned v = gy_ < Hb && gx_ < Wb ? (unsigned)(((gy_ * Wb + gx_) * OC + oc0) * 2 + (lane & 3) * 16) : 0x80000000u;
+            lds_dma16(a_g + (wv + 4 * k) * 1024, v, rs_g);
+            lds_dma16(a_g + GPL + (wv + 4 * k) * 1024, v == 0x80000000u ? v : v + 64, rs_g);
+        }
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    int buf = 0;
+    if (slice < ntiles) issue_tile(slice, 0);
+    for (int tile = slice; tile < ntiles; tile += nslices) {
+        const bool more = tile + nslices < ntiles;
+        if (more) {
+            issue_tile(tile + nslices, buf ^ 1);
+            wait_vmcnt(NPIECE);   // this tile has landed; the next one stays in flight
+        } else {
+            wait_vmcnt(0);
+        }
+        block_barrier();
+        const unsigned char* const xpl = lds_raw + buf * BUF + it * XPL;
+        const unsigned char* const gpl = lds_raw + buf * BUF + 2 * XPL + ot * GPL;
+#pragma unroll 1
+        for (int g = 0; g < NP / 16; ++g) {
+            const int ty = (g * 16) / TW, tx0 = (g * 16) % TW + 8 * hi;
+            const unsigned char* gp = gpl + (ty * TW + tx0 + t_row) * 64 + t_col;
+            const uint2 b0 = lds_tr16(gp), b1 = lds_tr16(gp + 4 * 64);
+            const bf16x8 bfrag = mk_frag(b0.x, b0.y, b1.x, b1.y);
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const unsigned char* xp = xpl + (((ty * S + ky) * PW + tx0 * S) + t_row * S) * 64 + t_col;
+                if (!S2) {
+                    const uint2 d0 = lds_tr16(xp), d1 = lds_tr16(xp + 4 * 64), d2 = lds_tr16(xp + 8 * 64);
+                    acc[ky * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk_frag(d0.x, d0.y, d1.x, d1.y), bfrag, acc[ky * 3 + 0], 0, 0, 0);
+                    acc[ky * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk_frag(shr16(d0.y, d0.x), shr16(d1.x, d0.y), shr16(d1.y, d1.x), shr16(d2.x, d1.y)), bfrag, acc[ky * 3 + 1], 0, 0, 0);
+                    acc[ky * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk_frag(d0.y, d1.x, d1.y, d2.x), bfrag, acc[ky * 3 + 2], 0, 0, 0);
+                } else {
+                    const uint2 e0 = lds_tr16(xp), e1 = lds_tr16(xp + 8 * 64), e2 = lds_tr16(xp + 16 * 64);
+                    const uint2 o0 = lds_tr16(xp + 64), o1 = lds_tr16(xp + 9 * 64);
+                    acc[ky * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk_frag(e0.x, e0.y, e1.x, e1.y), bfrag, acc[ky * 3 + 0], 0, 0, 0);
+                    acc[ky * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk_frag(o0.x, o0.y, o1.x, o1.y), bfrag, acc[ky * 3 + 1], 0, 0, 0);
+                    acc[ky * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk_frag(shr16(e0.y, e0.x), shr16(e1.x, e0.y), shr16(e1.y, e1.x), shr16(e2.x, e1.y)), bfrag, acc[ky * 3 + 2], 0, 0, 0);
+                }
+            }
+        }
+        block_barrier();  // every wave is done with this buffer: the next iteration may overwrite it
+        buf ^= 1;
+    }
+    // ---- D[ic i][oc j], lane = (j = l31, i = (r&3) + 8(r>>2) + 4hi)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        float* dst = part + (((long)slice * 9 + t) * IC + ic0 + it * 32) * OC + oc0 + ot * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[(long)((r & 3) + 8 * (r >> 2) + 4 * hi) * OC] = acc[t][r];
+    }
+}
+
 // ------------------------------------------------------------------------------ dispatch
 
 static int g_num_cus = 0;
@@ -869,16 +998,20 @@ int run_igemm(int mode, int variant, const void* x, const float* w_hwio, void* y
 }
 
 // ---- weight gradient (fp32 MFMA path)
+static bool wgrad_2x2(int mode, int dtype, int IC, int OC) { (void)mode; return dtype == GS_BF16 && IC % 64 == 0 && OC % 64 == 0; }
 static void wgrad_geometry(int mode, int dtype, int N, int Hb, int Wb, int IC, int OC, int* tw, int* tiles_x, int* tiles_y,
                            int* ntiles, int* nslices) {
-    const int np = (mode == MODE_S2 ? 64 : 128) * (dtype == GS_BF16 ? 2 : 1);
+    int np = (mode == MODE_S2 ? 64 : 128) * (dtype == GS_BF16 ? 2 : 1);
+    if (mode == MODE_S2 && wgrad_2x2(mode, dtype, IC, OC)) np = 64;
     *tw = Wb >= 32 ? 32 : 16;
     const int th = np / *tw;
     *tiles_x = cdiv(Wb, *tw);
     *tiles_y = cdiv(Hb, th);
     *ntiles = N * *tiles_x * *tiles_y;
-    const int pairs = (IC / 32) * (OC / 32);
-    int ns = (dtype == GS_BF16 ? 768 : 512) / pairs;
+    int pairs = (IC / 32) * (OC / 32);
+    int target = dtype == GS_BF16 ? 768 : 512;
+    if (wgrad_2x2(mode, dtype, IC, OC)) { pairs /= 4; target = 256; }   // 64 x 64 tiles, double-buffered: one block of 4 waves per CU
+    int ns = target / pairs;
     if (ns < 1) ns = 1;
     if (ns > *ntiles) ns = *ntiles;
     *nslices = ns;
@@ -914,8 +1047,28 @@ int run_wgrad_mfma(int mode, const void* x, const void* gy, float* gw, int N, in
 #define GS_WGB(M, TWV)                                                                                                  \
     hipLaunchKernelGGL((conv_wgrad_bf16_kernel<M, TWV>), grid, dim3(192), 0, st, reinterpret_cast<const bf16_t*>(x),    \
                        reinterpret_cast<const bf16_t*>(gy), part, N, Hi, Wi, IC, OC, Hb, Wb, tiles_x, tiles_y, ntiles, nslices)
-            if (mode == MODE_S1) { if (tw == 32) GS_WGB(MODE_S1, 32); else GS_WGB(MODE_S1, 16); }
-            else { if (tw == 32) GS_WGB(MODE_S2, 32); else GS_WGB(MODE_S2, 16); }
+#define GS_WGB2(M, TWV)                                                                                                 \
+    do {                                                                                                                \
+        constexpr int np_ = (M == MODE_S2 ? 64 : 256), th_ = np_ / TWV;                                                 \
+        constexpr int lds_ = 2 * (2 * ((((patch_dim<M>(th_) * patch_dim<M>(TWV) + 15) / 16 + 3) / 4) * 4096 + np_ * 64));  \
+        auto kern_ = conv_wgrad_bf16_2x2_kernel<M, TWV>;                                                                \
+        static bool set_ = false;                                                                                       \
+        if (!set_) {                                                                                                    \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern_), hipFuncAttributeMaxDynamicSharedMemorySize, lds_) != hipSuccess) \
+                return fail(GS_ERR_HIP, "conv wgrad: cannot reserve %d bytes of dynamic LDS", lds_);                    \
+            set_ = true;                                                                                                \
+        }                                                                                                               \
+        hipLaunchKernelGGL(kern_, dim3((IC / 64) * (OC / 64), nslices), dim3(256), lds_, st, reinterpret_cast<const bf16_t*>(x), \
+                           reinterpret_cast<const bf16_t*>(gy), part, N, Hi, Wi, IC, OC, Hb, Wb, tiles_x, tiles_y, ntiles, nslices); \
+    } while (0)
+            if (wgrad_2x2(mode, dtype, IC, OC)) {
+                if (mode == MODE_S1) { if (tw == 32) GS_WGB2(MODE_S1, 32); else GS_WGB2(MODE_S1, 16); }
+                else { if (tw == 32) GS_WGB2(MODE_S2, 32); else GS_WGB2(MODE_S2, 16); }
+            } else {
+                if (mode == MODE_S1) { if (tw == 32) GS_WGB(MODE_S1, 32); else GS_WGB(MODE_S1, 16); }
+                else { if (tw == 32) GS_WGB(MODE_S2, 32); else GS_WGB(MODE_S2, 16); }
+            }
+#undef GS_WGB2
 #undef GS_WGB
         }
 #undef GS_WG_ALL
