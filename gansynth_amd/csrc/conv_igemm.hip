@@ -475,8 +475,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
                                     o[0] += bv.x; o[1] += bv.y; o[2] += bv.z; o[3] += bv.w;
 #pragma unroll
                                     for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], slope * o[e]);  // leaky relu (slope 1: identity)
-                                    st4(reinterpret_cast<T*>(sw + l31 * RB) + qd * 8 + hi * 4, o);
+                                    if constexpr (A == 1) {   // 64-byte pixel rows: the detour does not pay, each lane stores its 8 / 16 bytes
+                                        const int q = (wv * B + b) * 32 + l31;
+                                        const int gy = by + q / TW, gx = bx + q % TW;
+                                        if (gy < Hb && gx < Wb) {
+                                            const int oy = MODE == MODE_T2 ? 2 * gy + (ph >> 1) : gy;
+                                            const int ox = MODE == MODE_T2 ? 2 * gx + (ph & 1) : gx;
+                                            st4(y + (((long)n * Ho + oy) * Wo + ox) * OC + oc0 + a * 32 + qd * 8 + hi * 4, o);
+                                        }
+                                    } else {
+                                        st4(reinterpret_cast<T*>(sw + l31 * RB) + qd * 8 + hi * 4, o);
+                                    }
                                 }
+                                if constexpr (A > 1) {
 #pragma unroll
                                 for (int it = 0; it < 32 / RPI; ++it) {
                                     const int row = it * RPI + r_row;
@@ -493,6 +504,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
                                         T* yp = y + (((long)n * Ho + oy) * Wo + ox) * OC + oc0 + a * 32 + r_seg * (16 / SZ);
                                         *reinterpret_cast<uint4*>(yp) = v;
                                     }
+                                }
                                 }
                             }
                         }
