@@ -14,7 +14,8 @@ int run_igemm(int mode, int variant, const void* x, const float* w_hwio, void* y
               int OCk, int w_ci, int w_co, int Hb, int Wb, float alpha, const float* bias, int act, int dtype, int w_prepared,
               void* ws, size_t ws_bytes, hipStream_t st);
 size_t wgrad_mfma_bytes(int mode, int dtype, int N, int Hb, int Wb, int IC, int OC);
-int run_wgrad_mfma(int mode, const void* x, const void* gy, float* gw, int N, int Hi, int Wi, int IC, int OC, int Hb,
+bool wgrad_mfma_has_bias(int dtype);
+int run_wgrad_mfma(int mode, const void* x, const void* gy, float* gw, float* gb, int N, int Hi, int Wi, int IC, int OC, int Hb,
                    int Wb, float alpha, int transpose, int accumulate, int dtype, void* ws, size_t ws_bytes, hipStream_t st);
 
 // ------------------------------------------------------------------------- direct gather conv
@@ -471,7 +472,7 @@ static int run_wgrad_direct(int mode, int ks, const void* x, const void* gy, flo
                                                         reinterpret_cast<const T*>(x), reinterpret_cast<const T*>(gy), tpart, C, npix, pps));
         }
         GS_CHECK_LAUNCH();
-        wgrad_reduce_launch(tpart, gw, (int)ns, 1, IC, OC, alpha, transpose, accumulate, st);
+        wgrad_reduce_launch(tpart, gw, nullptr, (int)ns, 1, IC, OC, alpha, transpose, accumulate, st);
         GS_CHECK_LAUNCH();
         return 0;
     }
@@ -483,7 +484,7 @@ static int run_wgrad_direct(int mode, int ks, const void* x, const void* gy, flo
                                                 reinterpret_cast<const T*>(x), reinterpret_cast<const T*>(gy), part, mode,
                                                 ks, N, Hi, Wi, IC, OC, Hb, Wb, E, npix, pps));
     GS_CHECK_LAUNCH();
-    wgrad_reduce_launch(part, gw, (int)ns, ks * ks, IC, OC, alpha, transpose, accumulate, st);
+    wgrad_reduce_launch(part, gw, nullptr, (int)ns, ks * ks, IC, OC, alpha, transpose, accumulate, st);
     GS_CHECK_LAUNCH();
     return 0;
 }
@@ -504,8 +505,11 @@ using namespace gs;
 extern "C" size_t gs_conv2d_workspace_bytes(int which, int n, int h, int w, int ci, int co, int ksize, int stride, int dtype) {
     const int hb = h / stride, wb = w / stride;
     if (which == GS_CONV_BWD_WEIGHT) {
-        if (ksize == 3 && wgrad_mfma_supported(ci, co, dtype)) return wgrad_mfma_bytes(stride == 2 ? MODE_S2 : MODE_S1, dtype, n, hb, wb, ci, co);
-        return wgrad_direct_bytes(ksize, n, hb, wb, ci, co);
+        const size_t cs = align256(gs_channel_sum_workspace_bytes((int64_t)n * hb * wb, co));  // bias-gradient fallback of gs_conv2d_bwd_weight_bias
+        size_t wg;
+        if (ksize == 3 && wgrad_mfma_supported(ci, co, dtype)) wg = wgrad_mfma_bytes(stride == 2 ? MODE_S2 : MODE_S1, dtype, n, hb, wb, ci, co);
+        else wg = wgrad_direct_bytes(ksize, n, hb, wb, ci, co);
+        return wg > cs ? wg : cs;
     }
     return align256((size_t)ksize * ksize * ci * co * 4);
 }
@@ -556,15 +560,28 @@ extern "C" int gs_conv2d_bwd_data(const void* gy, const float* w_hwio, void* gx,
     return run_direct(MODE_T2, 3, 2, gy, w_hwio, gx, n, hb, wb, co, ci, ci, co, h, w, alpha, dtype, w_prepared, ws, ws_bytes, st);
 }
 
-extern "C" int gs_conv2d_bwd_weight(const void* x, const void* gy, float* gw_hwio, int n, int h, int w, int ci, int co,
-                                    int ksize, int stride, float alpha, int accumulate, int dtype, void* ws, size_t ws_bytes, void* stream) {
+extern "C" size_t gs_channel_sum_workspace_bytes(int64_t p, int c);
+extern "C" int gs_channel_sum(const void* g, float* out, int64_t p, int c, int accumulate, int dtype, void* ws, size_t ws_bytes, void* stream);
+
+extern "C" int gs_conv2d_bwd_weight_bias(const void* x, const void* gy, float* gw_hwio, float* gb, int n, int h, int w, int ci, int co,
+                                         int ksize, int stride, float alpha, int accumulate, int dtype, void* ws, size_t ws_bytes, void* stream) {
     if (int e = check_conv_args(n, h, w, ci, co, ksize, stride, dtype)) return e;
     hipStream_t st = as_stream(stream);
     const int hb = h / stride, wb = w / stride;
     const int mode = stride == 2 ? MODE_S2 : MODE_S1;
-    if (ksize == 3 && wgrad_mfma_supported(ci, co, dtype))
-        return run_wgrad_mfma(mode, x, gy, gw_hwio, n, h, w, ci, co, hb, wb, alpha, 0, accumulate, dtype, ws, ws_bytes, st);
-    return run_wgrad_direct(mode, ksize, x, gy, gw_hwio, n, h, w, ci, co, hb, wb, alpha, 0, accumulate, dtype, ws, ws_bytes, st);
+    const bool mfma = ksize == 3 && wgrad_mfma_supported(ci, co, dtype);
+    const bool fused_bias = gb && mfma && wgrad_mfma_has_bias(dtype);
+    int rc;
+    if (mfma) rc = run_wgrad_mfma(mode, x, gy, gw_hwio, fused_bias ? gb : nullptr, n, h, w, ci, co, hb, wb, alpha, 0, accumulate, dtype, ws, ws_bytes, st);
+    else rc = run_wgrad_direct(mode, ksize, x, gy, gw_hwio, n, h, w, ci, co, hb, wb, alpha, 0, accumulate, dtype, ws, ws_bytes, st);
+    if (rc || !gb || fused_bias) return rc;
+    // shapes without the fused path: the plain channel sum (stream-ordered after the kernels above, same workspace)
+    return gs_channel_sum(gy, gb, (int64_t)n * hb * wb, co, accumulate, dtype, ws, ws_bytes, stream);
+}
+
+extern "C" int gs_conv2d_bwd_weight(const void* x, const void* gy, float* gw_hwio, int n, int h, int w, int ci, int co,
+                                    int ksize, int stride, float alpha, int accumulate, int dtype, void* ws, size_t ws_bytes, void* stream) {
+    return gs_conv2d_bwd_weight_bias(x, gy, gw_hwio, nullptr, n, h, w, ci, co, ksize, stride, alpha, accumulate, dtype, ws, ws_bytes, stream);
 }
 
 // ---- conv2d_transpose 3x3 stride 2: re-labelings of the stride-2 maps (see include/gansynth_hip.h)
@@ -617,6 +634,6 @@ extern "C" int gs_conv2d_transpose_s2_bwd_weight(const void* x, const void* gy, 
     hipStream_t st = as_stream(stream);
     // gw[k][ci][co] = sum x[i][ci] * gy[2i+k][co]: stride-2 wgrad with (input side = gy, output side = x), transposed
     if (wgrad_mfma_supported(co, ci, dtype))
-        return run_wgrad_mfma(MODE_S2, gy, x, gw_hwio, n, 2 * h, 2 * w, co, ci, h, w, alpha, 1, accumulate, dtype, ws, ws_bytes, st);
+        return run_wgrad_mfma(MODE_S2, gy, x, gw_hwio, nullptr, n, 2 * h, 2 * w, co, ci, h, w, alpha, 1, accumulate, dtype, ws, ws_bytes, st);
     return run_wgrad_direct(MODE_S2, 3, gy, x, gw_hwio, n, 2 * h, 2 * w, co, ci, h, w, alpha, 1, accumulate, dtype, ws, ws_bytes, st);
 }

@@ -646,10 +646,15 @@ __device__ inline uint2 lds_tr16(const unsigned char* p) {
     return __builtin_bit_cast(uint2, v);
 }
 
+// acc += a.lo + a.hi for a packed bf16 pair (v_dot2c_f32_bf16 against (1, 1); hipcc has no builtin for it on gfx950)
+__device__ inline void add_bf16_pair(float& acc, unsigned int a) {
+    asm volatile("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(acc) : "v"(a), "v"(0x3F803F80u));
+}
+
 template <int MODE, int TW>
 __global__ __launch_bounds__(192) void conv_wgrad_bf16_kernel(
     const bf16_t* __restrict__ x, const bf16_t* __restrict__ gy, float* __restrict__ part,
-    int N, int Hi, int Wi, int IC, int OC, int Hb, int Wb, int tiles_x, int tiles_y, int ntiles, int nslices) {
+    int N, int Hi, int Wi, int IC, int OC, int Hb, int Wb, int tiles_x, int tiles_y, int ntiles, int nslices, int with_bias) {
     constexpr bool S2 = MODE == MODE_S2;
     constexpr int NP = S2 ? 128 : 256;
     constexpr int TH = NP / TW;
@@ -675,6 +680,10 @@ __global__ __launch_bounds__(192) void conv_wgrad_bf16_kernel(
     for (int t = 0; t < 3; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    // bias gradient = sum over pixels of gy: the gradient fragment of a lane is 8 pixels of its output channel, four packed
+    // dot-2 adds per pixel group fold them into one register; done by the first wave of the blocks of input-channel tile 0
+    const bool do_bias = with_bias && wv == 0 && ic0 == 0;
+    float accb = 0.f;
 
     for (int tile = slice; tile < ntiles; tile += nslices) {
         int b = tile;
@@ -725,6 +734,7 @@ __global__ __launch_bounds__(192) void conv_wgrad_bf16_kernel(
             const unsigned char* gp = lg_ + (ty * TW + tx0 + t_row) * 64 + t_col;
             const uint2 b0 = lds_tr16(gp), b1 = lds_tr16(gp + 4 * 64);
             const bf16x8 bfrag = mk_frag(b0.x, b0.y, b1.x, b1.y);
+            if (do_bias) { add_bf16_pair(accb, b0.x); add_bf16_pair(accb, b0.y); add_bf16_pair(accb, b1.x); add_bf16_pair(accb, b1.y); }
             const unsigned char* xp = lx_ + (((ty * S + wv) * PW + tx0 * S) + t_row * S) * 64 + t_col;
             if (!S2) {
                 const uint2 d0 = lds_tr16(xp), d1 = lds_tr16(xp + 4 * 64), d2 = lds_tr16(xp + 8 * 64);
@@ -742,9 +752,14 @@ __global__ __launch_bounds__(192) void conv_wgrad_bf16_kernel(
         }
     }
     // ---- each wave owns its 3 taps: D[ic i][oc j], lane = (j = l31, i = (r&3) + 8(r>>2) + 4hi)
+    const long pstride = 9L * IC * OC + (with_bias ? OC : 0);   // fp32 elements per slice: 9 taps (+ the bias row)
+    if (do_bias) {   // the two lane halves hold different pixels of the same channel
+        const float tot = accb + __shfl_xor(accb, 32, 64);
+        if (hi == 0) part[(long)slice * pstride + 9L * IC * OC + oc0 + l31] = tot;
+    }
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
-        float* dst = part + (((long)slice * 9 + wv * 3 + kx) * IC + ic0) * OC + oc0 + l31;
+        float* dst = part + (long)slice * pstride + (((long)wv * 3 + kx) * IC + ic0) * OC + oc0 + l31;
 #pragma unroll
         for (int r = 0; r < 16; ++r) dst[(long)((r & 3) + 8 * (r >> 2) + 4 * hi) * OC] = acc[kx][r];
     }
@@ -759,7 +774,7 @@ __global__ __launch_bounds__(192) void conv_wgrad_bf16_kernel(
 template <int MODE, int TW>
 __global__ __launch_bounds__(256) void conv_wgrad_bf16_2x2_kernel(
     const bf16_t* __restrict__ x, const bf16_t* __restrict__ gy, float* __restrict__ part,
-    int N, int Hi, int Wi, int IC, int OC, int Hb, int Wb, int tiles_x, int tiles_y, int ntiles, int nslices) {
+    int N, int Hi, int Wi, int IC, int OC, int Hb, int Wb, int tiles_x, int tiles_y, int ntiles, int nslices, int with_bias) {
     constexpr bool S2 = MODE == MODE_S2;
     constexpr int NP = S2 ? 64 : 256;   // stride 2: the patch is 4-5x the tile, 64 output pixels keep two staged tiles in LDS
     constexpr int TH = NP / TW;
@@ -830,6 +845,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_2x2_kernel(
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    // bias gradient (see conv_wgrad_bf16_kernel): the two waves of input tile 0 in the blocks of input-channel tile 0
+    const bool do_bias = with_bias && it == 0 && ic0 == 0;
+    float accb = 0.f;
 
     int buf = 0;
     if (slice < ntiles) issue_tile(slice, 0);
@@ -850,6 +868,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_2x2_kernel(
             const unsigned char* gp = gpl + (ty * TW + tx0 + t_row) * 64 + t_col;
             const uint2 b0 = lds_tr16(gp), b1 = lds_tr16(gp + 4 * 64);
             const bf16x8 bfrag = mk_frag(b0.x, b0.y, b1.x, b1.y);
+            if (do_bias) { add_bf16_pair(accb, b0.x); add_bf16_pair(accb, b0.y); add_bf16_pair(accb, b1.x); add_bf16_pair(accb, b1.y); }
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
                 const unsigned char* xp = xpl + (((ty * S + ky) * PW + tx0 * S) + t_row * S) * 64 + t_col;
@@ -871,9 +890,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_2x2_kernel(
         buf ^= 1;
     }
     // ---- D[ic i][oc j], lane = (j = l31, i = (r&3) + 8(r>>2) + 4hi)
+    const long pstride = 9L * IC * OC + (with_bias ? OC : 0);
+    if (do_bias) {
+        const float tot = accb + __shfl_xor(accb, 32, 64);
+        if (hi == 0) part[(long)slice * pstride + 9L * IC * OC + oc0 + ot * 32 + l31] = tot;
+    }
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-        float* dst = part + (((long)slice * 9 + t) * IC + ic0 + it * 32) * OC + oc0 + ot * 32 + l31;
+        float* dst = part + (long)slice * pstride + ((long)t * IC + ic0 + it * 32) * OC + oc0 + ot * 32 + l31;
 #pragma unroll
         for (int r = 0; r < 16; ++r) dst[(long)((r & 3) + 8 * (r >> 2) + 4 * hi) * OC] = acc[t][r];
     }
@@ -1029,18 +1053,22 @@ static void wgrad_geometry(int mode, int dtype, int N, int Hb, int Wb, int IC, i
     *nslices = ns;
 }
 
+bool wgrad_mfma_has_bias(int dtype) { return dtype == GS_BF16; }   // the bf16 kernels produce the bias gradient on the side
 size_t wgrad_mfma_bytes(int mode, int dtype, int N, int Hb, int Wb, int IC, int OC) {
     int tw, tx, ty, nt, ns;
     wgrad_geometry(mode, dtype, N, Hb, Wb, IC, OC, &tw, &tx, &ty, &nt, &ns);
-    return align256(((size_t)ns * 9 * IC * OC + wgrad_reduce_extra(ns, 9L * IC * OC)) * sizeof(float));
+    return align256((size_t)ns * (9 * (size_t)IC * OC + OC) * sizeof(float));
 }
 
 // x: conv input side [N][Hi][Wi][IC]; gy: [N][Hb][Wb][OC]; gw[9][IC][OC] (or transposed)
-int run_wgrad_mfma(int mode, const void* x, const void* gy, float* gw, int N, int Hi, int Wi, int IC, int OC, int Hb,
+// gb (optional, bf16 only): bias gradient sum_pixels gy[.][oc], produced by the same two launches
+int run_wgrad_mfma(int mode, const void* x, const void* gy, float* gw, float* gb, int N, int Hi, int Wi, int IC, int OC, int Hb,
                    int Wb, float alpha, int transpose, int accumulate, int dtype, void* ws, size_t ws_bytes, hipStream_t st) {
     int tw, tiles_x, tiles_y, ntiles, nslices;
     wgrad_geometry(mode, dtype, N, Hb, Wb, IC, OC, &tw, &tiles_x, &tiles_y, &ntiles, &nslices);
-    const size_t need = ((size_t)nslices * 9 * IC * OC + wgrad_reduce_extra(nslices, 9L * IC * OC)) * sizeof(float);
+    if (gb && !wgrad_mfma_has_bias(dtype)) return fail(GS_ERR_UNSUPPORTED, "conv wgrad: fused bias gradient needs the bf16 kernels");
+    const int with_bias = gb != nullptr;
+    const size_t need = (size_t)nslices * (9 * (size_t)IC * OC + (with_bias ? OC : 0)) * sizeof(float);
     if (ws_bytes < need) return fail(GS_ERR_WORKSPACE, "conv wgrad: workspace %zu < %zu", ws_bytes, need);
     float* part = reinterpret_cast<float*>(ws);
     dim3 grid((IC / 32) * (OC / 32), nslices);
@@ -1058,7 +1086,7 @@ int run_wgrad_mfma(int mode, const void* x, const void* gy, float* gw, int N, in
         } else {
 #define GS_WGB(M, TWV)                                                                                                  \
     hipLaunchKernelGGL((conv_wgrad_bf16_kernel<M, TWV>), grid, dim3(192), 0, st, reinterpret_cast<const bf16_t*>(x),    \
-                       reinterpret_cast<const bf16_t*>(gy), part, N, Hi, Wi, IC, OC, Hb, Wb, tiles_x, tiles_y, ntiles, nslices)
+                       reinterpret_cast<const bf16_t*>(gy), part, N, Hi, Wi, IC, OC, Hb, Wb, tiles_x, tiles_y, ntiles, nslices, with_bias)
 #define GS_WGB2(M, TWV)                                                                                                 \
     do {                                                                                                                \
         constexpr int np_ = (M == MODE_S2 ? 64 : 256), th_ = np_ / TWV;                                                 \
@@ -1071,7 +1099,7 @@ int run_wgrad_mfma(int mode, const void* x, const void* gy, float* gw, int N, in
             set_ = true;                                                                                                \
         }                                                                                                               \
         hipLaunchKernelGGL(kern_, dim3((IC / 64) * (OC / 64), nslices), dim3(256), lds_, st, reinterpret_cast<const bf16_t*>(x), \
-                           reinterpret_cast<const bf16_t*>(gy), part, N, Hi, Wi, IC, OC, Hb, Wb, tiles_x, tiles_y, ntiles, nslices); \
+                           reinterpret_cast<const bf16_t*>(gy), part, N, Hi, Wi, IC, OC, Hb, Wb, tiles_x, tiles_y, ntiles, nslices, with_bias); \
     } while (0)
             if (wgrad_2x2(mode, dtype, IC, OC)) {
                 if (mode == MODE_S1) { if (tw == 32) GS_WGB2(MODE_S1, 32); else GS_WGB2(MODE_S1, 16); }
@@ -1087,7 +1115,7 @@ int run_wgrad_mfma(int mode, const void* x, const void* gy, float* gw, int N, in
 #undef GS_WG
     }
     GS_CHECK_LAUNCH();
-    wgrad_reduce_launch(part, gw, nslices, 9, IC, OC, alpha, transpose, accumulate, st);
+    wgrad_reduce_launch(part, gw, gb, nslices, 9, IC, OC, alpha, transpose, accumulate, st);
     GS_CHECK_LAUNCH();
     return 0;
 }

@@ -37,28 +37,34 @@ __global__ void weight_prep_kernel(const float* __restrict__ w, T* __restrict__ 
 // Block = (256 / L) consecutive elements x L slice lanes; one launch whatever the slice count (L = 4 for a few slices,
 // 16 for the hundreds of slices of the thin top-of-pyramid layers); fixed summation order -> deterministic.
 template <int L>
-static __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ gw, int nslices,
+static __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ gw, float* __restrict__ gb, int nslices,
                                                                   int taps, int ic, int oc, float alpha, int transpose, int accumulate) {
     constexpr int EPB = 256 / L;
     __shared__ float red[256];
     const long total = (long)taps * ic * oc;
+    const long pstride = total + (gb ? oc : 0);   // a slice = the taps (+ one row of bias sums when gb is given)
     const long e = (long)blockIdx.x * EPB + (threadIdx.x % EPB);
     const int sl = threadIdx.x / EPB;
     float s0 = 0.f, s1 = 0.f;
-    if (e < total) {
+    if (e < pstride) {
         int k = sl;
         for (; k + L < nslices; k += 2 * L) {
-            s0 += part[(long)k * total + e];
-            s1 += part[(long)(k + L) * total + e];
+            s0 += part[(long)k * pstride + e];
+            s1 += part[(long)(k + L) * pstride + e];
         }
-        if (k < nslices) s0 += part[(long)k * total + e];
+        if (k < nslices) s0 += part[(long)k * pstride + e];
     }
     red[threadIdx.x] = s0 + s1;
     __syncthreads();
-    if (sl == 0 && e < total) {
+    if (sl == 0 && e < pstride) {
         float s = 0.f;
 #pragma unroll
         for (int j = 0; j < L; ++j) s += red[threadIdx.x + j * EPB];
+        if (e >= total) {   // bias gradient: no equalized-LR scale
+            float* o = gb + (e - total);
+            *o = accumulate ? *o + s : s;
+            return;
+        }
         s *= alpha;
         long dst = e;
         if (transpose) {
@@ -71,14 +77,13 @@ static __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* _
     }
 }
 
-// extra fp32 elements the partial buffer needs behind its nslices*total partials (none any more; kept for the ABI size query)
 static inline size_t wgrad_reduce_extra(long nslices, long total) { (void)nslices; (void)total; return 0; }
-static inline void wgrad_reduce_launch(float* part, float* gw, int nslices, int taps, int ic, int oc, float alpha, int transpose, int accumulate, hipStream_t st) {
-    const long total = (long)taps * ic * oc;
+static inline void wgrad_reduce_launch(float* part, float* gw, float* gb, int nslices, int taps, int ic, int oc, float alpha, int transpose, int accumulate, hipStream_t st) {
+    const long n = (long)taps * ic * oc + (gb ? oc : 0);
     if (nslices <= 32) {
-        hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, part, gw, nslices, taps, ic, oc, alpha, transpose, accumulate);
+        hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, part, gw, gb, nslices, taps, ic, oc, alpha, transpose, accumulate);
     } else {
-        hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, st, part, gw, nslices, taps, ic, oc, alpha, transpose, accumulate);
+        hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, st, part, gw, gb, nslices, taps, ic, oc, alpha, transpose, accumulate);
     }
 }
 

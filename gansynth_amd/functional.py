@@ -40,8 +40,10 @@ class _ConvKind(object):
     def bwd_data(self, gy, w, x_shape, alpha):
         return _K().conv2d_bwd_data(gy, w, x_shape, self.ksize, self.stride, alpha)
 
-    def bwd_weight(self, x, gy, alpha, out=None):
-        return _K().conv2d_bwd_weight(x, gy, self.ksize, self.stride, alpha, out=out)
+    bias_in_wgrad = True   # the weight-gradient kernels can return the bias gradient of the block on the side
+
+    def bwd_weight(self, x, gy, alpha, out=None, bias_out=None):
+        return _K().conv2d_bwd_weight(x, gy, self.ksize, self.stride, alpha, out=out, bias_out=bias_out)
 
 
 class _ConvTransposeKind(object):
@@ -196,6 +198,13 @@ class _ConvBiasAct(Function):
     def backward(ctx, gz):
         x, w, z = ctx.saved_tensors
         want_b = ctx.has_bias and ctx.needs_input_grad[2]
+        if want_b and ctx.needs_input_grad[1] and getattr(ctx.kind, "bias_in_wgrad", False):
+            tw, tb = _accum_target(ctx.wref), _accum_target(ctx.bref)
+            if tw is not None and tb is not None:   # plain backward: weight and bias gradients from the same launches
+                gy = _ActBwd.apply(gz, z, ctx.act) if ctx.act != ACT_NONE else gz
+                gx = _BilinearBwdData.apply(gy, w, x.shape, ctx.kind, ctx.alpha) if ctx.needs_input_grad[0] else None
+                ctx.kind.bwd_weight(x, gy, ctx.alpha, out=tw, bias_out=tb)
+                return gx, None, None, None, None, None
         gy, gb = _bias_act_backward(gz, z if ctx.act != ACT_NONE else None, ctx.act, ctx.bref if want_b else None, want_b)
         gx = _BilinearBwdData.apply(gy, w, x.shape, ctx.kind, ctx.alpha) if ctx.needs_input_grad[0] else None
         gw = None

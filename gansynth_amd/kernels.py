@@ -157,17 +157,20 @@ class HipKernels(object):
                                                float(alpha), _dt(gy), prepared, ws.data_ptr(), ws.numel(), _stream()), "gs_conv2d_bwd_data")
         return gx
 
-    def conv2d_bwd_weight(self, x, gy, ksize, stride, alpha, out=None):
-        """gw (new tensor), or with `out` (fp32, contiguous) the gradient is ADDED into it inside the kernel."""
+    def conv2d_bwd_weight(self, x, gy, ksize, stride, alpha, out=None, bias_out=None):
+        """gw (new tensor), or with `out` (fp32, contiguous) the gradient is ADDED into it inside the kernel.  With `bias_out`
+        (needs `out`) the bias gradient sum_{n,h,w} gy is added into it by the same launches."""
         x, gy = _act(x), _act(gy)
         n, ci, h, wd = x.shape
         co = gy.shape[1]
         gw = torch.empty((ksize, ksize, ci, co), dtype=torch.float32, device=x.device) if out is None else out
         nb = self.lib.gs_conv2d_workspace_bytes(_lib.CONV_BWD_WEIGHT, n, h, wd, ci, co, ksize, stride, _dt(x))
         ws = _ws(nb, x.device)
-        _lib.check(self.lib.gs_conv2d_bwd_weight(x.data_ptr(), gy.data_ptr(), gw.data_ptr(), n, h, wd, ci, co, ksize, stride,
-                                                 float(alpha), 0 if out is None else 1, _dt(x), ws.data_ptr(), ws.numel(), _stream()),
-                   "gs_conv2d_bwd_weight")
+        if bias_out is not None:
+            assert out is not None and bias_out.dtype == torch.float32 and bias_out.is_contiguous()
+        _lib.check(self.lib.gs_conv2d_bwd_weight_bias(x.data_ptr(), gy.data_ptr(), gw.data_ptr(), None if bias_out is None else bias_out.data_ptr(),
+                                                      n, h, wd, ci, co, ksize, stride, float(alpha), 0 if out is None else 1, _dt(x),
+                                                      ws.data_ptr(), ws.numel(), _stream()), "gs_conv2d_bwd_weight_bias")
         return gw
 
     def conv2d_transpose_fwd(self, x, w, alpha):

@@ -77,6 +77,11 @@ int gs_conv2d_bwd_data(const void* gy, const float* w_hwio, void* gx, int n, int
                        int ksize, int stride, float alpha, int dtype, int w_prepared, void* ws, size_t ws_bytes, void* stream);
 int gs_conv2d_bwd_weight(const void* x, const void* gy, float* gw_hwio, int n, int h, int w, int ci, int co,
                          int ksize, int stride, float alpha, int accumulate, int dtype, void* ws, size_t ws_bytes, void* stream);
+/* bwd_weight that also returns the bias gradient of the block, gb[co] (+)= sum_{n,h,w} gy (fp32; no alpha): for bf16 3x3 convs
+ * the sum rides along in the same two launches (one extra MFMA per 16 pixels against an all-ones operand), other shapes fall
+ * back to gs_channel_sum inside.  gb may be NULL (= gs_conv2d_bwd_weight).  `accumulate` applies to gw and gb alike. */
+int gs_conv2d_bwd_weight_bias(const void* x, const void* gy, float* gw_hwio, float* gb, int n, int h, int w, int ci, int co,
+                              int ksize, int stride, float alpha, int accumulate, int dtype, void* ws, size_t ws_bytes, void* stream);
 
 /* tf.nn.conv2d_transpose NCHW, 3x3, stride 2, SAME, output = 2h x 2w (ops.py:266-276): the
  * gradient-of-conv definition out[2i+k] += x[i] * w[k][ci][co], cropped at the end.

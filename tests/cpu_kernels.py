@@ -51,10 +51,12 @@ class CpuEmuKernels(object):
             out.add_(val.to(out.dtype))
         return out
 
-    def conv2d_bwd_weight(self, x, gy, ksize, stride, alpha, out=None):
+    def conv2d_bwd_weight(self, x, gy, ksize, stride, alpha, out=None, bias_out=None):
         ci, co = x.shape[1], gy.shape[1]
         shape = (ksize, ksize, ci, co)
         g = _lin_grad(lambda z: self_conv(x.detach(), z, stride, alpha), shape, gy, gy.detach())
+        if bias_out is not None:
+            self.channel_sum(gy, out=bias_out)
         return self._out(g.float().detach(), out)
 
     def conv2d_transpose_fwd(self, x, w, alpha):

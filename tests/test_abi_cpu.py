@@ -33,7 +33,7 @@ def test_argument_validation_without_gpu():
     from gansynth_amd import _lib
     lib = _lib.load()
     assert lib.gs_conv2d_workspace_bytes(_lib.CONV_FWD, 8, 128, 1024, 32, 32, 3, 1, _lib.GS_F32) == 9 * 32 * 32 * 4
-    assert lib.gs_conv2d_workspace_bytes(_lib.CONV_BWD_WEIGHT, 8, 128, 1024, 32, 32, 3, 1, _lib.GS_F32) == 512 * 9 * 32 * 32 * 4  # f32: 512 pixel slices of fp32 partials
+    assert lib.gs_conv2d_workspace_bytes(_lib.CONV_BWD_WEIGHT, 8, 128, 1024, 32, 32, 3, 1, _lib.GS_F32) == 512 * (9 * 32 * 32 + 32) * 4  # 512 pixel slices of fp32 partials (9 taps + a bias row)
     assert lib.gs_conv2d_fwd(None, None, None, 1, 8, 8, 32, 32, 5, 1, 1.0, 0, 0, None, 0, None) == -1
     assert b"ksize" in lib.gs_last_error()
     assert lib.gs_batch_stddev_fwd(None, None, 6, 32, 256, 1e-12, 0, None) == -1  # batch % 4 (ops.py:341)

@@ -324,3 +324,19 @@ def test_parameter_gradients_accumulate_in_kernel(K, E, dtype):
         acc = dev(base)
         K.act_bwd_bias(dev(g, dtype), dev(y, dtype), 1, out=acc)
         close(acc, base + E.act_bwd_bias(g, y, 1)[1], rel=1e-4 if dtype == torch.float32 else 2e-2, name="act_bwd_bias +=")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", [(2, 32, 32, 8, 128, 3, 1), (2, 64, 64, 8, 64, 3, 1), (2, 64, 128, 8, 64, 3, 2), (2, 32, 64, 8, 128, 3, 2),
+                                  (4, 256, 256, 2, 16, 3, 1), (2, 2, 32, 8, 64, 1, 1)])
+def test_bias_gradient_rides_with_weight_gradient(K, E, case, dtype):
+    """gs_conv2d_bwd_weight_bias: gb += sum over pixels of gy from the weight-gradient launches (bf16 MFMA kernels) or the
+    channel-sum fallback (fp32 / thin shapes)."""
+    n, ci, co, h, w, ks, st = case
+    x = rnd(n, ci, h, w, seed=1).to(dtype).float()
+    gy = rnd(n, co, h // st, w // st, seed=2).to(dtype).float()
+    bw, bb = rnd(ks, ks, ci, co, seed=3), rnd(co, seed=4)
+    accw, accb = dev(bw).contiguous(), dev(bb)
+    K.conv2d_bwd_weight(dev(x, dtype), dev(gy, dtype), ks, st, 0.2, out=accw, bias_out=accb)
+    close(accw, bw + E.conv2d_bwd_weight(x, gy, ks, st, 0.2), rel=1e-4, name="gw +=")
+    close(accb, bb + E.channel_sum(gy), rel=1e-4, name="gb +=")
