@@ -117,43 +117,44 @@ __global__ __launch_bounds__(256) void dense_bwd_data_wide_kernel(const T* __res
 
 
 // ---- fast paths (vector loads; the generic kernels above remain for odd shapes) ------------------------------------
+constexpr int FB = 8;   // batch rows per pass of the fast kernels
 // y[b][o] = alpha * sum_i x[b][i] w[i][o], in % 4 == 0, out % 32 == 0.  Block = 8 column threads (float4: 32 columns) x 32 row
 // lanes; a row lane takes 4 consecutive rows per pass (one 8/16-byte load of x per batch row).  Row lanes are folded with
 // xor-shuffles inside a wave and through LDS across the 4 waves; with ksplit == 1 the result is written directly.
 template <typename T>
 __global__ __launch_bounds__(256) void dense_fwd_fast_kernel(const T* __restrict__ x, const float* __restrict__ w, float* __restrict__ part,
                                                              T* __restrict__ y, int b0, int nb, int in, int out, int b_total, int ipb, float alpha) {
-    __shared__ float red[4][DENSE_BT][32];
+    __shared__ float red[4][FB][32];
     const int tid = threadIdx.x;
     const int c = tid & 7, r = tid >> 3;           // column thread, row lane (0..31)
     const int col = blockIdx.x * 32 + c * 4;
     const int i0 = blockIdx.y * ipb;
     int i1 = i0 + ipb;
     if (i1 > in) i1 = in;
-    float acc[DENSE_BT][4];
+    float acc[FB][4];
 #pragma unroll
-    for (int b = 0; b < DENSE_BT; ++b)
+    for (int b = 0; b < FB; ++b)
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[b][e] = 0.f;
     for (int i = i0 + 4 * r; i < i1; i += 128) {
         float4 wv[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) wv[k] = *reinterpret_cast<const float4*>(w + (long)(i + k) * out + col);
+        // (loads are unconditional -- rows past nb re-read the last valid row and their sums are never written: a per-row
+        //  `if (b < nb) load` makes hipcc branch around every load and drain vmcnt(0) each time)
 #pragma unroll
-        for (int b = 0; b < DENSE_BT; ++b) {
-            if (b < nb) {
-                float xv[4];
-                ld4(x + (long)(b0 + b) * in + i, xv);
+        for (int b = 0; b < FB; ++b) {
+            float xv[4];
+            ld4(x + (long)(b0 + (b < nb ? b : nb - 1)) * in + i, xv);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    acc[b][0] += xv[k] * wv[k].x; acc[b][1] += xv[k] * wv[k].y; acc[b][2] += xv[k] * wv[k].z; acc[b][3] += xv[k] * wv[k].w;
-                }
+            for (int k = 0; k < 4; ++k) {
+                acc[b][0] += xv[k] * wv[k].x; acc[b][1] += xv[k] * wv[k].y; acc[b][2] += xv[k] * wv[k].z; acc[b][3] += xv[k] * wv[k].w;
             }
         }
     }
     // fold the 8 row lanes of the wave (lane = r_local * 8 + c)
 #pragma unroll
-    for (int b = 0; b < DENSE_BT; ++b) {
+    for (int b = 0; b < FB; ++b) {
         if (b < nb) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(256) void dense_fwd_fast_kernel(const T* __restrict
     const int wv_ = tid >> 6;
     if ((tid & 63) < 8) {
 #pragma unroll
-        for (int b = 0; b < DENSE_BT; ++b)
+        for (int b = 0; b < FB; ++b)
             if (b < nb) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) red[wv_][b][c * 4 + e] = acc[b][e];
@@ -189,23 +190,21 @@ __global__ __launch_bounds__(256) void dense_bwd_data_fast_kernel(const T* __res
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= in) return;
-    float acc[DENSE_BT];
+    float acc[FB];
 #pragma unroll
-    for (int b = 0; b < DENSE_BT; ++b) acc[b] = 0.f;
+    for (int b = 0; b < FB; ++b) acc[b] = 0.f;
     const float* wr = w + (long)i * out;
     for (int o = lane * 4; o < out; o += 256) {
         const float4 wv = *reinterpret_cast<const float4*>(wr + o);
 #pragma unroll
-        for (int b = 0; b < DENSE_BT; ++b) {
-            if (b < nb) {
-                float gv[4];
-                ld4(gy + (long)(b0 + b) * out + o, gv);
-                acc[b] += gv[0] * wv.x + gv[1] * wv.y + gv[2] * wv.z + gv[3] * wv.w;
-            }
+        for (int b = 0; b < FB; ++b) {   // unconditional loads, see dense_fwd_fast_kernel
+            float gv[4];
+            ld4(gy + (long)(b0 + (b < nb ? b : nb - 1)) * out + o, gv);
+            acc[b] += gv[0] * wv.x + gv[1] * wv.y + gv[2] * wv.z + gv[3] * wv.w;
         }
     }
 #pragma unroll
-    for (int b = 0; b < DENSE_BT; ++b) {
+    for (int b = 0; b < FB; ++b) {
         if (b < nb) {
             const float sum = wave_sum(acc[b]);
             if (lane == 0) DT<T>::st(gx + (long)(b0 + b) * in + i, sum * alpha);
@@ -224,25 +223,22 @@ __global__ __launch_bounds__(256) void dense_bwd_weight_fast_kernel(const T* __r
     const int ct = tid & 63, rl = tid >> 6;
     const int col = blockIdx.x * 256 + ct * 4;
     const int r0 = blockIdx.y * DENSE_WR;
-    for (int k = tid; k < b * DENSE_WR; k += 256) {
+    for (int k = tid; k < DENSE_BT * DENSE_WR; k += 256) {
         const int bb = k / DENSE_WR, rr = k % DENSE_WR;
-        xs[bb][rr] = r0 + rr < in ? DT<T>::ld(x + (long)bb * in + r0 + rr) * alpha : 0.f;
+        xs[bb][rr] = (bb < b && r0 + rr < in) ? DT<T>::ld(x + (long)bb * in + r0 + rr) * alpha : 0.f;
     }
     float g[DENSE_BT][4];
 #pragma unroll
-    for (int bb = 0; bb < DENSE_BT; ++bb) {
-        if (bb < b) ld4(gy + (long)bb * out + col, g[bb]);
-        else { g[bb][0] = g[bb][1] = g[bb][2] = g[bb][3] = 0.f; }
+    for (int bb = 0; bb < DENSE_BT; ++bb) {   // unconditional loads; rows past b are multiplied by the zeros staged in xs
+        ld4(gy + (long)(bb < b ? bb : b - 1) * out + col, g[bb]);
     }
     __syncthreads();
     for (int rr = rl; rr < DENSE_WR && r0 + rr < in; rr += 4) {
         float o[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int bb = 0; bb < DENSE_BT; ++bb) {
-            if (bb < b) {
-                const float xv = xs[bb][rr];
-                o[0] += xv * g[bb][0]; o[1] += xv * g[bb][1]; o[2] += xv * g[bb][2]; o[3] += xv * g[bb][3];
-            }
+            const float xv = xs[bb][rr];
+            o[0] += xv * g[bb][0]; o[1] += xv * g[bb][1]; o[2] += xv * g[bb][2]; o[3] += xv * g[bb][3];
         }
         float4* dst = reinterpret_cast<float4*>(gw + (long)(r0 + rr) * out + col);
         if (accumulate) {
@@ -407,8 +403,9 @@ extern "C" int gs_dense_fwd(const void* x, const float* w, void* y, int b, int i
     hipStream_t st = as_stream(stream);
     float* part = (float*)ws;
     const bool fast = dense_fwd_fast_ok(in, out);
-    for (int b0 = 0; b0 < b; b0 += DENSE_BT) {
-        const int nb = b - b0 < DENSE_BT ? b - b0 : DENSE_BT;
+    const int step = fast ? FB : DENSE_BT;
+    for (int b0 = 0; b0 < b; b0 += step) {
+        const int nb = b - b0 < step ? b - b0 : step;
         if (fast) {
             GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dense_fwd_fast_kernel<T>), dim3(out / 32, ks), dim3(256), 0, st, (const T*)x, w,
                                                         ks > 1 ? part : nullptr, (T*)y, b0, nb, in, out, b, ipb, alpha));
@@ -427,8 +424,9 @@ extern "C" int gs_dense_fwd(const void* x, const float* w, void* y, int b, int i
 extern "C" int gs_dense_bwd_data(const void* gy, const float* w, void* gx, int b, int in, int out, float alpha, int dtype, void* stream) {
     GS_CHECK_ARG(b > 0 && in > 0 && out > 0, "dense_bwd_data: bad args");
     hipStream_t st = as_stream(stream);
-    for (int b0 = 0; b0 < b; b0 += DENSE_BT) {
-        const int nb = b - b0 < DENSE_BT ? b - b0 : DENSE_BT;
+    const int step = out % 256 == 0 ? FB : DENSE_BT;
+    for (int b0 = 0; b0 < b; b0 += step) {
+        const int nb = b - b0 < step ? b - b0 : step;
         if (out % 256 == 0) {
             GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dense_bwd_data_fast_kernel<T>), dim3(cdiv(in, 4)), dim3(256), 0, st, (const T*)gy, w, (T*)gx, b0, nb, in, out, alpha));
         } else if (out >= 2048) {
