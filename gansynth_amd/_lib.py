@@ -24,6 +24,7 @@ SIGNATURES = {
     "gs_init": (I, []),
     "gs_prof_enable": (I, [I]),
     "gs_prof_collect": (I, [POINTER(c_int), POINTER(c_double), POINTER(c_double)]),
+    "gs_prof_roofline": (I, [ctypes.c_double, ctypes.c_double, P, P, P]),
     "gs_conv2d_workspace_bytes": (Z, [I, I, I, I, I, I, I, I, I]),
     "gs_conv2d_fwd": (I, [P, P, P, I, I, I, I, I, I, I, F, I, I, P, Z, P]),
     "gs_conv2d_fwd_bias_act": (I, [P, P, P, P, I, I, I, I, I, I, I, F, I, I, I, P, Z, P]),

@@ -31,15 +31,18 @@ struct ProfState {
     int created = 0;
     int used = 0;
     double flops = 0.0;
+    double lflops[MAXEV], lbytes[MAXEV];   // per launch: algorithmic flops and bytes (operands read once + result written once)
 };
 static ProfState g_prof;
 
 struct ProfScope {
     hipStream_t s;
     int idx = -1;
-    ProfScope(hipStream_t st, double flops) : s(st) {
+    ProfScope(hipStream_t st, double flops, double bytes = 0.0) : s(st) {
         if (!g_prof.on || g_prof.used >= ProfState::MAXEV) return;
         idx = g_prof.used++;
+        g_prof.lflops[idx] = flops;
+        g_prof.lbytes[idx] = bytes;
         if (idx >= g_prof.created) {
             hipEventCreate(&g_prof.ev[idx][0]);
             hipEventCreate(&g_prof.ev[idx][1]);
@@ -954,7 +957,9 @@ static int launch_igemm(ConvP p, hipStream_t st) {
     if (grid > total) grid = total;
     if (grid >= 8) grid &= ~7L;
     const double flops = 2.0 * 9.0 * (double)p.N * p.Hb * p.Wb * p.IC * p.OC;
-    ProfScope ps(st, flops);
+    const double out_px = (double)p.N * p.Hb * p.Wb * (MODE == MODE_T2 ? 4 : 1);
+    const double bytes = ((double)p.N * p.Hi * p.Wi * p.IC + out_px * p.OC + 9.0 * p.IC * p.OC) * sizeof(T);
+    ProfScope ps(st, flops, bytes);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, p);
     return 0;
 }
@@ -1126,6 +1131,22 @@ extern "C" int gs_prof_enable(int on) {
     gs::g_prof.on = on != 0;
     gs::g_prof.used = 0;
     gs::g_prof.flops = 0.0;
+    return 0;
+}
+
+// Roofline accounting of the same launches: total algorithmic bytes, and the sum over launches of the time the binding roof
+// (MFMA peak or HBM bandwidth, whichever is larger for that launch) allows.  Call BEFORE gs_prof_collect (which resets).
+extern "C" int gs_prof_roofline(double peak_tflops, double peak_gbps, double* total_bytes, double* roof_ms, double* roof_ms_hbm_bound) {
+    double bytes = 0.0, roof = 0.0, roof_hbm = 0.0;
+    for (int i = 0; i < gs::g_prof.used; ++i) {
+        const double tf = gs::g_prof.lflops[i] / (peak_tflops * 1e12) * 1e3, tb = gs::g_prof.lbytes[i] / (peak_gbps * 1e9) * 1e3;
+        bytes += gs::g_prof.lbytes[i];
+        roof += tf > tb ? tf : tb;
+        if (tb >= tf) roof_hbm += tb;
+    }
+    if (total_bytes) *total_bytes = bytes;
+    if (roof_ms) *roof_ms = roof;
+    if (roof_ms_hbm_bound) *roof_ms_hbm_bound = roof_hbm;
     return 0;
 }
 

@@ -414,6 +414,12 @@ class HipKernels(object):
     def prof_enable(self, on):
         self.lib.gs_prof_enable(1 if on else 0)
 
+    def prof_roofline(self, peak_tflops, peak_gbps):
+        """(algorithmic bytes, roofline ms, HBM-bound part of it) of the recorded launches; call before prof_collect()."""
+        b, r, rh = ctypes.c_double(0.0), ctypes.c_double(0.0), ctypes.c_double(0.0)
+        self.lib.gs_prof_roofline(float(peak_tflops), float(peak_gbps), ctypes.byref(b), ctypes.byref(r), ctypes.byref(rh))
+        return b.value, r.value, rh.value
+
     def prof_collect(self):
         n, ms, fl = ctypes.c_int(0), ctypes.c_double(0.0), ctypes.c_double(0.0)
         self.lib.gs_prof_collect(ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl))

@@ -48,6 +48,10 @@ int gs_init(void);
  * of launches, their summed duration (ms) and summed algorithmic FLOPs. */
 int gs_prof_enable(int on);
 int gs_prof_collect(int* launches, double* total_ms, double* total_flops);
+/* roofline accounting of the launches recorded since gs_prof_enable(1): algorithmic bytes (every operand read once, the result
+ * written once) and the time the binding roof allows, summed per launch (max of flops / peak_tflops and bytes / peak_gbps);
+ * roof_ms_hbm_bound = the part of it that comes from HBM-bound launches.  Call before gs_prof_collect (which resets). */
+int gs_prof_roofline(double peak_tflops, double peak_gbps, double* total_bytes, double* roof_ms, double* roof_ms_hbm_bound);
 
 /* ------------------------------------------------------------------------------- conv2d
  * tf.nn.conv2d NCHW/HWIO padding=SAME (ops.py:237-243) with ksize in {1,3}, stride in {1,2}
