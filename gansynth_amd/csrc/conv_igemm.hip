@@ -113,6 +113,9 @@ template <int MODE> __host__ __device__ constexpr int tap_off(int k) {  // patch
 // no ordinary global loads (the bias lives in LDS), only the epilogue stores.
 // TG == 9 with RESIDENT keeps all taps of all chunks in LDS for the life of the block (thin layers: 32 or
 // 64 output channels) and only the input patches stream.
+#ifndef GS_TOP_D
+#define GS_TOP_D 2
+#endif
 struct ConvP {
     const void* x;
     const void* wp;
@@ -478,10 +481,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
                                     o[0] += bv.x; o[1] += bv.y; o[2] += bv.z; o[3] += bv.w;
 #pragma unroll
                                     for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], slope * o[e]);  // leaky relu (slope 1: identity)
-                                    if constexpr (A == 1) {   // 64-byte pixel rows: the detour does not pay, each lane stores its 8 / 16 bytes
+                                    if constexpr (A == 1 && MODE != MODE_T2) {   // 64-byte pixel rows of adjacent pixels: the detour does not pay, each lane stores its 8 / 16 bytes
                                         const int q = (wv * B + b) * 32 + l31;
                                         const int gy = by + q / TW, gx = bx + q % TW;
+#ifdef GS_ABL_NOSTORE
+                                        if (gy < -1000) {
+#else
                                         if (gy < Hb && gx < Wb) {
+#endif
                                             const int oy = MODE == MODE_T2 ? 2 * gy + (ph >> 1) : gy;
                                             const int ox = MODE == MODE_T2 ? 2 * gx + (ph & 1) : gx;
                                             st4(y + (((long)n * Ho + oy) * Wo + ox) * OC + oc0 + a * 32 + qd * 8 + hi * 4, o);
@@ -490,7 +497,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
                                         st4(reinterpret_cast<T*>(sw + l31 * RB) + qd * 8 + hi * 4, o);
                                     }
                                 }
-                                if constexpr (A > 1) {
+                                if constexpr (A > 1 || MODE == MODE_T2) {   // (the transposed conv scatters a lane's pixels 2 apart: always staged)
 #pragma unroll
                                 for (int it = 0; it < 32 / RPI; ++it) {
                                     const int row = it * RPI + r_row;
@@ -937,7 +944,7 @@ static int launch_igemm(ConvP p, hipStream_t st) {
     p.noct = cdiv(p.OC, OCT);
     p.nch = p.IC / BK;
     const int wbufs = RESIDENT ? p.nch : NWB;
-    const size_t lds = (size_t)NPB * PBUF + (size_t)wbufs * WBUF + (size_t)((p.OC + 3) / 4) * 16 + 4 * 32 * (32 * sizeof(T) + 16);
+    const size_t lds = (size_t)NPB * PBUF + (size_t)wbufs * WBUF + (size_t)((p.OC + 3) / 4) * 16 + ((A > 1 || MODE == MODE_T2) ? 4 * 32 * (32 * sizeof(T) + 16) : 0);
     if (p.OC % OCT != 0) return fail(GS_ERR_UNSUPPORTED, "conv igemm: %d output channels with %d-wide tiles", p.OC, OCT);
     if ((size_t)p.Hi * p.Wi * p.IC * sizeof(T) >= (1ull << 31)) return fail(GS_ERR_UNSUPPORTED, "conv igemm: one image exceeds 2 GiB");
     if (lds > 160 * 1024) return fail(GS_ERR_UNSUPPORTED, "conv igemm: %zu bytes of LDS needed", lds);
@@ -976,7 +983,7 @@ static int dispatch_igemm(ConvP p, hipStream_t st) {
     // blocks the layer gives with 128*B-pixel x 64-channel tiles (TW = 32)
     auto items64 = [&](int B_) { return (long)p.N * cdiv(p.Hb, 4 * B_) * cdiv(Wb, 32) * (OC / 64); };
     if constexpr (MODE == MODE_T2) {
-        if (resident_ok && Wb >= 64) return launch_igemm<T, MODE, 1, 2, 64, 9, true>(p, st);
+        if (resident_ok && Wb >= 64) return launch_igemm<T, MODE, 1, 2, 64, 9, true, GS_TOP_D>(p, st);
         if (!a2) return launch_igemm<T, MODE, 1, 1, 32, 3>(p, st);
         if (Wb >= 32) return launch_igemm<T, MODE, 2, 1, 32, 3>(p, st);
         return launch_igemm<T, MODE, 2, 1, 16, 3>(p, st);
@@ -985,7 +992,7 @@ static int dispatch_igemm(ConvP p, hipStream_t st) {
         if (Wb >= 32) return launch_igemm<T, MODE, 2, 1, 32, 3>(p, st);
         return launch_igemm<T, MODE, 2, 1, 16, 3>(p, st);
     } else {
-        if (resident_ok && Wb >= 64) return launch_igemm<T, MODE, 1, 2, 64, 9, true>(p, st);
+        if (resident_ok && Wb >= 64) return launch_igemm<T, MODE, 1, 2, 64, 9, true, GS_TOP_D>(p, st);
         if (!a2) return launch_igemm<T, MODE, 1, 1, 32, 3>(p, st);
         if (resident64_ok && Wb >= 32 && items64(2) >= num_cus() / 2) return launch_igemm<T, MODE, 2, 2, 32, 9, true>(p, st);
         // every block re-streams its 64 x IC x 9 weight slab from L2: the more pixels a block owns the smaller that
