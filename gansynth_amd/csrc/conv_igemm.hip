@@ -202,7 +202,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
     unsigned char* const lpatch = lds;                // NPB x PBUF
     unsigned char* const lwgt = lds + NPB * PBUF;     // streamed: NWB x WBUF ; resident: nch x WBUF
     float* const lbias = reinterpret_cast<float*>(lwgt + (RESIDENT ? p.nch : NWB) * WBUF);  // OC floats (zeros without a bias)
-    unsigned char* const lstage = reinterpret_cast<unsigned char*>(lbias) + ((p.OC + 3) / 4) * 16;  // 4 x 32 rows of 32 channels + pad
     const unsigned a_patch = (unsigned)(uintptr_t)lds;  // low 32 bits of a flat LDS address = the LDS byte address
     const unsigned a_wgt = a_patch + NPB * PBUF;
 
@@ -452,69 +451,61 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
                     wait_vmcnt(younger);
 #endif
                 }
-                // ---- epilogue of the item.  D[oc][pixel]: a lane holds oc = 8q + 4hi + (0..3) of pixel l31 per accumulator quad,
-                //      i.e. 8 / 16 bytes per pixel row -- stored directly that is 64 separate small write requests per
-                //      instruction and the store path, not HBM, bounds the kernel.  So each 32-pixel x 32-channel tile takes a
-                //      detour through a wave-private LDS tile and leaves as 16-byte-per-lane stores whose lane quads cover
-                //      whole 64-byte runs of a pixel row.
+                // ---- epilogue of the item.  D[oc][pixel]: a lane holds oc = 8q + 4hi + (0..3) of pixel l31 per accumulator quad.
+                //      The store path sustains ~7 B/cycle/CU with 8-byte stores and twice that with 16-byte ones (measured with
+                //      the ablations of scripts/probe/igemm_trace.hip: the top-of-pyramid layers are bound by it), so a lane must
+                //      leave with 16 bytes.  fp32: a quad is 16 bytes.  bf16: v_permlane32_swap exchanges the quads q / q+1
+                //      between the two lane halves, after which lane (pixel, hi) owns 8 consecutive channels 16*(q/2) + 8*hi + ...
 #ifndef GS_ABL_NOEPI
                 if (tg == NTG - 1 && ch == NCH - 1) {
                     const int Ho = MODE == MODE_T2 ? 2 * Hb : Hb, Wo = MODE == MODE_T2 ? 2 * Wb : Wb;
-                    constexpr int RB = 32 * SZ + 16;       // staged row: 32 channels + pad (conflict-free quad writes)
-                    constexpr int LPR = 32 * SZ / 16;      // lanes per staged row when reading 16 bytes each
-                    constexpr int RPI = 64 / LPR;          // rows per read instruction
-                    unsigned char* const sw = lstage + wv * (32 * RB);
-                    const int r_row = lane / LPR, r_seg = lane % LPR;
                     const float slope = p.act == GS_ACT_LRELU ? 0.2f : 1.f;
 #pragma unroll
                     for (int b = 0; b < B; ++b) {
+                        const int q = (wv * B + b) * 32 + l31;
+                        const int gy = by + q / TW, gx = bx + q % TW;
+#ifdef GS_ABL_NOSTORE
+                        const bool inside = gy < -1000;
+#else
+                        const bool inside = gy < Hb && gx < Wb;
+#endif
 #pragma unroll
                         for (int ph = 0; ph < NPH; ++ph) {
+                            const int oy = MODE == MODE_T2 ? 2 * gy + (ph >> 1) : gy;
+                            const int ox = MODE == MODE_T2 ? 2 * gx + (ph & 1) : gx;
+                            T* const yp = y + (((long)n * Ho + oy) * Wo + ox) * OC + oc0;
 #pragma unroll
                             for (int a = 0; a < A; ++a) {
+                                float o[4][4];
 #pragma unroll
                                 for (int qd = 0; qd < 4; ++qd) {
-                                    float o[4];
-#pragma unroll
-                                    for (int e = 0; e < 4; ++e) o[e] = acc[ph][a][b][qd * 4 + e] * p.alpha;
                                     const float4 bv = *reinterpret_cast<const float4*>(lbias + oc0 + a * 32 + qd * 8 + hi * 4);
-                                    o[0] += bv.x; o[1] += bv.y; o[2] += bv.z; o[3] += bv.w;
+                                    const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
 #pragma unroll
-                                    for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], slope * o[e]);  // leaky relu (slope 1: identity)
-                                    if constexpr (A == 1 && MODE != MODE_T2) {   // 64-byte pixel rows of adjacent pixels: the detour does not pay, each lane stores its 8 / 16 bytes
-                                        const int q = (wv * B + b) * 32 + l31;
-                                        const int gy = by + q / TW, gx = bx + q % TW;
-#ifdef GS_ABL_NOSTORE
-                                        if (gy < -1000) {
-#else
-                                        if (gy < Hb && gx < Wb) {
-#endif
-                                            const int oy = MODE == MODE_T2 ? 2 * gy + (ph >> 1) : gy;
-                                            const int ox = MODE == MODE_T2 ? 2 * gx + (ph & 1) : gx;
-                                            st4(y + (((long)n * Ho + oy) * Wo + ox) * OC + oc0 + a * 32 + qd * 8 + hi * 4, o);
+                                    for (int e = 0; e < 4; ++e) {
+                                        const float v = acc[ph][a][b][qd * 4 + e] * p.alpha + bb[e];
+                                        o[qd][e] = fmaxf(v, slope * v);  // leaky relu (slope 1: identity)
+                                    }
+                                }
+                                if constexpr (SZ == 4) {
+#pragma unroll
+                                    for (int qd = 0; qd < 4; ++qd)
+                                        if (inside) st4(reinterpret_cast<float*>(yp) + a * 32 + qd * 8 + hi * 4, o[qd]);
+                                } else {
+#pragma unroll
+                                    for (int qp = 0; qp < 2; ++qp) {
+                                        float lo[4], hi4[4];
+#pragma unroll
+                                        for (int e = 0; e < 4; ++e) {
+                                            const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(o[2 * qp][e]), __float_as_uint(o[2 * qp + 1][e]), false, false);
+                                            lo[e] = __uint_as_float(r[0]);
+                                            hi4[e] = __uint_as_float(r[1]);
                                         }
-                                    } else {
-                                        st4(reinterpret_cast<T*>(sw + l31 * RB) + qd * 8 + hi * 4, o);
+                                        uint4 v;
+                                        v.x = pack_bf16x2(lo[0], lo[1]); v.y = pack_bf16x2(lo[2], lo[3]);
+                                        v.z = pack_bf16x2(hi4[0], hi4[1]); v.w = pack_bf16x2(hi4[2], hi4[3]);
+                                        if (inside) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(yp) + a * 32 + qp * 16 + hi * 8) = v;
                                     }
-                                }
-                                if constexpr (A > 1 || MODE == MODE_T2) {   // (the transposed conv scatters a lane's pixels 2 apart: always staged)
-#pragma unroll
-                                for (int it = 0; it < 32 / RPI; ++it) {
-                                    const int row = it * RPI + r_row;
-                                    const int q = (wv * B + b) * 32 + row;
-                                    const int gy = by + q / TW, gx = bx + q % TW;
-                                    const uint4 v = *reinterpret_cast<const uint4*>(sw + row * RB + r_seg * 16);
-#ifdef GS_ABL_NOSTORE
-                                    if (gy < -1000) {   // never (keeps the epilogue arithmetic alive)
-#else
-                                    if (gy < Hb && gx < Wb) {
-#endif
-                                        const int oy = MODE == MODE_T2 ? 2 * gy + (ph >> 1) : gy;
-                                        const int ox = MODE == MODE_T2 ? 2 * gx + (ph & 1) : gx;
-                                        T* yp = y + (((long)n * Ho + oy) * Wo + ox) * OC + oc0 + a * 32 + r_seg * (16 / SZ);
-                                        *reinterpret_cast<uint4*>(yp) = v;
-                                    }
-                                }
                                 }
                             }
                         }
@@ -944,7 +935,7 @@ static int launch_igemm(ConvP p, hipStream_t st) {
     p.noct = cdiv(p.OC, OCT);
     p.nch = p.IC / BK;
     const int wbufs = RESIDENT ? p.nch : NWB;
-    const size_t lds = (size_t)NPB * PBUF + (size_t)wbufs * WBUF + (size_t)((p.OC + 3) / 4) * 16 + ((A > 1 || MODE == MODE_T2) ? 4 * 32 * (32 * sizeof(T) + 16) : 0);
+    const size_t lds = (size_t)NPB * PBUF + (size_t)wbufs * WBUF + (size_t)((p.OC + 3) / 4) * 16 + 0;
     if (p.OC % OCT != 0) return fail(GS_ERR_UNSUPPORTED, "conv igemm: %d output channels with %d-wide tiles", p.OC, OCT);
     if ((size_t)p.Hi * p.Wi * p.IC * sizeof(T) >= (1ull << 31)) return fail(GS_ERR_UNSUPPORTED, "conv igemm: one image exceeds 2 GiB");
     if (lds > 160 * 1024) return fail(GS_ERR_UNSUPPORTED, "conv igemm: %zu bytes of LDS needed", lds);
