@@ -77,7 +77,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
-    distributed = world > 1
+    distributed = world > 1 or bool(os.environ.get("GS_BENCH_FORCE_DIST"))  # (the env switch exercises the RCCL path on one GPU)
     if distributed:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
