@@ -29,6 +29,7 @@ SIGNATURES = {
     "gs_conv2d_fwd": (I, [P, P, P, I, I, I, I, I, I, I, F, I, I, P, Z, P]),
     "gs_conv2d_fwd_bias_act": (I, [P, P, P, P, I, I, I, I, I, I, I, F, I, I, I, P, Z, P]),
     "gs_conv2d_bwd_data": (I, [P, P, P, I, I, I, I, I, I, I, F, I, I, P, Z, P]),
+    "gs_conv2d_bwd_data_mask": (I, [P, P, P, I, P, I, I, I, I, I, I, I, F, I, I, P, Z, P]),
     "gs_conv2d_bwd_weight": (I, [P, P, P, I, I, I, I, I, I, I, F, I, I, P, Z, P]),
     "gs_conv2d_bwd_weight_bias": (I, [P, P, P, P, I, I, I, I, I, I, I, F, I, I, P, Z, P]),
     "gs_conv2d_transpose_s2_workspace_bytes": (Z, [I, I, I, I, I, I, I]),
@@ -50,6 +51,7 @@ SIGNATURES = {
     "gs_channel_sum": (I, [P, P, L, I, I, I, P, Z, P]),
     "gs_pixel_norm_fwd": (I, [P, P, L, I, F, I, P]),
     "gs_pixel_norm_bwd": (I, [P, P, P, L, I, F, I, P]),
+    "gs_pixel_norm_bwd_act": (I, [P, P, P, L, I, F, I, I, P]),
     "gs_pixel_norm_bwd_bwd": (I, [P, P, P, P, L, I, F, I, P]),
     "gs_upscale2d": (I, [P, P, I, I, I, I, I, I, F, I, P]),
     "gs_blocksum2d": (I, [P, P, I, I, I, I, I, I, F, I, P]),

@@ -12,7 +12,7 @@ bool wgrad_mfma_supported(int ic, int oc, int dtype);
 size_t igemm_prep_bytes(int ic, int oc, int dtype);
 int run_igemm(int mode, int variant, const void* x, const float* w_hwio, void* y, int N, int Hi, int Wi, int ICk,
               int OCk, int w_ci, int w_co, int Hb, int Wb, float alpha, const float* bias, int act, int dtype, int w_prepared,
-              void* ws, size_t ws_bytes, hipStream_t st);
+              void* ws, size_t ws_bytes, hipStream_t st, const void* mask = nullptr, int mask_act = 0);
 size_t wgrad_mfma_bytes(int mode, int dtype, int N, int Hb, int Wb, int IC, int OC);
 bool wgrad_mfma_has_bias(int dtype);
 int run_wgrad_mfma(int mode, const void* x, const void* gy, float* gw, float* gb, int N, int Hi, int Wi, int IC, int OC, int Hb,
@@ -543,21 +543,40 @@ extern "C" int gs_conv2d_fwd_bias_act(const void* x, const float* w_hwio, const 
     return conv2d_fwd_impl(x, w_hwio, bias, act, y, n, h, w, ci, co, ksize, stride, alpha, dtype, w_prepared, ws, ws_bytes, stream);
 }
 
-extern "C" int gs_conv2d_bwd_data(const void* gy, const float* w_hwio, void* gx, int n, int h, int w, int ci, int co,
-                                  int ksize, int stride, float alpha, int dtype, int w_prepared, void* ws, size_t ws_bytes, void* stream) {
+extern "C" int gs_act_bwd(const void* g, const void* y, void* gx, int64_t numel, int act, int dtype, void* stream);
+
+// gx = conv2d_bwd_data(gy, w) * mask_act'(.) through `mask` (the activation OUTPUT that was the conv's input; NULL: plain)
+extern "C" int gs_conv2d_bwd_data_mask(const void* gy, const float* w_hwio, const void* mask, int mask_act, void* gx, int n, int h, int w, int ci, int co,
+                                       int ksize, int stride, float alpha, int dtype, int w_prepared, void* ws, size_t ws_bytes, void* stream) {
     if (int e = check_conv_args(n, h, w, ci, co, ksize, stride, dtype)) return e;
+    GS_CHECK_ARG(mask == nullptr || mask_act == GS_ACT_LRELU || mask_act == GS_ACT_TANH, "conv2d_bwd_data_mask: bad activation %d", mask_act);
     const float* bias = nullptr;
     const int act = GS_ACT_NONE;
     hipStream_t st = as_stream(stream);
     const int hb = h / stride, wb = w / stride;
+    int rc;
+    // In the epilogue the mask costs one more read of gx's size through the vector-memory path: measured a win where the kernel
+    // is MFMA-bound (>= 64 channels), a loss on the 32-channel top of the pyramid whose kernels are bound by exactly that path
+    // (there the separate in-place pass below is as fast and leaves the conv alone).
+    bool fused = mask != nullptr && ci >= 64;
+    const void* km = fused ? mask : nullptr;
     if (stride == 1) {  // flipped taps, roles of ci/co swapped
         if (ksize == 3 && igemm_supported(co, ci, dtype))
-            return run_igemm(MODE_S1, 1, gy, w_hwio, gx, n, h, w, co, ci, ci, co, h, w, alpha, bias, act, dtype, w_prepared, ws, ws_bytes, st);
-        return run_direct(MODE_S1, ksize, 1, gy, w_hwio, gx, n, h, w, co, ci, ci, co, h, w, alpha, dtype, w_prepared, ws, ws_bytes, st);
+            rc = run_igemm(MODE_S1, 1, gy, w_hwio, gx, n, h, w, co, ci, ci, co, h, w, alpha, bias, act, dtype, w_prepared, ws, ws_bytes, st, km, mask_act);
+        else { rc = run_direct(MODE_S1, ksize, 1, gy, w_hwio, gx, n, h, w, co, ci, ci, co, h, w, alpha, dtype, w_prepared, ws, ws_bytes, st); fused = false; }
+    } else if (igemm_supported(co, ci, dtype)) {
+        rc = run_igemm(MODE_T2, 2, gy, w_hwio, gx, n, hb, wb, co, ci, ci, co, hb, wb, alpha, bias, act, dtype, w_prepared, ws, ws_bytes, st, km, mask_act);
+    } else {
+        rc = run_direct(MODE_T2, 3, 2, gy, w_hwio, gx, n, hb, wb, co, ci, ci, co, h, w, alpha, dtype, w_prepared, ws, ws_bytes, st);
+        fused = false;
     }
-    if (igemm_supported(co, ci, dtype))
-        return run_igemm(MODE_T2, 2, gy, w_hwio, gx, n, hb, wb, co, ci, ci, co, hb, wb, alpha, bias, act, dtype, w_prepared, ws, ws_bytes, st);
-    return run_direct(MODE_T2, 3, 2, gy, w_hwio, gx, n, hb, wb, co, ci, ci, co, h, w, alpha, dtype, w_prepared, ws, ws_bytes, st);
+    if (rc || !mask || fused) return rc;
+    return gs_act_bwd(gx, mask, gx, (int64_t)n * h * w * ci, mask_act, dtype, stream);   // shapes without the MFMA kernel: in place
+}
+
+extern "C" int gs_conv2d_bwd_data(const void* gy, const float* w_hwio, void* gx, int n, int h, int w, int ci, int co,
+                                  int ksize, int stride, float alpha, int dtype, int w_prepared, void* ws, size_t ws_bytes, void* stream) {
+    return gs_conv2d_bwd_data_mask(gy, w_hwio, nullptr, 0, gx, n, h, w, ci, co, ksize, stride, alpha, dtype, w_prepared, ws, ws_bytes, stream);
 }
 
 extern "C" size_t gs_channel_sum_workspace_bytes(int64_t p, int c);

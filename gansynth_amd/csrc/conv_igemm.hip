@@ -122,6 +122,8 @@ struct ConvP {
     void* y;
     const float* bias;  // optional fused epilogue: y = act(alpha * conv + bias)
     int act;
+    const void* mask;   // optional (data gradients): y *= mask_act'(.) expressed through the activation OUTPUT mask[..] (y's shape)
+    int mask_act;
     int N, Hi, Wi, IC, OC, Hb, Wb, tiles_x, tiles_y, nsp, noct, nch;
     float alpha;
 #ifdef GS_IGEMM_TRACE
@@ -487,10 +489,20 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
                                         o[qd][e] = fmaxf(v, slope * v);  // leaky relu (slope 1: identity)
                                     }
                                 }
+                                auto mask_factor = [&](float z) __attribute__((always_inline)) {
+                                    return p.mask_act == GS_ACT_LRELU ? (z > 0.f ? 1.f : 0.2f) : 1.f - z * z;
+                                };
                                 if constexpr (SZ == 4) {
 #pragma unroll
-                                    for (int qd = 0; qd < 4; ++qd)
-                                        if (inside) st4(reinterpret_cast<float*>(yp) + a * 32 + qd * 8 + hi * 4, o[qd]);
+                                    for (int qd = 0; qd < 4; ++qd) {
+                                        if (inside) {
+                                            if (p.mask) {
+                                                const float4 zv = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.mask) + (yp - y) + a * 32 + qd * 8 + hi * 4);
+                                                o[qd][0] *= mask_factor(zv.x); o[qd][1] *= mask_factor(zv.y); o[qd][2] *= mask_factor(zv.z); o[qd][3] *= mask_factor(zv.w);
+                                            }
+                                            st4(reinterpret_cast<float*>(yp) + a * 32 + qd * 8 + hi * 4, o[qd]);
+                                        }
+                                    }
                                 } else {
 #pragma unroll
                                     for (int qp = 0; qp < 2; ++qp) {
@@ -500,6 +512,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
                                             const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(o[2 * qp][e]), __float_as_uint(o[2 * qp + 1][e]), false, false);
                                             lo[e] = __uint_as_float(r[0]);
                                             hi4[e] = __uint_as_float(r[1]);
+                                        }
+                                        if (p.mask && inside) {   // the lane's 8 channels of the mask sit where its 16 bytes go
+                                            const uint4 zv = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.mask) + (yp - y) + a * 32 + qp * 16 + hi * 8);
+                                            lo[0] *= mask_factor(__uint_as_float(zv.x << 16)); lo[1] *= mask_factor(__uint_as_float(zv.x & 0xffff0000u));
+                                            lo[2] *= mask_factor(__uint_as_float(zv.y << 16)); lo[3] *= mask_factor(__uint_as_float(zv.y & 0xffff0000u));
+                                            hi4[0] *= mask_factor(__uint_as_float(zv.z << 16)); hi4[1] *= mask_factor(__uint_as_float(zv.z & 0xffff0000u));
+                                            hi4[2] *= mask_factor(__uint_as_float(zv.w << 16)); hi4[3] *= mask_factor(__uint_as_float(zv.w & 0xffff0000u));
                                         }
                                         uint4 v;
                                         v.x = pack_bf16x2(lo[0], lo[1]); v.y = pack_bf16x2(lo[2], lo[3]);
@@ -1009,7 +1028,7 @@ size_t igemm_prep_bytes(int ic, int oc, int dtype) {
 template <typename T>
 static int run_igemm_t(int mode, int variant, const void* x, const float* w_hwio, void* y, int N, int Hi, int Wi,
                        int ICk, int OCk, int w_ci, int w_co, int Hb, int Wb, float alpha, const float* bias, int act,
-                       int w_prepared, void* ws, size_t ws_bytes, hipStream_t st) {
+                       int w_prepared, void* ws, size_t ws_bytes, hipStream_t st, const void* mask, int mask_act) {
     const size_t need = (size_t)9 * w_ci * w_co * sizeof(T);
     if (ws_bytes < need) return fail(GS_ERR_WORKSPACE, "conv igemm: workspace %zu < %zu", ws_bytes, need);
     T* wp = reinterpret_cast<T*>(ws);
@@ -1018,7 +1037,7 @@ static int run_igemm_t(int mode, int variant, const void* x, const float* w_hwio
         hipLaunchKernelGGL((weight_prep_kernel<T>), dim3(cdiv(total, 256)), dim3(256), 0, st, w_hwio, wp, 9, w_ci, w_co, variant);
     ConvP p;
     memset(&p, 0, sizeof(p));
-    p.x = x; p.wp = wp; p.y = y; p.bias = bias; p.act = act;
+    p.x = x; p.wp = wp; p.y = y; p.bias = bias; p.act = act; p.mask = mask; p.mask_act = mask_act;
     p.N = N; p.Hi = Hi; p.Wi = Wi; p.IC = ICk; p.OC = OCk; p.Hb = Hb; p.Wb = Wb; p.alpha = alpha;
     int rc;
     if (mode == MODE_S1) rc = dispatch_igemm<T, MODE_S1>(p, st);
@@ -1031,9 +1050,9 @@ static int run_igemm_t(int mode, int variant, const void* x, const float* w_hwio
 
 int run_igemm(int mode, int variant, const void* x, const float* w_hwio, void* y, int N, int Hi, int Wi, int ICk,
               int OCk, int w_ci, int w_co, int Hb, int Wb, float alpha, const float* bias, int act, int dtype, int w_prepared,
-              void* ws, size_t ws_bytes, hipStream_t st) {
+              void* ws, size_t ws_bytes, hipStream_t st, const void* mask, int mask_act) {
     GS_DISPATCH_DTYPE(dtype, return (run_igemm_t<T>(mode, variant, x, w_hwio, y, N, Hi, Wi, ICk, OCk, w_ci, w_co, Hb,
-                                                    Wb, alpha, bias, act, w_prepared, ws, ws_bytes, st)));
+                                                    Wb, alpha, bias, act, w_prepared, ws, ws_bytes, st, mask, mask_act)));
 }
 
 // ---- weight gradient (fp32 MFMA path)

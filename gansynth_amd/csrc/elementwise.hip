@@ -232,7 +232,9 @@ static int channel_sum_parts(long p, int c) {
 // MODE 0: y = x*r ; MODE 1: gx = r*(g - y*mean(y*g)) ; MODE 2: second-order term (see header).
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void pixel_norm_kernel(const T* __restrict__ a0, const T* __restrict__ a1, const T* __restrict__ a2,
-                                                         T* __restrict__ out, long p, int c, float eps) {
+                                                         T* __restrict__ out, long p, int c, float eps, int act) {
+    // `act` (MODE 1 only): x is itself the output of that activation and the caller wants the gradient w.r.t. the
+    // PRE-activation: gx is multiplied by act'(.) expressed through x (the separate act_bwd pass disappears)
     // a0 = x (MODE 0) | g (MODE 1) | gg (MODE 2);  a1 = x (MODE 1) | g (MODE 2);  a2 = x (MODE 2)
     const int quads = c >> 2;
     const int L = quads < 64 ? quads : 64;       // lanes per row (power of two)
@@ -285,7 +287,11 @@ __global__ __launch_bounds__(256) void pixel_norm_kernel(const T* __restrict__ a
                 if (k < passes && ok) {
                     float o4[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o4[e] = r * (gv[k][e] - xv[k][e] * r * q);
+                    for (int e = 0; e < 4; ++e) {
+                        o4[e] = r * (gv[k][e] - xv[k][e] * r * q);
+                        if (act == GS_ACT_LRELU) o4[e] = xv[k][e] > 0.f ? o4[e] : 0.2f * o4[e];
+                        else if (act == GS_ACT_TANH) o4[e] *= 1.f - xv[k][e] * xv[k][e];
+                    }
                     st4(out + row * c + (k * L + sub) * 4, o4);
                 }
         } else {
@@ -537,16 +543,16 @@ extern "C" int gs_act_bwd_bias(const void* g, const void* y, void* gx, float* gb
     return channel_sum_finalize(part, gb, nparts, c, accumulate, st);
 }
 
-static int pixel_norm_launch(int mode, const void* a0, const void* a1, const void* a2, void* out, int64_t p, int c, float eps, int dtype, void* stream) {
+static int pixel_norm_launch(int mode, const void* a0, const void* a1, const void* a2, void* out, int64_t p, int c, float eps, int dtype, void* stream, int act = 0) {
     GS_CHECK_ARG(p > 0 && c >= 4 && c <= 1024 && (c & (c - 1)) == 0, "pixel_norm: c=%d must be a power of two in [4,1024]", c);
     const int L = (c >> 2) < 64 ? (c >> 2) : 64;
     const long rows_per_block = 4 * (64 / L);
     dim3 grid(ew_grid(((long)p + rows_per_block - 1) / rows_per_block * 256));
     hipStream_t st = as_stream(stream);
     GS_DISPATCH_DTYPE(dtype, {
-        if (mode == 0) hipLaunchKernelGGL((pixel_norm_kernel<T, 0>), grid, dim3(256), 0, st, (const T*)a0, (const T*)a1, (const T*)a2, (T*)out, (long)p, c, eps);
-        else if (mode == 1) hipLaunchKernelGGL((pixel_norm_kernel<T, 1>), grid, dim3(256), 0, st, (const T*)a0, (const T*)a1, (const T*)a2, (T*)out, (long)p, c, eps);
-        else hipLaunchKernelGGL((pixel_norm_kernel<T, 2>), grid, dim3(256), 0, st, (const T*)a0, (const T*)a1, (const T*)a2, (T*)out, (long)p, c, eps);
+        if (mode == 0) hipLaunchKernelGGL((pixel_norm_kernel<T, 0>), grid, dim3(256), 0, st, (const T*)a0, (const T*)a1, (const T*)a2, (T*)out, (long)p, c, eps, act);
+        else if (mode == 1) hipLaunchKernelGGL((pixel_norm_kernel<T, 1>), grid, dim3(256), 0, st, (const T*)a0, (const T*)a1, (const T*)a2, (T*)out, (long)p, c, eps, act);
+        else hipLaunchKernelGGL((pixel_norm_kernel<T, 2>), grid, dim3(256), 0, st, (const T*)a0, (const T*)a1, (const T*)a2, (T*)out, (long)p, c, eps, act);
     });
     GS_CHECK_LAUNCH();
     return 0;
@@ -556,6 +562,10 @@ extern "C" int gs_pixel_norm_fwd(const void* x, void* y, int64_t p, int c, float
 }
 extern "C" int gs_pixel_norm_bwd(const void* g, const void* x, void* gx, int64_t p, int c, float eps, int dtype, void* stream) {
     return pixel_norm_launch(1, g, x, nullptr, gx, p, c, eps, dtype, stream);
+}
+extern "C" int gs_pixel_norm_bwd_act(const void* g, const void* x, void* gx, int64_t p, int c, float eps, int act, int dtype, void* stream) {
+    GS_CHECK_ARG(act == GS_ACT_NONE || act == GS_ACT_LRELU || act == GS_ACT_TANH, "pixel_norm_bwd_act: bad activation %d", act);
+    return pixel_norm_launch(1, g, x, nullptr, gx, p, c, eps, dtype, stream, act);
 }
 extern "C" int gs_pixel_norm_bwd_bwd(const void* gg, const void* g, const void* x, void* out, int64_t p, int c, float eps, int dtype, void* stream) {
     return pixel_norm_launch(2, gg, g, x, out, p, c, eps, dtype, stream);

@@ -40,6 +40,9 @@ class _ConvKind(object):
     def bwd_data(self, gy, w, x_shape, alpha):
         return _K().conv2d_bwd_data(gy, w, x_shape, self.ksize, self.stride, alpha)
 
+    def bwd_data_mask(self, gy, w, x_shape, alpha, mask, mask_act):
+        return _K().conv2d_bwd_data(gy, w, x_shape, self.ksize, self.stride, alpha, mask=mask, mask_act=mask_act)
+
     bias_in_wgrad = True   # the weight-gradient kernels can return the bias gradient of the block on the side
 
     def bwd_weight(self, x, gy, alpha, out=None, bias_out=None):
@@ -87,6 +90,32 @@ def _accum_target(param):
     if g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.shape != param.shape:
         return None
     return g
+
+
+# ---- "premasked" gradients ------------------------------------------------------------------------------------------------
+# A block z = act(conv(..) + b) has the backward gy = gz * act'(z) followed by the conv gradients.  When z has ONE consumer (the
+# caller says so: `in_act` of the consuming op -- networks.py knows its own wiring) and that consumer is a conv or a pixel norm,
+# the multiplication by act'(z) moves into the kernel that produces gz (its input x IS z): one full read-modify-write pass per
+# activation disappears from the plain backward.  The consumer tells the producer through the producer's ctx (= z.grad_fn)
+# which tensor is already masked; under create_graph nothing is fused (the pieces must stay differentiable Functions).
+_NO_PREMASK = bool(__import__("os").environ.get("GS_NO_PREMASK"))   # A/B switch for measurements
+
+
+def _premask_producer(x, in_act):
+    """ctx of the _ConvBiasAct that produced x when the fused path applies, else None."""
+    if in_act == ACT_NONE or torch.is_grad_enabled() or _NO_PREMASK:
+        return None
+    fn = x.grad_fn
+    if fn is not None and getattr(fn, "_gs_act_out", ACT_NONE) == in_act:
+        return fn
+    return None
+
+
+def _take_premasked(ctx, gz):
+    """True when the incoming gradient is the tensor a consumer marked as already multiplied by act'(z)."""
+    ptr = getattr(ctx, "_gs_premasked", None)
+    ctx._gs_premasked = None
+    return ptr is not None and ptr == gz.data_ptr()
 
 
 _KINDS = {}
@@ -187,9 +216,12 @@ class _ConvBiasAct(Function):
     """z = act(alpha * B(x, w) + bias) with the bias / activation fused into the GEMM epilogue."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, kind, alpha, act):
+    def forward(ctx, x, w, bias, kind, alpha, act, in_act=ACT_NONE):
         ctx.kind, ctx.alpha, ctx.act, ctx.has_bias = kind, alpha, act, bias is not None
         ctx.wref, ctx.bref = w, bias
+        ctx.in_act = in_act        # x is the single-consumer output of that activation (caller's promise)
+        ctx._gs_act_out = act      # what consumers of z may fold into their own kernels
+        ctx._gs_premasked = None
         z = kind.fwd_bias_act(x, w, bias, alpha, act)
         ctx.save_for_backward(x, w, z)
         return z
@@ -198,15 +230,27 @@ class _ConvBiasAct(Function):
     def backward(ctx, gz):
         x, w, z = ctx.saved_tensors
         want_b = ctx.has_bias and ctx.needs_input_grad[2]
+        act = ACT_NONE if _take_premasked(ctx, gz) else ctx.act   # (a consumer of z already applied act'(z))
+
+        def data_grad(gy):
+            if not ctx.needs_input_grad[0]:
+                return None
+            prod = _premask_producer(x, ctx.in_act) if hasattr(ctx.kind, "bwd_data_mask") else None
+            if prod is None:
+                return _BilinearBwdData.apply(gy, w, x.shape, ctx.kind, ctx.alpha)
+            gx_ = ctx.kind.bwd_data_mask(gy, w, x.shape, ctx.alpha, x, ctx.in_act)
+            prod._gs_premasked = gx_.data_ptr()
+            return gx_
+
         if want_b and ctx.needs_input_grad[1] and getattr(ctx.kind, "bias_in_wgrad", False):
             tw, tb = _accum_target(ctx.wref), _accum_target(ctx.bref)
             if tw is not None and tb is not None:   # plain backward: weight and bias gradients from the same launches
-                gy = _ActBwd.apply(gz, z, ctx.act) if ctx.act != ACT_NONE else gz
-                gx = _BilinearBwdData.apply(gy, w, x.shape, ctx.kind, ctx.alpha) if ctx.needs_input_grad[0] else None
+                gy = _ActBwd.apply(gz, z, act) if act != ACT_NONE else gz
+                gx = data_grad(gy)
                 ctx.kind.bwd_weight(x, gy, ctx.alpha, out=tw, bias_out=tb)
-                return gx, None, None, None, None, None
-        gy, gb = _bias_act_backward(gz, z if ctx.act != ACT_NONE else None, ctx.act, ctx.bref if want_b else None, want_b)
-        gx = _BilinearBwdData.apply(gy, w, x.shape, ctx.kind, ctx.alpha) if ctx.needs_input_grad[0] else None
+                return gx, None, None, None, None, None, None
+        gy, gb = _bias_act_backward(gz, z if act != ACT_NONE else None, act, ctx.bref if want_b else None, want_b)
+        gx = data_grad(gy)
         gw = None
         if ctx.needs_input_grad[1]:
             tgt = _accum_target(ctx.wref)
@@ -214,19 +258,19 @@ class _ConvBiasAct(Function):
                 ctx.kind.bwd_weight(x, gy, ctx.alpha, out=tgt)
             else:
                 gw = _BilinearBwdWeight.apply(x, gy, ctx.kind, ctx.alpha).to(w.dtype)
-        return gx, gw, gb, None, None, None
+        return gx, gw, gb, None, None, None, None
 
 
 def conv2d(x, w, ksize, stride, alpha):
     return _Bilinear.apply(x, w, _kind(("conv", ksize, stride)), alpha)
 
 
-def conv2d_bias_act(x, w, bias, ksize, stride, alpha, act):
-    return _ConvBiasAct.apply(x, w, bias, _kind(("conv", ksize, stride)), alpha, act)
+def conv2d_bias_act(x, w, bias, ksize, stride, alpha, act, in_act=ACT_NONE):
+    return _ConvBiasAct.apply(x, w, bias, _kind(("conv", ksize, stride)), alpha, act, in_act)
 
 
 def conv2d_transpose_bias_act(x, w, bias, alpha, act):
-    return _ConvBiasAct.apply(x, w, bias, _kind(("convT",)), alpha, act)
+    return _ConvBiasAct.apply(x, w, bias, _kind(("convT",)), alpha, act, ACT_NONE)
 
 
 def conv2d_transpose(x, w, alpha):
@@ -328,15 +372,20 @@ def bias_act(x, bias, act):
 # ------------------------------------------------------------------------- pixel norm
 class _PixelNorm(Function):
     @staticmethod
-    def forward(ctx, x, eps):
-        ctx.eps = eps
+    def forward(ctx, x, eps, in_act=ACT_NONE):
+        ctx.eps, ctx.in_act = eps, in_act
         ctx.save_for_backward(x)
         return _K().pixel_norm_fwd(x, eps)
 
     @staticmethod
     def backward(ctx, g):
         (x,) = ctx.saved_tensors
-        return _PixelNormBwd.apply(g, x, ctx.eps), None
+        prod = _premask_producer(x, ctx.in_act)
+        if prod is not None:   # x = act(..) with this norm as its only consumer: gradient w.r.t. the pre-activation directly
+            gx = _K().pixel_norm_bwd(g, x, ctx.eps, act=ctx.in_act)
+            prod._gs_premasked = gx.data_ptr()
+            return gx, None, None
+        return _PixelNormBwd.apply(g, x, ctx.eps), None, None
 
 
 class _PixelNormBwd(Function):
@@ -354,8 +403,8 @@ class _PixelNormBwd(Function):
         return g_g, g_x, None
 
 
-def pixel_norm(x, eps):
-    return _PixelNorm.apply(x, eps)
+def pixel_norm(x, eps, in_act=ACT_NONE):
+    return _PixelNorm.apply(x, eps, in_act)
 
 
 # ------------------------------------------------------------------ upscale / block sum

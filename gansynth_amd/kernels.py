@@ -146,15 +146,22 @@ class HipKernels(object):
                    "gs_conv2d_fwd_bias_act")
         return y
 
-    def conv2d_bwd_data(self, gy, w, x_shape, ksize, stride, alpha):
+    def conv2d_bwd_data(self, gy, w, x_shape, ksize, stride, alpha, mask=None, mask_act=0):
+        """gx, or with `mask` (the conv's forward input, itself the output of activation `mask_act`) gx * act'(.): the data
+        gradient w.r.t. the previous layer's pre-activation in one pass."""
         gy, w = _act(gy), _f32c(w)
         n, ci, h, wd = x_shape
         co = w.shape[3]
         gx = _empty_like_act((n, ci, h, wd), gy)
         nb = self.lib.gs_conv2d_workspace_bytes(_lib.CONV_BWD_DATA, n, h, wd, ci, co, ksize, stride, _dt(gy))
         ws, prepared = self._weight_ws(w, ("bwd_data", ksize, stride, _dt(gy)), nb, (_lib.PREP_CONV_BWD_DATA, ci, co, ksize, stride, _dt(gy)))
-        _lib.check(self.lib.gs_conv2d_bwd_data(gy.data_ptr(), w.data_ptr(), gx.data_ptr(), n, h, wd, ci, co, ksize, stride,
-                                               float(alpha), _dt(gy), prepared, ws.data_ptr(), ws.numel(), _stream()), "gs_conv2d_bwd_data")
+        mp = None
+        if mask is not None:
+            mask = _act(mask)
+            assert mask.shape == gx.shape and mask.dtype == gx.dtype
+            mp = mask.data_ptr()
+        _lib.check(self.lib.gs_conv2d_bwd_data_mask(gy.data_ptr(), w.data_ptr(), mp, int(mask_act), gx.data_ptr(), n, h, wd, ci, co, ksize, stride,
+                                                    float(alpha), _dt(gy), prepared, ws.data_ptr(), ws.numel(), _stream()), "gs_conv2d_bwd_data_mask")
         return gx
 
     def conv2d_bwd_weight(self, x, gy, ksize, stride, alpha, out=None, bias_out=None):
@@ -319,12 +326,14 @@ class HipKernels(object):
         _lib.check(self.lib.gs_pixel_norm_fwd(x.data_ptr(), y.data_ptr(), p, c, float(eps), _dt(x), _stream()), "gs_pixel_norm_fwd")
         return y
 
-    def pixel_norm_bwd(self, g, x, eps):
+    def pixel_norm_bwd(self, g, x, eps, act=0):
+        """gx; with `act` (x is itself the output of that activation) gx * act'(.), i.e. the gradient w.r.t. the pre-activation."""
         x = _act(x)
         g = _match(g, x)
         p, c = _rows_cols(x)
         gx = torch.empty_like(x)
-        _lib.check(self.lib.gs_pixel_norm_bwd(g.data_ptr(), x.data_ptr(), gx.data_ptr(), p, c, float(eps), _dt(x), _stream()), "gs_pixel_norm_bwd")
+        _lib.check(self.lib.gs_pixel_norm_bwd_act(g.data_ptr(), x.data_ptr(), gx.data_ptr(), p, c, float(eps), int(act), _dt(x), _stream()),
+                   "gs_pixel_norm_bwd_act")
         return gx
 
     def pixel_norm_bwd_bwd(self, gg, g, x, eps):

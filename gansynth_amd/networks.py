@@ -84,6 +84,8 @@ class PGGAN(object):
             with variable_scope("conv"):
                 x = ops.conv2d(x, filters=c, kernel_size=[3, 3], use_bias=True, variance_scale=2.0, scale_weight=True,
                                activation="leaky_relu")
+                # (no `input_activation` here although the norm is the only forward consumer: the mode-seeking term
+                #  differentiates through the norm's backward, which feeds a second gradient into the activation output)
                 x = ops.pixel_normalization(x)
         return x
 
@@ -132,7 +134,10 @@ class PGGAN(object):
             return ops.lerp(low, middle, fade)
 
     # ============================================================== discriminator
-    def _d_conv_block(self, x, depth, num_labels):
+    def _d_conv_block(self, x, depth, num_labels, fresh_activation=False):
+        """`fresh_activation`: x is the leaky-relu output of the previous conv and feeds nothing but this block's first conv
+        (true along the trunk, false after the fade-in lerp) -- lets the backward fold the activation derivative into the
+        data-gradient kernel (ops.conv2d `input_activation`)."""
         c = self.channels(depth)
         with variable_scope(self._block_name("conv", depth)):
             if depth == self.min_depth:
@@ -155,10 +160,10 @@ class PGGAN(object):
                 return features, logits
             with variable_scope("conv"):
                 x = ops.conv2d(x, filters=c, kernel_size=[3, 3], use_bias=True, variance_scale=2.0, scale_weight=True,
-                               activation="leaky_relu")
+                               activation="leaky_relu", input_activation="leaky_relu" if fresh_activation else None)
             with variable_scope("conv_downscale"):
                 x = ops.conv2d(x, filters=self.channels(depth - 1), kernel_size=[3, 3], strides=[2, 2], use_bias=True,
-                               variance_scale=2.0, scale_weight=True, activation="leaky_relu")
+                               variance_scale=2.0, scale_weight=True, activation="leaky_relu", input_activation="leaky_relu")
             return x
 
     def _d_color_block(self, x, depth):
@@ -205,9 +210,11 @@ class PGGAN(object):
 
             if head == self.min_depth:
                 return self._d_conv_block(from_images(head), head, num_labels)
-            x = self._d_conv_block(from_images(head), head, num_labels)
+            x = self._d_conv_block(from_images(head), head, num_labels, fresh_activation=True)
+            fresh = fade is None
             if fade is not None:
                 x = ops.lerp(from_images(head - 1), x, fade)
             for depth in range(head - 1, self.min_depth, -1):
-                x = self._d_conv_block(x, depth, num_labels)
-            return self._d_conv_block(x, self.min_depth, num_labels)
+                x = self._d_conv_block(x, depth, num_labels, fresh_activation=fresh)
+                fresh = True
+            return self._d_conv_block(x, self.min_depth, num_labels)   # (x also feeds batch_stddev there: never fused)

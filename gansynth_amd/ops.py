@@ -54,15 +54,19 @@ def embedding(inputs, units, variance_scale=2.0, scale_weight=False):
 
 
 def conv2d(inputs, filters, kernel_size, strides=[1, 1], use_bias=True, variance_scale=2.0, scale_weight=False,
-           activation=None):
-    """ops.py:221-247 (NCHW, SAME)."""
+           activation=None, input_activation=None):
+    """ops.py:221-247 (NCHW, SAME).  `input_activation`: the caller's promise that `inputs` is the output of a conv block
+    with that fused activation and feeds nothing but this conv -- the backward then folds the activation derivative into
+    this conv's data-gradient kernel (functional.py, "premasked gradients"); results are unchanged.  "Nothing but" includes
+    second-order graphs: a tensor whose consumers' backward is differentiated again (pixel norm under the mode-seeking term)
+    receives a second gradient and must not be declared."""
     kernel_size, strides = list(kernel_size), list(strides)
     if kernel_size[0] != kernel_size[1] or strides[0] != strides[1]:
         raise ValueError("conv2d: only square kernels / isotropic strides are on the hot path")
     weight, alpha = get_weight([*kernel_size, inputs.shape[1], filters], variance_scale, scale_weight)
     bias = get_bias([filters]) if use_bias else None
     if bias is not None or activation is not None:
-        return F.conv2d_bias_act(inputs, weight, bias, kernel_size[0], strides[0], alpha, _ACT[activation])
+        return F.conv2d_bias_act(inputs, weight, bias, kernel_size[0], strides[0], alpha, _ACT[activation], _ACT[input_activation])
     return F.conv2d(inputs, weight, kernel_size[0], strides[0], alpha)
 
 
@@ -94,9 +98,9 @@ def downscale2d(inputs, factors=[2, 2]):
     return F.avg_pool(inputs, int(factors[0]), int(factors[1]))
 
 
-def pixel_normalization(inputs, epsilon=1.0e-12):
-    """ops.py:330-333 (axis 1, also for the 2-D latent)."""
-    return F.pixel_norm(inputs, epsilon)
+def pixel_normalization(inputs, epsilon=1.0e-12, input_activation=None):
+    """ops.py:330-333 (axis 1, also for the 2-D latent).  `input_activation`: see conv2d."""
+    return F.pixel_norm(inputs, epsilon, _ACT[input_activation])
 
 
 def batch_stddev(inputs, groups=4, epsilon=1.0e-12):

@@ -79,6 +79,12 @@ int gs_conv2d_fwd_bias_act(const void* x, const float* w_hwio, const float* bias
                            void* stream);
 int gs_conv2d_bwd_data(const void* gy, const float* w_hwio, void* gx, int n, int h, int w, int ci, int co,
                        int ksize, int stride, float alpha, int dtype, int w_prepared, void* ws, size_t ws_bytes, void* stream);
+/* bwd_data whose result is multiplied by the derivative of the activation that PRODUCED the conv's input, expressed through
+ * that input itself: gx = conv2d_bwd_data(gy, w) * act'(.)|mask  (mask = x of the forward conv, same shape as gx; act = LRELU
+ * or TANH).  It is the data gradient w.r.t. the previous layer's pre-activation in one pass (the separate act_bwd pass of the
+ * previous layer disappears).  mask NULL = gs_conv2d_bwd_data. */
+int gs_conv2d_bwd_data_mask(const void* gy, const float* w_hwio, const void* mask, int mask_act, void* gx, int n, int h, int w, int ci, int co,
+                            int ksize, int stride, float alpha, int dtype, int w_prepared, void* ws, size_t ws_bytes, void* stream);
 int gs_conv2d_bwd_weight(const void* x, const void* gy, float* gw_hwio, int n, int h, int w, int ci, int co,
                          int ksize, int stride, float alpha, int accumulate, int dtype, void* ws, size_t ws_bytes, void* stream);
 /* bwd_weight that also returns the bias gradient of the block, gb[co] (+)= sum_{n,h,w} gy (fp32; no alpha): for bf16 3x3 convs
@@ -155,6 +161,8 @@ int gs_channel_sum(const void* g, float* out, int64_t p, int c, int accumulate, 
  *   (d<gg, bwd(g,x)>/dg = bwd(gg, x): the Jacobian is symmetric) */
 int gs_pixel_norm_fwd(const void* x, void* y, int64_t p, int c, float eps, int dtype, void* stream);
 int gs_pixel_norm_bwd(const void* g, const void* x, void* gx, int64_t p, int c, float eps, int dtype, void* stream);
+/* pixel_norm_bwd whose input x is itself an activation output: gx = pixel_norm_bwd(g, x) * act'(.)|x (gradient w.r.t. the pre-activation) */
+int gs_pixel_norm_bwd_act(const void* g, const void* x, void* gx, int64_t p, int c, float eps, int act, int dtype, void* stream);
 int gs_pixel_norm_bwd_bwd(const void* gg, const void* g, const void* x, void* out, int64_t p, int c, float eps, int dtype, void* stream);
 
 /* upscale2d / downscale2d (ops.py:283-305).

@@ -40,8 +40,9 @@ class CpuEmuKernels(object):
         gx = self.act_bwd(g, y, act)
         return gx, self.channel_sum(gx, out=out)
 
-    def conv2d_bwd_data(self, gy, w, x_shape, ksize, stride, alpha):
-        return _lin_grad(lambda z: self_conv(z, w, stride, alpha), tuple(x_shape), gy, gy.detach()).detach()
+    def conv2d_bwd_data(self, gy, w, x_shape, ksize, stride, alpha, mask=None, mask_act=0):
+        gx = _lin_grad(lambda z: self_conv(z, w, stride, alpha), tuple(x_shape), gy, gy.detach()).detach()
+        return gx if mask is None else self.act_bwd(gx, mask, mask_act)
 
     @staticmethod
     def _out(val, out):
@@ -115,11 +116,11 @@ class CpuEmuKernels(object):
     def pixel_norm_fwd(self, x, eps):
         return R.pixel_normalization(x.detach(), eps)
 
-    def pixel_norm_bwd(self, g, x, eps):
+    def pixel_norm_bwd(self, g, x, eps, act=0):
         with torch.enable_grad():
             xx = x.detach().clone().requires_grad_(True)
             (gx,) = torch.autograd.grad(R.pixel_normalization(xx, eps), xx, g.detach().expand_as(xx))
-        return gx
+        return gx if act == 0 else self.act_bwd(gx, x, act)
 
     def pixel_norm_bwd_bwd(self, gg, g, x, eps):
         with torch.enable_grad():

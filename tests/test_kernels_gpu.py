@@ -340,3 +340,29 @@ def test_bias_gradient_rides_with_weight_gradient(K, E, case, dtype):
     K.conv2d_bwd_weight(dev(x, dtype), dev(gy, dtype), ks, st, 0.2, out=accw, bias_out=accb)
     close(accw, bw + E.conv2d_bwd_weight(x, gy, ks, st, 0.2), rel=1e-4, name="gw +=")
     close(accb, bb + E.channel_sum(gy), rel=1e-4, name="gb +=")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", [(2, 32, 32, 8, 128, 3, 1), (2, 64, 64, 8, 64, 3, 1), (2, 32, 64, 8, 128, 3, 2), (2, 64, 128, 8, 64, 3, 2),
+                                  (4, 256, 256, 2, 16, 3, 1), (2, 64, 32, 6, 40, 3, 1), (2, 2, 32, 8, 64, 1, 1)])
+@pytest.mark.parametrize("act", [1, 2])
+def test_conv2d_bwd_data_with_activation_mask(K, E, case, dtype, act):
+    """gs_conv2d_bwd_data_mask: gx = bwd_data(gy, w) * act'(.) through the activation output that was the conv's input."""
+    n, ci, co, h, w, ks, st = case
+    wt = rnd(ks, ks, ci, co, seed=2)
+    wr = wt.to(dtype).float() if (dtype == torch.bfloat16 and ks == 3) else wt
+    gy = rnd(n, co, h // st, w // st, seed=3).to(dtype).float()
+    z = E.bias_act_fwd(rnd(n, ci, h, w, seed=4), None, act).to(dtype).float()   # an activation output (both signs for lrelu)
+    alpha = float(np.sqrt(2.0 / (ks * ks * ci)))
+    ref = E.conv2d_bwd_data(gy, wr, (n, ci, h, w), ks, st, alpha, mask=z, mask_act=act)
+    got = K.conv2d_bwd_data(dev(gy, dtype), dev(wt), (n, ci, h, w), ks, st, alpha, mask=dev(z, dtype), mask_act=act)
+    close(got, ref, rel=1e-3 if dtype == torch.float32 else 2e-2, name="masked bwd_data")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 32, 8, 64), (4, 256, 2, 16), (8, 512)])
+def test_pixel_norm_bwd_with_activation(K, E, shape, dtype):
+    x = E.bias_act_fwd(rnd(*shape, seed=1), None, 1).to(dtype).float()
+    g = rnd(*shape, seed=2).to(dtype).float()
+    ref = E.pixel_norm_bwd(g, x, 1e-8, act=1)
+    close(K.pixel_norm_bwd(dev(g, dtype), dev(x, dtype), 1e-8, act=1), ref, rel=1e-4 if dtype == torch.float32 else 2e-2, name="pn bwd * lrelu'")
