@@ -102,13 +102,45 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const T* __restrict__ 
     // thread handles channel quad q = tid % (c/4) (or single channels when c%4 != 0), row lane r = tid / quads
     __shared__ float red[256 * 4];
     const int tid = threadIdx.x;
-    if ((c & 3) == 0 && c <= 1024) {
+    if ((c == 1 || c == 2 || c == 4) && ((p * c) & 7) == 0) {
+        // colour-width tensors (the images: 2 channels): stream the flat array 8 elements per lane, element k belongs to
+        // channel k % c
+        const long n8 = (p * c) >> 3;
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (long i = (long)blockIdx.x * 256 + tid; i < n8; i += (long)gridDim.x * 256) {
+            float v[8];
+            ld4(g + i * 8, *reinterpret_cast<float(*)[4]>(v));
+            ld4(g + i * 8 + 4, *reinterpret_cast<float(*)[4]>(v + 4));
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a[k] += v[k];
+        }
+        for (int e = 0; e < c; ++e) {
+            float mine = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) mine += (k & (c - 1)) == e ? a[k] : 0.f;   // (c is a power of two here)
+            const float tot = block_sum<256>(mine, red);
+            if (tid == 0) part[(long)blockIdx.x * c + e] = tot;
+        }
+    } else if ((c & 3) == 0 && c <= 1024) {
         const int quads = c >> 2;
         const int rl = 256 / quads > 0 ? 256 / quads : 1;  // row lanes per block
         const int q = tid % quads, r = tid / quads;
         float a[4] = {0.f, 0.f, 0.f, 0.f};
         if (r < rl && quads <= 256) {
-            for (long row = (long)blockIdx.x * rl + r; row < p; row += (long)gridDim.x * rl) {
+            // four rows per trip: the loads of a trip are independent and in flight together (one load per trip leaves the
+            // kernel waiting a full memory latency per 8 bytes)
+            const long step = (long)gridDim.x * rl;
+            long row = (long)blockIdx.x * rl + r;
+            for (; row + 3 * step < p; row += 4 * step) {
+                float v0[4], v1[4], v2[4], v3[4];
+                ld4(g + row * c + q * 4, v0);
+                ld4(g + (row + step) * c + q * 4, v1);
+                ld4(g + (row + 2 * step) * c + q * 4, v2);
+                ld4(g + (row + 3 * step) * c + q * 4, v3);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a[e] += (v0[e] + v1[e]) + (v2[e] + v3[e]);
+            }
+            for (; row < p; row += step) {
                 float v[4];
                 ld4(g + row * c + q * 4, v);
                 a[0] += v[0]; a[1] += v[1]; a[2] += v[2]; a[3] += v[3];
@@ -157,7 +189,24 @@ __global__ __launch_bounds__(256) void act_bwd_sum_kernel(const T* __restrict__ 
     const int q = tid % quads, r = tid / quads;
     float a[4] = {0.f, 0.f, 0.f, 0.f};
     if (r < rl) {
-        for (long row = (long)blockIdx.x * rl + r; row < p; row += (long)gridDim.x * rl) {
+        const long step = (long)gridDim.x * rl;
+        long row = (long)blockIdx.x * rl + r;
+        for (; row + step < p; row += 2 * step) {   // two rows per trip: four independent loads in flight
+            float g0[4], y0[4], g1[4], y1[4];
+            ld4(g + row * c + q * 4, g0);
+            ld4(y + row * c + q * 4, y0);
+            ld4(g + (row + step) * c + q * 4, g1);
+            ld4(y + (row + step) * c + q * 4, y1);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (ACT == GS_ACT_LRELU) { g0[e] = y0[e] > 0.f ? g0[e] : 0.2f * g0[e]; g1[e] = y1[e] > 0.f ? g1[e] : 0.2f * g1[e]; }
+                if (ACT == GS_ACT_TANH) { g0[e] = g0[e] * (1.f - y0[e] * y0[e]); g1[e] = g1[e] * (1.f - y1[e] * y1[e]); }
+                a[e] += g0[e] + g1[e];
+            }
+            st4(gx + row * c + q * 4, g0);
+            st4(gx + (row + step) * c + q * 4, g1);
+        }
+        for (; row < p; row += step) {
             float gv[4], yv[4];
             ld4(g + row * c + q * 4, gv);
             ld4(y + row * c + q * 4, yv);
@@ -218,6 +267,16 @@ static int channel_sum_finalize(float* part, float* out, int nparts, int c, int 
     GS_CHECK_LAUNCH();
     return 0;
 }
+// few rows, many channels (dense-layer biases: [batch][8192]): a thread per channel, no partials
+template <typename T>
+__global__ __launch_bounds__(256) void channel_sum_rows_kernel(const T* __restrict__ g, float* __restrict__ out, int p, int c, int accumulate) {
+    const int ch = blockIdx.x * 256 + threadIdx.x;
+    if (ch >= c) return;
+    float s = 0.f;
+    for (int r = 0; r < p; ++r) s += DT<T>::ld(g + (long)r * c + ch);
+    out[ch] = accumulate ? out[ch] + s : s;
+}
+
 static int channel_sum_parts(long p, int c) {
     long rows_per_block = 256 / (c >= 4 ? ((c & 3) == 0 ? c / 4 : (c < 256 ? c : 256)) : c);
     if (rows_per_block < 1) rows_per_block = 1;
@@ -512,6 +571,11 @@ extern "C" size_t gs_channel_sum_workspace_bytes(int64_t p, int c) {
 
 extern "C" int gs_channel_sum(const void* g, float* out, int64_t p, int c, int accumulate, int dtype, void* ws, size_t ws_bytes, void* stream) {
     GS_CHECK_ARG(p > 0 && c > 0, "channel_sum: bad args");
+    if (p <= 64 && c >= 256) {
+        GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((channel_sum_rows_kernel<T>), dim3(cdiv(c, 256)), dim3(256), 0, as_stream(stream), (const T*)g, out, (int)p, c, accumulate));
+        GS_CHECK_LAUNCH();
+        return 0;
+    }
     const int nparts = channel_sum_parts(p, c);
     if (ws_bytes < gs_channel_sum_workspace_bytes(p, c)) return fail(GS_ERR_WORKSPACE, "channel_sum: workspace too small");
     hipStream_t st = as_stream(stream);
