@@ -20,8 +20,8 @@ struct gs_spectral_plan {
     float* hann;        // [frame_length]
     float2* tw;         // [nbins/2]  exp(-2 pi i k / nbins)
     float2* twp;        // [nbins+1]  exp(-2 pi i k / frame_length)
-    int* mel_idx;       // [nbins][maxnz] ELL by mel column
-    float* mel_val;     // [nbins][maxnz]
+    int* mel_idx;       // [maxnz][nbins] ELL by mel column, entry-major (lanes = consecutive mel bins read consecutive words)
+    float* mel_val;     // [maxnz][nbins]
     float* pinv;        // [nbins][nbins] or nullptr
     float* inv_window;  // [frame_length]
 };
@@ -56,7 +56,9 @@ __device__ inline int bitrev(int v, int bits) { return (int)(__brev((unsigned)v)
 
 // MODE 0: write magnitude/phase [b][T][H] (DC dropped).
 // MODE 1: fused mel: images[b][T][H][2] channel 0 = (log(mel_mag + 1e-6) + 3.76)/10.05 ; mel_phase[b][T][H] fp32
-template <typename T, int MODE>
+// MZ: compile-time ELL width of the mel tables (0: run-time p.maxnz) -- with it the table loads of a mel bin are unrolled and
+// in flight together instead of one dependent L1 round trip per entry
+template <typename T, int MODE, int MZ>
 __global__ __launch_bounds__(256) void stft_kernel(gs_spectral_plan p, const float* __restrict__ wave, int wave_len, int front_pad,
                                                    float* __restrict__ o0, float* __restrict__ o1, T* __restrict__ images) {
     __shared__ float2 z[1024];
@@ -95,11 +97,20 @@ __global__ __launch_bounds__(256) void stft_kernel(gs_spectral_plan p, const flo
         __syncthreads();
         for (int m = threadIdx.x; m < H; m += blockDim.x) {
             float am = 0.f, ap = 0.f;
-            for (int j = 0; j < p.maxnz; ++j) {
-                const int f = p.mel_idx[m * p.maxnz + j];
-                const float w = p.mel_val[m * p.maxnz + j];
-                am += smag[f] * w;
-                ap += sph[f] * w;
+            if (MZ > 0) {
+                int f[MZ > 0 ? MZ : 1];
+                float w[MZ > 0 ? MZ : 1];
+#pragma unroll
+                for (int j = 0; j < MZ; ++j) { f[j] = p.mel_idx[j * H + m]; w[j] = p.mel_val[j * H + m]; }
+#pragma unroll
+                for (int j = 0; j < MZ; ++j) { am += smag[f[j]] * w[j]; ap += sph[f[j]] * w[j]; }   // (ascending bins: the oracle's order)
+            } else {
+                for (int j = 0; j < p.maxnz; ++j) {
+                    const int f = p.mel_idx[j * H + m];
+                    const float w = p.mel_val[j * H + m];
+                    am += smag[f] * w;
+                    ap += sph[f] * w;
+                }
             }
             DT<T>::st(images + (row + m) * 2, (logf(am + 1.0e-6f) + 3.76f) / 10.05f);
             o0[row + m] = ap;
@@ -115,7 +126,7 @@ static __global__ void mel_project_kernel(gs_spectral_plan p, const float* __res
         const int m = i % H;
         const float* r = in + (i / H) * H;
         float a = 0.f;
-        for (int j = 0; j < p.maxnz; ++j) a += r[p.mel_idx[m * p.maxnz + j]] * p.mel_val[m * p.maxnz + j];
+        for (int j = 0; j < p.maxnz; ++j) a += r[p.mel_idx[j * H + m]] * p.mel_val[j * H + m];
         out[i] = a;
     }
 }
@@ -131,27 +142,37 @@ __global__ void if_unwrap_kernel(gs_spectral_plan p, const float* __restrict__ m
     const float pi = 3.14159274101257324f;  // float32(np.pi)
     const float two_pi = pi * 2.0f;
     float prev_p = 0.f, prev_u = 0.f, cum = 0.f;
-    for (int t = 0; t < TT; ++t) {
-        const long o = ((long)b * TT + t) * H + m;
-        const float ph = mel_phase[o];
-        float v;
-        if (t == 0) {
-            prev_u = ph;
-            v = ph / pi;
-        } else {
-            const float d = ph - prev_p;
-            float md = fmodf(d + pi, two_pi);
-            if (md < 0.f) md += two_pi;
-            md -= pi;
-            if (md == -pi && d > 0.f) md = pi;
-            cum += md - d;
-            const float u = ph + cum;
-            v = (u - prev_u) / pi;
-            prev_u = u;
+    // the recurrence is sequential in t but its inputs are not: eight phases are fetched per trip (one load per step leaves
+    // 128 dependent memory latencies per thread)
+    for (int t0 = 0; t0 < TT; t0 += 8) {
+        float phs[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) phs[k] = t0 + k < TT ? mel_phase[((long)b * TT + t0 + k) * H + m] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int t = t0 + k;
+            if (t >= TT) break;
+            const long o = ((long)b * TT + t) * H + m;
+            const float ph = phs[k];
+            float v;
+            if (t == 0) {
+                prev_u = ph;
+                v = ph / pi;
+            } else {
+                const float d = ph - prev_p;
+                float md = fmodf(d + pi, two_pi);
+                if (md < 0.f) md += two_pi;
+                md -= pi;
+                if (md == -pi && d > 0.f) md = pi;
+                cum += md - d;
+                const float u = ph + cum;
+                v = (u - prev_u) / pi;
+                prev_u = u;
+            }
+            prev_p = ph;
+            if (MODE == 0) out[o] = v;
+            else DT<T>::st(images + o * 2 + 1, v);
         }
-        prev_p = ph;
-        if (MODE == 0) out[o] = v;
-        else DT<T>::st(images + o * 2 + 1, v);
     }
 }
 
@@ -303,9 +324,10 @@ extern "C" int gs_spectral_plan_create(gs_spectral_plan** out, int frame_length,
     for (int k = 0; k <= H; ++k) twp[k] = make_float2((float)cos(-2.0 * M_PI * k / frame_length), (float)sin(-2.0 * M_PI * k / frame_length));
     int maxnz = 1;
     for (int m = 0; m < H; ++m) { int c = 0; for (int f = 0; f < H; ++f) if (mel_dense[(long)f * H + m] != 0.f) ++c; if (c > maxnz) maxnz = c; }
+    if (maxnz <= 8) maxnz = (maxnz + 1) & ~1;   // even widths have an unrolled kernel instantiation (padding = weight 0 on bin 0)
     std::vector<int> idx((long)H * maxnz, 0);
     std::vector<float> val((long)H * maxnz, 0.f);
-    for (int m = 0; m < H; ++m) { int c = 0; for (int f = 0; f < H; ++f) { const float w = mel_dense[(long)f * H + m]; if (w != 0.f) { idx[(long)m * maxnz + c] = f; val[(long)m * maxnz + c] = w; ++c; } } }
+    for (int m = 0; m < H; ++m) { int c = 0; for (int f = 0; f < H; ++f) { const float w = mel_dense[(long)f * H + m]; if (w != 0.f) { idx[(long)c * H + m] = f; val[(long)c * H + m] = w; ++c; } } }
     p->maxnz = maxnz;
     GS_HIP_OK(hipMalloc(&p->hann, frame_length * sizeof(float)));
     GS_HIP_OK(hipMalloc(&p->inv_window, frame_length * sizeof(float)));
@@ -338,7 +360,7 @@ extern "C" int gs_spectral_plan_destroy(gs_spectral_plan* p) {
 extern "C" int gs_stft_fwd(const gs_spectral_plan* p, const float* wave, int batch, int wave_len, int front_pad, float* magnitude,
                            float* phase, void* stream) {
     GS_CHECK_ARG(p && batch > 0 && wave_len > 0, "stft_fwd: bad args");
-    hipLaunchKernelGGL((stft_kernel<float, 0>), dim3(p->time_steps, batch), dim3(256), 0, as_stream(stream), *p, wave, wave_len, front_pad,
+    hipLaunchKernelGGL((stft_kernel<float, 0, 0>), dim3(p->time_steps, batch), dim3(256), 0, as_stream(stream), *p, wave, wave_len, front_pad,
                        magnitude, phase, (float*)nullptr);
     GS_CHECK_LAUNCH();
     return 0;
@@ -371,10 +393,12 @@ extern "C" int gs_stft_mel_if_fwd(const gs_spectral_plan* p, const float* wave, 
     if (ws_bytes < gs_stft_mel_if_workspace_bytes(p, batch)) return fail(GS_ERR_WORKSPACE, "stft_mel_if_fwd: workspace too small");
     hipStream_t st = as_stream(stream);
     float* mel_phase = (float*)ws;
+#define GS_STFT(MZV) hipLaunchKernelGGL((stft_kernel<T, 1, MZV>), dim3(p->time_steps, batch), dim3(256), 0, st, *p, wave, wave_len, front_pad, mel_phase, (float*)nullptr, (T*)images)
     GS_DISPATCH_DTYPE(dtype, {
-        hipLaunchKernelGGL((stft_kernel<T, 1>), dim3(p->time_steps, batch), dim3(256), 0, st, *p, wave, wave_len, front_pad, mel_phase, (float*)nullptr, (T*)images);
+        if (p->maxnz == 2) GS_STFT(2); else if (p->maxnz == 4) GS_STFT(4); else if (p->maxnz == 6) GS_STFT(6); else if (p->maxnz == 8) GS_STFT(8); else GS_STFT(0);
         hipLaunchKernelGGL((if_unwrap_kernel<T, 1>), dim3(cdiv((long)batch * p->nbins, 256)), dim3(256), 0, st, *p, mel_phase, (float*)nullptr, (T*)images, batch);
     });
+#undef GS_STFT
     GS_CHECK_LAUNCH();
     return 0;
 }
