@@ -4,7 +4,7 @@ set -e
 cd "$(dirname "$0")"
 OUT=${1:-..}
 mkdir -p obj
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result $GS_EXTRA_FLAGS"
 pids=()
 for f in conv_igemm conv_api elementwise small_ops spectral; do
   [ -f $f.hip ] || continue
