@@ -39,51 +39,92 @@ __global__ void weight_prep_kernel(const float* __restrict__ w, T* __restrict__ 
 template <int L>
 static __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ gw, float* __restrict__ gb, int nslices,
                                                                   int taps, int ic, int oc, float alpha, int transpose, int accumulate) {
+    // a thread sums 4 consecutive elements (one 16-byte load per slice) over its share of the slices; EPB element quads per block
     constexpr int EPB = 256 / L;
-    __shared__ float red[256];
+    __shared__ float4 red[256];
     const long total = (long)taps * ic * oc;
-    const long pstride = total + (gb ? oc : 0);   // a slice = the taps (+ one row of bias sums when gb is given)
-    const long e = (long)blockIdx.x * EPB + (threadIdx.x % EPB);
+    const long pstride = total + (gb ? oc : 0);   // a slice = the taps (+ one row of bias sums when gb is given); multiple of 4
+    const long e = ((long)blockIdx.x * EPB + (threadIdx.x % EPB)) * 4;
     const int sl = threadIdx.x / EPB;
-    float s0 = 0.f, s1 = 0.f;
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
     if (e < pstride) {
         int k = sl;
         for (; k + L < nslices; k += 2 * L) {
-            s0 += part[(long)k * pstride + e];
-            s1 += part[(long)(k + L) * pstride + e];
+            const float4 a = *reinterpret_cast<const float4*>(part + (long)k * pstride + e);
+            const float4 b = *reinterpret_cast<const float4*>(part + (long)(k + L) * pstride + e);
+            s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+            s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
         }
-        if (k < nslices) s0 += part[(long)k * pstride + e];
+        if (k < nslices) {
+            const float4 a = *reinterpret_cast<const float4*>(part + (long)k * pstride + e);
+            s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+        }
     }
-    red[threadIdx.x] = s0 + s1;
+    red[threadIdx.x] = make_float4(s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w);
     __syncthreads();
     if (sl == 0 && e < pstride) {
-        float s = 0.f;
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int j = 0; j < L; ++j) s += red[threadIdx.x + j * EPB];
+        for (int j = 0; j < L; ++j) {
+            const float4 v = red[threadIdx.x + j * EPB];
+            t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+        }
+        const float s[4] = {t.x, t.y, t.z, t.w};
         if (e >= total) {   // bias gradient: no equalized-LR scale
-            float* o = gb + (e - total);
-            *o = accumulate ? *o + s : s;
+            float4* o = reinterpret_cast<float4*>(gb + (e - total));
+            const float4 old = accumulate ? *o : make_float4(0.f, 0.f, 0.f, 0.f);
+            *o = make_float4(old.x + s[0], old.y + s[1], old.z + s[2], old.w + s[3]);
             return;
         }
-        s *= alpha;
-        long dst = e;
-        if (transpose) {
-            const int o = e % oc;
-            const int i = (e / oc) % ic;
-            const int t = e / ((long)ic * oc);
-            dst = ((long)t * oc + o) * ic + i;
+        if (!transpose) {
+            float4* o = reinterpret_cast<float4*>(gw + e);
+            const float4 old = accumulate ? *o : make_float4(0.f, 0.f, 0.f, 0.f);
+            *o = make_float4(old.x + s[0] * alpha, old.y + s[1] * alpha, old.z + s[2] * alpha, old.w + s[3] * alpha);
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const long ee = e + c;
+                const int o = ee % oc;
+                const int i = (ee / oc) % ic;
+                const int tp = ee / ((long)ic * oc);
+                const long dst = ((long)tp * oc + o) * ic + i;
+                gw[dst] = accumulate ? gw[dst] + s[c] * alpha : s[c] * alpha;
+            }
         }
-        gw[dst] = accumulate ? gw[dst] + s : s;
     }
+}
+
+// element counts that are not a multiple of 4 (odd channel counts of the direct kernels): one element per thread
+static __global__ __launch_bounds__(256) void wgrad_reduce_scalar_kernel(const float* __restrict__ part, float* __restrict__ gw, int nslices, int taps, int ic,
+                                                                         int oc, float alpha, int transpose, int accumulate) {
+    const long total = (long)taps * ic * oc;
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    float s = 0.f;
+    for (int k = 0; k < nslices; ++k) s += part[(long)k * total + e];
+    s *= alpha;
+    long dst = e;
+    if (transpose) {
+        const int o = e % oc;
+        const int i = (e / oc) % ic;
+        const int t = e / ((long)ic * oc);
+        dst = ((long)t * oc + o) * ic + i;
+    }
+    gw[dst] = accumulate ? gw[dst] + s : s;
 }
 
 static inline size_t wgrad_reduce_extra(long nslices, long total) { (void)nslices; (void)total; return 0; }
 static inline void wgrad_reduce_launch(float* part, float* gw, float* gb, int nslices, int taps, int ic, int oc, float alpha, int transpose, int accumulate, hipStream_t st) {
-    const long n = (long)taps * ic * oc + (gb ? oc : 0);
+    if ((((long)taps * ic * oc) & 3) != 0 || (gb && (oc & 3) != 0)) {
+        const long total = (long)taps * ic * oc;   // (gb never comes with such shapes: the fused bias path needs oc % 32 == 0)
+        hipLaunchKernelGGL(wgrad_reduce_scalar_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, part, gw, nslices, taps, ic, oc, alpha, transpose, accumulate);
+        return;
+    }
+    const long n4 = ((long)taps * ic * oc + (gb ? oc : 0)) / 4;   // element quads
     if (nslices <= 32) {
-        hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, part, gw, gb, nslices, taps, ic, oc, alpha, transpose, accumulate);
+        hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3((unsigned)((n4 + 63) / 64)), dim3(256), 0, st, part, gw, gb, nslices, taps, ic, oc, alpha, transpose, accumulate);
     } else {
-        hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, st, part, gw, gb, nslices, taps, ic, oc, alpha, transpose, accumulate);
+        hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, st, part, gw, gb, nslices, taps, ic, oc, alpha, transpose, accumulate);
     }
 }
 
