@@ -831,35 +831,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_2x2_kernel(
     }
     const unsigned ximg = (unsigned)Hi * Wi * IC * 2, gimg = (unsigned)Hb * Wb * OC * 2;
 
-    auto issue_tile = [&](int tile, int buf) __attribute__((always_inline)) {
-        int b = tile;
-        const int tile_x = b % tiles_x;
-        b /= tiles_x;
-        const int tile_y = b % tiles_y;
-        const int n = b / tiles_y;
-        const int by = tile_y * TH, bx = tile_x * TW;
-        const int oy0 = S2 ? 2 * by : by - 1;
-        const int ox0 = S2 ? 2 * bx : bx - 1;
-        const i32x4 rs_x = make_rsrc(reinterpret_cast<const unsigned char*>(x) + (size_t)n * ximg, ximg);
-        const i32x4 rs_g = make_rsrc(reinterpret_cast<const unsigned char*>(gy) + (size_t)n * gimg, gimg);
-        const int xorg = ((oy0 * Wi + ox0) * IC + ic0) * 2;
-        const unsigned a_x = a_base + buf * BUF, a_g = a_x + 2 * XPL;
-#pragma unroll
-        for (int k = 0; k < XK; ++k) {
-            const unsigned v = (unsigned)(ox0 + x_lx[k]) < (unsigned)Wi ? (unsigned)(xorg + x_voff[k]) : 0x80000000u;
-            lds_dma16(a_x + (wv + 4 * k) * 1024, v, rs_x);
-            lds_dma16(a_x + XPL + (wv + 4 * k) * 1024, v == 0x80000000u ? v : v + 64, rs_x);
-        }
-#pragma unroll
-        for (int k = 0; k < GK; ++k) {
-            const int pix = (wv + 4 * k) * 16 + (lane >> 2);
-            const int gy_ = by + pix / TW, gx_ = bx + pix % TW;
-            const unsigned v = gy_ < Hb && gx_ < Wb ? (unsigned)(((gy_ * Wb + gx_) * OC + oc0) * 2 + (lane & 3) * 16) : 0x80000000u;
-            lds_dma16(a_g + (wv + 4 * k) * 1024, v, rs_g);
-            lds_dma16(a_g + GPL + (wv + 4 * k) * 1024, v == 0x80000000u ? v : v + 64, rs_g);
-        }
-    };
-
     f32x16 acc[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
@@ -869,42 +840,107 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_2x2_kernel(
     const bool do_bias = with_bias && it == 0 && ic0 == 0;
     float accb = 0.f;
 
+    // one DMA piece of a tile (q in [0, NPIECE)): patch plane 0 / 1 pieces first, then the gradient planes
+    int n_t = 0, by_t = 0, bx_t = 0, ox0_t = 0, xorg_t = 0;
+    i32x4 rs_xt = make_rsrc(x, ximg), rs_gt = make_rsrc(gy, gimg);
+    auto tile_setup = [&](int tile) __attribute__((always_inline)) {
+        int b = tile;
+        const int tile_x = b % tiles_x;
+        b /= tiles_x;
+        const int tile_y = b % tiles_y;
+        n_t = b / tiles_y;
+        by_t = tile_y * TH;
+        bx_t = tile_x * TW;
+        const int oy0 = S2 ? 2 * by_t : by_t - 1;
+        ox0_t = S2 ? 2 * bx_t : bx_t - 1;
+        rs_xt = make_rsrc(reinterpret_cast<const unsigned char*>(x) + (size_t)n_t * ximg, ximg);
+        rs_gt = make_rsrc(reinterpret_cast<const unsigned char*>(gy) + (size_t)n_t * gimg, gimg);
+        xorg_t = ((oy0 * Wi + ox0_t) * IC + ic0) * 2;
+    };
+    auto issue_piece = [&](int q, int bufi) __attribute__((always_inline)) {
+        const unsigned a_x = a_base + bufi * BUF, a_g = a_x + 2 * XPL;
+        if (q < 2 * XK) {
+            const int k = q >> 1, pl = q & 1;
+            unsigned v = (unsigned)(ox0_t + x_lx[k]) < (unsigned)Wi ? (unsigned)(xorg_t + x_voff[k]) : 0x80000000u;
+            if (pl && v != 0x80000000u) v += 64;
+            lds_dma16(a_x + pl * XPL + (wv + 4 * k) * 1024, v, rs_xt);
+        } else {
+            const int k = (q - 2 * XK) >> 1, pl = (q - 2 * XK) & 1;
+            const int pix = (wv + 4 * k) * 16 + (lane >> 2);
+            const int gy_ = by_t + pix / TW, gx_ = bx_t + pix % TW;
+            unsigned v = gy_ < Hb && gx_ < Wb ? (unsigned)(((gy_ * Wb + gx_) * OC + oc0) * 2 + (lane & 3) * 16) : 0x80000000u;
+            if (pl && v != 0x80000000u) v += 64;
+            lds_dma16(a_g + pl * GPL + (wv + 4 * k) * 1024, v, rs_gt);
+        }
+    };
+
+    // fragments of one 16-pixel group: the gradient columns (2 transposing reads) and, per kernel row, the 3 (stride 1) or
+    // 5 (stride 2) reads of the input window.  Two sets: the reads of group g+1 are issued before the MFMAs of group g.
+    constexpr int XR = S2 ? 5 : 3;
+    constexpr int NG = NP / 16;
+    uint2 fb[2][2], fx[2][3][XR];
+    auto load_group = [&](int g, int fbuf, const unsigned char* xpl, const unsigned char* gpl) __attribute__((always_inline)) {
+        const int ty = (g * 16) / TW, tx0 = (g * 16) % TW + 8 * hi;
+        const unsigned char* gp = gpl + (ty * TW + tx0 + t_row) * 64 + t_col;
+        fb[fbuf][0] = lds_tr16(gp);
+        fb[fbuf][1] = lds_tr16(gp + 4 * 64);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const unsigned char* xp = xpl + (((ty * S + ky) * PW + tx0 * S) + t_row * S) * 64 + t_col;
+            if (!S2) {
+                fx[fbuf][ky][0] = lds_tr16(xp); fx[fbuf][ky][1] = lds_tr16(xp + 4 * 64); fx[fbuf][ky][2] = lds_tr16(xp + 8 * 64);
+            } else {
+                fx[fbuf][ky][0] = lds_tr16(xp); fx[fbuf][ky][1] = lds_tr16(xp + 8 * 64); fx[fbuf][ky][2] = lds_tr16(xp + 16 * 64);
+                fx[fbuf][ky][3] = lds_tr16(xp + 64); fx[fbuf][ky][4] = lds_tr16(xp + 9 * 64);
+            }
+        }
+    };
+    auto compute_group = [&](int fbuf) __attribute__((always_inline)) {
+        const uint2 b0 = fb[fbuf][0], b1 = fb[fbuf][1];
+        const bf16x8 bfrag = mk_frag(b0.x, b0.y, b1.x, b1.y);
+        if (do_bias) { add_bf16_pair(accb, b0.x); add_bf16_pair(accb, b0.y); add_bf16_pair(accb, b1.x); add_bf16_pair(accb, b1.y); }
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            if (!S2) {
+                const uint2 d0 = fx[fbuf][ky][0], d1 = fx[fbuf][ky][1], d2 = fx[fbuf][ky][2];
+                acc[ky * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk_frag(d0.x, d0.y, d1.x, d1.y), bfrag, acc[ky * 3 + 0], 0, 0, 0);
+                acc[ky * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk_frag(shr16(d0.y, d0.x), shr16(d1.x, d0.y), shr16(d1.y, d1.x), shr16(d2.x, d1.y)), bfrag, acc[ky * 3 + 1], 0, 0, 0);
+                acc[ky * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk_frag(d0.y, d1.x, d1.y, d2.x), bfrag, acc[ky * 3 + 2], 0, 0, 0);
+            } else {
+                // even columns 2(p)+0 / +2 share a 9-pixel window; odd columns 2(p)+1 are their own 8-pixel window
+                const uint2 e0 = fx[fbuf][ky][0], e1 = fx[fbuf][ky][1], e2 = fx[fbuf][ky][2], o0 = fx[fbuf][ky][3], o1 = fx[fbuf][ky][4];
+                acc[ky * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk_frag(e0.x, e0.y, e1.x, e1.y), bfrag, acc[ky * 3 + 0], 0, 0, 0);
+                acc[ky * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk_frag(o0.x, o0.y, o1.x, o1.y), bfrag, acc[ky * 3 + 1], 0, 0, 0);
+                acc[ky * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk_frag(shr16(e0.y, e0.x), shr16(e1.x, e0.y), shr16(e1.y, e1.x), shr16(e2.x, e1.y)), bfrag, acc[ky * 3 + 2], 0, 0, 0);
+            }
+        }
+    };
+
     int buf = 0;
-    if (slice < ntiles) issue_tile(slice, 0);
+    if (slice < ntiles) {
+        tile_setup(slice);
+#pragma unroll
+        for (int q = 0; q < NPIECE; ++q) issue_piece(q, 0);
+    }
+    constexpr int PPG = (NPIECE + NG - 1) / NG;   // DMA pieces of the next tile issued per pixel group of this one
     for (int tile = slice; tile < ntiles; tile += nslices) {
         const bool more = tile + nslices < ntiles;
-        if (more) {
-            issue_tile(tile + nslices, buf ^ 1);
-            wait_vmcnt(NPIECE);   // this tile has landed; the next one stays in flight
-        } else {
-            wait_vmcnt(0);
-        }
+        wait_vmcnt(0);    // this tile has landed (the next one is issued below, under the MFMAs)
         block_barrier();
+        if (more) tile_setup(tile + nslices);
         const unsigned char* const xpl = lds_raw + buf * BUF + it * XPL;
         const unsigned char* const gpl = lds_raw + buf * BUF + 2 * XPL + ot * GPL;
-#pragma unroll 1
-        for (int g = 0; g < NP / 16; ++g) {
-            const int ty = (g * 16) / TW, tx0 = (g * 16) % TW + 8 * hi;
-            const unsigned char* gp = gpl + (ty * TW + tx0 + t_row) * 64 + t_col;
-            const uint2 b0 = lds_tr16(gp), b1 = lds_tr16(gp + 4 * 64);
-            const bf16x8 bfrag = mk_frag(b0.x, b0.y, b1.x, b1.y);
-            if (do_bias) { add_bf16_pair(accb, b0.x); add_bf16_pair(accb, b0.y); add_bf16_pair(accb, b1.x); add_bf16_pair(accb, b1.y); }
+        load_group(0, 0, xpl, gpl);
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                const unsigned char* xp = xpl + (((ty * S + ky) * PW + tx0 * S) + t_row * S) * 64 + t_col;
-                if (!S2) {
-                    const uint2 d0 = lds_tr16(xp), d1 = lds_tr16(xp + 4 * 64), d2 = lds_tr16(xp + 8 * 64);
-                    acc[ky * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk_frag(d0.x, d0.y, d1.x, d1.y), bfrag, acc[ky * 3 + 0], 0, 0, 0);
-                    acc[ky * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk_frag(shr16(d0.y, d0.x), shr16(d1.x, d0.y), shr16(d1.y, d1.x), shr16(d2.x, d1.y)), bfrag, acc[ky * 3 + 1], 0, 0, 0);
-                    acc[ky * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk_frag(d0.y, d1.x, d1.y, d2.x), bfrag, acc[ky * 3 + 2], 0, 0, 0);
-                } else {
-                    const uint2 e0 = lds_tr16(xp), e1 = lds_tr16(xp + 8 * 64), e2 = lds_tr16(xp + 16 * 64);
-                    const uint2 o0 = lds_tr16(xp + 64), o1 = lds_tr16(xp + 9 * 64);
-                    acc[ky * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk_frag(e0.x, e0.y, e1.x, e1.y), bfrag, acc[ky * 3 + 0], 0, 0, 0);
-                    acc[ky * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk_frag(o0.x, o0.y, o1.x, o1.y), bfrag, acc[ky * 3 + 1], 0, 0, 0);
-                    acc[ky * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk_frag(shr16(e0.y, e0.x), shr16(e1.x, e0.y), shr16(e1.y, e1.x), shr16(e2.x, e1.y)), bfrag, acc[ky * 3 + 2], 0, 0, 0);
-                }
+        for (int g = 0; g < NG; ++g) {
+            if (g + 1 < NG) load_group(g + 1, (g + 1) & 1, xpl, gpl);
+            if (more) {
+#pragma unroll
+                for (int q = g * PPG; q < (g + 1) * PPG && q < NPIECE; ++q) issue_piece(q, buf ^ 1);
             }
+            __builtin_amdgcn_sched_barrier(0);
+            compute_group(g & 1);
+            __builtin_amdgcn_sched_barrier(0);
         }
         block_barrier();  // every wave is done with this buffer: the next iteration may overwrite it
         buf ^= 1;
