@@ -1031,6 +1031,8 @@ static int dispatch_igemm(ConvP p, hipStream_t st) {
     if constexpr (MODE == MODE_T2) {
         if (resident_ok && Wb >= 64) return launch_igemm<T, MODE, 1, 2, 64, 9, true, GS_TOP_D>(p, st);
         if (!a2) return launch_igemm<T, MODE, 1, 1, 32, 3>(p, st);
+        // small layers (no more blocks than CUs) are a serial chain of stages: all 9 taps per stage = a third of the barriers
+        if (items64(1) <= num_cus()) { if (Wb >= 32) return launch_igemm<T, MODE, 2, 1, 32, 9>(p, st); return launch_igemm<T, MODE, 2, 1, 16, 9>(p, st); }
         if (Wb >= 32) return launch_igemm<T, MODE, 2, 1, 32, 3>(p, st);
         return launch_igemm<T, MODE, 2, 1, 16, 3>(p, st);
     } else if constexpr (MODE == MODE_S2) {
@@ -1045,6 +1047,7 @@ static int dispatch_igemm(ConvP p, hipStream_t st) {
         // stream is per MFMA -- take the largest pixel tile that still gives every CU a block
         if (Wb >= 32 && items64(4) >= num_cus()) return launch_igemm<T, MODE, 2, 4, 32, 3>(p, st);
         if (Wb >= 32 && items64(2) >= num_cus()) return launch_igemm<T, MODE, 2, 2, 32, 3>(p, st);
+        if (items64(1) <= num_cus()) { if (Wb >= 32) return launch_igemm<T, MODE, 2, 1, 32, 9>(p, st); return launch_igemm<T, MODE, 2, 1, 16, 9>(p, st); }
         if (Wb >= 32) return launch_igemm<T, MODE, 2, 1, 32, 3>(p, st);
         return launch_igemm<T, MODE, 2, 1, 16, 3>(p, st);
     }
