@@ -148,10 +148,9 @@ __global__ __launch_bounds__(256) void thin_expand_kernel(const T* __restrict__ 
         for (int i = 0; i < IC; ++i) wr[v][i] = wp[(oc0 + v) * IC + i] * alpha;
     }
     const long ppb = 256 / groups;  // pixels per block pass
-    for (long pix = (long)blockIdx.x * ppb + threadIdx.x / groups; pix < P; pix += (long)gridDim.x * ppb) {
-        float xv[IC];
-#pragma unroll
-        for (int i = 0; i < IC; ++i) xv[i] = DT<T>::ld(x + pix * IC + i);
+    const long stride = (long)gridDim.x * ppb;
+    long pix = (long)blockIdx.x * ppb + threadIdx.x / groups;
+    auto one = [&](long px, const float* xv) __attribute__((always_inline)) {
         float o[WN];
 #pragma unroll
         for (int v = 0; v < WN; ++v) {
@@ -160,7 +159,22 @@ __global__ __launch_bounds__(256) void thin_expand_kernel(const T* __restrict__ 
             for (int i = 0; i < IC; ++i) a += xv[i] * wr[v][i];
             o[v] = thin_act(a, act);
         }
-        st_wide<T>(y + pix * OC + oc0, o);
+        st_wide<T>(y + px * OC + oc0, o);
+    };
+    for (; pix + 3 * stride < P; pix += 4 * stride) {   // four pixels per trip (loads first)
+        float xv[4][IC];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int i = 0; i < IC; ++i) xv[k][i] = DT<T>::ld(x + (pix + k * stride) * IC + i);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) one(pix + k * stride, xv[k]);
+    }
+    for (; pix < P; pix += stride) {
+        float xv[IC];
+#pragma unroll
+        for (int i = 0; i < IC; ++i) xv[i] = DT<T>::ld(x + pix * IC + i);
+        one(pix, xv);
     }
 }
 
@@ -394,7 +408,21 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const T* __restrict__ w
     if (p1 > npix) p1 = npix;
     float acc[4][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
     if (r < rpi) {
-        for (long p = p0 + r; p < p1; p += rpi) {
+        long p = p0 + r;
+        for (; p + 3 * rpi < p1; p += 4 * rpi) {   // four pixels per trip: their loads are in flight together
+            float w4[4][4], t[4][2];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                ld4(wide + (p + k * rpi) * C + q * 4, w4[k]);
+                t[k][0] = DT<T>::ld(thin + (p + k * rpi) * 2);
+                t[k][1] = DT<T>::ld(thin + (p + k * rpi) * 2 + 1);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { acc[e][0] += w4[k][e] * t[k][0]; acc[e][1] += w4[k][e] * t[k][1]; }
+        }
+        for (; p < p1; p += rpi) {
             float w4[4];
             ld4(wide + p * C + q * 4, w4);
             const float t0 = DT<T>::ld(thin + p * 2), t1 = DT<T>::ld(thin + p * 2 + 1);
@@ -435,7 +463,7 @@ static void thin_wgrad_geometry(long npix, int c, long* nslices, long* pps) {
 }
 
 static void wgrad_direct_geometry(long npix, long* nslices, long* pps) {
-    long ns = (npix + 1023) / 1024;
+    long ns = (npix + 63) / 64;   // a thread walks its slice serially (index arithmetic + two dependent loads per pixel): keep it short
     if (ns > 1024) ns = 1024;
     if (ns < 1) ns = 1;
     *pps = (npix + ns - 1) / ns;
