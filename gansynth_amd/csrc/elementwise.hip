@@ -291,9 +291,13 @@ static int channel_sum_parts(long p, int c) {
 // MODE 0: y = x*r ; MODE 1: gx = r*(g - y*mean(y*g)) ; MODE 2: second-order term (see header).
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void pixel_norm_kernel(const T* __restrict__ a0, const T* __restrict__ a1, const T* __restrict__ a2,
-                                                         T* __restrict__ out, long p, int c, float eps, int act) {
-    // `act` (MODE 1 only): x is itself the output of that activation and the caller wants the gradient w.r.t. the
-    // PRE-activation: gx is multiplied by act'(.) expressed through x (the separate act_bwd pass disappears)
+                                                         T* __restrict__ out, long p, int c, float eps, int act, int pre,
+                                                         const T* __restrict__ addend) {
+    // x is itself the output of an activation in the generator blocks (conv -> act -> norm), and the passes around this
+    // kernel fold into it:
+    //   act    (MODE 1): the result is multiplied by act'(.) through x  -> gradient w.r.t. the PRE-activation
+    //   addend (MODE 1): added to the norm's gradient before that       -> a second gradient into x (second-order terms)
+    //   pre    (MODE 1, 2): the incoming g / gg is first multiplied by act'(.) through x (transpose of the `act` form)
     // a0 = x (MODE 0) | g (MODE 1) | gg (MODE 2);  a1 = x (MODE 1) | g (MODE 2);  a2 = x (MODE 2)
     const int quads = c >> 2;
     const int L = quads < 64 ? quads : 64;       // lanes per row (power of two)
@@ -337,17 +341,22 @@ __global__ __launch_bounds__(256) void pixel_norm_kernel(const T* __restrict__ a
                     if (ok) ld4(a0 + row * c + (k * L + sub) * 4, gv[k]);
                     else gv[k][0] = gv[k][1] = gv[k][2] = gv[k][3] = 0.f;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) q += xv[k][e] * r * gv[k][e];
+                    for (int e = 0; e < 4; ++e) {
+                        if (pre == GS_ACT_LRELU) gv[k][e] = xv[k][e] > 0.f ? gv[k][e] : 0.2f * gv[k][e];
+                        else if (pre == GS_ACT_TANH) gv[k][e] *= 1.f - xv[k][e] * xv[k][e];
+                        q += xv[k][e] * r * gv[k][e];
+                    }
                 }
             for (int o = L >> 1; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
             q *= invc;
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 if (k < passes && ok) {
-                    float o4[4];
+                    float o4[4], ad[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (addend) ld4(addend + row * c + (k * L + sub) * 4, ad);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        o4[e] = r * (gv[k][e] - xv[k][e] * r * q);
+                        o4[e] = r * (gv[k][e] - xv[k][e] * r * q) + ad[e];
                         if (act == GS_ACT_LRELU) o4[e] = xv[k][e] > 0.f ? o4[e] : 0.2f * o4[e];
                         else if (act == GS_ACT_TANH) o4[e] *= 1.f - xv[k][e] * xv[k][e];
                     }
@@ -365,6 +374,8 @@ __global__ __launch_bounds__(256) void pixel_norm_kernel(const T* __restrict__ a
                     }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
+                        if (pre == GS_ACT_LRELU) ggv[k][e] = xv[k][e] > 0.f ? ggv[k][e] : 0.2f * ggv[k][e];
+                        else if (pre == GS_ACT_TANH) ggv[k][e] *= 1.f - xv[k][e] * xv[k][e];
                         const float yv = xv[k][e] * r;
                         sa += ggv[k][e] * gv[k][e];
                         sp += yv * ggv[k][e];
@@ -607,16 +618,17 @@ extern "C" int gs_act_bwd_bias(const void* g, const void* y, void* gx, float* gb
     return channel_sum_finalize(part, gb, nparts, c, accumulate, st);
 }
 
-static int pixel_norm_launch(int mode, const void* a0, const void* a1, const void* a2, void* out, int64_t p, int c, float eps, int dtype, void* stream, int act = 0) {
+static int pixel_norm_launch(int mode, const void* a0, const void* a1, const void* a2, void* out, int64_t p, int c, float eps, int dtype, void* stream, int act = 0,
+                             int pre = 0, const void* addend = nullptr) {
     GS_CHECK_ARG(p > 0 && c >= 4 && c <= 1024 && (c & (c - 1)) == 0, "pixel_norm: c=%d must be a power of two in [4,1024]", c);
     const int L = (c >> 2) < 64 ? (c >> 2) : 64;
     const long rows_per_block = 4 * (64 / L);
     dim3 grid(ew_grid(((long)p + rows_per_block - 1) / rows_per_block * 256));
     hipStream_t st = as_stream(stream);
     GS_DISPATCH_DTYPE(dtype, {
-        if (mode == 0) hipLaunchKernelGGL((pixel_norm_kernel<T, 0>), grid, dim3(256), 0, st, (const T*)a0, (const T*)a1, (const T*)a2, (T*)out, (long)p, c, eps, act);
-        else if (mode == 1) hipLaunchKernelGGL((pixel_norm_kernel<T, 1>), grid, dim3(256), 0, st, (const T*)a0, (const T*)a1, (const T*)a2, (T*)out, (long)p, c, eps, act);
-        else hipLaunchKernelGGL((pixel_norm_kernel<T, 2>), grid, dim3(256), 0, st, (const T*)a0, (const T*)a1, (const T*)a2, (T*)out, (long)p, c, eps, act);
+        if (mode == 0) hipLaunchKernelGGL((pixel_norm_kernel<T, 0>), grid, dim3(256), 0, st, (const T*)a0, (const T*)a1, (const T*)a2, (T*)out, (long)p, c, eps, act, pre, (const T*)addend);
+        else if (mode == 1) hipLaunchKernelGGL((pixel_norm_kernel<T, 1>), grid, dim3(256), 0, st, (const T*)a0, (const T*)a1, (const T*)a2, (T*)out, (long)p, c, eps, act, pre, (const T*)addend);
+        else hipLaunchKernelGGL((pixel_norm_kernel<T, 2>), grid, dim3(256), 0, st, (const T*)a0, (const T*)a1, (const T*)a2, (T*)out, (long)p, c, eps, act, pre, (const T*)addend);
     });
     GS_CHECK_LAUNCH();
     return 0;
@@ -627,9 +639,16 @@ extern "C" int gs_pixel_norm_fwd(const void* x, void* y, int64_t p, int c, float
 extern "C" int gs_pixel_norm_bwd(const void* g, const void* x, void* gx, int64_t p, int c, float eps, int dtype, void* stream) {
     return pixel_norm_launch(1, g, x, nullptr, gx, p, c, eps, dtype, stream);
 }
-extern "C" int gs_pixel_norm_bwd_act(const void* g, const void* x, void* gx, int64_t p, int c, float eps, int act, int dtype, void* stream) {
-    GS_CHECK_ARG(act == GS_ACT_NONE || act == GS_ACT_LRELU || act == GS_ACT_TANH, "pixel_norm_bwd_act: bad activation %d", act);
-    return pixel_norm_launch(1, g, x, nullptr, gx, p, c, eps, dtype, stream, act);
+static bool pn_act_ok(int a) { return a == GS_ACT_NONE || a == GS_ACT_LRELU || a == GS_ACT_TANH; }
+extern "C" int gs_pixel_norm_bwd_fused(const void* g, const void* x, const void* addend, void* gx, int64_t p, int c, float eps, int pre_act, int post_act,
+                                       int dtype, void* stream) {
+    GS_CHECK_ARG(pn_act_ok(pre_act) && pn_act_ok(post_act), "pixel_norm_bwd_fused: bad activation %d / %d", pre_act, post_act);
+    return pixel_norm_launch(1, g, x, nullptr, gx, p, c, eps, dtype, stream, post_act, pre_act, addend);
+}
+extern "C" int gs_pixel_norm_bwd_bwd_fused(const void* gg, const void* g, const void* x, void* out, int64_t p, int c, float eps, int pre_act, int dtype,
+                                           void* stream) {
+    GS_CHECK_ARG(pn_act_ok(pre_act), "pixel_norm_bwd_bwd_fused: bad activation %d", pre_act);
+    return pixel_norm_launch(2, gg, g, x, out, p, c, eps, dtype, stream, 0, pre_act, nullptr);
 }
 extern "C" int gs_pixel_norm_bwd_bwd(const void* gg, const void* g, const void* x, void* out, int64_t p, int c, float eps, int dtype, void* stream) {
     return pixel_norm_launch(2, gg, g, x, out, p, c, eps, dtype, stream);

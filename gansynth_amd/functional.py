@@ -78,6 +78,27 @@ class _DenseKind(object):
         return _K().dense_bwd_weight(x, gy, alpha, out=out)
 
 
+# ---- gradients w.r.t. data only -------------------------------------------------------------------------------------------
+# tf.gradients(ys, xs) (models.py:47,60: the R1 penalty differentiates w.r.t. the real images, the mode-seeking term w.r.t. the
+# latents) only builds what xs needs.  torch.autograd.grad(..., inputs) prunes nodes, but inside a node a custom Function is
+# still asked for every input that requires grad -- i.e. the weight and bias gradients of every conv on the path, computed and
+# thrown away (a quarter of all weight-gradient launches of an iteration).  The model wraps those two calls in this context.
+_PARAM_GRADS = [True]
+
+
+class data_grads_only(object):
+    def __enter__(self):
+        _PARAM_GRADS.append(False)
+
+    def __exit__(self, *exc):
+        _PARAM_GRADS.pop()
+        return False
+
+
+def _want_params():
+    return _PARAM_GRADS[-1]
+
+
 def _accum_target(param):
     """Where a parameter gradient may be ADDED in place by the producing kernel instead of being returned to autograd
     (which would allocate it and add it into .grad with one more pass): plain backward only (under create_graph the
@@ -146,7 +167,7 @@ class _Bilinear(Function):
         x, w = ctx.saved_tensors
         gx = _BilinearBwdData.apply(gy, w, x.shape, ctx.kind, ctx.alpha) if ctx.needs_input_grad[0] else None
         gw = None
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and _want_params():
             tgt = _accum_target(ctx.wref)
             if tgt is not None:
                 ctx.kind.bwd_weight(x, gy, ctx.alpha, out=tgt)
@@ -229,7 +250,8 @@ class _ConvBiasAct(Function):
     @staticmethod
     def backward(ctx, gz):
         x, w, z = ctx.saved_tensors
-        want_b = ctx.has_bias and ctx.needs_input_grad[2]
+        want_w = ctx.needs_input_grad[1] and _want_params()
+        want_b = ctx.has_bias and ctx.needs_input_grad[2] and _want_params()
         act = ACT_NONE if _take_premasked(ctx, gz) else ctx.act   # (a consumer of z already applied act'(z))
 
         def data_grad(gy):
@@ -242,7 +264,7 @@ class _ConvBiasAct(Function):
             prod._gs_premasked = gx_.data_ptr()
             return gx_
 
-        if want_b and ctx.needs_input_grad[1] and getattr(ctx.kind, "bias_in_wgrad", False):
+        if want_b and want_w and getattr(ctx.kind, "bias_in_wgrad", False):
             tw, tb = _accum_target(ctx.wref), _accum_target(ctx.bref)
             if tw is not None and tb is not None:   # plain backward: weight and bias gradients from the same launches
                 gy = _ActBwd.apply(gz, z, act) if act != ACT_NONE else gz
@@ -252,13 +274,98 @@ class _ConvBiasAct(Function):
         gy, gb = _bias_act_backward(gz, z if act != ACT_NONE else None, act, ctx.bref if want_b else None, want_b)
         gx = data_grad(gy)
         gw = None
-        if ctx.needs_input_grad[1]:
+        if want_w:
             tgt = _accum_target(ctx.wref)
             if tgt is not None:
                 ctx.kind.bwd_weight(x, gy, ctx.alpha, out=tgt)
             else:
                 gw = _BilinearBwdWeight.apply(x, gy, ctx.kind, ctx.alpha).to(w.dtype)
         return gx, gw, gb, None, None, None, None
+
+
+class _PnActBwd(Function):
+    """u = act'(z) * pixel_norm_bwd(g, z): the backward of (activation -> pixel norm) w.r.t. the pre-activation in ONE kernel,
+    differentiable once more (mode-seeking term): with M = diag(act'(z)) constant (leaky relu) and J(z) the symmetric Jacobian
+    of the norm, u = M J g, so  du/dg^T gg = J (M gg)  and  du/dz^T gg = d<M gg, J g>/dz  -- the norm's own first- and
+    second-order kernels with the mask folded in on the input side."""
+
+    @staticmethod
+    def forward(ctx, g, z, eps, act):
+        if act != ACT_LRELU:
+            raise NotImplementedError("_PnActBwd: piecewise-linear activations only (the tanh head has no pixel norm)")
+        ctx.eps, ctx.act = eps, act
+        ctx.save_for_backward(g, z)
+        return _K().pixel_norm_bwd(g, z, eps, act=act)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gg):
+        g, z = ctx.saved_tensors
+        g_g = _K().pixel_norm_bwd(gg, z, ctx.eps, pre_act=ctx.act) if ctx.needs_input_grad[0] else None
+        g_z = _K().pixel_norm_bwd_bwd(gg, g, z, ctx.eps, pre_act=ctx.act) if ctx.needs_input_grad[1] else None
+        return g_g, g_z, None, None
+
+
+class _ConvBiasActNorm(Function):
+    """(y, z) with z = act(alpha * B(x, w) + bias), y = pixel_norm(z): a generator block as one node.  z is returned only so
+    that second-order graphs built on it (the norm's backward is differentiated by the mode-seeking term) send their gradient
+    back here: the plain backward then forms (pixel_norm_bwd(g_y, z) + g_z) * act'(z) in one pass instead of
+    norm-backward, add, activation-backward."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, kind, alpha, act, eps):
+        ctx.kind, ctx.alpha, ctx.act, ctx.eps, ctx.has_bias = kind, alpha, act, eps, bias is not None
+        ctx.wref, ctx.bref = w, bias
+        ctx.set_materialize_grads(False)   # an absent gradient for z must arrive as None, not as a tensor of zeros
+        z = kind.fwd_bias_act(x, w, bias, alpha, act)
+        y = _K().pixel_norm_fwd(z, eps)
+        ctx.save_for_backward(x, w, z)
+        return y, z
+
+    @staticmethod
+    def backward(ctx, g_y, g_z):
+        x, w, z = ctx.saved_tensors
+        want_w = ctx.needs_input_grad[1] and _want_params()
+        want_b = ctx.has_bias and ctx.needs_input_grad[2] and _want_params()
+        if torch.is_grad_enabled():   # create_graph: differentiable pieces
+            gy = _PnActBwd.apply(g_y, z, ctx.eps, ctx.act) if g_y is not None else None
+            if g_z is not None:
+                extra = _ActBwd.apply(g_z, z, ctx.act)
+                gy = extra if gy is None else gy + extra
+            gx = _BilinearBwdData.apply(gy, w, x.shape, ctx.kind, ctx.alpha) if ctx.needs_input_grad[0] else None
+            gw = _BilinearBwdWeight.apply(x, gy, ctx.kind, ctx.alpha).to(w.dtype) if want_w else None
+            gb = _ChannelSum.apply(gy) if want_b else None
+            return gx, gw, gb, None, None, None, None
+        if g_y is None:
+            gy = _K().act_bwd(g_z, z, ctx.act)
+        else:
+            gy = _K().pixel_norm_bwd(g_y, z, ctx.eps, act=ctx.act, addend=g_z)
+        gx = _BilinearBwdData.apply(gy, w, x.shape, ctx.kind, ctx.alpha) if ctx.needs_input_grad[0] else None
+        gw = gb = None
+        tw = _accum_target(ctx.wref) if want_w else None
+        tb = _accum_target(ctx.bref) if want_b else None
+        if tw is not None and tb is not None and getattr(ctx.kind, "bias_in_wgrad", False):
+            ctx.kind.bwd_weight(x, gy, ctx.alpha, out=tw, bias_out=tb)
+            return gx, None, None, None, None, None, None
+        if want_b:
+            if tb is not None:
+                _K().channel_sum(gy, out=tb)
+            else:
+                gb = _K().channel_sum(gy)
+        if want_w:
+            if tw is not None:
+                ctx.kind.bwd_weight(x, gy, ctx.alpha, out=tw)
+            else:
+                gw = ctx.kind.bwd_weight(x, gy, ctx.alpha).to(w.dtype)
+        return gx, gw, gb, None, None, None, None
+
+
+def conv2d_bias_act_norm(x, w, bias, ksize, stride, alpha, act, eps):
+    return _ConvBiasActNorm.apply(x, w, bias, _kind(("conv", ksize, stride)), alpha, act, eps)[0]
+
+
+def conv2d_transpose_bias_act_norm(x, w, bias, alpha, act, eps):
+    return _ConvBiasActNorm.apply(x, w, bias, _kind(("convT",)), alpha, act, eps)[0]
 
 
 def conv2d(x, w, ksize, stride, alpha):
@@ -292,7 +399,7 @@ class _Embedding(Function):
     @staticmethod
     def backward(ctx, gy):
         (idx,) = ctx.saved_tensors
-        return None, _EmbeddingBwd.apply(idx, gy, ctx.rows, ctx.alpha), None, None
+        return None, (_EmbeddingBwd.apply(idx, gy, ctx.rows, ctx.alpha) if _want_params() else None), None, None
 
 
 class _EmbeddingBwd(Function):
@@ -340,7 +447,7 @@ class _BiasAct(Function):
 
     @staticmethod
     def backward(ctx, gz):
-        want_b = ctx.has_bias and ctx.needs_input_grad[1]
+        want_b = ctx.has_bias and ctx.needs_input_grad[1] and _want_params()
         z = ctx.saved_tensors[0] if ctx.act != ACT_NONE else None
         gx, gb = _bias_act_backward(gz, z, ctx.act, ctx.bref if want_b else None, want_b)
         return (gx if ctx.needs_input_grad[0] else None), gb, None

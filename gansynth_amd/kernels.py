@@ -326,23 +326,27 @@ class HipKernels(object):
         _lib.check(self.lib.gs_pixel_norm_fwd(x.data_ptr(), y.data_ptr(), p, c, float(eps), _dt(x), _stream()), "gs_pixel_norm_fwd")
         return y
 
-    def pixel_norm_bwd(self, g, x, eps, act=0):
-        """gx; with `act` (x is itself the output of that activation) gx * act'(.), i.e. the gradient w.r.t. the pre-activation."""
+    def pixel_norm_bwd(self, g, x, eps, act=0, pre_act=0, addend=None):
+        """gx = (pixel_norm_bwd(g * pre_act'(x), x) + addend) * act'(x)   (x: an activation output; see gs_pixel_norm_bwd_fused)."""
         x = _act(x)
         g = _match(g, x)
         p, c = _rows_cols(x)
         gx = torch.empty_like(x)
-        _lib.check(self.lib.gs_pixel_norm_bwd_act(g.data_ptr(), x.data_ptr(), gx.data_ptr(), p, c, float(eps), int(act), _dt(x), _stream()),
-                   "gs_pixel_norm_bwd_act")
+        ap = None
+        if addend is not None:
+            addend = _match(addend, x)
+            ap = addend.data_ptr()
+        _lib.check(self.lib.gs_pixel_norm_bwd_fused(g.data_ptr(), x.data_ptr(), ap, gx.data_ptr(), p, c, float(eps), int(pre_act), int(act), _dt(x),
+                                                    _stream()), "gs_pixel_norm_bwd_fused")
         return gx
 
-    def pixel_norm_bwd_bwd(self, gg, g, x, eps):
+    def pixel_norm_bwd_bwd(self, gg, g, x, eps, pre_act=0):
         x = _act(x)
         gg, g = _match(gg, x), _match(g, x)
         p, c = _rows_cols(x)
         out = torch.empty_like(x)
-        _lib.check(self.lib.gs_pixel_norm_bwd_bwd(gg.data_ptr(), g.data_ptr(), x.data_ptr(), out.data_ptr(), p, c, float(eps), _dt(x), _stream()),
-                   "gs_pixel_norm_bwd_bwd")
+        _lib.check(self.lib.gs_pixel_norm_bwd_bwd_fused(gg.data_ptr(), g.data_ptr(), x.data_ptr(), out.data_ptr(), p, c, float(eps), int(pre_act), _dt(x),
+                                                        _stream()), "gs_pixel_norm_bwd_bwd_fused")
         return out
 
     # --------------------------------------------------------------------- up / down scale

@@ -137,7 +137,8 @@ class GANSynth(object):
         fake_logits = self._label_logits(fake_logits, labels)
         losses = TF.softplus(-real_logits) + TF.softplus(fake_logits)
         if hp.real_gradient_penalty_weight:
-            (real_gradients,) = torch.autograd.grad(real_logits.sum(), real_images, create_graph=True)
+            with F.data_grads_only():   # tf.gradients(real_logits, [real_images]) (models.py:47): no parameter gradients on this pass
+                (real_gradients,) = torch.autograd.grad(real_logits.sum(), real_images, create_graph=True)
             losses = losses + F.sumsq_rows(real_gradients) * hp.real_gradient_penalty_weight
         if hp.get("fake_gradient_penalty_weight", 0.0):
             raise NotImplementedError("fake_gradient_penalty_weight is 0 in the reference configuration (gan_synth_main.py:87)")
@@ -152,7 +153,8 @@ class GANSynth(object):
         losses = TF.softplus(-fake_logits)
         if hp.mode_seeking_loss_weight:
             ones = torch.ones_like(fake_images)  # tf.gradients(ys) sums ys
-            (latent_gradients,) = torch.autograd.grad(fake_images, latents, grad_outputs=ones, create_graph=True)
+            with F.data_grads_only():   # tf.gradients(fake_images, [latents]) (models.py:60)
+                (latent_gradients,) = torch.autograd.grad(fake_images, latents, grad_outputs=ones, create_graph=True)
             mode_seeking = 1.0 / (latent_gradients.float().pow(2).sum(dim=1) + 1.0e-6)
             losses = losses + mode_seeking * hp.mode_seeking_loss_weight
         return losses

@@ -17,6 +17,10 @@ from . import variables
 from .variables import AUTO_REUSE, variable_scope
 
 
+PIXEL_NORM_EPS = 1.0e-12   # ops.pixel_normalization default (ops.py:330)
+_FUSE_NORM = not __import__("os").environ.get("GS_NO_FUSED_NORM")   # A/B switch for measurements
+
+
 def _ilog2(ratio):
     ratio = np.asanyarray(ratio)
     depth = 0
@@ -79,14 +83,15 @@ class PGGAN(object):
             else:
                 with variable_scope("upscale_conv"):
                     x = ops.conv2d_transpose(x, filters=c, kernel_size=[3, 3], strides=[2, 2], use_bias=True,
-                                             variance_scale=2.0, scale_weight=True, activation="leaky_relu")
-                    x = ops.pixel_normalization(x)
+                                             variance_scale=2.0, scale_weight=True, activation="leaky_relu",
+                                             pixel_norm_epsilon=PIXEL_NORM_EPS if _FUSE_NORM else None)   # conv -> leaky_relu -> pixel norm: one node
+                    if not _FUSE_NORM:
+                        x = ops.pixel_normalization(x)
             with variable_scope("conv"):
                 x = ops.conv2d(x, filters=c, kernel_size=[3, 3], use_bias=True, variance_scale=2.0, scale_weight=True,
-                               activation="leaky_relu")
-                # (no `input_activation` here although the norm is the only forward consumer: the mode-seeking term
-                #  differentiates through the norm's backward, which feeds a second gradient into the activation output)
-                x = ops.pixel_normalization(x)
+                               activation="leaky_relu", pixel_norm_epsilon=PIXEL_NORM_EPS if _FUSE_NORM else None)
+                if not _FUSE_NORM:
+                    x = ops.pixel_normalization(x)
         return x
 
     def _g_color_block(self, x, depth):

@@ -161,8 +161,17 @@ int gs_channel_sum(const void* g, float* out, int64_t p, int c, int accumulate, 
  *   (d<gg, bwd(g,x)>/dg = bwd(gg, x): the Jacobian is symmetric) */
 int gs_pixel_norm_fwd(const void* x, void* y, int64_t p, int c, float eps, int dtype, void* stream);
 int gs_pixel_norm_bwd(const void* g, const void* x, void* gx, int64_t p, int c, float eps, int dtype, void* stream);
-/* pixel_norm_bwd whose input x is itself an activation output: gx = pixel_norm_bwd(g, x) * act'(.)|x (gradient w.r.t. the pre-activation) */
-int gs_pixel_norm_bwd_act(const void* g, const void* x, void* gx, int64_t p, int c, float eps, int act, int dtype, void* stream);
+/* The generator blocks are conv -> activation -> pixel norm, i.e. the norm's input x is an activation OUTPUT.  The passes
+ * that surround the norm's gradients fold into them (act'(.) is expressed through x; act = NONE / LRELU / TANH):
+ *   bwd_fused    : gx = (pixel_norm_bwd(g * pre_act'(x), x) + addend) * post_act'(x)      (addend may be NULL)
+ *     post_act  -> gradient w.r.t. the pre-activation (replaces the act_bwd pass that follows);
+ *     addend    -> a second gradient arriving at x (from the second-order graph), summed in the same pass;
+ *     pre_act   -> the transposed form, used when this chain is itself differentiated (mode-seeking term)
+ *   bwd_bwd_fused: out = pixel_norm_bwd_bwd(gg * pre_act'(x), g, x) */
+int gs_pixel_norm_bwd_fused(const void* g, const void* x, const void* addend, void* gx, int64_t p, int c, float eps, int pre_act, int post_act,
+                            int dtype, void* stream);
+int gs_pixel_norm_bwd_bwd_fused(const void* gg, const void* g, const void* x, void* out, int64_t p, int c, float eps, int pre_act, int dtype,
+                                void* stream);
 int gs_pixel_norm_bwd_bwd(const void* gg, const void* g, const void* x, void* out, int64_t p, int c, float eps, int dtype, void* stream);
 
 /* upscale2d / downscale2d (ops.py:283-305).

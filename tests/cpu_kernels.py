@@ -116,13 +116,20 @@ class CpuEmuKernels(object):
     def pixel_norm_fwd(self, x, eps):
         return R.pixel_normalization(x.detach(), eps)
 
-    def pixel_norm_bwd(self, g, x, eps, act=0):
+    def pixel_norm_bwd(self, g, x, eps, act=0, pre_act=0, addend=None):
+        g = g.detach().expand_as(x)
+        if pre_act:
+            g = self.act_bwd(g, x, pre_act)
         with torch.enable_grad():
             xx = x.detach().clone().requires_grad_(True)
-            (gx,) = torch.autograd.grad(R.pixel_normalization(xx, eps), xx, g.detach().expand_as(xx))
+            (gx,) = torch.autograd.grad(R.pixel_normalization(xx, eps), xx, g)
+        if addend is not None:
+            gx = gx + addend.detach()
         return gx if act == 0 else self.act_bwd(gx, x, act)
 
-    def pixel_norm_bwd_bwd(self, gg, g, x, eps):
+    def pixel_norm_bwd_bwd(self, gg, g, x, eps, pre_act=0):
+        if pre_act:
+            gg = self.act_bwd(gg.detach().expand_as(x), x, pre_act)
         with torch.enable_grad():
             xx = x.detach().clone().requires_grad_(True)
             (gx,) = torch.autograd.grad(R.pixel_normalization(xx, eps), xx, g.detach().expand_as(xx), create_graph=True)

@@ -364,5 +364,13 @@ def test_conv2d_bwd_data_with_activation_mask(K, E, case, dtype, act):
 def test_pixel_norm_bwd_with_activation(K, E, shape, dtype):
     x = E.bias_act_fwd(rnd(*shape, seed=1), None, 1).to(dtype).float()
     g = rnd(*shape, seed=2).to(dtype).float()
+    tol = 1e-4 if dtype == torch.float32 else 2e-2
     ref = E.pixel_norm_bwd(g, x, 1e-8, act=1)
-    close(K.pixel_norm_bwd(dev(g, dtype), dev(x, dtype), 1e-8, act=1), ref, rel=1e-4 if dtype == torch.float32 else 2e-2, name="pn bwd * lrelu'")
+    close(K.pixel_norm_bwd(dev(g, dtype), dev(x, dtype), 1e-8, act=1), ref, rel=tol, name="pn bwd * lrelu'")
+    ad = rnd(*shape, seed=3).to(dtype).float()
+    close(K.pixel_norm_bwd(dev(g, dtype), dev(x, dtype), 1e-8, act=1, addend=dev(ad, dtype)), E.pixel_norm_bwd(g, x, 1e-8, act=1, addend=ad), rel=tol,
+          name="(pn bwd + addend) * lrelu'")
+    close(K.pixel_norm_bwd(dev(g, dtype), dev(x, dtype), 1e-8, pre_act=1), E.pixel_norm_bwd(g, x, 1e-8, pre_act=1), rel=tol, name="pn bwd(g * lrelu')")
+    gg = rnd(*shape, seed=4).to(dtype).float()
+    close(K.pixel_norm_bwd_bwd(dev(gg, dtype), dev(g, dtype), dev(x, dtype), 1e-8, pre_act=1), E.pixel_norm_bwd_bwd(gg, g, x, 1e-8, pre_act=1),
+          rel=1e-3 if dtype == torch.float32 else 3e-2, name="pn bwd_bwd(gg * lrelu')")
