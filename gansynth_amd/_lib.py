@@ -52,7 +52,7 @@ SIGNATURES = {
     "gs_pixel_norm_fwd": (I, [P, P, L, I, F, I, P]),
     "gs_pixel_norm_bwd": (I, [P, P, P, L, I, F, I, P]),
     "gs_pixel_norm_bwd_fused": (I, [P, P, P, P, L, I, F, I, I, I, P]),
-    "gs_pixel_norm_bwd_bwd_fused": (I, [P, P, P, P, L, I, F, I, I, P]),
+    "gs_pixel_norm_bwd_bwd_fused": (I, [P, P, P, P, P, L, I, F, I, I, P]),
     "gs_pixel_norm_bwd_bwd": (I, [P, P, P, P, L, I, F, I, P]),
     "gs_upscale2d": (I, [P, P, I, I, I, I, I, I, F, I, P]),
     "gs_blocksum2d": (I, [P, P, I, I, I, I, I, I, F, I, P]),

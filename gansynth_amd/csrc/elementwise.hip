@@ -292,12 +292,13 @@ static int channel_sum_parts(long p, int c) {
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void pixel_norm_kernel(const T* __restrict__ a0, const T* __restrict__ a1, const T* __restrict__ a2,
                                                          T* __restrict__ out, long p, int c, float eps, int act, int pre,
-                                                         const T* __restrict__ addend) {
+                                                         const T* __restrict__ addend, T* __restrict__ out2) {
     // x is itself the output of an activation in the generator blocks (conv -> act -> norm), and the passes around this
     // kernel fold into it:
     //   act    (MODE 1): the result is multiplied by act'(.) through x  -> gradient w.r.t. the PRE-activation
     //   addend (MODE 1): added to the norm's gradient before that       -> a second gradient into x (second-order terms)
     //   pre    (MODE 1, 2): the incoming g / gg is first multiplied by act'(.) through x (transpose of the `act` form)
+    //   out2   (MODE 2): also write pixel_norm_bwd(gg', x) -- the two gradients of a differentiated norm-backward in one pass
     // a0 = x (MODE 0) | g (MODE 1) | gg (MODE 2);  a1 = x (MODE 1) | g (MODE 2);  a2 = x (MODE 2)
     const int quads = c >> 2;
     const int L = quads < 64 ? quads : 64;       // lanes per row (power of two)
@@ -398,6 +399,12 @@ __global__ __launch_bounds__(256) void pixel_norm_kernel(const T* __restrict__ a
                         o4[e] = k0 * (-sa * yv - sq * ggv[k][e] - sp * gv[k][e] + 3.f * sp * sq * yv * invc);
                     }
                     st4(out + row * c + (k * L + sub) * 4, o4);
+                    if (out2) {   // r * (gg' - y * mean(y * gg')), sp = sum(y * gg')
+                        float o2[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o2[e] = r * (ggv[k][e] - xv[k][e] * r * (sp * invc));
+                        st4(out2 + row * c + (k * L + sub) * 4, o2);
+                    }
                 }
         }
     }
@@ -619,16 +626,16 @@ extern "C" int gs_act_bwd_bias(const void* g, const void* y, void* gx, float* gb
 }
 
 static int pixel_norm_launch(int mode, const void* a0, const void* a1, const void* a2, void* out, int64_t p, int c, float eps, int dtype, void* stream, int act = 0,
-                             int pre = 0, const void* addend = nullptr) {
+                             int pre = 0, const void* addend = nullptr, void* out2 = nullptr) {
     GS_CHECK_ARG(p > 0 && c >= 4 && c <= 1024 && (c & (c - 1)) == 0, "pixel_norm: c=%d must be a power of two in [4,1024]", c);
     const int L = (c >> 2) < 64 ? (c >> 2) : 64;
     const long rows_per_block = 4 * (64 / L);
     dim3 grid(ew_grid(((long)p + rows_per_block - 1) / rows_per_block * 256));
     hipStream_t st = as_stream(stream);
     GS_DISPATCH_DTYPE(dtype, {
-        if (mode == 0) hipLaunchKernelGGL((pixel_norm_kernel<T, 0>), grid, dim3(256), 0, st, (const T*)a0, (const T*)a1, (const T*)a2, (T*)out, (long)p, c, eps, act, pre, (const T*)addend);
-        else if (mode == 1) hipLaunchKernelGGL((pixel_norm_kernel<T, 1>), grid, dim3(256), 0, st, (const T*)a0, (const T*)a1, (const T*)a2, (T*)out, (long)p, c, eps, act, pre, (const T*)addend);
-        else hipLaunchKernelGGL((pixel_norm_kernel<T, 2>), grid, dim3(256), 0, st, (const T*)a0, (const T*)a1, (const T*)a2, (T*)out, (long)p, c, eps, act, pre, (const T*)addend);
+        if (mode == 0) hipLaunchKernelGGL((pixel_norm_kernel<T, 0>), grid, dim3(256), 0, st, (const T*)a0, (const T*)a1, (const T*)a2, (T*)out, (long)p, c, eps, act, pre, (const T*)addend, (T*)out2);
+        else if (mode == 1) hipLaunchKernelGGL((pixel_norm_kernel<T, 1>), grid, dim3(256), 0, st, (const T*)a0, (const T*)a1, (const T*)a2, (T*)out, (long)p, c, eps, act, pre, (const T*)addend, (T*)out2);
+        else hipLaunchKernelGGL((pixel_norm_kernel<T, 2>), grid, dim3(256), 0, st, (const T*)a0, (const T*)a1, (const T*)a2, (T*)out, (long)p, c, eps, act, pre, (const T*)addend, (T*)out2);
     });
     GS_CHECK_LAUNCH();
     return 0;
@@ -645,10 +652,10 @@ extern "C" int gs_pixel_norm_bwd_fused(const void* g, const void* x, const void*
     GS_CHECK_ARG(pn_act_ok(pre_act) && pn_act_ok(post_act), "pixel_norm_bwd_fused: bad activation %d / %d", pre_act, post_act);
     return pixel_norm_launch(1, g, x, nullptr, gx, p, c, eps, dtype, stream, post_act, pre_act, addend);
 }
-extern "C" int gs_pixel_norm_bwd_bwd_fused(const void* gg, const void* g, const void* x, void* out, int64_t p, int c, float eps, int pre_act, int dtype,
-                                           void* stream) {
+extern "C" int gs_pixel_norm_bwd_bwd_fused(const void* gg, const void* g, const void* x, void* out, void* out_g, int64_t p, int c, float eps, int pre_act,
+                                           int dtype, void* stream) {
     GS_CHECK_ARG(pn_act_ok(pre_act), "pixel_norm_bwd_bwd_fused: bad activation %d", pre_act);
-    return pixel_norm_launch(2, gg, g, x, out, p, c, eps, dtype, stream, 0, pre_act, nullptr);
+    return pixel_norm_launch(2, gg, g, x, out, p, c, eps, dtype, stream, 0, pre_act, nullptr, out_g);
 }
 extern "C" int gs_pixel_norm_bwd_bwd(const void* gg, const void* g, const void* x, void* out, int64_t p, int c, float eps, int dtype, void* stream) {
     return pixel_norm_launch(2, gg, g, x, out, p, c, eps, dtype, stream);

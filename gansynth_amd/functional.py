@@ -301,6 +301,9 @@ class _PnActBwd(Function):
     @once_differentiable
     def backward(ctx, gg):
         g, z = ctx.saved_tensors
+        if ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:   # both from one pass over gg, g, z
+            g_z, g_g = _K().pixel_norm_bwd_bwd(gg, g, z, ctx.eps, pre_act=ctx.act, with_g=True)
+            return g_g, g_z, None, None
         g_g = _K().pixel_norm_bwd(gg, z, ctx.eps, pre_act=ctx.act) if ctx.needs_input_grad[0] else None
         g_z = _K().pixel_norm_bwd_bwd(gg, g, z, ctx.eps, pre_act=ctx.act) if ctx.needs_input_grad[1] else None
         return g_g, g_z, None, None

@@ -340,14 +340,16 @@ class HipKernels(object):
                                                     _stream()), "gs_pixel_norm_bwd_fused")
         return gx
 
-    def pixel_norm_bwd_bwd(self, gg, g, x, eps, pre_act=0):
+    def pixel_norm_bwd_bwd(self, gg, g, x, eps, pre_act=0, with_g=False):
+        """d<gg', pixel_norm_bwd(g, x)>/dx with gg' = gg * pre_act'(x); with_g: also pixel_norm_bwd(gg', x) (same pass) -> (out, out_g)."""
         x = _act(x)
         gg, g = _match(gg, x), _match(g, x)
         p, c = _rows_cols(x)
         out = torch.empty_like(x)
-        _lib.check(self.lib.gs_pixel_norm_bwd_bwd_fused(gg.data_ptr(), g.data_ptr(), x.data_ptr(), out.data_ptr(), p, c, float(eps), int(pre_act), _dt(x),
-                                                        _stream()), "gs_pixel_norm_bwd_bwd_fused")
-        return out
+        out_g = torch.empty_like(x) if with_g else None
+        _lib.check(self.lib.gs_pixel_norm_bwd_bwd_fused(gg.data_ptr(), g.data_ptr(), x.data_ptr(), out.data_ptr(), None if out_g is None else out_g.data_ptr(),
+                                                        p, c, float(eps), int(pre_act), _dt(x), _stream()), "gs_pixel_norm_bwd_bwd_fused")
+        return (out, out_g) if with_g else out
 
     # --------------------------------------------------------------------- up / down scale
     def upscale2d(self, x, fy, fx, scale):

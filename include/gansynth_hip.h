@@ -167,11 +167,12 @@ int gs_pixel_norm_bwd(const void* g, const void* x, void* gx, int64_t p, int c, 
  *     post_act  -> gradient w.r.t. the pre-activation (replaces the act_bwd pass that follows);
  *     addend    -> a second gradient arriving at x (from the second-order graph), summed in the same pass;
  *     pre_act   -> the transposed form, used when this chain is itself differentiated (mode-seeking term)
- *   bwd_bwd_fused: out = pixel_norm_bwd_bwd(gg * pre_act'(x), g, x) */
+ *   bwd_bwd_fused: out = pixel_norm_bwd_bwd(gg', g, x) with gg' = gg * pre_act'(x); out_g (may be NULL) = pixel_norm_bwd(gg', x)
+ *                  -- both gradients of a differentiated norm-backward node from one pass over gg, g, x */
 int gs_pixel_norm_bwd_fused(const void* g, const void* x, const void* addend, void* gx, int64_t p, int c, float eps, int pre_act, int post_act,
                             int dtype, void* stream);
-int gs_pixel_norm_bwd_bwd_fused(const void* gg, const void* g, const void* x, void* out, int64_t p, int c, float eps, int pre_act, int dtype,
-                                void* stream);
+int gs_pixel_norm_bwd_bwd_fused(const void* gg, const void* g, const void* x, void* out, void* out_g, int64_t p, int c, float eps, int pre_act,
+                                int dtype, void* stream);
 int gs_pixel_norm_bwd_bwd(const void* gg, const void* g, const void* x, void* out, int64_t p, int c, float eps, int dtype, void* stream);
 
 /* upscale2d / downscale2d (ops.py:283-305).

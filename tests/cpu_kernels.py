@@ -127,7 +127,9 @@ class CpuEmuKernels(object):
             gx = gx + addend.detach()
         return gx if act == 0 else self.act_bwd(gx, x, act)
 
-    def pixel_norm_bwd_bwd(self, gg, g, x, eps, pre_act=0):
+    def pixel_norm_bwd_bwd(self, gg, g, x, eps, pre_act=0, with_g=False):
+        if with_g:
+            return self.pixel_norm_bwd_bwd(gg, g, x, eps, pre_act=pre_act), self.pixel_norm_bwd(gg, x, eps, pre_act=pre_act)
         if pre_act:
             gg = self.act_bwd(gg.detach().expand_as(x), x, pre_act)
         with torch.enable_grad():

@@ -374,3 +374,6 @@ def test_pixel_norm_bwd_with_activation(K, E, shape, dtype):
     gg = rnd(*shape, seed=4).to(dtype).float()
     close(K.pixel_norm_bwd_bwd(dev(gg, dtype), dev(g, dtype), dev(x, dtype), 1e-8, pre_act=1), E.pixel_norm_bwd_bwd(gg, g, x, 1e-8, pre_act=1),
           rel=1e-3 if dtype == torch.float32 else 3e-2, name="pn bwd_bwd(gg * lrelu')")
+    o, og = K.pixel_norm_bwd_bwd(dev(gg, dtype), dev(g, dtype), dev(x, dtype), 1e-8, pre_act=1, with_g=True)
+    close(o, E.pixel_norm_bwd_bwd(gg, g, x, 1e-8, pre_act=1), rel=1e-3 if dtype == torch.float32 else 3e-2, name="pair: d/dx")
+    close(og, E.pixel_norm_bwd(gg, x, 1e-8, pre_act=1), rel=tol, name="pair: d/dg")
