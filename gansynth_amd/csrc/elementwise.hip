@@ -471,22 +471,31 @@ __global__ void blocksum_small_kernel(const T* __restrict__ x, T* __restrict__ y
 }
 
 // --------------------------------------------------------------------- row reductions
-// out[r] = sum_j x[r][j]^2, one block per row (deterministic order).
+// out[r] = sum_j x[r][j]^2.  A row is split over SSQ_CHUNKS blocks (8 rows of 262144 elements would otherwise keep 8 CUs busy);
+// pass 1 writes one partial per (row, chunk), pass 2 (one wave per row) sums them in a fixed order: deterministic.
+constexpr int SSQ_CHUNKS = 64;
 template <typename T>
-__global__ __launch_bounds__(256) void sumsq_rows_kernel(const T* __restrict__ x, float* __restrict__ out, long cols) {
+__global__ __launch_bounds__(256) void sumsq_rows_kernel(const T* __restrict__ x, float* __restrict__ part, long cols) {
     __shared__ float red[4];
-    const int r = blockIdx.x;
+    const int r = blockIdx.y, ck = blockIdx.x;
     const T* xr = x + (long)r * cols;
-    float s = 0.f;
     const long nvec = cols >> 2;
-    for (long i = threadIdx.x; i < nvec; i += 256) {
+    const long per = (nvec + SSQ_CHUNKS - 1) / SSQ_CHUNKS;
+    const long i0 = ck * per, i1 = i0 + per < nvec ? i0 + per : nvec;
+    float s = 0.f;
+    for (long i = i0 + threadIdx.x; i < i1; i += 256) {
         float v[4];
         ld4(xr + i * 4, v);
         s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
     }
-    for (long i = nvec * 4 + threadIdx.x; i < cols; i += 256) { const float v = DT<T>::ld(xr + i); s += v * v; }
+    if (ck == SSQ_CHUNKS - 1)
+        for (long i = nvec * 4 + threadIdx.x; i < cols; i += 256) { const float v = DT<T>::ld(xr + i); s += v * v; }
     s = block_sum<256>(s, red);
-    if (threadIdx.x == 0) out[r] = s;
+    if (threadIdx.x == 0) part[(long)r * SSQ_CHUNKS + ck] = s;
+}
+static __global__ __launch_bounds__(64) void sumsq_rows_final_kernel(const float* __restrict__ part, float* __restrict__ out) {
+    const float s = wave_sum(part[(long)blockIdx.x * SSQ_CHUNKS + threadIdx.x]);   // SSQ_CHUNKS == 64 lanes
+    if (threadIdx.x == 0) out[blockIdx.x] = s;
 }
 template <typename T>
 __global__ void row_scale_kernel(const T* __restrict__ x, const float* __restrict__ s, T* __restrict__ out, int rows, long cols) {
@@ -683,9 +692,15 @@ extern "C" int gs_blocksum2d(const void* x, void* y, int n, int h, int w, int c,
     return 0;
 }
 
-extern "C" int gs_sumsq_rows(const void* x, float* out, int rows, int64_t cols, int dtype, void* stream) {
+extern "C" size_t gs_sumsq_rows_workspace_bytes(int rows) { return (size_t)(rows > 0 ? rows : 0) * SSQ_CHUNKS * sizeof(float); }
+
+extern "C" int gs_sumsq_rows(const void* x, float* out, int rows, int64_t cols, int dtype, void* ws, size_t ws_bytes, void* stream) {
     GS_CHECK_ARG(rows > 0 && cols > 0, "sumsq_rows: bad args");
-    GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((sumsq_rows_kernel<T>), dim3(rows), dim3(256), 0, as_stream(stream), (const T*)x, out, (long)cols));
+    if (ws_bytes < gs_sumsq_rows_workspace_bytes(rows)) return fail(GS_ERR_WORKSPACE, "sumsq_rows: workspace too small");
+    float* part = (float*)ws;
+    GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((sumsq_rows_kernel<T>), dim3(SSQ_CHUNKS, rows), dim3(256), 0, as_stream(stream), (const T*)x, part, (long)cols));
+    GS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(sumsq_rows_final_kernel, dim3(rows), dim3(64), 0, as_stream(stream), part, out);
     GS_CHECK_LAUNCH();
     return 0;
 }

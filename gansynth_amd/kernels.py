@@ -406,7 +406,8 @@ class HipKernels(object):
         x = _act(x)
         rows = x.shape[0]
         out = torch.empty((rows,), dtype=torch.float32, device=x.device)
-        _lib.check(self.lib.gs_sumsq_rows(x.data_ptr(), out.data_ptr(), rows, x.numel() // rows, _dt(x), _stream()), "gs_sumsq_rows")
+        ws = _ws(self.lib.gs_sumsq_rows_workspace_bytes(rows), x.device)
+        _lib.check(self.lib.gs_sumsq_rows(x.data_ptr(), out.data_ptr(), rows, x.numel() // rows, _dt(x), ws.data_ptr(), ws.numel(), _stream()), "gs_sumsq_rows")
         return out
 
     def row_scale(self, x, s):

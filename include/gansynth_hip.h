@@ -194,7 +194,8 @@ int gs_axpby(const void* a, const void* b, void* out, int64_t numel, float ca, f
 
 /* per-sample sum of squares (the R1 penalty reduction, models.py:48): out[r] = sum_j x[r][j]^2 (fp32 out);
  * row_scale: out[r][j] = s[r] * x[r][j]  (its gradient, s fp32). */
-int gs_sumsq_rows(const void* x, float* out, int rows, int64_t cols, int dtype, void* stream);
+size_t gs_sumsq_rows_workspace_bytes(int rows);
+int gs_sumsq_rows(const void* x, float* out, int rows, int64_t cols, int dtype, void* ws, size_t ws_bytes, void* stream);
 int gs_row_scale(const void* x, const float* s, void* out, int rows, int64_t cols, int dtype, void* stream);
 
 /* tf.train.AdamOptimizer step (models.py:67-89), TF form, fused over one flat fp32 buffer:
