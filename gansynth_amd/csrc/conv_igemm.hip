@@ -1037,6 +1037,10 @@ static int dispatch_igemm(ConvP p, hipStream_t st) {
         return launch_igemm<T, MODE, 2, 1, 16, 3>(p, st);
     } else if constexpr (MODE == MODE_S2) {
         if (!a2) return launch_igemm<T, MODE, 1, 1, 32, 3>(p, st);
+        // stride 2: the patch is 4.6x the output tile, so a 128-channel tile (the patch staged once for all of them) is worth
+        // more than a second pixel tile as long as every CU still gets a block
+        if (OC == 64 && nch == 1 && Wb >= 32 && items64(1) >= num_cus()) return launch_igemm<T, MODE, 2, 1, 32, 9, true, 1>(p, st);   // 36 KiB of weights: resident
+        if (OC % 128 == 0 && Wb >= 32 && (long)p.N * cdiv(p.Hb, 4) * cdiv(Wb, 32) * (OC / 128) >= num_cus()) return launch_igemm<T, MODE, 4, 1, 32, 3>(p, st);
         if (Wb >= 32) return launch_igemm<T, MODE, 2, 1, 32, 3>(p, st);
         return launch_igemm<T, MODE, 2, 1, 16, 3>(p, st);
     } else {
