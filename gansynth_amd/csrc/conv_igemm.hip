@@ -354,11 +354,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) a_off[ks] = l31 * 64 + (((ks * 2 + hi) ^ ((l31 >> 2) & 3)) << 4);
 
-    for (int c = tid; c < OC; c += 256) lbias[c] = p.bias ? p.bias[c] : 0.f;
-    block_barrier();  // (also drains hipcc's own loads above before the first DMA is issued)
+    // ---- prologue: resident weights and the first D stages go out first, the bias is staged while they fly (hipcc waits
+    //      vmcnt(0) for the bias loads, which drains the DMAs too -- at this point that is exactly the wait that is needed)
     GS_TR(1);
-
-    // ---- prologue: resident weights, then the first D stages
     if (RESIDENT) {
         for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
@@ -372,6 +370,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
         issue_advance(d % NTG);
     }
     GS_TR(2);
+    for (int c = tid; c < OC; c += 256) lbias[c] = p.bias ? p.bias[c] : 0.f;
     wait_vmcnt(0);
     block_barrier();
     GS_TR(3);

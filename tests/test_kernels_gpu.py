@@ -377,3 +377,87 @@ def test_pixel_norm_bwd_with_activation(K, E, shape, dtype):
     o, og = K.pixel_norm_bwd_bwd(dev(gg, dtype), dev(g, dtype), dev(x, dtype), 1e-8, pre_act=1, with_g=True)
     close(o, E.pixel_norm_bwd_bwd(gg, g, x, 1e-8, pre_act=1), rel=1e-3 if dtype == torch.float32 else 3e-2, name="pair: d/dx")
     close(og, E.pixel_norm_bwd(gg, x, 1e-8, pre_act=1), rel=tol, name="pair: d/dg")
+
+
+# ---- size-independent properties at the BASELINE layer sizes (the oracle cannot run these shapes in seconds) -----------------
+FULL_CASES = [
+    (8, 32, 32, 128, 1024, 1),    # top of the pyramid
+    (8, 64, 64, 64, 512, 1),
+    (8, 32, 64, 128, 1024, 2),    # discriminator downscale conv
+    (8, 128, 128, 32, 256, 1),
+    (8, 128, 256, 32, 256, 2),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", FULL_CASES)
+def test_three_maps_are_mutually_adjoint_at_full_size(K, case, dtype):
+    """<conv(x, w), gy> = <x, bwd_data(gy, w)> = <w, bwd_weight(x, gy)> -- the three kernels of a layer are one bilinear form.
+    Holds for any correct implementation whatever the size; checked on device in float64 at the BASELINE resolutions."""
+    n, ci, co, h, w, st = case
+    g = torch.Generator(device="cuda").manual_seed(7)
+    x = torch.randn(n, ci, h, w, device="cuda", generator=g).to(dtype).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(n, co, h // st, w // st, device="cuda", generator=g).to(dtype).contiguous(memory_format=torch.channels_last)
+    wt = torch.randn(3, 3, ci, co, device="cuda", generator=g)
+    if dtype == torch.bfloat16:
+        wt = wt.bfloat16().float()   # the conv kernels round the operand copy of the weight; make the three forms see the same values
+    alpha = float(np.sqrt(2.0 / (9 * ci)))
+    y = K.conv2d_fwd(x, wt, 3, st, alpha)
+    gx = K.conv2d_bwd_data(gy, wt, x.shape, 3, st, alpha)
+    gw = K.conv2d_bwd_weight(x, gy, 3, st, alpha)
+    a = float((y.double() * gy.double()).sum())
+    b = float((x.double() * gx.double()).sum())
+    c = float((wt.double() * gw.double()).sum())
+    scale = float(y.double().norm() * gy.double().norm())   # Cauchy-Schwarz scale of the pairing
+    tol = 1e-5 if dtype == torch.float32 else 2e-3          # bf16: y and gx are rounded to 8 bits of mantissa element-wise
+    assert abs(a - b) <= tol * scale and abs(a - c) <= tol * scale, (a, b, c, scale)
+
+
+@pytest.mark.parametrize("case", [(8, 64, 64, 64, 512), (8, 256, 128, 16, 128)])
+def test_transposed_conv_is_the_adjoint_of_the_stride2_conv_at_full_size(K, case):
+    """conv2d_transpose(x, w) pairs with the stride-2 conv of the flipped roles: <convT(x, w), g> = <x, convT_bwd_data(g, w)> = <w, convT_bwd_weight(x, g)>."""
+    n, ci, co, h, w = case
+    g = torch.Generator(device="cuda").manual_seed(9)
+    x = torch.randn(n, ci, h, w, device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(n, co, 2 * h, 2 * w, device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
+    wt = torch.randn(3, 3, ci, co, device="cuda", generator=g)
+    y = K.conv2d_transpose_fwd(x, wt, 0.05)
+    gx = K.conv2d_transpose_bwd_data(gy, wt, 0.05)
+    gw = K.conv2d_transpose_bwd_weight(x, gy, 0.05)
+    a, b, c = float((y.double() * gy.double()).sum()), float((x.double() * gx.double()).sum()), float((wt.double() * gw.double()).sum())
+    scale = float(y.double().norm() * gy.double().norm())
+    assert abs(a - b) <= 1e-5 * scale and abs(a - c) <= 1e-5 * scale, (a, b, c, scale)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", [(1, 64, 64, 6, 40, 3, 1), (1, 64, 128, 12, 72, 3, 2), (3, 128, 64, 5, 33, 3, 1), (1, 32, 32, 1, 7, 3, 1)])
+def test_ragged_and_single_image_shapes(K, E, case, dtype):
+    """Tiles that hang over the image edge, odd widths, batch 1 -- through all three maps (64x64-tile weight gradient included)."""
+    n, ci, co, h, w, ks, st = case
+    ho, wo = (h + st - 1) // st if st == 1 else h // st, (w + st - 1) // st if st == 1 else w // st
+    x = rnd(n, ci, h, w, seed=1).to(dtype).float()
+    wt = rnd(ks, ks, ci, co, seed=2)
+    wr = wt.to(dtype).float() if dtype == torch.bfloat16 else wt
+    gy = rnd(n, co, ho, wo, seed=3).to(dtype).float()
+    alpha = float(np.sqrt(2.0 / (ks * ks * ci)))
+    tol = 1e-3 if dtype == torch.float32 else 2e-2
+    close(K.conv2d_fwd(dev(x, dtype), dev(wt), ks, st, alpha), E.conv2d_fwd(x, wr, ks, st, alpha), rel=tol, name="fwd")
+    close(K.conv2d_bwd_data(dev(gy, dtype), dev(wt), x.shape, ks, st, alpha), E.conv2d_bwd_data(gy, wr, x.shape, ks, st, alpha), rel=tol, name="bwd_data")
+    close(K.conv2d_bwd_weight(dev(x, dtype), dev(gy, dtype), ks, st, alpha), E.conv2d_bwd_weight(x, gy, ks, st, alpha), rel=1e-3 if dtype == torch.float32 else 1e-2,
+          name="bwd_weight")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_pixel_norm_gradient_forms_pair_up_at_full_size(K, dtype):
+    """The norm's Jacobian is symmetric, and the pre-/post-activation forms of the fused backward are each other's transpose:
+    <gg, (J g) * m> = <g, J (gg * m)> at 8 x 32 x 128 x 1024."""
+    g_ = torch.Generator(device="cuda").manual_seed(11)
+    shape = (8, 32, 128, 1024)
+    z = torch.nn.functional.leaky_relu(torch.randn(*shape, device="cuda", generator=g_), 0.2).to(dtype).contiguous(memory_format=torch.channels_last)
+    g = torch.randn(*shape, device="cuda", generator=g_).to(dtype).contiguous(memory_format=torch.channels_last)
+    gg = torch.randn(*shape, device="cuda", generator=g_).to(dtype).contiguous(memory_format=torch.channels_last)
+    post = K.pixel_norm_bwd(g, z, 1e-8, act=1)        # (J g) * m
+    pre = K.pixel_norm_bwd(gg, z, 1e-8, pre_act=1)    # J (gg * m)
+    a, b = float((gg.double() * post.double()).sum()), float((g.double() * pre.double()).sum())
+    scale = float(gg.double().norm() * post.double().norm())
+    assert abs(a - b) <= (1e-5 if dtype == torch.float32 else 2e-3) * scale, (a, b, scale)
