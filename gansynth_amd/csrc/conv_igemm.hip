@@ -113,9 +113,6 @@ template <int MODE> __host__ __device__ constexpr int tap_off(int k) {  // patch
 // no ordinary global loads (the bias lives in LDS), only the epilogue stores.
 // TG == 9 with RESIDENT keeps all taps of all chunks in LDS for the life of the block (thin layers: 32 or
 // 64 output channels) and only the input patches stream.
-#ifndef GS_TOP_D
-#define GS_TOP_D 2
-#endif
 struct ConvP {
     const void* x;
     const void* wp;
@@ -133,7 +130,10 @@ struct ConvP {
 #ifdef GS_IGEMM_TRACE
 #define GS_TR(slot)                                                                                              \
     do {                                                                                                         \
-        if (p.trace && threadIdx.x == 0 && (slot) < 64) p.trace[blockIdx.x * 64 + (slot)] = __builtin_amdgcn_s_memtime(); \
+        if (p.trace && threadIdx.x == 0 && (slot) < 64) {                                                        \
+            p.trace[blockIdx.x * 64 + (slot)] = __builtin_amdgcn_s_memtime();                                    \
+            if ((slot) == 0 || (slot) == 63) p.trace[4096 * 64 + blockIdx.x * 2 + ((slot) == 63)] = __builtin_amdgcn_s_memrealtime(); \
+        }                                                                                                        \
     } while (0)
 #else
 #define GS_TR(slot) do { } while (0)
@@ -1027,30 +1027,39 @@ static int dispatch_igemm(ConvP p, hipStream_t st) {
     const int a2 = OC % 64 == 0;
     // blocks the layer gives with 128*B-pixel x 64-channel tiles (TW = 32)
     auto items64 = [&](int B_) { return (long)p.N * cdiv(p.Hb, 4 * B_) * cdiv(Wb, 32) * (OC / 64); };
+#ifdef GS_FORCE_CFG   // probes only: -DGS_FORCE_MODE=0 -DGS_FORCE_CFG=2,2,32,3,false,1
+    if constexpr (MODE == GS_FORCE_MODE) return launch_igemm<T, MODE, GS_FORCE_CFG>(p, st);
+#endif
+    // Measured on the layers of the fully grown networks (scripts/probe/run_variants.sh): two resident blocks per CU (<= 80 KiB
+    // of LDS each, i.e. a one-stage-deep ring) beat one block with a deeper ring or a larger tile wherever the layer has at
+    // least two blocks per CU to give -- the epilogue and DMA waits of one block run under the MFMAs of the other.
+    const long cus = num_cus();
+    const bool small = items64(1) <= cus;   // no more blocks than CUs: a serial chain of stages per block
     if constexpr (MODE == MODE_T2) {
-        if (resident_ok && Wb >= 64) return launch_igemm<T, MODE, 1, 2, 64, 9, true, GS_TOP_D>(p, st);
-        if (!a2) return launch_igemm<T, MODE, 1, 1, 32, 3>(p, st);
-        // small layers (no more blocks than CUs) are a serial chain of stages: all 9 taps per stage = a third of the barriers
-        if (items64(1) <= num_cus()) { if (Wb >= 32) return launch_igemm<T, MODE, 2, 1, 32, 9>(p, st); return launch_igemm<T, MODE, 2, 1, 16, 9>(p, st); }
+        if (resident_ok && Wb >= 64) return launch_igemm<T, MODE, 1, 1, 64, 9, true, 1>(p, st);
+        // few blocks: 32-channel tiles double the number of busy CUs
+        if (!a2 || small) { if (Wb >= 32) return launch_igemm<T, MODE, 1, 1, 32, 3>(p, st); return launch_igemm<T, MODE, 1, 1, 16, 3>(p, st); }
         if (Wb >= 32) return launch_igemm<T, MODE, 2, 1, 32, 3>(p, st);
         return launch_igemm<T, MODE, 2, 1, 16, 3>(p, st);
     } else if constexpr (MODE == MODE_S2) {
         if (!a2) return launch_igemm<T, MODE, 1, 1, 32, 3>(p, st);
         // stride 2: the patch is 4.6x the output tile, so a 128-channel tile (the patch staged once for all of them) is worth
         // more than a second pixel tile as long as every CU still gets a block
-        if (OC == 64 && nch == 1 && Wb >= 32 && items64(1) >= num_cus()) return launch_igemm<T, MODE, 2, 1, 32, 9, true, 1>(p, st);   // 36 KiB of weights: resident
-        if (OC % 128 == 0 && Wb >= 32 && (long)p.N * cdiv(p.Hb, 4) * cdiv(Wb, 32) * (OC / 128) >= num_cus()) return launch_igemm<T, MODE, 4, 1, 32, 3>(p, st);
+        if (OC == 64 && nch == 1 && Wb >= 32 && items64(1) >= cus) return launch_igemm<T, MODE, 2, 1, 32, 9, true, 1>(p, st);   // 36 KiB of weights: resident
+        if (OC % 128 == 0 && Wb >= 32 && (long)p.N * cdiv(p.Hb, 4) * cdiv(Wb, 32) * (OC / 128) >= cus) return launch_igemm<T, MODE, 4, 1, 32, 3>(p, st);
+        // few blocks: all 9 taps per stage = a third of the barriers and DMA round trips of the chain
+        if (small) { if (Wb >= 32) return launch_igemm<T, MODE, 2, 1, 32, 9, false, 1>(p, st); return launch_igemm<T, MODE, 2, 1, 16, 9, false, 1>(p, st); }
         if (Wb >= 32) return launch_igemm<T, MODE, 2, 1, 32, 3>(p, st);
         return launch_igemm<T, MODE, 2, 1, 16, 3>(p, st);
     } else {
-        if (resident_ok && Wb >= 64) return launch_igemm<T, MODE, 1, 2, 64, 9, true, GS_TOP_D>(p, st);
+        if (resident_ok && Wb >= 64) return launch_igemm<T, MODE, 1, 2, 64, 9, true, 1>(p, st);
         if (!a2) return launch_igemm<T, MODE, 1, 1, 32, 3>(p, st);
-        if (resident64_ok && Wb >= 32 && items64(2) >= num_cus() / 2) return launch_igemm<T, MODE, 2, 2, 32, 9, true>(p, st);
+        if (Wb >= 32 && items64(2) >= 2 * cus) return launch_igemm<T, MODE, 2, 2, 32, 3, false, 1>(p, st);
+        if (resident64_ok && Wb >= 32 && items64(2) >= cus / 2) return launch_igemm<T, MODE, 2, 2, 32, 9, true>(p, st);
         // every block re-streams its 64 x IC x 9 weight slab from L2: the more pixels a block owns the smaller that
         // stream is per MFMA -- take the largest pixel tile that still gives every CU a block
-        if (Wb >= 32 && items64(4) >= num_cus()) return launch_igemm<T, MODE, 2, 4, 32, 3>(p, st);
-        if (Wb >= 32 && items64(2) >= num_cus()) return launch_igemm<T, MODE, 2, 2, 32, 3>(p, st);
-        if (items64(1) <= num_cus()) { if (Wb >= 32) return launch_igemm<T, MODE, 2, 1, 32, 9>(p, st); return launch_igemm<T, MODE, 2, 1, 16, 9>(p, st); }
+        if (Wb >= 32 && items64(2) >= cus) return launch_igemm<T, MODE, 2, 2, 32, 3>(p, st);
+        if (small) { if (Wb >= 32) return launch_igemm<T, MODE, 2, 1, 32, 9, false, 1>(p, st); return launch_igemm<T, MODE, 2, 1, 16, 9, false, 1>(p, st); }
         if (Wb >= 32) return launch_igemm<T, MODE, 2, 1, 32, 3>(p, st);
         return launch_igemm<T, MODE, 2, 1, 16, 3>(p, st);
     }

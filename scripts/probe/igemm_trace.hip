@@ -19,7 +19,7 @@ int main(int argc, char** argv) {
     for (auto& v : hw) v = 0x3c00 + (rand() & 0x3ff);
     void *x, *w, *y;
     unsigned long long* tr;
-    hipMalloc(&x, nx * 2); hipMalloc(&w, nw * 2); hipMalloc(&y, ny * 2); hipMalloc(&tr, 4096 * 64 * 8);
+    hipMalloc(&x, nx * 2); hipMalloc(&w, nw * 2); hipMalloc(&y, ny * 2); hipMalloc(&tr, 4096 * 66 * 8);
     hipMemcpy(x, hx.data(), nx * 2, hipMemcpyHostToDevice);
     hipMemcpy(w, hw.data(), nw * 2, hipMemcpyHostToDevice);
     ConvP p;
@@ -29,7 +29,7 @@ int main(int argc, char** argv) {
     hipEventCreate(&e0); hipEventCreate(&e1);
     float best = 1e9f;
     for (int r = 0; r < reps; ++r) {
-        hipMemset(tr, 0, 4096 * 64 * 8);
+        hipMemset(tr, 0, 4096 * 66 * 8);
         hipEventRecord(e0, 0);
         int rc = mode == 0 ? dispatch_igemm<bf16_t, MODE_S1>(p, 0) : (mode == 1 ? dispatch_igemm<bf16_t, MODE_S2>(p, 0) : dispatch_igemm<bf16_t, MODE_T2>(p, 0));
         hipEventRecord(e1, 0);
@@ -39,7 +39,18 @@ int main(int argc, char** argv) {
         hipEventElapsedTime(&ms, e0, e1);
         if (ms < best) best = ms;
     }
-    std::vector<unsigned long long> h(4096 * 64);
+    float burst = 0;
+    {   // back-to-back launches (what a graph replay looks like: no idle gaps, clocks stay up)
+        hipEventRecord(e0, 0);
+        for (int r = 0; r < 50; ++r) {
+            if (mode == 0) dispatch_igemm<bf16_t, MODE_S1>(p, 0); else if (mode == 1) dispatch_igemm<bf16_t, MODE_S2>(p, 0); else dispatch_igemm<bf16_t, MODE_T2>(p, 0);
+        }
+        hipEventRecord(e1, 0);
+        hipEventSynchronize(e1);
+        hipEventElapsedTime(&burst, e0, e1);
+        burst /= 50;
+    }
+    std::vector<unsigned long long> h(4096 * 66);
     hipMemcpy(h.data(), tr, h.size() * 8, hipMemcpyDeviceToHost);
     int nb = 0;
     double sum[64] = {0};
@@ -51,7 +62,18 @@ int main(int argc, char** argv) {
         if (h[b * 64 + 63] > t1max) t1max = h[b * 64 + 63];
         for (int s = 0; s < 64; ++s) sum[s] += h[b * 64 + s] ? (double)(h[b * 64 + s] - h[b * 64]) : 0.0;
     }
-    printf("event time %.1f us; %d blocks traced; first start -> last end %.0f ticks\n", best * 1e3, nb, (double)(t1max - t0min));
+    unsigned long long r0min = ~0ull, r1max = 0;
+    double rsum = 0;
+    for (int b = 0; b < 4096; ++b) {
+        if (!h[b * 64]) continue;
+        const unsigned long long r0 = h[4096 * 64 + 2 * b], r1 = h[4096 * 64 + 2 * b + 1];
+        if (r0 < r0min) r0min = r0;
+        if (r1 > r1max) r1max = r1;
+        rsum += (double)(r1 - r0);
+    }
+    printf("single %.1f us, burst avg %.1f us; %d blocks; kernel (first start -> last end) %.2f us, mean block %.2f us = %.0f shader ticks (%.0f MHz)\n", best * 1e3, burst * 1e3, nb,
+           (double)(r1max - r0min) / 100.0, rsum / nb / 100.0, sum[63] / nb, sum[63] / nb / (rsum / nb / 100.0));
+    if (getenv("GS_TRACE_QUIET")) return 0;
     const char* names[4] = {"start", "bias staged", "prologue issued", "stage 0 landed"};
     double prev = 0;
     for (int s = 0; s < 64; ++s) {
