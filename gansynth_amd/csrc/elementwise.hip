@@ -287,9 +287,19 @@ static int channel_sum_parts(long p, int c) {
 }
 
 // ------------------------------------------------------------------------- pixel norm
-// Row p of C channels is owned by L = min(64, C/4) lanes (4 channels per lane per pass).
+// Row p of C channels is owned by L = min(64, C/E) lanes, E = 16 bytes of channels per lane per pass (4 fp32 / 8 bf16; E = 4
+// for narrower rows), P passes per row (1 up to 256 fp32 / 512 bf16 channels), U independent row groups per loop trip so that
+// a wave keeps 2U..3U 1-KiB loads in flight -- the kernel is a pure HBM stream.
 // MODE 0: y = x*r ; MODE 1: gx = r*(g - y*mean(y*g)) ; MODE 2: second-order term (see header).
-template <typename T, int MODE>
+template <typename T, int E> __device__ inline void pn_ld(const T* p, float* o) {
+    if constexpr (E == Wide<T>::N) ld_wide<T>(p, o);
+    else ld4(p, *reinterpret_cast<float(*)[4]>(o));
+}
+template <typename T, int E> __device__ inline void pn_st(T* p, const float* o) {
+    if constexpr (E == Wide<T>::N) st_wide<T>(p, o);
+    else st4(p, *reinterpret_cast<const float(*)[4]>(o));
+}
+template <typename T, int MODE, int E, int P, int U>
 __global__ __launch_bounds__(256) void pixel_norm_kernel(const T* __restrict__ a0, const T* __restrict__ a1, const T* __restrict__ a2,
                                                          T* __restrict__ out, long p, int c, float eps, int act, int pre,
                                                          const T* __restrict__ addend, T* __restrict__ out2) {
@@ -300,112 +310,107 @@ __global__ __launch_bounds__(256) void pixel_norm_kernel(const T* __restrict__ a
     //   pre    (MODE 1, 2): the incoming g / gg is first multiplied by act'(.) through x (transpose of the `act` form)
     //   out2   (MODE 2): also write pixel_norm_bwd(gg', x) -- the two gradients of a differentiated norm-backward in one pass
     // a0 = x (MODE 0) | g (MODE 1) | gg (MODE 2);  a1 = x (MODE 1) | g (MODE 2);  a2 = x (MODE 2)
-    const int quads = c >> 2;
-    const int L = quads < 64 ? quads : 64;       // lanes per row (power of two)
-    const int passes = quads / L;                // 1, 2 (c=512) ...
+    const int vecs = c / E;
+    const int L = vecs < 64 ? vecs : 64;         // lanes per row (power of two)
     const int rows_per_wave = 64 / L;
     const int lane = threadIdx.x & 63;
     const int sub = lane % L;
     const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
     const float invc = 1.f / (float)c;
-    for (long row0 = wave * rows_per_wave; row0 < p; row0 += nwaves * rows_per_wave) {
-        const long row = row0 + lane / L;
-        const bool ok = row < p;
-        const T* xr = (MODE == 0 ? a0 : (MODE == 1 ? a1 : a2)) + row * c;
-        float xv[4][4], s = 0.f;  // up to 4 passes (c <= 1024)
+    const T* const xbase = MODE == 0 ? a0 : (MODE == 1 ? a1 : a2);
+    auto dact = [&](int kind, float xv) __attribute__((always_inline)) {   // act'(.) through the activation output
+        return kind == GS_ACT_LRELU ? (xv > 0.f ? 1.f : 0.2f) : (kind == GS_ACT_TANH ? 1.f - xv * xv : 1.f);
+    };
+    for (long row0 = wave * rows_per_wave; row0 < p; row0 += nwaves * rows_per_wave * U) {
+        long off[U];
+        bool ok[U];
+        float xv[U][P][E], av[U][P][E], bv[U][P][E];   // x ; g (MODE 1) / gg (MODE 2) ; g (MODE 2)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (k < passes) {
-                if (ok) ld4(xr + (k * L + sub) * 4, xv[k]);
-                else xv[k][0] = xv[k][1] = xv[k][2] = xv[k][3] = 0.f;
+        for (int u = 0; u < U; ++u) {
+            const long row = row0 + u * nwaves * rows_per_wave + lane / L;
+            ok[u] = row < p;
+            off[u] = (ok[u] ? row : 0) * c + sub * E;     // clamped: the loads stay unconditional
 #pragma unroll
-                for (int e = 0; e < 4; ++e) s += xv[k][e] * xv[k][e];
+            for (int k = 0; k < P; ++k) {
+                pn_ld<T, E>(xbase + off[u] + k * L * E, xv[u][k]);
+                if (MODE >= 1) pn_ld<T, E>(a0 + off[u] + k * L * E, av[u][k]);
+                if (MODE == 2) pn_ld<T, E>(a1 + off[u] + k * L * E, bv[u][k]);
             }
         }
-        for (int o = L >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-        const float r = rsqrtf(s * invc + eps);
-        if (MODE == 0) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (k < passes && ok) {
-                    float o4[4];
+        for (int u = 0; u < U; ++u) {
+            float s = 0.f;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o4[e] = xv[k][e] * r;
-                    st4(out + row * c + (k * L + sub) * 4, o4);
+            for (int k = 0; k < P; ++k)
+#pragma unroll
+                for (int e = 0; e < E; ++e) s += xv[u][k][e] * xv[u][k][e];
+            for (int o = L >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+            const float r = rsqrtf(s * invc + eps);
+            if (MODE == 0) {
+#pragma unroll
+                for (int k = 0; k < P; ++k) {
+                    float o[E];
+#pragma unroll
+                    for (int e = 0; e < E; ++e) o[e] = xv[u][k][e] * r;
+                    if (ok[u]) pn_st<T, E>(out + off[u] + k * L * E, o);
                 }
-        } else if (MODE == 1) {
-            float gv[4][4], q = 0.f;
+            } else if (MODE == 1) {
+                float q = 0.f;
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (k < passes) {
-                    if (ok) ld4(a0 + row * c + (k * L + sub) * 4, gv[k]);
-                    else gv[k][0] = gv[k][1] = gv[k][2] = gv[k][3] = 0.f;
+                for (int k = 0; k < P; ++k)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if (pre == GS_ACT_LRELU) gv[k][e] = xv[k][e] > 0.f ? gv[k][e] : 0.2f * gv[k][e];
-                        else if (pre == GS_ACT_TANH) gv[k][e] *= 1.f - xv[k][e] * xv[k][e];
-                        q += xv[k][e] * r * gv[k][e];
+                    for (int e = 0; e < E; ++e) {
+                        av[u][k][e] *= dact(pre, xv[u][k][e]);
+                        q += xv[u][k][e] * r * av[u][k][e];
                     }
+                for (int o = L >> 1; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+                q *= invc;
+#pragma unroll
+                for (int k = 0; k < P; ++k) {
+                    float o[E], ad[E];
+#pragma unroll
+                    for (int e = 0; e < E; ++e) ad[e] = 0.f;
+                    if (addend) pn_ld<T, E>(addend + off[u] + k * L * E, ad);
+#pragma unroll
+                    for (int e = 0; e < E; ++e) o[e] = (r * (av[u][k][e] - xv[u][k][e] * r * q) + ad[e]) * dact(act, xv[u][k][e]);
+                    if (ok[u]) pn_st<T, E>(out + off[u] + k * L * E, o);
                 }
-            for (int o = L >> 1; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
-            q *= invc;
+            } else {
+                float sa = 0.f, sp = 0.f, sq = 0.f;
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (k < passes && ok) {
-                    float o4[4], ad[4] = {0.f, 0.f, 0.f, 0.f};
-                    if (addend) ld4(addend + row * c + (k * L + sub) * 4, ad);
+                for (int k = 0; k < P; ++k)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        o4[e] = r * (gv[k][e] - xv[k][e] * r * q) + ad[e];
-                        if (act == GS_ACT_LRELU) o4[e] = xv[k][e] > 0.f ? o4[e] : 0.2f * o4[e];
-                        else if (act == GS_ACT_TANH) o4[e] *= 1.f - xv[k][e] * xv[k][e];
+                    for (int e = 0; e < E; ++e) {
+                        av[u][k][e] *= dact(pre, xv[u][k][e]);
+                        const float yv = xv[u][k][e] * r;
+                        sa += av[u][k][e] * bv[u][k][e];
+                        sp += yv * av[u][k][e];
+                        sq += yv * bv[u][k][e];
                     }
-                    st4(out + row * c + (k * L + sub) * 4, o4);
+                for (int o = L >> 1; o > 0; o >>= 1) {
+                    sa += __shfl_xor(sa, o, 64);
+                    sp += __shfl_xor(sp, o, 64);
+                    sq += __shfl_xor(sq, o, 64);
                 }
-        } else {
-            float ggv[4][4], gv[4][4], sa = 0.f, sp = 0.f, sq = 0.f;
+                const float k0 = r * r * invc;
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (k < passes) {
-                    if (ok) { ld4(a0 + row * c + (k * L + sub) * 4, ggv[k]); ld4(a1 + row * c + (k * L + sub) * 4, gv[k]); }
-                    else {
+                for (int k = 0; k < P; ++k) {
+                    float o[E];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) ggv[k][e] = gv[k][e] = 0.f;
+                    for (int e = 0; e < E; ++e) {
+                        const float yv = xv[u][k][e] * r;
+                        o[e] = k0 * (-sa * yv - sq * av[u][k][e] - sp * bv[u][k][e] + 3.f * sp * sq * yv * invc);
                     }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if (pre == GS_ACT_LRELU) ggv[k][e] = xv[k][e] > 0.f ? ggv[k][e] : 0.2f * ggv[k][e];
-                        else if (pre == GS_ACT_TANH) ggv[k][e] *= 1.f - xv[k][e] * xv[k][e];
-                        const float yv = xv[k][e] * r;
-                        sa += ggv[k][e] * gv[k][e];
-                        sp += yv * ggv[k][e];
-                        sq += yv * gv[k][e];
-                    }
-                }
-            for (int o = L >> 1; o > 0; o >>= 1) {
-                sa += __shfl_xor(sa, o, 64);
-                sp += __shfl_xor(sp, o, 64);
-                sq += __shfl_xor(sq, o, 64);
-            }
-            const float k0 = r * r * invc;
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (k < passes && ok) {
-                    float o4[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float yv = xv[k][e] * r;
-                        o4[e] = k0 * (-sa * yv - sq * ggv[k][e] - sp * gv[k][e] + 3.f * sp * sq * yv * invc);
-                    }
-                    st4(out + row * c + (k * L + sub) * 4, o4);
+                    if (ok[u]) pn_st<T, E>(out + off[u] + k * L * E, o);
                     if (out2) {   // r * (gg' - y * mean(y * gg')), sp = sum(y * gg')
-                        float o2[4];
+                        float o2[E];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) o2[e] = r * (ggv[k][e] - xv[k][e] * r * (sp * invc));
-                        st4(out2 + row * c + (k * L + sub) * 4, o2);
+                        for (int e = 0; e < E; ++e) o2[e] = r * (av[u][k][e] - xv[u][k][e] * r * (sp * invc));
+                        if (ok[u]) pn_st<T, E>(out2 + off[u] + k * L * E, o2);
                     }
                 }
+            }
         }
     }
 }
@@ -634,17 +639,33 @@ extern "C" int gs_act_bwd_bias(const void* g, const void* y, void* gx, float* gb
     return channel_sum_finalize(part, gb, nparts, c, accumulate, st);
 }
 
+template <typename T, int MODE>
+static void pixel_norm_launch_t(const void* a0, const void* a1, const void* a2, void* out, long p, int c, float eps, int act, int pre, const void* addend,
+                                void* out2, hipStream_t st) {
+    constexpr int WN = Wide<T>::N;
+    const int E = c % WN == 0 ? WN : 4;
+    const int vecs = c / E, L = vecs < 64 ? vecs : 64, P = vecs / L;   // P in {1, 2, 4}
+    const int U = P == 1 ? 2 : 1;
+    const long rows_per_block = 4L * (64 / L) * U;
+    dim3 grid(ew_grid((p + rows_per_block - 1) / rows_per_block * 256));
+#define GS_PN(EE, PP, UU)                                                                                                          \
+    hipLaunchKernelGGL((pixel_norm_kernel<T, MODE, EE, PP, UU>), grid, dim3(256), 0, st, (const T*)a0, (const T*)a1, (const T*)a2, (T*)out, p, c, eps, \
+                       act, pre, (const T*)addend, (T*)out2)
+    if (E == WN) {
+        if (P == 1) GS_PN(WN, 1, 2); else if (P == 2) GS_PN(WN, 2, 1); else GS_PN(WN, 4, 1);
+    } else {
+        if (P == 1) GS_PN(4, 1, 2); else if (P == 2) GS_PN(4, 2, 1); else GS_PN(4, 4, 1);
+    }
+#undef GS_PN
+}
 static int pixel_norm_launch(int mode, const void* a0, const void* a1, const void* a2, void* out, int64_t p, int c, float eps, int dtype, void* stream, int act = 0,
                              int pre = 0, const void* addend = nullptr, void* out2 = nullptr) {
     GS_CHECK_ARG(p > 0 && c >= 4 && c <= 1024 && (c & (c - 1)) == 0, "pixel_norm: c=%d must be a power of two in [4,1024]", c);
-    const int L = (c >> 2) < 64 ? (c >> 2) : 64;
-    const long rows_per_block = 4 * (64 / L);
-    dim3 grid(ew_grid(((long)p + rows_per_block - 1) / rows_per_block * 256));
     hipStream_t st = as_stream(stream);
     GS_DISPATCH_DTYPE(dtype, {
-        if (mode == 0) hipLaunchKernelGGL((pixel_norm_kernel<T, 0>), grid, dim3(256), 0, st, (const T*)a0, (const T*)a1, (const T*)a2, (T*)out, (long)p, c, eps, act, pre, (const T*)addend, (T*)out2);
-        else if (mode == 1) hipLaunchKernelGGL((pixel_norm_kernel<T, 1>), grid, dim3(256), 0, st, (const T*)a0, (const T*)a1, (const T*)a2, (T*)out, (long)p, c, eps, act, pre, (const T*)addend, (T*)out2);
-        else hipLaunchKernelGGL((pixel_norm_kernel<T, 2>), grid, dim3(256), 0, st, (const T*)a0, (const T*)a1, (const T*)a2, (T*)out, (long)p, c, eps, act, pre, (const T*)addend, (T*)out2);
+        if (mode == 0) pixel_norm_launch_t<T, 0>(a0, a1, a2, out, (long)p, c, eps, act, pre, addend, out2, st);
+        else if (mode == 1) pixel_norm_launch_t<T, 1>(a0, a1, a2, out, (long)p, c, eps, act, pre, addend, out2, st);
+        else pixel_norm_launch_t<T, 2>(a0, a1, a2, out, (long)p, c, eps, act, pre, addend, out2, st);
     });
     GS_CHECK_LAUNCH();
     return 0;

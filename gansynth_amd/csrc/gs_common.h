@@ -85,6 +85,26 @@ __device__ inline void st4(bf16_t* p, const float (&o)[4]) {
     *reinterpret_cast<uint2*>(p) = v;
 }
 
+// 16-byte accesses: 4 floats or 8 bf16 per lane (what the memory path wants from a streaming kernel)
+template <typename T> struct Wide;   // 16 bytes of T
+template <> struct Wide<float> { static constexpr int N = 4; };
+template <> struct Wide<bf16_t> { static constexpr int N = 8; };
+template <typename T> __device__ inline void ld_wide(const T* p, float* o);
+template <> __device__ inline void ld_wide<float>(const float* p, float* o) { ld4(p, *reinterpret_cast<float(*)[4]>(o)); }
+template <> __device__ inline void ld_wide<bf16_t>(const bf16_t* p, float* o) {
+    const uint4 v = *reinterpret_cast<const uint4*>(p);
+    const unsigned int w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { o[2 * i] = __uint_as_float(w[i] << 16); o[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+}
+template <typename T> __device__ inline void st_wide(T* p, const float* o);
+template <> __device__ inline void st_wide<float>(float* p, const float* o) { *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]); }
+template <> __device__ inline void st_wide<bf16_t>(bf16_t* p, const float* o) {
+    uint4 v;
+    v.x = pack_bf16x2(o[0], o[1]); v.y = pack_bf16x2(o[2], o[3]); v.z = pack_bf16x2(o[4], o[5]); v.w = pack_bf16x2(o[6], o[7]);
+    *reinterpret_cast<uint4*>(p) = v;
+}
+
 // ------------------------------------------------------------- wave64 / block reductions
 __device__ inline float wave_sum(float v) {
 #pragma unroll
