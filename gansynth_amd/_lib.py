@@ -32,6 +32,9 @@ SIGNATURES = {
     "gs_conv2d_bwd_data_mask": (I, [P, P, P, I, P, I, I, I, I, I, I, I, F, I, I, P, Z, P]),
     "gs_conv2d_bwd_weight": (I, [P, P, P, I, I, I, I, I, I, I, F, I, I, P, Z, P]),
     "gs_conv2d_bwd_weight_bias": (I, [P, P, P, P, I, I, I, I, I, I, I, F, I, I, P, Z, P]),
+    "gs_conv2d_bwd_weight_bias_partial": (I, [P, P, P, P, I, I, I, I, I, I, I, F, I, I, P, Z, P, P]),
+    "gs_conv2d_transpose_s2_bwd_weight_partial": (I, [P, P, P, I, I, I, I, I, F, I, I, P, Z, P, P]),
+    "gs_wgrad_reduce_batch": (I, [P, I, P]),
     "gs_conv2d_transpose_s2_workspace_bytes": (Z, [I, I, I, I, I, I, I]),
     "gs_conv2d_transpose_s2_fwd": (I, [P, P, P, I, I, I, I, I, F, I, I, P, Z, P]),
     "gs_conv2d_transpose_s2_fwd_bias_act": (I, [P, P, P, P, I, I, I, I, I, F, I, I, I, P, Z, P]),
@@ -75,6 +78,13 @@ SIGNATURES = {
     "gs_mel_if_to_waveform": (I, [P, P, I, I, I, P, I, P, Z, P]),
     "gs_mel_if_to_waveform_workspace_bytes": (Z, [P, I]),
 }
+
+class GsWgradReduce(ctypes.Structure):
+    """include/gansynth_hip.h: one pending slice reduction of a weight gradient."""
+    _fields_ = [("partials", c_void_p), ("gw", c_void_p), ("gb", c_void_p), ("nslices", ctypes.c_int32), ("taps", ctypes.c_int32),
+                ("ic", ctypes.c_int32), ("oc", ctypes.c_int32), ("alpha", c_float), ("transpose", ctypes.c_int32),
+                ("accumulate", ctypes.c_int32)]
+
 
 _lib = None
 

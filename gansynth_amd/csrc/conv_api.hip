@@ -16,7 +16,8 @@ int run_igemm(int mode, int variant, const void* x, const float* w_hwio, void* y
 size_t wgrad_mfma_bytes(int mode, int dtype, int N, int Hb, int Wb, int IC, int OC);
 bool wgrad_mfma_has_bias(int dtype);
 int run_wgrad_mfma(int mode, const void* x, const void* gy, float* gw, float* gb, int N, int Hi, int Wi, int IC, int OC, int Hb,
-                   int Wb, float alpha, int transpose, int accumulate, int dtype, void* ws, size_t ws_bytes, hipStream_t st);
+                   int Wb, float alpha, int transpose, int accumulate, int dtype, void* ws, size_t ws_bytes, hipStream_t st,
+                   GsWgradReduce* defer = nullptr);
 
 // ------------------------------------------------------------------------- direct gather conv
 // y[n][oy][ox][oc0..oc0+OCV) = alpha * sum_{tap,ic} x[n][iy][ix][ic] * wp[tap][oc][ic]   (wp fp32)
@@ -464,7 +465,7 @@ static size_t wgrad_direct_bytes(int ks, int N, int Hb, int Wb, int IC, int OC) 
 
 static int run_wgrad_direct(int mode, int ks, const void* x, const void* gy, float* gw, int N, int Hi, int Wi, int IC,
                             int OC, int Hb, int Wb, float alpha, int transpose, int accumulate, int dtype, void* ws, size_t ws_bytes,
-                            hipStream_t st) {
+                            hipStream_t st, GsWgradReduce* defer = nullptr) {
     long ns, pps;
     const long npix = (long)N * Hb * Wb;
     const long E = (long)ks * ks * IC * OC;
@@ -481,7 +482,7 @@ static int run_wgrad_direct(int mode, int ks, const void* x, const void* gy, flo
                                                         reinterpret_cast<const T*>(x), reinterpret_cast<const T*>(gy), tpart, C, npix, pps));
         }
         GS_CHECK_LAUNCH();
-        wgrad_reduce_launch(tpart, gw, nullptr, (int)ns, 1, IC, OC, alpha, transpose, accumulate, st);
+        wgrad_reduce_launch(tpart, gw, nullptr, (int)ns, 1, IC, OC, alpha, transpose, accumulate, st, defer);
         GS_CHECK_LAUNCH();
         return 0;
     }
@@ -493,7 +494,7 @@ static int run_wgrad_direct(int mode, int ks, const void* x, const void* gy, flo
                                                 reinterpret_cast<const T*>(x), reinterpret_cast<const T*>(gy), part, mode,
                                                 ks, N, Hi, Wi, IC, OC, Hb, Wb, E, npix, pps));
     GS_CHECK_LAUNCH();
-    wgrad_reduce_launch(part, gw, nullptr, (int)ns, ks * ks, IC, OC, alpha, transpose, accumulate, st);
+    wgrad_reduce_launch(part, gw, nullptr, (int)ns, ks * ks, IC, OC, alpha, transpose, accumulate, st, defer);
     GS_CHECK_LAUNCH();
     return 0;
 }
@@ -567,7 +568,8 @@ extern "C" int gs_conv2d_bwd_data_mask(const void* gy, const float* w_hwio, cons
     // In the epilogue the mask costs one more read of gx's size through the vector-memory path: measured a win where the kernel
     // is MFMA-bound (>= 64 channels), a loss on the 32-channel top of the pyramid whose kernels are bound by exactly that path
     // (there the separate in-place pass below is as fast and leaves the conv alone).
-    bool fused = mask != nullptr && ci >= 64;
+    static const int fuse_min_ci = [] { const char* e = getenv("GS_MASK_FUSE_MIN_CI"); return e ? atoi(e) : 64; }();   // measurement knob
+    bool fused = mask != nullptr && ci >= fuse_min_ci;
     const void* km = fused ? mask : nullptr;
     if (stride == 1) {  // flipped taps, roles of ci/co swapped
         if (ksize == 3 && igemm_supported(co, ci, dtype))
@@ -591,20 +593,62 @@ extern "C" int gs_conv2d_bwd_data(const void* gy, const float* w_hwio, void* gx,
 extern "C" size_t gs_channel_sum_workspace_bytes(int64_t p, int c);
 extern "C" int gs_channel_sum(const void* g, float* out, int64_t p, int c, int accumulate, int dtype, void* ws, size_t ws_bytes, void* stream);
 
-extern "C" int gs_conv2d_bwd_weight_bias(const void* x, const void* gy, float* gw_hwio, float* gb, int n, int h, int w, int ci, int co,
-                                         int ksize, int stride, float alpha, int accumulate, int dtype, void* ws, size_t ws_bytes, void* stream) {
+extern "C" int gs_conv2d_bwd_weight_bias_partial(const void* x, const void* gy, float* gw_hwio, float* gb, int n, int h, int w, int ci, int co,
+                                                 int ksize, int stride, float alpha, int accumulate, int dtype, void* ws, size_t ws_bytes,
+                                                 GsWgradReduce* pending, void* stream) {
     if (int e = check_conv_args(n, h, w, ci, co, ksize, stride, dtype)) return e;
     hipStream_t st = as_stream(stream);
     const int hb = h / stride, wb = w / stride;
     const int mode = stride == 2 ? MODE_S2 : MODE_S1;
     const bool mfma = ksize == 3 && wgrad_mfma_supported(ci, co, dtype);
     const bool fused_bias = gb && mfma && wgrad_mfma_has_bias(dtype);
+    if (pending) memset(pending, 0, sizeof(*pending));
+    // the channel-sum fallback of the bias gradient reuses ws: such calls cannot leave their partials pending
+    GsWgradReduce* defer = (gb && !fused_bias) ? nullptr : pending;
     int rc;
-    if (mfma) rc = run_wgrad_mfma(mode, x, gy, gw_hwio, fused_bias ? gb : nullptr, n, h, w, ci, co, hb, wb, alpha, 0, accumulate, dtype, ws, ws_bytes, st);
-    else rc = run_wgrad_direct(mode, ksize, x, gy, gw_hwio, n, h, w, ci, co, hb, wb, alpha, 0, accumulate, dtype, ws, ws_bytes, st);
+    if (mfma) rc = run_wgrad_mfma(mode, x, gy, gw_hwio, fused_bias ? gb : nullptr, n, h, w, ci, co, hb, wb, alpha, 0, accumulate, dtype, ws, ws_bytes, st, defer);
+    else rc = run_wgrad_direct(mode, ksize, x, gy, gw_hwio, n, h, w, ci, co, hb, wb, alpha, 0, accumulate, dtype, ws, ws_bytes, st, defer);
     if (rc || !gb || fused_bias) return rc;
     // shapes without the fused path: the plain channel sum (stream-ordered after the kernels above, same workspace)
     return gs_channel_sum(gy, gb, (int64_t)n * hb * wb, co, accumulate, dtype, ws, ws_bytes, stream);
+}
+
+extern "C" int gs_conv2d_bwd_weight_bias(const void* x, const void* gy, float* gw_hwio, float* gb, int n, int h, int w, int ci, int co,
+                                         int ksize, int stride, float alpha, int accumulate, int dtype, void* ws, size_t ws_bytes, void* stream) {
+    return gs_conv2d_bwd_weight_bias_partial(x, gy, gw_hwio, gb, n, h, w, ci, co, ksize, stride, alpha, accumulate, dtype, ws, ws_bytes, nullptr, stream);
+}
+
+// many pending slice reductions in a handful of launches: up to GS_REDUCE_BATCH entries per launch, a new launch whenever an
+// entry adds into a gradient that the current launch already touches (list order = summation order)
+extern "C" int gs_wgrad_reduce_batch(const GsWgradReduce* pending, int n, void* stream) {
+    GS_CHECK_ARG(n >= 0 && (n == 0 || pending), "wgrad_reduce_batch: bad args");
+    hipStream_t st = as_stream(stream);
+    ReduceBatch b;
+    int cnt = 0;
+    long gx = 0;
+    auto flush = [&]() {
+        if (cnt == 0) return;
+        hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((unsigned)gx, (unsigned)cnt), dim3(256), 0, st, b);
+        cnt = 0;
+        gx = 0;
+    };
+    for (int i = 0; i < n; ++i) {
+        const GsWgradReduce& d = pending[i];
+        if (d.nslices <= 0) continue;   // nothing pending for this call
+        GS_CHECK_ARG(d.partials && d.gw && d.taps > 0 && d.ic > 0 && d.oc > 0 && (((long)d.taps * d.ic * d.oc) & 3) == 0 && (!d.gb || (d.oc & 3) == 0),
+                     "wgrad_reduce_batch: entry %d is not a pending reduction", i);
+        bool clash = cnt == GS_REDUCE_BATCH;
+        for (int j = 0; j < cnt && !clash; ++j) clash = b.e[j].gw == d.gw || (d.gb && b.e[j].gb == d.gb);
+        if (clash) flush();
+        b.e[cnt++] = d;
+        const long pstride = (long)d.taps * d.ic * d.oc + (d.gb ? d.oc : 0);
+        const long epb = 64;   // element quads per block (see the kernel)
+        const long blocks = (pstride / 4 + epb - 1) / epb;
+        if (blocks > gx) gx = blocks;
+    }
+    flush();
+    GS_CHECK_LAUNCH();
+    return 0;
 }
 
 extern "C" int gs_conv2d_bwd_weight(const void* x, const void* gy, float* gw_hwio, int n, int h, int w, int ci, int co,
@@ -656,12 +700,19 @@ extern "C" int gs_conv2d_transpose_s2_bwd_data(const void* gy, const float* w_hw
     return run_direct(MODE_S2, 3, 2, gy, w_hwio, gx, n, 2 * h, 2 * w, co, ci, ci, co, h, w, alpha, dtype, w_prepared, ws, ws_bytes, st);
 }
 
-extern "C" int gs_conv2d_transpose_s2_bwd_weight(const void* x, const void* gy, float* gw_hwio, int n, int h, int w, int ci,
-                                                 int co, float alpha, int accumulate, int dtype, void* ws, size_t ws_bytes, void* stream) {
+extern "C" int gs_conv2d_transpose_s2_bwd_weight_partial(const void* x, const void* gy, float* gw_hwio, int n, int h, int w, int ci,
+                                                         int co, float alpha, int accumulate, int dtype, void* ws, size_t ws_bytes,
+                                                         GsWgradReduce* pending, void* stream) {
     if (int e = check_conv_args(n, 2 * h, 2 * w, co, ci, 3, 2, dtype)) return e;
     hipStream_t st = as_stream(stream);
+    if (pending) memset(pending, 0, sizeof(*pending));
     // gw[k][ci][co] = sum x[i][ci] * gy[2i+k][co]: stride-2 wgrad with (input side = gy, output side = x), transposed
     if (wgrad_mfma_supported(co, ci, dtype))
-        return run_wgrad_mfma(MODE_S2, gy, x, gw_hwio, nullptr, n, 2 * h, 2 * w, co, ci, h, w, alpha, 1, accumulate, dtype, ws, ws_bytes, st);
-    return run_wgrad_direct(MODE_S2, 3, gy, x, gw_hwio, n, 2 * h, 2 * w, co, ci, h, w, alpha, 1, accumulate, dtype, ws, ws_bytes, st);
+        return run_wgrad_mfma(MODE_S2, gy, x, gw_hwio, nullptr, n, 2 * h, 2 * w, co, ci, h, w, alpha, 1, accumulate, dtype, ws, ws_bytes, st, pending);
+    return run_wgrad_direct(MODE_S2, 3, gy, x, gw_hwio, n, 2 * h, 2 * w, co, ci, h, w, alpha, 1, accumulate, dtype, ws, ws_bytes, st, pending);
+}
+
+extern "C" int gs_conv2d_transpose_s2_bwd_weight(const void* x, const void* gy, float* gw_hwio, int n, int h, int w, int ci,
+                                                 int co, float alpha, int accumulate, int dtype, void* ws, size_t ws_bytes, void* stream) {
+    return gs_conv2d_transpose_s2_bwd_weight_partial(x, gy, gw_hwio, n, h, w, ci, co, alpha, accumulate, dtype, ws, ws_bytes, nullptr, stream);
 }

@@ -1136,7 +1136,8 @@ size_t wgrad_mfma_bytes(int mode, int dtype, int N, int Hb, int Wb, int IC, int 
 // x: conv input side [N][Hi][Wi][IC]; gy: [N][Hb][Wb][OC]; gw[9][IC][OC] (or transposed)
 // gb (optional, bf16 only): bias gradient sum_pixels gy[.][oc], produced by the same two launches
 int run_wgrad_mfma(int mode, const void* x, const void* gy, float* gw, float* gb, int N, int Hi, int Wi, int IC, int OC, int Hb,
-                   int Wb, float alpha, int transpose, int accumulate, int dtype, void* ws, size_t ws_bytes, hipStream_t st) {
+                   int Wb, float alpha, int transpose, int accumulate, int dtype, void* ws, size_t ws_bytes, hipStream_t st,
+                   GsWgradReduce* defer) {
     int tw, tiles_x, tiles_y, ntiles, nslices;
     wgrad_geometry(mode, dtype, N, Hb, Wb, IC, OC, &tw, &tiles_x, &tiles_y, &ntiles, &nslices);
     if (gb && !wgrad_mfma_has_bias(dtype)) return fail(GS_ERR_UNSUPPORTED, "conv wgrad: fused bias gradient needs the bf16 kernels");
@@ -1188,7 +1189,7 @@ int run_wgrad_mfma(int mode, const void* x, const void* gy, float* gw, float* gb
 #undef GS_WG
     }
     GS_CHECK_LAUNCH();
-    wgrad_reduce_launch(part, gw, gb, nslices, 9, IC, OC, alpha, transpose, accumulate, st);
+    wgrad_reduce_launch(part, gw, gb, nslices, 9, IC, OC, alpha, transpose, accumulate, st, defer);
     GS_CHECK_LAUNCH();
     return 0;
 }

@@ -113,9 +113,90 @@ static __global__ __launch_bounds__(256) void wgrad_reduce_scalar_kernel(const f
     gw[dst] = accumulate ? gw[dst] + s : s;
 }
 
+// ---- many reductions per launch (gs_wgrad_reduce_batch): blockIdx.y = entry, blockIdx.x = element chunk of that entry
+#define GS_REDUCE_BATCH 16
+struct ReduceBatch {
+    GsWgradReduce e[GS_REDUCE_BATCH];
+};
+static __global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const ReduceBatch b) {
+    // block = 64 consecutive element quads (1 KiB per slice row: whole DRAM bursts) x 4 slice lanes; a thread keeps four slice
+    // rows in flight
+    const GsWgradReduce& d = b.e[blockIdx.y];
+    const int nslices = d.nslices, oc = d.oc, ic = d.ic;
+    constexpr int L = 4, EPB = 64;
+    __shared__ float4 red[256];
+    const long total = (long)d.taps * ic * oc;
+    const long pstride = total + (d.gb ? oc : 0);
+    const long e = ((long)blockIdx.x * EPB + (threadIdx.x % EPB)) * 4;
+    if ((long)blockIdx.x * EPB * 4 >= pstride) return;   // (whole block past the end of this entry)
+    const int sl = threadIdx.x / EPB;
+    const float* __restrict__ part = d.partials;
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+    if (e < pstride) {
+        int k = sl;
+        for (; k + 3 * L < nslices; k += 4 * L) {
+            const float4 a0 = *reinterpret_cast<const float4*>(part + (long)k * pstride + e);
+            const float4 a1 = *reinterpret_cast<const float4*>(part + (long)(k + L) * pstride + e);
+            const float4 a2 = *reinterpret_cast<const float4*>(part + (long)(k + 2 * L) * pstride + e);
+            const float4 a3 = *reinterpret_cast<const float4*>(part + (long)(k + 3 * L) * pstride + e);
+            s0.x += a0.x; s0.y += a0.y; s0.z += a0.z; s0.w += a0.w;
+            s1.x += a1.x; s1.y += a1.y; s1.z += a1.z; s1.w += a1.w;
+            s2.x += a2.x; s2.y += a2.y; s2.z += a2.z; s2.w += a2.w;
+            s3.x += a3.x; s3.y += a3.y; s3.z += a3.z; s3.w += a3.w;
+        }
+        for (; k < nslices; k += L) {
+            const float4 a = *reinterpret_cast<const float4*>(part + (long)k * pstride + e);
+            s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+        }
+    }
+    s0.x += s2.x; s0.y += s2.y; s0.z += s2.z; s0.w += s2.w;
+    s1.x += s3.x; s1.y += s3.y; s1.z += s3.z; s1.w += s3.w;
+    red[threadIdx.x] = make_float4(s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w);
+    __syncthreads();
+    if (sl != 0 || e >= pstride) return;
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < L; ++j) {
+        const float4 v = red[threadIdx.x + j * EPB];
+        t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+    }
+    const float s[4] = {t.x, t.y, t.z, t.w};
+    const int accumulate = d.accumulate;
+    if (e >= total) {   // bias gradient: no equalized-LR scale
+        float4* o = reinterpret_cast<float4*>(d.gb + (e - total));
+        const float4 old = accumulate ? *o : make_float4(0.f, 0.f, 0.f, 0.f);
+        *o = make_float4(old.x + s[0], old.y + s[1], old.z + s[2], old.w + s[3]);
+        return;
+    }
+    const float alpha = d.alpha;
+    float* __restrict__ gw = d.gw;
+    if (!d.transpose) {
+        float4* o = reinterpret_cast<float4*>(gw + e);
+        const float4 old = accumulate ? *o : make_float4(0.f, 0.f, 0.f, 0.f);
+        *o = make_float4(old.x + s[0] * alpha, old.y + s[1] * alpha, old.z + s[2] * alpha, old.w + s[3] * alpha);
+    } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const long ee = e + c;
+            const int o = ee % oc;
+            const int i = (ee / oc) % ic;
+            const int tp = ee / ((long)ic * oc);
+            const long dst = ((long)tp * oc + o) * ic + i;
+            gw[dst] = accumulate ? gw[dst] + s[c] * alpha : s[c] * alpha;
+        }
+    }
+}
+
 static inline size_t wgrad_reduce_extra(long nslices, long total) { (void)nslices; (void)total; return 0; }
-static inline void wgrad_reduce_launch(float* part, float* gw, float* gb, int nslices, int taps, int ic, int oc, float alpha, int transpose, int accumulate, hipStream_t st) {
-    if ((((long)taps * ic * oc) & 3) != 0 || (gb && (oc & 3) != 0)) {
+static inline void wgrad_reduce_launch(float* part, float* gw, float* gb, int nslices, int taps, int ic, int oc, float alpha, int transpose, int accumulate, hipStream_t st,
+                                       GsWgradReduce* defer = nullptr) {
+    const bool vec = !((((long)taps * ic * oc) & 3) != 0 || (gb && (oc & 3) != 0));
+    if (defer && vec) {   // phase 2 is left to gs_wgrad_reduce_batch
+        defer->partials = part; defer->gw = gw; defer->gb = gb;
+        defer->nslices = nslices; defer->taps = taps; defer->ic = ic; defer->oc = oc;
+        defer->alpha = alpha; defer->transpose = transpose; defer->accumulate = accumulate;
+        return;
+    }
+    if (!vec) {
         const long total = (long)taps * ic * oc;   // (gb never comes with such shapes: the fused bias path needs oc % 32 == 0)
         hipLaunchKernelGGL(wgrad_reduce_scalar_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, part, gw, nslices, taps, ic, oc, alpha, transpose, accumulate);
         return;

@@ -70,6 +70,7 @@ class HipKernels(object):
         self._param_ranges = []   # (ptr, nbytes) of registered flat parameter buffers
         self._wcache = {}         # (weight ptr, map tag) -> (persistent workspace holding the re-laid operand, stamp)
         self._prep_tables = {}    # tuple of cache keys -> device table of GsPrepDesc rows (refresh_weights)
+        self._pending = None      # deferred weight-gradient reductions: [(GsWgradReduce, workspace kept alive)] while deferring
 
     # --------------------------------------------------------- prepared-weight workspaces
     def register_param_buffer(self, flat):
@@ -126,6 +127,22 @@ class HipKernels(object):
             e[1] = (e[4][2], e[2]._version)
         return len(stale)
 
+    # ------------------------------------------------- deferred weight-gradient reductions
+    def defer_wgrad_reductions(self):
+        """From now on the in-place (`out=`) weight gradients only write their block partials; flush_wgrad_reductions() folds
+        all of them in a handful of launches (a backward pass has ~70 such reductions, each a launch of its own otherwise).
+        The gradients in the `out` buffers are complete only after the flush."""
+        if self._pending is None:
+            self._pending = []
+
+    def flush_wgrad_reductions(self):
+        pend, self._pending = self._pending, None
+        if not pend:
+            return 0
+        arr = (_lib.GsWgradReduce * len(pend))(*[d for d, _ in pend])
+        _lib.check(self.lib.gs_wgrad_reduce_batch(ctypes.cast(arr, ctypes.c_void_p), len(pend), _stream()), "gs_wgrad_reduce_batch")
+        return len(pend)   # (the workspaces die here: every later launch is stream-ordered behind the reduction)
+
     # ------------------------------------------------------------------------------- conv
     def conv2d_fwd(self, x, w, ksize, stride, alpha):
         return self.conv2d_fwd_bias_act(x, w, None, ksize, stride, alpha, _lib.ACT_NONE)
@@ -175,9 +192,14 @@ class HipKernels(object):
         ws = _ws(nb, x.device)
         if bias_out is not None:
             assert out is not None and bias_out.dtype == torch.float32 and bias_out.is_contiguous()
-        _lib.check(self.lib.gs_conv2d_bwd_weight_bias(x.data_ptr(), gy.data_ptr(), gw.data_ptr(), None if bias_out is None else bias_out.data_ptr(),
-                                                      n, h, wd, ci, co, ksize, stride, float(alpha), 0 if out is None else 1, _dt(x),
-                                                      ws.data_ptr(), ws.numel(), _stream()), "gs_conv2d_bwd_weight_bias")
+        pend = _lib.GsWgradReduce() if (out is not None and self._pending is not None) else None
+        _lib.check(self.lib.gs_conv2d_bwd_weight_bias_partial(x.data_ptr(), gy.data_ptr(), gw.data_ptr(),
+                                                              None if bias_out is None else bias_out.data_ptr(),
+                                                              n, h, wd, ci, co, ksize, stride, float(alpha), 0 if out is None else 1, _dt(x),
+                                                              ws.data_ptr(), ws.numel(), None if pend is None else ctypes.addressof(pend),
+                                                              _stream()), "gs_conv2d_bwd_weight_bias_partial")
+        if pend is not None and pend.nslices > 0:
+            self._pending.append((pend, ws))
         return gw
 
     def conv2d_transpose_fwd(self, x, w, alpha):
@@ -218,9 +240,13 @@ class HipKernels(object):
         gw = torch.empty((3, 3, ci, co), dtype=torch.float32, device=x.device) if out is None else out
         nb = self.lib.gs_conv2d_transpose_s2_workspace_bytes(_lib.CONV_BWD_WEIGHT, n, h, wd, ci, co, _dt(x))
         ws = _ws(nb, x.device)
-        _lib.check(self.lib.gs_conv2d_transpose_s2_bwd_weight(x.data_ptr(), gy.data_ptr(), gw.data_ptr(), n, h, wd, ci, co, float(alpha),
-                                                              0 if out is None else 1, _dt(x), ws.data_ptr(), ws.numel(), _stream()),
-                   "gs_conv2d_transpose_s2_bwd_weight")
+        pend = _lib.GsWgradReduce() if (out is not None and self._pending is not None) else None
+        _lib.check(self.lib.gs_conv2d_transpose_s2_bwd_weight_partial(x.data_ptr(), gy.data_ptr(), gw.data_ptr(), n, h, wd, ci, co, float(alpha),
+                                                                      0 if out is None else 1, _dt(x), ws.data_ptr(), ws.numel(),
+                                                                      None if pend is None else ctypes.addressof(pend), _stream()),
+                   "gs_conv2d_transpose_s2_bwd_weight_partial")
+        if pend is not None and pend.nslices > 0:
+            self._pending.append((pend, ws))
         return gw
 
     # ------------------------------------------------------------------------------ dense

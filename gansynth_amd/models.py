@@ -27,6 +27,9 @@ from . import variables
 _PAD = 64  # floats; keeps every parameter view 256-byte aligned inside the flat buffer
 
 
+_DEFER_REDUCTIONS = not __import__("os").environ.get("GS_NO_DEFERRED_REDUCE")   # A/B switch for measurements
+
+
 class _FlatParams(object):
     """All trainable variables of one scope re-homed into one flat fp32 buffer (+grad, m, v)."""
 
@@ -180,7 +183,15 @@ class GANSynth(object):
             self.d_params.requires_grad_(False)
             self.g_params.zero_grad()
             loss = self.generator_losses(*inputs).mean()
-        loss.backward()
+        K = kernels.get()
+        deferring = _DEFER_REDUCTIONS and hasattr(K, "defer_wgrad_reductions")   # parameter gradients are only read after the whole backward:
+        if deferring:                                        # their ~70 slice reductions are folded in one go at the end
+            K.defer_wgrad_reductions()
+        try:
+            loss.backward()
+        finally:
+            if deferring:
+                K.flush_wgrad_reductions()
         return loss.detach()
 
     def _graphable(self):

@@ -112,6 +112,28 @@ int gs_conv2d_transpose_s2_bwd_data(const void* gy, const float* w_hwio, void* g
 int gs_conv2d_transpose_s2_bwd_weight(const void* x, const void* gy, float* gw_hwio, int n, int h, int w, int ci, int co,
                                       float alpha, int accumulate, int dtype, void* ws, size_t ws_bytes, void* stream);
 
+/* Deferred slice reduction of the weight gradients.  Every bwd_weight call is two phases: block-partial sums over pixel slices
+ * (in ws), then a reduction over the slices into gw (+ gb).  The `_partial` entry points run phase 1 only and describe phase 2 in
+ * `pending`; gs_wgrad_reduce_batch then folds many pending reductions in a handful of launches (a backward pass has ~70 of them;
+ * each is a 10 us launch on its own).  Contract: the call's ws must stay untouched until gs_wgrad_reduce_batch has been enqueued
+ * on the same stream; pending->nslices == 0 on return means nothing is pending (shapes without the vector reduce ran both
+ * phases at once).  Entries that add into the same gw are applied in list order (the sum stays deterministic). */
+typedef struct GsWgradReduce {
+    const float* partials; /* [nslices][taps*ic*oc (+ oc when gb)] fp32, inside the call's ws */
+    float* gw;             /* [taps][ic][oc], or [taps][oc][ic] when transpose */
+    float* gb;             /* optional [oc] */
+    int32_t nslices, taps, ic, oc;
+    float alpha;
+    int32_t transpose, accumulate;
+} GsWgradReduce;
+int gs_conv2d_bwd_weight_bias_partial(const void* x, const void* gy, float* gw_hwio, float* gb, int n, int h, int w, int ci, int co,
+                                      int ksize, int stride, float alpha, int accumulate, int dtype, void* ws, size_t ws_bytes,
+                                      GsWgradReduce* pending, void* stream);
+int gs_conv2d_transpose_s2_bwd_weight_partial(const void* x, const void* gy, float* gw_hwio, int n, int h, int w, int ci, int co,
+                                              float alpha, int accumulate, int dtype, void* ws, size_t ws_bytes,
+                                              GsWgradReduce* pending, void* stream);
+int gs_wgrad_reduce_batch(const GsWgradReduce* pending, int n, void* stream);   /* `pending`: host array */
+
 /* Refreshing many prepared weight operands in one launch (after an optimizer step: ~60 conv maps, one kernel instead of
  * one re-layout launch in front of each conv).  A descriptor names the fp32 HWIO master weight, the persistent workspace
  * of one (weight, map) pair and the map: GS_PREP_* below, (ci, co, ksize, stride) of the variable, activation dtype.

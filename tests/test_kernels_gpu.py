@@ -461,3 +461,43 @@ def test_pixel_norm_gradient_forms_pair_up_at_full_size(K, dtype):
     a, b = float((gg.double() * post.double()).sum()), float((g.double() * pre.double()).sum())
     scale = float(gg.double().norm() * post.double().norm())
     assert abs(a - b) <= (1e-5 if dtype == torch.float32 else 2e-3) * scale, (a, b, scale)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_deferred_weight_gradient_reductions_match_immediate_ones(K, dtype):
+    """gs_*_bwd_weight*_partial + gs_wgrad_reduce_batch: the same block partials folded later, many per launch -- bit-identical to
+    the immediate reduction, including two contributions into one gradient (list order), the bias row, the transposed conv,
+    the thin / direct kernels and more entries than one launch holds."""
+    cases = [(2, 32, 32, 8, 128, 3, 1), (2, 64, 64, 8, 64, 3, 1), (2, 64, 128, 8, 64, 3, 2), (2, 32, 64, 8, 128, 3, 2), (2, 128, 128, 4, 32, 3, 1),
+             (2, 32, 2, 8, 64, 1, 1), (2, 2, 32, 8, 64, 1, 1), (4, 1, 16, 2, 16, 3, 1), (2, 256, 256, 2, 16, 3, 1)]
+    cases = cases + cases[:5] + cases[:5]   # > 16 entries, repeated targets
+    work = []
+    for i, (n, ci, co, h, w, ks, st) in enumerate(cases):
+        x = dev(rnd(n, ci, h, w, seed=10 + i), dtype)
+        gy = dev(rnd(n, co, h // st, w // st, seed=40 + i), dtype)
+        work.append((x, gy, ks, st))
+    xt, gyt = dev(rnd(2, 64, 8, 64, seed=4), dtype), dev(rnd(2, 32, 16, 128, seed=5), dtype)
+
+    def run(deferred):
+        grads = {}
+        for (x, gy, ks, st) in work:   # repeated cases share their gradient buffers
+            key = (tuple(x.shape), tuple(gy.shape), ks, st)
+            if key not in grads:
+                grads[key] = (torch.full((ks, ks, x.shape[1], gy.shape[1]), 0.5, device="cuda"), torch.full((gy.shape[1],), -0.25, device="cuda"))
+        gt = torch.full((3, 3, 64, 32), 0.125, device="cuda")
+        if deferred:
+            K.defer_wgrad_reductions()
+        for (x, gy, ks, st) in work:
+            gw, gb = grads[(tuple(x.shape), tuple(gy.shape), ks, st)]
+            K.conv2d_bwd_weight(x, gy, ks, st, 0.2, out=gw, bias_out=gb if (ks == 3 and dtype == torch.bfloat16) else None)   # (fp32 bias sums are not deferrable)
+        K.conv2d_transpose_bwd_weight(xt, gyt, 0.1, out=gt)
+        K.conv2d_transpose_bwd_weight(xt, gyt, 0.3, out=gt)
+        if deferred:
+            assert K.flush_wgrad_reductions() > 16
+        torch.cuda.synchronize()
+        return [t.clone() for pair in grads.values() for t in pair] + [gt.clone()]
+
+    now, later = run(False), run(True)
+    for a, b in zip(now, later):   # (the batched kernel sums the slices in a different association: equal to rounding, not to the bit)
+        assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max())
+    assert K._pending is None
