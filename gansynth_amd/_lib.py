@@ -35,6 +35,8 @@ SIGNATURES = {
     "gs_conv2d_bwd_weight_bias_partial": (I, [P, P, P, P, I, I, I, I, I, I, I, F, I, I, P, Z, P, P]),
     "gs_conv2d_transpose_s2_bwd_weight_partial": (I, [P, P, P, I, I, I, I, I, F, I, I, P, Z, P, P]),
     "gs_wgrad_reduce_batch": (I, [P, I, P]),
+    "gs_conv2d_bwd_weight_bias_multi": (I, [P, P, I, ctypes.c_uint, P, P, I, I, I, I, I, I, I, F, I, I, P, Z, P, P]),
+    "gs_conv2d_transpose_s2_bwd_weight_multi": (I, [P, P, I, P, I, I, I, I, I, F, I, I, P, Z, P, P]),
     "gs_conv2d_transpose_s2_workspace_bytes": (Z, [I, I, I, I, I, I, I]),
     "gs_conv2d_transpose_s2_fwd": (I, [P, P, P, I, I, I, I, I, F, I, I, P, Z, P]),
     "gs_conv2d_transpose_s2_fwd_bias_act": (I, [P, P, P, P, I, I, I, I, I, F, I, I, I, P, Z, P]),
@@ -78,6 +80,9 @@ SIGNATURES = {
     "gs_mel_if_to_waveform": (I, [P, P, I, I, I, P, I, P, Z, P]),
     "gs_mel_if_to_waveform_workspace_bytes": (Z, [P, I]),
 }
+
+WGRAD_MAX_SOURCES = 4   # GS_WGRAD_MAX_SOURCES
+
 
 class GsWgradReduce(ctypes.Structure):
     """include/gansynth_hip.h: one pending slice reduction of a weight gradient."""

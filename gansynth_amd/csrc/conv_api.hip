@@ -15,7 +15,7 @@ int run_igemm(int mode, int variant, const void* x, const float* w_hwio, void* y
               void* ws, size_t ws_bytes, hipStream_t st, const void* mask = nullptr, int mask_act = 0);
 size_t wgrad_mfma_bytes(int mode, int dtype, int N, int Hb, int Wb, int IC, int OC);
 bool wgrad_mfma_has_bias(int dtype);
-int run_wgrad_mfma(int mode, const void* x, const void* gy, float* gw, float* gb, int N, int Hi, int Wi, int IC, int OC, int Hb,
+int run_wgrad_mfma(int mode, const WgradSrcs& srcs, int nsrc, float* gw, float* gb, int N, int Hi, int Wi, int IC, int OC, int Hb,
                    int Wb, float alpha, int transpose, int accumulate, int dtype, void* ws, size_t ws_bytes, hipStream_t st,
                    GsWgradReduce* defer = nullptr);
 
@@ -593,24 +593,59 @@ extern "C" int gs_conv2d_bwd_data(const void* gy, const float* w_hwio, void* gx,
 extern "C" size_t gs_channel_sum_workspace_bytes(int64_t p, int c);
 extern "C" int gs_channel_sum(const void* g, float* out, int64_t p, int c, int accumulate, int dtype, void* ws, size_t ws_bytes, void* stream);
 
-extern "C" int gs_conv2d_bwd_weight_bias_partial(const void* x, const void* gy, float* gw_hwio, float* gb, int n, int h, int w, int ci, int co,
-                                                 int ksize, int stride, float alpha, int accumulate, int dtype, void* ws, size_t ws_bytes,
-                                                 GsWgradReduce* pending, void* stream) {
+// the (x, gy) pairs of one launch, as the kernels want them; for the transposed conv the roles of the two sides swap
+static WgradSrcs make_srcs(const void* const* xs, const void* const* gys, int nsrc, int n_per, unsigned bias_mask, bool swap) {
+    WgradSrcs s;
+    memset(&s, 0, sizeof(s));
+    for (int i = 0; i < nsrc && i < GS_WGRAD_MAX_SRC; ++i) {
+        s.x[i] = swap ? gys[i] : xs[i];
+        s.gy[i] = swap ? xs[i] : gys[i];
+    }
+    s.n_per = n_per;
+    s.bias_mask = bias_mask;
+    return s;
+}
+
+extern "C" int gs_conv2d_bwd_weight_bias_multi(const void* const* xs, const void* const* gys, int nsrc, unsigned bias_mask, float* gw_hwio, float* gb,
+                                               int n, int h, int w, int ci, int co, int ksize, int stride, float alpha, int accumulate, int dtype,
+                                               void* ws, size_t ws_bytes, GsWgradReduce* pending, void* stream) {
     if (int e = check_conv_args(n, h, w, ci, co, ksize, stride, dtype)) return e;
+    GS_CHECK_ARG(xs && gys && nsrc >= 1 && nsrc <= GS_WGRAD_MAX_SRC, "conv2d_bwd_weight_bias_multi: %d sources (1..%d)", nsrc, GS_WGRAD_MAX_SRC);
+    for (int i = 0; i < nsrc; ++i) GS_CHECK_ARG(xs[i] && gys[i], "conv2d_bwd_weight_bias_multi: null source %d", i);
     hipStream_t st = as_stream(stream);
     const int hb = h / stride, wb = w / stride;
     const int mode = stride == 2 ? MODE_S2 : MODE_S1;
     const bool mfma = ksize == 3 && wgrad_mfma_supported(ci, co, dtype);
-    const bool fused_bias = gb && mfma && wgrad_mfma_has_bias(dtype);
     if (pending) memset(pending, 0, sizeof(*pending));
+    if (!gb) bias_mask = 0;
+    if (nsrc > 1 && !(mfma && (!gb || wgrad_mfma_has_bias(dtype)))) {
+        // shapes without the multi-source kernels: one call per source (the first applies `accumulate`, the rest add)
+        for (int i = 0; i < nsrc; ++i) {
+            const int rc = gs_conv2d_bwd_weight_bias_multi(xs + i, gys + i, 1, 1u, gw_hwio, ((bias_mask >> i) & 1u) ? gb : nullptr, n, h, w, ci, co, ksize, stride,
+                                                           alpha, i == 0 ? accumulate : 1, dtype, ws, ws_bytes, nullptr, stream);
+            if (rc) return rc;
+        }
+        return 0;
+    }
+    const bool fused_bias = bias_mask && mfma && wgrad_mfma_has_bias(dtype);
     // the channel-sum fallback of the bias gradient reuses ws: such calls cannot leave their partials pending
-    GsWgradReduce* defer = (gb && !fused_bias) ? nullptr : pending;
+    GsWgradReduce* defer = (bias_mask && !fused_bias) ? nullptr : pending;
     int rc;
-    if (mfma) rc = run_wgrad_mfma(mode, x, gy, gw_hwio, fused_bias ? gb : nullptr, n, h, w, ci, co, hb, wb, alpha, 0, accumulate, dtype, ws, ws_bytes, st, defer);
-    else rc = run_wgrad_direct(mode, ksize, x, gy, gw_hwio, n, h, w, ci, co, hb, wb, alpha, 0, accumulate, dtype, ws, ws_bytes, st, defer);
-    if (rc || !gb || fused_bias) return rc;
+    if (mfma) {
+        const WgradSrcs srcs = make_srcs(xs, gys, nsrc, n, bias_mask, false);
+        rc = run_wgrad_mfma(mode, srcs, nsrc, gw_hwio, fused_bias ? gb : nullptr, n * nsrc, h, w, ci, co, hb, wb, alpha, 0, accumulate, dtype, ws, ws_bytes, st, defer);
+    } else {
+        rc = run_wgrad_direct(mode, ksize, xs[0], gys[0], gw_hwio, n, h, w, ci, co, hb, wb, alpha, 0, accumulate, dtype, ws, ws_bytes, st, defer);
+    }
+    if (rc || !bias_mask || fused_bias) return rc;
     // shapes without the fused path: the plain channel sum (stream-ordered after the kernels above, same workspace)
-    return gs_channel_sum(gy, gb, (int64_t)n * hb * wb, co, accumulate, dtype, ws, ws_bytes, stream);
+    return gs_channel_sum(gys[0], gb, (int64_t)n * hb * wb, co, accumulate, dtype, ws, ws_bytes, stream);
+}
+
+extern "C" int gs_conv2d_bwd_weight_bias_partial(const void* x, const void* gy, float* gw_hwio, float* gb, int n, int h, int w, int ci, int co,
+                                                 int ksize, int stride, float alpha, int accumulate, int dtype, void* ws, size_t ws_bytes,
+                                                 GsWgradReduce* pending, void* stream) {
+    return gs_conv2d_bwd_weight_bias_multi(&x, &gy, 1, 1u, gw_hwio, gb, n, h, w, ci, co, ksize, stride, alpha, accumulate, dtype, ws, ws_bytes, pending, stream);
 }
 
 extern "C" int gs_conv2d_bwd_weight_bias(const void* x, const void* gy, float* gw_hwio, float* gb, int n, int h, int w, int ci, int co,
@@ -700,16 +735,31 @@ extern "C" int gs_conv2d_transpose_s2_bwd_data(const void* gy, const float* w_hw
     return run_direct(MODE_S2, 3, 2, gy, w_hwio, gx, n, 2 * h, 2 * w, co, ci, ci, co, h, w, alpha, dtype, w_prepared, ws, ws_bytes, st);
 }
 
-extern "C" int gs_conv2d_transpose_s2_bwd_weight_partial(const void* x, const void* gy, float* gw_hwio, int n, int h, int w, int ci,
-                                                         int co, float alpha, int accumulate, int dtype, void* ws, size_t ws_bytes,
-                                                         GsWgradReduce* pending, void* stream) {
+extern "C" int gs_conv2d_transpose_s2_bwd_weight_multi(const void* const* xs, const void* const* gys, int nsrc, float* gw_hwio, int n, int h, int w,
+                                                       int ci, int co, float alpha, int accumulate, int dtype, void* ws, size_t ws_bytes,
+                                                       GsWgradReduce* pending, void* stream) {
     if (int e = check_conv_args(n, 2 * h, 2 * w, co, ci, 3, 2, dtype)) return e;
+    GS_CHECK_ARG(xs && gys && nsrc >= 1 && nsrc <= GS_WGRAD_MAX_SRC, "conv2d_transpose_s2_bwd_weight_multi: %d sources (1..%d)", nsrc, GS_WGRAD_MAX_SRC);
+    for (int i = 0; i < nsrc; ++i) GS_CHECK_ARG(xs[i] && gys[i], "conv2d_transpose_s2_bwd_weight_multi: null source %d", i);
     hipStream_t st = as_stream(stream);
     if (pending) memset(pending, 0, sizeof(*pending));
     // gw[k][ci][co] = sum x[i][ci] * gy[2i+k][co]: stride-2 wgrad with (input side = gy, output side = x), transposed
-    if (wgrad_mfma_supported(co, ci, dtype))
-        return run_wgrad_mfma(MODE_S2, gy, x, gw_hwio, nullptr, n, 2 * h, 2 * w, co, ci, h, w, alpha, 1, accumulate, dtype, ws, ws_bytes, st, pending);
-    return run_wgrad_direct(MODE_S2, 3, gy, x, gw_hwio, n, 2 * h, 2 * w, co, ci, h, w, alpha, 1, accumulate, dtype, ws, ws_bytes, st, pending);
+    if (wgrad_mfma_supported(co, ci, dtype)) {
+        const WgradSrcs srcs = make_srcs(xs, gys, nsrc, n, 0u, true);
+        return run_wgrad_mfma(MODE_S2, srcs, nsrc, gw_hwio, nullptr, n * nsrc, 2 * h, 2 * w, co, ci, h, w, alpha, 1, accumulate, dtype, ws, ws_bytes, st, pending);
+    }
+    for (int i = 0; i < nsrc; ++i) {   // (direct kernels: one call per source)
+        const int rc = run_wgrad_direct(MODE_S2, 3, gys[i], xs[i], gw_hwio, n, 2 * h, 2 * w, co, ci, h, w, alpha, 1, i == 0 ? accumulate : 1, dtype, ws, ws_bytes, st,
+                                        nsrc == 1 ? pending : nullptr);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+extern "C" int gs_conv2d_transpose_s2_bwd_weight_partial(const void* x, const void* gy, float* gw_hwio, int n, int h, int w, int ci,
+                                                         int co, float alpha, int accumulate, int dtype, void* ws, size_t ws_bytes,
+                                                         GsWgradReduce* pending, void* stream) {
+    return gs_conv2d_transpose_s2_bwd_weight_multi(&x, &gy, 1, gw_hwio, n, h, w, ci, co, alpha, accumulate, dtype, ws, ws_bytes, pending, stream);
 }
 
 extern "C" int gs_conv2d_transpose_s2_bwd_weight(const void* x, const void* gy, float* gw_hwio, int n, int h, int w, int ci,

@@ -554,7 +554,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
 // LDS and write one fp32 partial per slice (summed by wgrad_reduce_kernel -> deterministic).
 template <typename T, int MODE, int TW>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(
-    const T* __restrict__ x, const T* __restrict__ gy, float* __restrict__ part,
+    const WgradSrcs srcs, float* __restrict__ part,
     int N, int Hi, int Wi, int IC, int OC, int Hb, int Wb, int tiles_x, int tiles_y, int ntiles, int nslices) {
     // T = bf16: operands are widened to fp32 while staging (exact), the contraction runs on the fp32 MFMA.
     constexpr int NP = MODE == MODE_S2 ? 64 : 128;
@@ -585,7 +585,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
         const int tile_x = b % tiles_x;
         b /= tiles_x;
         const int tile_y = b % tiles_y;
-        const int n = b / tiles_y;
+        const int nn = b / tiles_y, src = nn / srcs.n_per, n = nn - src * srcs.n_per;
+        const T* __restrict__ x = reinterpret_cast<const T*>(srcs.x[src]);
+        const T* __restrict__ gy = reinterpret_cast<const T*>(srcs.gy[src]);
         const int by = tile_y * TH, bx = tile_x * TW;
         const int oy0 = MODE == MODE_S2 ? 2 * by : by - 1;
         const int ox0 = MODE == MODE_S2 ? 2 * bx : bx - 1;
@@ -672,7 +674,7 @@ __device__ inline void add_bf16_pair(float& acc, unsigned int a) {
 
 template <int MODE, int TW>
 __global__ __launch_bounds__(192) void conv_wgrad_bf16_kernel(
-    const bf16_t* __restrict__ x, const bf16_t* __restrict__ gy, float* __restrict__ part,
+    const WgradSrcs srcs, float* __restrict__ part,
     int N, int Hi, int Wi, int IC, int OC, int Hb, int Wb, int tiles_x, int tiles_y, int ntiles, int nslices, int with_bias) {
     constexpr bool S2 = MODE == MODE_S2;
     constexpr int NP = S2 ? 128 : 256;
@@ -701,7 +703,7 @@ __global__ __launch_bounds__(192) void conv_wgrad_bf16_kernel(
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     // bias gradient = sum over pixels of gy: the gradient fragment of a lane is 8 pixels of its output channel, four packed
     // dot-2 adds per pixel group fold them into one register; done by the first wave of the blocks of input-channel tile 0
-    const bool do_bias = with_bias && wv == 0 && ic0 == 0;
+    const bool bias_wave = with_bias && wv == 0 && ic0 == 0;
     float accb = 0.f;
 
     for (int tile = slice; tile < ntiles; tile += nslices) {
@@ -709,7 +711,10 @@ __global__ __launch_bounds__(192) void conv_wgrad_bf16_kernel(
         const int tile_x = b % tiles_x;
         b /= tiles_x;
         const int tile_y = b % tiles_y;
-        const int n = b / tiles_y;
+        const int nn = b / tiles_y, src = nn / srcs.n_per, n = nn - src * srcs.n_per;
+        const bf16_t* __restrict__ x = reinterpret_cast<const bf16_t*>(srcs.x[src]);
+        const bf16_t* __restrict__ gy = reinterpret_cast<const bf16_t*>(srcs.gy[src]);
+        const bool do_bias = bias_wave && ((srcs.bias_mask >> src) & 1u);
         const int by = tile_y * TH, bx = tile_x * TW;
         const int oy0 = S2 ? 2 * by : by - 1;
         const int ox0 = S2 ? 2 * bx : bx - 1;
@@ -772,7 +777,7 @@ __global__ __launch_bounds__(192) void conv_wgrad_bf16_kernel(
     }
     // ---- each wave owns its 3 taps: D[ic i][oc j], lane = (j = l31, i = (r&3) + 8(r>>2) + 4hi)
     const long pstride = 9L * IC * OC + (with_bias ? OC : 0);   // fp32 elements per slice: 9 taps (+ the bias row)
-    if (do_bias) {   // the two lane halves hold different pixels of the same channel
+    if (bias_wave) {   // the two lane halves hold different pixels of the same channel
         const float tot = accb + __shfl_xor(accb, 32, 64);
         if (hi == 0) part[(long)slice * pstride + 9L * IC * OC + oc0 + l31] = tot;
     }
@@ -792,7 +797,7 @@ __global__ __launch_bounds__(192) void conv_wgrad_bf16_kernel(
 // conflict-free 64-byte rows.
 template <int MODE, int TW>
 __global__ __launch_bounds__(256) void conv_wgrad_bf16_2x2_kernel(
-    const bf16_t* __restrict__ x, const bf16_t* __restrict__ gy, float* __restrict__ part,
+    const WgradSrcs srcs, float* __restrict__ part,
     int N, int Hi, int Wi, int IC, int OC, int Hb, int Wb, int tiles_x, int tiles_y, int ntiles, int nslices, int with_bias) {
     constexpr bool S2 = MODE == MODE_S2;
     constexpr int NP = S2 ? 64 : 256;   // stride 2: the patch is 4-5x the tile, 64 output pixels keep two staged tiles in LDS
@@ -836,24 +841,27 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_2x2_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     // bias gradient (see conv_wgrad_bf16_kernel): the two waves of input tile 0 in the blocks of input-channel tile 0
-    const bool do_bias = with_bias && it == 0 && ic0 == 0;
+    const bool bias_wave = with_bias && it == 0 && ic0 == 0;
+    bool do_bias = false, bias_next = false;   // per tile: does the tile's source contribute to the bias gradient
     float accb = 0.f;
 
     // one DMA piece of a tile (q in [0, NPIECE)): patch plane 0 / 1 pieces first, then the gradient planes
     int n_t = 0, by_t = 0, bx_t = 0, ox0_t = 0, xorg_t = 0;
-    i32x4 rs_xt = make_rsrc(x, ximg), rs_gt = make_rsrc(gy, gimg);
+    i32x4 rs_xt = make_rsrc(srcs.x[0], ximg), rs_gt = make_rsrc(srcs.gy[0], gimg);
     auto tile_setup = [&](int tile) __attribute__((always_inline)) {
         int b = tile;
         const int tile_x = b % tiles_x;
         b /= tiles_x;
         const int tile_y = b % tiles_y;
-        n_t = b / tiles_y;
+        const int nn = b / tiles_y, src = nn / srcs.n_per;
+        n_t = nn - src * srcs.n_per;
+        bias_next = bias_wave && ((srcs.bias_mask >> src) & 1u);
         by_t = tile_y * TH;
         bx_t = tile_x * TW;
         const int oy0 = S2 ? 2 * by_t : by_t - 1;
         ox0_t = S2 ? 2 * bx_t : bx_t - 1;
-        rs_xt = make_rsrc(reinterpret_cast<const unsigned char*>(x) + (size_t)n_t * ximg, ximg);
-        rs_gt = make_rsrc(reinterpret_cast<const unsigned char*>(gy) + (size_t)n_t * gimg, gimg);
+        rs_xt = make_rsrc(reinterpret_cast<const unsigned char*>(srcs.x[src]) + (size_t)n_t * ximg, ximg);
+        rs_gt = make_rsrc(reinterpret_cast<const unsigned char*>(srcs.gy[src]) + (size_t)n_t * gimg, gimg);
         xorg_t = ((oy0 * Wi + ox0_t) * IC + ic0) * 2;
     };
     auto issue_piece = [&](int q, int bufi) __attribute__((always_inline)) {
@@ -926,6 +934,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_2x2_kernel(
         const bool more = tile + nslices < ntiles;
         wait_vmcnt(0);    // this tile has landed (the next one is issued below, under the MFMAs)
         block_barrier();
+        do_bias = bias_next;
         if (more) tile_setup(tile + nslices);
         const unsigned char* const xpl = lds_raw + buf * BUF + it * XPL;
         const unsigned char* const gpl = lds_raw + buf * BUF + 2 * XPL + ot * GPL;
@@ -946,7 +955,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_2x2_kernel(
     }
     // ---- D[ic i][oc j], lane = (j = l31, i = (r&3) + 8(r>>2) + 4hi)
     const long pstride = 9L * IC * OC + (with_bias ? OC : 0);
-    if (do_bias) {
+    if (bias_wave) {
         const float tot = accb + __shfl_xor(accb, 32, 64);
         if (hi == 0) part[(long)slice * pstride + 9L * IC * OC + oc0 + ot * 32 + l31] = tot;
     }
@@ -1135,9 +1144,11 @@ size_t wgrad_mfma_bytes(int mode, int dtype, int N, int Hb, int Wb, int IC, int 
 
 // x: conv input side [N][Hi][Wi][IC]; gy: [N][Hb][Wb][OC]; gw[9][IC][OC] (or transposed)
 // gb (optional, bf16 only): bias gradient sum_pixels gy[.][oc], produced by the same two launches
-int run_wgrad_mfma(int mode, const void* x, const void* gy, float* gw, float* gb, int N, int Hi, int Wi, int IC, int OC, int Hb,
+int run_wgrad_mfma(int mode, const WgradSrcs& srcs, int nsrc, float* gw, float* gb, int N, int Hi, int Wi, int IC, int OC, int Hb,
                    int Wb, float alpha, int transpose, int accumulate, int dtype, void* ws, size_t ws_bytes, hipStream_t st,
                    GsWgradReduce* defer) {
+    // N = images of ALL sources (nsrc x srcs.n_per)
+    if (nsrc < 1 || nsrc > GS_WGRAD_MAX_SRC || srcs.n_per * nsrc != N) return fail(GS_ERR_ARG, "conv wgrad: %d sources of %d images for N=%d", nsrc, srcs.n_per, N);
     int tw, tiles_x, tiles_y, ntiles, nslices;
     wgrad_geometry(mode, dtype, N, Hb, Wb, IC, OC, &tw, &tiles_x, &tiles_y, &ntiles, &nslices);
     if (gb && !wgrad_mfma_has_bias(dtype)) return fail(GS_ERR_UNSUPPORTED, "conv wgrad: fused bias gradient needs the bf16 kernels");
@@ -1148,8 +1159,8 @@ int run_wgrad_mfma(int mode, const void* x, const void* gy, float* gw, float* gb
     dim3 grid((IC / 32) * (OC / 32), nslices);
     {
 #define GS_WG(TT, M, TWV)                                                                                              \
-    hipLaunchKernelGGL((conv_wgrad_kernel<TT, M, TWV>), grid, dim3(256), 0, st, reinterpret_cast<const TT*>(x),        \
-                       reinterpret_cast<const TT*>(gy), part, N, Hi, Wi, IC, OC, Hb, Wb, tiles_x, tiles_y, ntiles, nslices)
+    hipLaunchKernelGGL((conv_wgrad_kernel<TT, M, TWV>), grid, dim3(256), 0, st, srcs,                                  \
+                       part, N, Hi, Wi, IC, OC, Hb, Wb, tiles_x, tiles_y, ntiles, nslices)
 #define GS_WG_ALL(TT)                                                                       \
     do {                                                                                    \
         if (mode == MODE_S1) { if (tw == 32) GS_WG(TT, MODE_S1, 32); else GS_WG(TT, MODE_S1, 16); } \
@@ -1159,8 +1170,8 @@ int run_wgrad_mfma(int mode, const void* x, const void* gy, float* gw, float* gb
             GS_WG_ALL(float);
         } else {
 #define GS_WGB(M, TWV)                                                                                                  \
-    hipLaunchKernelGGL((conv_wgrad_bf16_kernel<M, TWV>), grid, dim3(192), 0, st, reinterpret_cast<const bf16_t*>(x),    \
-                       reinterpret_cast<const bf16_t*>(gy), part, N, Hi, Wi, IC, OC, Hb, Wb, tiles_x, tiles_y, ntiles, nslices, with_bias)
+    hipLaunchKernelGGL((conv_wgrad_bf16_kernel<M, TWV>), grid, dim3(192), 0, st, srcs,                                  \
+                       part, N, Hi, Wi, IC, OC, Hb, Wb, tiles_x, tiles_y, ntiles, nslices, with_bias)
 #define GS_WGB2(M, TWV)                                                                                                 \
     do {                                                                                                                \
         constexpr int np_ = (M == MODE_S2 ? 64 : 256), th_ = np_ / TWV;                                                 \
@@ -1172,8 +1183,8 @@ int run_wgrad_mfma(int mode, const void* x, const void* gy, float* gw, float* gb
                 return fail(GS_ERR_HIP, "conv wgrad: cannot reserve %d bytes of dynamic LDS", lds_);                    \
             set_ = true;                                                                                                \
         }                                                                                                               \
-        hipLaunchKernelGGL(kern_, dim3((IC / 64) * (OC / 64), nslices), dim3(256), lds_, st, reinterpret_cast<const bf16_t*>(x), \
-                           reinterpret_cast<const bf16_t*>(gy), part, N, Hi, Wi, IC, OC, Hb, Wb, tiles_x, tiles_y, ntiles, nslices, with_bias); \
+        hipLaunchKernelGGL(kern_, dim3((IC / 64) * (OC / 64), nslices), dim3(256), lds_, st, srcs,                          \
+                           part, N, Hi, Wi, IC, OC, Hb, Wb, tiles_x, tiles_y, ntiles, nslices, with_bias);              \
     } while (0)
             if (wgrad_2x2(mode, dtype, IC, OC)) {
                 if (mode == MODE_S1) { if (tw == 32) GS_WGB2(MODE_S1, 32); else GS_WGB2(MODE_S1, 16); }

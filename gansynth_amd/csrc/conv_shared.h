@@ -5,8 +5,19 @@
 namespace gs {
 
 enum { MODE_S1 = 0, MODE_S2 = 1, MODE_T2 = 2 };
+#define GS_WGRAD_MAX_SRC 4   // (x, gy) pairs one weight-gradient launch contracts (gs_conv2d_bwd_weight_bias_multi)
 
 static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+// Several (x, gy) pairs of ONE layer -- the real and the fake discriminator pass, the second-order contribution -- are contracted
+// by one launch: the images of all sources form one list (image n -> source n / n_per), so the layer costs one set of block
+// partials and one slice reduction instead of one per pair.  bias_mask: which sources contribute to the bias gradient.
+struct WgradSrcs {
+    const void* x[GS_WGRAD_MAX_SRC];
+    const void* gy[GS_WGRAD_MAX_SRC];
+    int n_per;
+    unsigned bias_mask;
+};
 
 // ------------------------------------------------------------------------------ weight prep
 // Re-lays the fp32 HWIO master weight into the kernel operand Wp[tap][OCk][ICk] (ICk contiguous,

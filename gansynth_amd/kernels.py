@@ -70,7 +70,7 @@ class HipKernels(object):
         self._param_ranges = []   # (ptr, nbytes) of registered flat parameter buffers
         self._wcache = {}         # (weight ptr, map tag) -> (persistent workspace holding the re-laid operand, stamp)
         self._prep_tables = {}    # tuple of cache keys -> device table of GsPrepDesc rows (refresh_weights)
-        self._pending = None      # deferred weight-gradient reductions: [(GsWgradReduce, workspace kept alive)] while deferring
+        self._pending = None      # deferred weight gradients while deferring: {layer key: {out, bias, [(x, gy, with bias)]}}
 
     # --------------------------------------------------------- prepared-weight workspaces
     def register_param_buffer(self, flat):
@@ -127,21 +127,58 @@ class HipKernels(object):
             e[1] = (e[4][2], e[2]._version)
         return len(stale)
 
-    # ------------------------------------------------- deferred weight-gradient reductions
+    # ----------------------------------------------------------- deferred weight gradients
     def defer_wgrad_reductions(self):
-        """From now on the in-place (`out=`) weight gradients only write their block partials; flush_wgrad_reductions() folds
-        all of them in a handful of launches (a backward pass has ~70 such reductions, each a launch of its own otherwise).
-        The gradients in the `out` buffers are complete only after the flush."""
+        """From now on the in-place (`out=`) conv weight gradients are only RECORDED; flush_wgrad_reductions() then runs, per
+        weight, ONE multi-source launch over all recorded (x, gy) pairs of that layer (real + fake discriminator pass, the
+        second-order contribution of the penalty terms ...) and folds the slice partials of all layers in a handful of launches.
+        A backward pass has ~70 such gradients, each otherwise its own partials + reduction.  The `out` buffers are complete
+        only after the flush; x and gy are kept alive (and must not be written) until then."""
         if self._pending is None:
-            self._pending = []
+            self._pending = {}
+
+    def _defer_wgrad(self, key, x, gy, out, bias_out):
+        grp = self._pending.setdefault(key, {"out": out, "bias": None, "src": []})
+        if bias_out is not None:
+            assert grp["bias"] is None or grp["bias"].data_ptr() == bias_out.data_ptr()
+            grp["bias"] = bias_out
+        grp["src"].append((x, gy, bias_out is not None))
 
     def flush_wgrad_reductions(self):
-        pend, self._pending = self._pending, None
-        if not pend:
+        groups, self._pending = self._pending, None
+        if not groups:
             return 0
-        arr = (_lib.GsWgradReduce * len(pend))(*[d for d, _ in pend])
-        _lib.check(self.lib.gs_wgrad_reduce_batch(ctypes.cast(arr, ctypes.c_void_p), len(pend), _stream()), "gs_wgrad_reduce_batch")
-        return len(pend)   # (the workspaces die here: every later launch is stream-ordered behind the reduction)
+        pend, keep = [], []
+        for key, grp in groups.items():
+            kind, ksize, stride, alpha = key[0], key[2], key[3], key[4]
+            out, bias, src = grp["out"], grp["bias"], grp["src"]
+            n, ci, h, wd = src[0][0].shape
+            co = src[0][1].shape[1]
+            dt = _dt(src[0][0])
+            for i in range(0, len(src), _lib.WGRAD_MAX_SOURCES):
+                part = src[i:i + _lib.WGRAD_MAX_SOURCES]
+                k = len(part)
+                xs = (ctypes.c_void_p * k)(*[p[0].data_ptr() for p in part])
+                gys = (ctypes.c_void_p * k)(*[p[1].data_ptr() for p in part])
+                mask = sum(1 << j for j, p in enumerate(part) if p[2])
+                d = _lib.GsWgradReduce()
+                if kind == "conv":
+                    ws = _ws(self.lib.gs_conv2d_workspace_bytes(_lib.CONV_BWD_WEIGHT, n * k, h, wd, ci, co, ksize, stride, dt), out.device)
+                    _lib.check(self.lib.gs_conv2d_bwd_weight_bias_multi(xs, gys, k, mask, out.data_ptr(), None if (bias is None or not mask) else bias.data_ptr(),
+                                                                        n, h, wd, ci, co, ksize, stride, float(alpha), 1, dt, ws.data_ptr(), ws.numel(),
+                                                                        ctypes.addressof(d), _stream()), "gs_conv2d_bwd_weight_bias_multi")
+                else:
+                    ws = _ws(self.lib.gs_conv2d_transpose_s2_workspace_bytes(_lib.CONV_BWD_WEIGHT, n * k, h, wd, ci, co, dt), out.device)
+                    _lib.check(self.lib.gs_conv2d_transpose_s2_bwd_weight_multi(xs, gys, k, out.data_ptr(), n, h, wd, ci, co, float(alpha), 1, dt,
+                                                                                ws.data_ptr(), ws.numel(), ctypes.addressof(d), _stream()),
+                               "gs_conv2d_transpose_s2_bwd_weight_multi")
+                if d.nslices > 0:
+                    pend.append(d)
+                    keep.append(ws)
+        if pend:
+            arr = (_lib.GsWgradReduce * len(pend))(*pend)
+            _lib.check(self.lib.gs_wgrad_reduce_batch(ctypes.cast(arr, ctypes.c_void_p), len(pend), _stream()), "gs_wgrad_reduce_batch")
+        return sum(len(g["src"]) for g in groups.values())   # (workspaces and sources die here: later launches are stream-ordered behind)
 
     # ------------------------------------------------------------------------------- conv
     def conv2d_fwd(self, x, w, ksize, stride, alpha):
@@ -188,18 +225,16 @@ class HipKernels(object):
         n, ci, h, wd = x.shape
         co = gy.shape[1]
         gw = torch.empty((ksize, ksize, ci, co), dtype=torch.float32, device=x.device) if out is None else out
-        nb = self.lib.gs_conv2d_workspace_bytes(_lib.CONV_BWD_WEIGHT, n, h, wd, ci, co, ksize, stride, _dt(x))
-        ws = _ws(nb, x.device)
         if bias_out is not None:
             assert out is not None and bias_out.dtype == torch.float32 and bias_out.is_contiguous()
-        pend = _lib.GsWgradReduce() if (out is not None and self._pending is not None) else None
-        _lib.check(self.lib.gs_conv2d_bwd_weight_bias_partial(x.data_ptr(), gy.data_ptr(), gw.data_ptr(),
-                                                              None if bias_out is None else bias_out.data_ptr(),
-                                                              n, h, wd, ci, co, ksize, stride, float(alpha), 0 if out is None else 1, _dt(x),
-                                                              ws.data_ptr(), ws.numel(), None if pend is None else ctypes.addressof(pend),
-                                                              _stream()), "gs_conv2d_bwd_weight_bias_partial")
-        if pend is not None and pend.nslices > 0:
-            self._pending.append((pend, ws))
+        if out is not None and self._pending is not None:
+            self._defer_wgrad(("conv", out.data_ptr(), ksize, stride, float(alpha), tuple(x.shape), tuple(gy.shape), x.dtype), x, gy, out, bias_out)
+            return gw
+        nb = self.lib.gs_conv2d_workspace_bytes(_lib.CONV_BWD_WEIGHT, n, h, wd, ci, co, ksize, stride, _dt(x))
+        ws = _ws(nb, x.device)
+        _lib.check(self.lib.gs_conv2d_bwd_weight_bias(x.data_ptr(), gy.data_ptr(), gw.data_ptr(), None if bias_out is None else bias_out.data_ptr(),
+                                                      n, h, wd, ci, co, ksize, stride, float(alpha), 0 if out is None else 1, _dt(x),
+                                                      ws.data_ptr(), ws.numel(), _stream()), "gs_conv2d_bwd_weight_bias")
         return gw
 
     def conv2d_transpose_fwd(self, x, w, alpha):
@@ -238,15 +273,14 @@ class HipKernels(object):
         n, ci, h, wd = x.shape
         co = gy.shape[1]
         gw = torch.empty((3, 3, ci, co), dtype=torch.float32, device=x.device) if out is None else out
+        if out is not None and self._pending is not None:
+            self._defer_wgrad(("convT", out.data_ptr(), 3, 2, float(alpha), tuple(x.shape), tuple(gy.shape), x.dtype), x, gy, out, None)
+            return gw
         nb = self.lib.gs_conv2d_transpose_s2_workspace_bytes(_lib.CONV_BWD_WEIGHT, n, h, wd, ci, co, _dt(x))
         ws = _ws(nb, x.device)
-        pend = _lib.GsWgradReduce() if (out is not None and self._pending is not None) else None
-        _lib.check(self.lib.gs_conv2d_transpose_s2_bwd_weight_partial(x.data_ptr(), gy.data_ptr(), gw.data_ptr(), n, h, wd, ci, co, float(alpha),
-                                                                      0 if out is None else 1, _dt(x), ws.data_ptr(), ws.numel(),
-                                                                      None if pend is None else ctypes.addressof(pend), _stream()),
-                   "gs_conv2d_transpose_s2_bwd_weight_partial")
-        if pend is not None and pend.nslices > 0:
-            self._pending.append((pend, ws))
+        _lib.check(self.lib.gs_conv2d_transpose_s2_bwd_weight(x.data_ptr(), gy.data_ptr(), gw.data_ptr(), n, h, wd, ci, co, float(alpha),
+                                                              0 if out is None else 1, _dt(x), ws.data_ptr(), ws.numel(), _stream()),
+                   "gs_conv2d_transpose_s2_bwd_weight")
         return gw
 
     # ------------------------------------------------------------------------------ dense

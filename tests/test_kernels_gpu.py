@@ -465,9 +465,10 @@ def test_pixel_norm_gradient_forms_pair_up_at_full_size(K, dtype):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_deferred_weight_gradient_reductions_match_immediate_ones(K, dtype):
-    """gs_*_bwd_weight*_partial + gs_wgrad_reduce_batch: the same block partials folded later, many per launch -- bit-identical to
-    the immediate reduction, including two contributions into one gradient (list order), the bias row, the transposed conv,
-    the thin / direct kernels and more entries than one launch holds."""
+    """Deferred weight gradients (gs_*_bwd_weight*_multi + gs_wgrad_reduce_batch): the (x, gy) pairs of a layer contracted by one
+    launch and the slice partials of all layers folded together -- equal (to fp32 rounding) to one immediate call per pair,
+    including sources without a bias contribution, the transposed conv, the thin / direct kernels and more layers than one
+    reduction launch holds."""
     cases = [(2, 32, 32, 8, 128, 3, 1), (2, 64, 64, 8, 64, 3, 1), (2, 64, 128, 8, 64, 3, 2), (2, 32, 64, 8, 128, 3, 2), (2, 128, 128, 4, 32, 3, 1),
              (2, 32, 2, 8, 64, 1, 1), (2, 2, 32, 8, 64, 1, 1), (4, 1, 16, 2, 16, 3, 1), (2, 256, 256, 2, 16, 3, 1)]
     cases = cases + cases[:5] + cases[:5]   # > 16 entries, repeated targets
@@ -487,9 +488,10 @@ def test_deferred_weight_gradient_reductions_match_immediate_ones(K, dtype):
         gt = torch.full((3, 3, 64, 32), 0.125, device="cuda")
         if deferred:
             K.defer_wgrad_reductions()
-        for (x, gy, ks, st) in work:
+        for i, (x, gy, ks, st) in enumerate(work):
             gw, gb = grads[(tuple(x.shape), tuple(gy.shape), ks, st)]
-            K.conv2d_bwd_weight(x, gy, ks, st, 0.2, out=gw, bias_out=gb if (ks == 3 and dtype == torch.bfloat16) else None)   # (fp32 bias sums are not deferrable)
+            # (fp32 bias sums are not deferrable; the third round contributes to the weights only, like a second-order term)
+            K.conv2d_bwd_weight(x, gy, ks, st, 0.2, out=gw, bias_out=gb if (ks == 3 and dtype == torch.bfloat16 and i < 14) else None)
         K.conv2d_transpose_bwd_weight(xt, gyt, 0.1, out=gt)
         K.conv2d_transpose_bwd_weight(xt, gyt, 0.3, out=gt)
         if deferred:
@@ -499,5 +501,24 @@ def test_deferred_weight_gradient_reductions_match_immediate_ones(K, dtype):
 
     now, later = run(False), run(True)
     for a, b in zip(now, later):   # (the batched kernel sums the slices in a different association: equal to rounding, not to the bit)
-        assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max())
+        assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max()), (a.shape, float((a - b).abs().max()), float(a.abs().max()))
     assert K._pending is None
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_multi_source_weight_gradient_matches_oracle(K, E, dtype):
+    """gs_conv2d_bwd_weight_bias_multi against the CPU restatement: gw = sum over the pairs, gb over the masked ones."""
+    for (n, ci, co, h, w, ks, st) in [(2, 64, 64, 8, 64, 3, 1), (2, 32, 64, 8, 128, 3, 2), (1, 128, 64, 6, 40, 3, 1)]:
+        xs = [rnd(n, ci, h, w, seed=70 + i).to(dtype).float() for i in range(3)]
+        gys = [rnd(n, co, h // st, w // st, seed=80 + i).to(dtype).float() for i in range(3)]
+        gw = torch.zeros(ks, ks, ci, co, device="cuda")
+        gb = torch.zeros(co, device="cuda")
+        with_b = dtype == torch.bfloat16
+        K.defer_wgrad_reductions()
+        for i in range(3):
+            K.conv2d_bwd_weight(dev(xs[i], dtype), dev(gys[i], dtype), ks, st, 0.3, out=gw, bias_out=gb if (with_b and i != 1) else None)
+        K.flush_wgrad_reductions()
+        ref = sum(E.conv2d_bwd_weight(xs[i], gys[i], ks, st, 0.3) for i in range(3))
+        close(gw, ref, rel=1e-4, name=f"multi wgrad {ci}->{co} s{st}")
+        if with_b:
+            close(gb, E.channel_sum(gys[0]) + E.channel_sum(gys[2]), rel=1e-4, name="multi wgrad bias (sources 0 and 2)")
