@@ -1046,29 +1046,30 @@ static int dispatch_igemm(ConvP p, hipStream_t st) {
     const bool small = items64(1) <= cus;   // no more blocks than CUs: a serial chain of stages per block
     if constexpr (MODE == MODE_T2) {
         if (resident_ok && Wb >= 64) return launch_igemm<T, MODE, 1, 1, 64, 9, true, 1>(p, st);
-        // few blocks: 32-channel tiles double the number of busy CUs
-        if (!a2 || small) { if (Wb >= 32) return launch_igemm<T, MODE, 1, 1, 32, 3>(p, st); return launch_igemm<T, MODE, 1, 1, 16, 3>(p, st); }
+        // few blocks, each a serial chain of stages: 32-channel tiles double the number of busy CUs, 9-tap stages cut the
+        // barriers and DMA round trips of the chain to a third
+        if (small) { if (Wb >= 32) return launch_igemm<T, MODE, 1, 1, 32, 9, false, 1>(p, st); return launch_igemm<T, MODE, 1, 1, 16, 9, false, 1>(p, st); }
+        if (!a2) { if (Wb >= 32) return launch_igemm<T, MODE, 1, 1, 32, 3>(p, st); return launch_igemm<T, MODE, 1, 1, 16, 3>(p, st); }
         if (Wb >= 32) return launch_igemm<T, MODE, 2, 1, 32, 3>(p, st);
         return launch_igemm<T, MODE, 2, 1, 16, 3>(p, st);
     } else if constexpr (MODE == MODE_S2) {
+        if (small) { if (Wb >= 32) return launch_igemm<T, MODE, 1, 1, 32, 9, false, 1>(p, st); return launch_igemm<T, MODE, 1, 1, 16, 9, false, 1>(p, st); }
         if (!a2) return launch_igemm<T, MODE, 1, 1, 32, 3>(p, st);
         // stride 2: the patch is 4.6x the output tile, so a 128-channel tile (the patch staged once for all of them) is worth
         // more than a second pixel tile as long as every CU still gets a block
         if (OC == 64 && nch == 1 && Wb >= 32 && items64(1) >= cus) return launch_igemm<T, MODE, 2, 1, 32, 9, true, 1>(p, st);   // 36 KiB of weights: resident
         if (OC % 128 == 0 && Wb >= 32 && (long)p.N * cdiv(p.Hb, 4) * cdiv(Wb, 32) * (OC / 128) >= cus) return launch_igemm<T, MODE, 4, 1, 32, 3>(p, st);
-        // few blocks: all 9 taps per stage = a third of the barriers and DMA round trips of the chain
-        if (small) { if (Wb >= 32) return launch_igemm<T, MODE, 2, 1, 32, 9, false, 1>(p, st); return launch_igemm<T, MODE, 2, 1, 16, 9, false, 1>(p, st); }
         if (Wb >= 32) return launch_igemm<T, MODE, 2, 1, 32, 3>(p, st);
         return launch_igemm<T, MODE, 2, 1, 16, 3>(p, st);
     } else {
         if (resident_ok && Wb >= 64) return launch_igemm<T, MODE, 1, 2, 64, 9, true, 1>(p, st);
+        if (small) { if (Wb >= 32) return launch_igemm<T, MODE, 1, 1, 32, 9, false, 1>(p, st); return launch_igemm<T, MODE, 1, 1, 16, 9, false, 1>(p, st); }
         if (!a2) return launch_igemm<T, MODE, 1, 1, 32, 3>(p, st);
         if (Wb >= 32 && items64(2) >= 2 * cus) return launch_igemm<T, MODE, 2, 2, 32, 3, false, 1>(p, st);
         if (resident64_ok && Wb >= 32 && items64(2) >= cus / 2) return launch_igemm<T, MODE, 2, 2, 32, 9, true>(p, st);
         // every block re-streams its 64 x IC x 9 weight slab from L2: the more pixels a block owns the smaller that
         // stream is per MFMA -- take the largest pixel tile that still gives every CU a block
         if (Wb >= 32 && items64(2) >= cus) return launch_igemm<T, MODE, 2, 2, 32, 3>(p, st);
-        if (small) { if (Wb >= 32) return launch_igemm<T, MODE, 2, 1, 32, 9, false, 1>(p, st); return launch_igemm<T, MODE, 2, 1, 16, 9, false, 1>(p, st); }
         if (Wb >= 32) return launch_igemm<T, MODE, 2, 1, 32, 3>(p, st);
         return launch_igemm<T, MODE, 2, 1, 16, 3>(p, st);
     }
