@@ -1043,7 +1043,8 @@ static int dispatch_igemm(ConvP p, hipStream_t st) {
     // of LDS each, i.e. a one-stage-deep ring) beat one block with a deeper ring or a larger tile wherever the layer has at
     // least two blocks per CU to give -- the epilogue and DMA waits of one block run under the MFMAs of the other.
     const long cus = num_cus();
-    const bool small = items64(1) <= cus;   // no more blocks than CUs: a serial chain of stages per block
+    static const bool no_small = getenv("GS_NO_SMALL_TILES") != nullptr;   // measurement knob
+    const bool small = !no_small && items64(1) <= cus;   // no more blocks than CUs: a serial chain of stages per block
     if constexpr (MODE == MODE_T2) {
         if (resident_ok && Wb >= 64) return launch_igemm<T, MODE, 1, 1, 64, 9, true, 1>(p, st);
         // few blocks, each a serial chain of stages: 32-channel tiles double the number of busy CUs, 9-tap stages cut the

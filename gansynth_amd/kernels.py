@@ -49,7 +49,13 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+_POISON = bool(__import__("os").environ.get("GS_DEBUG_POISON_WS"))   # debugging: workspaces start as NaN bit patterns, so that a
+                                                                     # kernel reading workspace it never wrote shows up as NaN
+
+
 def _ws(nbytes, device):
+    if _POISON:
+        return torch.full((max(int(nbytes), 256),), 0xFF, dtype=torch.uint8, device=device)
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
 
 

@@ -27,7 +27,9 @@ from . import variables
 _PAD = 64  # floats; keeps every parameter view 256-byte aligned inside the flat buffer
 
 
-_DEFER_REDUCTIONS = not __import__("os").environ.get("GS_NO_DEFERRED_REDUCE")   # A/B switch for measurements
+_DEFER_REDUCTIONS = not __import__("os").environ.get("GS_NO_DEFERRED_REDUCE")   # A/B switches for measurements
+_PIPELINE = bool(__import__("os").environ.get("GS_PIPELINE"))   # opt-in, see GANSynth.pipeline
+_PIPE_SIDE = {"0": False, "1": True}.get(__import__("os").environ.get("GS_PIPE_SIDE", ""))
 
 
 class _FlatParams(object):
@@ -84,6 +86,14 @@ class GANSynth(object):
         # fully grown regime (no fade coefficient); the optimizer update and the all-reduce stay outside the graph.
         self.use_graphs = bool(use_graphs)
         self._graphs = {}
+        # Pipelined iteration (opt-in: pipeline=True / GS_PIPELINE=1; train_step with graphs): every run is captured as two
+        # graphs (own-network part A, the rest B) so that the gradient all-reduce of one network can run on a side stream under
+        # part A of the other network's run, which needs none of it.  Off by default: on this ROCm stack a cross-stream event
+        # hop between hipGraph replays costs 0.25-0.75 ms by itself (scripts/cross_stream_cost.py; the one-GPU step loses 6 %
+        # with the side stream on and nothing to hide), about what an 8-GPU all-reduce of these 26 / 34 MiB buffers takes.
+        self.pipeline = _PIPELINE
+        self.pipe_side = None     # None: side stream iff data-parallel (see _train_step_pipelined)
+        self._pipe = None
 
     # ----------------------------------------------------------------------------- build
     def _build(self, latents, labels):
@@ -129,60 +139,94 @@ class GANSynth(object):
         """tf.gather_nd(logits, tf.where(labels)) for one-hot labels (models.py:39-40)."""
         return (logits.float() * labels.float()).sum(dim=1)
 
-    def discriminator_losses(self, latents, labels, real_images):
+    # Each run splits into a part that touches only the network being updated and a part that needs the other network:
+    #   D run:  A = D(real) + the R1 first-order pass          B = G(z) (no grad), D(fake), loss, backward
+    #   G run:  A = G(z) + the mode-seeking first-order pass    B = D(G(z)), loss, backward
+    # (`_a` functions return what `_b` needs).  The pipelined step overlaps the optimizer update of one network (all-reduce,
+    # Adam, operand refresh on a side stream) with part A of the other network's run.
+    def _d_losses_a(self, labels, real_images):
         hp = self.hyper_params
-        with torch.no_grad():  # var_list is the discriminator's only: no generator backward (models.py:86-89)
-            fake_images = self.generator(latents, labels)
         real_images = real_images.detach().requires_grad_(True)
         _, real_logits = self.discriminator(real_images, labels)
-        _, fake_logits = self.discriminator(fake_images, labels)
         real_logits = self._label_logits(real_logits, labels)
-        fake_logits = self._label_logits(fake_logits, labels)
-        losses = TF.softplus(-real_logits) + TF.softplus(fake_logits)
+        real_losses = TF.softplus(-real_logits)
+        penalty = None
         if hp.real_gradient_penalty_weight:
             with F.data_grads_only():   # tf.gradients(real_logits, [real_images]) (models.py:47): no parameter gradients on this pass
                 (real_gradients,) = torch.autograd.grad(real_logits.sum(), real_images, create_graph=True)
-            losses = losses + F.sumsq_rows(real_gradients) * hp.real_gradient_penalty_weight
+            penalty = F.sumsq_rows(real_gradients) * hp.real_gradient_penalty_weight
         if hp.get("fake_gradient_penalty_weight", 0.0):
             raise NotImplementedError("fake_gradient_penalty_weight is 0 in the reference configuration (gan_synth_main.py:87)")
+        return real_losses, penalty
+
+    def _d_losses_b(self, part_a, latents, labels):
+        real_losses, penalty = part_a
+        with torch.no_grad():  # var_list is the discriminator's only: no generator backward (models.py:86-89)
+            fake_images = self.generator(latents, labels)
+        _, fake_logits = self.discriminator(fake_images, labels)
+        fake_logits = self._label_logits(fake_logits, labels)
+        losses = real_losses + TF.softplus(fake_logits)
+        if penalty is not None:
+            losses = losses + penalty
         return losses
 
-    def generator_losses(self, latents, labels):
+    def discriminator_losses(self, latents, labels, real_images):
+        return self._d_losses_b(self._d_losses_a(labels, real_images), latents, labels)
+
+    def _g_losses_a(self, latents, labels):
         hp = self.hyper_params
         latents = latents.detach().requires_grad_(True)
         fake_images = self.generator(latents, labels)
-        _, fake_logits = self.discriminator(fake_images, labels)
-        fake_logits = self._label_logits(fake_logits, labels)
-        losses = TF.softplus(-fake_logits)
+        mode_seeking = None
         if hp.mode_seeking_loss_weight:
             ones = torch.ones_like(fake_images)  # tf.gradients(ys) sums ys
             with F.data_grads_only():   # tf.gradients(fake_images, [latents]) (models.py:60)
                 (latent_gradients,) = torch.autograd.grad(fake_images, latents, grad_outputs=ones, create_graph=True)
             mode_seeking = 1.0 / (latent_gradients.float().pow(2).sum(dim=1) + 1.0e-6)
+        return fake_images, mode_seeking
+
+    def _g_losses_b(self, part_a, labels):
+        hp = self.hyper_params
+        fake_images, mode_seeking = part_a
+        _, fake_logits = self.discriminator(fake_images, labels)
+        fake_logits = self._label_logits(fake_logits, labels)
+        losses = TF.softplus(-fake_logits)
+        if mode_seeking is not None:
             losses = losses + mode_seeking * hp.mode_seeking_loss_weight
         return losses
 
+    def generator_losses(self, latents, labels):
+        return self._g_losses_b(self._g_losses_a(latents, labels), labels)
+
     # ------------------------------------------------------------------------- updates
-    def _apply(self, params, lr, beta1, beta2):
+    def _reduce(self, params):
         if self.distributed:
             torch.distributed.all_reduce(params.grad)
+
+    def _apply(self, params, lr, beta1, beta2, reduced=False):
+        if not reduced:
+            self._reduce(params)
         params.t += 1
         lr_t = lr * math.sqrt(1.0 - beta2 ** params.t) / (1.0 - beta1 ** params.t)
         kernels.get().adam_tf_step(params.flat, params.grad, params.m, params.v, lr_t, beta1, beta2, 1.0e-8,
                                    1.0 / self.world)
 
-    def _forward_backward(self, which, *inputs):
-        """Gradients of one run into the flat gradient buffer; returns the (detached) mean loss."""
+    def _part_a(self, which, *inputs):
+        """Own-network part of a run (see _d_losses_a / _g_losses_a); also arms the run: requires_grad flags, zeroed gradients."""
         if which == "d":
             self.g_params.requires_grad_(False)
             self.d_params.requires_grad_(True)
             self.d_params.zero_grad()
-            loss = self.discriminator_losses(*inputs).mean()
-        else:
-            self.g_params.requires_grad_(True)
-            self.d_params.requires_grad_(False)
-            self.g_params.zero_grad()
-            loss = self.generator_losses(*inputs).mean()
+            return self._d_losses_a(*inputs)        # (labels, real_images)
+        self.g_params.requires_grad_(True)
+        self.d_params.requires_grad_(False)
+        self.g_params.zero_grad()
+        return self._g_losses_a(*inputs)            # (latents, labels)
+
+    def _part_b(self, which, part_a, *inputs):
+        """The rest of the run: losses, backward into the flat gradient buffer; returns the (detached) mean loss."""
+        losses = self._d_losses_b(part_a, *inputs) if which == "d" else self._g_losses_b(part_a, *inputs)   # (latents, labels) | (labels,)
+        loss = losses.mean()
         K = kernels.get()
         deferring = _DEFER_REDUCTIONS and hasattr(K, "defer_wgrad_reductions")   # parameter gradients are only read after the whole backward:
         if deferring:                                        # their ~70 slice reductions are folded in one go at the end
@@ -194,6 +238,15 @@ class GANSynth(object):
                 K.flush_wgrad_reductions()
         return loss.detach()
 
+    def _forward_backward(self, which, *inputs):
+        """Gradients of one run into the flat gradient buffer; returns the (detached) mean loss.
+        inputs: (latents, labels, real_images) for "d", (latents, labels) for "g"."""
+        if which == "d":
+            latents, labels, real_images = inputs
+            return self._part_b("d", self._part_a("d", labels, real_images), latents, labels)
+        latents, labels = inputs
+        return self._part_b("g", self._part_a("g", latents, labels), labels)
+
     def _graphable(self):
         owner = getattr(self.generator, "__self__", None)
         if not self.use_graphs or owner is None or not hasattr(owner, "_head_depth"):
@@ -202,6 +255,7 @@ class GANSynth(object):
         return fade is None and head == owner.max_depth
 
     def _run(self, which, *inputs):
+        self._join_updates()
         if not self._graphable():
             self._graphs.clear()
             return self._forward_backward(which, *inputs)
@@ -245,12 +299,107 @@ class GANSynth(object):
         self.generator_loss = loss
         return self.generator_loss
 
+    # ------------------------------------------------------------------ pipelined iteration
+    def _join_updates(self):
+        """A pipelined step leaves the generator's update pending (its all-reduce may still run on the side stream): apply it."""
+        if self._pipe is not None and self._pipe.get("g_pending"):
+            hp = self.hyper_params
+            self._pipe["g_pending"] = False
+            torch.cuda.current_stream().wait_event(self._pipe["g_reduced"])
+            self._apply(self.g_params, hp.generator_learning_rate, hp.generator_beta1, hp.generator_beta2, reduced=True)
+
+    def synchronize(self):
+        """Everything a train_step enqueued (including the pending update) has finished."""
+        self._join_updates()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+
+    def _capture_pair(self, which, a_inputs, b_inputs):
+        """Two graphs for one run: part A (own network) and part B (the rest), sharing one memory pool (replayed A, B, A, B ...)."""
+        K = kernels.get()
+        sa = [t.detach().clone() for t in a_inputs]
+        sb = [t.detach().clone() for t in b_inputs]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):  # one eager pass on a side stream (allocator / lazy-init warm-up)
+            self._part_b(which, self._part_a(which, *sa), *sb)
+        torch.cuda.current_stream().wait_stream(side)
+        K.refresh_weights()   # (see _run: the captured graphs hold no re-layout launches)
+        ga = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(ga):
+            part_a = self._part_a(which, *sa)
+        gb = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gb, pool=ga.pool()):
+            loss = self._part_b(which, part_a, *sb)
+        return {"a": ga, "b": gb, "sa": sa, "sb": sb, "loss": loss}
+
+    def _pipelined_ok(self):
+        return self.pipeline and self.use_graphs and torch.cuda.is_available() and self._graphable()
+
+    def _train_step_pipelined(self, d_latents, d_labels, real_images, g_latents, g_labels):
+        """D.A | update G | D.B | G.A | update D | G.B, the gradient all-reduce of each update on a side stream under the part A
+        that follows it (part A needs neither the gradients being reduced nor the parameters about to change).  The Adam /
+        operand-refresh launches stay on the main stream: streaming kernels beside the persistent conv blocks cost the main
+        stream 5 % on one MI355X (measured), an all-reduce in flight is what the overlap is for.  Single GPU: no side stream."""
+        hp = self.hyper_params
+        main = torch.cuda.current_stream()
+        if self._pipe is None:
+            ev = lambda: torch.cuda.Event()
+            self._pipe = {"side": torch.cuda.Stream(), "d_done": ev(), "g_done": ev(), "d_reduced": ev(), "g_reduced": ev(), "g_pending": False}
+        P = self._pipe
+        use_side = self.pipe_side if self.pipe_side is not None else (self.distributed if _PIPE_SIDE is None else _PIPE_SIDE)
+
+        def fresh(entry, a_inputs, b_inputs):
+            return entry is None or any(x.shape != y.shape or x.dtype != y.dtype for x, y in zip(entry["sa"] + entry["sb"], list(a_inputs) + list(b_inputs)))
+
+        d_in = ((d_labels, real_images), (d_latents, d_labels))
+        g_in = ((g_latents, g_labels), (g_labels,))
+        if fresh(P.get("d"), *d_in) or fresh(P.get("g"), *g_in):
+            self._join_updates()
+            P["d"] = self._capture_pair("d", *d_in)
+            P["g"] = self._capture_pair("g", *g_in)
+        D, G = P["d"], P["g"]
+        for dst, src in zip(D["sa"] + D["sb"] + G["sa"] + G["sb"], list(d_in[0]) + list(d_in[1]) + list(g_in[0]) + list(g_in[1])):
+            dst.copy_(src)
+
+        def reduce_async(params, done, reduced):
+            done.record(main)
+            if use_side:
+                with torch.cuda.stream(P["side"]):
+                    P["side"].wait_event(done)
+                    self._reduce(params)
+                    reduced.record(P["side"])
+            else:
+                self._reduce(params)
+                reduced.record(main)
+
+        # D run.  Part A reads the discriminator only: it runs under the all-reduce of the previous generator gradients.
+        D["a"].replay()
+        self._join_updates()                        # the generator's update; part B runs the generator
+        D["b"].replay()
+        reduce_async(self.d_params, P["d_done"], P["d_reduced"])
+        # G run.  Part A reads the generator only: it runs under the all-reduce of the discriminator's gradients.
+        G["a"].replay()
+        main.wait_event(P["d_reduced"])
+        self._apply(self.d_params, hp.discriminator_learning_rate, hp.discriminator_beta1, hp.discriminator_beta2, reduced=True)
+        G["b"].replay()                             # runs the updated discriminator
+        reduce_async(self.g_params, P["g_done"], P["g_reduced"])
+        P["g_pending"] = True                       # applied before the next part B (or by _join_updates / synchronize)
+        self.global_step += 1  # models.py:84
+        self.discriminator_loss, self.generator_loss = D["loss"], G["loss"]
+        return D["loss"], G["loss"]
+
     def train_step(self):
         """models.py:191-192: one discriminator run then one generator run, fresh inputs for each."""
         real_images, labels = self._real_batch()
-        d_loss = self.discriminator_step(self.fake_input_fn().to(self.dtype), labels, real_images)
-        _, labels = self.real_input_fn()  # the G run only consumes the labels of its batch (waveform branch is pruned)
-        g_loss = self.generator_step(self.fake_input_fn().to(self.dtype), labels.to(self.dtype))
+        d_latents = self.fake_input_fn().to(self.dtype)
+        _, g_labels = self.real_input_fn()  # the G run only consumes the labels of its batch (waveform branch is pruned)
+        g_latents, g_labels = self.fake_input_fn().to(self.dtype), g_labels.to(self.dtype)
+        self._ensure_built(d_latents, labels)
+        if self._pipelined_ok():
+            return self._train_step_pipelined(d_latents, labels, real_images, g_latents, g_labels)
+        d_loss = self.discriminator_step(d_latents, labels, real_images)
+        g_loss = self.generator_step(g_latents, g_labels)
         return d_loss, g_loss
 
     def train(self, total_steps, log_tensor_steps=100, log=print):
@@ -263,6 +412,7 @@ class GANSynth(object):
 
     def generate(self, latents, labels):
         """models.py:232-250: fake waveforms for a batch."""
+        self._join_updates()
         with torch.no_grad():
             images = self.generator(latents.to(self.dtype), labels.to(self.dtype))
         return spectral_ops.convert_images_to_waveform(images, **self.spectral_params)
