@@ -298,90 +298,111 @@ __global__ void embedding_bwd_kernel(const int64_t* __restrict__ idx, const T* _
 
 // -------------------------------------------------------------------------- batch stddev
 // x [b][hw][c] (channels-last), groups of 4: column j in [0, M=b/4) holds samples j, j+M, j+2M, j+3M.
-// One block per column j.
-template <typename T>
-__device__ inline void bs_load(const T* x, int M, int j, long pos, long npos, float (&v)[4]) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = DT<T>::ld(x + ((long)(i * M + j)) * npos + pos);
+// One block per column j (M = 2 at batch 8: a latency chain, not a bandwidth problem): 1024 threads, VN = 16 bytes of
+// positions per thread and member (VN = 1: scalar fallback for odd sizes), so that the 4 x 8192 values of the model's 2x16x256
+// block are one trip of four independent 16-byte loads per thread.
+template <typename T, int VN> __device__ inline void bs_ld(const T* p, float* o) {
+    if constexpr (VN == 1) o[0] = DT<T>::ld(p); else ld_wide<T>(p, o);
 }
+template <typename T, int VN> __device__ inline void bs_st(T* p, const float* o) {
+    if constexpr (VN == 1) DT<T>::st(p, o[0]); else st_wide<T>(p, o);
+}
+template <typename T, int VN>
+__device__ inline void bs_load(const T* x, int M, int j, long pos, long npos, float (&v)[4][VN]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bs_ld<T, VN>(x + ((long)(i * M + j)) * npos + pos, v[i]);
+}
+constexpr int BS_NT = 1024;
 
-template <typename T>
-__global__ __launch_bounds__(256) void batch_stddev_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int M, int hw, int c, float eps) {
-    __shared__ float red[4];
+template <typename T, int VN>
+__global__ __launch_bounds__(BS_NT) void batch_stddev_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int M, int hw, int c, float eps) {
+    __shared__ float red[BS_NT / 64];
     const int j = blockIdx.x;
     const long npos = (long)hw * c;
     float s = 0.f;
-    for (long pos = threadIdx.x; pos < npos; pos += 256) {
-        float v[4];
-        bs_load(x, M, j, pos, npos, v);
-        const float mu = 0.25f * (v[0] + v[1] + v[2] + v[3]);
-        float var = 0.f;
+    for (long pos = (long)threadIdx.x * VN; pos < npos; pos += (long)BS_NT * VN) {
+        float v[4][VN];
+        bs_load<T, VN>(x, M, j, pos, npos, v);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) var += (v[i] - mu) * (v[i] - mu);
-        s += sqrtf(0.25f * var + eps);
+        for (int e = 0; e < VN; ++e) {
+            const float mu = 0.25f * (v[0][e] + v[1][e] + v[2][e] + v[3][e]);
+            float var = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) var += (v[i][e] - mu) * (v[i][e] - mu);
+            s += sqrtf(0.25f * var + eps);
+        }
     }
-    s = block_sum<256>(s, red) / (float)npos;
-    for (int k = threadIdx.x; k < 4 * hw; k += 256) {
+    s = block_sum<BS_NT>(s, red) / (float)npos;
+    for (int k = threadIdx.x; k < 4 * hw; k += BS_NT) {
         const int i = k / hw, p = k % hw;
         DT<T>::st(y + (long)(i * M + j) * hw + p, s);
     }
 }
 
 // gx_i = gs_j * d_i / (4 sigma N),  gs_j = sum over members/pixels of gy
-template <typename T>
-__global__ __launch_bounds__(256) void batch_stddev_bwd_kernel(const T* __restrict__ gy, const T* __restrict__ x, T* __restrict__ gx,
-                                                               int M, int hw, int c, float eps) {
-    __shared__ float red[4];
+template <typename T, int VN>
+__global__ __launch_bounds__(BS_NT) void batch_stddev_bwd_kernel(const T* __restrict__ gy, const T* __restrict__ x, T* __restrict__ gx,
+                                                                 int M, int hw, int c, float eps) {
+    __shared__ float red[BS_NT / 64];
     const int j = blockIdx.x;
     const long npos = (long)hw * c;
     float g = 0.f;
-    for (int k = threadIdx.x; k < 4 * hw; k += 256) g += DT<T>::ld(gy + (long)((k / hw) * M + j) * hw + (k % hw));
-    g = block_sum<256>(g, red);
+    for (int k = threadIdx.x; k < 4 * hw; k += BS_NT) g += DT<T>::ld(gy + (long)((k / hw) * M + j) * hw + (k % hw));
+    g = block_sum<BS_NT>(g, red);
     const float coef = g / (4.f * (float)npos);
-    for (long pos = threadIdx.x; pos < npos; pos += 256) {
-        float v[4];
-        bs_load(x, M, j, pos, npos, v);
-        const float mu = 0.25f * (v[0] + v[1] + v[2] + v[3]);
-        float var = 0.f;
+    for (long pos = (long)threadIdx.x * VN; pos < npos; pos += (long)BS_NT * VN) {
+        float v[4][VN], o[4][VN];
+        bs_load<T, VN>(x, M, j, pos, npos, v);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) var += (v[i] - mu) * (v[i] - mu);
-        const float inv = coef / sqrtf(0.25f * var + eps);
+        for (int e = 0; e < VN; ++e) {
+            const float mu = 0.25f * (v[0][e] + v[1][e] + v[2][e] + v[3][e]);
+            float var = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) DT<T>::st(gx + ((long)(i * M + j)) * npos + pos, (v[i] - mu) * inv);
+            for (int i = 0; i < 4; ++i) var += (v[i][e] - mu) * (v[i][e] - mu);
+            const float inv = coef / sqrtf(0.25f * var + eps);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i][e] = (v[i][e] - mu) * inv;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bs_st<T, VN>(gx + ((long)(i * M + j)) * npos + pos, o[i]);
     }
 }
 
 // F = sum_pos gs_j/(4N) * S/sigma,  S = sum_i ggx_i d_i
 //   ggy (every member / pixel of column j) = sum_pos S / (4 sigma N)
 //   gx2_k = gs_j/(4N) * [ (ggx_k - mean_i ggx_i)/sigma - S d_k / (4 sigma^3) ]
-template <typename T>
-__global__ __launch_bounds__(256) void batch_stddev_bwd_bwd_kernel(const T* __restrict__ ggx, const T* __restrict__ gy, const T* __restrict__ x,
-                                                                   T* __restrict__ ggy, T* __restrict__ gx2, int M, int hw, int c, float eps) {
-    __shared__ float red[4];
+template <typename T, int VN>
+__global__ __launch_bounds__(BS_NT) void batch_stddev_bwd_bwd_kernel(const T* __restrict__ ggx, const T* __restrict__ gy, const T* __restrict__ x,
+                                                                     T* __restrict__ ggy, T* __restrict__ gx2, int M, int hw, int c, float eps) {
+    __shared__ float red[BS_NT / 64];
     const int j = blockIdx.x;
     const long npos = (long)hw * c;
     float g = 0.f;
-    for (int k = threadIdx.x; k < 4 * hw; k += 256) g += DT<T>::ld(gy + (long)((k / hw) * M + j) * hw + (k % hw));
-    g = block_sum<256>(g, red);
+    for (int k = threadIdx.x; k < 4 * hw; k += BS_NT) g += DT<T>::ld(gy + (long)((k / hw) * M + j) * hw + (k % hw));
+    g = block_sum<BS_NT>(g, red);
     const float coef = g / (4.f * (float)npos);
     float t = 0.f;
-    for (long pos = threadIdx.x; pos < npos; pos += 256) {
-        float v[4], gg[4];
-        bs_load(x, M, j, pos, npos, v);
-        bs_load(ggx, M, j, pos, npos, gg);
-        const float mu = 0.25f * (v[0] + v[1] + v[2] + v[3]);
-        const float gm = 0.25f * (gg[0] + gg[1] + gg[2] + gg[3]);
-        float var = 0.f, S = 0.f;
+    for (long pos = (long)threadIdx.x * VN; pos < npos; pos += (long)BS_NT * VN) {
+        float v[4][VN], gg[4][VN], o[4][VN];
+        bs_load<T, VN>(x, M, j, pos, npos, v);
+        bs_load<T, VN>(ggx, M, j, pos, npos, gg);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { var += (v[i] - mu) * (v[i] - mu); S += gg[i] * (v[i] - mu); }
-        const float sig = sqrtf(0.25f * var + eps);
-        t += S / sig;
+        for (int e = 0; e < VN; ++e) {
+            const float mu = 0.25f * (v[0][e] + v[1][e] + v[2][e] + v[3][e]);
+            const float gm = 0.25f * (gg[0][e] + gg[1][e] + gg[2][e] + gg[3][e]);
+            float var = 0.f, S = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            DT<T>::st(gx2 + ((long)(i * M + j)) * npos + pos, coef * ((gg[i] - gm) / sig - S * (v[i] - mu) / (4.f * sig * sig * sig)));
+            for (int i = 0; i < 4; ++i) { var += (v[i][e] - mu) * (v[i][e] - mu); S += gg[i][e] * (v[i][e] - mu); }
+            const float sig = sqrtf(0.25f * var + eps);
+            t += S / sig;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i][e] = coef * ((gg[i][e] - gm) / sig - S * (v[i][e] - mu) / (4.f * sig * sig * sig));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bs_st<T, VN>(gx2 + ((long)(i * M + j)) * npos + pos, o[i]);
     }
-    t = block_sum<256>(t, red) / (4.f * (float)npos);
-    for (int k = threadIdx.x; k < 4 * hw; k += 256) DT<T>::st(ggy + (long)((k / hw) * M + j) * hw + (k % hw), t);
+    t = block_sum<BS_NT>(t, red) / (4.f * (float)npos);
+    for (int k = threadIdx.x; k < 4 * hw; k += BS_NT) DT<T>::st(ggy + (long)((k / hw) * M + j) * hw + (k % hw), t);
 }
 
 }  // namespace gs
@@ -469,21 +490,30 @@ extern "C" int gs_embedding_bwd(const int64_t* idx, const void* gy, float* gw, i
 
 extern "C" int gs_batch_stddev_fwd(const void* x, void* y, int b, int hw, int c, float eps, int dtype, void* stream) {
     GS_CHECK_ARG(b > 0 && b % 4 == 0 && hw > 0 && c > 0, "batch_stddev: batch %d must be a positive multiple of 4 (ops.py:341)", b);
-    GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((batch_stddev_fwd_kernel<T>), dim3(b / 4), dim3(256), 0, as_stream(stream), (const T*)x, (T*)y, b / 4, hw, c, eps));
+    GS_DISPATCH_DTYPE(dtype, {
+        if (((long)hw * c) % Wide<T>::N == 0) hipLaunchKernelGGL((batch_stddev_fwd_kernel<T, Wide<T>::N>), dim3(b / 4), dim3(BS_NT), 0, as_stream(stream), (const T*)x, (T*)y, b / 4, hw, c, eps);
+        else hipLaunchKernelGGL((batch_stddev_fwd_kernel<T, 1>), dim3(b / 4), dim3(BS_NT), 0, as_stream(stream), (const T*)x, (T*)y, b / 4, hw, c, eps);
+    });
     GS_CHECK_LAUNCH();
     return 0;
 }
 
 extern "C" int gs_batch_stddev_bwd(const void* gy, const void* x, void* gx, int b, int hw, int c, float eps, int dtype, void* stream) {
     GS_CHECK_ARG(b > 0 && b % 4 == 0 && hw > 0 && c > 0, "batch_stddev_bwd: bad args");
-    GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((batch_stddev_bwd_kernel<T>), dim3(b / 4), dim3(256), 0, as_stream(stream), (const T*)gy, (const T*)x, (T*)gx, b / 4, hw, c, eps));
+    GS_DISPATCH_DTYPE(dtype, {
+        if (((long)hw * c) % Wide<T>::N == 0) hipLaunchKernelGGL((batch_stddev_bwd_kernel<T, Wide<T>::N>), dim3(b / 4), dim3(BS_NT), 0, as_stream(stream), (const T*)gy, (const T*)x, (T*)gx, b / 4, hw, c, eps);
+        else hipLaunchKernelGGL((batch_stddev_bwd_kernel<T, 1>), dim3(b / 4), dim3(BS_NT), 0, as_stream(stream), (const T*)gy, (const T*)x, (T*)gx, b / 4, hw, c, eps);
+    });
     GS_CHECK_LAUNCH();
     return 0;
 }
 
 extern "C" int gs_batch_stddev_bwd_bwd(const void* ggx, const void* gy, const void* x, void* ggy, void* gx2, int b, int hw, int c, float eps, int dtype, void* stream) {
     GS_CHECK_ARG(b > 0 && b % 4 == 0 && hw > 0 && c > 0, "batch_stddev_bwd_bwd: bad args");
-    GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((batch_stddev_bwd_bwd_kernel<T>), dim3(b / 4), dim3(256), 0, as_stream(stream), (const T*)ggx, (const T*)gy, (const T*)x, (T*)ggy, (T*)gx2, b / 4, hw, c, eps));
+    GS_DISPATCH_DTYPE(dtype, {
+        if (((long)hw * c) % Wide<T>::N == 0) hipLaunchKernelGGL((batch_stddev_bwd_bwd_kernel<T, Wide<T>::N>), dim3(b / 4), dim3(BS_NT), 0, as_stream(stream), (const T*)ggx, (const T*)gy, (const T*)x, (T*)ggy, (T*)gx2, b / 4, hw, c, eps);
+        else hipLaunchKernelGGL((batch_stddev_bwd_bwd_kernel<T, 1>), dim3(b / 4), dim3(BS_NT), 0, as_stream(stream), (const T*)ggx, (const T*)gy, (const T*)x, (T*)ggy, (T*)gx2, b / 4, hw, c, eps);
+    });
     GS_CHECK_LAUNCH();
     return 0;
 }

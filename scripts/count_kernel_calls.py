@@ -42,14 +42,15 @@ class Wrapped(object):
 
 kernels.set_backend(Wrapped(CpuEmuKernels()))
 variables.set_default_store(variables.VariableStore(device="cpu"))
-pg = PGGAN(min_resolution=[2, 16], max_resolution=[8, 64], min_channels=8, max_channels=16, growing_level=1.0)
+RES = [int(v) for v in __import__("os").environ.get("GS_COUNT_RES", "8,64").split(",")]
+pg = PGGAN(min_resolution=[2, 16], max_resolution=RES, min_channels=8, max_channels=16, growing_level=1.0)
 hyper = Dict(generator_learning_rate=8e-4, generator_beta1=0.0, generator_beta2=0.99, discriminator_learning_rate=8e-4,
              discriminator_beta1=0.0, discriminator_beta2=0.99, mode_seeking_loss_weight=0.1, real_gradient_penalty_weight=5.0,
              fake_gradient_penalty_weight=0.0)
 g = torch.Generator().manual_seed(0)
 lat = torch.randn(4, 16, generator=g)
 lab = torch.nn.functional.one_hot(torch.randint(0, 5, (4,), generator=g), 5).float()
-img = torch.randn(4, 2, 8, 64, generator=g).clamp(-1, 1)
+img = torch.randn(4, 2, *RES, generator=g).clamp(-1, 1)
 model = GANSynth(pg.generator, pg.discriminator, None, None, None, hyper)
 model.discriminator_step(lat, lab, img)
 model.generator_step(lat, lab)
