@@ -41,13 +41,22 @@ __global__ __launch_bounds__(256) void dense_fwd_kernel(const T* __restrict__ x,
             part[((long)ks * b_total + b0 + b) * out + col] = red[0][b][tid] + red[1][b][tid] + red[2][b][tid] + red[3][b][tid];
     }
 }
+// block = 64 elements x 4 split lanes (a narrow layer has few elements and up to 64 splits: a thread per element would walk them
+// as one chain in a handful of blocks)
 template <typename T>
-__global__ void dense_finalize_kernel(const float* __restrict__ part, T* __restrict__ y, long n, int ksplit, float alpha) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float s = 0.f;
-    for (int k = 0; k < ksplit; ++k) s += part[(long)k * n + i];
-    DT<T>::st(y + i, s * alpha);
+__global__ __launch_bounds__(256) void dense_finalize_kernel(const float* __restrict__ part, T* __restrict__ y, long n, int ksplit, float alpha) {
+    __shared__ float red[4][64];
+    const int e = threadIdx.x & 63, kl = threadIdx.x >> 6;
+    const long i = (long)blockIdx.x * 64 + e;
+    float s0 = 0.f, s1 = 0.f;
+    if (i < n) {
+        int k = kl;
+        for (; k + 4 < ksplit; k += 8) { s0 += part[(long)k * n + i]; s1 += part[(long)(k + 4) * n + i]; }
+        if (k < ksplit) s0 += part[(long)k * n + i];
+    }
+    red[kl][e] = s0 + s1;
+    __syncthreads();
+    if (kl == 0 && i < n) DT<T>::st(y + i, (red[0][e] + red[1][e] + red[2][e] + red[3][e]) * alpha);
 }
 
 // ------------------------------------------------------------------------ dense bwd data
@@ -183,18 +192,21 @@ __global__ __launch_bounds__(256) void dense_fwd_fast_kernel(const T* __restrict
     }
 }
 
-// gx[b][i] = alpha * sum_o gy[b][o] w[i][o], out % 256 == 0: one wave per weight row, 16 bytes of w per lane per pass.
-template <typename T>
+// gx[b][i] = alpha * sum_o gy[b][o] w[i][o], out % 256 == 0: WPR waves per weight row (1: a wave per row; 4: the block's four
+// waves split a long row -- the generator's 512 x 8192 dense has only 512 rows, a wave per row is 128 blocks of 32 serial
+// trips), 16 bytes of w per lane per pass.
+template <typename T, int WPR>
 __global__ __launch_bounds__(256) void dense_bwd_data_fast_kernel(const T* __restrict__ gy, const float* __restrict__ w, T* __restrict__ gx,
                                                                   int b0, int nb, int in, int out, float alpha) {
-    const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= in) return;
+    __shared__ float red[4][FB];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int i = blockIdx.x * (4 / WPR) + wv / WPR;
+    const int sub = wv % WPR;
     float acc[FB];
 #pragma unroll
     for (int b = 0; b < FB; ++b) acc[b] = 0.f;
-    const float* wr = w + (long)i * out;
-    for (int o = lane * 4; o < out; o += 256) {
+    const float* wr = w + (long)(i < in ? i : in - 1) * out;
+    for (int o = (sub * 64 + lane) * 4; o < out; o += 256 * WPR) {
         const float4 wv = *reinterpret_cast<const float4*>(wr + o);
 #pragma unroll
         for (int b = 0; b < FB; ++b) {   // unconditional loads, see dense_fwd_fast_kernel
@@ -203,12 +215,24 @@ __global__ __launch_bounds__(256) void dense_bwd_data_fast_kernel(const T* __res
             acc[b] += gv[0] * wv.x + gv[1] * wv.y + gv[2] * wv.z + gv[3] * wv.w;
         }
     }
+    if constexpr (WPR == 1) {
+        if (i >= in) return;
 #pragma unroll
-    for (int b = 0; b < FB; ++b) {
-        if (b < nb) {
-            const float sum = wave_sum(acc[b]);
-            if (lane == 0) DT<T>::st(gx + (long)(b0 + b) * in + i, sum * alpha);
+        for (int b = 0; b < FB; ++b) {
+            if (b < nb) {
+                const float sum = wave_sum(acc[b]);
+                if (lane == 0) DT<T>::st(gx + (long)(b0 + b) * in + i, sum * alpha);
+            }
         }
+    } else {
+#pragma unroll
+        for (int b = 0; b < FB; ++b) {
+            const float sum = wave_sum(acc[b]);
+            if (lane == 0) red[wv][b] = sum;
+        }
+        __syncthreads();
+        if (threadIdx.x < nb && i < in)
+            DT<T>::st(gx + (long)(b0 + threadIdx.x) * in + i, (red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]) * alpha);
     }
 }
 
@@ -253,7 +277,7 @@ static bool dense_fwd_fast_ok(int in, int out) { return in % 4 == 0 && out % 32 
 static void dense_split(int in, int out, int* ksplit, int* ipb) {
     if (dense_fwd_fast_ok(in, out)) {   // (out/32) x ksplit blocks should cover the chip twice; a split handles >= 128 rows
         const int tiles = out / 32;
-        int ks = (512 + tiles - 1) / tiles;
+        int ks = tiles >= 128 ? 1 : (512 + tiles - 1) / tiles;   // >= 128 column tiles: no split, no finalize launch
         const int maxks = in / 128 > 0 ? in / 128 : 1;
         if (ks > maxks) ks = maxks;
         if (ks < 1) ks = 1;
@@ -437,7 +461,7 @@ extern "C" int gs_dense_fwd(const void* x, const float* w, void* y, int b, int i
     }
     if (fast && ks == 1) return 0;
     const long n = (long)b * out;
-    GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dense_finalize_kernel<T>), dim3(cdiv(n, 256)), dim3(256), 0, st, part, (T*)y, n, ks, alpha));
+    GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dense_finalize_kernel<T>), dim3(cdiv(n, 64)), dim3(256), 0, st, part, (T*)y, n, ks, alpha));
     GS_CHECK_LAUNCH();
     return 0;
 }
@@ -449,7 +473,11 @@ extern "C" int gs_dense_bwd_data(const void* gy, const float* w, void* gx, int b
     for (int b0 = 0; b0 < b; b0 += step) {
         const int nb = b - b0 < step ? b - b0 : step;
         if (out % 256 == 0) {
-            GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dense_bwd_data_fast_kernel<T>), dim3(cdiv(in, 4)), dim3(256), 0, st, (const T*)gy, w, (T*)gx, b0, nb, in, out, alpha));
+            if (in <= 1024 && out >= 1024) {   // few long rows: the whole block on one row
+                GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dense_bwd_data_fast_kernel<T, 4>), dim3(in), dim3(256), 0, st, (const T*)gy, w, (T*)gx, b0, nb, in, out, alpha));
+            } else {
+                GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dense_bwd_data_fast_kernel<T, 1>), dim3(cdiv(in, 4)), dim3(256), 0, st, (const T*)gy, w, (T*)gx, b0, nb, in, out, alpha));
+            }
         } else if (out >= 2048) {
             GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dense_bwd_data_wide_kernel<T>), dim3(in), dim3(256), 0, st, (const T*)gy, w, (T*)gx, b0, nb, in, out, alpha));
         } else {
