@@ -113,6 +113,29 @@ def _accum_target(param):
     return g
 
 
+class _WeightSlice(Function):
+    """w[:, :, lo:hi, :] as a contiguous kernel operand (the 257-input-channel conv of the last discriminator block is evaluated
+    as two convs on slices of one variable).  Plain backward: the slice's gradient is added straight into that slice of w.grad
+    (one launch) instead of autograd's zero-filled full-size tensor + copy + accumulate (three)."""
+
+    @staticmethod
+    def forward(ctx, w, lo, hi):
+        ctx.lo, ctx.hi, ctx.wref = lo, hi, w
+        return w[:, :, lo:hi, :].contiguous()
+
+    @staticmethod
+    def backward(ctx, g):
+        tgt = _accum_target(ctx.wref)
+        if tgt is not None:
+            tgt[:, :, ctx.lo:ctx.hi, :].add_(g)
+            return None, None, None
+        return torch.nn.functional.pad(g, (0, 0, ctx.lo, ctx.wref.shape[2] - ctx.hi)), None, None
+
+
+def weight_slice(w, lo, hi):
+    return _WeightSlice.apply(w, lo, hi)
+
+
 # ---- "premasked" gradients ------------------------------------------------------------------------------------------------
 # A block z = act(conv(..) + b) has the backward gy = gz * act'(z) followed by the conv gradients.  When z has ONE consumer (the
 # caller says so: `in_act` of the consuming op -- networks.py knows its own wiring) and that consumer is a conv or a pixel norm,

@@ -137,7 +137,8 @@ class GANSynth(object):
     @staticmethod
     def _label_logits(logits, labels):
         """tf.gather_nd(logits, tf.where(labels)) for one-hot labels (models.py:39-40)."""
-        return (logits.float() * labels.float()).sum(dim=1)
+        # (labels are one-hot: the product is exact in the activation dtype and the fp32 sum has one non-zero term)
+        return (logits * labels.to(logits.dtype)).sum(dim=1, dtype=torch.float32)
 
     # Each run splits into a part that touches only the network being updated and a part that needs the other network:
     #   D run:  A = D(real) + the R1 first-order pass          B = G(z) (no grad), D(fake), loss, backward

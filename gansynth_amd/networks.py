@@ -153,8 +153,8 @@ class PGGAN(object):
                 with variable_scope("conv"):
                     weight, alpha = ops.get_weight([3, 3, c + 1, c], 2.0, True)
                     bias = ops.get_bias([c])
-                    y = F.axpby(F.conv2d(x, weight[:, :, :c, :].contiguous(), 3, 1, alpha),
-                                F.conv2d(stddev, weight[:, :, c:, :].contiguous(), 3, 1, alpha), 1.0, 1.0)
+                    y = F.axpby(F.conv2d(x, F.weight_slice(weight, 0, c), 3, 1, alpha),
+                                F.conv2d(stddev, F.weight_slice(weight, c, c + 1), 3, 1, alpha), 1.0, 1.0)
                     x = F.bias_act(y, bias, ops._ACT["leaky_relu"])
                 with variable_scope("dense"):
                     x = x.reshape(x.shape[0], -1)  # tf.layers.flatten of NCHW: channel-major
