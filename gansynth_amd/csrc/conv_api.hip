@@ -12,7 +12,7 @@ bool wgrad_mfma_supported(int ic, int oc, int dtype);
 size_t igemm_prep_bytes(int ic, int oc, int dtype);
 int run_igemm(int mode, int variant, const void* x, const float* w_hwio, void* y, int N, int Hi, int Wi, int ICk,
               int OCk, int w_ci, int w_co, int Hb, int Wb, float alpha, const float* bias, int act, int dtype, int w_prepared,
-              void* ws, size_t ws_bytes, hipStream_t st, const void* mask = nullptr, int mask_act = 0);
+              void* ws, size_t ws_bytes, hipStream_t st, const void* mask = nullptr, int mask_act = 0, void* y2 = nullptr, float pn_eps = 0.f);
 size_t wgrad_mfma_bytes(int mode, int dtype, int N, int Hb, int Wb, int IC, int OC);
 bool wgrad_mfma_has_bias(int dtype);
 int run_wgrad_mfma(int mode, const WgradSrcs& srcs, int nsrc, float* gw, float* gb, int N, int Hi, int Wi, int IC, int OC, int Hb,
@@ -527,18 +527,25 @@ extern "C" size_t gs_conv2d_workspace_bytes(int which, int n, int h, int w, int 
 // the bias/activation epilogue for the shapes that do not go through the MFMA kernel
 extern "C" int gs_bias_act_fwd(const void* x, const float* bias, void* y, int64_t p, int c, int act, int dtype, void* stream);
 
+// y2 (optional): y2 = pixel_norm(act(conv + bias)) as well -- fused into the conv epilogue where the tile owns all channels of a
+// pixel, a separate pass otherwise; y (the activation itself) may then be NULL
 static int conv2d_fwd_impl(const void* x, const float* w_hwio, const float* bias, int act, void* y, int n, int h, int w, int ci, int co, int ksize,
-                           int stride, float alpha, int dtype, int w_prepared, void* ws, size_t ws_bytes, void* stream) {
+                           int stride, float alpha, int dtype, int w_prepared, void* ws, size_t ws_bytes, void* stream, void* y2 = nullptr,
+                           float pn_eps = 0.f) {
     if (int e = check_conv_args(n, h, w, ci, co, ksize, stride, dtype)) return e;
     GS_CHECK_ARG(act == GS_ACT_NONE || act == GS_ACT_LRELU || act == GS_ACT_TANH, "conv2d: bad activation %d", act);
+    GS_CHECK_ARG(y || y2, "conv2d: no output");
     hipStream_t st = as_stream(stream);
     const int hb = h / stride, wb = w / stride;
     const int mode = stride == 2 ? MODE_S2 : MODE_S1;
     if (ksize == 3 && igemm_supported(ci, co, dtype) && act != GS_ACT_TANH)
-        return run_igemm(mode, 0, x, w_hwio, y, n, h, w, ci, co, ci, co, hb, wb, alpha, bias, act, dtype, w_prepared, ws, ws_bytes, st);
+        return run_igemm(mode, 0, x, w_hwio, y, n, h, w, ci, co, ci, co, hb, wb, alpha, bias, act, dtype, w_prepared, ws, ws_bytes, st, nullptr, 0, y2, pn_eps);
+    void* z = y ? y : y2;
     bool fused = false;
-    if (int e = run_direct(mode, ksize, 0, x, w_hwio, y, n, h, w, ci, co, ci, co, hb, wb, alpha, dtype, w_prepared, ws, ws_bytes, st, bias, act, &fused)) return e;
-    if (!fused && (bias || act != GS_ACT_NONE)) return gs_bias_act_fwd(y, bias, y, (int64_t)n * hb * wb, co, act, dtype, stream);
+    if (int e = run_direct(mode, ksize, 0, x, w_hwio, z, n, h, w, ci, co, ci, co, hb, wb, alpha, dtype, w_prepared, ws, ws_bytes, st, bias, act, &fused)) return e;
+    if (!fused && (bias || act != GS_ACT_NONE))
+        if (int e = gs_bias_act_fwd(z, bias, z, (int64_t)n * hb * wb, co, act, dtype, stream)) return e;
+    if (y2) return gs_pixel_norm_fwd(z, y2, (int64_t)n * hb * wb, co, pn_eps, dtype, stream);
     return 0;
 }
 
@@ -551,6 +558,13 @@ extern "C" int gs_conv2d_fwd_bias_act(const void* x, const float* w_hwio, const 
                                       int ksize, int stride, float alpha, int act, int dtype, int w_prepared, void* ws, size_t ws_bytes,
                                       void* stream) {
     return conv2d_fwd_impl(x, w_hwio, bias, act, y, n, h, w, ci, co, ksize, stride, alpha, dtype, w_prepared, ws, ws_bytes, stream);
+}
+
+extern "C" int gs_conv2d_fwd_bias_act_norm(const void* x, const float* w_hwio, const float* bias, void* z, void* y, int n, int h, int w, int ci, int co,
+                                           int ksize, int stride, float alpha, int act, float eps, int dtype, int w_prepared, void* ws,
+                                           size_t ws_bytes, void* stream) {
+    GS_CHECK_ARG(y != nullptr, "conv2d_fwd_bias_act_norm: y is required (z is optional)");
+    return conv2d_fwd_impl(x, w_hwio, bias, act, z, n, h, w, ci, co, ksize, stride, alpha, dtype, w_prepared, ws, ws_bytes, stream, y, eps);
 }
 
 extern "C" int gs_act_bwd(const void* g, const void* y, void* gx, int64_t numel, int act, int dtype, void* stream);
@@ -701,20 +715,32 @@ extern "C" size_t gs_conv2d_transpose_s2_workspace_bytes(int which, int n, int h
 }
 
 static int conv2d_transpose_fwd_impl(const void* x, const float* w_hwio, const float* bias, int act, void* y, int n, int h, int w, int ci,
-                                     int co, float alpha, int dtype, int w_prepared, void* ws, size_t ws_bytes, void* stream) {
+                                     int co, float alpha, int dtype, int w_prepared, void* ws, size_t ws_bytes, void* stream, void* y2 = nullptr,
+                                     float pn_eps = 0.f) {
     if (int e = check_conv_args(n, 2 * h, 2 * w, co, ci, 3, 2, dtype)) return e;
+    GS_CHECK_ARG(y || y2, "conv2d_transpose: no output");
     hipStream_t st = as_stream(stream);
     // out[2i+k][co] += x[i][ci] * w[k][ci][co]: kernel roles ICk = ci, OCk = co, Wp[t][co][ci] (variant 0)
     if (igemm_supported(ci, co, dtype) && act != GS_ACT_TANH)
-        return run_igemm(MODE_T2, 0, x, w_hwio, y, n, h, w, ci, co, ci, co, h, w, alpha, bias, act, dtype, w_prepared, ws, ws_bytes, st);
-    if (int e = run_direct(MODE_T2, 3, 0, x, w_hwio, y, n, h, w, ci, co, ci, co, 2 * h, 2 * w, alpha, dtype, w_prepared, ws, ws_bytes, st)) return e;
-    if (bias || act != GS_ACT_NONE) return gs_bias_act_fwd(y, bias, y, (int64_t)n * 4 * h * w, co, act, dtype, stream);
+        return run_igemm(MODE_T2, 0, x, w_hwio, y, n, h, w, ci, co, ci, co, h, w, alpha, bias, act, dtype, w_prepared, ws, ws_bytes, st, nullptr, 0, y2, pn_eps);
+    void* z = y ? y : y2;
+    if (int e = run_direct(MODE_T2, 3, 0, x, w_hwio, z, n, h, w, ci, co, ci, co, 2 * h, 2 * w, alpha, dtype, w_prepared, ws, ws_bytes, st)) return e;
+    if (bias || act != GS_ACT_NONE)
+        if (int e = gs_bias_act_fwd(z, bias, z, (int64_t)n * 4 * h * w, co, act, dtype, stream)) return e;
+    if (y2) return gs_pixel_norm_fwd(z, y2, (int64_t)n * 4 * h * w, co, pn_eps, dtype, stream);
     return 0;
 }
 
 extern "C" int gs_conv2d_transpose_s2_fwd(const void* x, const float* w_hwio, void* y, int n, int h, int w, int ci, int co,
                                           float alpha, int dtype, int w_prepared, void* ws, size_t ws_bytes, void* stream) {
     return conv2d_transpose_fwd_impl(x, w_hwio, nullptr, GS_ACT_NONE, y, n, h, w, ci, co, alpha, dtype, w_prepared, ws, ws_bytes, stream);
+}
+
+extern "C" int gs_conv2d_transpose_s2_fwd_bias_act_norm(const void* x, const float* w_hwio, const float* bias, void* z, void* y, int n, int h, int w,
+                                                        int ci, int co, float alpha, int act, float eps, int dtype, int w_prepared, void* ws,
+                                                        size_t ws_bytes, void* stream) {
+    GS_CHECK_ARG(y != nullptr, "conv2d_transpose_s2_fwd_bias_act_norm: y is required (z is optional)");
+    return conv2d_transpose_fwd_impl(x, w_hwio, bias, act, z, n, h, w, ci, co, alpha, dtype, w_prepared, ws, ws_bytes, stream, y, eps);
 }
 
 extern "C" int gs_conv2d_transpose_s2_fwd_bias_act(const void* x, const float* w_hwio, const float* bias, void* y, int n, int h, int w, int ci,

@@ -16,6 +16,8 @@
 // ops.py:269-276 (plus the tf.gradients of both, models.py:47,60,81-89).
 #include "conv_shared.h"
 
+extern "C" int gs_pixel_norm_fwd(const void* x, void* y, int64_t p, int c, float eps, int dtype, void* stream);
+
 namespace gs {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -121,6 +123,9 @@ struct ConvP {
     int act;
     const void* mask;   // optional (data gradients): y *= mask_act'(.) expressed through the activation OUTPUT mask[..] (y's shape)
     int mask_act;
+    void* y2;           // optional (NORM kernels): y2 = pixel_norm(y) over the channels, y itself optional then
+    float pn_eps;
+    int* norm_pending;  // host side: set to 1 when the chosen kernel did not fuse the norm
     int N, Hi, Wi, IC, OC, Hb, Wb, tiles_x, tiles_y, nsp, noct, nch;
     float alpha;
 #ifdef GS_IGEMM_TRACE
@@ -176,7 +181,7 @@ __device__ __forceinline__ void block_barrier() {
     asm volatile("" ::: "memory");
 }
 
-template <typename T, int MODE, int A, int B, int TW, int TG, bool RESIDENT, int D>
+template <typename T, int MODE, int A, int B, int TW, int TG, bool RESIDENT, int D, bool NORM>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
     constexpr int NP = 128 * B;
     constexpr int TH = NP / TW;
@@ -461,6 +466,59 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
                 if (tg == NTG - 1 && ch == NCH - 1) {
                     const int Ho = MODE == MODE_T2 ? 2 * Hb : Hb, Wo = MODE == MODE_T2 ? 2 * Wb : Wb;
                     const float slope = p.act == GS_ACT_LRELU ? 0.2f : 1.f;
+                    auto mask_factor = [&](float z) __attribute__((always_inline)) {
+                        return p.mask_act == GS_ACT_LRELU ? (z > 0.f ? 1.f : 0.2f) : 1.f - z * z;
+                    };
+                    // the 32 channels of tile a of one pixel: act(alpha * acc + bias); o[qd][e] = channel 8 qd + 4 hi + e
+                    auto finish = [&](int ph, int a, int b, float (&o)[4][4]) __attribute__((always_inline)) {
+#pragma unroll
+                        for (int qd = 0; qd < 4; ++qd) {
+                            const float4 bv = *reinterpret_cast<const float4*>(lbias + oc0 + a * 32 + qd * 8 + hi * 4);
+                            const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float v = acc[ph][a][b][qd * 4 + e] * p.alpha + bb[e];
+                                o[qd][e] = fmaxf(v, slope * v);  // leaky relu (slope 1: identity)
+                            }
+                        }
+                    };
+                    // ... to dst[off + a * 32 + ...] (16 bytes per lane), optionally times mask_act'(.) through mask[off + ...]
+                    auto store = [&](T* dst, long off, int a, float (&o)[4][4], bool inside, const void* mask) __attribute__((always_inline)) {
+                        if constexpr (SZ == 4) {
+#pragma unroll
+                            for (int qd = 0; qd < 4; ++qd) {
+                                if (inside) {
+                                    if (mask) {
+                                        const float4 zv = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(mask) + off + a * 32 + qd * 8 + hi * 4);
+                                        o[qd][0] *= mask_factor(zv.x); o[qd][1] *= mask_factor(zv.y); o[qd][2] *= mask_factor(zv.z); o[qd][3] *= mask_factor(zv.w);
+                                    }
+                                    st4(reinterpret_cast<float*>(dst) + off + a * 32 + qd * 8 + hi * 4, o[qd]);
+                                }
+                            }
+                        } else {
+#pragma unroll
+                            for (int qp = 0; qp < 2; ++qp) {
+                                float lo[4], hi4[4];
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(o[2 * qp][e]), __float_as_uint(o[2 * qp + 1][e]), false, false);
+                                    lo[e] = __uint_as_float(r[0]);
+                                    hi4[e] = __uint_as_float(r[1]);
+                                }
+                                if (mask && inside) {   // the lane's 8 channels of the mask sit where its 16 bytes go
+                                    const uint4 zv = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(mask) + off + a * 32 + qp * 16 + hi * 8);
+                                    lo[0] *= mask_factor(__uint_as_float(zv.x << 16)); lo[1] *= mask_factor(__uint_as_float(zv.x & 0xffff0000u));
+                                    lo[2] *= mask_factor(__uint_as_float(zv.y << 16)); lo[3] *= mask_factor(__uint_as_float(zv.y & 0xffff0000u));
+                                    hi4[0] *= mask_factor(__uint_as_float(zv.z << 16)); hi4[1] *= mask_factor(__uint_as_float(zv.z & 0xffff0000u));
+                                    hi4[2] *= mask_factor(__uint_as_float(zv.w << 16)); hi4[3] *= mask_factor(__uint_as_float(zv.w & 0xffff0000u));
+                                }
+                                uint4 v;
+                                v.x = pack_bf16x2(lo[0], lo[1]); v.y = pack_bf16x2(lo[2], lo[3]);
+                                v.z = pack_bf16x2(hi4[0], hi4[1]); v.w = pack_bf16x2(hi4[2], hi4[3]);
+                                if (inside) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(dst) + off + a * 32 + qp * 16 + hi * 8) = v;
+                            }
+                        }
+                    };
 #pragma unroll
                     for (int b = 0; b < B; ++b) {
                         const int q = (wv * B + b) * 32 + l31;
@@ -474,56 +532,37 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
                         for (int ph = 0; ph < NPH; ++ph) {
                             const int oy = MODE == MODE_T2 ? 2 * gy + (ph >> 1) : gy;
                             const int ox = MODE == MODE_T2 ? 2 * gx + (ph & 1) : gx;
-                            T* const yp = y + (((long)n * Ho + oy) * Wo + ox) * OC + oc0;
+                            const long off = (((long)n * Ho + oy) * Wo + ox) * OC + oc0;
+                            if constexpr (NORM) {
+                                // the block owns every channel of the pixel (OC == 32 A): pixel norm in the same pass.  The lane and its
+                                // partner in the other half hold the pixel's channels between them.
+                                float o[A][4][4], ssq = 0.f;
 #pragma unroll
-                            for (int a = 0; a < A; ++a) {
-                                float o[4][4];
+                                for (int a = 0; a < A; ++a) {
+                                    finish(ph, a, b, o[a]);
 #pragma unroll
-                                for (int qd = 0; qd < 4; ++qd) {
-                                    const float4 bv = *reinterpret_cast<const float4*>(lbias + oc0 + a * 32 + qd * 8 + hi * 4);
-                                    const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
-#pragma unroll
-                                    for (int e = 0; e < 4; ++e) {
-                                        const float v = acc[ph][a][b][qd * 4 + e] * p.alpha + bb[e];
-                                        o[qd][e] = fmaxf(v, slope * v);  // leaky relu (slope 1: identity)
-                                    }
+                                    for (int k = 0; k < 16; ++k) ssq += o[a][k >> 2][k & 3] * o[a][k >> 2][k & 3];
                                 }
-                                auto mask_factor = [&](float z) __attribute__((always_inline)) {
-                                    return p.mask_act == GS_ACT_LRELU ? (z > 0.f ? 1.f : 0.2f) : 1.f - z * z;
-                                };
-                                if constexpr (SZ == 4) {
+                                ssq += __shfl_xor(ssq, 32, 64);
+                                const float r = rsqrtf(ssq * (1.f / (float)(32 * A)) + p.pn_eps);
 #pragma unroll
-                                    for (int qd = 0; qd < 4; ++qd) {
-                                        if (inside) {
-                                            if (p.mask) {
-                                                const float4 zv = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.mask) + (yp - y) + a * 32 + qd * 8 + hi * 4);
-                                                o[qd][0] *= mask_factor(zv.x); o[qd][1] *= mask_factor(zv.y); o[qd][2] *= mask_factor(zv.z); o[qd][3] *= mask_factor(zv.w);
-                                            }
-                                            st4(reinterpret_cast<float*>(yp) + a * 32 + qd * 8 + hi * 4, o[qd]);
-                                        }
+                                for (int a = 0; a < A; ++a) {
+                                    if (y) {   // the pre-norm activation, kept for the backward
+                                        float oz[4][4];
+#pragma unroll
+                                        for (int k = 0; k < 16; ++k) oz[k >> 2][k & 3] = o[a][k >> 2][k & 3];
+                                        store(y, off, a, oz, inside, nullptr);
                                     }
-                                } else {
 #pragma unroll
-                                    for (int qp = 0; qp < 2; ++qp) {
-                                        float lo[4], hi4[4];
+                                    for (int k = 0; k < 16; ++k) o[a][k >> 2][k & 3] *= r;
+                                    store(reinterpret_cast<T*>(p.y2), off, a, o[a], inside, nullptr);
+                                }
+                            } else {
 #pragma unroll
-                                        for (int e = 0; e < 4; ++e) {
-                                            const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(o[2 * qp][e]), __float_as_uint(o[2 * qp + 1][e]), false, false);
-                                            lo[e] = __uint_as_float(r[0]);
-                                            hi4[e] = __uint_as_float(r[1]);
-                                        }
-                                        if (p.mask && inside) {   // the lane's 8 channels of the mask sit where its 16 bytes go
-                                            const uint4 zv = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.mask) + (yp - y) + a * 32 + qp * 16 + hi * 8);
-                                            lo[0] *= mask_factor(__uint_as_float(zv.x << 16)); lo[1] *= mask_factor(__uint_as_float(zv.x & 0xffff0000u));
-                                            lo[2] *= mask_factor(__uint_as_float(zv.y << 16)); lo[3] *= mask_factor(__uint_as_float(zv.y & 0xffff0000u));
-                                            hi4[0] *= mask_factor(__uint_as_float(zv.z << 16)); hi4[1] *= mask_factor(__uint_as_float(zv.z & 0xffff0000u));
-                                            hi4[2] *= mask_factor(__uint_as_float(zv.w << 16)); hi4[3] *= mask_factor(__uint_as_float(zv.w & 0xffff0000u));
-                                        }
-                                        uint4 v;
-                                        v.x = pack_bf16x2(lo[0], lo[1]); v.y = pack_bf16x2(lo[2], lo[3]);
-                                        v.z = pack_bf16x2(hi4[0], hi4[1]); v.w = pack_bf16x2(hi4[2], hi4[3]);
-                                        if (inside) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(yp) + a * 32 + qp * 16 + hi * 8) = v;
-                                    }
+                                for (int a = 0; a < A; ++a) {
+                                    float o[4][4];
+                                    finish(ph, a, b, o);
+                                    store(y, off, a, o, inside, p.mask);
                                 }
                             }
                         }
@@ -981,7 +1020,7 @@ static int num_cus() {
     return g_num_cus;
 }
 
-template <typename T, int MODE, int A, int B, int TW, int TG, bool RESIDENT = false, int D = 2>
+template <typename T, int MODE, int A, int B, int TW, int TG, bool RESIDENT = false, int D = 2, bool NORM = false>
 static int launch_igemm(ConvP p, hipStream_t st) {
     constexpr int NP = 128 * B;
     constexpr int TH = NP / TW;
@@ -1002,7 +1041,13 @@ static int launch_igemm(ConvP p, hipStream_t st) {
     if (p.OC % OCT != 0) return fail(GS_ERR_UNSUPPORTED, "conv igemm: %d output channels with %d-wide tiles", p.OC, OCT);
     if ((size_t)p.Hi * p.Wi * p.IC * sizeof(T) >= (1ull << 31)) return fail(GS_ERR_UNSUPPORTED, "conv igemm: one image exceeds 2 GiB");
     if (lds > 160 * 1024) return fail(GS_ERR_UNSUPPORTED, "conv igemm: %zu bytes of LDS needed", lds);
-    auto kern = conv_igemm_kernel<T, MODE, A, B, TW, TG, RESIDENT, D>;
+    if (NORM && p.OC != OCT) return fail(GS_ERR_UNSUPPORTED, "conv igemm: fused pixel norm needs the whole channel range in one tile");
+    if (!NORM && p.y2) {   // the norm stays a separate pass: this launch leaves the activation where that pass will read it
+        if (!p.y) p.y = p.y2;
+        p.y2 = nullptr;
+        if (p.norm_pending) *p.norm_pending = 1;
+    }
+    auto kern = conv_igemm_kernel<T, MODE, A, B, TW, TG, RESIDENT, D, NORM>;
     static size_t max_set = 0;  // per template instantiation
     if (lds > max_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -1045,13 +1090,17 @@ static int dispatch_igemm(ConvP p, hipStream_t st) {
     const long cus = num_cus();
     static const bool no_small = getenv("GS_NO_SMALL_TILES") != nullptr;   // measurement knob
     const bool small = !no_small && items64(1) <= cus;   // no more blocks than CUs: a serial chain of stages per block
+    // Fused pixel norm (p.y2): only the configurations whose tile owns every channel of a pixel (OC = 32 A) and that the generator's
+    // 32- / 64-channel blocks actually use; everything else runs the plain kernel and the caller's separate norm pass (p.y2 = NULL
+    // on return tells it so -- see run_igemm_t).
+    const bool norm = p.y2 != nullptr;
     if constexpr (MODE == MODE_T2) {
-        if (resident_ok && Wb >= 64) return launch_igemm<T, MODE, 1, 1, 64, 9, true, 1>(p, st);
+        if (resident_ok && Wb >= 64) { if (norm) return launch_igemm<T, MODE, 1, 1, 64, 9, true, 1, true>(p, st); return launch_igemm<T, MODE, 1, 1, 64, 9, true, 1>(p, st); }
         // few blocks, each a serial chain of stages: 32-channel tiles double the number of busy CUs, 9-tap stages cut the
         // barriers and DMA round trips of the chain to a third
         if (small) { if (Wb >= 32) return launch_igemm<T, MODE, 1, 1, 32, 9, false, 1>(p, st); return launch_igemm<T, MODE, 1, 1, 16, 9, false, 1>(p, st); }
         if (!a2) { if (Wb >= 32) return launch_igemm<T, MODE, 1, 1, 32, 3>(p, st); return launch_igemm<T, MODE, 1, 1, 16, 3>(p, st); }
-        if (Wb >= 32) return launch_igemm<T, MODE, 2, 1, 32, 3>(p, st);
+        if (Wb >= 32) { if (norm && OC == 64) return launch_igemm<T, MODE, 2, 1, 32, 3, false, 2, true>(p, st); return launch_igemm<T, MODE, 2, 1, 32, 3>(p, st); }
         return launch_igemm<T, MODE, 2, 1, 16, 3>(p, st);
     } else if constexpr (MODE == MODE_S2) {
         if (small) { if (Wb >= 32) return launch_igemm<T, MODE, 1, 1, 32, 9, false, 1>(p, st); return launch_igemm<T, MODE, 1, 1, 16, 9, false, 1>(p, st); }
@@ -1063,10 +1112,10 @@ static int dispatch_igemm(ConvP p, hipStream_t st) {
         if (Wb >= 32) return launch_igemm<T, MODE, 2, 1, 32, 3>(p, st);
         return launch_igemm<T, MODE, 2, 1, 16, 3>(p, st);
     } else {
-        if (resident_ok && Wb >= 64) return launch_igemm<T, MODE, 1, 2, 64, 9, true, 1>(p, st);
+        if (resident_ok && Wb >= 64) { if (norm) return launch_igemm<T, MODE, 1, 2, 64, 9, true, 1, true>(p, st); return launch_igemm<T, MODE, 1, 2, 64, 9, true, 1>(p, st); }
         if (small) { if (Wb >= 32) return launch_igemm<T, MODE, 1, 1, 32, 9, false, 1>(p, st); return launch_igemm<T, MODE, 1, 1, 16, 9, false, 1>(p, st); }
         if (!a2) return launch_igemm<T, MODE, 1, 1, 32, 3>(p, st);
-        if (Wb >= 32 && items64(2) >= 2 * cus) return launch_igemm<T, MODE, 2, 2, 32, 3, false, 1>(p, st);
+        if (Wb >= 32 && items64(2) >= 2 * cus) { if (norm && OC == 64) return launch_igemm<T, MODE, 2, 2, 32, 3, false, 1, true>(p, st); return launch_igemm<T, MODE, 2, 2, 32, 3, false, 1>(p, st); }
         if (resident64_ok && Wb >= 32 && items64(2) >= cus / 2) return launch_igemm<T, MODE, 2, 2, 32, 9, true>(p, st);
         // every block re-streams its 64 x IC x 9 weight slab from L2: the more pixels a block owns the smaller that
         // stream is per MFMA -- take the largest pixel tile that still gives every CU a block
@@ -1090,7 +1139,7 @@ size_t igemm_prep_bytes(int ic, int oc, int dtype) {
 template <typename T>
 static int run_igemm_t(int mode, int variant, const void* x, const float* w_hwio, void* y, int N, int Hi, int Wi,
                        int ICk, int OCk, int w_ci, int w_co, int Hb, int Wb, float alpha, const float* bias, int act,
-                       int w_prepared, void* ws, size_t ws_bytes, hipStream_t st, const void* mask, int mask_act) {
+                       int w_prepared, void* ws, size_t ws_bytes, hipStream_t st, const void* mask, int mask_act, void* y2, float pn_eps) {
     const size_t need = (size_t)9 * w_ci * w_co * sizeof(T);
     if (ws_bytes < need) return fail(GS_ERR_WORKSPACE, "conv igemm: workspace %zu < %zu", ws_bytes, need);
     T* wp = reinterpret_cast<T*>(ws);
@@ -1101,20 +1150,26 @@ static int run_igemm_t(int mode, int variant, const void* x, const float* w_hwio
     memset(&p, 0, sizeof(p));
     p.x = x; p.wp = wp; p.y = y; p.bias = bias; p.act = act; p.mask = mask; p.mask_act = mask_act;
     p.N = N; p.Hi = Hi; p.Wi = Wi; p.IC = ICk; p.OC = OCk; p.Hb = Hb; p.Wb = Wb; p.alpha = alpha;
+    int pending = 0;
+    p.y2 = y2; p.pn_eps = pn_eps; p.norm_pending = &pending;
     int rc;
     if (mode == MODE_S1) rc = dispatch_igemm<T, MODE_S1>(p, st);
     else if (mode == MODE_S2) rc = dispatch_igemm<T, MODE_S2>(p, st);
     else rc = dispatch_igemm<T, MODE_T2>(p, st);
     if (rc) return rc;
     GS_CHECK_LAUNCH();
+    if (pending) {   // y2 = pixel_norm(activation), the activation sitting in y (or in y2 itself when the caller keeps no copy)
+        const long px = (long)N * Hb * Wb * (mode == MODE_T2 ? 4 : 1);
+        return gs_pixel_norm_fwd(y ? y : y2, y2, px, OCk, pn_eps, sizeof(T) == 4 ? GS_F32 : GS_BF16, st);
+    }
     return 0;
 }
 
 int run_igemm(int mode, int variant, const void* x, const float* w_hwio, void* y, int N, int Hi, int Wi, int ICk,
               int OCk, int w_ci, int w_co, int Hb, int Wb, float alpha, const float* bias, int act, int dtype, int w_prepared,
-              void* ws, size_t ws_bytes, hipStream_t st, const void* mask, int mask_act) {
+              void* ws, size_t ws_bytes, hipStream_t st, const void* mask, int mask_act, void* y2, float pn_eps) {
     GS_DISPATCH_DTYPE(dtype, return (run_igemm_t<T>(mode, variant, x, w_hwio, y, N, Hi, Wi, ICk, OCk, w_ci, w_co, Hb,
-                                                    Wb, alpha, bias, act, w_prepared, ws, ws_bytes, st, mask, mask_act)));
+                                                    Wb, alpha, bias, act, w_prepared, ws, ws_bytes, st, mask, mask_act, y2, pn_eps)));
 }
 
 // ---- weight gradient (fp32 MFMA path)

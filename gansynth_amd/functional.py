@@ -37,6 +37,13 @@ class _ConvKind(object):
     def fwd_bias_act(self, x, w, bias, alpha, act):
         return _K().conv2d_fwd_bias_act(x, w, bias, self.ksize, self.stride, alpha, act)
 
+    def fwd_bias_act_norm(self, x, w, bias, alpha, act, eps, want_z):
+        K = _K()
+        if hasattr(K, "conv2d_fwd_bias_act_norm"):   # (z, y) from one call; the norm rides in the conv epilogue where it can
+            return K.conv2d_fwd_bias_act_norm(x, w, bias, self.ksize, self.stride, alpha, act, eps, want_z=want_z)
+        z = self.fwd_bias_act(x, w, bias, alpha, act)
+        return z, K.pixel_norm_fwd(z, eps)
+
     def bwd_data(self, gy, w, x_shape, alpha):
         return _K().conv2d_bwd_data(gy, w, x_shape, self.ksize, self.stride, alpha)
 
@@ -57,6 +64,13 @@ class _ConvTransposeKind(object):
 
     def fwd_bias_act(self, x, w, bias, alpha, act):
         return _K().conv2d_transpose_fwd_bias_act(x, w, bias, alpha, act)
+
+    def fwd_bias_act_norm(self, x, w, bias, alpha, act, eps, want_z):
+        K = _K()
+        if hasattr(K, "conv2d_transpose_fwd_bias_act_norm"):
+            return K.conv2d_transpose_fwd_bias_act_norm(x, w, bias, alpha, act, eps, want_z=want_z)
+        z = self.fwd_bias_act(x, w, bias, alpha, act)
+        return z, K.pixel_norm_fwd(z, eps)
 
     def bwd_data(self, gy, w, x_shape, alpha):
         return _K().conv2d_transpose_bwd_data(gy, w, alpha)
@@ -332,6 +346,9 @@ class _PnActBwd(Function):
         return g_g, g_z, None, None
 
 
+_FUSE_NORM_EPILOGUE = not __import__("os").environ.get("GS_NO_NORM_EPILOGUE")   # A/B switch for measurements
+
+
 class _ConvBiasActNorm(Function):
     """(y, z) with z = act(alpha * B(x, w) + bias), y = pixel_norm(z): a generator block as one node.  z is returned only so
     that second-order graphs built on it (the norm's backward is differentiated by the mode-seeking term) send their gradient
@@ -343,9 +360,14 @@ class _ConvBiasActNorm(Function):
         ctx.kind, ctx.alpha, ctx.act, ctx.eps, ctx.has_bias = kind, alpha, act, eps, bias is not None
         ctx.wref, ctx.bref = w, bias
         ctx.set_materialize_grads(False)   # an absent gradient for z must arrive as None, not as a tensor of zeros
-        z = kind.fwd_bias_act(x, w, bias, alpha, act)
-        y = _K().pixel_norm_fwd(z, eps)
-        ctx.save_for_backward(x, w, z)
+        want_z = any(ctx.needs_input_grad)   # no backward (the no-grad generator pass of the D run): the activation is not kept
+        if _FUSE_NORM_EPILOGUE:
+            z, y = kind.fwd_bias_act_norm(x, w, bias, alpha, act, eps, want_z)
+        else:
+            z = kind.fwd_bias_act(x, w, bias, alpha, act)
+            y = _K().pixel_norm_fwd(z, eps)
+        if want_z:
+            ctx.save_for_backward(x, w, z)
         return y, z
 
     @staticmethod

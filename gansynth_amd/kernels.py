@@ -206,6 +206,42 @@ class HipKernels(object):
                    "gs_conv2d_fwd_bias_act")
         return y
 
+    def conv2d_fwd_bias_act_norm(self, x, w, bias, ksize, stride, alpha, act, eps, want_z=True):
+        """(z, y): z = act(alpha * conv + bias), y = pixel_norm(z) -- one launch where the conv tile owns all channels of a pixel;
+        z is None with want_z=False (no backward will need the activation)."""
+        x, w = _act(x), _f32c(w)
+        n, ci, h, wd = x.shape
+        co = w.shape[3]
+        y = _empty_like_act((n, co, h // stride, wd // stride), x)
+        z = _empty_like_act((n, co, h // stride, wd // stride), x) if want_z else None
+        nb = self.lib.gs_conv2d_workspace_bytes(_lib.CONV_FWD, n, h, wd, ci, co, ksize, stride, _dt(x))
+        ws, prepared = self._weight_ws(w, ("fwd", ksize, stride, _dt(x)), nb, (_lib.PREP_CONV_FWD, ci, co, ksize, stride, _dt(x)))
+        bp = None
+        if bias is not None:
+            bias = _f32c(bias)
+            bp = bias.data_ptr()
+        _lib.check(self.lib.gs_conv2d_fwd_bias_act_norm(x.data_ptr(), w.data_ptr(), bp, None if z is None else z.data_ptr(), y.data_ptr(), n, h, wd,
+                                                        ci, co, ksize, stride, float(alpha), act, float(eps), _dt(x), prepared, ws.data_ptr(),
+                                                        ws.numel(), _stream()), "gs_conv2d_fwd_bias_act_norm")
+        return z, y
+
+    def conv2d_transpose_fwd_bias_act_norm(self, x, w, bias, alpha, act, eps, want_z=True):
+        x, w = _act(x), _f32c(w)
+        n, ci, h, wd = x.shape
+        co = w.shape[3]
+        y = _empty_like_act((n, co, 2 * h, 2 * wd), x)
+        z = _empty_like_act((n, co, 2 * h, 2 * wd), x) if want_z else None
+        nb = self.lib.gs_conv2d_transpose_s2_workspace_bytes(_lib.CONV_FWD, n, h, wd, ci, co, _dt(x))
+        ws, prepared = self._weight_ws(w, ("t_fwd", _dt(x)), nb, (_lib.PREP_CONVT_FWD, ci, co, 3, 2, _dt(x)))
+        bp = None
+        if bias is not None:
+            bias = _f32c(bias)
+            bp = bias.data_ptr()
+        _lib.check(self.lib.gs_conv2d_transpose_s2_fwd_bias_act_norm(x.data_ptr(), w.data_ptr(), bp, None if z is None else z.data_ptr(), y.data_ptr(),
+                                                                     n, h, wd, ci, co, float(alpha), act, float(eps), _dt(x), prepared,
+                                                                     ws.data_ptr(), ws.numel(), _stream()), "gs_conv2d_transpose_s2_fwd_bias_act_norm")
+        return z, y
+
     def conv2d_bwd_data(self, gy, w, x_shape, ksize, stride, alpha, mask=None, mask_act=0):
         """gx, or with `mask` (the conv's forward input, itself the output of activation `mask_act`) gx * act'(.): the data
         gradient w.r.t. the previous layer's pre-activation in one pass."""

@@ -79,6 +79,17 @@ int gs_conv2d_fwd_bias_act(const void* x, const float* w_hwio, const float* bias
                            void* stream);
 int gs_conv2d_bwd_data(const void* gy, const float* w_hwio, void* gx, int n, int h, int w, int ci, int co,
                        int ksize, int stride, float alpha, int dtype, int w_prepared, void* ws, size_t ws_bytes, void* stream);
+/* A generator block in one call (networks.py:44-61: conv -> leaky_relu -> pixel_norm): z = act(alpha * conv(x, w) + bias),
+ * y = pixel_norm(z, eps) over the channels (ops.py:330).  The norm is fused into the conv epilogue where a tile owns every
+ * channel of a pixel (co = 32 / 64 on the MFMA path), a separate pass otherwise; z may be NULL when the caller keeps no copy
+ * of the activation (inference, the no-grad generator pass of the D run).  gs_conv2d_transpose_s2_fwd_bias_act_norm: same
+ * for the upscaling conv. */
+int gs_conv2d_fwd_bias_act_norm(const void* x, const float* w_hwio, const float* bias, void* z, void* y, int n, int h, int w, int ci, int co,
+                                int ksize, int stride, float alpha, int act, float eps, int dtype, int w_prepared, void* ws,
+                                size_t ws_bytes, void* stream);
+int gs_conv2d_transpose_s2_fwd_bias_act_norm(const void* x, const float* w_hwio, const float* bias, void* z, void* y, int n, int h, int w,
+                                             int ci, int co, float alpha, int act, float eps, int dtype, int w_prepared, void* ws,
+                                             size_t ws_bytes, void* stream);
 /* bwd_data whose result is multiplied by the derivative of the activation that PRODUCED the conv's input, expressed through
  * that input itself: gx = conv2d_bwd_data(gy, w) * act'(.)|mask  (mask = x of the forward conv, same shape as gx; act = LRELU
  * or TANH).  It is the data gradient w.r.t. the previous layer's pre-activation in one pass (the separate act_bwd pass of the

@@ -522,3 +522,31 @@ def test_multi_source_weight_gradient_matches_oracle(K, E, dtype):
         close(gw, ref, rel=1e-4, name=f"multi wgrad {ci}->{co} s{st}")
         if with_b:
             close(gb, E.channel_sum(gys[0]) + E.channel_sum(gys[2]), rel=1e-4, name="multi wgrad bias (sources 0 and 2)")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", [("conv", 2, 32, 32, 8, 128), ("conv", 8, 64, 64, 64, 512), ("conv", 2, 64, 64, 8, 64), ("conv", 2, 256, 256, 4, 32),
+                                  ("convT", 2, 64, 32, 8, 64), ("convT", 8, 128, 64, 32, 256), ("convT", 2, 256, 256, 4, 32)])
+def test_conv_bias_act_norm_in_one_call(K, E, case, dtype):
+    """gs_conv2d[_transpose_s2]_fwd_bias_act_norm: (z, y) = (act(conv + b), pixel_norm(z)) -- fused into the conv epilogue for the
+    32- / 64-channel tiles (first, second, fifth and sixth case), conv + separate norm pass otherwise; with and without z."""
+    kind, n, ci, co, h, w = case
+    x = rnd(n, ci, h, w, seed=1).to(dtype).float()
+    wt = rnd(3, 3, ci, co, seed=2)
+    bias = rnd(co, seed=3, scale=0.1)
+    eps, alpha = 1e-8, 0.05
+    if kind == "conv":
+        zr = E.conv2d_fwd_bias_act(x, wt, bias, 3, 1, alpha, 1)
+        run = lambda want_z: K.conv2d_fwd_bias_act_norm(dev(x, dtype), dev(wt), dev(bias), 3, 1, alpha, 1, eps, want_z=want_z)
+    else:
+        zr = E.conv2d_transpose_fwd_bias_act(x, wt, bias, alpha, 1)
+        run = lambda want_z: K.conv2d_transpose_fwd_bias_act_norm(dev(x, dtype), dev(wt), dev(bias), alpha, 1, eps, want_z=want_z)
+    yr = E.pixel_norm_fwd(zr, eps)
+    tol = 1e-3 if dtype == torch.float32 else 2e-2
+    z, y = run(True)
+    close(z, zr, rel=tol, name=f"{case} z")
+    close(y, yr, rel=tol, name=f"{case} y")
+    z2, y2 = run(False)
+    assert z2 is None
+    close(y2, yr, rel=tol, name=f"{case} y (no z)")
+    assert torch.equal(y, y2) or dtype == torch.bfloat16   # fp32: the same fused arithmetic either way
