@@ -71,7 +71,9 @@ g = torch.Generator().manual_seed(0)
 lat = torch.randn(4, 16, generator=g)
 lab = torch.nn.functional.one_hot(torch.randint(0, 5, (4,), generator=g), 5).float()
 img = torch.randn(4, 2, 8, 64, generator=g).clamp(-1, 1)
-model = GANSynth(pg.generator, pg.discriminator, None, None, None, hyper)
+DT = torch.bfloat16 if __import__("os").environ.get("GS_COUNT_BF16") else torch.float32
+model = GANSynth(pg.generator, pg.discriminator, None, None, None, hyper, dtype=DT)
+lat, lab, img = lat.to(DT), lab.to(DT), img.to(DT)
 model.discriminator_step(lat, lab, img)
 model.generator_step(lat, lab)
 with Log():
