@@ -156,12 +156,16 @@ def weight_slice(w, lo, hi):
 # the multiplication by act'(z) moves into the kernel that produces gz (its input x IS z): one full read-modify-write pass per
 # activation disappears from the plain backward.  The consumer tells the producer through the producer's ctx (= z.grad_fn)
 # which tensor is already masked; under create_graph nothing is fused (the pieces must stay differentiable Functions).
-_NO_PREMASK = bool(__import__("os").environ.get("GS_NO_PREMASK"))   # A/B switch for measurements
+_NO_PREMASK = bool(__import__("os").environ.get("GS_NO_PREMASK"))   # A/B switches for measurements
+_NO_PREMASK_GRAPH = bool(__import__("os").environ.get("GS_NO_PREMASK_GRAPH"))
 
 
-def _premask_producer(x, in_act):
-    """ctx of the _ConvBiasAct that produced x when the fused path applies, else None."""
-    if in_act == ACT_NONE or torch.is_grad_enabled() or _NO_PREMASK:
+def _premask_producer(x, in_act, differentiable=False):
+    """ctx of the _ConvBiasAct that produced x when the fused path applies, else None.  Under create_graph only the
+    `differentiable` caller (which then uses _BwdDataMasked) and only for leaky relu."""
+    if in_act == ACT_NONE or _NO_PREMASK:
+        return None
+    if torch.is_grad_enabled() and not (differentiable and in_act == ACT_LRELU and not _NO_PREMASK_GRAPH):
         return None
     fn = x.grad_fn
     if fn is not None and getattr(fn, "_gs_act_out", ACT_NONE) == in_act:
@@ -236,6 +240,35 @@ class _BilinearBwdData(Function):
         return g_gy, g_w, None, None, None
 
 
+class _BwdDataMasked(Function):
+    """u = m * B^T(gy, w) with m = act'(.) through x, the (piecewise-linear) activation output that was the conv's input: the
+    data gradient w.r.t. the previous layer's PRE-activation in one launch, under create_graph (the first-order pass of the R1
+    penalty).  m is constant, so u is bilinear in (gy, w) like B^T itself: d<gg, u>/dgy = B(m gg, w), d<gg, u>/dw =
+    bwd_weight(m gg, gy).  Leaky relu only (a smooth activation would add a term through m)."""
+
+    @staticmethod
+    def forward(ctx, gy, w, x, kind, alpha, act):
+        if act != ACT_LRELU:
+            raise NotImplementedError("_BwdDataMasked: piecewise-linear activations only")
+        ctx.kind, ctx.alpha, ctx.act, ctx.wref = kind, alpha, act, w
+        ctx.save_for_backward(gy, w, x)
+        return kind.bwd_data_mask(gy, w, x.shape, alpha, x, act)
+
+    @staticmethod
+    def backward(ctx, gg):
+        gy, w, x = ctx.saved_tensors
+        t = _ActBwd.apply(gg, x, ctx.act)
+        g_gy = _Bilinear.apply(t, w, ctx.kind, ctx.alpha) if ctx.needs_input_grad[0] else None
+        g_w = None
+        if ctx.needs_input_grad[1]:
+            tgt = _accum_target(ctx.wref)
+            if tgt is not None:   # second-order term of the penalty, added straight into w.grad
+                ctx.kind.bwd_weight(t, gy, ctx.alpha, out=tgt)
+            else:
+                g_w = _BilinearBwdWeight.apply(t, gy, ctx.kind, ctx.alpha).to(w.dtype)
+        return g_gy, g_w, None, None, None, None
+
+
 class _BilinearBwdWeight(Function):
     """gw = alpha * d<gy, B(x,w)>/dw   (linear in x and in gy); fp32 out."""
 
@@ -294,10 +327,13 @@ class _ConvBiasAct(Function):
         def data_grad(gy):
             if not ctx.needs_input_grad[0]:
                 return None
-            prod = _premask_producer(x, ctx.in_act) if hasattr(ctx.kind, "bwd_data_mask") else None
+            prod = _premask_producer(x, ctx.in_act, differentiable=True) if hasattr(ctx.kind, "bwd_data_mask") else None
             if prod is None:
                 return _BilinearBwdData.apply(gy, w, x.shape, ctx.kind, ctx.alpha)
-            gx_ = ctx.kind.bwd_data_mask(gy, w, x.shape, ctx.alpha, x, ctx.in_act)
+            if torch.is_grad_enabled():   # create_graph: the same fusion as a differentiable Function
+                gx_ = _BwdDataMasked.apply(gy, w, x, ctx.kind, ctx.alpha, ctx.in_act)
+            else:
+                gx_ = ctx.kind.bwd_data_mask(gy, w, x.shape, ctx.alpha, x, ctx.in_act)
             prod._gs_premasked = gx_.data_ptr()
             return gx_
 
