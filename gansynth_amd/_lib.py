@@ -31,6 +31,7 @@ SIGNATURES = {
     "gs_conv2d_bwd_data": (I, [P, P, P, I, I, I, I, I, I, I, F, I, I, P, Z, P]),
     "gs_conv2d_fwd_bias_act_norm": (I, [P, P, P, P, P, I, I, I, I, I, I, I, F, I, F, I, I, P, Z, P]),
     "gs_conv2d_transpose_s2_fwd_bias_act_norm": (I, [P, P, P, P, P, I, I, I, I, I, F, I, F, I, I, P, Z, P]),
+    "gs_conv2d_fwd_mask": (I, [P, P, P, I, P, I, I, I, I, I, I, I, F, I, I, P, Z, P]),
     "gs_conv2d_bwd_data_mask": (I, [P, P, P, I, P, I, I, I, I, I, I, I, F, I, I, P, Z, P]),
     "gs_conv2d_bwd_weight": (I, [P, P, P, I, I, I, I, I, I, I, F, I, I, P, Z, P]),
     "gs_conv2d_bwd_weight_bias": (I, [P, P, P, P, I, I, I, I, I, I, I, F, I, I, P, Z, P]),

@@ -560,6 +560,28 @@ extern "C" int gs_conv2d_fwd_bias_act(const void* x, const float* w_hwio, const 
     return conv2d_fwd_impl(x, w_hwio, bias, act, y, n, h, w, ci, co, ksize, stride, alpha, dtype, w_prepared, ws, ws_bytes, stream);
 }
 
+extern "C" int gs_act_bwd(const void* g, const void* y, void* gx, int64_t numel, int act, int dtype, void* stream);
+
+// y = conv2d(x, w) * mask_act'(.) through `mask` (an activation OUTPUT of y's shape): the second-order pass of the R1 penalty runs
+// the discriminator's convs forward on cotangents and multiplies each result by the derivative of the activation that follows
+// the conv; in the epilogue for >= 64 output channels (see gs_conv2d_bwd_data_mask), in place after the conv otherwise
+extern "C" int gs_conv2d_fwd_mask(const void* x, const float* w_hwio, const void* mask, int mask_act, void* y, int n, int h, int w, int ci, int co,
+                                  int ksize, int stride, float alpha, int dtype, int w_prepared, void* ws, size_t ws_bytes, void* stream) {
+    if (int e = check_conv_args(n, h, w, ci, co, ksize, stride, dtype)) return e;
+    GS_CHECK_ARG(mask == nullptr || mask_act == GS_ACT_LRELU || mask_act == GS_ACT_TANH, "conv2d_fwd_mask: bad activation %d", mask_act);
+    hipStream_t st = as_stream(stream);
+    const int hb = h / stride, wb = w / stride;
+    const int mode = stride == 2 ? MODE_S2 : MODE_S1;
+    const bool fused = mask != nullptr && co >= 64 && ksize == 3 && igemm_supported(ci, co, dtype);
+    int rc;
+    if (ksize == 3 && igemm_supported(ci, co, dtype))
+        rc = run_igemm(mode, 0, x, w_hwio, y, n, h, w, ci, co, ci, co, hb, wb, alpha, nullptr, GS_ACT_NONE, dtype, w_prepared, ws, ws_bytes, st, fused ? mask : nullptr, mask_act);
+    else
+        rc = run_direct(mode, ksize, 0, x, w_hwio, y, n, h, w, ci, co, ci, co, hb, wb, alpha, dtype, w_prepared, ws, ws_bytes, st);
+    if (rc || !mask || fused) return rc;
+    return gs_act_bwd(y, mask, y, (int64_t)n * hb * wb * co, mask_act, dtype, stream);
+}
+
 extern "C" int gs_conv2d_fwd_bias_act_norm(const void* x, const float* w_hwio, const float* bias, void* z, void* y, int n, int h, int w, int ci, int co,
                                            int ksize, int stride, float alpha, int act, float eps, int dtype, int w_prepared, void* ws,
                                            size_t ws_bytes, void* stream) {

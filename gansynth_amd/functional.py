@@ -37,6 +37,12 @@ class _ConvKind(object):
     def fwd_bias_act(self, x, w, bias, alpha, act):
         return _K().conv2d_fwd_bias_act(x, w, bias, self.ksize, self.stride, alpha, act)
 
+    def fwd_mask(self, x, w, alpha, mask, mask_act):
+        K = _K()
+        if hasattr(K, "conv2d_fwd_mask"):
+            return K.conv2d_fwd_mask(x, w, self.ksize, self.stride, alpha, mask, mask_act)
+        return K.act_bwd(self.fwd(x, w, alpha), mask, mask_act)
+
     def fwd_bias_act_norm(self, x, w, bias, alpha, act, eps, want_z):
         K = _K()
         if hasattr(K, "conv2d_fwd_bias_act_norm"):   # (z, y) from one call; the norm rides in the conv epilogue where it can
@@ -158,6 +164,7 @@ def weight_slice(w, lo, hi):
 # which tensor is already masked; under create_graph nothing is fused (the pieces must stay differentiable Functions).
 _NO_PREMASK = bool(__import__("os").environ.get("GS_NO_PREMASK"))   # A/B switches for measurements
 _NO_PREMASK_GRAPH = bool(__import__("os").environ.get("GS_NO_PREMASK_GRAPH"))
+_NO_PREMASK_GRAPH2 = bool(__import__("os").environ.get("GS_NO_PREMASK_GRAPH2"))
 
 
 def _premask_producer(x, in_act, differentiable=False):
@@ -252,13 +259,28 @@ class _BwdDataMasked(Function):
             raise NotImplementedError("_BwdDataMasked: piecewise-linear activations only")
         ctx.kind, ctx.alpha, ctx.act, ctx.wref = kind, alpha, act, w
         ctx.save_for_backward(gy, w, x)
+        # The chain of these nodes runs in reverse in the second-order pass: this node's backward hands B(m gg, w) to the node that
+        # produced gy, whose first step is to multiply by ITS mask (its x).  When gy comes straight from such a node and feeds
+        # nothing else (data-gradients-only pass), that multiplication moves into this node's conv epilogue.
+        up = gy.grad_fn
+        ctx._gs_up = up if (isinstance(up, _BwdDataMasked._backward_cls) and not _want_params() and hasattr(kind, "fwd_mask") and not _NO_PREMASK_GRAPH2) else None
+        ctx._gs_gg_premasked = None
         return kind.bwd_data_mask(gy, w, x.shape, alpha, x, act)
 
     @staticmethod
     def backward(ctx, gg):
         gy, w, x = ctx.saved_tensors
-        t = _ActBwd.apply(gg, x, ctx.act)
-        g_gy = _Bilinear.apply(t, w, ctx.kind, ctx.alpha) if ctx.needs_input_grad[0] else None
+        pre, ctx._gs_gg_premasked = ctx._gs_gg_premasked, None
+        if pre is not None and pre == gg.data_ptr() and not torch.is_grad_enabled():
+            t = gg                                   # the producer of gg already applied this node's mask
+        else:
+            t = _ActBwd.apply(gg, x, ctx.act)
+        up = ctx._gs_up
+        if up is not None and ctx.needs_input_grad[0] and not torch.is_grad_enabled():
+            g_gy = ctx.kind.fwd_mask(t, w, ctx.alpha, up.saved_tensors[2], up.act)
+            up._gs_gg_premasked = g_gy.data_ptr()
+        else:
+            g_gy = _Bilinear.apply(t, w, ctx.kind, ctx.alpha) if ctx.needs_input_grad[0] else None
         g_w = None
         if ctx.needs_input_grad[1]:
             tgt = _accum_target(ctx.wref)

@@ -190,6 +190,19 @@ class HipKernels(object):
     def conv2d_fwd(self, x, w, ksize, stride, alpha):
         return self.conv2d_fwd_bias_act(x, w, None, ksize, stride, alpha, _lib.ACT_NONE)
 
+    def conv2d_fwd_mask(self, x, w, ksize, stride, alpha, mask, mask_act):
+        """conv2d_fwd(x, w) * mask_act'(.) through `mask` (an activation output of the result's shape) in one pass."""
+        x, w, mask = _act(x), _f32c(w), _act(mask)
+        n, ci, h, wd = x.shape
+        co = w.shape[3]
+        y = _empty_like_act((n, co, h // stride, wd // stride), x)
+        assert mask.shape == y.shape and mask.dtype == y.dtype
+        nb = self.lib.gs_conv2d_workspace_bytes(_lib.CONV_FWD, n, h, wd, ci, co, ksize, stride, _dt(x))
+        ws, prepared = self._weight_ws(w, ("fwd", ksize, stride, _dt(x)), nb, (_lib.PREP_CONV_FWD, ci, co, ksize, stride, _dt(x)))
+        _lib.check(self.lib.gs_conv2d_fwd_mask(x.data_ptr(), w.data_ptr(), mask.data_ptr(), int(mask_act), y.data_ptr(), n, h, wd, ci, co, ksize, stride,
+                                               float(alpha), _dt(x), prepared, ws.data_ptr(), ws.numel(), _stream()), "gs_conv2d_fwd_mask")
+        return y
+
     def conv2d_fwd_bias_act(self, x, w, bias, ksize, stride, alpha, act):
         x, w = _act(x), _f32c(w)
         n, ci, h, wd = x.shape

@@ -96,6 +96,10 @@ int gs_conv2d_transpose_s2_fwd_bias_act_norm(const void* x, const float* w_hwio,
  * previous layer disappears).  mask NULL = gs_conv2d_bwd_data. */
 int gs_conv2d_bwd_data_mask(const void* gy, const float* w_hwio, const void* mask, int mask_act, void* gx, int n, int h, int w, int ci, int co,
                             int ksize, int stride, float alpha, int dtype, int w_prepared, void* ws, size_t ws_bytes, void* stream);
+/* The same on the forward map: y = conv2d(x, w) * act'(.)|mask with mask of y's shape (the second-order pass of a gradient penalty
+ * runs the convs forward on cotangents; each result meets the derivative of the activation that follows that conv). */
+int gs_conv2d_fwd_mask(const void* x, const float* w_hwio, const void* mask, int mask_act, void* y, int n, int h, int w, int ci, int co,
+                       int ksize, int stride, float alpha, int dtype, int w_prepared, void* ws, size_t ws_bytes, void* stream);
 int gs_conv2d_bwd_weight(const void* x, const void* gy, float* gw_hwio, int n, int h, int w, int ci, int co,
                          int ksize, int stride, float alpha, int accumulate, int dtype, void* ws, size_t ws_bytes, void* stream);
 /* bwd_weight that also returns the bias gradient of the block, gb[co] (+)= sum_{n,h,w} gy (fp32; no alpha): for bf16 3x3 convs

@@ -550,3 +550,17 @@ def test_conv_bias_act_norm_in_one_call(K, E, case, dtype):
     assert z2 is None
     close(y2, yr, rel=tol, name=f"{case} y (no z)")
     assert torch.equal(y, y2) or dtype == torch.bfloat16   # fp32: the same fused arithmetic either way
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", [(2, 32, 32, 8, 128, 3, 1), (2, 64, 64, 8, 64, 3, 1), (2, 64, 128, 8, 64, 3, 2), (2, 32, 64, 8, 128, 3, 2), (2, 2, 32, 8, 64, 1, 1)])
+def test_conv2d_fwd_with_activation_mask(K, E, case, dtype):
+    """gs_conv2d_fwd_mask: conv2d(x, w) * lrelu'(.) through an activation output of the result's shape (epilogue for >= 64 output
+    channels, in place after the conv otherwise)."""
+    n, ci, co, h, w, ks, st = case
+    x = rnd(n, ci, h, w, seed=1).to(dtype).float()
+    wt = rnd(ks, ks, ci, co, seed=2)
+    z = E.bias_act_fwd(rnd(n, co, h // st, w // st, seed=3), None, 1).to(dtype).float()
+    ref = E.act_bwd(E.conv2d_fwd(x, wt, ks, st, 0.1), z, 1)
+    got = K.conv2d_fwd_mask(dev(x, dtype), dev(wt), ks, st, 0.1, dev(z, dtype), 1)
+    close(got, ref, rel=1e-3 if dtype == torch.float32 else 2e-2, name=f"fwd mask {case}")
