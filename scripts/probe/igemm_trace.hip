@@ -4,6 +4,8 @@
 #define GS_IGEMM_TRACE 1
 #include "../../gansynth_amd/csrc/conv_igemm.hip"
 #include "../../gansynth_amd/csrc/core.cpp"
+// (the conv TU calls the norm entry point of another TU for its unfused fallback: never reached by the probe)
+extern "C" int gs_pixel_norm_fwd(const void*, void*, int64_t, int, float, int, void*) { return -3; }
 #include <stdlib.h>
 #include <vector>
 
