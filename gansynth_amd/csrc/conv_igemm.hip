@@ -1020,6 +1020,9 @@ static int num_cus() {
     return g_num_cus;
 }
 
+#ifndef GS_MAX_BLOCKS_PER_CU
+#define GS_MAX_BLOCKS_PER_CU 2
+#endif
 template <typename T, int MODE, int A, int B, int TW, int TG, bool RESIDENT = false, int D = 2, bool NORM = false>
 static int launch_igemm(ConvP p, hipStream_t st) {
     constexpr int NP = 128 * B;
@@ -1056,7 +1059,7 @@ static int launch_igemm(ConvP p, hipStream_t st) {
     }
     // resident blocks per CU: LDS-limited, and at most 2 (accumulator-heavy kernels hold 1-2 waves per SIMD)
     int per_cu = (int)((160 * 1024) / lds);
-    if (per_cu > 2) per_cu = 2;
+    if (per_cu > GS_MAX_BLOCKS_PER_CU) per_cu = GS_MAX_BLOCKS_PER_CU;
     if (per_cu < 1) per_cu = 1;
     const long total = (long)p.nsp * p.noct;
     long grid = (long)per_cu * num_cus();
