@@ -38,8 +38,8 @@ SIGNATURES = {
     "gs_conv2d_bwd_weight_bias_partial": (I, [P, P, P, P, I, I, I, I, I, I, I, F, I, I, P, Z, P, P]),
     "gs_conv2d_transpose_s2_bwd_weight_partial": (I, [P, P, P, I, I, I, I, I, F, I, I, P, Z, P, P]),
     "gs_wgrad_reduce_batch": (I, [P, I, P]),
-    "gs_conv2d_bwd_weight_bias_multi": (I, [P, P, I, ctypes.c_uint, P, P, I, I, I, I, I, I, I, F, I, I, P, Z, P, P]),
-    "gs_conv2d_transpose_s2_bwd_weight_multi": (I, [P, P, I, P, I, I, I, I, I, F, I, I, P, Z, P, P]),
+    "gs_conv2d_bwd_weight_bias_multi": (I, [P, P, P, I, ctypes.c_uint, P, P, I, I, I, I, I, I, I, F, I, I, P, Z, P, P]),
+    "gs_conv2d_transpose_s2_bwd_weight_multi": (I, [P, P, P, I, P, I, I, I, I, I, F, I, I, P, Z, P, P]),
     "gs_conv2d_transpose_s2_workspace_bytes": (Z, [I, I, I, I, I, I, I]),
     "gs_conv2d_transpose_s2_fwd": (I, [P, P, P, I, I, I, I, I, F, I, I, P, Z, P]),
     "gs_conv2d_transpose_s2_fwd_bias_act": (I, [P, P, P, P, I, I, I, I, I, F, I, I, I, P, Z, P]),

@@ -630,21 +630,26 @@ extern "C" size_t gs_channel_sum_workspace_bytes(int64_t p, int c);
 extern "C" int gs_channel_sum(const void* g, float* out, int64_t p, int c, int accumulate, int dtype, void* ws, size_t ws_bytes, void* stream);
 
 // the (x, gy) pairs of one launch, as the kernels want them; for the transposed conv the roles of the two sides swap
-static WgradSrcs make_srcs(const void* const* xs, const void* const* gys, int nsrc, int n_per, unsigned bias_mask, bool swap) {
+static WgradSrcs make_srcs(const void* const* xs, const void* const* gys, int nsrc, int n_per, const int* ns, unsigned bias_mask, bool swap, int* total) {
     WgradSrcs s;
     memset(&s, 0, sizeof(s));
-    for (int i = 0; i < nsrc && i < GS_WGRAD_MAX_SRC; ++i) {
-        s.x[i] = swap ? gys[i] : xs[i];
-        s.gy[i] = swap ? xs[i] : gys[i];
+    int end = 0;
+    for (int i = 0; i < GS_WGRAD_MAX_SRC; ++i) {
+        if (i < nsrc) {
+            s.x[i] = swap ? gys[i] : xs[i];
+            s.gy[i] = swap ? xs[i] : gys[i];
+            end += ns ? ns[i] : n_per;
+        }
+        s.n_end[i] = end;
     }
-    s.n_per = n_per;
     s.bias_mask = bias_mask;
+    *total = end;
     return s;
 }
 
-extern "C" int gs_conv2d_bwd_weight_bias_multi(const void* const* xs, const void* const* gys, int nsrc, unsigned bias_mask, float* gw_hwio, float* gb,
-                                               int n, int h, int w, int ci, int co, int ksize, int stride, float alpha, int accumulate, int dtype,
-                                               void* ws, size_t ws_bytes, GsWgradReduce* pending, void* stream) {
+extern "C" int gs_conv2d_bwd_weight_bias_multi(const void* const* xs, const void* const* gys, const int* ns, int nsrc, unsigned bias_mask, float* gw_hwio,
+                                               float* gb, int n, int h, int w, int ci, int co, int ksize, int stride, float alpha, int accumulate,
+                                               int dtype, void* ws, size_t ws_bytes, GsWgradReduce* pending, void* stream) {
     if (int e = check_conv_args(n, h, w, ci, co, ksize, stride, dtype)) return e;
     GS_CHECK_ARG(xs && gys && nsrc >= 1 && nsrc <= GS_WGRAD_MAX_SRC, "conv2d_bwd_weight_bias_multi: %d sources (1..%d)", nsrc, GS_WGRAD_MAX_SRC);
     for (int i = 0; i < nsrc; ++i) GS_CHECK_ARG(xs[i] && gys[i], "conv2d_bwd_weight_bias_multi: null source %d", i);
@@ -657,8 +662,8 @@ extern "C" int gs_conv2d_bwd_weight_bias_multi(const void* const* xs, const void
     if (nsrc > 1 && !(mfma && (!gb || wgrad_mfma_has_bias(dtype)))) {
         // shapes without the multi-source kernels: one call per source (the first applies `accumulate`, the rest add)
         for (int i = 0; i < nsrc; ++i) {
-            const int rc = gs_conv2d_bwd_weight_bias_multi(xs + i, gys + i, 1, 1u, gw_hwio, ((bias_mask >> i) & 1u) ? gb : nullptr, n, h, w, ci, co, ksize, stride,
-                                                           alpha, i == 0 ? accumulate : 1, dtype, ws, ws_bytes, nullptr, stream);
+            const int rc = gs_conv2d_bwd_weight_bias_multi(xs + i, gys + i, nullptr, 1, 1u, gw_hwio, ((bias_mask >> i) & 1u) ? gb : nullptr, ns ? ns[i] : n, h, w, ci, co,
+                                                           ksize, stride, alpha, i == 0 ? accumulate : 1, dtype, ws, ws_bytes, nullptr, stream);
             if (rc) return rc;
         }
         return 0;
@@ -667,21 +672,23 @@ extern "C" int gs_conv2d_bwd_weight_bias_multi(const void* const* xs, const void
     // the channel-sum fallback of the bias gradient reuses ws: such calls cannot leave their partials pending
     GsWgradReduce* defer = (bias_mask && !fused_bias) ? nullptr : pending;
     int rc;
+    const int n0 = ns ? ns[0] : n;   // (the single-source paths below)
     if (mfma) {
-        const WgradSrcs srcs = make_srcs(xs, gys, nsrc, n, bias_mask, false);
-        rc = run_wgrad_mfma(mode, srcs, nsrc, gw_hwio, fused_bias ? gb : nullptr, n * nsrc, h, w, ci, co, hb, wb, alpha, 0, accumulate, dtype, ws, ws_bytes, st, defer);
+        int total = 0;
+        const WgradSrcs srcs = make_srcs(xs, gys, nsrc, n, ns, bias_mask, false, &total);
+        rc = run_wgrad_mfma(mode, srcs, nsrc, gw_hwio, fused_bias ? gb : nullptr, total, h, w, ci, co, hb, wb, alpha, 0, accumulate, dtype, ws, ws_bytes, st, defer);
     } else {
-        rc = run_wgrad_direct(mode, ksize, xs[0], gys[0], gw_hwio, n, h, w, ci, co, hb, wb, alpha, 0, accumulate, dtype, ws, ws_bytes, st, defer);
+        rc = run_wgrad_direct(mode, ksize, xs[0], gys[0], gw_hwio, n0, h, w, ci, co, hb, wb, alpha, 0, accumulate, dtype, ws, ws_bytes, st, defer);
     }
     if (rc || !bias_mask || fused_bias) return rc;
     // shapes without the fused path: the plain channel sum (stream-ordered after the kernels above, same workspace)
-    return gs_channel_sum(gys[0], gb, (int64_t)n * hb * wb, co, accumulate, dtype, ws, ws_bytes, stream);
+    return gs_channel_sum(gys[0], gb, (int64_t)n0 * hb * wb, co, accumulate, dtype, ws, ws_bytes, stream);
 }
 
 extern "C" int gs_conv2d_bwd_weight_bias_partial(const void* x, const void* gy, float* gw_hwio, float* gb, int n, int h, int w, int ci, int co,
                                                  int ksize, int stride, float alpha, int accumulate, int dtype, void* ws, size_t ws_bytes,
                                                  GsWgradReduce* pending, void* stream) {
-    return gs_conv2d_bwd_weight_bias_multi(&x, &gy, 1, 1u, gw_hwio, gb, n, h, w, ci, co, ksize, stride, alpha, accumulate, dtype, ws, ws_bytes, pending, stream);
+    return gs_conv2d_bwd_weight_bias_multi(&x, &gy, nullptr, 1, 1u, gw_hwio, gb, n, h, w, ci, co, ksize, stride, alpha, accumulate, dtype, ws, ws_bytes, pending, stream);
 }
 
 extern "C" int gs_conv2d_bwd_weight_bias(const void* x, const void* gy, float* gw_hwio, float* gb, int n, int h, int w, int ci, int co,
@@ -783,8 +790,8 @@ extern "C" int gs_conv2d_transpose_s2_bwd_data(const void* gy, const float* w_hw
     return run_direct(MODE_S2, 3, 2, gy, w_hwio, gx, n, 2 * h, 2 * w, co, ci, ci, co, h, w, alpha, dtype, w_prepared, ws, ws_bytes, st);
 }
 
-extern "C" int gs_conv2d_transpose_s2_bwd_weight_multi(const void* const* xs, const void* const* gys, int nsrc, float* gw_hwio, int n, int h, int w,
-                                                       int ci, int co, float alpha, int accumulate, int dtype, void* ws, size_t ws_bytes,
+extern "C" int gs_conv2d_transpose_s2_bwd_weight_multi(const void* const* xs, const void* const* gys, const int* ns, int nsrc, float* gw_hwio, int n, int h,
+                                                       int w, int ci, int co, float alpha, int accumulate, int dtype, void* ws, size_t ws_bytes,
                                                        GsWgradReduce* pending, void* stream) {
     if (int e = check_conv_args(n, 2 * h, 2 * w, co, ci, 3, 2, dtype)) return e;
     GS_CHECK_ARG(xs && gys && nsrc >= 1 && nsrc <= GS_WGRAD_MAX_SRC, "conv2d_transpose_s2_bwd_weight_multi: %d sources (1..%d)", nsrc, GS_WGRAD_MAX_SRC);
@@ -793,11 +800,12 @@ extern "C" int gs_conv2d_transpose_s2_bwd_weight_multi(const void* const* xs, co
     if (pending) memset(pending, 0, sizeof(*pending));
     // gw[k][ci][co] = sum x[i][ci] * gy[2i+k][co]: stride-2 wgrad with (input side = gy, output side = x), transposed
     if (wgrad_mfma_supported(co, ci, dtype)) {
-        const WgradSrcs srcs = make_srcs(xs, gys, nsrc, n, 0u, true);
-        return run_wgrad_mfma(MODE_S2, srcs, nsrc, gw_hwio, nullptr, n * nsrc, 2 * h, 2 * w, co, ci, h, w, alpha, 1, accumulate, dtype, ws, ws_bytes, st, pending);
+        int total = 0;
+        const WgradSrcs srcs = make_srcs(xs, gys, nsrc, n, ns, 0u, true, &total);
+        return run_wgrad_mfma(MODE_S2, srcs, nsrc, gw_hwio, nullptr, total, 2 * h, 2 * w, co, ci, h, w, alpha, 1, accumulate, dtype, ws, ws_bytes, st, pending);
     }
     for (int i = 0; i < nsrc; ++i) {   // (direct kernels: one call per source)
-        const int rc = run_wgrad_direct(MODE_S2, 3, gys[i], xs[i], gw_hwio, n, 2 * h, 2 * w, co, ci, h, w, alpha, 1, i == 0 ? accumulate : 1, dtype, ws, ws_bytes, st,
+        const int rc = run_wgrad_direct(MODE_S2, 3, gys[i], xs[i], gw_hwio, ns ? ns[i] : n, 2 * h, 2 * w, co, ci, h, w, alpha, 1, i == 0 ? accumulate : 1, dtype, ws, ws_bytes, st,
                                         nsrc == 1 ? pending : nullptr);
         if (rc) return rc;
     }
@@ -807,7 +815,7 @@ extern "C" int gs_conv2d_transpose_s2_bwd_weight_multi(const void* const* xs, co
 extern "C" int gs_conv2d_transpose_s2_bwd_weight_partial(const void* x, const void* gy, float* gw_hwio, int n, int h, int w, int ci,
                                                          int co, float alpha, int accumulate, int dtype, void* ws, size_t ws_bytes,
                                                          GsWgradReduce* pending, void* stream) {
-    return gs_conv2d_transpose_s2_bwd_weight_multi(&x, &gy, 1, gw_hwio, n, h, w, ci, co, alpha, accumulate, dtype, ws, ws_bytes, pending, stream);
+    return gs_conv2d_transpose_s2_bwd_weight_multi(&x, &gy, nullptr, 1, gw_hwio, n, h, w, ci, co, alpha, accumulate, dtype, ws, ws_bytes, pending, stream);
 }
 
 extern "C" int gs_conv2d_transpose_s2_bwd_weight(const void* x, const void* gy, float* gw_hwio, int n, int h, int w, int ci,

@@ -624,7 +624,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
         const int tile_x = b % tiles_x;
         b /= tiles_x;
         const int tile_y = b % tiles_y;
-        const int nn = b / tiles_y, src = nn / srcs.n_per, n = nn - src * srcs.n_per;
+        int n;
+        const int src = wgrad_source(srcs, b / tiles_y, n);
         const T* __restrict__ x = reinterpret_cast<const T*>(srcs.x[src]);
         const T* __restrict__ gy = reinterpret_cast<const T*>(srcs.gy[src]);
         const int by = tile_y * TH, bx = tile_x * TW;
@@ -750,7 +751,8 @@ __global__ __launch_bounds__(192) void conv_wgrad_bf16_kernel(
         const int tile_x = b % tiles_x;
         b /= tiles_x;
         const int tile_y = b % tiles_y;
-        const int nn = b / tiles_y, src = nn / srcs.n_per, n = nn - src * srcs.n_per;
+        int n;
+        const int src = wgrad_source(srcs, b / tiles_y, n);
         const bf16_t* __restrict__ x = reinterpret_cast<const bf16_t*>(srcs.x[src]);
         const bf16_t* __restrict__ gy = reinterpret_cast<const bf16_t*>(srcs.gy[src]);
         const bool do_bias = bias_wave && ((srcs.bias_mask >> src) & 1u);
@@ -892,8 +894,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_2x2_kernel(
         const int tile_x = b % tiles_x;
         b /= tiles_x;
         const int tile_y = b % tiles_y;
-        const int nn = b / tiles_y, src = nn / srcs.n_per;
-        n_t = nn - src * srcs.n_per;
+        const int src = wgrad_source(srcs, b / tiles_y, n_t);
         bias_next = bias_wave && ((srcs.bias_mask >> src) & 1u);
         by_t = tile_y * TH;
         bx_t = tile_x * TW;
@@ -1207,8 +1208,8 @@ size_t wgrad_mfma_bytes(int mode, int dtype, int N, int Hb, int Wb, int IC, int 
 int run_wgrad_mfma(int mode, const WgradSrcs& srcs, int nsrc, float* gw, float* gb, int N, int Hi, int Wi, int IC, int OC, int Hb,
                    int Wb, float alpha, int transpose, int accumulate, int dtype, void* ws, size_t ws_bytes, hipStream_t st,
                    GsWgradReduce* defer) {
-    // N = images of ALL sources (nsrc x srcs.n_per)
-    if (nsrc < 1 || nsrc > GS_WGRAD_MAX_SRC || srcs.n_per * nsrc != N) return fail(GS_ERR_ARG, "conv wgrad: %d sources of %d images for N=%d", nsrc, srcs.n_per, N);
+    // N = images of ALL sources
+    if (nsrc < 1 || nsrc > GS_WGRAD_MAX_SRC || srcs.n_end[nsrc - 1] != N) return fail(GS_ERR_ARG, "conv wgrad: %d sources ending at image %d for N=%d", nsrc, srcs.n_end[nsrc > 0 ? nsrc - 1 : 0], N);
     int tw, tiles_x, tiles_y, ntiles, nslices;
     wgrad_geometry(mode, dtype, N, Hb, Wb, IC, OC, &tw, &tiles_x, &tiles_y, &ntiles, &nslices);
     if (gb && !wgrad_mfma_has_bias(dtype)) return fail(GS_ERR_UNSUPPORTED, "conv wgrad: fused bias gradient needs the bf16 kernels");

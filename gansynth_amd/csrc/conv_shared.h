@@ -10,14 +10,19 @@ enum { MODE_S1 = 0, MODE_S2 = 1, MODE_T2 = 2 };
 static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 // Several (x, gy) pairs of ONE layer -- the real and the fake discriminator pass, the second-order contribution -- are contracted
-// by one launch: the images of all sources form one list (image n -> source n / n_per), so the layer costs one set of block
+// by one launch: the images of all sources form one list (source s owns images n_end[s-1] .. n_end[s] - 1), so the layer costs one set of block
 // partials and one slice reduction instead of one per pair.  bias_mask: which sources contribute to the bias gradient.
 struct WgradSrcs {
     const void* x[GS_WGRAD_MAX_SRC];
     const void* gy[GS_WGRAD_MAX_SRC];
-    int n_per;
+    int n_end[GS_WGRAD_MAX_SRC];   // cumulative image counts (unused entries = the total)
     unsigned bias_mask;
 };
+__device__ __forceinline__ int wgrad_source(const WgradSrcs& s, int nn, int& n_local) {
+    const int src = (nn >= s.n_end[0]) + (nn >= s.n_end[1]) + (nn >= s.n_end[2]);
+    n_local = nn - (src ? s.n_end[src - 1] : 0);
+    return src;
+}
 
 // ------------------------------------------------------------------------------ weight prep
 // Re-lays the fp32 HWIO master weight into the kernel operand Wp[tap][OCk][ICk] (ICk contiguous,

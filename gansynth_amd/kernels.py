@@ -158,7 +158,7 @@ class HipKernels(object):
         for key, grp in groups.items():
             kind, ksize, stride, alpha = key[0], key[2], key[3], key[4]
             out, bias, src = grp["out"], grp["bias"], grp["src"]
-            n, ci, h, wd = src[0][0].shape
+            _, ci, h, wd = src[0][0].shape   # (the pairs of a layer may differ in their image counts)
             co = src[0][1].shape[1]
             dt = _dt(src[0][0])
             for i in range(0, len(src), _lib.WGRAD_MAX_SOURCES):
@@ -166,16 +166,18 @@ class HipKernels(object):
                 k = len(part)
                 xs = (ctypes.c_void_p * k)(*[p[0].data_ptr() for p in part])
                 gys = (ctypes.c_void_p * k)(*[p[1].data_ptr() for p in part])
+                ns = (ctypes.c_int * k)(*[p[0].shape[0] for p in part])
+                n, ntot = part[0][0].shape[0], sum(p[0].shape[0] for p in part)
                 mask = sum(1 << j for j, p in enumerate(part) if p[2])
                 d = _lib.GsWgradReduce()
                 if kind == "conv":
-                    ws = _ws(self.lib.gs_conv2d_workspace_bytes(_lib.CONV_BWD_WEIGHT, n * k, h, wd, ci, co, ksize, stride, dt), out.device)
-                    _lib.check(self.lib.gs_conv2d_bwd_weight_bias_multi(xs, gys, k, mask, out.data_ptr(), None if (bias is None or not mask) else bias.data_ptr(),
+                    ws = _ws(self.lib.gs_conv2d_workspace_bytes(_lib.CONV_BWD_WEIGHT, ntot, h, wd, ci, co, ksize, stride, dt), out.device)
+                    _lib.check(self.lib.gs_conv2d_bwd_weight_bias_multi(xs, gys, ns, k, mask, out.data_ptr(), None if (bias is None or not mask) else bias.data_ptr(),
                                                                         n, h, wd, ci, co, ksize, stride, float(alpha), 1, dt, ws.data_ptr(), ws.numel(),
                                                                         ctypes.addressof(d), _stream()), "gs_conv2d_bwd_weight_bias_multi")
                 else:
-                    ws = _ws(self.lib.gs_conv2d_transpose_s2_workspace_bytes(_lib.CONV_BWD_WEIGHT, n * k, h, wd, ci, co, dt), out.device)
-                    _lib.check(self.lib.gs_conv2d_transpose_s2_bwd_weight_multi(xs, gys, k, out.data_ptr(), n, h, wd, ci, co, float(alpha), 1, dt,
+                    ws = _ws(self.lib.gs_conv2d_transpose_s2_workspace_bytes(_lib.CONV_BWD_WEIGHT, ntot, h, wd, ci, co, dt), out.device)
+                    _lib.check(self.lib.gs_conv2d_transpose_s2_bwd_weight_multi(xs, gys, ns, k, out.data_ptr(), n, h, wd, ci, co, float(alpha), 1, dt,
                                                                                 ws.data_ptr(), ws.numel(), ctypes.addressof(d), _stream()),
                                "gs_conv2d_transpose_s2_bwd_weight_multi")
                 if d.nslices > 0:
@@ -283,7 +285,7 @@ class HipKernels(object):
         if bias_out is not None:
             assert out is not None and bias_out.dtype == torch.float32 and bias_out.is_contiguous()
         if out is not None and self._pending is not None:
-            self._defer_wgrad(("conv", out.data_ptr(), ksize, stride, float(alpha), tuple(x.shape), tuple(gy.shape), x.dtype), x, gy, out, bias_out)
+            self._defer_wgrad(("conv", out.data_ptr(), ksize, stride, float(alpha), tuple(x.shape[1:]), tuple(gy.shape[1:]), x.dtype), x, gy, out, bias_out)
             return gw
         nb = self.lib.gs_conv2d_workspace_bytes(_lib.CONV_BWD_WEIGHT, n, h, wd, ci, co, ksize, stride, _dt(x))
         ws = _ws(nb, x.device)
@@ -329,7 +331,7 @@ class HipKernels(object):
         co = gy.shape[1]
         gw = torch.empty((3, 3, ci, co), dtype=torch.float32, device=x.device) if out is None else out
         if out is not None and self._pending is not None:
-            self._defer_wgrad(("convT", out.data_ptr(), 3, 2, float(alpha), tuple(x.shape), tuple(gy.shape), x.dtype), x, gy, out, None)
+            self._defer_wgrad(("convT", out.data_ptr(), 3, 2, float(alpha), tuple(x.shape[1:]), tuple(gy.shape[1:]), x.dtype), x, gy, out, None)
             return gw
         nb = self.lib.gs_conv2d_transpose_s2_workspace_bytes(_lib.CONV_BWD_WEIGHT, n, h, wd, ci, co, _dt(x))
         ws = _ws(nb, x.device)

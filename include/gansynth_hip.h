@@ -149,16 +149,16 @@ int gs_conv2d_transpose_s2_bwd_weight_partial(const void* x, const void* gy, flo
                                               GsWgradReduce* pending, void* stream);
 int gs_wgrad_reduce_batch(const GsWgradReduce* pending, int n, void* stream);   /* `pending`: host array */
 /* Several (x, gy) pairs of ONE layer in one launch: gw (+)= sum_s bwd_weight(xs[s], gys[s]) -- the real and the fake pass of the
- * discriminator, the second-order contribution of a gradient penalty.  All pairs share (n, h, w, ci, co); the layer then costs
- * one set of block partials and one slice reduction instead of one per pair.  nsrc <= GS_WGRAD_MAX_SOURCES; bit s of bias_mask
+ * discriminator, the second-order contribution of a gradient penalty.  All pairs share (h, w, ci, co); pair s has ns[s] images
+ * (ns NULL: n each).  The layer then costs one set of block partials and one slice reduction instead of one per pair.  nsrc <= GS_WGRAD_MAX_SOURCES; bit s of bias_mask
  * says whether pair s contributes to gb (ignored when gb is NULL).  `pending` as above (NULL = reduce at once); ws sized by
- * gs_conv2d_workspace_bytes(GS_CONV_BWD_WEIGHT, n * nsrc, ...) / gs_conv2d_transpose_s2_workspace_bytes(.., n * nsrc, ..). */
+ * gs_conv2d_workspace_bytes(GS_CONV_BWD_WEIGHT, total images, ...) / gs_conv2d_transpose_s2_workspace_bytes(.., total images, ..). */
 #define GS_WGRAD_MAX_SOURCES 4
-int gs_conv2d_bwd_weight_bias_multi(const void* const* xs, const void* const* gys, int nsrc, unsigned bias_mask, float* gw_hwio, float* gb,
-                                    int n, int h, int w, int ci, int co, int ksize, int stride, float alpha, int accumulate, int dtype,
-                                    void* ws, size_t ws_bytes, GsWgradReduce* pending, void* stream);
-int gs_conv2d_transpose_s2_bwd_weight_multi(const void* const* xs, const void* const* gys, int nsrc, float* gw_hwio, int n, int h, int w,
-                                            int ci, int co, float alpha, int accumulate, int dtype, void* ws, size_t ws_bytes,
+int gs_conv2d_bwd_weight_bias_multi(const void* const* xs, const void* const* gys, const int* ns, int nsrc, unsigned bias_mask, float* gw_hwio,
+                                    float* gb, int n, int h, int w, int ci, int co, int ksize, int stride, float alpha, int accumulate,
+                                    int dtype, void* ws, size_t ws_bytes, GsWgradReduce* pending, void* stream);
+int gs_conv2d_transpose_s2_bwd_weight_multi(const void* const* xs, const void* const* gys, const int* ns, int nsrc, float* gw_hwio, int n, int h,
+                                            int w, int ci, int co, float alpha, int accumulate, int dtype, void* ws, size_t ws_bytes,
                                             GsWgradReduce* pending, void* stream);
 
 /* Refreshing many prepared weight operands in one launch (after an optimizer step: ~60 conv maps, one kernel instead of
