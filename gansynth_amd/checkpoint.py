@@ -1,0 +1,122 @@
+"""Checkpoints keyed by the reference's TensorFlow variable names.
+
+A `tf.train.Saver` checkpoint of the reference graph (models.py:123-130) holds, by name:
+  * every trainable variable under its scope name, e.g. `generator/conv_block_4x32/upscale_conv/weight`, conv filters in
+    HWIO layout, dense weights [in, out] (ops.py:149-180) -- exactly how variables.VariableStore keeps them;
+  * the Adam slots `<variable>/Adam` (m) and `<variable>/Adam_1` (v) (tf.train.AdamOptimizer slot names);
+  * the non-slot accumulators of the two optimizers: `beta1_power`, `beta2_power` for the generator's (created first,
+    models.py:81), `beta1_power_1`, `beta2_power_1` for the discriminator's (models.py:86);
+  * `global_step` (int64).
+The TF tensor-bundle container cannot be written without TensorFlow; the same names, shapes and layouts are stored in a
+`.safetensors` file, so that weights can be exchanged with a real TF run by a ten-line converter on a machine that has
+both (tf.train.load_checkpoint(...).get_tensor(name) <-> this dict).
+"""
+import glob
+import os
+import re
+
+import torch
+
+try:
+    from safetensors.torch import load_file, save_file
+except ImportError:   # pragma: no cover
+    load_file = save_file = None
+
+
+def state_dict(model):
+    """name -> tensor (CPU) for everything a tf.train.Saver would write for `model` (a models.GANSynth after _build)."""
+    if model.g_params is None:
+        raise RuntimeError("checkpoint: the model has no variables yet (run a step or call _build first)")
+    if hasattr(model, "synchronize"):
+        model.synchronize()
+    hp = model.hyper_params
+    out = {}
+    for params, suffix, b1, b2 in ((model.g_params, "", hp.generator_beta1, hp.generator_beta2),
+                                   (model.d_params, "_1", hp.discriminator_beta1, hp.discriminator_beta2)):
+        for name, p in params.named.items():
+            n = p.numel()
+            off = (p.data.data_ptr() - params.flat.data_ptr()) // 4
+            out[name] = p.data.detach().cpu().clone()
+            out[name + "/Adam"] = params.m[off:off + n].view(p.shape).detach().cpu().clone()
+            out[name + "/Adam_1"] = params.v[off:off + n].view(p.shape).detach().cpu().clone()
+        # tf.train.AdamOptimizer keeps beta^t as variables, multiplied once per apply_gradients (t = params.t here)
+        out["beta1_power" + suffix] = torch.tensor(float(b1) ** (params.t + 1), dtype=torch.float32)
+        out["beta2_power" + suffix] = torch.tensor(float(b2) ** (params.t + 1), dtype=torch.float32)
+        out["optimizer_steps" + suffix] = torch.tensor(params.t, dtype=torch.int64)   # (not a TF variable: the exponent itself)
+    out["global_step"] = torch.tensor(model.global_step, dtype=torch.int64)
+    return out
+
+
+def load_state_dict(model, state, strict=True):
+    if model.g_params is None:
+        raise RuntimeError("checkpoint: build the model's variables first (GANSynth._build)")
+    if hasattr(model, "synchronize"):
+        model.synchronize()
+    missing = []
+    for params, suffix in ((model.g_params, ""), (model.d_params, "_1")):
+        for name, p in params.named.items():
+            n = p.numel()
+            off = (p.data.data_ptr() - params.flat.data_ptr()) // 4
+            for key, dst in ((name, p.data), (name + "/Adam", params.m[off:off + n].view(p.shape)), (name + "/Adam_1", params.v[off:off + n].view(p.shape))):
+                if key in state:
+                    src = state[key]
+                    if tuple(src.shape) != tuple(dst.shape):
+                        raise ValueError(f"checkpoint: {key} has shape {tuple(src.shape)}, the variable has {tuple(dst.shape)}")
+                    dst.copy_(src.to(dst.device, dst.dtype))
+                else:
+                    missing.append(key)
+        key = "optimizer_steps" + suffix
+        if key in state:
+            params.t = int(state[key])
+        else:
+            missing.append(key)
+    if "global_step" in state:
+        model.global_step = int(state["global_step"])
+    else:
+        missing.append("global_step")
+    if strict and missing:
+        raise KeyError(f"checkpoint: {len(missing)} entries missing, e.g. {missing[:4]}")
+    from . import kernels
+    K = kernels.get()
+    if hasattr(K, "invalidate_weights"):   # the conv kernels' re-laid weight operands are stale now; captured graphs expect fresh ones
+        K.invalidate_weights()
+        K.refresh_weights()
+    return missing
+
+
+def save(model, model_dir, keep=10):
+    """`model_dir/model.ckpt-<global_step>.safetensors` (+ a `checkpoint` text file naming the latest, like tf.train.Saver);
+    keeps the newest `keep` files (max_to_keep=10, models.py:126)."""
+    if save_file is None:
+        raise RuntimeError("checkpoint: the safetensors package is not importable")
+    os.makedirs(model_dir, exist_ok=True)
+    path = os.path.join(model_dir, f"model.ckpt-{model.global_step}.safetensors")
+    save_file({k: v.contiguous() for k, v in state_dict(model).items()}, path)
+    with open(os.path.join(model_dir, "checkpoint"), "w") as f:
+        f.write(f'model_checkpoint_path: "{os.path.basename(path)}"\n')
+    old = sorted(glob.glob(os.path.join(model_dir, "model.ckpt-*.safetensors")), key=lambda p: int(re.findall(r"ckpt-(\d+)", p)[-1]))
+    for p in old[:-keep] if keep else []:
+        os.remove(p)
+    return path
+
+
+def latest(model_dir):
+    marker = os.path.join(model_dir, "checkpoint")
+    if os.path.exists(marker):
+        m = re.search(r'model_checkpoint_path: "([^"]+)"', open(marker).read())
+        if m and os.path.exists(os.path.join(model_dir, m.group(1))):
+            return os.path.join(model_dir, m.group(1))
+    files = glob.glob(os.path.join(model_dir, "model.ckpt-*.safetensors"))
+    return max(files, key=lambda p: int(re.findall(r"ckpt-(\d+)", p)[-1])) if files else None
+
+
+def restore(model, model_dir_or_file, strict=True):
+    """Load the latest checkpoint of a directory (or a given file); returns its path, or None when there is none
+    (a fresh run, like tf.train.MonitoredSession with an empty checkpoint_dir)."""
+    if load_file is None:
+        raise RuntimeError("checkpoint: the safetensors package is not importable")
+    path = model_dir_or_file if os.path.isfile(model_dir_or_file) else latest(model_dir_or_file)
+    if path is None:
+        return None
+    load_state_dict(model, load_file(path), strict=strict)
+    return path

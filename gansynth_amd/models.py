@@ -86,6 +86,7 @@ class GANSynth(object):
         # fully grown regime (no fade coefficient); the optimizer update and the all-reduce stay outside the graph.
         self.use_graphs = bool(use_graphs)
         self._graphs = {}
+        self._restore_from, self.restored_from = None, None
         # Pipelined iteration (opt-in: pipeline=True / GS_PIPELINE=1; train_step with graphs): every run is captured as two
         # graphs (own-network part A, the rest B) so that the gradient all-reduce of one network can run on a side stream under
         # part A of the other network's run, which needs none of it.  Off by default: on this ROCm stack a cross-stream event
@@ -122,6 +123,10 @@ class GANSynth(object):
     def _ensure_built(self, latents, labels):
         if self.g_params is None:
             self._build(latents, labels)
+            if self._restore_from is not None:   # train(model_dir=...): resume like tf.train.MonitoredSession(checkpoint_dir=...)
+                from . import checkpoint
+                self.restored_from = checkpoint.restore(self, self._restore_from)
+                self._restore_from = None
 
     # -------------------------------------------------------------------------- inputs
     def _real_batch(self):
@@ -403,13 +408,30 @@ class GANSynth(object):
         g_loss = self.generator_step(g_latents, g_labels)
         return d_loss, g_loss
 
-    def train(self, total_steps, log_tensor_steps=100, log=print):
-        """models.py:110-194 without the TF hooks: loop until global_step reaches total_steps."""
+    def train(self, total_steps, log_tensor_steps=100, log=print, model_dir=None, save_checkpoint_steps=1000):
+        """models.py:110-194 without the TF summary hooks: resume from the latest checkpoint of `model_dir` (CheckpointSaverHook /
+        MonitoredSession semantics), alternate D and G runs until global_step reaches total_steps (StopAtStepHook) or the input
+        runs dry (OutOfRangeError, :193), log the two losses every `log_tensor_steps` (LoggingTensorHook), checkpoint every
+        `save_checkpoint_steps` and at the end."""
+        from . import checkpoint
+        if model_dir is not None and self.g_params is None:
+            self._restore_from = model_dir
+        elif model_dir is not None:
+            self.restored_from = checkpoint.restore(self, model_dir)
+        last_saved = None
         while self.global_step < total_steps:
-            d_loss, g_loss = self.train_step()
+            try:
+                d_loss, g_loss = self.train_step()
+            except StopIteration:
+                break
             if log is not None and self.global_step % log_tensor_steps == 0:
                 log(f"global_step = {self.global_step}, generator_loss = {float(g_loss):.6f}, "
                     f"discriminator_loss = {float(d_loss):.6f}")
+            if model_dir is not None and save_checkpoint_steps and self.global_step % save_checkpoint_steps == 0:
+                last_saved = self.global_step
+                checkpoint.save(self, model_dir)
+        if model_dir is not None and self.g_params is not None and last_saved != self.global_step:
+            checkpoint.save(self, model_dir)
 
     def generate(self, latents, labels):
         """models.py:232-250: fake waveforms for a batch."""

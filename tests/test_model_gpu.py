@@ -263,3 +263,63 @@ def test_pipelined_train_step_equals_sequential(gpu_store):
     assert out["pipelined"][0] == out["pipelined+side"][0]
     assert torch.equal(out["pipelined"][1], out["pipelined+side"][1]) and torch.equal(out["pipelined"][2], out["pipelined+side"][2])
     assert model.global_step == 4
+
+
+def test_training_driver_visits_every_growing_regime_and_resumes(gpu_store, tmp_path):
+    """BASELINE.json config 5 at reduced size: GANSynth.train with the reference's loop semantics (models.py:110-194) -- generated
+    notes -> HIP spectral front end -> real images, growing_level = global_step / growing_steps walking from the 2x16 stage through
+    every fade-in to the fully grown networks (where the step switches to hipGraph replay), checkpoints under the TF variable
+    names, and a second trainer that resumes from them."""
+    from gansynth_amd import checkpoint, variables
+    from gansynth_amd.dataset import synthetic_nsynth_input_fn
+    from gansynth_amd.models import GANSynth
+    from gansynth_amd.networks import PGGAN
+    from gansynth_amd.utils import Dict
+
+    growing_steps, total = 24, 16
+    spectral = Dict(waveform_length=1024, sample_rate=16000, spectrogram_shape=[16, 128], overlap=0.75)
+
+    def make(seed):
+        variables.set_default_store(variables.VariableStore(device="cuda", seed=seed))
+        holder = {}
+        pg = PGGAN(min_resolution=[2, 16], max_resolution=[16, 128], min_channels=32, max_channels=64,
+                   growing_level=lambda: holder["m"].global_step / growing_steps)
+        notes = synthetic_nsynth_input_fn(4, range(24, 85), device="cuda", seed=7)
+
+        def real_input_fn():
+            wav, lab = notes()
+            return wav[:, :1024].contiguous(), lab
+
+        gen = torch.Generator(device="cuda").manual_seed(11)
+        m = GANSynth(pg.generator, pg.discriminator, real_input_fn, lambda: torch.randn(4, 256, device="cuda", generator=gen), spectral,
+                     Dict(R.DEFAULT_HYPER), use_graphs=True)
+        holder["m"] = m
+        return m, pg
+
+    logs = []
+    model, pg = make(0)
+    depths = []
+    orig = model.train_step
+
+    def step():
+        depths.append(pg.growing_depth)
+        return orig()
+
+    model.train_step = step
+    model.train(total_steps=total, log_tensor_steps=4, log=logs.append, model_dir=str(tmp_path), save_checkpoint_steps=8)
+    assert model.global_step == total and len(logs) == total // 4 and all("generator_loss" in l for l in logs)
+    assert depths[0] == 0.0 and any(0.0 < d < 1.0 for d in depths) and any(1.0 < d < 2.0 for d in depths) and any(2.0 < d < 3.0 for d in depths)
+    assert depths[-1] > 3.0 and set(model._graphs) == {"d", "g"}            # fully grown at the end: replaying graphs
+    assert torch.isfinite(model.g_params.flat).all() and torch.isfinite(model.d_params.flat).all()
+    assert np.isfinite(float(model.discriminator_loss)) and np.isfinite(float(model.generator_loss))
+    assert checkpoint.latest(str(tmp_path)).endswith(f"model.ckpt-{total}.safetensors")
+    # resume: everything comes from the file; two more iterations run (fully grown from the first step on)
+    again, _ = make(99)
+    again.train(total_steps=total + 2, log=None, model_dir=str(tmp_path), save_checkpoint_steps=0)
+    assert again.restored_from.endswith(f"model.ckpt-{total}.safetensors") and again.global_step == total + 2
+    assert again.d_params.t == total + 2 and torch.isfinite(again.g_params.flat).all()
+    # generate (models.py:232-250): waveforms of the configured length in [-1, 1]-ish range
+    lat = torch.randn(4, 256, device="cuda")
+    lab = torch.nn.functional.one_hot(torch.randint(0, 61, (4,)), 61).float().cuda()
+    wav = again.generate(lat, lab)
+    assert tuple(wav.shape) == (4, 1024) and torch.isfinite(wav).all()
