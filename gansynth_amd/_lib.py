@@ -68,6 +68,7 @@ SIGNATURES = {
     "gs_batch_stddev_bwd": (I, [P, P, P, I, I, I, F, I, P]),
     "gs_batch_stddev_bwd_bwd": (I, [P, P, P, P, P, I, I, I, F, I, P]),
     "gs_axpby": (I, [P, P, P, L, F, F, I, P]),
+    "gs_axpby_dev": (I, [P, P, P, L, P, I, I, I, P]),
     "gs_sumsq_rows_workspace_bytes": (Z, [I]),
     "gs_sumsq_rows": (I, [P, P, I, L, I, P, Z, P]),
     "gs_row_scale": (I, [P, P, P, I, L, I, P]),

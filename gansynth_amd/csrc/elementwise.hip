@@ -588,6 +588,32 @@ extern "C" int gs_tanh_bwd_bwd(const void* gg, const void* g, const void* y, voi
     return 0;
 }
 
+// out = coef[ia] * a + coef[ib] * b with the coefficients read from device memory: the fade-in weight of the progressive schedule
+// changes every step, and a by-value scalar would be frozen into a captured hipGraph
+template <typename T>
+__global__ void axpby_dev_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out, long n, const float* __restrict__ coef, int ia, int ib) {
+    const float ca = coef[ia], cb = coef[ib];
+    const long nvec = n >> 2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+        float av[4], bv[4];
+        ld4(a + i * 4, av);
+        ld4(b + i * 4, bv);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) av[e] = ca * av[e] + cb * bv[e];
+        st4(out + i * 4, av);
+    }
+    const long t = nvec * 4 + (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) DT<T>::st(out + t, ca * DT<T>::ld(a + t) + cb * DT<T>::ld(b + t));
+}
+
+extern "C" int gs_axpby_dev(const void* a, const void* b, void* out, int64_t numel, const float* coef, int ia, int ib, int dtype, void* stream) {
+    GS_CHECK_ARG(numel > 0 && coef && ia >= 0 && ib >= 0, "axpby_dev: bad args");
+    GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((axpby_dev_kernel<T>), dim3(ew_grid((numel >> 2) + 4)), dim3(256), 0, as_stream(stream),
+                                                (const T*)a, (const T*)b, (T*)out, (long)numel, coef, ia, ib));
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int gs_axpby(const void* a, const void* b, void* out, int64_t numel, float ca, float cb, int dtype, void* stream) {
     GS_CHECK_ARG(numel > 0, "axpby: bad args");
     GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((axpby_kernel<T>), dim3(ew_grid((numel >> 2) + 4)), dim3(256), 0, as_stream(stream),

@@ -685,6 +685,41 @@ def batch_stddev(x, eps):
 
 
 # --------------------------------------------------------------------------------- lerp
+class DeviceLerp(object):
+    """The fade-in weight t of `lerp(a, b, t) = t a + (1 - t) b` (networks.py:10-11) kept in device memory: it changes every step
+    of the progressive schedule, and a by-value kernel scalar would be frozen into a captured hipGraph.  `weights()` gives the two
+    coefficients as objects the kernel layer resolves to (table, index); float() of them is the current host value (what the CPU
+    emulation of the tests uses).  Table = [t, 1 - t, 0, 1]."""
+
+    class Coef(object):
+        def __init__(self, owner, index):
+            self.owner, self.index = owner, index
+
+        def __float__(self):
+            return float(self.owner.host[self.index])
+
+    def __init__(self, device):
+        self.host = torch.tensor([0.0, 1.0, 0.0, 1.0], dtype=torch.float32)
+        if torch.device(device).type == "cuda":
+            self.host = self.host.pin_memory()
+        self.table = self.host.to(device)
+
+    def set(self, t):
+        self.host[0], self.host[1] = float(t), 1.0 - float(t)
+        self.table.copy_(self.host, non_blocking=True)   # stream-ordered before the next launch / graph replay
+
+    def weights(self):
+        return DeviceLerp.Coef(self, 0), DeviceLerp.Coef(self, 1)
+
+    def zero(self):
+        return DeviceLerp.Coef(self, 2)
+
+
+def _coef_zero(c):
+    """0 in the same representation as coefficient c (a device-table entry stays a device-table entry)."""
+    return c.owner.zero() if isinstance(c, DeviceLerp.Coef) else 0.0
+
+
 class _Axpby(Function):
     @staticmethod
     def forward(ctx, a, b, ca, cb):
@@ -694,8 +729,8 @@ class _Axpby(Function):
     @staticmethod
     def backward(ctx, g):
         ca, cb = ctx.c
-        ga = _Axpby.apply(g, g, ca, 0.0) if ctx.needs_input_grad[0] else None
-        gb = _Axpby.apply(g, g, 0.0, cb) if ctx.needs_input_grad[1] else None
+        ga = _Axpby.apply(g, g, ca, _coef_zero(ca)) if ctx.needs_input_grad[0] else None
+        gb = _Axpby.apply(g, g, _coef_zero(cb), cb) if ctx.needs_input_grad[1] else None
         return ga, gb, None, None
 
 

@@ -516,6 +516,12 @@ class HipKernels(object):
         a = _act(a)
         b = _match(b, a)
         out = torch.empty_like(a)
+        if hasattr(ca, "owner") or hasattr(cb, "owner"):   # functional.DeviceLerp.Coef: coefficients read from a device table
+            if not (hasattr(ca, "owner") and hasattr(cb, "owner") and ca.owner is cb.owner):
+                raise TypeError("axpby: device coefficients must come from one DeviceLerp table")
+            _lib.check(self.lib.gs_axpby_dev(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), ca.owner.table.data_ptr(), ca.index, cb.index,
+                                             _dt(a), _stream()), "gs_axpby_dev")
+            return out
         _lib.check(self.lib.gs_axpby(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), float(ca), float(cb), _dt(a), _stream()), "gs_axpby")
         return out
 

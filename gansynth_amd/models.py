@@ -87,6 +87,7 @@ class GANSynth(object):
         self.use_graphs = bool(use_graphs)
         self._graphs = {}
         self._restore_from, self.restored_from = None, None
+        self._graph_key, self._lerp = None, None
         # Pipelined iteration (opt-in: pipeline=True / GS_PIPELINE=1; train_step with graphs): every run is captured as two
         # graphs (own-network part A, the rest B) so that the gradient all-reduce of one network can run on a side stream under
         # part A of the other network's run, which needs none of it.  Off by default: on this ROCm stack a cross-stream event
@@ -253,33 +254,58 @@ class GANSynth(object):
         latents, labels = inputs
         return self._part_b("g", self._part_a("g", latents, labels), labels)
 
-    def _graphable(self):
+    def _regime(self):
+        """(head depth, fade weight or None) of the networks at the current growing depth; None for foreign network objects."""
         owner = getattr(self.generator, "__self__", None)
-        if not self.use_graphs or owner is None or not hasattr(owner, "_head_depth"):
-            return False
-        head, fade = owner._head_depth(owner.growing_depth)
-        return fade is None and head == owner.max_depth
+        if owner is None or not hasattr(owner, "_head_depth") or getattr(self.discriminator, "__self__", None) is not owner:
+            return None
+        return owner._head_depth(owner.growing_depth)
+
+    def _graphable(self):
+        """hipGraph replay needs a step-invariant launch sequence: the network structure is fixed within a growing regime (head
+        depth, faded or not -- graphs are re-captured when it changes) and the one per-step scalar, the fade-in weight, is read
+        from device memory (functional.DeviceLerp)."""
+        return self.use_graphs and torch.cuda.is_available() and self._regime() is not None
+
+    def _fully_grown(self):
+        reg = self._regime()
+        owner = getattr(self.generator, "__self__", None)
+        return reg is not None and reg[1] is None and reg[0] == owner.max_depth
 
     def _run(self, which, *inputs):
         self._join_updates()
+        owner = getattr(self.generator, "__self__", None)
         if not self._graphable():
             self._graphs.clear()
             return self._forward_backward(which, *inputs)
+        head, fade = self._regime()
+        key = (head, fade is None)
+        if self._graph_key != key:   # a new growing regime: different launch sequence
+            self._graphs.clear()
+            self._graph_key = key
+        if fade is not None:
+            if self._lerp is None:
+                self._lerp = F.DeviceLerp(self.g_params.flat.device)
+            self._lerp.set(fade)   # (stream-ordered before the replay below)
         entry = self._graphs.get(which)
         if entry is None or any(a.shape != b.shape or a.dtype != b.dtype for a, b in zip(entry[1], inputs)):
             static = [t.detach().clone() for t in inputs]
             K = kernels.get()
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):  # one eager pass on a side stream (allocator / lazy-init warm-up)
-                self._forward_backward(which, *static)
-            torch.cuda.current_stream().wait_stream(side)
-            # the prepared weight operands live in persistent workspaces that the optimizer step refreshes eagerly
-            # (kernels.adam_tf_step): bring them up to date now so that the captured graph holds no re-layout launches
-            K.refresh_weights()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                loss = self._forward_backward(which, *static)
+            owner.fade_weight = self._lerp if fade is not None else None   # the networks read the weight from the device table
+            try:
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):  # one eager pass on a side stream (allocator / lazy-init warm-up)
+                    self._forward_backward(which, *static)
+                torch.cuda.current_stream().wait_stream(side)
+                # the prepared weight operands live in persistent workspaces that the optimizer step refreshes eagerly
+                # (kernels.adam_tf_step): bring them up to date now so that the captured graph holds no re-layout launches
+                K.refresh_weights()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    loss = self._forward_backward(which, *static)
+            finally:
+                owner.fade_weight = None   # (only captured launches use the table; eager callers keep passing the number)
             entry = (graph, static, loss)
             self._graphs[which] = entry
         graph, static, loss = entry
@@ -340,7 +366,7 @@ class GANSynth(object):
         return {"a": ga, "b": gb, "sa": sa, "sb": sb, "loss": loss}
 
     def _pipelined_ok(self):
-        return self.pipeline and self.use_graphs and torch.cuda.is_available() and self._graphable()
+        return self.pipeline and self._graphable() and self._fully_grown()
 
     def _train_step_pipelined(self, d_latents, d_labels, real_images, g_latents, g_labels):
         """D.A | update G | D.B | G.A | update D | G.B, the gradient all-reduce of each update on a side stream under the part A

@@ -39,6 +39,7 @@ class PGGAN(object):
         self.max_channels = max_channels
         self.growing_level = growing_level  # float, or a zero-argument callable (e.g. step / growing_steps)
         self.min_depth = 0
+        self.fade_weight = None   # a functional.DeviceLerp: the trainer keeps the fade-in weight in device memory (hipGraph replay)
         self.max_depth = _ilog2(self.max_resolution // self.min_resolution)
 
     # ------------------------------------------------------------------ schedule (networks.py:24-29)
@@ -136,7 +137,7 @@ class PGGAN(object):
             if fade is None:
                 return middle
             low = ops.upscale2d(self._g_color_block(x, head - 1), full // self.resolution(head - 1))
-            return ops.lerp(low, middle, fade)
+            return ops.lerp(low, middle, fade if self.fade_weight is None else self.fade_weight)
 
     # ============================================================== discriminator
     def _d_conv_block(self, x, depth, num_labels, fresh_activation=False):
@@ -218,7 +219,7 @@ class PGGAN(object):
             x = self._d_conv_block(from_images(head), head, num_labels, fresh_activation=True)
             fresh = fade is None
             if fade is not None:
-                x = ops.lerp(from_images(head - 1), x, fade)
+                x = ops.lerp(from_images(head - 1), x, fade if self.fade_weight is None else self.fade_weight)
             for depth in range(head - 1, self.min_depth, -1):
                 x = self._d_conv_block(x, depth, num_labels, fresh_activation=fresh)
                 fresh = True

@@ -127,5 +127,8 @@ def tanh(inputs):
 
 
 def lerp(a, b, t):
-    """networks.py:10-11."""
+    """networks.py:10-11.  `t`: a number, or a functional.DeviceLerp whose weight lives in device memory (hipGraph-safe)."""
+    if isinstance(t, F.DeviceLerp):
+        ca, cb = t.weights()
+        return F.axpby(a, b, ca, cb)
     return F.axpby(a, b, float(t), 1.0 - float(t))

@@ -240,6 +240,9 @@ int gs_batch_stddev_bwd_bwd(const void* ggx, const void* gy, const void* x, void
 
 /* lerp (networks.py:10-11) and generic fused axpby: out = ca*a + cb*b. */
 int gs_axpby(const void* a, const void* b, void* out, int64_t numel, float ca, float cb, int dtype, void* stream);
+/* The same with the two coefficients read from a device table (coef[ia], coef[ib]): a fade-in weight that changes every step
+ * must not be frozen into a captured hipGraph as a by-value scalar. */
+int gs_axpby_dev(const void* a, const void* b, void* out, int64_t numel, const float* coef, int ia, int ib, int dtype, void* stream);
 
 /* per-sample sum of squares (the R1 penalty reduction, models.py:48): out[r] = sum_j x[r][j]^2 (fp32 out);
  * row_scale: out[r][j] = s[r] * x[r][j]  (its gradient, s fp32). */

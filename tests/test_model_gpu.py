@@ -323,3 +323,35 @@ def test_training_driver_visits_every_growing_regime_and_resumes(gpu_store, tmp_
     lab = torch.nn.functional.one_hot(torch.randint(0, 61, (4,)), 61).float().cuda()
     wav = again.generate(lat, lab)
     assert tuple(wav.shape) == (4, 1024) and torch.isfinite(wav).all()
+
+
+def test_hipgraph_replay_in_a_fade_in_regime(gpu_store):
+    """Graphs are captured in every growing regime: the fade-in weight is read from device memory (gs_axpby_dev), so the replayed
+    step follows a growing_level that changes every iteration; a regime change re-captures.  Same losses / parameters as eager
+    launches (up to the order of fp32 gradient accumulation)."""
+    from gansynth_amd import variables
+    out = {}
+    for graphs in (False, True):
+        variables.set_default_store(variables.VariableStore(device="cuda"))
+        step = [0]
+        pg, opg, model = make(lambda: 0.20 + 0.03 * step[0], variables.default_store(), full=False)   # depth 2.0 .. 2.5 .. 3.1 of 3
+        model.use_graphs = graphs
+        gp, dp = opg.init_params(seed=0, bias_std=0.1)
+        losses, keys = [], []
+        for it in range(7):
+            step[0] = it
+            lat, lab, real = R.synthetic_batch(4, rank=it, image_shape=(2, 16, 128))
+            if it == 0:
+                model._build(cuda(lat), cuda(lab))
+                variables.default_store().load_state_dict({**gp, **dp})
+            losses.append(float(model.discriminator_step(cuda(lat), cuda(lab), cuda(real))))
+            losses.append(float(model.generator_step(cuda(lat), cuda(lab))))
+            keys.append(model._graph_key)
+        out[graphs] = (losses, model.d_params.flat.clone(), model.g_params.flat.clone())
+        if graphs:
+            assert set(model._graphs) == {"d", "g"} and pg.fade_weight is None
+            assert len(set(keys)) >= 2 and keys[0][1] is False     # started inside a fade-in, crossed into the next regime
+    for i, (a, b) in enumerate(zip(out[False][0], out[True][0])):
+        _same_up_to_accumulation_order(a, b, f"loss {i}")
+    _same_up_to_accumulation_order(out[False][1], out[True][1], "discriminator parameters")
+    _same_up_to_accumulation_order(out[False][2], out[True][2], "generator parameters")
