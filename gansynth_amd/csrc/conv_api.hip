@@ -529,6 +529,11 @@ extern "C" int gs_bias_act_fwd(const void* x, const float* bias, void* y, int64_
 
 // y2 (optional): y2 = pixel_norm(act(conv + bias)) as well -- fused into the conv epilogue where the tile owns all channels of a
 // pixel, a separate pass otherwise; y (the activation itself) may then be NULL
+static int mask_fuse_min_channels() {
+    static const int v = [] { const char* e = getenv("GS_MASK_FUSE_MIN_CI"); return e ? atoi(e) : 32; }();   // (env: measurement knob)
+    return v;
+}
+
 static int conv2d_fwd_impl(const void* x, const float* w_hwio, const float* bias, int act, void* y, int n, int h, int w, int ci, int co, int ksize,
                            int stride, float alpha, int dtype, int w_prepared, void* ws, size_t ws_bytes, void* stream, void* y2 = nullptr,
                            float pn_eps = 0.f) {
@@ -564,7 +569,7 @@ extern "C" int gs_act_bwd(const void* g, const void* y, void* gx, int64_t numel,
 
 // y = conv2d(x, w) * mask_act'(.) through `mask` (an activation OUTPUT of y's shape): the second-order pass of the R1 penalty runs
 // the discriminator's convs forward on cotangents and multiplies each result by the derivative of the activation that follows
-// the conv; in the epilogue for >= 64 output channels (see gs_conv2d_bwd_data_mask), in place after the conv otherwise
+// the conv; in the epilogue on the MFMA path (see gs_conv2d_bwd_data_mask), in place after the conv otherwise
 extern "C" int gs_conv2d_fwd_mask(const void* x, const float* w_hwio, const void* mask, int mask_act, void* y, int n, int h, int w, int ci, int co,
                                   int ksize, int stride, float alpha, int dtype, int w_prepared, void* ws, size_t ws_bytes, void* stream) {
     if (int e = check_conv_args(n, h, w, ci, co, ksize, stride, dtype)) return e;
@@ -572,7 +577,7 @@ extern "C" int gs_conv2d_fwd_mask(const void* x, const float* w_hwio, const void
     hipStream_t st = as_stream(stream);
     const int hb = h / stride, wb = w / stride;
     const int mode = stride == 2 ? MODE_S2 : MODE_S1;
-    const bool fused = mask != nullptr && co >= 64 && ksize == 3 && igemm_supported(ci, co, dtype);
+    const bool fused = mask != nullptr && co >= mask_fuse_min_channels() && ksize == 3 && igemm_supported(ci, co, dtype);
     int rc;
     if (ksize == 3 && igemm_supported(ci, co, dtype))
         rc = run_igemm(mode, 0, x, w_hwio, y, n, h, w, ci, co, ci, co, hb, wb, alpha, nullptr, GS_ACT_NONE, dtype, w_prepared, ws, ws_bytes, st, fused ? mask : nullptr, mask_act);
@@ -601,11 +606,10 @@ extern "C" int gs_conv2d_bwd_data_mask(const void* gy, const float* w_hwio, cons
     hipStream_t st = as_stream(stream);
     const int hb = h / stride, wb = w / stride;
     int rc;
-    // In the epilogue the mask costs one more read of gx's size through the vector-memory path: measured a win where the kernel
-    // is MFMA-bound (>= 64 channels), a loss on the 32-channel top of the pyramid whose kernels are bound by exactly that path
-    // (there the separate in-place pass below is as fast and leaves the conv alone).
-    static const int fuse_min_ci = [] { const char* e = getenv("GS_MASK_FUSE_MIN_CI"); return e ? atoi(e) : 64; }();   // measurement knob
-    bool fused = mask != nullptr && ci >= fuse_min_ci;
+    // In the epilogue the mask costs one more read of gx's size; with the mask vectors fetched ahead of the epilogue arithmetic
+    // (conv_igemm.hip) that beats the separate in-place pass on every MFMA-path layer, the HBM-bound 32-channel top included
+    // (+1.6 % on the step against fusing from 64 channels up).
+    bool fused = mask != nullptr && ci >= mask_fuse_min_channels();
     const void* km = fused ? mask : nullptr;
     if (stride == 1) {  // flipped taps, roles of ci/co swapped
         if (ksize == 3 && igemm_supported(co, ci, dtype))

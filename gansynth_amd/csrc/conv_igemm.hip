@@ -14,6 +14,7 @@
 //
 // Reference call sites replaced: tf.nn.conv2d ops.py:237-243 and tf.nn.conv2d_transpose
 // ops.py:269-276 (plus the tf.gradients of both, models.py:47,60,81-89).
+#include <type_traits>
 #include "conv_shared.h"
 
 extern "C" int gs_pixel_norm_fwd(const void* x, void* y, int64_t p, int c, float eps, int dtype, void* stream);
@@ -483,17 +484,28 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
                         }
                     };
                     // ... to dst[off + a * 32 + ...] (16 bytes per lane), optionally times mask_act'(.) through mask[off + ...]
-                    auto store = [&](T* dst, long off, int a, float (&o)[4][4], bool inside, const void* mask) __attribute__((always_inline)) {
+                    // The mask vectors of a lane (its 16-byte pieces of the activation output, laid out like its stores) are fetched
+                    // AHEAD of the arithmetic, several at a time: loaded where they are used, each costs the lane a full memory
+                    // round trip (4-8 dependent trips per tile).
+                    typedef typename std::conditional<SZ == 4, float4, uint4>::type mvec_t;
+                    constexpr int NV = SZ == 4 ? 4 : 2;              // mask vectors per 32-channel tile of a pixel
+                    auto mask_fetch = [&](long off, bool inside, mvec_t (&mz)[A][NV]) __attribute__((always_inline)) {
+                        const long base = inside ? off : 0;          // clamped: the loads stay unconditional
+#pragma unroll
+                        for (int a = 0; a < A; ++a)
+#pragma unroll
+                            for (int v = 0; v < NV; ++v)
+                                mz[a][v] = *reinterpret_cast<const mvec_t*>(reinterpret_cast<const T*>(p.mask) + base + a * 32 + v * (32 / NV) + hi * (16 / NV));
+                    };
+                    auto store = [&](T* dst, long off, int a, float (&o)[4][4], bool inside, const mvec_t* mz) __attribute__((always_inline)) {
                         if constexpr (SZ == 4) {
 #pragma unroll
                             for (int qd = 0; qd < 4; ++qd) {
-                                if (inside) {
-                                    if (mask) {
-                                        const float4 zv = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(mask) + off + a * 32 + qd * 8 + hi * 4);
-                                        o[qd][0] *= mask_factor(zv.x); o[qd][1] *= mask_factor(zv.y); o[qd][2] *= mask_factor(zv.z); o[qd][3] *= mask_factor(zv.w);
-                                    }
-                                    st4(reinterpret_cast<float*>(dst) + off + a * 32 + qd * 8 + hi * 4, o[qd]);
+                                if (mz) {
+                                    const float4 zv = mz[qd];
+                                    o[qd][0] *= mask_factor(zv.x); o[qd][1] *= mask_factor(zv.y); o[qd][2] *= mask_factor(zv.z); o[qd][3] *= mask_factor(zv.w);
                                 }
+                                if (inside) st4(reinterpret_cast<float*>(dst) + off + a * 32 + qd * 8 + hi * 4, o[qd]);
                             }
                         } else {
 #pragma unroll
@@ -505,8 +517,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
                                     lo[e] = __uint_as_float(r[0]);
                                     hi4[e] = __uint_as_float(r[1]);
                                 }
-                                if (mask && inside) {   // the lane's 8 channels of the mask sit where its 16 bytes go
-                                    const uint4 zv = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(mask) + off + a * 32 + qp * 16 + hi * 8);
+                                if (mz) {   // the lane's 8 channels of the mask sit where its 16 bytes go
+                                    const uint4 zv = mz[qp];
                                     lo[0] *= mask_factor(__uint_as_float(zv.x << 16)); lo[1] *= mask_factor(__uint_as_float(zv.x & 0xffff0000u));
                                     lo[2] *= mask_factor(__uint_as_float(zv.y << 16)); lo[3] *= mask_factor(__uint_as_float(zv.y & 0xffff0000u));
                                     hi4[0] *= mask_factor(__uint_as_float(zv.z << 16)); hi4[1] *= mask_factor(__uint_as_float(zv.z & 0xffff0000u));
@@ -519,6 +531,24 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
                             }
                         }
                     };
+                    // all mask vectors of the tile in one go when they fit in 32 registers, else one (pixel group, phase) at a time
+                    constexpr bool MASK_ALL = !NORM && B * NPH * A * NV <= 8;
+                    mvec_t mz_all[MASK_ALL ? B * NPH : 1][A][NV];
+                    if constexpr (MASK_ALL) {
+                        if (p.mask) {
+#pragma unroll
+                            for (int b = 0; b < B; ++b) {
+                                const int q = (wv * B + b) * 32 + l31;
+                                const int gy = by + q / TW, gx = bx + q % TW;
+#pragma unroll
+                                for (int ph = 0; ph < NPH; ++ph) {
+                                    const int oy = MODE == MODE_T2 ? 2 * gy + (ph >> 1) : gy;
+                                    const int ox = MODE == MODE_T2 ? 2 * gx + (ph & 1) : gx;
+                                    mask_fetch((((long)n * Ho + oy) * Wo + ox) * OC + oc0, gy < Hb && gx < Wb, mz_all[b * NPH + ph]);
+                                }
+                            }
+                        }
+                    }
 #pragma unroll
                     for (int b = 0; b < B; ++b) {
                         const int q = (wv * B + b) * 32 + l31;
@@ -551,18 +581,23 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
                                         float oz[4][4];
 #pragma unroll
                                         for (int k = 0; k < 16; ++k) oz[k >> 2][k & 3] = o[a][k >> 2][k & 3];
-                                        store(y, off, a, oz, inside, nullptr);
+                                        store(y, off, a, oz, inside, static_cast<const mvec_t*>(nullptr));
                                     }
 #pragma unroll
                                     for (int k = 0; k < 16; ++k) o[a][k >> 2][k & 3] *= r;
-                                    store(reinterpret_cast<T*>(p.y2), off, a, o[a], inside, nullptr);
+                                    store(reinterpret_cast<T*>(p.y2), off, a, o[a], inside, static_cast<const mvec_t*>(nullptr));
                                 }
                             } else {
+                                mvec_t mz_one[A][NV];
+                                if constexpr (!MASK_ALL) {
+                                    if (p.mask) mask_fetch(off, inside, mz_one);
+                                }
 #pragma unroll
                                 for (int a = 0; a < A; ++a) {
                                     float o[4][4];
                                     finish(ph, a, b, o);
-                                    store(y, off, a, o, inside, p.mask);
+                                    const mvec_t* mz = MASK_ALL ? mz_all[MASK_ALL ? b * NPH + ph : 0][a] : mz_one[a];
+                                    store(y, off, a, o, inside, p.mask ? mz : static_cast<const mvec_t*>(nullptr));
                                 }
                             }
                         }
