@@ -73,6 +73,8 @@ SIGNATURES = {
     "gs_sumsq_rows": (I, [P, P, I, L, I, P, Z, P]),
     "gs_row_scale": (I, [P, P, P, I, L, I, P]),
     "gs_weight_prep_batch": (I, [P, I, P]),
+    "gs_gan_d_loss": (I, [P, P, P, P, I, I, P, P, P, I, P]),
+    "gs_gan_g_loss": (I, [P, P, P, F, F, I, I, P, P, P, I, P]),
     "gs_adam_tf_step": (I, [P, P, P, P, L, F, F, F, F, F, P]),
     "gs_spectral_plan_create": (I, [POINTER(c_void_p), I, I, I, P, P]),
     "gs_spectral_plan_destroy": (I, [P]),

@@ -429,9 +429,92 @@ __global__ __launch_bounds__(BS_NT) void batch_stddev_bwd_bwd_kernel(const T* __
     for (int k = threadIdx.x; k < 4 * hw; k += BS_NT) DT<T>::st(ggy + (long)((k / hw) * M + j) * hw + (k % hw), t);
 }
 
+// ------------------------------------------------------------------------------ GAN losses
+// The loss algebra of models.py:39-65 on [N] / [N, C] tensors was ~50 torch launches per iteration (casts, products, sums,
+// softplus, mean and their autograd mirror images); here each loss is ONE single-block launch that also writes the gradients of
+// the mean w.r.t. its inputs (the backward of the autograd node then only scales them by the incoming scalar).
+__device__ inline float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }       // tf.nn.softplus
+__device__ inline float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
+
+// L_D = mean_i [ softplus(-r_i) + softplus(f_i) + pen_i ],  r_i / f_i = sum_c logits[i][c] * labels[i][c] (one-hot labels:
+// tf.gather_nd(logits, tf.where(labels)), models.py:39-40).  g_real = d L_D / d real_logits etc.
+template <typename T>
+__global__ __launch_bounds__(256) void gan_d_loss_kernel(const T* __restrict__ rl, const T* __restrict__ fl, const T* __restrict__ lab,
+                                                         const float* __restrict__ pen, int n, int c, float* __restrict__ loss,
+                                                         T* __restrict__ g_real, T* __restrict__ g_fake) {
+    __shared__ float red[4];
+    __shared__ float sr[1024], sf[1024];
+    const float inv_n = 1.f / (float)n;
+    float part = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        float r = 0.f, f = 0.f;
+        for (int k = 0; k < c; ++k) {
+            const float l = DT<T>::ld(lab + (long)i * c + k);
+            r += DT<T>::ld(rl + (long)i * c + k) * l;
+            f += DT<T>::ld(fl + (long)i * c + k) * l;
+        }
+        part += softplus_f(-r) + softplus_f(f) + (pen ? pen[i] : 0.f);
+        sr[i] = -sigmoid_f(-r) * inv_n;   // d mean / d r_i
+        sf[i] = sigmoid_f(f) * inv_n;     // d mean / d f_i
+    }
+    const float tot = block_sum<256>(part, red);
+    if (threadIdx.x == 0) loss[0] = tot * inv_n;
+    __syncthreads();
+    for (int e = threadIdx.x; e < n * c; e += 256) {
+        const float l = DT<T>::ld(lab + e);
+        DT<T>::st(g_real + e, sr[e / c] * l);
+        DT<T>::st(g_fake + e, sf[e / c] * l);
+    }
+}
+
+// L_G = mean_i [ softplus(-f_i) + w / (s_i + eps) ],  s_i = sum((d sum(G(z)) / d z_i)^2) (models.py:57-64); g_s = d L_G / d s.
+template <typename T>
+__global__ __launch_bounds__(256) void gan_g_loss_kernel(const T* __restrict__ fl, const T* __restrict__ lab, const float* __restrict__ ssq, float w,
+                                                         float eps, int n, int c, float* __restrict__ loss, T* __restrict__ g_fake,
+                                                         float* __restrict__ g_ssq) {
+    __shared__ float red[4];
+    __shared__ float sf[1024];
+    const float inv_n = 1.f / (float)n;
+    float part = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        float f = 0.f;
+        for (int k = 0; k < c; ++k) f += DT<T>::ld(fl + (long)i * c + k) * DT<T>::ld(lab + (long)i * c + k);
+        part += softplus_f(-f);
+        sf[i] = -sigmoid_f(-f) * inv_n;
+        if (ssq) {
+            const float d = ssq[i] + eps;
+            part += w / d;
+            g_ssq[i] = -w / (d * d) * inv_n;
+        }
+    }
+    const float tot = block_sum<256>(part, red);
+    if (threadIdx.x == 0) loss[0] = tot * inv_n;
+    __syncthreads();
+    for (int e = threadIdx.x; e < n * c; e += 256) DT<T>::st(g_fake + e, sf[e / c] * DT<T>::ld(lab + e));
+}
+
 }  // namespace gs
 
 using namespace gs;
+
+extern "C" int gs_gan_d_loss(const void* real_logits, const void* fake_logits, const void* labels, const float* penalty, int n, int c, float* loss,
+                             void* g_real, void* g_fake, int dtype, void* stream) {
+    GS_CHECK_ARG(n > 0 && n <= 1024 && c > 0 && real_logits && fake_logits && labels && loss && g_real && g_fake, "gan_d_loss: bad args (batch %d <= 1024)", n);
+    GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gan_d_loss_kernel<T>), dim3(1), dim3(256), 0, as_stream(stream), (const T*)real_logits, (const T*)fake_logits,
+                                                (const T*)labels, penalty, n, c, loss, (T*)g_real, (T*)g_fake));
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gs_gan_g_loss(const void* fake_logits, const void* labels, const float* sumsq, float weight, float eps, int n, int c, float* loss,
+                             void* g_fake, float* g_sumsq, int dtype, void* stream) {
+    GS_CHECK_ARG(n > 0 && n <= 1024 && c > 0 && fake_logits && labels && loss && g_fake && (!sumsq || g_sumsq), "gan_g_loss: bad args (batch %d <= 1024)", n);
+    GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gan_g_loss_kernel<T>), dim3(1), dim3(256), 0, as_stream(stream), (const T*)fake_logits, (const T*)labels, sumsq,
+                                                weight, eps, n, c, loss, (T*)g_fake, g_sumsq));
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
 
 extern "C" size_t gs_dense_fwd_workspace_bytes(int b, int in, int out) {
     int ks, ipb;

@@ -738,6 +738,54 @@ def axpby(a, b, ca, cb):
     return _Axpby.apply(a, b, ca, cb)
 
 
+# ------------------------------------------------------------------------------ GAN losses
+class _GanDLoss(Function):
+    """L_D = mean(softplus(-r) + softplus(f) + penalty) with r / f the label logits (models.py:39-49, 65): loss and gradients in
+    one launch; the backward scales the stored gradients by the incoming scalar.  First order only (the second-order terms of the
+    step live in `penalty`'s own graph)."""
+
+    @staticmethod
+    def forward(ctx, real_logits, fake_logits, labels, penalty):
+        loss, g_real, g_fake = _K().gan_d_loss(real_logits, fake_logits, labels, penalty)
+        ctx.save_for_backward(g_real, g_fake)
+        ctx.n, ctx.has_penalty = real_logits.shape[0], penalty is not None
+        return loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        g_real, g_fake = ctx.saved_tensors
+        gp = (g / ctx.n).expand(ctx.n) if ctx.has_penalty and ctx.needs_input_grad[3] else None
+        return (g_real * g.to(g_real.dtype) if ctx.needs_input_grad[0] else None,
+                g_fake * g.to(g_fake.dtype) if ctx.needs_input_grad[1] else None, None, gp)
+
+
+class _GanGLoss(Function):
+    """L_G = mean(softplus(-f) + weight / (sumsq + eps)) (models.py:57-64), same scheme."""
+
+    @staticmethod
+    def forward(ctx, fake_logits, labels, sumsq, weight, eps):
+        loss, g_fake, g_sumsq = _K().gan_g_loss(fake_logits, labels, sumsq, weight, eps)
+        ctx.has_ms = sumsq is not None
+        ctx.save_for_backward(g_fake, g_sumsq if ctx.has_ms else g_fake)
+        return loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        g_fake, g_sumsq = ctx.saved_tensors
+        return (g_fake * g.to(g_fake.dtype) if ctx.needs_input_grad[0] else None, None,
+                g_sumsq * g if ctx.has_ms and ctx.needs_input_grad[2] else None, None, None)
+
+
+def gan_d_loss(real_logits, fake_logits, labels, penalty):
+    return _GanDLoss.apply(real_logits, fake_logits, labels, penalty)
+
+
+def gan_g_loss(fake_logits, labels, sumsq, weight, eps):
+    return _GanGLoss.apply(fake_logits, labels, sumsq, weight, eps)
+
+
 # ----------------------------------------------------------------- R1 penalty reduction
 class _SumSqRows(Function):
     """out[b] = sum_j x[b][...]^2  (models.py:48)."""

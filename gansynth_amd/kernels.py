@@ -541,6 +541,38 @@ class HipKernels(object):
         _lib.check(self.lib.gs_row_scale(x.data_ptr(), s.data_ptr(), out.data_ptr(), rows, x.numel() // rows, _dt(x), _stream()), "gs_row_scale")
         return out
 
+    def gan_d_loss(self, real_logits, fake_logits, labels, penalty):
+        """(loss, g_real_logits, g_fake_logits): mean of softplus(-r) + softplus(f) + penalty and its gradients, one launch."""
+        real_logits, fake_logits = _act(real_logits), _act(fake_logits)
+        labels = _match(labels, real_logits)
+        n, c = real_logits.shape
+        loss = torch.empty((), dtype=torch.float32, device=real_logits.device)
+        g_real, g_fake = torch.empty_like(real_logits), torch.empty_like(fake_logits)
+        pp = None
+        if penalty is not None:
+            penalty = _f32c(penalty)
+            pp = penalty.data_ptr()
+        _lib.check(self.lib.gs_gan_d_loss(real_logits.data_ptr(), fake_logits.data_ptr(), labels.data_ptr(), pp, n, c, loss.data_ptr(), g_real.data_ptr(),
+                                          g_fake.data_ptr(), _dt(real_logits), _stream()), "gs_gan_d_loss")
+        return loss, g_real, g_fake
+
+    def gan_g_loss(self, fake_logits, labels, sumsq, weight, eps):
+        """(loss, g_fake_logits, g_sumsq): mean of softplus(-f) + weight / (sumsq + eps) and its gradients, one launch."""
+        fake_logits = _act(fake_logits)
+        labels = _match(labels, fake_logits)
+        n, c = fake_logits.shape
+        loss = torch.empty((), dtype=torch.float32, device=fake_logits.device)
+        g_fake = torch.empty_like(fake_logits)
+        sp = gp = None
+        g_sumsq = None
+        if sumsq is not None:
+            sumsq = _f32c(sumsq)
+            g_sumsq = torch.empty_like(sumsq)
+            sp, gp = sumsq.data_ptr(), g_sumsq.data_ptr()
+        _lib.check(self.lib.gs_gan_g_loss(fake_logits.data_ptr(), labels.data_ptr(), sp, float(weight), float(eps), n, c, loss.data_ptr(), g_fake.data_ptr(), gp,
+                                          _dt(fake_logits), _stream()), "gs_gan_g_loss")
+        return loss, g_fake, g_sumsq
+
     def adam_tf_step(self, p, g, m, v, lr_t, beta1, beta2, eps, grad_scale=1.0):
         for t in (p, g, m, v):
             assert t.dtype == torch.float32 and t.is_contiguous()

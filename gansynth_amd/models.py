@@ -28,6 +28,7 @@ _PAD = 64  # floats; keeps every parameter view 256-byte aligned inside the flat
 
 
 _DEFER_REDUCTIONS = not __import__("os").environ.get("GS_NO_DEFERRED_REDUCE")   # A/B switches for measurements
+_FUSED_LOSSES = not __import__("os").environ.get("GS_NO_FUSED_LOSSES")
 _PIPELINE = bool(__import__("os").environ.get("GS_PIPELINE"))   # opt-in, see GANSynth.pipeline
 _PIPE_SIDE = {"0": False, "1": True}.get(__import__("os").environ.get("GS_PIPE_SIDE", ""))
 
@@ -151,28 +152,40 @@ class GANSynth(object):
     #   G run:  A = G(z) + the mode-seeking first-order pass    B = D(G(z)), loss, backward
     # (`_a` functions return what `_b` needs).  The pipelined step overlaps the optimizer update of one network (all-reduce,
     # Adam, operand refresh on a side stream) with part A of the other network's run.
-    def _d_losses_a(self, labels, real_images):
+    # `fused`: the loss algebra on the [N] / [N, C] tensors -- label-logit select, softplus, penalty, mean, and their autograd
+    # mirror images, ~50 torch launches per iteration -- as ONE kernel per loss (gs_gan_d_loss / gs_gan_g_loss: value and
+    # gradients); `_b` then returns the mean loss itself instead of the per-sample losses.  The public *_losses methods keep
+    # the per-sample form of the reference.
+    @staticmethod
+    def _fused_losses():
+        return _FUSED_LOSSES and hasattr(kernels.get(), "gan_d_loss")
+
+    def _d_losses_a(self, labels, real_images, fused=False):
         hp = self.hyper_params
         real_images = real_images.detach().requires_grad_(True)
-        _, real_logits = self.discriminator(real_images, labels)
-        real_logits = self._label_logits(real_logits, labels)
-        real_losses = TF.softplus(-real_logits)
+        _, raw = self.discriminator(real_images, labels)
+        real_logits = None if fused else self._label_logits(raw, labels)
         penalty = None
         if hp.real_gradient_penalty_weight:
             with F.data_grads_only():   # tf.gradients(real_logits, [real_images]) (models.py:47): no parameter gradients on this pass
-                (real_gradients,) = torch.autograd.grad(real_logits.sum(), real_images, create_graph=True)
+                if fused:   # d sum_i real_logit_i / d logits = the one-hot labels themselves
+                    (real_gradients,) = torch.autograd.grad(raw, real_images, grad_outputs=labels.to(raw.dtype), create_graph=True)
+                else:
+                    (real_gradients,) = torch.autograd.grad(real_logits.sum(), real_images, create_graph=True)
             penalty = F.sumsq_rows(real_gradients) * hp.real_gradient_penalty_weight
         if hp.get("fake_gradient_penalty_weight", 0.0):
             raise NotImplementedError("fake_gradient_penalty_weight is 0 in the reference configuration (gan_synth_main.py:87)")
-        return real_losses, penalty
+        return (raw, penalty) if fused else (TF.softplus(-real_logits), penalty)
 
-    def _d_losses_b(self, part_a, latents, labels):
-        real_losses, penalty = part_a
+    def _d_losses_b(self, part_a, latents, labels, fused=False):
+        real_part, penalty = part_a
         with torch.no_grad():  # var_list is the discriminator's only: no generator backward (models.py:86-89)
             fake_images = self.generator(latents, labels)
         _, fake_logits = self.discriminator(fake_images, labels)
+        if fused:
+            return F.gan_d_loss(real_part, fake_logits, labels, penalty)
         fake_logits = self._label_logits(fake_logits, labels)
-        losses = real_losses + TF.softplus(fake_logits)
+        losses = real_part + TF.softplus(fake_logits)
         if penalty is not None:
             losses = losses + penalty
         return losses
@@ -180,7 +193,7 @@ class GANSynth(object):
     def discriminator_losses(self, latents, labels, real_images):
         return self._d_losses_b(self._d_losses_a(labels, real_images), latents, labels)
 
-    def _g_losses_a(self, latents, labels):
+    def _g_losses_a(self, latents, labels, fused=False):
         hp = self.hyper_params
         latents = latents.detach().requires_grad_(True)
         fake_images = self.generator(latents, labels)
@@ -189,13 +202,18 @@ class GANSynth(object):
             ones = torch.ones_like(fake_images)  # tf.gradients(ys) sums ys
             with F.data_grads_only():   # tf.gradients(fake_images, [latents]) (models.py:60)
                 (latent_gradients,) = torch.autograd.grad(fake_images, latents, grad_outputs=ones, create_graph=True)
-            mode_seeking = 1.0 / (latent_gradients.float().pow(2).sum(dim=1) + 1.0e-6)
+            if fused:
+                mode_seeking = F.sumsq_rows(latent_gradients)   # (the kernel forms weight / (. + 1e-6))
+            else:
+                mode_seeking = 1.0 / (latent_gradients.float().pow(2).sum(dim=1) + 1.0e-6)
         return fake_images, mode_seeking
 
-    def _g_losses_b(self, part_a, labels):
+    def _g_losses_b(self, part_a, labels, fused=False):
         hp = self.hyper_params
         fake_images, mode_seeking = part_a
         _, fake_logits = self.discriminator(fake_images, labels)
+        if fused:
+            return F.gan_g_loss(fake_logits, labels, mode_seeking, hp.mode_seeking_loss_weight, 1.0e-6)
         fake_logits = self._label_logits(fake_logits, labels)
         losses = TF.softplus(-fake_logits)
         if mode_seeking is not None:
@@ -224,16 +242,17 @@ class GANSynth(object):
             self.g_params.requires_grad_(False)
             self.d_params.requires_grad_(True)
             self.d_params.zero_grad()
-            return self._d_losses_a(*inputs)        # (labels, real_images)
+            return self._d_losses_a(*inputs, fused=self._fused_losses())        # (labels, real_images)
         self.g_params.requires_grad_(True)
         self.d_params.requires_grad_(False)
         self.g_params.zero_grad()
-        return self._g_losses_a(*inputs)            # (latents, labels)
+        return self._g_losses_a(*inputs, fused=self._fused_losses())            # (latents, labels)
 
     def _part_b(self, which, part_a, *inputs):
         """The rest of the run: losses, backward into the flat gradient buffer; returns the (detached) mean loss."""
-        losses = self._d_losses_b(part_a, *inputs) if which == "d" else self._g_losses_b(part_a, *inputs)   # (latents, labels) | (labels,)
-        loss = losses.mean()
+        fused = self._fused_losses()
+        losses = self._d_losses_b(part_a, *inputs, fused=fused) if which == "d" else self._g_losses_b(part_a, *inputs, fused=fused)   # (latents, labels) | (labels,)
+        loss = losses if losses.dim() == 0 else losses.mean()   # (the fused loss kernels return the mean itself)
         K = kernels.get()
         deferring = _DEFER_REDUCTIONS and hasattr(K, "defer_wgrad_reductions")   # parameter gradients are only read after the whole backward:
         if deferring:                                        # their ~70 slice reductions are folded in one go at the end

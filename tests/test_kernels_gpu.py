@@ -564,3 +564,32 @@ def test_conv2d_fwd_with_activation_mask(K, E, case, dtype):
     ref = E.act_bwd(E.conv2d_fwd(x, wt, ks, st, 0.1), z, 1)
     got = K.conv2d_fwd_mask(dev(x, dtype), dev(wt), ks, st, 0.1, dev(z, dtype), 1)
     close(got, ref, rel=1e-3 if dtype == torch.float32 else 2e-2, name=f"fwd mask {case}")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gan_losses_in_one_launch(K, dtype):
+    """gs_gan_d_loss / gs_gan_g_loss against the loss algebra of models.py:39-65 written out in torch (value and gradients)."""
+    import torch.nn.functional as TF
+    n, c = 8, 61
+    g = torch.Generator().manual_seed(3)
+    real = (torch.randn(n, c, generator=g) * 3).to(dtype).float().requires_grad_(True)
+    fake = (torch.randn(n, c, generator=g) * 3).to(dtype).float().requires_grad_(True)
+    lab = torch.nn.functional.one_hot(torch.randint(0, c, (n,), generator=g), c).float()
+    pen = (torch.rand(n, generator=g) * 2).requires_grad_(True)
+    ssq = (torch.rand(n, generator=g) * 1e-3).requires_grad_(True)
+    ld = (TF.softplus(-(real * lab).sum(1)) + TF.softplus((fake * lab).sum(1)) + pen).mean()
+    g_real, g_fake, g_pen = torch.autograd.grad(ld, [real, fake, pen])
+    loss, kr, kf = K.gan_d_loss(dev(real.detach(), dtype), dev(fake.detach(), dtype), dev(lab, dtype), pen.detach().cuda())
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert abs(float(loss) - float(ld)) <= 1e-5 * abs(float(ld))
+    close(kr, g_real, rel=tol, name="d loss: d/d real logits")
+    close(kf, g_fake, rel=tol, name="d loss: d/d fake logits")
+    assert torch.allclose(g_pen, torch.full((n,), 1.0 / n))
+    lg = (TF.softplus(-(fake * lab).sum(1)) + 0.1 / (ssq + 1e-6)).mean()
+    g_fake2, g_ssq = torch.autograd.grad(lg, [fake, ssq])
+    loss, kf, ks = K.gan_g_loss(dev(fake.detach(), dtype), dev(lab, dtype), ssq.detach().cuda(), 0.1, 1e-6)
+    assert abs(float(loss) - float(lg)) <= 1e-5 * abs(float(lg))
+    close(kf, g_fake2, rel=tol, name="g loss: d/d fake logits")
+    close(ks, g_ssq, rel=1e-5, name="g loss: d/d sumsq")
+    loss, kf, ks = K.gan_g_loss(dev(fake.detach(), dtype), dev(lab, dtype), None, 0.0, 1e-6)
+    assert ks is None and abs(float(loss) - float(TF.softplus(-(fake * lab).sum(1)).mean())) <= 1e-5
