@@ -1103,7 +1103,8 @@ static int launch_igemm(ConvP p, hipStream_t st) {
     if (grid >= 8) grid &= ~7L;
     const double flops = 2.0 * 9.0 * (double)p.N * p.Hb * p.Wb * p.IC * p.OC;
     const double out_px = (double)p.N * p.Hb * p.Wb * (MODE == MODE_T2 ? 4 : 1);
-    const double bytes = ((double)p.N * p.Hi * p.Wi * p.IC + out_px * p.OC + 9.0 * p.IC * p.OC) * sizeof(T);
+    // algorithmic bytes: input + output + weights, + the activation mask a masked launch reads, + the second output of a fused norm
+    const double bytes = ((double)p.N * p.Hi * p.Wi * p.IC + out_px * p.OC * (1.0 + (p.mask ? 1.0 : 0.0) + ((NORM && p.y) ? 1.0 : 0.0)) + 9.0 * p.IC * p.OC) * sizeof(T);
     ProfScope ps(st, flops, bytes);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, p);
     return 0;
