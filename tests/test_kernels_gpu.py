@@ -581,15 +581,15 @@ def test_gan_losses_in_one_launch(K, dtype):
     g_real, g_fake, g_pen = torch.autograd.grad(ld, [real, fake, pen])
     loss, kr, kf = K.gan_d_loss(dev(real.detach(), dtype), dev(fake.detach(), dtype), dev(lab, dtype), pen.detach().cuda())
     tol = 1e-5 if dtype == torch.float32 else 1e-2
-    assert abs(float(loss) - float(ld)) <= 1e-5 * abs(float(ld))
+    assert abs(float(loss) - float(ld.detach())) <= 1e-5 * abs(float(ld.detach()))
     close(kr, g_real, rel=tol, name="d loss: d/d real logits")
     close(kf, g_fake, rel=tol, name="d loss: d/d fake logits")
     assert torch.allclose(g_pen, torch.full((n,), 1.0 / n))
     lg = (TF.softplus(-(fake * lab).sum(1)) + 0.1 / (ssq + 1e-6)).mean()
     g_fake2, g_ssq = torch.autograd.grad(lg, [fake, ssq])
     loss, kf, ks = K.gan_g_loss(dev(fake.detach(), dtype), dev(lab, dtype), ssq.detach().cuda(), 0.1, 1e-6)
-    assert abs(float(loss) - float(lg)) <= 1e-5 * abs(float(lg))
+    assert abs(float(loss) - float(lg.detach())) <= 1e-5 * abs(float(lg.detach()))
     close(kf, g_fake2, rel=tol, name="g loss: d/d fake logits")
     close(ks, g_ssq, rel=1e-5, name="g loss: d/d sumsq")
     loss, kf, ks = K.gan_g_loss(dev(fake.detach(), dtype), dev(lab, dtype), None, 0.0, 1e-6)
-    assert ks is None and abs(float(loss) - float(TF.softplus(-(fake * lab).sum(1)).mean())) <= 1e-5
+    assert ks is None and abs(float(loss) - float(TF.softplus(-(fake.detach() * lab).sum(1)).mean())) <= 1e-5
