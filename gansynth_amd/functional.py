@@ -133,6 +133,9 @@ def _accum_target(param):
     return g
 
 
+_DERIVED_SLICES = not __import__("os").environ.get("GS_NO_DERIVED_SLICES")   # A/B switch for measurements
+
+
 class _WeightSlice(Function):
     """w[:, :, lo:hi, :] as a contiguous kernel operand (the 257-input-channel conv of the last discriminator block is evaluated
     as two convs on slices of one variable).  Plain backward: the slice's gradient is added straight into that slice of w.grad
@@ -141,6 +144,9 @@ class _WeightSlice(Function):
     @staticmethod
     def forward(ctx, w, lo, hi):
         ctx.lo, ctx.hi, ctx.wref = lo, hi, w
+        K = _K()
+        if _DERIVED_SLICES and hasattr(K, "derived_slice"):   # persistent copy, refreshed with the parameter (kernels.derived_slice)
+            return K.derived_slice(w, lo, hi)
         return w[:, :, lo:hi, :].contiguous()
 
     @staticmethod

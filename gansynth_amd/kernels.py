@@ -76,6 +76,7 @@ class HipKernels(object):
         self._param_ranges = []   # (ptr, nbytes) of registered flat parameter buffers
         self._wcache = {}         # (weight ptr, map tag) -> (persistent workspace holding the re-laid operand, stamp)
         self._prep_tables = {}    # tuple of cache keys -> device table of GsPrepDesc rows (refresh_weights)
+        self._derived = {}        # (parent weight ptr, lo, hi) -> [contiguous slice buffer, stamp, parent, lo, hi] (derived_slice)
         self._pending = None      # deferred weight gradients while deferring: {layer key: {out, bias, [(x, gy, with bias)]}}
 
     # --------------------------------------------------------- prepared-weight workspaces
@@ -109,9 +110,48 @@ class HipKernels(object):
         self._prep_tables.clear()
         return self._wcache[key][0], 0
 
+    def _stamp(self, w):
+        ptr = w.data_ptr()
+        rng = next((r for r in self._param_ranges if r[0] <= ptr < r[0] + r[1]), None)
+        return (None if rng is None else rng[2], w._version)
+
+    def derived_slice(self, w, lo, hi):
+        """A persistent contiguous copy of w[:, :, lo:hi, :] (the 257-input-channel conv of the last discriminator block runs as
+        two convs on slices of ONE variable): refreshed when the parent changes -- here on use, and by refresh_weights() right
+        after an optimizer step -- so that a pass neither copies the slice nor re-lays its kernel operands every time, and a
+        captured graph contains neither.  Returns an alias (fresh tensor object, same storage)."""
+        key = (w.data_ptr(), int(lo), int(hi))
+        ent = self._derived.get(key)
+        stamp = self._stamp(w)
+        with torch.no_grad():
+            if ent is None or ent[0].shape[2] != hi - lo or ent[0].shape != w[:, :, lo:hi, :].shape:
+                buf = w.detach()[:, :, lo:hi, :].contiguous()
+                self.register_param_buffer(buf)
+                ent = self._derived[key] = [buf, stamp, w, int(lo), int(hi)]
+            elif ent[1] != stamp:
+                self._refresh_derived(ent, w)
+        return ent[0].detach()
+
+    def _refresh_derived(self, ent, w):
+        ent[0].copy_(w.detach()[:, :, ent[3]:ent[4], :])
+        ent[1], ent[2] = self._stamp(w), w
+        self.invalidate_weights(ent[0])
+
     def refresh_weights(self, flat=None):
         """Rebuild, in ONE launch, every stale prepared operand of the parameters living in `flat` (all registered
         buffers when None) -- called after an optimizer step instead of letting each conv re-lay its weight."""
+        if self._derived and not getattr(self, "_in_derived_refresh", False):   # slices of parameters first, then their operands
+            lo_, hi_ = (None, None) if flat is None else (flat.data_ptr(), flat.data_ptr() + flat.numel() * flat.element_size())
+            self._in_derived_refresh = True
+            try:
+                with torch.no_grad():
+                    for ent in self._derived.values():
+                        w = ent[2]
+                        if (lo_ is None or lo_ <= w.data_ptr() < hi_) and ent[1] != self._stamp(w):
+                            self._refresh_derived(ent, w)
+                            self.refresh_weights(ent[0])
+            finally:
+                self._in_derived_refresh = False
         ptr = None if flat is None else flat.data_ptr()
         stale = [k for k, e in self._wcache.items()
                  if e[3] is not None and (ptr is None or e[4][0] <= ptr < e[4][0] + e[4][1]) and e[1] != (e[4][2], e[2]._version)]
