@@ -24,6 +24,39 @@ def _K():
     return kernels.get()
 
 
+# ---- activation tap ---------------------------------------------------------------------------------------------------------
+# Parity tests compare this path with the oracle on the SAME linear pieces of leaky_relu (a pre-activation within an fp32 ulp
+# of 0 may fall on either side, which moves that unit's gradient 5x -- tests/test_model_gpu.py).  Inside `activation_tap()`
+# every forward network call records (name, [leaky_relu outputs in call order]); nothing else changes.
+class activation_tap(object):
+    active = None
+
+    def __init__(self):
+        self.calls = []
+
+    def __enter__(self):
+        activation_tap.active = self
+        return self
+
+    def __exit__(self, *exc):
+        activation_tap.active = None
+        return False
+
+    def masks(self):
+        """[(network name, [z > 0 as CPU bool tensors, logical layout])] -- what oracle.torch_ref.lrelu_tape("override") takes."""
+        return [(name, [(z > 0).cpu().contiguous() for z in zs]) for name, zs in self.calls]
+
+
+def tap_begin(name):
+    if activation_tap.active is not None:
+        activation_tap.active.calls.append((name, []))
+
+
+def _tap(z, act):
+    if activation_tap.active is not None and act == ACT_LRELU:
+        activation_tap.active.calls[-1][1].append(z.detach())
+
+
 # ------------------------------------------------------------------ bilinear map families
 class _ConvKind(object):
     """tf.nn.conv2d SAME (ops.py:237-243), ksize in {1,3}, stride in {1,2}."""
@@ -342,6 +375,7 @@ class _ConvBiasAct(Function):
         ctx._gs_act_out = act      # what consumers of z may fold into their own kernels
         ctx._gs_premasked = None
         z = kind.fwd_bias_act(x, w, bias, alpha, act)
+        _tap(z, act)
         ctx.save_for_backward(x, w, z)
         return z
 
@@ -424,13 +458,16 @@ class _ConvBiasActNorm(Function):
         ctx.kind, ctx.alpha, ctx.act, ctx.eps, ctx.has_bias = kind, alpha, act, eps, bias is not None
         ctx.wref, ctx.bref = w, bias
         ctx.set_materialize_grads(False)   # an absent gradient for z must arrive as None, not as a tensor of zeros
-        want_z = any(ctx.needs_input_grad)   # no backward (the no-grad generator pass of the D run): the activation is not kept
+        keep = any(ctx.needs_input_grad)   # no backward (the no-grad generator pass of the D run): the activation is not kept
+        want_z = keep or activation_tap.active is not None
         if _FUSE_NORM_EPILOGUE:
             z, y = kind.fwd_bias_act_norm(x, w, bias, alpha, act, eps, want_z)
         else:
             z = kind.fwd_bias_act(x, w, bias, alpha, act)
             y = _K().pixel_norm_fwd(z, eps)
         if want_z:
+            _tap(z, act)
+        if keep:
             ctx.save_for_backward(x, w, z)
         return y, z
 
@@ -550,6 +587,7 @@ class _BiasAct(Function):
     @staticmethod
     def forward(ctx, x, bias, act):
         z = _K().bias_act_fwd(x, bias, act)
+        _tap(z, act)
         ctx.act = act
         ctx.has_bias = bias is not None
         ctx.bref = bias

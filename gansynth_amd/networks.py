@@ -125,6 +125,7 @@ class PGGAN(object):
                     ops.get_bias([2])
 
     def generator(self, latents, labels, name="generator", reuse=AUTO_REUSE):
+        F.tap_begin("generator")
         with variable_scope(name, reuse=reuse):
             self._g_variables(latents.shape[1], labels.shape[1])
             embedded = ops.embedding(labels, units=latents.shape[1], variance_scale=1.0, scale_weight=True)
@@ -206,6 +207,7 @@ class PGGAN(object):
 
     def discriminator(self, images, labels, name="discriminator", reuse=AUTO_REUSE):
         num_labels = labels.shape[1]
+        F.tap_begin("discriminator")
         with variable_scope(name, reuse=reuse):
             self._d_variables(num_labels)
             head, fade = self._head_depth(self.growing_depth)
@@ -216,10 +218,11 @@ class PGGAN(object):
 
             if head == self.min_depth:
                 return self._d_conv_block(from_images(head), head, num_labels)
+            low = from_images(head - 1) if fade is not None else None   # lerp(low(), middle(), .): low first, like networks.py:271-275
             x = self._d_conv_block(from_images(head), head, num_labels, fresh_activation=True)
             fresh = fade is None
             if fade is not None:
-                x = ops.lerp(from_images(head - 1), x, fade if self.fade_weight is None else self.fade_weight)
+                x = ops.lerp(low, x, fade if self.fade_weight is None else self.fade_weight)
             for depth in range(head - 1, self.min_depth, -1):
                 x = self._d_conv_block(x, depth, num_labels, fresh_activation=fresh)
                 fresh = True

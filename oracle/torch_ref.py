@@ -87,8 +87,44 @@ def batch_stddev(x, groups=4, epsilon=1e-12):
     return y.repeat(groups, 1, *shape[2:])
 
 
+class lrelu_tape(object):
+    """Test instrumentation for the one ill-conditioned op of the graph.  leaky_relu is piecewise linear: a pre-activation
+    that differs in its last fp32 bits between two implementations can land on either side of 0, which moves that unit's
+    gradient 5x.  `lrelu_tape("record")` keeps, per network call (`calls[i] = (name, [x, ...])`, in call order), every
+    leaky_relu input; `lrelu_tape("override", masks)` evaluates leaky_relu as where(mask, x, 0.2 x) with the masks of another
+    implementation (same nesting), so that the two can be compared on the same linear pieces."""
+    active = None
+
+    def __init__(self, mode, masks=None):
+        self.mode, self.masks, self.calls = mode, masks, []
+        self._cursor = None
+
+    def __enter__(self):
+        lrelu_tape.active = self
+        return self
+
+    def __exit__(self, *exc):
+        lrelu_tape.active = None
+        return False
+
+    def begin(self, name):
+        self.calls.append((name, []))
+        if self.mode == "override":
+            want = self.masks[len(self.calls) - 1]
+            assert want[0] == name, (want[0], name)
+            self._cursor = iter(want[1])
+
+
 def leaky_relu(x):
-    return F.leaky_relu(x, 0.2)
+    tape = lrelu_tape.active
+    if tape is None:
+        return F.leaky_relu(x, 0.2)
+    if tape.mode == "record":
+        tape.calls[-1][1].append(x.detach())
+        return F.leaky_relu(x, 0.2)
+    mask = next(tape._cursor)
+    assert mask.shape == x.shape, (tuple(mask.shape), tuple(x.shape))
+    return torch.where(mask, x, x * 0.2)
 
 
 def lerp(a, b, t):
@@ -186,6 +222,8 @@ class PGGAN(object):
         """networks.py:31-161."""
         P = params
         gd = self.growing_depth
+        if lrelu_tape.active is not None:
+            lrelu_tape.active.begin("generator")
 
         def rname(depth):
             return "{}x{}".format(*self.resolution(depth))
@@ -234,6 +272,8 @@ class PGGAN(object):
         """networks.py:163-290."""
         P = params
         gd = self.growing_depth
+        if lrelu_tape.active is not None:
+            lrelu_tape.active.begin("discriminator")
 
         def rname(depth):
             return "{}x{}".format(*self.resolution(depth))
