@@ -43,23 +43,89 @@ def synthetic_pool(batch, rank, dtype, n=4):
     return pool
 
 
-def cpu_baseline():
-    """The CPU oracle (torch-CPU fp32 restatement of the reference graph) timed on this host's cores,
-    on a bounded sample: ONE iteration (D update + G update) at batch 4, fully grown 128x1024."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(batch=8, timed=2):
+    """The CPU oracle (torch-CPU fp32 restatement of the reference graph: the TF1 reference itself cannot run here, SURVEY.md
+    8c/D3) timed on this host's cores as SURVEY.md 8(d) specifies: batch 8, fully grown 128x1024x2, one warm-up iteration
+    (D update + G update, R1 + mode-seeking double-backward, TF-Adam) then `timed` timed ones."""
     from oracle import torch_ref as R
-    cores = min(os.cpu_count() or 1, 32)  # beyond ~32 threads torch-CPU conv backward stops scaling (256-thread run: 40x slower)
+    total = os.cpu_count() or 1
+    cores = min(total, 32)  # beyond ~32 threads torch-CPU conv backward stops scaling (a 256-thread run was 40x slower)
     torch.set_num_threads(cores)
     pg = R.PGGAN([2, 16], [128, 1024], 32, 256, 1.0)
     gp, dp = pg.init_params(seed=0)
     tr = R.Trainer(pg, gp, dp)
-    lat, lab, real = R.synthetic_batch(4)
-    t0 = time.time()
+    lat, lab, real = R.synthetic_batch(batch)
     tr.d_step(lat, lab, real)
     tr.g_step(lat, lab)
-    dt = time.time() - t0
-    return {"value": 4.0 / dt, "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": "1 iteration (D update + G update incl. R1 + mode-seeking double-backward, TF-Adam) at batch 4, "
-                      "fully grown 128x1024x2, fp32, torch-CPU oracle (oracle/torch_ref.py)"}
+    t0 = time.time()
+    for i in range(timed):
+        lat, lab, real = R.synthetic_batch(batch, rank=1 + i)
+        tr.d_step(lat, lab, real)
+        tr.g_step(lat, lab)
+    dt = (time.time() - t0) / timed
+    return {"value": batch / dt, "unit": "images/sec", "cores": cores, "kind": "port", "host_cores": total, "cpu_model": cpu_model(),
+            "seconds_per_iteration": dt,
+            "sample": "1 warm-up + %d timed iterations (D update + G update incl. R1 + mode-seeking double-backward, TF-Adam) at batch %d, "
+                      "fully grown 128x1024x2, fp32, torch-CPU oracle (oracle/torch_ref.py), %d threads" % (timed, batch, cores)}
+
+
+SPECTRAL_BYTES_PER_EXAMPLE = 64000 * 4 + 2 * 128 * 1024 * 4   # SURVEY.md 8(d): waveform read once + (log-mel, IF) written once, fp32
+
+
+def spectral_bench(batch=256, iters=20, cpu=True):
+    """BASELINE.json configs[3]: waveform [256, 64000] -> (log-mel, IF) images [256, 2, 128, 1024] (spectral_ops.py:45-94), one
+    fused HIP launch per batch, inputs resident in HBM.  HBM-bound by design (1.30 MB of algorithmic traffic per example); the
+    kernel is timed with HIP events on its launch stream."""
+    import numpy as np
+    from gansynth_amd import spectral_ops as G
+    P = dict(waveform_length=64000, sample_rate=16000, spectrogram_shape=[128, 1024], overlap=0.75)
+    rng = np.random.default_rng(4000)
+    w = np.clip(rng.normal(0.0, 0.1, (batch, 64000)), -1, 1).astype(np.float32)   # SURVEY.md 8(d) synthetic waveforms
+    x = torch.from_numpy(w).cuda()
+    for _ in range(3):
+        G.convert_to_images(x, **P)
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    t0 = time.perf_counter()
+    for s, e in evs:
+        s.record()
+        G.convert_to_images(x, **P)
+        e.record()
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / iters
+    kern_ms = sorted(s.elapsed_time(e) for s, e in evs)[iters // 2]   # median launch (event pair around each launch)
+    bytes_alg = batch * SPECTRAL_BYTES_PER_EXAMPLE
+    achieved = bytes_alg / (kern_ms * 1e-3) / 1e9
+    traffic = None
+    pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_spectral_pmc_traffic.json")))
+    if pmcs and batch == 256:
+        traffic = json.load(open(pmcs[-1]))["avg_hbm_bytes_per_launch"]
+    out = {"workload": "BASELINE.json configs[3]: %d x 64000-sample waveforms -> (log-mel, IF) [%d, 2, 128, 1024], fp32, one fused launch" % (batch, batch),
+           "value": batch / wall, "unit": "examples/sec", "us_per_batch": wall * 1e6, "dtype": "f32",
+           "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_GBPS, "unit": "GB/s", "frac": achieved / HBM_GBPS,
+                        "traffic": traffic, "traffic_source": "committed rocprofv3 PMC passes (profiles/, FETCH_SIZE x2 + WRITE_SIZE), not measured in this run",
+                        "algorithmic_bytes_per_launch": bytes_alg, "avg_launch_ms": kern_ms,
+                        "kernel": "stft_wave_kernel<float, 1> (framing + Hann + 2048-point real FFT + |.| / atan2 + mel gather + log / IF per wave)",
+                        "note": "the kernel is LDS-pipe / VALU bound, not HBM bound (profiles/r02_*_spectral_pmc.txt); frac is against the HBM roof SURVEY.md 8(d) prescribes"}}
+    if cpu:
+        from oracle import spectral_np as S
+        n = 16
+        t0 = time.time()
+        S.convert_to_spectrogram(w[:n], **P)
+        dt = time.time() - t0
+        out["cpu_baseline"] = {"value": n / dt, "unit": "examples/sec", "cores": 1, "kind": "port", "cpu_model": cpu_model(),
+                               "sample": "%d of the %d waveforms through the numpy oracle (oracle/spectral_np.py, fp32, one thread)" % (n, batch)}
+    return out
 
 
 def main():
@@ -71,12 +137,17 @@ def main():
     ap.add_argument("--dtype", choices=["f32", "bf16"], default=os.environ.get("GS_BENCH_DTYPE", "bf16"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graphs", action="store_true", help="launch every kernel eagerly instead of replaying hipGraphs")
+    ap.add_argument("--no-spectral", action="store_true", help="skip the configs[3] (waveform -> mel + IF) leg")
+    ap.add_argument("--spectral-only", action="store_true", help="run only the configs[3] leg and print its object")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
+    if args.spectral_only:
+        print(json.dumps(spectral_bench(cpu=not args.no_cpu_baseline)), flush=True)
+        return
     distributed = world > 1 or bool(os.environ.get("GS_BENCH_FORCE_DIST"))  # (the env switch exercises the RCCL path on one GPU)
     if distributed:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -166,6 +237,7 @@ def main():
             # time the binding roof allows, summed per launch, over the measured time.
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK[args.dtype], "unit": "TFLOP/s",
                          "frac": achieved / PEAK[args.dtype], "traffic": traffic,
+                         "traffic_source": "committed rocprofv3 PMC passes (profiles/r*_pmc_igemm_traffic.json: FETCH_SIZE x2 + WRITE_SIZE), not measured in this run",
                          "roof_frac": roof_ms / conv_ms if conv_ms > 0 else 0.0,
                          "hbm_bound_share_of_roof": roof_ms_hbm / roof_ms if roof_ms > 0 else 0.0,
                          "algorithmic_gbps": conv_bytes / (conv_ms * 1e-3) / 1e9 if conv_ms > 0 else 0.0, "hbm_peak_gbps": HBM_GBPS,
@@ -178,6 +250,8 @@ def main():
             "model_flops_utilization": value * FLOPS_PER_IMAGE / 1e12 / PEAK[args.dtype] / world,
             "losses": {"discriminator": float(d_loss), "generator": float(g_loss)},
         }
+        if world == 1 and not args.no_spectral:
+            out["spectral"] = spectral_bench(cpu=not args.no_cpu_baseline)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -6,12 +6,14 @@ OUT=${1:-..}
 mkdir -p obj
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result $GS_EXTRA_FLAGS"
 pids=()
-for f in conv_igemm conv_api elementwise small_ops spectral; do
+for f in conv_igemm conv_api elementwise small_ops spectral spectral_wave; do
   [ -f $f.hip ] || continue
-  if [ ! -f obj/$f.o ] || [ $f.hip -nt obj/$f.o ] || [ gs_common.h -nt obj/$f.o ] || [ conv_shared.h -nt obj/$f.o ] || [ ../../include/gansynth_hip.h -nt obj/$f.o ]; then
+  if [ ! -f obj/$f.o ] || [ $f.hip -nt obj/$f.o ] || [ gs_common.h -nt obj/$f.o ] || [ conv_shared.h -nt obj/$f.o ] || [ spectral_plan.h -nt obj/$f.o ] || [ ../../include/gansynth_hip.h -nt obj/$f.o ]; then
     EXTRA=""
     # MFMA accumulators in VGPRs (hipcc otherwise parks them in AGPRs and every epilogue value costs a v_accvgpr_read)
     [ $f = conv_igemm ] && EXTRA="-mllvm -amdgpu-mfma-vgpr-form"
+    # (complex arithmetic as float2: SLP-packing it into v_pk_* costs more register shuffling than it saves -- measured -8 %)
+    [ $f = spectral_wave ] && EXTRA="-fno-slp-vectorize $GS_SW_FLAGS"
     ( hipcc $FLAGS $EXTRA -c $f.hip -o obj/$f.o ) &
     pids+=($!)
   fi

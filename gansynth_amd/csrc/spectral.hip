@@ -11,20 +11,11 @@
 //  inverse         exp / cumsum prep, dense pinv(mel) contraction on fp32 MFMA (this one IS a
 //                  dense GEMM), packed inverse FFT, windowed overlap-add.
 #include "gs_common.h"
+#include "spectral_plan.h"
 
 #include <math.h>
+#include <stdlib.h>
 #include <vector>
-
-struct gs_spectral_plan {
-    int frame_length, frame_step, time_steps, nbins, log2h, maxnz;
-    float* hann;        // [frame_length]
-    float2* tw;         // [nbins/2]  exp(-2 pi i k / nbins)
-    float2* twp;        // [nbins+1]  exp(-2 pi i k / frame_length)
-    int* mel_idx;       // [maxnz][nbins] ELL by mel column, entry-major (lanes = consecutive mel bins read consecutive words)
-    float* mel_val;     // [maxnz][nbins]
-    float* pinv;        // [nbins][nbins] or nullptr
-    float* inv_window;  // [frame_length]
-};
 
 namespace gs {
 
@@ -341,6 +332,41 @@ extern "C" int gs_spectral_plan_create(gs_spectral_plan** out, int frame_length,
     GS_HIP_OK(hipMemcpy(p->twp, twp.data(), (H + 1) * sizeof(float2), hipMemcpyHostToDevice));
     GS_HIP_OK(hipMemcpy(p->mel_idx, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice));
     GS_HIP_OK(hipMemcpy(p->mel_val, val.data(), val.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (H == 1024 && !getenv("GS_SPECTRAL_GENERIC")) {
+        // wave-per-frame path (spectral_wave.hip): every mel column's non-zeros must be ONE run of linear bins, the longest run
+        // of each 128-column block as in the reference configuration
+        std::vector<int> lo(H, 0), len(H, 0);
+        bool ok = true;
+        for (int m = 0; m < H && ok; ++m) {
+            int first = -1, last = -1, c = 0;
+            for (int f = 0; f < H; ++f) if (mel_dense[(long)f * H + m] != 0.f) { if (first < 0) first = f; last = f; ++c; }
+            if (c) { lo[m] = first; len[m] = last - first + 1; ok = len[m] <= 8; }
+        }
+        if (ok) {
+            int tot = 0;
+            for (int j = 0; j < 8; ++j) {
+                int c = 1;
+                for (int m = 128 * j; m < 128 * (j + 1); ++m) c = len[m] > c ? len[m] : c;
+                p->mel_cnt[j] = c; p->mel_off[j] = tot; tot += c * 128;
+            }
+            std::vector<float> w(tot, 0.f);
+            for (int j = 0; j < 8; ++j)
+                for (int m = 128 * j; m < 128 * (j + 1); ++m) {
+                    if (lo[m] + p->mel_cnt[j] > H) lo[m] = H - p->mel_cnt[j];   // keep every gathered bin inside the row (weight 0 there)
+                    for (int e = 0; e < p->mel_cnt[j]; ++e) w[p->mel_off[j] + e * 128 + (m - 128 * j)] = mel_dense[(long)(lo[m] + e) * H + m];
+                }
+            std::vector<float2> t1k(1024);
+            for (int k = 0; k < 1024; ++k) t1k[k] = make_float2((float)cos(-2.0 * M_PI * k / 1024.0), (float)sin(-2.0 * M_PI * k / 1024.0));
+            p->mel_wtot = tot;
+            GS_HIP_OK(hipMalloc(&p->tw1k, 1024 * sizeof(float2)));
+            GS_HIP_OK(hipMalloc(&p->mel_lo, H * sizeof(int)));
+            GS_HIP_OK(hipMalloc(&p->mel_w, (size_t)tot * sizeof(float)));
+            GS_HIP_OK(hipMemcpy(p->tw1k, t1k.data(), 1024 * sizeof(float2), hipMemcpyHostToDevice));
+            GS_HIP_OK(hipMemcpy(p->mel_lo, lo.data(), H * sizeof(int), hipMemcpyHostToDevice));
+            GS_HIP_OK(hipMemcpy(p->mel_w, w.data(), (size_t)tot * sizeof(float), hipMemcpyHostToDevice));
+            p->fast = stft_wave_shape_ok(p->mel_cnt) ? 1 : 0;   // (the kernel's gather is unrolled for the reference configuration's shape)
+        }
+    }
     if (mel_pinv) {
         GS_HIP_OK(hipMalloc(&p->pinv, (size_t)H * H * sizeof(float)));
         GS_HIP_OK(hipMemcpy(p->pinv, mel_pinv, (size_t)H * H * sizeof(float), hipMemcpyHostToDevice));
@@ -353,6 +379,7 @@ extern "C" int gs_spectral_plan_destroy(gs_spectral_plan* p) {
     if (!p) return 0;
     hipFree(p->hann); hipFree(p->inv_window); hipFree(p->tw); hipFree(p->twp); hipFree(p->mel_idx); hipFree(p->mel_val);
     if (p->pinv) hipFree(p->pinv);
+    if (p->fast) { hipFree(p->tw1k); hipFree(p->mel_lo); hipFree(p->mel_w); }
     delete p;
     return 0;
 }
@@ -360,6 +387,7 @@ extern "C" int gs_spectral_plan_destroy(gs_spectral_plan* p) {
 extern "C" int gs_stft_fwd(const gs_spectral_plan* p, const float* wave, int batch, int wave_len, int front_pad, float* magnitude,
                            float* phase, void* stream) {
     GS_CHECK_ARG(p && batch > 0 && wave_len > 0, "stft_fwd: bad args");
+    if (p->fast) return launch_stft_wave_magphase(p, wave, batch, wave_len, front_pad, magnitude, phase, as_stream(stream));
     hipLaunchKernelGGL((stft_kernel<float, 0, 0>), dim3(p->time_steps, batch), dim3(256), 0, as_stream(stream), *p, wave, wave_len, front_pad,
                        magnitude, phase, (float*)nullptr);
     GS_CHECK_LAUNCH();
@@ -384,12 +412,14 @@ extern "C" int gs_if_unwrap(const gs_spectral_plan* p, const float* mel_phase, f
 }
 
 extern "C" size_t gs_stft_mel_if_workspace_bytes(const gs_spectral_plan* p, int batch) {
+    if (p && p->fast) return 0;   // the wave-per-frame path keeps the mel phases in registers
     return p ? (size_t)batch * p->time_steps * p->nbins * sizeof(float) : 0;
 }
 
 extern "C" int gs_stft_mel_if_fwd(const gs_spectral_plan* p, const float* wave, int batch, int wave_len, int front_pad, void* images,
                                   int dtype, void* ws, size_t ws_bytes, void* stream) {
     GS_CHECK_ARG(p && batch > 0 && wave_len > 0, "stft_mel_if_fwd: bad args");
+    if (p->fast) return launch_stft_wave_fused(p, wave, batch, wave_len, front_pad, images, dtype, as_stream(stream));
     if (ws_bytes < gs_stft_mel_if_workspace_bytes(p, batch)) return fail(GS_ERR_WORKSPACE, "stft_mel_if_fwd: workspace too small");
     hipStream_t st = as_stream(stream);
     float* mel_phase = (float*)ws;

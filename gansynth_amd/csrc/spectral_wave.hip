@@ -1,0 +1,415 @@
+// waveform -> (log-mel magnitude, instantaneous frequency), wave-per-frame path for 2048-sample frames (gfx950).
+// Reference: spectral_ops.py:45-94 (front pad, tf.signal.stft 2048/512 periodic Hann, drop DC, abs / angle, tensordot with the
+// mel matrix on magnitude AND phase, log + normalise, unwrap / diff along time).
+//
+// The path is VALU-bound (1024-point FFT + hypot / atan2 / log per bin: ~1900 vector instructions per frame and lane), and a
+// gfx950 wave issues at most one VALU instruction per ~5 cycles whatever its ILP while four waves per SIMD issue four
+// (scripts/probe/valu_rate.hip).  So the design target is FOUR WAVES PER SIMD: <= 128 VGPRs and <= 10 KB of LDS per wave.
+//
+// One WAVEFRONT owns a frame; nothing is shared between the waves of a block except read-only tables, so there is no
+// s_barrier after the prologue.  Per frame:
+//   A  lane l loads z[n] = x[2n] + i x[2n+1], n = l + 64 j (16 coalesced 8-byte loads), times the periodic Hann window
+//   B  16-point DFT over j in registers (radix 4 x 4), twiddle W_1024^(l k1)
+//   D  one transpose through LDS (8.5 KB, padded rows: conflict-free both ways): lane (k1, l') holds l = l' + 4 j'
+//   E  16-point DFT over j' in registers, twiddle W_64^(l' k2a)
+//   G  the last radix-4 runs ACROSS the four lanes of a quad with DPP quad_perm moves (no LDS)
+//   H  Z[k] to LDS in natural order;  I  real-FFT untangle on (k, 1024 - k) pairs: X[k] = E + W_2048^k O and
+//      X[1024 - k] = conj(E - W_2048^k O) share one complex multiply; |.| and atan2 (polynomial) -> (mag, phase) back to LDS
+//      in place (two halves ordered so that no unread Z is overwritten)
+//   J  mel projection as a gather: the non-zeros of a mel column are one run of <= 6 linear bins (2042 non-zeros in the
+//      1024 x 1024 matrix) -- never a dense GEMM;  K  log / normalise, IF, one 16-byte store per lane and 128-column block
+// The reference's IF is diff(unwrap(phase)) / pi with unwrap = phase + cumsum(wrap(d) - d); in exact arithmetic that is
+// wrap(d) / pi with d = phase[t] - phase[t-1], which needs only the previous frame.  A wave therefore walks a RUN of
+// consecutive frames, keeps the previous frame's 16 mel phases per lane in registers and recomputes frame t0 - 1 once per
+// run; fp32 deviation from the cumsum form <= 1e-4 (|unwrapped| reaches a few hundred rad).
+#include "spectral_plan.h"
+
+namespace gs {
+
+#ifndef SW_WAVES
+#define SW_WAVES 12         // waves per block = per CU.  Measured at batch 256: 12 waves (3 per SIMD, <= 168 VGPRs) 126 us, 16 waves
+#endif                      // (128 VGPRs, Hann / run starts through L1) 149 us, 8 waves (256 VGPRs) 156 us: the LDS pipe is the bound
+#if SW_WAVES > 12           // 16 waves x 8.5 KB leave 24 KB of LDS for tables: the Hann window and the mel run starts stay in L1 / L2
+#define SW_TABLES_IN_LDS 0
+#else
+#define SW_TABLES_IN_LDS 1
+#endif
+#define SW_ROW 68           // float2 per transposed row: 64 + 4 pad (the k1 rows land on distinct bank groups)
+#define SW_BUF (16 * SW_ROW)
+#define SW_WTOT (22 * 128)  // floats of mel weights for SW_SHAPE
+
+// run lengths of the mel columns per 128-column block in the reference configuration (1024 mel bins over 0..8 kHz at 16 kHz):
+// compile-time, so the gather has no branch per bin.  Other mel shapes use the generic kernels of spectral.hip.
+__device__ constexpr int SW_SHAPE[8] = {1, 1, 2, 2, 3, 3, 4, 6};
+static const int SW_SHAPE_HOST[8] = {1, 1, 2, 2, 3, 3, 4, 6};
+
+// 8-byte LDS read that the backend will not pair into ds_read2_b64: the paired form moves 128 B/clk, two ds_read_b64 256 B/clk
+// (MI355X_MICROARCH.md, LDS table), and the LDS pipe is what bounds this kernel
+typedef float v2f_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float2 lds_ld(const float2* p) {
+    typedef const volatile __attribute__((address_space(3))) v2f_t* lds_ptr_t;   // (a volatile generic pointer would become a flat load)
+    const v2f_t t = *(lds_ptr_t)(p);
+    return make_float2(t.x, t.y);
+}
+
+__device__ __forceinline__ float2 cmulw(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+
+// forward 4-point DFT in place: (a, b, c, d) = x[0..3] -> X[0..3]
+__device__ __forceinline__ void dft4(float2& a, float2& b, float2& c, float2& d) {
+    const float2 s0 = make_float2(a.x + c.x, a.y + c.y), s1 = make_float2(a.x - c.x, a.y - c.y);
+    const float2 s2 = make_float2(b.x + d.x, b.y + d.y), s3 = make_float2(b.x - d.x, b.y - d.y);
+    a = make_float2(s0.x + s2.x, s0.y + s2.y);
+    c = make_float2(s0.x - s2.x, s0.y - s2.y);
+    b = make_float2(s1.x + s3.y, s1.y - s3.x);   // s1 - i s3
+    d = make_float2(s1.x - s3.y, s1.y + s3.x);   // s1 + i s3
+}
+
+// forward 16-point DFT in place, input v[n] natural; output position p holds X[KPOS(p)], KPOS(p) = (p >> 2) + 4 (p & 3)
+#define KPOS(p) (((p) >> 2) + 4 * ((p) & 3))
+__device__ __forceinline__ void dft16(float2 (&v)[16]) {
+    const float c1 = 0.92387953251128674f, s1 = 0.38268343236508977f, r = 0.70710678118654752f;
+#pragma unroll
+    for (int n2 = 0; n2 < 4; ++n2) dft4(v[n2], v[n2 + 4], v[n2 + 8], v[n2 + 12]);   // v[n2 + 4 k1]
+    float2 t;
+    t = v[5];  v[5]  = make_float2(t.x * c1 + t.y * s1, t.y * c1 - t.x * s1);       // W16^1 = (c1, -s1)
+    t = v[9];  v[9]  = make_float2(r * (t.x + t.y), r * (t.y - t.x));                // W16^2 = (r, -r)
+    t = v[13]; v[13] = make_float2(t.x * s1 + t.y * c1, t.y * s1 - t.x * c1);       // W16^3 = (s1, -c1)
+    t = v[6];  v[6]  = make_float2(r * (t.x + t.y), r * (t.y - t.x));                // W16^2
+    t = v[10]; v[10] = make_float2(t.y, -t.x);                                       // W16^4 = -i
+    t = v[14]; v[14] = make_float2(r * (t.y - t.x), -r * (t.x + t.y));               // W16^6 = (-r, -r)
+    t = v[7];  v[7]  = make_float2(t.x * s1 + t.y * c1, t.y * s1 - t.x * c1);       // W16^3
+    t = v[11]; v[11] = make_float2(r * (t.y - t.x), -r * (t.x + t.y));               // W16^6
+    t = v[15]; v[15] = make_float2(-t.x * c1 - t.y * s1, t.x * s1 - t.y * c1);       // W16^9 = (-c1, s1)
+#pragma unroll
+    for (int k1 = 0; k1 < 4; ++k1) dft4(v[4 * k1], v[4 * k1 + 1], v[4 * k1 + 2], v[4 * k1 + 3]);
+}
+
+template <int CTRL>
+__device__ __forceinline__ float quad_mov(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false));
+}
+
+// atan2 with |error| <= 2e-7 rad: odd minimax polynomial of degree 15 on [0, 1] + octant reduction; (0, 0) -> 0 like np.angle
+__device__ __forceinline__ float atan2_poly(float y, float x) {
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    const float t = mn * __builtin_amdgcn_rcpf(mx);
+    const float s = t * t;
+    float r = -0.00405456405133009f;
+    r = fmaf(r, s, 0.021862946450710297f);
+    r = fmaf(r, s, -0.055912308394908905f);
+    r = fmaf(r, s, 0.09642195701599121f);
+    r = fmaf(r, s, -0.1390862911939621f);
+    r = fmaf(r, s, 0.19946566224098206f);
+    r = fmaf(r, s, -0.33329859375953674f);
+    r = fmaf(r, s, 0.9999993443489075f);
+    r *= t;
+    r = ay > ax ? 1.57079637050628662f - r : r;
+    r = x < 0.f ? 3.14159274101257324f - r : r;
+    r = mx == 0.f ? 0.f : r;
+    return copysignf(r, y);
+}
+
+// Samples of one frame, lane l holding z[n] = (x[2n], x[2n+1]) for n = l + 64 j (zeros outside the waveform).
+__device__ __forceinline__ void load_frame(const float* __restrict__ wv, int wave_len, int base, bool vec_ok, int lane, float2 (&xs)[16]) {
+    if (base + 2048 <= 0 || base >= wave_len) {   // entirely inside the padding
+#pragma unroll
+        for (int j = 0; j < 16; ++j) xs[j] = make_float2(0.f, 0.f);
+    } else if (vec_ok && base >= 0 && base + 2048 <= wave_len) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) xs[j] = *reinterpret_cast<const float2*>(wv + base + 2 * (lane + 64 * j));
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int s0 = base + 2 * (lane + 64 * j);
+            xs[j].x = (s0 >= 0 && s0 < wave_len) ? wv[s0] : 0.f;
+            xs[j].y = (s0 + 1 >= 0 && s0 + 1 < wave_len) ? wv[s0 + 1] : 0.f;
+        }
+    }
+}
+
+// One frame: windowed samples v (consumed) -> buf[k] = (|X[k]|, arg X[k]) for bins k = 1..1024 (this wave's LDS buffer).
+//   s_twc: W_1024^(lane * KPOS(q)) as [q][lane];  s_twf: W_64^k (k < 64);  s_twu: W_2048^k (k < 512), all in LDS
+__device__ __forceinline__ void frame_to_magphase(float2 (&v)[16], const float2* s_twc, const float2* s_twf, const float2 (&twu)[8],
+                                                  float2* buf, int lane) {
+    // B: DFT over j, twiddle W_1024^(l k1)
+    dft16(v);
+#pragma unroll
+    for (int q = 1; q < 16; ++q) v[q] = cmulw(v[q], lds_ld(s_twc + 64 * q + lane));
+    __builtin_amdgcn_sched_barrier(0);
+    // D: transpose.  write Y[l][k1] at k1 * ROW + l; lane (k1 = lane >> 2, l' = lane & 3) reads l = l' + 4 j'
+#pragma unroll
+    for (int q = 0; q < 16; ++q) buf[KPOS(q) * SW_ROW + lane] = v[q];
+    {
+        const float2* src = buf + (lane >> 2) * SW_ROW + (lane & 3);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = lds_ld(src + 4 * j);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // E: DFT over j', twiddle W_64^(l' k2a)
+    dft16(v);
+    {
+        const int lq = lane & 3;
+#pragma unroll
+        for (int q = 1; q < 16; ++q) v[q] = cmulw(v[q], lds_ld(s_twf + lq * KPOS(q)));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // G: radix 4 across the quad.  after it lane l' holds k2b = bitrev2(l')
+    {
+        const int lq = lane & 3;
+        const float sa = (lq & 2) ? -1.f : 1.f;
+        const float sb = (lq & 1) ? -1.f : 1.f;
+        const bool rot = lq == 3;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const float ux = fmaf(sa, v[q].x, quad_mov<0x4E>(v[q].x));   // own +- partner (lane ^ 2)
+            const float uy = fmaf(sa, v[q].y, quad_mov<0x4E>(v[q].y));
+            const float rx = rot ? uy : ux, ry = rot ? -ux : uy;         // lane 3: times -i
+            v[q].x = fmaf(sb, rx, quad_mov<0xB1>(rx));                   // own +- partner (lane ^ 1)
+            v[q].y = fmaf(sb, ry, quad_mov<0xB1>(ry));
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // H: Z[k], k = k1 + 16 k2a + 256 k2b, at P(k) = k + 4 (k >> 8) (the four k2b planes on distinct bank groups)
+    {
+        const int lq = lane & 3;
+        const int k2b = ((lq & 1) << 1) | (lq >> 1);
+        float2* dst = buf + (lane >> 2) + k2b * 260;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) dst[16 * KPOS(q)] = v[q];
+    }
+    // I: untangle the packed real FFT on pairs (ka, 1024 - ka), ka = lane + 64 i; (mag, phase) of bin k goes to buf[k], in
+    // place over Z.  Half A (i = 4..7) reads P in [260, 780] and writes [256, 511] + [513, 768]; half B (i = 0..3) reads
+    // [0, 255] + [781, 1035] + P(0), untouched by A's writes, and writes [1, 255] + 512 + [769, 1024].  Within a half every
+    // read precedes every write in program order (LDS executes a wave's accesses in order).
+    const float2 z512 = buf[512 + 8];
+#pragma unroll
+    for (int half = 1; half >= 0; --half) {
+        __builtin_amdgcn_sched_barrier(0);
+        float2 z1[4], z2[4], oa[4], ob[4];
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            const int i = 4 * half + ii;
+            const int ka = lane + 64 * i;
+            const int kb = (1024 - ka) & 1023;
+            z1[ii] = lds_ld(buf + ka + 4 * (i >> 2));
+            z2[ii] = lds_ld(buf + kb + 4 * (kb >> 8));
+        }
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            const int i = 4 * half + ii;
+            const float2 e = make_float2(0.5f * (z1[ii].x + z2[ii].x), 0.5f * (z1[ii].y - z2[ii].y));    // (Z[k] + conj Z[N-k]) / 2
+            const float2 o = make_float2(0.5f * (z1[ii].y + z2[ii].y), -0.5f * (z1[ii].x - z2[ii].x));   // (Z[k] - conj Z[N-k]) / 2i
+            const float2 t = cmulw(twu[i], o);
+            float2 xa = make_float2(e.x + t.x, e.y + t.y);          // X[ka]
+            const float2 xb = make_float2(e.x - t.x, t.y - e.y);    // X[1024 - ka] = conj(E - T)
+            if (i == 0 && lane == 0) xa = make_float2(z512.x, -z512.y);   // the ka = 0 slot carries bin 512 = conj(Z[512]); its xb is bin 1024
+            oa[ii] = make_float2(__builtin_amdgcn_sqrtf(xa.x * xa.x + xa.y * xa.y), atan2_poly(xa.y, xa.x));
+            ob[ii] = make_float2(__builtin_amdgcn_sqrtf(xb.x * xb.x + xb.y * xb.y), atan2_poly(xb.y, xb.x));
+        }
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            const int i = 4 * half + ii;
+            const int ka = lane + 64 * i;
+            buf[(i == 0 && lane == 0) ? 512 : ka] = oa[ii];
+            buf[1024 - ka] = ob[ii];
+        }
+    }
+}
+
+// LDS carve (bytes): mel weights | mel run starts (u16) | W_64 | W_2048 (k < 512) | W_1024^(lane k1) | Hann half table | wave buffers
+#define SW_LDS_W 0
+#define SW_LDS_LO (SW_LDS_W + SW_WTOT * 4)
+#define SW_LDS_TWF (SW_LDS_LO + (SW_TABLES_IN_LDS ? 1024 * 2 : 0))
+#define SW_LDS_TWU (SW_LDS_TWF + 64 * 8)
+#define SW_LDS_TWC (SW_LDS_TWU + 512 * 8)
+#define SW_LDS_HANN (SW_LDS_TWC + 16 * 64 * 8)
+#define SW_LDS_BUF (SW_LDS_HANN + (SW_TABLES_IN_LDS ? 1040 * 4 : 0))
+#define SW_LDS_TOTAL (SW_LDS_BUF + SW_WAVES * SW_BUF * 8)
+
+// MODE 1: images[b][T][1024][2] = (log-mel, IF);  MODE 0: o0 / o1 = magnitude / phase [b][T][1024]
+template <typename T, int MODE>
+__global__ __launch_bounds__(64 * SW_WAVES) void stft_wave_kernel(const float* __restrict__ hann, const float2* __restrict__ tw1k,
+                                                                  const float2* __restrict__ twp, const int* __restrict__ mel_lo,
+                                                                  const float* __restrict__ mel_w, int TT, int step,
+                                                                  const float* __restrict__ wave, int wave_len, int front_pad,
+                                                                  int batch, int runs, float* __restrict__ o0, float* __restrict__ o1,
+                                                                  T* __restrict__ images) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* s_w = reinterpret_cast<float*>(smem + SW_LDS_W);
+    unsigned short* s_lo = reinterpret_cast<unsigned short*>(smem + SW_LDS_LO);
+    float2* s_twf = reinterpret_cast<float2*>(smem + SW_LDS_TWF);
+    float2* s_twu = reinterpret_cast<float2*>(smem + SW_LDS_TWU);
+    float2* s_twc = reinterpret_cast<float2*>(smem + SW_LDS_TWC);   // [q][lane] = W_1024^(lane KPOS(q))
+    float* s_hann = reinterpret_cast<float*>(smem + SW_LDS_HANN);   // w[0..1024]; w[i] = w[2048 - i] beyond
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    float2* buf = reinterpret_cast<float2*>(smem + SW_LDS_BUF) + wid * SW_BUF;
+    for (int i = threadIdx.x; i < 1024; i += 64 * SW_WAVES) {
+        if (SW_TABLES_IN_LDS) {
+            s_hann[i] = hann[i];
+            if (i == 0) s_hann[1024] = hann[1024];
+            if (MODE == 1) s_lo[i] = (unsigned short)mel_lo[i];
+        }
+        if (i < 64) s_twf[i] = tw1k[16 * i];
+        if (i < 512) s_twu[i] = twp[i];
+        s_twc[i] = tw1k[(i & 63) * KPOS(i >> 6)];
+    }
+    if (MODE == 1)
+        for (int k = threadIdx.x; k < SW_WTOT; k += 64 * SW_WAVES) s_w[k] = mel_w[k];
+    __syncthreads();   // the only block-level barrier
+    const long wr = (long)blockIdx.x * SW_WAVES + wid;
+    if (wr >= (long)batch * runs) return;
+    // frames of an example split into `runs` runs as evenly as possible: the first (TT % runs) runs have one frame more
+    const int b = (int)(wr / runs), r = (int)(wr % runs);
+    const int q = TT / runs, rem = TT % runs;
+    const int t0 = r * q + min(r, rem);
+    const int t1 = t0 + q + (r < rem ? 1 : 0);
+    const float* wv = wave + (long)b * wave_len;
+    const bool vec_ok = ((step | front_pad | wave_len) & 1) == 0;
+
+    float2 twu[8];   // W_2048^(lane + 64 i): lane constants, kept in registers (the LDS pipe is the bound of this kernel)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) twu[i] = s_twu[lane + 64 * i];
+    int2 lo[8];
+    if (MODE == 1) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) lo[j] = *reinterpret_cast<const int2*>(mel_lo + 128 * j + 2 * lane);
+    }
+    float prev[16];
+    if (MODE == 1) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) prev[j] = 0.f;
+    }
+    const float pi = 3.14159274101257324f;   // float32(np.pi), the constant the reference's unwrap uses
+    const float two_pi = pi * 2.0f;
+
+    const int tfirst = (MODE == 1 && t0 > 0) ? t0 - 1 : t0;
+    for (int t = tfirst; t < t1; ++t) {
+        const bool lead = t < t0;                       // frame t0 - 1: only its mel phases are needed
+        const int base = t * step - front_pad;
+        const bool silent = base + 2048 <= 0 || base >= wave_len;   // entirely inside the padding: spectrum exactly 0
+        if (!silent) {
+            float2 v[16], xs[16];
+            load_frame(wv, wave_len, base, vec_ok, lane, xs);   // (no software prefetch: the other three waves of the SIMD cover the latency)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int n = lane + 64 * j;
+                float2 h;
+                if (!SW_TABLES_IN_LDS) h = *reinterpret_cast<const float2*>(hann + 2 * n);   // (8 KB table shared by every wave: L1)
+                else if (j < 8) h = *reinterpret_cast<const float2*>(s_hann + 2 * n);        // w[2n], w[2n+1]
+                else h = make_float2(s_hann[2048 - 2 * n], s_hann[2047 - 2 * n]);             // symmetric half
+                v[j] = make_float2(xs[j].x * h.x, xs[j].y * h.y);
+            }
+            frame_to_magphase(v, s_twc, s_twf, twu, buf, lane);
+        }
+        const long row = ((long)b * TT + t) * 1024;
+        if (MODE == 0) {
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                const int f = 4 * lane + 256 * qq;   // bins f+1 .. f+4
+                float4 mg = make_float4(0.f, 0.f, 0.f, 0.f), ph = mg;
+                if (!silent) {
+                    const float2 a = buf[f + 1], c = buf[f + 2], d = buf[f + 3], e = buf[f + 4];
+                    mg = make_float4(a.x, c.x, d.x, e.x);
+                    ph = make_float4(a.y, c.y, d.y, e.y);
+                }
+                *reinterpret_cast<float4*>(o0 + row + f) = mg;
+                *reinterpret_cast<float4*>(o1 + row + f) = ph;
+            }
+            continue;
+        }
+        // J: mel projection of magnitude and phase; lane owns columns m = 128 j + 2 lane + {0, 1}
+        int off = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float am0 = 0.f, ap0 = 0.f, am1 = 0.f, ap1 = 0.f;
+            if (!silent) {
+                const float* wj = s_w + off + 2 * lane;
+                const float2* ma = buf + 1 + lo[j].x;
+                const float2* mb = buf + 1 + lo[j].y;
+#pragma unroll
+                for (int e = 0; e < SW_SHAPE[j]; ++e) {   // ascending bins: the order of the oracle's dot product over the non-zeros
+                    const float2 w2 = lds_ld(reinterpret_cast<const float2*>(wj + 128 * e));
+                    const float2 xa = lds_ld(ma + e), xb = lds_ld(mb + e);
+                    am0 = fmaf(w2.x, xa.x, am0); ap0 = fmaf(w2.x, xa.y, ap0);
+                    am1 = fmaf(w2.y, xb.x, am1); ap1 = fmaf(w2.y, xb.y, ap1);
+                }
+            }
+            off += 128 * SW_SHAPE[j];
+            // K: spectral_ops.py:88-92 and :21-44
+            float vif[2];
+            const float ap[2] = {ap0, ap1};
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float d = ap[e] - prev[2 * j + e];
+                const float x = d + pi;
+                float md = fmaf(-floorf(x * 0.15915494309189535f), two_pi, x);   // floor-mod(d + pi, 2 pi) (exact: one fma)
+                if (md < 0.f) md += two_pi;
+                if (md >= two_pi) md -= two_pi;
+                md -= pi;
+                if (md == -pi && d > 0.f) md = pi;
+                vif[e] = (t == 0 ? ap[e] : md) * 0.31830988618379069f;
+                prev[2 * j + e] = ap[e];
+            }
+            if (!lead) {
+                const float l0 = (__builtin_amdgcn_logf(am0 + 1.0e-6f) * 0.69314718055994531f + 3.76f) * (1.0f / 10.05f);
+                const float l1 = (__builtin_amdgcn_logf(am1 + 1.0e-6f) * 0.69314718055994531f + 3.76f) * (1.0f / 10.05f);
+                const float o[4] = {l0, vif[0], l1, vif[1]};
+                st4(images + (row + 128 * j + 2 * lane) * 2, o);
+            }
+        }
+    }
+}
+
+// runs per example: enough wave-runs to fill SW_WAVES waves on every CU (a run of R frames costs R + 1 transforms), at most one per frame
+static int runs_per_example(int batch, int time_steps) {
+    int runs = (256 * SW_WAVES + batch - 1) / batch;
+    if (runs > time_steps) runs = time_steps;
+    if (runs < 1) runs = 1;
+    return runs;
+}
+
+template <typename KernT>
+static int set_lds(KernT kern, size_t bytes) {
+    static bool done = false;   // per kernel instantiation
+    if (done) return 0;
+    if (bytes > 65536 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
+        return fail(GS_ERR_HIP, "stft_wave: cannot reserve %zu bytes of LDS", bytes);
+    done = true;
+    return 0;
+}
+
+bool stft_wave_shape_ok(const int* cnt) {
+    for (int j = 0; j < 8; ++j) if (cnt[j] != SW_SHAPE_HOST[j]) return false;
+    return true;
+}
+
+int launch_stft_wave_fused(const gs_spectral_plan* p, const float* wave, int batch, int wave_len, int front_pad, void* images, int dtype,
+                           hipStream_t st) {
+    const int runs = runs_per_example(batch, p->time_steps);
+    const long nruns = (long)batch * runs;
+    GS_DISPATCH_DTYPE(dtype, {
+        auto kern = stft_wave_kernel<T, 1>;
+        if (int e = set_lds(kern, SW_LDS_TOTAL)) return e;
+        hipLaunchKernelGGL(kern, dim3((unsigned)cdiv(nruns, SW_WAVES)), dim3(64 * SW_WAVES), SW_LDS_TOTAL, st, (const float*)p->hann,
+                           (const float2*)p->tw1k, (const float2*)p->twp, (const int*)p->mel_lo, (const float*)p->mel_w, p->time_steps,
+                           p->frame_step, wave, wave_len, front_pad, batch, runs, (float*)nullptr, (float*)nullptr, (T*)images);
+    });
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+int launch_stft_wave_magphase(const gs_spectral_plan* p, const float* wave, int batch, int wave_len, int front_pad, float* mag, float* phase,
+                              hipStream_t st) {
+    const int runs = runs_per_example(batch, p->time_steps);
+    const long nruns = (long)batch * runs;
+    auto kern = stft_wave_kernel<float, 0>;
+    if (int e = set_lds(kern, SW_LDS_TOTAL)) return e;
+    hipLaunchKernelGGL(kern, dim3((unsigned)cdiv(nruns, SW_WAVES)), dim3(64 * SW_WAVES), SW_LDS_TOTAL, st, (const float*)p->hann,
+                       (const float2*)p->tw1k, (const float2*)p->twp, (const int*)p->mel_lo, (const float*)p->mel_w, p->time_steps, p->frame_step,
+                       wave, wave_len, front_pad, batch, runs, mag, phase, (float*)nullptr);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace gs
