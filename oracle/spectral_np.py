@@ -150,8 +150,10 @@ def inverse_stft(stfts, frame_length, frame_step, dtype=np.float32):
     return out
 
 
-def convert_to_waveform(log_mel, mel_if, waveform_length, sample_rate, spectrogram_shape, overlap, dtype=np.float32):
-    """spectral_ops.py:97-149."""
+def convert_to_waveform(log_mel, mel_if, waveform_length, sample_rate, spectrogram_shape, overlap, dtype=np.float32,
+                        mel_inverse=None):
+    """spectral_ops.py:97-149.  `mel_inverse`: use this pinv(mel) (cast to `dtype`) instead of building one in `dtype` -- the
+    float64 twin of a float32 run must contract with the SAME float32-built matrix to isolate arithmetic error."""
     dt = np.dtype(dtype).type
     pi = dt(np.float32(np.pi)) if dtype == np.float32 else dt(np.pi)
     time_steps, nbins, frame_length, frame_step, num_samples = _params(spectrogram_shape, overlap)
@@ -160,7 +162,7 @@ def convert_to_waveform(log_mel, mel_if, waveform_length, sample_rate, spectrogr
     mel_mag = np.exp(log_mel)                                             # :110
     mel_phase = np.cumsum(mel_if * pi, axis=-2, dtype=dtype)              # :111
     mel = linear_to_mel_weight_matrix(nbins, nbins, sample_rate, 0.0, sample_rate / 2.0, dtype)
-    mel_inv = pinv(mel)                                                   # :122
+    mel_inv = pinv(mel) if mel_inverse is None else np.asarray(mel_inverse, dtype=dtype)   # :122
     mag = (mel_mag @ mel_inv).astype(dtype)                               # :123
     phase = (mel_phase @ mel_inv).astype(dtype)                           # :125
     s = mag * (np.cos(phase) + 1j * np.sin(phase))                        # :128

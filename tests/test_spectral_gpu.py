@@ -21,8 +21,40 @@ def waves():
 
 
 def wrap2(d):
-    """IF differences are compared modulo 2 (a +-pi branch flip of an ill-conditioned phase is a 2.0 jump)."""
+    """An IF difference modulo 2 (a +-pi branch flip is a 2.0 jump) -- only applied to bins PROVEN ill-conditioned, see
+    if_conditioning."""
     return (d + 1.0) % 2.0 - 1.0
+
+
+def if_conditioning(st64, margin=1e-3, cut=1e-4):
+    """Where the reference's IF (spectral_ops.py:21-44) is discontinuous in its input, from the float64 oracle:
+      on_cut[b,t,m]  the wrapped phase difference sits within `margin` rad of +-pi: wrap() may take either branch (IF = +-1);
+      branch[b,t,m]  a linear bin feeding mel column m has |arg X| within `cut` of pi at frame t or t-1 (with magnitude): atan2
+                     may return +pi or -pi there, which moves the mel phase by 2 pi w -- NOT a multiple of 2 pi.
+    Everything else is well conditioned and must agree plainly."""
+    ph = st64["mel_phase"]
+    d = np.diff(ph, axis=-2)
+    md = np.mod(d + np.pi, 2 * np.pi) - np.pi
+    on_cut = np.zeros(ph.shape, bool)
+    on_cut[:, 1:] = np.pi - np.abs(md) < margin
+    lin, mag = st64["phase"], st64["magnitude"]
+    near = (np.pi - np.abs(lin) < cut) & (mag > 1e-6 * mag.max())
+    hit = (near.astype(np.float64) @ (st64["mel"] != 0).astype(np.float64)) > 0          # [b, t, m]
+    branch = hit.copy()
+    branch[:, 1:] |= hit[:, :-1]
+    return on_cut, branch
+
+
+def check_if(got, ref, on_cut, branch, where=None, tol=1e-3, max_branch=2e-3):
+    """IF parity: plain on the well-conditioned bins, modulo 2 on the branch cut of wrap(), nothing on atan2 branch hits; the
+    ill-conditioned sets must stay the small sets they are."""
+    where = np.ones(ref.shape, bool) if where is None else where
+    plain = where & ~on_cut & ~branch
+    assert np.abs(got - ref)[plain].max() < tol, np.abs(got - ref)[plain].max()
+    cut = where & on_cut & ~branch
+    if cut.any():
+        assert np.abs(wrap2(got - ref))[cut].max() < tol
+    assert on_cut[where].mean() < 2e-3 and branch[where].mean() < max_branch, (on_cut[where].mean(), branch[where].mean())
 
 
 def test_stagewise_vs_oracle():
@@ -41,8 +73,7 @@ def test_stagewise_vs_oracle():
     mm = G.mel_project(torch.from_numpy(st["magnitude"]).cuda(), **P).cpu().numpy()
     assert np.abs(mm - st["mel_magnitude"]).max() <= 1e-5 * st["mel_magnitude"].max()
     mi = G.instantaneous_frequency(torch.from_numpy(st["mel_phase"]).cuda(), **P).cpu().numpy()
-    d = wrap2(mi - st["mel_if"])
-    assert np.abs(d).max() < 1e-3, np.abs(d).max()
+    assert np.abs(mi - st["mel_if"]).max() < 1e-5, np.abs(mi - st["mel_if"]).max()   # same inputs, same fp32 recurrence: no modulo
 
 
 def test_fused_vs_oracle_and_golden():
@@ -58,10 +89,12 @@ def test_fused_vs_oracle_and_golden():
     lm, mi = G.convert_to_spectrogram(torch.from_numpy(w).cuda(), **P)
     lm, mi = lm.cpu().numpy(), mi.cpu().numpy()
     assert lm.shape == mi.shape == (2, 128, 1024)
+    on_cut, branch = if_conditioning(st64)
     # noise: everywhere
     assert np.abs(lm[1] - st["log_mel"][1]).max() < 1e-3
     assert np.abs(lm[1] - st64["log_mel"][1]).max() < 1e-3
-    assert np.abs(wrap2(mi[1] - st["mel_if"][1])).max() < 1e-3
+    check_if(mi[1], st64["mel_if"][1], on_cut[1], branch[1])
+    check_if(mi[1], st["mel_if"][1], on_cut[1], branch[1])
     # tone: linear domain everywhere, log/IF where there is signal
     mel_lin = np.exp(lm * 10.05 - 3.76) - 1e-6
     for i in range(2):
@@ -69,12 +102,15 @@ def test_fused_vs_oracle_and_golden():
         assert np.abs(mel_lin[i] - ref).max() <= 3e-4 * ref.max()
         loud = ref > 1e-3 * ref.max()
         assert np.abs(lm[i] - st64["log_mel"][i])[loud].max() < 1e-3
-        assert np.abs(wrap2(mi[i] - st64["mel_if"][i]))[loud].max() < 1e-3
+        prev_loud = loud.copy()
+        prev_loud[1:] &= loud[:-1]                     # IF at t is a difference of the phases at t and t - 1
+        # (a stationary tone keeps re-visiting the same phases: ~1 % of its audible bins sit on the atan2 branch, 3e-5 of the noise's)
+        check_if(mi[i], st64["mel_if"][i], on_cut[i], branch[i], where=prev_loud, max_branch=3e-2 if i == 0 else 2e-3)
     assert np.allclose(lm[:, :3], (np.log(1e-6) + 3.76) / 10.05, atol=1e-6) and np.all(mi[:, :3] == 0)
     gold = np.load(os.path.join(GOLD, "spectral_tone_noise.npz"))
     fr = gold["frames"]
     assert np.abs(lm[1][fr] - gold["log_mel"][1]).max() < 1e-3
-    assert np.abs(wrap2(mi[1][fr] - gold["mel_if"][1])).max() < 1e-3
+    check_if(mi[1][fr], gold["mel_if"][1], on_cut[1][fr], branch[1][fr])
     loud = gold["mel_magnitude"][0] > 1e-3 * gold["mel_magnitude"][0].max()
     assert np.abs(lm[0][fr] - gold["log_mel"][0])[loud].max() < 1e-3
 
@@ -83,13 +119,21 @@ def test_inverse_vs_oracle():
     from gansynth_amd import spectral_ops as G
     w = waves()
     lm, mi = S.convert_to_spectrogram(w, **P)
-    ref = S.convert_to_waveform(lm, mi, **P)
+    ref32 = S.convert_to_waveform(lm, mi, **P)
+    mel32 = S.linear_to_mel_weight_matrix(1024, 1024, 16000, 0.0, 8000.0, np.float32)
+    ref64 = S.convert_to_waveform(lm.astype(np.float64), mi.astype(np.float64), **P, dtype=np.float64, mel_inverse=S.pinv(mel32))
     got = G.convert_to_waveform(torch.from_numpy(lm).cuda(), torch.from_numpy(mi).cuda(), **P).cpu().numpy()
-    assert got.shape == ref.shape == (2, 64000)
-    # cos/sin of phases up to ~1e3 rad amplify fp32 rounding of the pinv contraction: compare by correlation and rms
-    for a, b in zip(got, ref):
-        assert S.cross_correlation(a, b) > 0.999
-        assert np.sqrt(np.mean((a - b) ** 2)) < 2e-2 * np.sqrt(np.mean(b ** 2))
+    assert got.shape == ref32.shape == (2, 64000)
+    # The contract is 1e-3 relative; measured (MI355X, round 2): 2.7e-6 of the peak against the exact (float64) evaluation with the
+    # same float32-built pinv(mel), the float32 oracle itself sitting 2.7e-6 from it.  (Phases reach ~1e3 rad before cos / sin, so
+    # the comparison must share the float32-built matrix: a float64-built pinv differs by 1.6e-4 relative = 0.16 rad.)
+    for a, b32, b64 in zip(got, ref32, ref64):
+        scale = np.abs(b64).max()
+        own = np.abs(b32 - b64).max() / scale            # what float32 arithmetic costs the reference itself
+        err = np.abs(a - b64).max() / scale
+        print(f"inverse: HIP vs exact {err:.2e}, fp32 oracle vs exact {own:.2e}")
+        assert err < 1e-4 and np.abs(a - b32).max() / scale < 1e-4, (err, own)
+        assert S.cross_correlation(a, b64) > 0.999999
 
 
 def test_batch256_properties():
