@@ -85,7 +85,7 @@ def main(args):
 
     if args.train:
         model.train(total_steps=args.total_steps, log_tensor_steps=args.log_tensor_steps, log=print if rank == 0 else None,
-                    model_dir=args.model_dir if rank == 0 else None, save_checkpoint_steps=args.save_checkpoint_steps)
+                    model_dir=args.model_dir, save_checkpoint_steps=args.save_checkpoint_steps)   # every rank restores, rank 0 saves
         if rank == 0:
             print(f"stopped at global_step = {model.global_step}")
 

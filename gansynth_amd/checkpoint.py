@@ -8,10 +8,13 @@ A `tf.train.Saver` checkpoint of the reference graph (models.py:123-130) holds, 
     models.py:81), `beta1_power_1`, `beta2_power_1` for the discriminator's (models.py:86);
   * `global_step` (int64).
 The TF tensor-bundle container cannot be written without TensorFlow; the same names, shapes and layouts are stored in a
-`.safetensors` file, so that weights can be exchanged with a real TF run by a ten-line converter on a machine that has
-both (tf.train.load_checkpoint(...).get_tensor(name) <-> this dict).
+`.safetensors` file; `scripts/tf_checkpoint_convert.py` copies a TF checkpoint into that container (and back) on a machine
+that has TensorFlow -- the only format gap (INTEGRATION.md).  `optimizer_steps[_1]` is an extra key (the exponent t itself);
+a converted TF checkpoint lacks it and t is recovered from beta2_power = beta2^(t+1).  Not implemented:
+keep_checkpoint_every_n_hours=12 (models.py:127) -- only max_to_keep=10.
 """
 import glob
+import math
 import os
 import re
 
@@ -68,6 +71,12 @@ def load_state_dict(model, state, strict=True):
         key = "optimizer_steps" + suffix
         if key in state:
             params.t = int(state[key])
+        elif "beta2_power" + suffix in state:
+            # a checkpoint converted from a real tf.train.Saver file has only TF's own accumulators: beta2_power = beta2^(t+1)
+            hp = model.hyper_params
+            b2 = float(hp.generator_beta2 if suffix == "" else hp.discriminator_beta2)
+            p2 = float(state["beta2_power" + suffix])
+            params.t = max(0, int(round(math.log(p2) / math.log(b2))) - 1) if 0.0 < p2 < 1.0 and 0.0 < b2 < 1.0 else 0
         else:
             missing.append(key)
     if "global_step" in state:

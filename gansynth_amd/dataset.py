@@ -228,7 +228,9 @@ def nsynth_input_fn(filenames, batch_size, num_epochs, shuffle, buffer_size=None
                 break
         # drop_remainder=True (dataset.py:82): a trailing partial batch is discarded
 
-    return _Prefetcher(make_batches, prefetch, device)
+    fn = _Prefetcher(make_batches, prefetch, device)
+    fn.finite = num_epochs is not None   # (models.GANSynth.train: data-parallel ranks vote before each step when the input can run dry)
+    return fn
 
 
 def synthetic_nsynth_input_fn(batch_size, pitches=range(24, 85), num_batches=None, device=None, seed=0, prefetch=2):
@@ -255,4 +257,6 @@ def synthetic_nsynth_input_fn(batch_size, pitches=range(24, 85), num_batches=Non
             yield wav, lab
             k += 1
 
-    return _Prefetcher(make_batches, prefetch, device)
+    fn = _Prefetcher(make_batches, prefetch, device)
+    fn.finite = num_batches is not None
+    return fn

@@ -742,15 +742,32 @@ class DeviceLerp(object):
         def __float__(self):
             return float(self.owner.host[self.index])
 
+    _SLOTS = 4
+
     def __init__(self, device):
-        self.host = torch.tensor([0.0, 1.0, 0.0, 1.0], dtype=torch.float32)
-        if torch.device(device).type == "cuda":
-            self.host = self.host.pin_memory()
+        self.host = torch.tensor([0.0, 1.0, 0.0, 1.0], dtype=torch.float32)   # current value (float() of the coefficients reads it)
+        self._cuda = torch.device(device).type == "cuda"
+        # the async H2D copy reads its pinned source when the DMA executes, and with graph replay the host runs steps ahead of
+        # the device: every set() stages through its own pinned slot, reused only after the copy that read it has completed
+        self._ring = [self.host.clone().pin_memory() for _ in range(self._SLOTS)] if self._cuda else None
+        self._done = [None] * self._SLOTS
+        self._next = 0
         self.table = self.host.to(device)
 
     def set(self, t):
         self.host[0], self.host[1] = float(t), 1.0 - float(t)
-        self.table.copy_(self.host, non_blocking=True)   # stream-ordered before the next launch / graph replay
+        if not self._cuda:
+            self.table.copy_(self.host)
+            return
+        i = self._next
+        self._next = (i + 1) % self._SLOTS
+        if self._done[i] is not None:
+            self._done[i].synchronize()
+        self._ring[i].copy_(self.host)
+        self.table.copy_(self._ring[i], non_blocking=True)   # stream-ordered before the next launch / graph replay
+        ev = torch.cuda.Event()
+        ev.record()
+        self._done[i] = ev
 
     def weights(self):
         return DeviceLerp.Coef(self, 0), DeviceLerp.Coef(self, 1)

@@ -190,10 +190,27 @@ class HipKernels(object):
             grp["bias"] = bias_out
         grp["src"].append((x, gy, bias_out is not None))
 
-    def flush_wgrad_reductions(self):
+    def flush_wgrad_reductions(self, group_of=None, on_group_done=None):
+        """`group_of(out.data_ptr()) -> int | None` orders the layers into groups (the trainer's gradient buckets, in completion
+        order); each group is contracted and folded before the next one starts and `on_group_done(group)` is called right after
+        its last launch -- the data-parallel trainer puts that bucket's all-reduce on the wire there."""
         groups, self._pending = self._pending, None
         if not groups:
             return 0
+        if group_of is not None:
+            tagged = {}
+            for key, grp in groups.items():
+                tagged.setdefault(group_of(grp["out"].data_ptr()), []).append((key, grp))
+            order = sorted((g for g in tagged if g is not None)) + ([None] if None in tagged else [])
+            n = 0
+            for g in order:
+                n += self._flush_groups(dict(tagged[g]))
+                if g is not None and on_group_done is not None:
+                    on_group_done(g)
+            return n
+        return self._flush_groups(groups)
+
+    def _flush_groups(self, groups):
         pend, keep = [], []
         for key, grp in groups.items():
             kind, ksize, stride, alpha = key[0], key[2], key[3], key[4]
@@ -613,13 +630,15 @@ class HipKernels(object):
                                           _dt(fake_logits), _stream()), "gs_gan_g_loss")
         return loss, g_fake, g_sumsq
 
-    def adam_tf_step(self, p, g, m, v, lr_t, beta1, beta2, eps, grad_scale=1.0):
+    def adam_tf_step(self, p, g, m, v, lr_t, beta1, beta2, eps, grad_scale=1.0, refresh=True):
+        """`refresh=False`: the caller updates a buffer range by range (gradient buckets) and refreshes the operands once."""
         for t in (p, g, m, v):
             assert t.dtype == torch.float32 and t.is_contiguous()
         _lib.check(self.lib.gs_adam_tf_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), float(lr_t), float(beta1),
                                             float(beta2), float(eps), float(grad_scale), _stream()), "gs_adam_tf_step")
-        self.invalidate_weights(p)  # parameter values changed: cached kernel operands of that buffer are stale ...
-        self.refresh_weights(p)     # ... and are rebuilt here in one launch
+        if refresh:
+            self.invalidate_weights(p)  # parameter values changed: cached kernel operands of that buffer are stale ...
+            self.refresh_weights(p)     # ... and are rebuilt here in one launch
 
     # --------------------------------------------------------------------------- profiling
     def prof_enable(self, on):

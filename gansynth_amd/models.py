@@ -54,6 +54,37 @@ class _FlatParams(object):
             p.data = self.flat[off:off + n].view(p.shape)
             p.grad = self.grad[off:off + n].view(p.shape)
         self.t = 0
+        self.buckets = [(0, total)]
+        self._offsets = list(zip(offs, sizes, self.named.keys()))
+
+    def make_buckets(self, max_floats, reverse=False):
+        """Split the flat buffer into contiguous ranges of whole tensors, each <= max_floats unless a single tensor is larger
+        (the generator's 4.2 M-element dense weight gets a bucket of its own), ordered as the backward pass completes them:
+        `reverse` for the generator (its backward ends at the first variables), natural order for the discriminator."""
+        total = self.flat.numel()
+        starts = [o for o, _, _ in self._offsets] + [total]
+        buckets, a = [], 0
+        for i in range(len(self._offsets)):
+            nxt = starts[i + 1]
+            if nxt - a > max_floats and starts[i] > a:      # closing before this tensor keeps the bucket under the limit
+                buckets.append((a, starts[i]))
+                a = starts[i]
+            if nxt - a >= max_floats:
+                buckets.append((a, nxt))
+                a = nxt
+        if a < total:
+            buckets.append((a, total))
+        self.buckets = buckets[::-1] if reverse else buckets
+        return self.buckets
+
+    def bucket_of(self, ptr):
+        """Index (in completion order) of the bucket holding the gradient element at device address `ptr`, or None."""
+        off = (ptr - self.grad.data_ptr()) // 4
+        if 0 <= off < self.grad.numel():
+            for i, (a, b) in enumerate(self.buckets):
+                if a <= off < b:
+                    return i
+        return None
 
     def requires_grad_(self, flag):
         for p in self.named.values():
@@ -69,7 +100,7 @@ class _FlatParams(object):
 class GANSynth(object):
 
     def __init__(self, generator, discriminator, real_input_fn, fake_input_fn, spectral_params, hyper_params,
-                 dtype=torch.float32, store=None, distributed=False, use_graphs=False):
+                 dtype=torch.float32, store=None, distributed=False, use_graphs=False, bucket_bytes=8 << 20):
         self.generator, self.discriminator = generator, discriminator
         self.real_input_fn, self.fake_input_fn = real_input_fn, fake_input_fn
         self.spectral_params, self.hyper_params = spectral_params, hyper_params
@@ -77,6 +108,10 @@ class GANSynth(object):
         self.store = store if store is not None else variables.default_store()
         self.distributed = bool(distributed)
         self.world = torch.distributed.get_world_size() if self.distributed else 1
+        self.rank = torch.distributed.get_rank() if self.distributed else 0
+        self.bucket_bytes = int(bucket_bytes)   # gradient all-reduce granularity (data parallel only)
+        self._inflight = None                   # (params, [(bucket, work)]) all-reduces launched during the eager backward's tail
+        self._peeked = None                     # a batch fetched ahead of the first step (train: eager build / restore)
         self.global_step = 0
         self.g_params = None
         self.d_params = None
@@ -116,6 +151,8 @@ class GANSynth(object):
         if self.distributed:  # identical weights on every rank
             torch.distributed.broadcast(self.g_params.flat, 0)
             torch.distributed.broadcast(self.d_params.flat, 0)
+            self.g_params.make_buckets(self.bucket_bytes // 4, reverse=True)
+            self.d_params.make_buckets(self.bucket_bytes // 4, reverse=False)
         K = kernels.get()
         if hasattr(K, "register_param_buffer"):  # lets the conv kernels keep their re-laid weight operands between calls
             K.register_param_buffer(self.g_params.flat)
@@ -125,10 +162,6 @@ class GANSynth(object):
     def _ensure_built(self, latents, labels):
         if self.g_params is None:
             self._build(latents, labels)
-            if self._restore_from is not None:   # train(model_dir=...): resume like tf.train.MonitoredSession(checkpoint_dir=...)
-                from . import checkpoint
-                self.restored_from = checkpoint.restore(self, self._restore_from)
-                self._restore_from = None
 
     # -------------------------------------------------------------------------- inputs
     def _real_batch(self):
@@ -224,17 +257,43 @@ class GANSynth(object):
         return self._g_losses_b(self._g_losses_a(latents, labels), labels)
 
     # ------------------------------------------------------------------------- updates
+    # Data parallelism (the reference is single-GPU): the flat gradient of a network is all-reduced in BUCKETS of
+    # whole tensors (<= bucket_bytes; the generator's 16.8 MB dense weight alone), in the order the backward pass completes them.
+    # Every bucket's all-reduce is launched asynchronously (torch.distributed runs it on the communicator's own stream, backend
+    # "nccl" = RCCL over xGMI) and the TF-Adam update of bucket k runs while bucket k+1 is still on the wire; in eager mode the
+    # first buckets are already launched from inside the backward's tail (the per-layer weight-gradient contraction,
+    # kernels.flush_wgrad_reductions) as soon as their last gradient is written.  The 1/world averaging is folded into the Adam
+    # kernel.  One bucket == the whole buffer when not distributed: one launch, as before.
+    def _launch_reduce(self, params, bucket):
+        a, b = params.buckets[bucket]
+        return torch.distributed.all_reduce(params.grad[a:b], async_op=True)
+
     def _reduce(self, params):
+        """Blocking form (pipelined step): every bucket reduced, in order, on the current stream's timeline."""
         if self.distributed:
-            torch.distributed.all_reduce(params.grad)
+            for i in range(len(params.buckets)):
+                self._launch_reduce(params, i).wait()
 
     def _apply(self, params, lr, beta1, beta2, reduced=False):
-        if not reduced:
-            self._reduce(params)
         params.t += 1
         lr_t = lr * math.sqrt(1.0 - beta2 ** params.t) / (1.0 - beta1 ** params.t)
-        kernels.get().adam_tf_step(params.flat, params.grad, params.m, params.v, lr_t, beta1, beta2, 1.0e-8,
-                                   1.0 / self.world)
+        K = kernels.get()
+        if not self.distributed or reduced:
+            K.adam_tf_step(params.flat, params.grad, params.m, params.v, lr_t, beta1, beta2, 1.0e-8, 1.0 / self.world)
+            return
+        works = {}
+        if self._inflight is not None and self._inflight[0] is params:
+            works = dict(self._inflight[1])
+        self._inflight = None
+        for i in range(len(params.buckets)):
+            if i not in works:
+                works[i] = self._launch_reduce(params, i)
+        for i, (a, b) in enumerate(params.buckets):
+            works[i].wait()   # (stream-side wait: the host does not block)
+            K.adam_tf_step(params.flat[a:b], params.grad[a:b], params.m[a:b], params.v[a:b], lr_t, beta1, beta2, 1.0e-8,
+                           1.0 / self.world, refresh=False)
+        K.invalidate_weights(params.flat)
+        K.refresh_weights(params.flat)
 
     def _part_a(self, which, *inputs):
         """Own-network part of a run (see _d_losses_a / _g_losses_a); also arms the run: requires_grad flags, zeroed gradients."""
@@ -257,12 +316,26 @@ class GANSynth(object):
         deferring = _DEFER_REDUCTIONS and hasattr(K, "defer_wgrad_reductions")   # parameter gradients are only read after the whole backward:
         if deferring:                                        # their ~70 slice reductions are folded in one go at the end
             K.defer_wgrad_reductions()
+        params = self.d_params if which == "d" else self.g_params
+        overlap = (self.distributed and deferring and len(params.buckets) > 1 and not self._capturing()
+                   and not getattr(self, "_warming_up", False))
+        launched = []
         try:
             loss.backward()
         finally:
             if deferring:
-                K.flush_wgrad_reductions()
+                if overlap:   # contract the layers bucket by bucket; a finished bucket goes on the wire under the next one's kernels
+                    K.flush_wgrad_reductions(group_of=params.bucket_of,
+                                             on_group_done=lambda i: launched.append((i, self._launch_reduce(params, i))))
+                else:
+                    K.flush_wgrad_reductions()
+        if launched:
+            self._inflight = (params, launched)
         return loss.detach()
+
+    @staticmethod
+    def _capturing():
+        return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
 
     def _forward_backward(self, which, *inputs):
         """Gradients of one run into the flat gradient buffer; returns the (detached) mean loss.
@@ -314,8 +387,12 @@ class GANSynth(object):
             try:
                 side = torch.cuda.Stream()
                 side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(side):  # one eager pass on a side stream (allocator / lazy-init warm-up)
-                    self._forward_backward(which, *static)
+                self._warming_up = True
+                try:
+                    with torch.cuda.stream(side):  # one eager pass on a side stream (allocator / lazy-init warm-up)
+                        self._forward_backward(which, *static)
+                finally:
+                    self._warming_up = False
                 torch.cuda.current_stream().wait_stream(side)
                 # the prepared weight operands live in persistent workspaces that the optimizer step refreshes eagerly
                 # (kernels.adam_tf_step): bring them up to date now so that the captured graph holds no re-layout launches
@@ -440,12 +517,20 @@ class GANSynth(object):
         self.discriminator_loss, self.generator_loss = D["loss"], G["loss"]
         return D["loss"], G["loss"]
 
-    def train_step(self):
-        """models.py:191-192: one discriminator run then one generator run, fresh inputs for each."""
+    def _next_inputs(self):
+        """One iteration's inputs (models.py:191-192: a fresh batch for each of the two runs).  StopIteration = the input ran dry."""
+        if self._peeked is not None:
+            out, self._peeked = self._peeked, None
+            return out
         real_images, labels = self._real_batch()
         d_latents = self.fake_input_fn().to(self.dtype)
         _, g_labels = self.real_input_fn()  # the G run only consumes the labels of its batch (waveform branch is pruned)
         g_latents, g_labels = self.fake_input_fn().to(self.dtype), g_labels.to(self.dtype)
+        return real_images, labels, d_latents, g_latents, g_labels
+
+    def train_step(self):
+        """models.py:191-192: one discriminator run then one generator run, fresh inputs for each."""
+        real_images, labels, d_latents, g_latents, g_labels = self._next_inputs()
         self._ensure_built(d_latents, labels)
         if self._pipelined_ok():
             return self._train_step_pipelined(d_latents, labels, real_images, g_latents, g_labels)
@@ -453,29 +538,60 @@ class GANSynth(object):
         g_loss = self.generator_step(g_latents, g_labels)
         return d_loss, g_loss
 
-    def train(self, total_steps, log_tensor_steps=100, log=print, model_dir=None, save_checkpoint_steps=1000):
+    def _all_ranks_have_input(self, have):
+        """Data parallel: the input shards are rank-local (files[rank::world], per-record filters), so they run dry at different
+        steps; a rank that stopped alone would leave the others blocked in the next all-reduce.  Every rank votes before each
+        iteration and all stop together at the first "no" (the reference's single process stops at its OutOfRangeError,
+        models.py:193).  Inputs that cannot run dry (`real_input_fn.finite == False`) skip the vote and its host sync."""
+        if not self.distributed or not getattr(self.real_input_fn, "finite", True):
+            return have
+        dev = self.g_params.flat.device if self.g_params is not None else (torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu"))
+        flag = torch.tensor([1 if have else 0], dtype=torch.int32, device=dev)
+        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+        return bool(flag.item())
+
+    def train(self, total_steps, log_tensor_steps=100, log=print, model_dir=None, save_checkpoint_steps=1000, save=None):
         """models.py:110-194 without the TF summary hooks: resume from the latest checkpoint of `model_dir` (CheckpointSaverHook /
         MonitoredSession semantics), alternate D and G runs until global_step reaches total_steps (StopAtStepHook) or the input
         runs dry (OutOfRangeError, :193), log the two losses every `log_tensor_steps` (LoggingTensorHook), checkpoint every
-        `save_checkpoint_steps` and at the end."""
+        `save_checkpoint_steps` and at the end.  Data parallel: EVERY rank passes `model_dir` and restores from the same file
+        (weights, Adam slots, optimizer steps, global_step -- so that all ranks resume in the same growing regime); only rank 0
+        writes (`save` defaults to rank == 0)."""
         from . import checkpoint
+        save = (self.rank == 0) if save is None else bool(save)
+        have = True
         if model_dir is not None and self.g_params is None:
-            self._restore_from = model_dir
+            # the variables exist from step 0 in the reference's graph: build them from the first batch's shapes and restore BEFORE the
+            # stop condition is looked at (a finished run resumes to zero further steps, not one)
+            try:
+                self._peeked = self._next_inputs()
+            except StopIteration:
+                have = False
+            if self._all_ranks_have_input(have):
+                _, labels, d_latents, _, _ = self._peeked
+                self._ensure_built(d_latents, labels)
+                self.restored_from = checkpoint.restore(self, model_dir)
+            else:
+                have, self._peeked = False, None
         elif model_dir is not None:
             self.restored_from = checkpoint.restore(self, model_dir)
         last_saved = None
-        while self.global_step < total_steps:
+        while have and self.global_step < total_steps:
             try:
-                d_loss, g_loss = self.train_step()
+                inputs = self._next_inputs()
             except StopIteration:
+                inputs = None
+            if not self._all_ranks_have_input(inputs is not None):
                 break
+            self._peeked = inputs
+            d_loss, g_loss = self.train_step()
             if log is not None and self.global_step % log_tensor_steps == 0:
                 log(f"global_step = {self.global_step}, generator_loss = {float(g_loss):.6f}, "
                     f"discriminator_loss = {float(d_loss):.6f}")
-            if model_dir is not None and save_checkpoint_steps and self.global_step % save_checkpoint_steps == 0:
+            if model_dir is not None and save and save_checkpoint_steps and self.global_step % save_checkpoint_steps == 0:
                 last_saved = self.global_step
                 checkpoint.save(self, model_dir)
-        if model_dir is not None and self.g_params is not None and last_saved != self.global_step:
+        if model_dir is not None and save and self.g_params is not None and last_saved != self.global_step:
             checkpoint.save(self, model_dir)
 
     def generate(self, latents, labels):

@@ -22,6 +22,35 @@ def _lin_grad(fn, shape, like, gy):
 
 class CpuEmuKernels(object):
     lib = None
+    _pending = None   # deferred in-place conv weight gradients (mirrors kernels.HipKernels.defer / flush_wgrad_reductions)
+
+    def defer_wgrad_reductions(self):
+        if self._pending is None:
+            self._pending = []
+
+    def flush_wgrad_reductions(self, group_of=None, on_group_done=None):
+        pending, self._pending = self._pending, None
+        if not pending:
+            return 0
+        if group_of is None:
+            for _, fn in pending:
+                fn()
+            return len(pending)
+        tagged = {}
+        for out, fn in pending:
+            tagged.setdefault(group_of(out.data_ptr()), []).append(fn)
+        for g in sorted(k for k in tagged if k is not None) + ([None] if None in tagged else []):
+            for fn in tagged[g]:
+                fn()
+            if g is not None and on_group_done is not None:
+                on_group_done(g)
+        return len(pending)
+
+    def invalidate_weights(self, flat=None):
+        pass
+
+    def refresh_weights(self, flat=None):
+        return 0
 
     # conv2d (alpha folded, no bias)
     def conv2d_fwd(self, x, w, ksize, stride, alpha):
@@ -53,6 +82,12 @@ class CpuEmuKernels(object):
         return out
 
     def conv2d_bwd_weight(self, x, gy, ksize, stride, alpha, out=None, bias_out=None):
+        if out is not None and self._pending is not None:
+            x, gy = x.detach(), gy.detach()
+            pending, self._pending = self._pending, None
+            pending.append((out, lambda: self.conv2d_bwd_weight(x, gy, ksize, stride, alpha, out=out, bias_out=bias_out)))
+            self._pending = pending
+            return out
         ci, co = x.shape[1], gy.shape[1]
         shape = (ksize, ksize, ci, co)
         g = _lin_grad(lambda z: self_conv(x.detach(), z, stride, alpha), shape, gy, gy.detach())
@@ -69,6 +104,12 @@ class CpuEmuKernels(object):
         return _lin_grad(lambda z: self_convT(z, w.detach().to(gy.dtype), alpha), (n, ci, h2 // 2, w2 // 2), gy, gy.detach()).detach()
 
     def conv2d_transpose_bwd_weight(self, x, gy, alpha, out=None):
+        if out is not None and self._pending is not None:
+            x, gy = x.detach(), gy.detach()
+            pending, self._pending = self._pending, None
+            pending.append((out, lambda: self.conv2d_transpose_bwd_weight(x, gy, alpha, out=out)))
+            self._pending = pending
+            return out
         shape = (3, 3, x.shape[1], gy.shape[1])
         return self._out(_lin_grad(lambda z: self_convT(x.detach(), z, alpha), shape, gy, gy.detach()).float().detach(), out)
 
@@ -170,7 +211,7 @@ class CpuEmuKernels(object):
     def row_scale(self, x, s):
         return x.detach() * s.detach().to(x.dtype).view(-1, *([1] * (x.dim() - 1)))
 
-    def adam_tf_step(self, p, g, m, v, lr_t, beta1, beta2, eps, grad_scale=1.0):
+    def adam_tf_step(self, p, g, m, v, lr_t, beta1, beta2, eps, grad_scale=1.0, refresh=True):
         with torch.no_grad():
             gr = g * grad_scale
             m.mul_(beta1).add_(gr, alpha=1 - beta1)

@@ -189,3 +189,10 @@ def test_checkpoint_round_trip_resumes_bit_identically(cpu_backend, tmp_path):
     assert torch.equal(second.g_params.flat, straight.g_params.flat) and torch.equal(second.d_params.flat, straight.d_params.flat)
     assert torch.equal(second.g_params.v, straight.g_params.v)
     assert checkpoint.latest(str(tmp_path)).endswith("model.ckpt-4.safetensors")
+    # a checkpoint converted from a real tf.train.Saver file has no `optimizer_steps`: t comes back from beta2_power = beta2^(t+1)
+    tf_like = {k: v for k, v in load_file(checkpoint.latest(str(tmp_path))).items() if not k.startswith("optimizer_steps")}
+    third, _ = make(7)
+    third._build(torch.zeros(4, 16), torch.zeros(4, 5))
+    assert checkpoint.load_state_dict(third, tf_like, strict=True) == []
+    assert (third.g_params.t, third.d_params.t, third.global_step) == (4, 4, 4)
+    assert torch.equal(third.g_params.flat, straight.g_params.flat)

@@ -36,32 +36,49 @@ def _shard(rank):
     return lat, lab, img
 
 
-def _worker(rank, world, port, out_dir):
+def _init(rank, world, port):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(2)
+
+
+def _worker(rank, world, port, out_dir, bucket_bytes):
+    _init(rank, world, port)
     pg, hyper, GANSynth = _setup()
-    model = GANSynth(pg.generator, pg.discriminator, None, None, None, hyper, distributed=True)
+    model = GANSynth(pg.generator, pg.discriminator, None, None, None, hyper, distributed=True, bucket_bytes=bucket_bytes)
     lat, lab, img = _shard(rank)
     model.discriminator_step(lat, lab, img)
+    nd = len(model.d_params.buckets)
     model.generator_step(lat, lab)
-    torch.save({"d": model.d_params.flat.clone(), "g": model.g_params.flat.clone(), "step": model.global_step},
+    torch.save({"d": model.d_params.flat.clone(), "g": model.g_params.flat.clone(), "step": model.global_step,
+                "buckets": (nd, len(model.g_params.buckets)), "g_buckets": model.g_params.buckets},
                os.path.join(out_dir, f"rank{rank}.pt"))
     torch.distributed.destroy_process_group()
 
 
-@pytest.mark.timeout(600)
-def test_two_rank_gloo_matches_gradient_average():
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world,bucket_bytes", [(2, 8 << 20), (4, 16 << 10)])
+def test_gloo_ranks_match_gradient_average(world, bucket_bytes):
+    """world 2 with one bucket per network (the whole flat gradient) and world 4 with 16 KiB buckets: the bucketed path -- buckets
+    of whole tensors in completion order, each all-reduce launched from inside the backward's tail as its last gradient lands
+    (kernels.flush_wgrad_reductions per bucket), TF-Adam bucket by bucket behind its own all-reduce."""
     sys.path.insert(0, ROOT)
-    world = 2
-    port = 29500 + (os.getpid() % 2000)
+    port = 29500 + (os.getpid() % 2000) + world
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_worker, args=(world, port, d), nprocs=world, join=True)
-        r0 = torch.load(os.path.join(d, "rank0.pt"))
-        r1 = torch.load(os.path.join(d, "rank1.pt"))
-    assert torch.equal(r0["d"], r1["d"]) and torch.equal(r0["g"], r1["g"])  # replicas stay bit-identical
+        mp.spawn(_worker, args=(world, port, d, bucket_bytes), nprocs=world, join=True)
+        rs = [torch.load(os.path.join(d, f"rank{r}.pt")) for r in range(world)]
+    r0 = rs[0]
+    for r in rs[1:]:
+        assert torch.equal(r0["d"], r["d"]) and torch.equal(r0["g"], r["g"])  # replicas stay bit-identical
     assert r0["step"] == 1
+    if bucket_bytes < (1 << 20):
+        assert r0["buckets"][0] > 2 and r0["buckets"][1] > 2, r0["buckets"]
+        gb = r0["g_buckets"]
+        assert gb[0][0] > gb[-1][0]   # generator: completion order = reverse of the variable order (its backward ends at the embedding)
+        cover = sorted(gb)
+        assert cover[0][0] == 0 and all(a[1] == b[0] for a, b in zip(cover, cover[1:])) and cover[-1][1] == r0["g"].numel()
+
 
     # single-process reference: average of the per-shard gradients, then one TF-Adam step
     from gansynth_amd import kernels, variables
@@ -92,3 +109,64 @@ def test_two_rank_gloo_matches_gradient_average():
         torch.testing.assert_close(r0["g"], model.g_params.flat, rtol=1e-5, atol=1e-6)
     finally:
         kernels._K, variables._default = old_k, old_s
+
+
+# ---------------------------------------------------------------------------------------------- train(): resume and input exhaustion
+def _finite_input(rank, n_batches):
+    """real_input_fn with `n_batches` batches then StopIteration (an epoch-limited shard); images, not waveforms."""
+    state = {"k": 0}
+
+    def fn():
+        if state["k"] >= n_batches:
+            raise StopIteration
+        state["k"] += 1
+        _, lab, img = _shard(rank * 100 + state["k"])
+        return img, lab
+
+    fn.finite = True
+    return fn
+
+
+def _train_worker(rank, world, port, out_dir, model_dir, total_steps, batches):
+    _init(rank, world, port)
+    pg, hyper, GANSynth = _setup(level=lambda: 0.3)
+    gen = torch.Generator().manual_seed(7 + rank)
+    model = GANSynth(pg.generator, pg.discriminator, _finite_input(rank, batches[rank]), lambda: torch.randn(4, 16, generator=gen), None, hyper,
+                     distributed=True, bucket_bytes=16 << 10)
+    model.train(total_steps=total_steps, log=None, model_dir=model_dir, save_checkpoint_steps=0)
+    torch.save({"d": model.d_params.flat.clone() if model.d_params is not None else None,
+                "g": model.g_params.flat.clone() if model.g_params is not None else None, "step": model.global_step,
+                "t": (model.d_params.t, model.g_params.t) if model.d_params is not None else None, "restored": model.restored_from,
+                "files": sorted(os.listdir(model_dir))}, os.path.join(out_dir, f"rank{rank}.pt"))
+    torch.distributed.destroy_process_group()
+
+
+def _run_train(world, model_dir, total_steps, batches):
+    port = 31500 + (os.getpid() % 2000) + total_steps
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_train_worker, args=(world, port, d, model_dir, total_steps, batches), nprocs=world, join=True)
+        return [torch.load(os.path.join(d, f"rank{r}.pt")) for r in range(world)]
+
+
+@pytest.mark.timeout(900)
+def test_two_rank_resume_and_uneven_input():
+    """(i) Every rank restores the SAME checkpoint (weights, Adam slots, optimizer steps, global_step) so that a resumed
+    data-parallel run continues in one growing regime with identical replicas; only rank 0 writes.  (ii) Rank-local inputs that run
+    dry at different steps stop every rank at the same iteration instead of hanging the others in an all-reduce."""
+    sys.path.insert(0, ROOT)
+    with tempfile.TemporaryDirectory() as model_dir:
+        first = _run_train(2, model_dir, 2, [100, 100])
+        assert [r["step"] for r in first] == [2, 2] and all(r["restored"] is None for r in first)
+        assert first[0]["files"] == ["checkpoint", "model.ckpt-2.safetensors"]            # written once, by rank 0
+        again = _run_train(2, model_dir, 3, [100, 100])
+        assert all(r["restored"] is not None and r["restored"].endswith("model.ckpt-2.safetensors") for r in again)
+        assert [r["step"] for r in again] == [3, 3] and all(r["t"] == (3, 3) for r in again)
+        assert torch.equal(again[0]["d"], again[1]["d"]) and torch.equal(again[0]["g"], again[1]["g"])
+        assert not torch.equal(again[0]["d"], first[0]["d"])
+        done = _run_train(2, model_dir, 3, [100, 100])                                     # a finished run resumes to zero further steps
+        assert [r["step"] for r in done] == [3, 3] and torch.equal(done[0]["g"], again[0]["g"])
+    with tempfile.TemporaryDirectory() as model_dir:
+        # each iteration draws two batches (D run, G run): rank 0 can do 3 iterations, rank 1 only 2 -> both stop after 2
+        uneven = _run_train(2, model_dir, 50, [6, 4])
+        assert [r["step"] for r in uneven] == [2, 2]
+        assert torch.equal(uneven[0]["d"], uneven[1]["d"]) and torch.equal(uneven[0]["g"], uneven[1]["g"])

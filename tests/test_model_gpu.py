@@ -446,3 +446,42 @@ def test_hipgraph_replay_in_a_fade_in_regime(gpu_store):
         _same_up_to_accumulation_order(a, b, f"loss {i}")
     _same_up_to_accumulation_order(out[False][1], out[True][1], "discriminator parameters")
     _same_up_to_accumulation_order(out[False][2], out[True][2], "generator parameters")
+
+
+def test_distributed_step_on_rccl_world_size_1():
+    """The data-parallel path on the real collective backend: torch.distributed backend "nccl" (= RCCL on ROCm) with ONE rank --
+    the only world size this box has.  Bucketed gradient all-reduce (16 KiB buckets: many collectives per run, launched from the
+    backward's tail in eager mode, behind the graph replay otherwise), TF-Adam bucket by bucket.  With one rank the sum is the
+    identity and the averaging factor 1, so parameters must be BIT-identical to the non-distributed step, eager and replayed."""
+    import torch.distributed as dist
+    from gansynth_amd import variables
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % (29400 + os.getpid() % 500), rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        out = {}
+        for mode in ("plain", "dist", "dist+graphs"):
+            variables.set_default_store(variables.VariableStore(device="cuda"))
+            pg, opg, model = make(1.0, variables.default_store(), full=False)
+            model.distributed, model.world, model.bucket_bytes = mode != "plain", 1, 16 << 10
+            model.use_graphs = mode == "dist+graphs"
+            gp, dp = opg.init_params(seed=0, bias_std=0.1)
+            losses = []
+            for step in range(3):
+                lat, lab, real = R.synthetic_batch(4, rank=step, image_shape=(2, 16, 128))
+                if step == 0:
+                    model._build(cuda(lat), cuda(lab))
+                    variables.default_store().load_state_dict({**gp, **dp})
+                losses.append(float(model.discriminator_step(cuda(lat), cuda(lab), cuda(real))))
+                losses.append(float(model.generator_step(cuda(lat), cuda(lab))))
+            torch.cuda.synchronize()
+            out[mode] = (losses, model.d_params.flat.clone(), model.g_params.flat.clone(), len(model.g_params.buckets))
+        assert out["plain"][3] == 1 and out["dist"][3] > 4
+        assert out["plain"][0] == out["dist"][0]
+        assert torch.equal(out["plain"][1], out["dist"][1]) and torch.equal(out["plain"][2], out["dist"][2])
+        for i, (a, b) in enumerate(zip(out["plain"][0], out["dist+graphs"][0])):
+            _same_up_to_accumulation_order(a, b, f"loss {i}")
+        _same_up_to_accumulation_order(out["plain"][1], out["dist+graphs"][1], "discriminator parameters")
+        _same_up_to_accumulation_order(out["plain"][2], out["dist+graphs"][2], "generator parameters")
+    finally:
+        dist.destroy_process_group()
