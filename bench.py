@@ -128,6 +128,61 @@ def spectral_bench(batch=256, iters=20, cpu=True):
     return out
 
 
+_KIND = {0: "conv3x3 s1", 1: "conv3x3 s2", 2: "conv3x3 transposed s2", 10: "wgrad conv3x3 s1", 11: "wgrad conv3x3 s2", 12: "wgrad transposed (as s2)"}
+
+
+def per_stage(records, iterations, peak_tflops, dtype):
+    """Group the per-launch records (gs_prof_records) by layer geometry.  One row per (kernel role, N, H x W, Cin -> Cout):
+    launches per iteration, average duration, algorithmic GFLOP and MB per launch, which roof binds, and frac = roof time /
+    measured time."""
+    groups = {}
+    for ms, fl, by, d in records:
+        kind, n, hb, wb, ic, oc, a, b = d
+        key = (kind, n, hb, wb, ic, oc, a if kind < 10 else 0, b if kind < 10 else 0)
+        g = groups.setdefault(key, [0, 0.0, fl, by, 0])
+        g[0] += 1
+        g[1] += ms
+        g[4] = max(g[4], a) if kind >= 10 else 0
+    rows = []
+    for (kind, n, hb, wb, ic, oc, masked, norm), (cnt, ms, fl, by, srcs) in sorted(groups.items()):
+        avg = ms / cnt
+        t_mfma, t_hbm = fl / (peak_tflops * 1e12) * 1e3, by / (HBM_GBPS * 1e9) * 1e3
+        row = {"stage": "%s %d->%d @ %dx%d x%d%s%s" % (_KIND.get(kind, str(kind)), ic, oc, hb, wb, n, " +mask" if masked else "", " +norm" if norm else ""),
+               "launches_per_iteration": cnt / max(iterations, 1), "avg_us": avg * 1e3, "gflop": fl / 1e9, "mbytes": by / 1e6,
+               "bound": "mfma" if t_mfma >= t_hbm else "hbm", "tflops": fl / (avg * 1e-3) / 1e12 if avg > 0 else 0.0,
+               "gbps": by / (avg * 1e-3) / 1e9 if avg > 0 else 0.0, "frac": max(t_mfma, t_hbm) / avg if avg > 0 else 0.0}
+        if kind >= 10:
+            row["sources"] = srcs
+        rows.append(row)
+    return rows
+
+
+def count_launches(model):
+    """Kernel launches of one iteration (D run + G run + both updates), counted by the profiler hooks of torch: every device
+    kernel, ours and torch's own (copies, fills) alike."""
+    from torch.profiler import ProfilerActivity, profile
+    was = model.use_graphs
+    model.use_graphs = False
+    try:
+        model.train_step()
+        torch.cuda.synchronize()
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            model.train_step()
+            torch.cuda.synchronize()
+        ours = native = 0
+        for ev in prof.events():
+            if ev.device_type is not None and str(ev.device_type).endswith("CUDA"):
+                if "gs::" in ev.name or "gs_" in ev.name:
+                    ours += 1
+                else:
+                    native += 1
+        return {"total": ours + native, "hip_extension": ours, "torch_native_and_copies": native}
+    except Exception as exc:   # (the profiler is optional equipment)
+        return {"error": repr(exc)[:200]}
+    finally:
+        model.use_graphs = was
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -138,6 +193,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graphs", action="store_true", help="launch every kernel eagerly instead of replaying hipGraphs")
     ap.add_argument("--no-spectral", action="store_true", help="skip the configs[3] (waveform -> mel + IF) leg")
+    ap.add_argument("--no-launch-count", action="store_true", help="skip the torch.profiler count of kernel launches per iteration")
     ap.add_argument("--spectral-only", action="store_true", help="run only the configs[3] leg and print its object")
     args = ap.parse_args()
 
@@ -151,6 +207,10 @@ def main():
     distributed = world > 1 or bool(os.environ.get("GS_BENCH_FORCE_DIST"))  # (the env switch exercises the RCCL path on one GPU)
     if distributed:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("NCCL_DEBUG", "WARN")   # (keeps RCCL's version banner off stdout: rank 0 prints exactly one JSON line)
+        if world == 1:   # GS_BENCH_FORCE_DIST without a launcher: a one-rank RCCL communicator
+            for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29431"), ("RANK", "0"), ("WORLD_SIZE", "1")):
+                os.environ.setdefault(k, v)
         torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
@@ -180,7 +240,8 @@ def main():
         return lat
 
     model = GANSynth(pggan.generator, pggan.discriminator, real_input_fn, fake_input_fn, None, hyper, dtype=dtype,
-                     distributed=distributed, use_graphs=not args.no_graphs)
+                     distributed=distributed, use_graphs=not args.no_graphs,
+                     **({"bucket_bytes": int(float(os.environ["GS_BUCKET_MB"]) * (1 << 20))} if os.environ.get("GS_BUCKET_MB") else {}))
     K = kernels.get()
 
     def barrier():
@@ -207,8 +268,11 @@ def main():
         model.train_step()
     barrier()
     conv_bytes, roof_ms, roof_ms_hbm = K.prof_roofline(PEAK[args.dtype], HBM_GBPS)
+    records = K.prof_records() if hasattr(K, "prof_records") else []
     launches, conv_ms, conv_flops = K.prof_collect()
     K.prof_enable(False)
+    stages = per_stage(records, prof_steps, PEAK[args.dtype], args.dtype)
+    kernel_launches = count_launches(model) if rank == 0 and not args.no_launch_count else None
     if distributed:
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -247,6 +311,10 @@ def main():
                          "launches": launches, "avg_launch_ms": conv_ms / max(launches, 1),
                          "time_share": (conv_ms / prof_steps) / (elapsed * 1e3 / args.steps),
                          "measured_over": "%d eager iterations after the timed region (same build, same inputs)" % prof_steps},
+            # every conv stage by itself (same eager iterations): frac = time the binding roof (MFMA peak or 8 TB/s on the
+            # algorithmic bytes) allows / measured time; north_star asks >= 0.40 at each conv stage
+            "stages": stages,
+            "kernel_launches_per_iteration": kernel_launches,
             "model_flops_utilization": value * FLOPS_PER_IMAGE / 1e12 / PEAK[args.dtype] / world,
             "losses": {"discriminator": float(d_loss), "generator": float(g_loss)},
         }

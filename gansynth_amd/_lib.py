@@ -25,6 +25,12 @@ SIGNATURES = {
     "gs_prof_enable": (I, [I]),
     "gs_prof_collect": (I, [POINTER(c_int), POINTER(c_double), POINTER(c_double)]),
     "gs_prof_roofline": (I, [ctypes.c_double, ctypes.c_double, P, P, P]),
+    "gs_prof_records": (I, [I, P, P, P, P, P]),
+    "gs_comm_unique_id": (I, [P]),
+    "gs_comm_init": (I, [POINTER(P), I, I, P]),
+    "gs_comm_destroy": (I, [P]),
+    "gs_allreduce_sum_f32": (I, [P, P, ctypes.c_int64, P]),
+    "gs_broadcast_f32": (I, [P, P, ctypes.c_int64, I, P]),
     "gs_conv2d_workspace_bytes": (Z, [I, I, I, I, I, I, I, I, I]),
     "gs_conv2d_fwd": (I, [P, P, P, I, I, I, I, I, I, I, F, I, I, P, Z, P]),
     "gs_conv2d_fwd_bias_act": (I, [P, P, P, P, I, I, I, I, I, I, I, F, I, I, I, P, Z, P]),

@@ -22,6 +22,10 @@ if [ ! -f obj/core.o ] || [ core.cpp -nt obj/core.o ] || [ gs_common.h -nt obj/c
   ( hipcc $FLAGS -x hip -c core.cpp -o obj/core.o ) &
   pids+=($!)
 fi
+if [ ! -f obj/comm.o ] || [ comm.cpp -nt obj/comm.o ] || [ gs_common.h -nt obj/comm.o ] || [ ../../include/gansynth_hip.h -nt obj/comm.o ]; then
+  ( hipcc $FLAGS -x hip -c comm.cpp -o obj/comm.o ) &
+  pids+=($!)
+fi
 for p in "${pids[@]}"; do wait $p; done
-hipcc --offload-arch=gfx950 -shared -fPIC obj/*.o -o $OUT/libgansynth_hip.so
+hipcc --offload-arch=gfx950 -shared -fPIC obj/*.o -ldl -o $OUT/libgansynth_hip.so
 echo "built $OUT/libgansynth_hip.so"

@@ -1,0 +1,101 @@
+// Thin C-ABI wrappers over an RCCL communicator (gs_comm_init / gs_allreduce_*).
+// The reference is single-GPU (gan_synth_main.py:91-98): data parallelism is new.  One process per GPU; the flat fp32 gradient
+// of a network is summed over ranks with ncclAllReduce ON THE CALLER'S STREAM -- the stream the backward ran on -- so the
+// collective is ordered behind the gradients and ahead of the optimizer update without any cross-stream event (on this ROCm
+// stack an event hop between a hipGraph replay and another stream costs ~0.25 ms, more than the collective itself).
+// RCCL is resolved at run time (dlopen of the already-loaded librccl.so.1 when the host process has one, e.g. PyTorch's), so the
+// library carries no link-time dependency on it and single-GPU users never load it.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include "gs_common.h"
+
+namespace {
+
+struct Rccl {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+Rccl g_rccl;
+
+int load_rccl() {
+    if (g_rccl.lib) return 0;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    void* h = nullptr;
+    for (const char* n : names) if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;   // the copy the process already uses
+    if (!h) for (const char* n : names) if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!h) return gs::fail(GS_ERR_UNSUPPORTED, "gs_comm: librccl.so.1 not found (%s)", dlerror());
+#define GS_SYM(field, name)                                                                                    \
+    g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(h, name));                                   \
+    if (!g_rccl.field) return gs::fail(GS_ERR_UNSUPPORTED, "gs_comm: symbol %s missing in librccl", name)
+    GS_SYM(GetUniqueId, "ncclGetUniqueId");
+    GS_SYM(CommInitRank, "ncclCommInitRank");
+    GS_SYM(CommDestroy, "ncclCommDestroy");
+    GS_SYM(AllReduce, "ncclAllReduce");
+    GS_SYM(Broadcast, "ncclBroadcast");
+    GS_SYM(GetErrorString, "ncclGetErrorString");
+#undef GS_SYM
+    g_rccl.lib = h;
+    return 0;
+}
+
+#define GS_NCCL_OK(expr)                                                                                      \
+    do {                                                                                                      \
+        ncclResult_t r__ = (expr);                                                                            \
+        if (r__ != ncclSuccess) return gs::fail(GS_ERR_HIP, "%s: %s", #expr, g_rccl.GetErrorString(r__));     \
+    } while (0)
+
+}  // namespace
+
+struct gs_comm {
+    ncclComm_t comm;
+    int rank, world;
+};
+
+extern "C" int gs_comm_unique_id(void* id128) {
+    GS_CHECK_ARG(id128, "gs_comm_unique_id: null buffer");
+    if (int e = load_rccl()) return e;
+    static_assert(sizeof(ncclUniqueId) == GS_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+    GS_NCCL_OK(g_rccl.GetUniqueId(reinterpret_cast<ncclUniqueId*>(id128)));
+    return 0;
+}
+
+extern "C" int gs_comm_init(gs_comm** out, int rank, int world, const void* id128) {
+    GS_CHECK_ARG(out && id128 && world >= 1 && rank >= 0 && rank < world, "gs_comm_init: bad arguments (rank %d of %d)", rank, world);
+    if (int e = load_rccl()) return e;
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    ncclComm_t c;
+    GS_NCCL_OK(g_rccl.CommInitRank(&c, world, id, rank));   // (binds to the calling thread's current HIP device)
+    gs_comm* p = new gs_comm();
+    p->comm = c; p->rank = rank; p->world = world;
+    *out = p;
+    return 0;
+}
+
+extern "C" int gs_comm_destroy(gs_comm* c) {
+    if (!c) return 0;
+    if (g_rccl.lib) g_rccl.CommDestroy(c->comm);
+    delete c;
+    return 0;
+}
+
+extern "C" int gs_allreduce_sum_f32(gs_comm* c, float* data, int64_t count, void* stream) {
+    GS_CHECK_ARG(c && data && count >= 0, "gs_allreduce_sum_f32: bad arguments");
+    if (count == 0) return 0;
+    GS_NCCL_OK(g_rccl.AllReduce(data, data, (size_t)count, ncclFloat32, ncclSum, c->comm, gs::as_stream(stream)));
+    return 0;
+}
+
+extern "C" int gs_broadcast_f32(gs_comm* c, float* data, int64_t count, int root, void* stream) {
+    GS_CHECK_ARG(c && data && count >= 0 && root >= 0 && root < c->world, "gs_broadcast_f32: bad arguments");
+    if (count == 0) return 0;
+    GS_NCCL_OK(g_rccl.Broadcast(data, data, (size_t)count, ncclFloat32, root, c->comm, gs::as_stream(stream)));
+    return 0;
+}

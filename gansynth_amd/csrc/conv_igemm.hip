@@ -35,17 +35,21 @@ struct ProfState {
     int used = 0;
     double flops = 0.0;
     double lflops[MAXEV], lbytes[MAXEV];   // per launch: algorithmic flops and bytes (operands read once + result written once)
+    int ldesc[MAXEV][8];                   // per launch: {kind, N, Hb, Wb, IC, OC, masked, fused norm}; kind = conv mode, +10 for weight gradients
 };
 static ProfState g_prof;
 
 struct ProfScope {
     hipStream_t s;
     int idx = -1;
-    ProfScope(hipStream_t st, double flops, double bytes = 0.0) : s(st) {
+    ProfScope(hipStream_t st, double flops, double bytes, int kind, int N, int Hb, int Wb, int IC, int OC, int masked, int norm) : s(st) {
         if (!g_prof.on || g_prof.used >= ProfState::MAXEV) return;
         idx = g_prof.used++;
         g_prof.lflops[idx] = flops;
         g_prof.lbytes[idx] = bytes;
+        const int d[8] = {kind, N, Hb, Wb, IC, OC, masked, norm};
+        for (int i = 0; i < 8; ++i) g_prof.ldesc[idx][i] = d[i];
+        if (kind >= 10) flops = 0.0;   // (the family totals of gs_prof_collect count the implicit-GEMM launches only)
         if (idx >= g_prof.created) {
             hipEventCreate(&g_prof.ev[idx][0]);
             hipEventCreate(&g_prof.ev[idx][1]);
@@ -1105,7 +1109,7 @@ static int launch_igemm(ConvP p, hipStream_t st) {
     const double out_px = (double)p.N * p.Hb * p.Wb * (MODE == MODE_T2 ? 4 : 1);
     // algorithmic bytes: input + output + weights, + the activation mask a masked launch reads, + the second output of a fused norm
     const double bytes = ((double)p.N * p.Hi * p.Wi * p.IC + out_px * p.OC * (1.0 + (p.mask ? 1.0 : 0.0) + ((NORM && p.y) ? 1.0 : 0.0)) + 9.0 * p.IC * p.OC) * sizeof(T);
-    ProfScope ps(st, flops, bytes);
+    ProfScope ps(st, flops, bytes, MODE, p.N, p.Hb, p.Wb, p.IC, p.OC, p.mask ? 1 : 0, NORM ? 1 : 0);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, p);
     return 0;
 }
@@ -1254,6 +1258,10 @@ int run_wgrad_mfma(int mode, const WgradSrcs& srcs, int nsrc, float* gw, float* 
     if (ws_bytes < need) return fail(GS_ERR_WORKSPACE, "conv wgrad: workspace %zu < %zu", ws_bytes, need);
     float* part = reinterpret_cast<float*>(ws);
     dim3 grid((IC / 32) * (OC / 32), nslices);
+    // algorithmic work of a weight gradient: the forward conv's FLOPs over all sources; bytes = x + gy read once, gw written once
+    const double wg_flops = 2.0 * 9.0 * (double)N * Hb * Wb * IC * OC;
+    const double wg_bytes = ((double)N * Hi * Wi * IC + (double)N * Hb * Wb * OC) * (dtype == GS_F32 ? 4.0 : 2.0) + 9.0 * IC * OC * 4.0;
+    ProfScope ps(st, wg_flops, wg_bytes, 10 + mode, N, Hb, Wb, IC, OC, nsrc, defer ? 1 : 0);
     {
 #define GS_WG(TT, M, TWV)                                                                                              \
     hipLaunchKernelGGL((conv_wgrad_kernel<TT, M, TWV>), grid, dim3(256), 0, st, srcs,                                  \
@@ -1316,6 +1324,7 @@ extern "C" int gs_prof_enable(int on) {
 extern "C" int gs_prof_roofline(double peak_tflops, double peak_gbps, double* total_bytes, double* roof_ms, double* roof_ms_hbm_bound) {
     double bytes = 0.0, roof = 0.0, roof_hbm = 0.0;
     for (int i = 0; i < gs::g_prof.used; ++i) {
+        if (gs::g_prof.ldesc[i][0] >= 10) continue;
         const double tf = gs::g_prof.lflops[i] / (peak_tflops * 1e12) * 1e3, tb = gs::g_prof.lbytes[i] / (peak_gbps * 1e9) * 1e3;
         bytes += gs::g_prof.lbytes[i];
         roof += tf > tb ? tf : tb;
@@ -1327,14 +1336,33 @@ extern "C" int gs_prof_roofline(double peak_tflops, double peak_gbps, double* to
     return 0;
 }
 
+// Per-launch records of everything recorded since gs_prof_enable(1) (implicit-GEMM convs AND weight gradients): duration (ms),
+// algorithmic FLOPs and bytes, and 8 ints {kind, N, Hb, Wb, IC, OC, masked | sources, fused norm | deferred}; kind = conv mode
+// (0 stride 1, 1 stride 2, 2 transposed) or 10 + mode for the weight gradient of that conv.  Call BEFORE gs_prof_collect.
+extern "C" int gs_prof_records(int max_records, int* n, double* ms, double* flops, double* bytes, int* desc) {
+    int k = 0;
+    for (int i = 0; i < gs::g_prof.used && k < max_records; ++i, ++k) {
+        hipEventSynchronize(gs::g_prof.ev[i][1]);
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, gs::g_prof.ev[i][0], gs::g_prof.ev[i][1]) != hipSuccess) t = 0.f;
+        ms[k] = t; flops[k] = gs::g_prof.lflops[i]; bytes[k] = gs::g_prof.lbytes[i];
+        for (int j = 0; j < 8; ++j) desc[8 * k + j] = gs::g_prof.ldesc[i][j];
+    }
+    if (n) *n = k;
+    return 0;
+}
+
 extern "C" int gs_prof_collect(int* launches, double* total_ms, double* total_flops) {
     double ms = 0.0;
+    int count = 0;
     for (int i = 0; i < gs::g_prof.used; ++i) {
+        if (gs::g_prof.ldesc[i][0] >= 10) continue;
+        ++count;
         hipEventSynchronize(gs::g_prof.ev[i][1]);
         float t = 0.f;
         if (hipEventElapsedTime(&t, gs::g_prof.ev[i][0], gs::g_prof.ev[i][1]) == hipSuccess) ms += t;
     }
-    if (launches) *launches = gs::g_prof.used;
+    if (launches) *launches = count;
     if (total_ms) *total_ms = ms;
     if (total_flops) *total_flops = gs::g_prof.flops;
     gs::g_prof.used = 0;

@@ -650,6 +650,16 @@ class HipKernels(object):
         self.lib.gs_prof_roofline(float(peak_tflops), float(peak_gbps), ctypes.byref(b), ctypes.byref(r), ctypes.byref(rh))
         return b.value, r.value, rh.value
 
+    def prof_records(self, max_records=8192):
+        """[(ms, flops, bytes, (kind, N, Hb, Wb, IC, OC, a, b))] of the recorded launches; call before prof_collect()."""
+        n = ctypes.c_int(0)
+        ms = (ctypes.c_double * max_records)()
+        fl = (ctypes.c_double * max_records)()
+        by = (ctypes.c_double * max_records)()
+        desc = (ctypes.c_int * (8 * max_records))()
+        self.lib.gs_prof_records(max_records, ctypes.byref(n), ms, fl, by, desc)
+        return [(ms[i], fl[i], by[i], tuple(desc[8 * i:8 * i + 8])) for i in range(n.value)]
+
     def prof_collect(self):
         n, ms, fl = ctypes.c_int(0), ctypes.c_double(0.0), ctypes.c_double(0.0)
         self.lib.gs_prof_collect(ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl))

@@ -111,6 +111,7 @@ class GANSynth(object):
         self.rank = torch.distributed.get_rank() if self.distributed else 0
         self.bucket_bytes = int(bucket_bytes)   # gradient all-reduce granularity (data parallel only)
         self._inflight = None                   # (params, [(bucket, work)]) all-reduces launched during the eager backward's tail
+        self._comm = None                       # comm.RcclComm: the gradient all-reduce on the backward's own stream (HIP + nccl only)
         self._peeked = None                     # a batch fetched ahead of the first step (train: eager build / restore)
         self.global_step = 0
         self.g_params = None
@@ -149,8 +150,15 @@ class GANSynth(object):
         self.g_params = _FlatParams(self.store.trainable_variables("generator"))
         self.d_params = _FlatParams(self.store.trainable_variables("discriminator"))
         if self.distributed:  # identical weights on every rank
-            torch.distributed.broadcast(self.g_params.flat, 0)
-            torch.distributed.broadcast(self.d_params.flat, 0)
+            from . import comm
+            if self._comm is None and not __import__("os").environ.get("GS_TORCH_COLLECTIVES"):
+                self._comm = comm.create(self.g_params.flat.device)   # RCCL on the backward's own stream (None on CPU / gloo)
+            if self._comm is not None:
+                self._comm.broadcast_(self.g_params.flat, 0)
+                self._comm.broadcast_(self.d_params.flat, 0)
+            else:
+                torch.distributed.broadcast(self.g_params.flat, 0)
+                torch.distributed.broadcast(self.d_params.flat, 0)
             self.g_params.make_buckets(self.bucket_bytes // 4, reverse=True)
             self.d_params.make_buckets(self.bucket_bytes // 4, reverse=False)
         K = kernels.get()
@@ -266,6 +274,8 @@ class GANSynth(object):
     # kernel.  One bucket == the whole buffer when not distributed: one launch, as before.
     def _launch_reduce(self, params, bucket):
         a, b = params.buckets[bucket]
+        if self._comm is not None:   # same stream as the backward: ordered by the stream itself, no event hop
+            return self._comm.all_reduce_(params.grad[a:b])
         return torch.distributed.all_reduce(params.grad[a:b], async_op=True)
 
     def _reduce(self, params):

@@ -52,6 +52,26 @@ int gs_prof_collect(int* launches, double* total_ms, double* total_flops);
  * written once) and the time the binding roof allows, summed per launch (max of flops / peak_tflops and bytes / peak_gbps);
  * roof_ms_hbm_bound = the part of it that comes from HBM-bound launches.  Call before gs_prof_collect (which resets). */
 int gs_prof_roofline(double peak_tflops, double peak_gbps, double* total_bytes, double* roof_ms, double* roof_ms_hbm_bound);
+/* per-launch records (implicit-GEMM convs and their weight gradients) for a per-stage roofline: duration, algorithmic FLOPs and
+ * bytes, and desc[8 * i .. +8] = {kind, N, Hb, Wb, IC, OC, masked | sources, fused norm | deferred}; kind = 0 / 1 / 2 for the
+ * stride-1 / stride-2 / transposed conv map (ops.py:237-243, 269-276), 10 + that for its weight gradient.  Before gs_prof_collect. */
+int gs_prof_records(int max_records, int* n, double* ms, double* flops, double* bytes, int* desc);
+
+/* ------------------------------------------------------------------------ data parallelism (new: the reference is single GPU,
+ * gan_synth_main.py:91-98).  One process per GPU.  A communicator wraps ncclCommInitRank of RCCL (resolved at run
+ * time from the librccl.so.1 the process already has, none needed on one GPU); the collectives run ON THE CALLER'S STREAM, i.e.
+ * ordered behind the backward that produced the gradients and ahead of gs_adam_tf_step, with no cross-stream event.
+ *   gs_comm_unique_id   rank 0 fills 128 bytes (ncclGetUniqueId) and ships them to the other ranks by any means
+ *   gs_comm_init        every rank, same id; binds to the current HIP device
+ *   gs_allreduce_sum_f32 / gs_broadcast_f32   in place, fp32 (the flat gradient / parameter buffers of models.py:67-89's two
+ *                       optimizers; the 1 / world averaging is gs_adam_tf_step's grad_scale) */
+#define GS_COMM_ID_BYTES 128
+typedef struct gs_comm gs_comm;
+int gs_comm_unique_id(void* id128);
+int gs_comm_init(gs_comm** out, int rank, int world, const void* id128);
+int gs_comm_destroy(gs_comm* comm);
+int gs_allreduce_sum_f32(gs_comm* comm, float* data, int64_t count, void* stream);
+int gs_broadcast_f32(gs_comm* comm, float* data, int64_t count, int root, void* stream);
 
 /* ------------------------------------------------------------------------------- conv2d
  * tf.nn.conv2d NCHW/HWIO padding=SAME (ops.py:237-243) with ksize in {1,3}, stride in {1,2}
