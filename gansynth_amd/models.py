@@ -100,7 +100,7 @@ class _FlatParams(object):
 class GANSynth(object):
 
     def __init__(self, generator, discriminator, real_input_fn, fake_input_fn, spectral_params, hyper_params,
-                 dtype=torch.float32, store=None, distributed=False, use_graphs=False, bucket_bytes=8 << 20):
+                 dtype=torch.float32, store=None, distributed=False, use_graphs=False, bucket_bytes=None):
         self.generator, self.discriminator = generator, discriminator
         self.real_input_fn, self.fake_input_fn = real_input_fn, fake_input_fn
         self.spectral_params, self.hyper_params = spectral_params, hyper_params
@@ -109,7 +109,7 @@ class GANSynth(object):
         self.distributed = bool(distributed)
         self.world = torch.distributed.get_world_size() if self.distributed else 1
         self.rank = torch.distributed.get_rank() if self.distributed else 0
-        self.bucket_bytes = int(bucket_bytes)   # gradient all-reduce granularity (data parallel only)
+        self.bucket_bytes = None if bucket_bytes is None else int(bucket_bytes)   # gradient all-reduce granularity (None: see _build)
         self._inflight = None                   # (params, [(bucket, work)]) all-reduces launched during the eager backward's tail
         self._comm = None                       # comm.RcclComm: the gradient all-reduce on the backward's own stream (HIP + nccl only)
         self._peeked = None                     # a batch fetched ahead of the first step (train: eager build / restore)
@@ -159,6 +159,11 @@ class GANSynth(object):
             else:
                 torch.distributed.broadcast(self.g_params.flat, 0)
                 torch.distributed.broadcast(self.d_params.flat, 0)
+            if self.bucket_bytes is None:
+                # same-stream RCCL: collectives and updates are serial on the one stream whatever the granularity, so ONE
+                # all-reduce per network (fewest launches); torch.distributed's own collectives run on the communicator's stream
+                # and do overlap the per-bucket updates: 8 MiB buckets there
+                self.bucket_bytes = (64 << 20) if self._comm is not None else (8 << 20)
             self.g_params.make_buckets(self.bucket_bytes // 4, reverse=True)
             self.d_params.make_buckets(self.bucket_bytes // 4, reverse=False)
         K = kernels.get()
@@ -266,12 +271,16 @@ class GANSynth(object):
 
     # ------------------------------------------------------------------------- updates
     # Data parallelism (the reference is single-GPU): the flat gradient of a network is all-reduced in BUCKETS of
-    # whole tensors (<= bucket_bytes; the generator's 16.8 MB dense weight alone), in the order the backward pass completes them.
-    # Every bucket's all-reduce is launched asynchronously (torch.distributed runs it on the communicator's own stream, backend
-    # "nccl" = RCCL over xGMI) and the TF-Adam update of bucket k runs while bucket k+1 is still on the wire; in eager mode the
-    # first buckets are already launched from inside the backward's tail (the per-layer weight-gradient contraction,
-    # kernels.flush_wgrad_reductions) as soon as their last gradient is written.  The 1/world averaging is folded into the Adam
-    # kernel.  One bucket == the whole buffer when not distributed: one launch, as before.
+    # whole tensors (<= bucket_bytes; the generator's 16.8 MB dense weight alone), in the order the backward pass completes them,
+    # and the TF-Adam update runs bucket by bucket behind its all-reduce; in eager mode the first buckets are launched from inside
+    # the backward's tail (the per-layer weight-gradient contraction, kernels.flush_wgrad_reductions) as soon as their last
+    # gradient is written.  The 1/world averaging is folded into the Adam kernel.
+    # Two transports.  (i) Default on HIP: libgansynth_hip.so's own RCCL communicator (comm.py, gs_comm_*), every collective on
+    # the backward's stream.  Nothing overlaps then -- and nothing needs an event: measured on one MI355X (RCCL, world 1, graphs):
+    # 7.31 ms per iteration against 7.28 without any collective, whereas two all-reduces through torch.distributed's
+    # communicator stream cost 0.43-0.49 ms of cross-stream hops (7.71-7.82 ms) before a single byte moves.  One bucket per network
+    # by default (fewest launches).  (ii) torch.distributed's collectives (CPU / gloo tests, GS_TORCH_COLLECTIVES=1): asynchronous
+    # on the communicator's stream, bucket k+1 on the wire under the update of bucket k.
     def _launch_reduce(self, params, bucket):
         a, b = params.buckets[bucket]
         if self._comm is not None:   # same stream as the backward: ordered by the stream itself, no event hop
