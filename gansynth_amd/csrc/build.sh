@@ -11,7 +11,7 @@ for f in conv_igemm conv_api elementwise small_ops spectral spectral_wave; do
   if [ ! -f obj/$f.o ] || [ $f.hip -nt obj/$f.o ] || [ gs_common.h -nt obj/$f.o ] || [ conv_shared.h -nt obj/$f.o ] || [ spectral_plan.h -nt obj/$f.o ] || [ ../../include/gansynth_hip.h -nt obj/$f.o ]; then
     EXTRA=""
     # MFMA accumulators in VGPRs (hipcc otherwise parks them in AGPRs and every epilogue value costs a v_accvgpr_read)
-    [ $f = conv_igemm ] && EXTRA="-mllvm -amdgpu-mfma-vgpr-form"
+    [ $f = conv_igemm ] && EXTRA="-mllvm -amdgpu-mfma-vgpr-form $GS_IGEMM_FLAGS"
     # (complex arithmetic as float2: SLP-packing it into v_pk_* costs more register shuffling than it saves -- measured -8 %)
     [ $f = spectral_wave ] && EXTRA="-fno-slp-vectorize $GS_SW_FLAGS"
     ( hipcc $FLAGS $EXTRA -c $f.hip -o obj/$f.o ) &

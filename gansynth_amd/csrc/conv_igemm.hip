@@ -1063,6 +1063,9 @@ static int num_cus() {
 #ifndef GS_MAX_BLOCKS_PER_CU
 #define GS_MAX_BLOCKS_PER_CU 2
 #endif
+#ifndef GS_SMALL_D
+#define GS_SMALL_D 2   // stages in flight for the few-block ("small") configurations
+#endif
 template <typename T, int MODE, int A, int B, int TW, int TG, bool RESIDENT = false, int D = 2, bool NORM = false>
 static int launch_igemm(ConvP p, hipStream_t st) {
     constexpr int NP = 128 * B;
@@ -1142,7 +1145,7 @@ static int dispatch_igemm(ConvP p, hipStream_t st) {
         if (resident_ok && Wb >= 64) { if (norm) return launch_igemm<T, MODE, 1, 1, 64, 9, true, 1, true>(p, st); return launch_igemm<T, MODE, 1, 1, 64, 9, true, 1>(p, st); }
         // few blocks, each a serial chain of stages: 32-channel tiles double the number of busy CUs, 9-tap stages cut the
         // barriers and DMA round trips of the chain to a third
-        if (small) { if (Wb >= 32) return launch_igemm<T, MODE, 1, 1, 32, 9, false, 1>(p, st); return launch_igemm<T, MODE, 1, 1, 16, 9, false, 1>(p, st); }
+        if (small) { if (Wb >= 32) return launch_igemm<T, MODE, 1, 1, 32, 9, false, GS_SMALL_D>(p, st); return launch_igemm<T, MODE, 1, 1, 16, 9, false, GS_SMALL_D>(p, st); }
         if (!a2) { if (Wb >= 32) return launch_igemm<T, MODE, 1, 1, 32, 3>(p, st); return launch_igemm<T, MODE, 1, 1, 16, 3>(p, st); }
         if (Wb >= 32) { if (norm && OC == 64) return launch_igemm<T, MODE, 2, 1, 32, 3, false, 2, true>(p, st); return launch_igemm<T, MODE, 2, 1, 32, 3>(p, st); }
         return launch_igemm<T, MODE, 2, 1, 16, 3>(p, st);
@@ -1157,7 +1160,7 @@ static int dispatch_igemm(ConvP p, hipStream_t st) {
         return launch_igemm<T, MODE, 2, 1, 16, 3>(p, st);
     } else {
         if (resident_ok && Wb >= 64) { if (norm) return launch_igemm<T, MODE, 1, 2, 64, 9, true, 1, true>(p, st); return launch_igemm<T, MODE, 1, 2, 64, 9, true, 1>(p, st); }
-        if (small) { if (Wb >= 32) return launch_igemm<T, MODE, 1, 1, 32, 9, false, 1>(p, st); return launch_igemm<T, MODE, 1, 1, 16, 9, false, 1>(p, st); }
+        if (small) { if (Wb >= 32) return launch_igemm<T, MODE, 1, 1, 32, 9, false, GS_SMALL_D>(p, st); return launch_igemm<T, MODE, 1, 1, 16, 9, false, GS_SMALL_D>(p, st); }
         if (!a2) return launch_igemm<T, MODE, 1, 1, 32, 3>(p, st);
         if (Wb >= 32 && items64(2) >= 2 * cus) { if (norm && OC == 64) return launch_igemm<T, MODE, 2, 2, 32, 3, false, 1, true>(p, st); return launch_igemm<T, MODE, 2, 2, 32, 3, false, 1>(p, st); }
         if (resident64_ok && Wb >= 32 && items64(2) >= cus / 2) return launch_igemm<T, MODE, 2, 2, 32, 9, true>(p, st);

@@ -492,3 +492,60 @@ def test_distributed_step_on_rccl_world_size_1():
     finally:
         os.environ.pop("GS_TORCH_COLLECTIVES", None)
         dist.destroy_process_group()
+
+
+def test_full_size_progressive_schedule_end_to_end():
+    """BASELINE.json configs[4] at FULL size on the one GPU there is: the whole progressive schedule 2x16 -> 128x1024 (gan_synth_main.py:51-54,
+    networks.py:24-29) with growing_steps shortened to 1000 so that 520 iterations walk through every one of the eight graph regimes
+    (the 2x16 stage, six fade-ins, fully grown) -- batch 8, 64000-sample notes through the HIP spectral front end into
+    [8, 2, 128, 1024] real images, hipGraphs re-captured at every regime change, the fade weight read from device memory.
+    Checks: every regime visited in order, losses finite throughout, parameters finite, every colour block's gradient path used
+    at least once (its Adam second moment is non-zero), global_step bookkeeping."""
+    from gansynth_amd import variables
+    from gansynth_amd.dataset import synthetic_nsynth_input_fn
+    from gansynth_amd.models import GANSynth
+    from gansynth_amd.networks import PGGAN
+    from gansynth_amd.utils import Dict
+
+    growing_steps, total = 1000, 520
+    variables.set_default_store(variables.VariableStore(device="cuda", seed=0))
+    holder = {}
+    pg = PGGAN(min_resolution=[2, 16], max_resolution=[128, 1024], min_channels=32, max_channels=256,
+               growing_level=lambda: holder["m"].global_step / growing_steps)
+    notes = synthetic_nsynth_input_fn(8, range(24, 85), device="cuda", seed=3, num_batches=6)
+    pool = [notes() for _ in range(6)]          # six batches of generated notes, cycled (the generator itself is tests/test_dataset*)
+    cursor = [0]
+
+    def real_input_fn():
+        cursor[0] += 1
+        return pool[cursor[0] % len(pool)]
+
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    spectral = Dict(waveform_length=64000, sample_rate=16000, spectrogram_shape=[128, 1024], overlap=0.75)
+    model = GANSynth(pg.generator, pg.discriminator, real_input_fn, lambda: torch.randn(8, 256, device="cuda", generator=gen), spectral,
+                     Dict(R.DEFAULT_HYPER), dtype=torch.bfloat16, use_graphs=True)
+    holder["m"] = model
+    regimes, losses = [], []
+    orig = model.train_step
+
+    def step():
+        head, fade = pg._head_depth(pg.growing_depth)
+        if not regimes or regimes[-1] != (head, fade is not None):
+            regimes.append((head, fade is not None))
+        out = orig()
+        if model.global_step % 20 == 0:
+            losses.append((float(out[0]), float(out[1])))
+        return out
+
+    model.train_step = step
+    model.train(total_steps=total, log=None)
+    assert model.global_step == total and model.d_params.t == total and model.g_params.t == total
+    assert regimes == [(0, False)] + [(d, True) for d in range(1, 7)] + [(6, False)], regimes
+    assert all(np.isfinite(a) and np.isfinite(b) for a, b in losses), losses
+    assert torch.isfinite(model.g_params.flat).all() and torch.isfinite(model.d_params.flat).all()
+    for params in (model.g_params, model.d_params):
+        for name, p in params.named.items():
+            if "color_block" in name:
+                off = (p.data.data_ptr() - params.flat.data_ptr()) // 4
+                assert float(params.v[off:off + p.numel()].abs().max()) > 0, name   # every head was trained at some depth
+    assert set(model._graphs) == {"d", "g"} and model._graph_key == (6, True)
