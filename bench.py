@@ -95,15 +95,18 @@ def spectral_bench(batch=256, iters=20, cpu=True):
     for _ in range(3):
         G.convert_to_images(x, **P)
     torch.cuda.synchronize()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    # one HIP event pair around `iters` back-to-back launches on the launch stream: the host enqueues faster than the kernel
+    # runs, so the device stays busy and the average is the kernel's launch-to-launch time (an event pair around a single call
+    # would also time the ~10 us of host work between the first event and the launch)
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    for s, e in evs:
-        s.record()
+    s.record()
+    for _ in range(iters):
         G.convert_to_images(x, **P)
-        e.record()
+    e.record()
     torch.cuda.synchronize()
     wall = (time.perf_counter() - t0) / iters
-    kern_ms = sorted(s.elapsed_time(e) for s, e in evs)[iters // 2]   # median launch (event pair around each launch)
+    kern_ms = s.elapsed_time(e) / iters
     bytes_alg = batch * SPECTRAL_BYTES_PER_EXAMPLE
     achieved = bytes_alg / (kern_ms * 1e-3) / 1e9
     traffic = None

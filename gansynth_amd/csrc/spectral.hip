@@ -412,14 +412,14 @@ extern "C" int gs_if_unwrap(const gs_spectral_plan* p, const float* mel_phase, f
 }
 
 extern "C" size_t gs_stft_mel_if_workspace_bytes(const gs_spectral_plan* p, int batch) {
-    if (p && p->fast) return 0;   // the wave-per-frame path keeps the mel phases in registers
+    if (p && p->fast) return stft_wave_edge_bytes(p, batch);   // the mel phases stay in registers; 4 KB per run for the run-edge exchange
     return p ? (size_t)batch * p->time_steps * p->nbins * sizeof(float) : 0;
 }
 
 extern "C" int gs_stft_mel_if_fwd(const gs_spectral_plan* p, const float* wave, int batch, int wave_len, int front_pad, void* images,
                                   int dtype, void* ws, size_t ws_bytes, void* stream) {
     GS_CHECK_ARG(p && batch > 0 && wave_len > 0, "stft_mel_if_fwd: bad args");
-    if (p->fast) return launch_stft_wave_fused(p, wave, batch, wave_len, front_pad, images, dtype, as_stream(stream));
+    if (p->fast) return launch_stft_wave_fused(p, wave, batch, wave_len, front_pad, images, dtype, ws, ws_bytes, as_stream(stream));
     if (ws_bytes < gs_stft_mel_if_workspace_bytes(p, batch)) return fail(GS_ERR_WORKSPACE, "stft_mel_if_fwd: workspace too small");
     hipStream_t st = as_stream(stream);
     float* mel_phase = (float*)ws;

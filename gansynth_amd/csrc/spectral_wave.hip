@@ -52,6 +52,22 @@ __device__ __forceinline__ float2 lds_ld(const float2* p) {
     return make_float2(t.x, t.y);
 }
 
+// streaming store of one lane's (log-mel, IF) x 2 mel bins: the 1 MB per example of output must not evict the waveform lines the
+// next frames re-read (75 % overlap) from the XCD's L2
+__device__ __forceinline__ void st4_stream(float* p, const float (&o)[4]) {
+    typedef float f4_t __attribute__((ext_vector_type(4)));
+    const f4_t v = {o[0], o[1], o[2], o[3]};
+    __builtin_nontemporal_store(v, reinterpret_cast<f4_t*>(p));
+}
+__device__ __forceinline__ void st4_stream(bf16_t* p, const float (&o)[4]) {
+    typedef unsigned int u2_t __attribute__((ext_vector_type(2)));
+    const u2_t v = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+    __builtin_nontemporal_store(v, reinterpret_cast<u2_t*>(p));
+}
+
+// (Tried and measured slower: complex numbers as 2-vectors compiled to v_pk_add / v_pk_fma_f32 -- 7 % fewer VALU instructions, but
+//  aligned register pairs push the kernel over 168 VGPRs (14 spilled: 140 us) and without spills the hazard nops and longer
+//  dependent chains cost more than the issue slots save: 127 us against 119 us.)
 __device__ __forceinline__ float2 cmulw(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 
 // forward 4-point DFT in place: (a, b, c, d) = x[0..3] -> X[0..3]
@@ -198,12 +214,13 @@ __device__ __forceinline__ void frame_to_magphase(float2 (&v)[16], const float2*
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii) {
             const int i = 4 * half + ii;
-            const float2 e = make_float2(0.5f * (z1[ii].x + z2[ii].x), 0.5f * (z1[ii].y - z2[ii].y));    // (Z[k] + conj Z[N-k]) / 2
-            const float2 o = make_float2(0.5f * (z1[ii].y + z2[ii].y), -0.5f * (z1[ii].x - z2[ii].x));   // (Z[k] - conj Z[N-k]) / 2i
+            // (the window table carries the factor 1/2 of the untangle: Z here is half the transform, exactly)
+            const float2 e = make_float2(z1[ii].x + z2[ii].x, z1[ii].y - z2[ii].y);    // (Z[k] + conj Z[N-k]) / 2
+            const float2 o = make_float2(z1[ii].y + z2[ii].y, z2[ii].x - z1[ii].x);    // (Z[k] - conj Z[N-k]) / 2i
             const float2 t = cmulw(twu[i], o);
             float2 xa = make_float2(e.x + t.x, e.y + t.y);          // X[ka]
             const float2 xb = make_float2(e.x - t.x, t.y - e.y);    // X[1024 - ka] = conj(E - T)
-            if (i == 0 && lane == 0) xa = make_float2(z512.x, -z512.y);   // the ka = 0 slot carries bin 512 = conj(Z[512]); its xb is bin 1024
+            if (i == 0 && lane == 0) xa = make_float2(2.f * z512.x, -2.f * z512.y);   // the ka = 0 slot carries bin 512 = conj(Z[512]); its xb is bin 1024
             oa[ii] = make_float2(__builtin_amdgcn_sqrtf(xa.x * xa.x + xa.y * xa.y), atan2_poly(xa.y, xa.x));
             ob[ii] = make_float2(__builtin_amdgcn_sqrtf(xb.x * xb.x + xb.y * xb.y), atan2_poly(xb.y, xb.x));
         }
@@ -225,7 +242,8 @@ __device__ __forceinline__ void frame_to_magphase(float2 (&v)[16], const float2*
 #define SW_LDS_TWC (SW_LDS_TWU + 512 * 8)
 #define SW_LDS_HANN (SW_LDS_TWC + 16 * 64 * 8)
 #define SW_LDS_BUF (SW_LDS_HANN + (SW_TABLES_IN_LDS ? 1040 * 4 : 0))
-#define SW_LDS_TOTAL (SW_LDS_BUF + SW_WAVES * SW_BUF * 8)
+#define SW_LDS_FLAG (SW_LDS_BUF + SW_WAVES * SW_BUF * 8)
+#define SW_LDS_TOTAL (SW_LDS_FLAG + 64)
 
 // MODE 1: images[b][T][1024][2] = (log-mel, IF);  MODE 0: o0 / o1 = magnitude / phase [b][T][1024]
 template <typename T, int MODE>
@@ -234,7 +252,7 @@ __global__ __launch_bounds__(64 * SW_WAVES) void stft_wave_kernel(const float* _
                                                                   const float* __restrict__ mel_w, int TT, int step,
                                                                   const float* __restrict__ wave, int wave_len, int front_pad,
                                                                   int batch, int runs, float* __restrict__ o0, float* __restrict__ o1,
-                                                                  T* __restrict__ images) {
+                                                                  T* __restrict__ images, float* __restrict__ edge) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* s_w = reinterpret_cast<float*>(smem + SW_LDS_W);
     unsigned short* s_lo = reinterpret_cast<unsigned short*>(smem + SW_LDS_LO);
@@ -246,8 +264,8 @@ __global__ __launch_bounds__(64 * SW_WAVES) void stft_wave_kernel(const float* _
     float2* buf = reinterpret_cast<float2*>(smem + SW_LDS_BUF) + wid * SW_BUF;
     for (int i = threadIdx.x; i < 1024; i += 64 * SW_WAVES) {
         if (SW_TABLES_IN_LDS) {
-            s_hann[i] = hann[i];
-            if (i == 0) s_hann[1024] = hann[1024];
+            s_hann[i] = 0.5f * hann[i];   // (x 1/2: see the untangle)
+            if (i == 0) s_hann[1024] = 0.5f * hann[1024];
             if (MODE == 1) s_lo[i] = (unsigned short)mel_lo[i];
         }
         if (i < 64) s_twf[i] = tw1k[16 * i];
@@ -256,6 +274,8 @@ __global__ __launch_bounds__(64 * SW_WAVES) void stft_wave_kernel(const float* _
     }
     if (MODE == 1)
         for (int k = threadIdx.x; k < SW_WTOT; k += 64 * SW_WAVES) s_w[k] = mel_w[k];
+    volatile int* s_flag = reinterpret_cast<volatile int*>(smem + SW_LDS_FLAG);
+    if (threadIdx.x < 16) s_flag[threadIdx.x] = 0;
     __syncthreads();   // the only block-level barrier
     const long wr = (long)blockIdx.x * SW_WAVES + wid;
     if (wr >= (long)batch * runs) return;
@@ -267,7 +287,7 @@ __global__ __launch_bounds__(64 * SW_WAVES) void stft_wave_kernel(const float* _
     const float* wv = wave + (long)b * wave_len;
     const bool vec_ok = ((step | front_pad | wave_len) & 1) == 0;
 
-    float2 twu[8];   // W_2048^(lane + 64 i): lane constants, kept in registers (the LDS pipe is the bound of this kernel)
+    float2 twu[8];   // W_2048^(lane + 64 i): lane constants, kept in registers
 #pragma unroll
     for (int i = 0; i < 8; ++i) twu[i] = s_twu[lane + 64 * i];
     int2 lo[8];
@@ -283,19 +303,35 @@ __global__ __launch_bounds__(64 * SW_WAVES) void stft_wave_kernel(const float* _
     const float pi = 3.14159274101257324f;   // float32(np.pi), the constant the reference's unwrap uses
     const float two_pi = pi * 2.0f;
 
-    const int tfirst = (MODE == 1 && t0 > 0) ? t0 - 1 : t0;
+    // IF of a run's FIRST frame needs the mel phases of the frame before it, which the previous run owns.  When the runs of an
+    // example fill whole blocks (runs % SW_WAVES == 0) wave w+1 publishes the phases of its first frame (global scratch `edge`,
+    // an LDS flag behind a workgroup release) and wave w, done with its own last frame, writes that frame's IF; only the first
+    // wave of a block recomputes frame t0 - 1 ("lead").  Otherwise every run recomputes its lead frame.
+    const bool exch = MODE == 1 && edge != nullptr && runs % SW_WAVES == 0;
+    const bool from_left = exch && wid != 0 && t0 > 0;                               // my first frame's IF is written by wave wid - 1
+    const bool to_right = exch && wid != SW_WAVES - 1 && t1 < TT;                    // I write the IF of frame t1 (wave wid + 1's first)
+    auto wrapped = [&](float d) __attribute__((always_inline)) {                      // spectral_ops.py:21-33 on one difference
+        const float x = d + pi;
+        float md = fmaf(-floorf(x * 0.15915494309189535f), two_pi, x);   // floor-mod(d + pi, 2 pi) (exact: one fma)
+        if (md < 0.f) md += two_pi;
+        if (md >= two_pi) md -= two_pi;
+        md -= pi;
+        if (md == -pi && d > 0.f) md = pi;
+        return md;
+    };
+    const int tfirst = (MODE == 1 && t0 > 0 && !from_left) ? t0 - 1 : t0;
     for (int t = tfirst; t < t1; ++t) {
         const bool lead = t < t0;                       // frame t0 - 1: only its mel phases are needed
         const int base = t * step - front_pad;
         const bool silent = base + 2048 <= 0 || base >= wave_len;   // entirely inside the padding: spectrum exactly 0
         if (!silent) {
             float2 v[16], xs[16];
-            load_frame(wv, wave_len, base, vec_ok, lane, xs);   // (no software prefetch: the other three waves of the SIMD cover the latency)
+            load_frame(wv, wave_len, base, vec_ok, lane, xs);   // (a register prefetch of the next frame spills at 168 VGPRs: measured 150 us)
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const int n = lane + 64 * j;
                 float2 h;
-                if (!SW_TABLES_IN_LDS) h = *reinterpret_cast<const float2*>(hann + 2 * n);   // (8 KB table shared by every wave: L1)
+                if (!SW_TABLES_IN_LDS) { h = *reinterpret_cast<const float2*>(hann + 2 * n); h.x *= 0.5f; h.y *= 0.5f; }   // (8 KB table shared by every wave: L1)
                 else if (j < 8) h = *reinterpret_cast<const float2*>(s_hann + 2 * n);        // w[2n], w[2n+1]
                 else h = make_float2(s_hann[2048 - 2 * n], s_hann[2047 - 2 * n]);             // symmetric half
                 v[j] = make_float2(xs[j].x * h.x, xs[j].y * h.y);
@@ -341,22 +377,35 @@ __global__ __launch_bounds__(64 * SW_WAVES) void stft_wave_kernel(const float* _
             const float ap[2] = {ap0, ap1};
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                const float d = ap[e] - prev[2 * j + e];
-                const float x = d + pi;
-                float md = fmaf(-floorf(x * 0.15915494309189535f), two_pi, x);   // floor-mod(d + pi, 2 pi) (exact: one fma)
-                if (md < 0.f) md += two_pi;
-                if (md >= two_pi) md -= two_pi;
-                md -= pi;
-                if (md == -pi && d > 0.f) md = pi;
-                vif[e] = (t == 0 ? ap[e] : md) * 0.31830988618379069f;
+                const float md = wrapped(ap[e] - prev[2 * j + e]);
+                vif[e] = (t == 0 ? ap[e] : md) * 0.31830988618379069f;   // (a run's first frame in exchange mode: placeholder, see below)
                 prev[2 * j + e] = ap[e];
             }
+            if (from_left && t == t0)
+                *reinterpret_cast<float2*>(edge + ((long)b * runs + r) * 1024 + 128 * j + 2 * lane) = make_float2(ap0, ap1);
             if (!lead) {
-                const float l0 = (__builtin_amdgcn_logf(am0 + 1.0e-6f) * 0.69314718055994531f + 3.76f) * (1.0f / 10.05f);
-                const float l1 = (__builtin_amdgcn_logf(am1 + 1.0e-6f) * 0.69314718055994531f + 3.76f) * (1.0f / 10.05f);
+                // (ln(x) + 3.76) / 10.05 = log2(x) * (ln 2 / 10.05) + 3.76 / 10.05
+                const float l0 = fmaf(__builtin_amdgcn_logf(am0 + 1.0e-6f), 0.068969869f, 0.37412935f);
+                const float l1 = fmaf(__builtin_amdgcn_logf(am1 + 1.0e-6f), 0.068969869f, 0.37412935f);
                 const float o[4] = {l0, vif[0], l1, vif[1]};
-                st4(images + (row + 128 * j + 2 * lane) * 2, o);
+                st4_stream(images + (row + 128 * j + 2 * lane) * 2, o);
             }
+        }
+        if (from_left && t == t0) {   // this frame's image row and phases are out: tell wave wid - 1
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) s_flag[wid] = 1;
+        }
+    }
+    if (MODE == 1 && to_right) {
+        while (s_flag[wid + 1] == 0) __builtin_amdgcn_s_sleep(8);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const float* nxt = edge + ((long)b * runs + r + 1) * 1024;
+        T* dst = images + ((long)b * TT + t1) * 2048;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float2 p2 = *reinterpret_cast<const float2*>(nxt + 128 * j + 2 * lane);
+            DT<T>::st(dst + (128 * j + 2 * lane) * 2 + 1, wrapped(p2.x - prev[2 * j]) * 0.31830988618379069f);
+            DT<T>::st(dst + (128 * j + 2 * lane) * 2 + 3, wrapped(p2.y - prev[2 * j + 1]) * 0.31830988618379069f);
         }
     }
 }
@@ -366,6 +415,7 @@ static int runs_per_example(int batch, int time_steps) {
     int runs = (256 * SW_WAVES + batch - 1) / batch;
     if (runs > time_steps) runs = time_steps;
     if (runs < 1) runs = 1;
+    if (runs >= SW_WAVES) runs -= runs % SW_WAVES;   // whole blocks per example: neighbouring runs exchange their edge phases in the block
     return runs;
 }
 
@@ -384,16 +434,21 @@ bool stft_wave_shape_ok(const int* cnt) {
     return true;
 }
 
+size_t stft_wave_edge_bytes(const gs_spectral_plan* p, int batch) {
+    return (size_t)batch * runs_per_example(batch, p->time_steps) * 1024 * sizeof(float);
+}
+
 int launch_stft_wave_fused(const gs_spectral_plan* p, const float* wave, int batch, int wave_len, int front_pad, void* images, int dtype,
-                           hipStream_t st) {
+                           void* ws, size_t ws_bytes, hipStream_t st) {
     const int runs = runs_per_example(batch, p->time_steps);
+    float* edge = ws_bytes >= stft_wave_edge_bytes(p, batch) ? reinterpret_cast<float*>(ws) : nullptr;   // (no scratch: every run recomputes its lead frame)
     const long nruns = (long)batch * runs;
     GS_DISPATCH_DTYPE(dtype, {
         auto kern = stft_wave_kernel<T, 1>;
         if (int e = set_lds(kern, SW_LDS_TOTAL)) return e;
         hipLaunchKernelGGL(kern, dim3((unsigned)cdiv(nruns, SW_WAVES)), dim3(64 * SW_WAVES), SW_LDS_TOTAL, st, (const float*)p->hann,
                            (const float2*)p->tw1k, (const float2*)p->twp, (const int*)p->mel_lo, (const float*)p->mel_w, p->time_steps,
-                           p->frame_step, wave, wave_len, front_pad, batch, runs, (float*)nullptr, (float*)nullptr, (T*)images);
+                           p->frame_step, wave, wave_len, front_pad, batch, runs, (float*)nullptr, (float*)nullptr, (T*)images, edge);
     });
     GS_CHECK_LAUNCH();
     return 0;
@@ -407,7 +462,7 @@ int launch_stft_wave_magphase(const gs_spectral_plan* p, const float* wave, int 
     if (int e = set_lds(kern, SW_LDS_TOTAL)) return e;
     hipLaunchKernelGGL(kern, dim3((unsigned)cdiv(nruns, SW_WAVES)), dim3(64 * SW_WAVES), SW_LDS_TOTAL, st, (const float*)p->hann,
                        (const float2*)p->tw1k, (const float2*)p->twp, (const int*)p->mel_lo, (const float*)p->mel_w, p->time_steps, p->frame_step,
-                       wave, wave_len, front_pad, batch, runs, mag, phase, (float*)nullptr);
+                       wave, wave_len, front_pad, batch, runs, mag, phase, (float*)nullptr, (float*)nullptr);
     GS_CHECK_LAUNCH();
     return 0;
 }
