@@ -220,6 +220,78 @@ static __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __res
     }
 }
 
+// C[M][N] = A[M][K] @ B[K][N] for M, N multiples of 128 and K a multiple of 16: exact-fp32 MFMA (v_mfma_f32_32x32x2_f32, 157 TF/s
+// peak), 128 x 128 block tile, 4 waves each owning 64 x 64 (2 x 2 accumulator tiles), K step 16.  Both operand tiles sit k-major in
+// LDS (As[k][m], Bs[k][n], rows padded to 132) so that the one-float-per-lane MFMA operands are conflict-free ds_read_b32; A is
+// transposed on its way in (coalesced 64-byte rows from global, 2-way conflicts on the LDS write).  Two blocks per CU (34 KB of LDS,
+// ~110 VGPRs) overlap one block's staging with the other's MFMAs.  The pinv(mel) contraction of the inverse path: M = 2 x examples
+// x 128 frames (magnitude and phase stacked), N = K = 1024; the 4 MB B matrix stays in L2.
+static __global__ __launch_bounds__(256) void gemm_f32_128_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
+                                                                    int M, int N, int K) {
+    __shared__ float As[16][132];
+    __shared__ float Bs[16][132];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, hi = lane >> 5, l31 = lane & 31;
+    // (blocks of one B column panel are adjacent: the 64 KB panel of B stays hot while A streams)
+    const int nb = N / 128;
+    const int m0 = (blockIdx.x / nb) * 128, n0 = (blockIdx.x % nb) * 128;
+    const int wm = (wv >> 1) * 64, wn = (wv & 1) * 64;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // staging roles: A -- 4 lanes per 64-byte row, 64 rows per pass, 2 passes; B -- 32 lanes per 512-byte row, 8 rows per pass, 2 passes
+    const int a_row = tid >> 2, a_kq = tid & 3;
+    const int b_row = tid >> 5, b_col = (tid & 31) * 4;
+    const float* ap = A + (long)(m0 + a_row) * K + 4 * a_kq;
+    const float* bp = B + (long)b_row * N + n0 + b_col;
+    float4 ra[2], rb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        ra[i] = *reinterpret_cast<const float4*>(ap + (long)(64 * i) * K);
+        rb[i] = *reinterpret_cast<const float4*>(bp + (long)(8 * i) * N);
+    }
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        __syncthreads();   // the previous step's fragment reads are done
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            As[4 * a_kq + 0][a_row + 64 * i] = ra[i].x;
+            As[4 * a_kq + 1][a_row + 64 * i] = ra[i].y;
+            As[4 * a_kq + 2][a_row + 64 * i] = ra[i].z;
+            As[4 * a_kq + 3][a_row + 64 * i] = ra[i].w;
+            *reinterpret_cast<float4*>(&Bs[b_row + 8 * i][b_col]) = rb[i];
+        }
+        __syncthreads();
+        if (k0 + 16 < K) {   // the next step's global loads fly under this step's MFMAs
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ra[i] = *reinterpret_cast<const float4*>(ap + (long)(64 * i) * K + k0 + 16);
+                rb[i] = *reinterpret_cast<const float4*>(bp + (long)(k0 + 16 + 8 * i) * N);
+            }
+        }
+#pragma unroll
+        for (int kk = 0; kk < 16; kk += 2) {
+            const float a0 = As[kk + hi][wm + l31], a1 = As[kk + hi][wm + 32 + l31];
+            const float b0 = Bs[kk + hi][wn + l31], b1 = Bs[kk + hi][wn + 32 + l31];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                C[(long)row * N + n0 + wn + 32 * j + l31] = acc[i][j][r];
+            }
+}
+
 // one workgroup per (frame, example): spectrum from (mag, phase), DC = 0 (spectral_ops.py:128-131), packed inverse
 // real FFT, multiply by the inverse window; frames[b][T][L]
 static __global__ __launch_bounds__(256) void istft_kernel(gs_spectral_plan p, const float* __restrict__ mag, const float* __restrict__ phase, float* __restrict__ frames) {
@@ -454,9 +526,14 @@ extern "C" int gs_mel_if_to_waveform(const gs_spectral_plan* p, const void* imag
     float* frames = ph + rows * H;
     GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((inv_prep_kernel<T>), dim3(cdiv((long)batch * H, 256)), dim3(256), 0, st, *p, (const T*)images, mel_mag, mel_ph, batch));
     GS_CHECK_LAUNCH();
-    dim3 gg(cdiv(H, 64), cdiv(rows, 64));
-    hipLaunchKernelGGL(gemm_f32_kernel, gg, dim3(256), 0, st, mel_mag, p->pinv, mag, (int)rows, H, H);
-    hipLaunchKernelGGL(gemm_f32_kernel, gg, dim3(256), 0, st, mel_ph, p->pinv, ph, (int)rows, H, H);
+    // [mel_mag; mel_phase] @ pinv(mel) -> [mag; phase]: the two contractions of spectral_ops.py:123,125 share the matrix and are
+    // stacked in the workspace, so they are ONE GEMM with 2 x rows
+    if ((2 * rows) % 128 == 0 && H % 128 == 0) {
+        hipLaunchKernelGGL(gemm_f32_128_kernel, dim3((unsigned)((2 * rows / 128) * (H / 128))), dim3(256), 0, st, mel_mag, p->pinv, mag, (int)(2 * rows), H, H);
+    } else {
+        dim3 gg(cdiv(H, 64), cdiv(2 * rows, 64));
+        hipLaunchKernelGGL(gemm_f32_kernel, gg, dim3(256), 0, st, mel_mag, p->pinv, mag, (int)(2 * rows), H, H);
+    }
     GS_CHECK_LAUNCH();
     hipLaunchKernelGGL(istft_kernel, dim3(p->time_steps, batch), dim3(256), 0, st, *p, mag, ph, frames);
     GS_CHECK_LAUNCH();
