@@ -275,7 +275,8 @@ def main():
     launches, conv_ms, conv_flops = K.prof_collect()
     K.prof_enable(False)
     stages = per_stage(records, prof_steps, PEAK[args.dtype], args.dtype)
-    kernel_launches = count_launches(model) if rank == 0 and not args.no_launch_count else None
+    # (one GPU only: an extra iteration on rank 0 alone would leave the other ranks out of its collectives)
+    kernel_launches = count_launches(model) if world == 1 and not distributed and not args.no_launch_count else None
     if distributed:
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
