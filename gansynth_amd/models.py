@@ -33,6 +33,24 @@ _PIPELINE = bool(__import__("os").environ.get("GS_PIPELINE"))   # opt-in, see GA
 _PIPE_SIDE = {"0": False, "1": True}.get(__import__("os").environ.get("GS_PIPE_SIDE", ""))
 
 
+class _quiet_gc(object):
+    """Collect garbage NOW and keep the cyclic collector off while a hipGraph is being captured: a collection in the middle of a
+    capture may destroy an old CUDAGraph / event of an earlier trainer (a destructor that is illegal during capture: the process
+    aborts).  torch.cuda.graph no longer collects on entry by itself."""
+
+    def __enter__(self):
+        import gc
+        self._gc = gc
+        gc.collect()
+        self._was = gc.isenabled()
+        gc.disable()
+
+    def __exit__(self, *exc):
+        if self._was:
+            self._gc.enable()
+        return False
+
+
 class _FlatParams(object):
     """All trainable variables of one scope re-homed into one flat fp32 buffer (+grad, m, v)."""
 
@@ -417,7 +435,7 @@ class GANSynth(object):
                 # (kernels.adam_tf_step): bring them up to date now so that the captured graph holds no re-layout launches
                 K.refresh_weights()
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
+                with _quiet_gc(), torch.cuda.graph(graph):
                     loss = self._forward_backward(which, *static)
             finally:
                 owner.fade_weight = None   # (only captured launches use the table; eager callers keep passing the number)
@@ -473,10 +491,10 @@ class GANSynth(object):
         torch.cuda.current_stream().wait_stream(side)
         K.refresh_weights()   # (see _run: the captured graphs hold no re-layout launches)
         ga = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(ga):
+        with _quiet_gc(), torch.cuda.graph(ga):
             part_a = self._part_a(which, *sa)
         gb = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gb, pool=ga.pool()):
+        with _quiet_gc(), torch.cuda.graph(gb, pool=ga.pool()):
             loss = self._part_b(which, part_a, *sb)
         return {"a": ga, "b": gb, "sa": sa, "sb": sb, "loss": loss}
 
