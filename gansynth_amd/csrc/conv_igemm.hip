@@ -186,28 +186,39 @@ __device__ __forceinline__ void block_barrier() {
     asm volatile("" ::: "memory");
 }
 
-template <typename T, int MODE, int A, int B, int TW, int TG, bool RESIDENT, int D, bool NORM>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
+// RB: bytes of an operand row in LDS = of a channel chunk (64: four 16-byte slots, the original layout; 128: eight slots, whole
+// 128-byte cache lines per DMA row -- 53-60 instead of 30 B/cycle/CU through the L2 -> LDS path, scripts/probe/dma_rate.hip -- and
+// half the stages, barriers and DMA round trips per item; bf16 only)
+// SPEC: wave-specialised block of 8 waves -- waves 0-3 run the fragment reads, MFMAs and the epilogue exactly as before, waves 4-7
+// (one on each SIMD beside its compute wave) issue every DMA piece and hold the counted waits.  A wave issues one instruction per
+// ~5 cycles whatever it is (scripts/probe/valu_rate.hip), so in a 4-wave block the ~60 cycles of each DMA piece (offset arithmetic,
+// M0, the load) come ON TOP of the MFMAs of the stage -- measured 2260 ticks per stage for 1152 ticks of MFMA on the few-block layers
+// (scripts/probe/igemm_trace.hip); on their own wave they run under them.
+template <typename T, int MODE, int A, int B, int TW, int TG, bool RESIDENT, int D, bool NORM, int RB = 64, bool SPEC = false>
+__global__ __launch_bounds__(SPEC ? 512 : 256) void conv_igemm_kernel(const ConvP p) {
     constexpr int NP = 128 * B;
     constexpr int TH = NP / TW;
     constexpr int PH = patch_dim<MODE>(TH), PW = patch_dim<MODE>(TW);
     constexpr int S = MODE == MODE_S2 ? 2 : 1;
     constexpr int NPH = MODE == MODE_T2 ? 4 : 1;
     constexpr int SZ = (int)sizeof(T);
-    constexpr int BK = 64 / SZ;
+    static_assert(RB == 64 || (RB == 128 && SZ == 2), "128-byte rows: bf16 only");
+    constexpr int BK = RB / SZ;
+    constexpr int SL = RB / 16;               // 16-byte slots per row
+    constexpr int KS = RB / 32;               // MFMA k-steps per row (a k-step = two slots: one per lane half)
     constexpr int OCT = 32 * A;
     constexpr int NTG = 9 / TG;
-    constexpr int PCH = PH * PW * 4;          // 16-byte slots of a patch chunk
+    constexpr int PCH = PH * PW * SL;         // 16-byte slots of a patch chunk
     constexpr int NPP = (PCH + 63) / 64;      // its 1 KiB DMA pieces ...
     constexpr int PP = (NPP + 3) / 4;         // ... per wave
     constexpr int PBUF = PP * 4096;           // bytes of one patch buffer (whole pieces for every wave; the excess is zero-filled)
-    constexpr int WBYTES = TG * OCT * 64;     // bytes of one weight stage
+    constexpr int WBYTES = TG * OCT * RB;     // bytes of one weight stage
     constexpr int NWP = WBYTES / 1024;
     constexpr int WP = (NWP + 3) / 4;
     constexpr int WBUF = WP * 4096;           // bytes of one weight buffer
     constexpr int NPB = 1 + (D + NTG - 1) / NTG;  // patch ring
     constexpr int NWB = D + 1;                    // weight ring
-    constexpr int NSTEP = 2 * TG;                 // (tap, k-step) MFMA steps of a stage
+    constexpr int NSTEP = KS * TG;                // (tap, k-step) MFMA steps of a stage
     typedef typename Mma<T>::frag_t frag_t;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -223,7 +234,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wv8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = SPEC && wv8 >= 4;     // issues the DMA; !loader computes
+    const bool issuer = !SPEC || loader;
+    const bool computer = !SPEC || !loader;
+    const int wv = wv8 & 3;                   // index within the role: the wave's DMA pieces / its 32*B pixels
 
     // ---- this block's item list (XCD-contiguous when the grid is a multiple of 8)
     const int total = p.nsp * p.noct;
@@ -249,23 +264,33 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
 #pragma unroll
     for (int k = 0; k < PP; ++k) {
         const int slot = (wv + 4 * k) * 64 + lane;
-        const int row = slot >> 2, pos = slot & 3;
+        const int row = slot / SL, pos = slot % SL;
         const int ly = row / PW, lx = row - ly * PW;
-        p_voff[k] = ((ly * Wi + lx) * IC) * SZ + ((pos ^ ((lx >> 2) & 3)) << 4);
+        // slot swizzle: rows one bank row (256 bytes) apart must land on different slots -- every 4th row of 64 bytes, every 2nd of 128
+        p_voff[k] = ((ly * Wi + lx) * IC) * SZ + ((pos ^ (RB == 64 ? (lx >> 2) & 3 : (lx >> 1) & 7)) << 4);
         p_lx[k] = slot < PCH ? lx : 0x40000000;  // never inside the image
     }
-    const int w_lane = ((lane >> 2) * IC) * SZ + (((lane & 3) ^ ((lane >> 4) & 3)) << 4);
-    // block-constant scalar part of every weight piece: rows [tap tt][16*sub ..] of the stage (T2 walks the taps phase by phase)
+    // a 1 KiB weight piece = RPP rows of the stage; row r of a 32-row channel tile takes slot key (r >> 2) & 3 (64-byte rows) or
+    // (r >> 1) & 7 (128-byte rows: pieces of 8 rows, so the key also depends on the parity of the piece: two lane offsets)
+    constexpr int RPP = 1024 / RB;            // rows per piece
+    constexpr int SUBS = OCT / RPP;           // pieces per tap
+    const int w_lane0 = RB == 64 ? ((lane >> 2) * IC) * SZ + (((lane & 3) ^ ((lane >> 4) & 3)) << 4)
+                                 : ((lane >> 3) * IC) * SZ + (((lane & 7) ^ (lane >> 4)) << 4);
+    const int w_lane1 = RB == 64 ? w_lane0 : ((lane >> 3) * IC) * SZ + (((lane & 7) ^ (4 + (lane >> 4))) << 4);
+    // block-constant scalar part of every weight piece: rows [tap tt][RPP*sub ..] of the stage (T2 walks the taps phase by phase)
     int w_soff[NTG][WP];
+    bool w_odd[WP];
+#pragma unroll
+    for (int k = 0; k < WP; ++k) w_odd[k] = RB == 128 && (((wv + 4 * k) % SUBS) & 1);
 #pragma unroll
     for (int tg = 0; tg < NTG; ++tg)
 #pragma unroll
         for (int k = 0; k < WP; ++k) {
             const int j = wv + 4 * k;
-            const int tt = j / (2 * A), sub = j % (2 * A);
+            const int tt = j / SUBS, sub = j % SUBS;
             const int i = tg * TG + tt;
             const int wt = MODE == MODE_T2 ? (int)((0x453718620ULL >> (4 * (i < 9 ? i : 0))) & 15) : i;
-            w_soff[tg][k] = (NWP % 4 == 0 || j < NWP) ? ((wt * OC + sub * 16) * IC) * SZ : (int)0x80000000;
+            w_soff[tg][k] = (NWP % 4 == 0 || j < NWP) ? ((wt * OC + sub * RPP) * IC) * SZ : (int)0x80000000;
         }
     const unsigned img_bytes = (unsigned)Hi * Wi * IC * SZ;
     const unsigned w_bytes = 9u * IC * OC * SZ;
@@ -311,7 +336,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
     };
     auto issue_weight_piece = [&](int k, int tg, int wbase, unsigned dst_base) __attribute__((always_inline)) {
         // (pieces past the end of the stage carry 0x80000000: out of range for any descriptor)
-        lds_dma16(dst_base + a_wave + k * 4096, (unsigned)(w_lane + (w_soff[tg][k] + wbase)), rs_w);
+        lds_dma16(dst_base + a_wave + k * 4096, (unsigned)((w_odd[k] ? w_lane1 : w_lane0) + (w_soff[tg][k] + wbase)), rs_w);
     };
     constexpr int NPW = RESIDENT ? 0 : WP;
     auto stage_pieces = [](int tg) { return (tg == 0 ? PP : 0) + NPW; };  // DMA pieces a wave issues for a stage
@@ -349,38 +374,41 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
 
     // fragment byte offsets with the slot swizzle folded in: B side per (pixel group, horizontal tap offset, k step),
     // A side per k step; the vertical tap offset and the tap / channel-tile row are compile-time immediates
-    int b_off[B][3][2], a_off[2];
+    int b_off[B][3][KS], a_off[KS];
 #pragma unroll
     for (int b = 0; b < B; ++b) {
         const int q = (wv * B + b) * 32 + l31;
         const int pb0 = ((q / TW) * S) * PW + (q % TW) * S;
 #pragma unroll
         for (int ox = 0; ox < 3; ++ox) {
-            const int key = (((q % TW) * S + ox) >> 2) & 3;
+            const int lx = (q % TW) * S + ox;
+            const int key = RB == 64 ? (lx >> 2) & 3 : (lx >> 1) & 7;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) b_off[b][ox][ks] = (pb0 + ox) * 64 + (((ks * 2 + hi) ^ key) << 4);
+            for (int ks = 0; ks < KS; ++ks) b_off[b][ox][ks] = (pb0 + ox) * RB + (((ks * 2 + hi) ^ key) << 4);
         }
     }
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) a_off[ks] = l31 * 64 + (((ks * 2 + hi) ^ ((l31 >> 2) & 3)) << 4);
+    for (int ks = 0; ks < KS; ++ks) a_off[ks] = l31 * RB + (((ks * 2 + hi) ^ (RB == 64 ? (l31 >> 2) & 3 : (l31 >> 1) & 7)) << 4);
 
     // ---- prologue: resident weights and the first D stages go out first, the bias is staged while they fly (hipcc waits
     //      vmcnt(0) for the bias loads, which drains the DMAs too -- at this point that is exactly the wait that is needed)
     GS_TR(1);
-    if (RESIDENT) {
-        for (int ch = 0; ch < NCH; ++ch)
+    if (issuer) {
+        if (RESIDENT) {
+            for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
-            for (int k = 0; k < WP; ++k) issue_weight_piece(k, 0, (i_oc0 * IC + ch * BK) * SZ, a_wgt + ch * WBUF);
-    }
+                for (int k = 0; k < WP; ++k) issue_weight_piece(k, 0, (i_oc0 * IC + ch * BK) * SZ, a_wgt + ch * WBUF);
+        }
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
-        issue_setup(d % NTG);
+        for (int d = 0; d < D; ++d) {
+            issue_setup(d % NTG);
 #pragma unroll
-        for (int q = 0; q < stage_pieces(d % NTG); ++q) issue_piece(q, d % NTG);
-        issue_advance(d % NTG);
+            for (int q = 0; q < stage_pieces(d % NTG); ++q) issue_piece(q, d % NTG);
+            issue_advance(d % NTG);
+        }
     }
     GS_TR(2);
-    for (int c = tid; c < OC; c += 256) lbias[c] = p.bias ? p.bias[c] : 0.f;
+    for (int c = tid; c < OC; c += (SPEC ? 512 : 256)) lbias[c] = p.bias ? p.bias[c] : 0.f;
     wait_vmcnt(0);
     block_barrier();
     GS_TR(3);
@@ -398,22 +426,26 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
             for (int tg = 0; tg < NTG; ++tg) {
                 const int itg = (tg + D) % NTG;            // tap group of the stage issued during this one
                 const int npiece = stage_pieces(itg);
-                issue_setup(itg);
+                if (issuer) issue_setup(itg);
+                if (SPEC && loader) {   // the whole stage +D in one go, under the compute waves' MFMAs
+#pragma unroll
+                    for (int q = 0; q < npiece; ++q) issue_piece(q, itg);
+                }
                 // ---- MFMAs of this stage; fragment reads run one (tap, k-step) ahead, the DMA pieces of stage +D are
                 //      spread over the steps
                 const unsigned char* lp = lpatch + c_pb * PBUF;
                 const unsigned char* lw = RESIDENT ? lwgt + ch * WBUF : lwgt + c_wb * WBUF;
-                {
+                if (computer) {
                     constexpr int PF = NSTEP >= 6 ? 2 : 1;   // fragment reads run PF steps ahead of their MFMAs (LDS latency with 4
                                                              // waves on the pipe exceeds one step of 2-4 MFMAs)
                     frag_t af[PF + 1][A], bf[PF + 1][B];
                     // one fragment read of (step, r): r < A -> weight rows of channel tile r, else pixel group r - A
                     auto load_frag = [&](int step, int r) __attribute__((always_inline)) {
-                        const int tt = step >> 1, ks = step & 1, buf = step % (PF + 1);
+                        const int tt = step / KS, ks = step % KS, buf = step % (PF + 1);
                         const int i = tg * TG + tt;
                         const int oyv = tap_off<MODE>(tap_ky<MODE>(i)), oxv = tap_off<MODE>(tap_kx<MODE>(i));
-                        if (r < A) af[buf][r] = *reinterpret_cast<const frag_t*>(lw + (tt * OCT + r * 32) * 64 + a_off[ks]);
-                        else bf[buf][r - A] = *reinterpret_cast<const frag_t*>(lp + oyv * PW * 64 + b_off[r - A][oxv][ks]);
+                        if (r < A) af[buf][r] = *reinterpret_cast<const frag_t*>(lw + (tt * OCT + r * 32) * RB + a_off[ks]);
+                        else bf[buf][r - A] = *reinterpret_cast<const frag_t*>(lp + oyv * PW * RB + b_off[r - A][oxv][ks]);
                     };
 #if !defined(GS_ABL_NOMMA)
 #pragma unroll
@@ -429,7 +461,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
                     const int ppm = (npiece + NSTEP * NMMA - 1) / (NSTEP * NMMA);  // DMA pieces per MFMA slot
 #pragma unroll
                     for (int step = 0; step < NSTEP; ++step) {
-                        const int ph = tap_phase<MODE>(tg * TG + (step >> 1));
+                        const int ph = tap_phase<MODE>(tg * TG + step / KS);
 #pragma unroll
                         for (int m = 0; m < NMMA; ++m) {
 #ifndef GS_ABL_NOMMA
@@ -442,7 +474,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
 #endif
 #endif
 #ifndef GS_ABL_NODMA
-                            {
+                            if constexpr (!SPEC) {
                                 const int slot = step * NMMA + m;
 #pragma unroll
                                 for (int q = slot * ppm; q < (slot + 1) * ppm && q < npiece; ++q) issue_piece(q, itg);
@@ -452,9 +484,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
                         }
                     }
                 }
-                issue_advance(itg);
+                if (issuer) issue_advance(itg);
                 // ---- the next stage must have landed before the barrier below: leave only the younger stages in flight
-                {
+                if (issuer) {
                     int younger = 0;
 #pragma unroll
                     for (int d = 2; d <= D; ++d) younger += stage_pieces((tg + d) % NTG);
@@ -468,7 +500,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
                 //      leave with 16 bytes.  fp32: a quad is 16 bytes.  bf16: v_permlane32_swap exchanges the quads q / q+1
                 //      between the two lane halves, after which lane (pixel, hi) owns 8 consecutive channels 16*(q/2) + 8*hi + ...
 #ifndef GS_ABL_NOEPI
-                if (tg == NTG - 1 && ch == NCH - 1) {
+                if (tg == NTG - 1 && ch == NCH - 1 && computer) {
                     const int Ho = MODE == MODE_T2 ? 2 * Hb : Hb, Wo = MODE == MODE_T2 ? 2 * Wb : Wb;
                     const float slope = p.act == GS_ACT_LRELU ? 0.2f : 1.f;
                     auto mask_factor = [&](float z) __attribute__((always_inline)) {
@@ -1066,16 +1098,16 @@ static int num_cus() {
 #ifndef GS_SMALL_D
 #define GS_SMALL_D 2   // stages in flight for the few-block ("small") configurations
 #endif
-template <typename T, int MODE, int A, int B, int TW, int TG, bool RESIDENT = false, int D = 2, bool NORM = false>
+template <typename T, int MODE, int A, int B, int TW, int TG, bool RESIDENT = false, int D = 2, bool NORM = false, int RB = 64, bool SPEC = false>
 static int launch_igemm(ConvP p, hipStream_t st) {
     constexpr int NP = 128 * B;
     constexpr int TH = NP / TW;
     constexpr int PH = patch_dim<MODE>(TH), PW = patch_dim<MODE>(TW);
     constexpr int OCT = 32 * A;
-    constexpr int BK = 64 / (int)sizeof(T);
+    constexpr int BK = RB / (int)sizeof(T);
     constexpr int NTG = 9 / TG;
-    constexpr int PBUF = ((PH * PW * 4 + 255) / 256) * 4096;
-    constexpr int WBUF = ((TG * OCT * 64 + 4095) / 4096) * 4096;
+    constexpr int PBUF = ((PH * PW * (RB / 16) + 255) / 256) * 4096;
+    constexpr int WBUF = ((TG * OCT * RB + 4095) / 4096) * 4096;
     constexpr int NPB = 1 + (D + NTG - 1) / NTG, NWB = D + 1;
     p.tiles_x = cdiv(p.Wb, TW);
     p.tiles_y = cdiv(p.Hb, TH);
@@ -1093,7 +1125,8 @@ static int launch_igemm(ConvP p, hipStream_t st) {
         p.y2 = nullptr;
         if (p.norm_pending) *p.norm_pending = 1;
     }
-    auto kern = conv_igemm_kernel<T, MODE, A, B, TW, TG, RESIDENT, D, NORM>;
+    if (p.IC % BK != 0) return fail(GS_ERR_UNSUPPORTED, "conv igemm: %d input channels with %d-channel chunks", p.IC, BK);
+    auto kern = conv_igemm_kernel<T, MODE, A, B, TW, TG, RESIDENT, D, NORM, RB, SPEC>;
     static size_t max_set = 0;  // per template instantiation
     if (lds > max_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -1103,7 +1136,7 @@ static int launch_igemm(ConvP p, hipStream_t st) {
     // resident blocks per CU: LDS-limited, and at most 2 (accumulator-heavy kernels hold 1-2 waves per SIMD)
     int per_cu = (int)((160 * 1024) / lds);
     if (per_cu > GS_MAX_BLOCKS_PER_CU) per_cu = GS_MAX_BLOCKS_PER_CU;
-    if (per_cu < 1) per_cu = 1;
+    if (per_cu < 1 || SPEC) per_cu = 1;   // (8 waves of up to 256 VGPRs: one block per CU)
     const long total = (long)p.nsp * p.noct;
     long grid = (long)per_cu * num_cus();
     if (grid > total) grid = total;
@@ -1113,11 +1146,19 @@ static int launch_igemm(ConvP p, hipStream_t st) {
     // algorithmic bytes: input + output + weights, + the activation mask a masked launch reads, + the second output of a fused norm
     const double bytes = ((double)p.N * p.Hi * p.Wi * p.IC + out_px * p.OC * (1.0 + (p.mask ? 1.0 : 0.0) + ((NORM && p.y) ? 1.0 : 0.0)) + 9.0 * p.IC * p.OC) * sizeof(T);
     ProfScope ps(st, flops, bytes, MODE, p.N, p.Hb, p.Wb, p.IC, p.OC, p.mask ? 1 : 0, NORM ? 1 : 0);
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(SPEC ? 512 : 256), lds, st, p);
     return 0;
 }
 
 // choose the tile configuration from (OC, Wb, problem size)
+// Which configuration families run wave-specialised (bit 0 few-block, 1 S1, 2 S2 / T2; GS_SPEC overrides for measurements).  Measured
+// per iteration of configs[1] (scripts/run_spec.sh): few-block layers 1086 -> 1068 us; the larger S1 / S2 / T2 tiles LOSE 60-190 us
+// (their stages are bound by the fragment reads and the barrier, not by the DMA issue) -- so only bit 0 is on.
+static int spec_mask() {
+    static const int m = getenv("GS_SPEC") ? atoi(getenv("GS_SPEC")) : 1;
+    return m;
+}
+
 template <typename T, int MODE>
 static int dispatch_igemm(ConvP p, hipStream_t st) {
     constexpr int BK = 64 / (int)sizeof(T);
@@ -1129,7 +1170,7 @@ static int dispatch_igemm(ConvP p, hipStream_t st) {
     // blocks the layer gives with 128*B-pixel x 64-channel tiles (TW = 32)
     auto items64 = [&](int B_) { return (long)p.N * cdiv(p.Hb, 4 * B_) * cdiv(Wb, 32) * (OC / 64); };
 #ifdef GS_FORCE_CFG   // probes only: -DGS_FORCE_MODE=0 -DGS_FORCE_CFG=2,2,32,3,false,1
-    if constexpr (MODE == GS_FORCE_MODE) return launch_igemm<T, MODE, GS_FORCE_CFG>(p, st);
+    if constexpr (MODE == GS_FORCE_MODE && sizeof(T) == 2) return launch_igemm<T, MODE, GS_FORCE_CFG>(p, st);
 #endif
     // Measured on the layers of the fully grown networks (scripts/probe/run_variants.sh): two resident blocks per CU (<= 80 KiB
     // of LDS each, i.e. a one-stage-deep ring) beat one block with a deeper ring or a larger tile wherever the layer has at
@@ -1145,9 +1186,29 @@ static int dispatch_igemm(ConvP p, hipStream_t st) {
         if (resident_ok && Wb >= 64) { if (norm) return launch_igemm<T, MODE, 1, 1, 64, 9, true, 1, true>(p, st); return launch_igemm<T, MODE, 1, 1, 64, 9, true, 1>(p, st); }
         // few blocks, each a serial chain of stages: 32-channel tiles double the number of busy CUs, 9-tap stages cut the
         // barriers and DMA round trips of the chain to a third
-        if (small) { if (Wb >= 32) return launch_igemm<T, MODE, 1, 1, 32, 9, false, GS_SMALL_D>(p, st); return launch_igemm<T, MODE, 1, 1, 16, 9, false, GS_SMALL_D>(p, st); }
+        if (small) {
+            // 128-byte operand rows (whole cache lines per DMA row, half the stages): the few-block layers are bound by the L2 -> LDS
+            // rate of a CU, not by its MFMAs
+            if constexpr (sizeof(T) == 2) {
+                static const bool rb128 = getenv("GS_NO_RB128") == nullptr;
+                if (rb128 && p.IC % 64 == 0) {
+                    if (spec_mask() & 1) {
+                        if (Wb >= 32) return launch_igemm<T, MODE, 1, 1, 32, 9, false, 1, false, 128, true>(p, st);
+                        return launch_igemm<T, MODE, 1, 1, 16, 9, false, 1, false, 128, true>(p, st);
+                    }
+                    if (Wb >= 32) return launch_igemm<T, MODE, 1, 1, 32, 9, false, 1, false, 128>(p, st);
+                    return launch_igemm<T, MODE, 1, 1, 16, 9, false, 1, false, 128>(p, st);
+                }
+            }
+            if (Wb >= 32) return launch_igemm<T, MODE, 1, 1, 32, 9, false, GS_SMALL_D>(p, st);
+            return launch_igemm<T, MODE, 1, 1, 16, 9, false, GS_SMALL_D>(p, st);
+        }
         if (!a2) { if (Wb >= 32) return launch_igemm<T, MODE, 1, 1, 32, 3>(p, st); return launch_igemm<T, MODE, 1, 1, 16, 3>(p, st); }
-        if (Wb >= 32) { if (norm && OC == 64) return launch_igemm<T, MODE, 2, 1, 32, 3, false, 2, true>(p, st); return launch_igemm<T, MODE, 2, 1, 32, 3>(p, st); }
+        if (Wb >= 32) {
+            if (norm && OC == 64) return launch_igemm<T, MODE, 2, 1, 32, 3, false, 2, true>(p, st);
+            if (spec_mask() & 4) return launch_igemm<T, MODE, 2, 1, 32, 3, false, 2, false, 64, true>(p, st);
+            return launch_igemm<T, MODE, 2, 1, 32, 3>(p, st);
+        }
         return launch_igemm<T, MODE, 2, 1, 16, 3>(p, st);
     } else if constexpr (MODE == MODE_S2) {
         if (small) { if (Wb >= 32) return launch_igemm<T, MODE, 1, 1, 32, 9, false, 1>(p, st); return launch_igemm<T, MODE, 1, 1, 16, 9, false, 1>(p, st); }
@@ -1155,19 +1216,56 @@ static int dispatch_igemm(ConvP p, hipStream_t st) {
         // stride 2: the patch is 4.6x the output tile, so a 128-channel tile (the patch staged once for all of them) is worth
         // more than a second pixel tile as long as every CU still gets a block
         if (OC == 64 && nch == 1 && Wb >= 32 && items64(1) >= cus) return launch_igemm<T, MODE, 2, 1, 32, 9, true, 1>(p, st);   // 36 KiB of weights: resident
-        if (OC % 128 == 0 && Wb >= 32 && (long)p.N * cdiv(p.Hb, 4) * cdiv(Wb, 32) * (OC / 128) >= cus) return launch_igemm<T, MODE, 4, 1, 32, 3>(p, st);
-        if (Wb >= 32) return launch_igemm<T, MODE, 2, 1, 32, 3>(p, st);
+        if (OC % 128 == 0 && Wb >= 32 && (long)p.N * cdiv(p.Hb, 4) * cdiv(Wb, 32) * (OC / 128) >= cus) {
+            if (spec_mask() & 4) return launch_igemm<T, MODE, 4, 1, 32, 3, false, 2, false, 64, true>(p, st);
+            return launch_igemm<T, MODE, 4, 1, 32, 3>(p, st);
+        }
+        if (Wb >= 32) {
+            if (spec_mask() & 4) return launch_igemm<T, MODE, 2, 1, 32, 3, false, 2, false, 64, true>(p, st);
+            return launch_igemm<T, MODE, 2, 1, 32, 3>(p, st);
+        }
         return launch_igemm<T, MODE, 2, 1, 16, 3>(p, st);
     } else {
         if (resident_ok && Wb >= 64) { if (norm) return launch_igemm<T, MODE, 1, 2, 64, 9, true, 1, true>(p, st); return launch_igemm<T, MODE, 1, 2, 64, 9, true, 1>(p, st); }
-        if (small) { if (Wb >= 32) return launch_igemm<T, MODE, 1, 1, 32, 9, false, GS_SMALL_D>(p, st); return launch_igemm<T, MODE, 1, 1, 16, 9, false, GS_SMALL_D>(p, st); }
+        if (small) {
+            // 128-byte operand rows (whole cache lines per DMA row, half the stages): the few-block layers are bound by the L2 -> LDS
+            // rate of a CU, not by its MFMAs
+            if constexpr (sizeof(T) == 2) {
+                static const bool rb128 = getenv("GS_NO_RB128") == nullptr;
+                if (rb128 && p.IC % 64 == 0) {
+                    if (spec_mask() & 1) {
+                        if (Wb >= 32) return launch_igemm<T, MODE, 1, 1, 32, 9, false, 1, false, 128, true>(p, st);
+                        return launch_igemm<T, MODE, 1, 1, 16, 9, false, 1, false, 128, true>(p, st);
+                    }
+                    if (Wb >= 32) return launch_igemm<T, MODE, 1, 1, 32, 9, false, 1, false, 128>(p, st);
+                    return launch_igemm<T, MODE, 1, 1, 16, 9, false, 1, false, 128>(p, st);
+                }
+            }
+            if (Wb >= 32) return launch_igemm<T, MODE, 1, 1, 32, 9, false, GS_SMALL_D>(p, st);
+            return launch_igemm<T, MODE, 1, 1, 16, 9, false, GS_SMALL_D>(p, st);
+        }
         if (!a2) return launch_igemm<T, MODE, 1, 1, 32, 3>(p, st);
-        if (Wb >= 32 && items64(2) >= 2 * cus) { if (norm && OC == 64) return launch_igemm<T, MODE, 2, 2, 32, 3, false, 1, true>(p, st); return launch_igemm<T, MODE, 2, 2, 32, 3, false, 1>(p, st); }
+        if (Wb >= 32 && items64(2) >= 2 * cus) {
+            if (norm && OC == 64) return launch_igemm<T, MODE, 2, 2, 32, 3, false, 1, true>(p, st);
+            if (spec_mask() & 2) return launch_igemm<T, MODE, 2, 2, 32, 3, false, 2, false, 64, true>(p, st);
+            return launch_igemm<T, MODE, 2, 2, 32, 3, false, 1>(p, st);
+        }
         if (resident64_ok && Wb >= 32 && items64(2) >= cus / 2) return launch_igemm<T, MODE, 2, 2, 32, 9, true>(p, st);
         // every block re-streams its 64 x IC x 9 weight slab from L2: the more pixels a block owns the smaller that
         // stream is per MFMA -- take the largest pixel tile that still gives every CU a block
-        if (Wb >= 32 && items64(2) >= cus) return launch_igemm<T, MODE, 2, 2, 32, 3>(p, st);
-        if (Wb >= 32) return launch_igemm<T, MODE, 2, 1, 32, 3>(p, st);
+        if (Wb >= 32 && items64(2) >= cus) {
+            if (spec_mask() & 2) return launch_igemm<T, MODE, 2, 2, 32, 3, false, 2, false, 64, true>(p, st);
+            // one block per CU: 128-byte rows halve the stages of the chain (22.0 -> 20.1 us on 256 -> 256 @ 16x128 x8, scripts/run_abl.sh)
+            if constexpr (sizeof(T) == 2) {
+                static const bool rb128 = getenv("GS_NO_RB128") == nullptr;
+                if (rb128 && p.IC % 64 == 0) return launch_igemm<T, MODE, 2, 2, 32, 3, false, 1, false, 128>(p, st);
+            }
+            return launch_igemm<T, MODE, 2, 2, 32, 3>(p, st);
+        }
+        if (Wb >= 32) {
+            if (spec_mask() & 2) return launch_igemm<T, MODE, 2, 1, 32, 3, false, 2, false, 64, true>(p, st);
+            return launch_igemm<T, MODE, 2, 1, 32, 3>(p, st);
+        }
         return launch_igemm<T, MODE, 2, 1, 16, 3>(p, st);
     }
 }
