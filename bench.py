@@ -146,16 +146,23 @@ def per_stage(records, iterations, peak_tflops, dtype):
         g[0] += 1
         g[1] += ms
         g[4] = max(g[4], a) if kind >= 10 else 0
+        if kind >= 20:   # a grouped launch: the work of all its layers
+            g[2], g[3] = max(g[2], fl), max(g[3], by)
     rows = []
     for (kind, n, hb, wb, ic, oc, masked, norm), (cnt, ms, fl, by, srcs) in sorted(groups.items()):
         avg = ms / cnt
         t_mfma, t_hbm = fl / (peak_tflops * 1e12) * 1e3, by / (HBM_GBPS * 1e9) * 1e3
-        row = {"stage": "%s %d->%d @ %dx%d x%d%s%s" % (_KIND.get(kind, str(kind)), ic, oc, hb, wb, n, " +mask" if masked else "", " +norm" if norm else ""),
+        name = "%s %d->%d @ %dx%d x%d%s%s" % (_KIND.get(kind, str(kind)), ic, oc, hb, wb, n, " +mask" if masked else "", " +norm" if norm else "")
+        if kind >= 20:   # gs_conv_wgrad_jobs group: (layers, tile width, blocks, units, runs) in the geometry slots
+            name = "wgrad group %s, %d-wide tiles: %d layers, %d units on %d blocks, %d runs" % ("s1" if kind == 20 else "s2", hb, n, ic, wb, oc)
+        row = {"stage": name,
                "launches_per_iteration": cnt / max(iterations, 1), "avg_us": avg * 1e3, "gflop": fl / 1e9, "mbytes": by / 1e6,
                "bound": "mfma" if t_mfma >= t_hbm else "hbm", "tflops": fl / (avg * 1e-3) / 1e12 if avg > 0 else 0.0,
                "gbps": by / (avg * 1e-3) / 1e9 if avg > 0 else 0.0, "frac": max(t_mfma, t_hbm) / avg if avg > 0 else 0.0}
-        if kind >= 10:
+        if 10 <= kind < 20:
             row["sources"] = srcs
+        elif kind >= 20:
+            row["images"] = srcs
         rows.append(row)
     return rows
 

@@ -46,6 +46,8 @@ SIGNATURES = {
     "gs_wgrad_reduce_batch": (I, [P, I, P]),
     "gs_conv2d_bwd_weight_bias_multi": (I, [P, P, P, I, ctypes.c_uint, P, P, I, I, I, I, I, I, I, F, I, I, P, Z, P, P]),
     "gs_conv2d_transpose_s2_bwd_weight_multi": (I, [P, P, P, I, P, I, I, I, I, I, F, I, I, P, Z, P, P]),
+    "gs_conv_wgrad_jobs_workspace_bytes": (Z, [P, I]),
+    "gs_conv_wgrad_jobs": (I, [P, I, P, Z, P]),
     "gs_conv2d_transpose_s2_workspace_bytes": (Z, [I, I, I, I, I, I, I]),
     "gs_conv2d_transpose_s2_fwd": (I, [P, P, P, I, I, I, I, I, F, I, I, P, Z, P]),
     "gs_conv2d_transpose_s2_fwd_bias_act": (I, [P, P, P, P, I, I, I, I, I, F, I, I, I, P, Z, P]),
@@ -101,6 +103,15 @@ class GsWgradReduce(ctypes.Structure):
     _fields_ = [("partials", c_void_p), ("gw", c_void_p), ("gb", c_void_p), ("nslices", ctypes.c_int32), ("taps", ctypes.c_int32),
                 ("ic", ctypes.c_int32), ("oc", ctypes.c_int32), ("alpha", c_float), ("transpose", ctypes.c_int32),
                 ("accumulate", ctypes.c_int32)]
+
+
+class GsWgradJob(ctypes.Structure):
+    """include/gansynth_hip.h: one layer's weight gradient (up to WGRAD_MAX_SOURCES (x, gy) pairs) for gs_conv_wgrad_jobs."""
+    _fields_ = [("x", c_void_p * WGRAD_MAX_SOURCES), ("gy", c_void_p * WGRAD_MAX_SOURCES), ("n", ctypes.c_int32 * WGRAD_MAX_SOURCES),
+                ("nsrc", ctypes.c_int32), ("bias_mask", ctypes.c_uint32), ("gw", c_void_p), ("gb", c_void_p),
+                ("h", ctypes.c_int32), ("w", ctypes.c_int32), ("ci", ctypes.c_int32), ("co", ctypes.c_int32), ("ksize", ctypes.c_int32),
+                ("stride", ctypes.c_int32), ("transposed", ctypes.c_int32), ("alpha", c_float), ("accumulate", ctypes.c_int32),
+                ("dtype", ctypes.c_int32), ("gw_ci_stride", ctypes.c_int32)]
 
 
 _lib = None

@@ -2,6 +2,8 @@
 // channel counts the MFMA implicit GEMM does not take: the 2-channel colour 1x1 convs
 // (networks.py:98-105, 233-240) and the 1-channel minibatch-stddev plane (networks.py:174-176).
 #include "conv_shared.h"
+#include <utility>
+#include <vector>
 
 namespace gs {
 
@@ -18,6 +20,12 @@ bool wgrad_mfma_has_bias(int dtype);
 int run_wgrad_mfma(int mode, const WgradSrcs& srcs, int nsrc, float* gw, float* gb, int N, int Hi, int Wi, int IC, int OC, int Hb,
                    int Wb, float alpha, int transpose, int accumulate, int dtype, void* ws, size_t ws_bytes, hipStream_t st,
                    GsWgradReduce* defer = nullptr);
+bool wgrad_sk_supported(int mode, int dtype, int IC, int OC);
+int wgrad_sk_tile_width(int Wb);
+void wgrad_sk_job_geometry(int mode, int tw, int N, SkJob& q);
+void wgrad_sk_plan(int mode, SkGroup& g);
+size_t wgrad_sk_bytes(const SkGroup& g);
+int run_wgrad_sk(int mode, int tw, const SkGroup& g, void* ws, size_t ws_bytes, hipStream_t st);
 
 // ------------------------------------------------------------------------- direct gather conv
 // y[n][oy][ox][oc0..oc0+OCV) = alpha * sum_{tap,ic} x[n][iy][ix][ic] * wp[tap][oc][ic]   (wp fp32)
@@ -730,6 +738,125 @@ extern "C" int gs_wgrad_reduce_batch(const GsWgradReduce* pending, int n, void* 
     }
     flush();
     GS_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---- all weight gradients of a backward pass in one call (gs_conv_wgrad_jobs): the layers the 64 x 64-tile bf16 kernel takes are
+// grouped by its instantiation (conv mode, tile width) and each group runs as ONE stream-K launch + one fold (conv_shared.h); every
+// other layer goes through the per-layer entry points above, its slice reduction left pending, and one gs_wgrad_reduce_batch folds
+// those at the end.  Workspace: the largest group (groups run one after the other on the stream) + the sum of the per-layer needs.
+namespace gs {
+struct JobPlan {
+    std::vector<std::pair<int, SkGroup>> groups;   // (mode * 64 + tile width, group), in launch order
+    std::vector<int> single;                      // jobs on the per-layer path
+    std::vector<size_t> single_off;               // their workspace offsets
+    size_t group_bytes = 0, total_bytes = 0;
+};
+static int job_check(const GsWgradJob& jb, int idx) {
+    GS_CHECK_ARG(jb.nsrc >= 1 && jb.nsrc <= GS_WGRAD_MAX_SRC && jb.gw, "conv_wgrad_jobs: job %d has %d sources (1..%d) / no output", idx, jb.nsrc, GS_WGRAD_MAX_SRC);
+    for (int i = 0; i < jb.nsrc; ++i) GS_CHECK_ARG(jb.x[i] && jb.gy[i] && jb.n[i] > 0, "conv_wgrad_jobs: job %d, null or empty source %d", idx, i);
+    GS_CHECK_ARG(!jb.transposed || (jb.ksize == 3 && jb.stride == 2 && !jb.gb), "conv_wgrad_jobs: job %d: the transposed conv is 3x3 stride 2 without bias", idx);
+    GS_CHECK_ARG(jb.gw_ci_stride == 0 || (jb.gw_ci_stride >= jb.ci && !jb.transposed), "conv_wgrad_jobs: job %d: bad gw_ci_stride %d", idx, jb.gw_ci_stride);
+    if (jb.transposed) return check_conv_args(jb.n[0], 2 * jb.h, 2 * jb.w, jb.co, jb.ci, 3, 2, jb.dtype);
+    return check_conv_args(jb.n[0], jb.h, jb.w, jb.ci, jb.co, jb.ksize, jb.stride, jb.dtype);
+}
+static int job_total_images(const GsWgradJob& jb) {
+    int t = 0;
+    for (int i = 0; i < jb.nsrc; ++i) t += jb.n[i];
+    return t;
+}
+static int plan_jobs(const GsWgradJob* jobs, int njobs, JobPlan& plan) {
+    static const bool no_sk = getenv("GS_NO_WGRAD_GROUPS") != nullptr;   // measurement knob: everything on the per-layer path
+    std::vector<int> open_idx(256, -1);   // key -> index of the group still accepting jobs
+    for (int i = 0; i < njobs; ++i) {
+        const GsWgradJob& jb = jobs[i];
+        if (int e = job_check(jb, i)) return e;
+        // kernel-role geometry: a transposed conv's gradient is the stride-2 one with the two sides swapped, stored transposed
+        const int mode = jb.transposed ? MODE_S2 : (jb.stride == 2 ? MODE_S2 : MODE_S1);
+        const int IC = jb.transposed ? jb.co : jb.ci, OC = jb.transposed ? jb.ci : jb.co;
+        const int Hi = jb.transposed ? 2 * jb.h : jb.h, Wi = jb.transposed ? 2 * jb.w : jb.w;
+        const int Hb = jb.transposed ? jb.h : jb.h / jb.stride, Wb = jb.transposed ? jb.w : jb.w / jb.stride;
+        const int total = job_total_images(jb);
+        if (!no_sk && jb.ksize == 3 && wgrad_sk_supported(mode, jb.dtype, IC, OC)) {
+            const int tw = wgrad_sk_tile_width(Wb);
+            const int key = mode * 64 + tw;
+            int gi = open_idx[key];
+            if (gi >= 0) {   // a full group, or one that already adds into this gradient, is closed (launch order = summation order)
+                const SkGroup& og = plan.groups[gi].second;
+                bool close = og.njobs == GS_SK_MAX_JOBS;
+                for (int j = 0; j < og.njobs && !close; ++j) close = og.job[j].gw == jb.gw || (jb.gb && og.job[j].gb == jb.gb);
+                if (close) gi = -1;
+            }
+            if (gi < 0) {
+                SkGroup ng;
+                memset(&ng, 0, sizeof(ng));
+                plan.groups.push_back(std::make_pair(key, ng));
+                gi = (int)plan.groups.size() - 1;
+                open_idx[key] = gi;
+            }
+            SkGroup& g = plan.groups[gi].second;
+            SkJob& q = g.job[g.njobs++];
+            int tot = 0;
+            q.srcs = make_srcs(jb.x, jb.gy, jb.nsrc, 0, jb.n, jb.gb ? jb.bias_mask : 0u, jb.transposed != 0, &tot);
+            q.gw = jb.gw; q.gb = jb.gb; q.alpha = jb.alpha; q.transpose = jb.transposed ? 1 : 0; q.accumulate = jb.accumulate;
+            q.Hi = Hi; q.Wi = Wi; q.IC = IC; q.OC = OC; q.Hb = Hb; q.Wb = Wb;
+            q.ICld = jb.gw_ci_stride > 0 ? jb.gw_ci_stride : IC;
+            wgrad_sk_job_geometry(mode, tw, total, q);
+        } else {
+            GS_CHECK_ARG(jb.gw_ci_stride == 0 || jb.gw_ci_stride == jb.ci, "conv_wgrad_jobs: job %d: a channel-slice target needs a grouped (bf16, >= 64-channel, 3x3) layer", i);
+            plan.single.push_back(i);
+        }
+    }
+    for (auto& kg : plan.groups) {
+        wgrad_sk_plan(kg.first / 64, kg.second);
+        const size_t b = wgrad_sk_bytes(kg.second);
+        if (b > plan.group_bytes) plan.group_bytes = b;
+    }
+    size_t off = plan.group_bytes;
+    for (int i : plan.single) {
+        const GsWgradJob& jb = jobs[i];
+        const int total = job_total_images(jb);
+        plan.single_off.push_back(off);
+        off += jb.transposed ? gs_conv2d_transpose_s2_workspace_bytes(GS_CONV_BWD_WEIGHT, total, jb.h, jb.w, jb.ci, jb.co, jb.dtype)
+                             : gs_conv2d_workspace_bytes(GS_CONV_BWD_WEIGHT, total, jb.h, jb.w, jb.ci, jb.co, jb.ksize, jb.stride, jb.dtype);
+    }
+    plan.total_bytes = off;
+    return 0;
+}
+}  // namespace gs
+
+extern "C" size_t gs_conv_wgrad_jobs_workspace_bytes(const GsWgradJob* jobs, int njobs) {
+    if (!jobs || njobs <= 0) return 0;
+    JobPlan plan;
+    if (plan_jobs(jobs, njobs, plan)) return 0;
+    return plan.total_bytes;
+}
+
+extern "C" int gs_conv_wgrad_jobs(const GsWgradJob* jobs, int njobs, void* ws, size_t ws_bytes, void* stream) {
+    GS_CHECK_ARG(njobs >= 0 && (njobs == 0 || jobs), "conv_wgrad_jobs: bad args");
+    if (njobs == 0) return 0;
+    JobPlan plan;
+    if (int e = plan_jobs(jobs, njobs, plan)) return e;
+    if (ws_bytes < plan.total_bytes) return fail(GS_ERR_WORKSPACE, "conv_wgrad_jobs: workspace %zu < %zu", ws_bytes, plan.total_bytes);
+    hipStream_t st = as_stream(stream);
+    for (auto& kg : plan.groups)
+        if (int e = run_wgrad_sk(kg.first / 64, kg.first % 64, kg.second, ws, plan.group_bytes, st)) return e;
+    std::vector<GsWgradReduce> pend;
+    for (size_t k = 0; k < plan.single.size(); ++k) {
+        const GsWgradJob& jb = jobs[plan.single[k]];
+        unsigned char* jws = reinterpret_cast<unsigned char*>(ws) + plan.single_off[k];
+        const size_t jbytes = (k + 1 < plan.single.size() ? plan.single_off[k + 1] : plan.total_bytes) - plan.single_off[k];
+        GsWgradReduce d;
+        int rc;
+        if (jb.transposed)
+            rc = gs_conv2d_transpose_s2_bwd_weight_multi(jb.x, jb.gy, jb.n, jb.nsrc, jb.gw, jb.n[0], jb.h, jb.w, jb.ci, jb.co, jb.alpha, jb.accumulate, jb.dtype, jws, jbytes, &d, stream);
+        else
+            rc = gs_conv2d_bwd_weight_bias_multi(jb.x, jb.gy, jb.n, jb.nsrc, jb.bias_mask, jb.gw, jb.gb, jb.n[0], jb.h, jb.w, jb.ci, jb.co, jb.ksize, jb.stride, jb.alpha,
+                                                 jb.accumulate, jb.dtype, jws, jbytes, &d, stream);
+        if (rc) return rc;
+        if (d.nslices > 0) pend.push_back(d);
+    }
+    if (!pend.empty()) return gs_wgrad_reduce_batch(pend.data(), (int)pend.size(), stream);
     return 0;
 }
 

@@ -1078,6 +1078,257 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_2x2_kernel(
     }
 }
 
+// The same kernel over a GROUP of layers (conv_shared.h, SkGroup): block b walks the units [b T / nb, (b + 1) T / nb) of the group's
+// unit list; the pipeline (DMA of unit u+1 under the MFMAs of unit u) runs straight across run and layer boundaries -- the MFMA
+// side only sees staged LDS tiles, whatever layer they came from -- and the accumulators are flushed to partial `b + run` where the
+// block's range leaves a run.
+template <int MODE, int TW>
+__global__ __launch_bounds__(256) void conv_wgrad_bf16_2x2_sk_kernel(const SkGroup g, float* __restrict__ part) {
+    constexpr bool S2 = MODE == MODE_S2;
+    constexpr int NP = S2 ? 64 : 256;
+    constexpr int TH = NP / TW;
+    constexpr int PH = patch_dim<MODE>(TH), PW = patch_dim<MODE>(TW);
+    constexpr int S = S2 ? 2 : 1;
+    constexpr int XRG = (PH * PW + 15) / 16;
+    constexpr int GRG = NP / 16;
+    constexpr int XK = (XRG + 3) / 4, GK = GRG / 4;
+    constexpr int XPL = XK * 4096, GPL = NP * 64;
+    constexpr int BUF = 2 * XPL + 2 * GPL;
+    constexpr int NPIECE = 2 * XK + 2 * GK;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const unsigned a_base = (unsigned)(uintptr_t)lds_raw;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int it = wv >> 1, ot = wv & 1;
+    const int t_row = (lane & 15) >> 2;
+    const int t_col = (((lane >> 4) & 1) * 16 + (lane & 3) * 4) * 2;
+    const long nb = gridDim.x, total = g.total_units;
+    const int U0 = (int)((blockIdx.x * total) / nb), U1 = (int)(((blockIdx.x + 1) * total) / nb);
+    if (U0 >= U1) return;
+
+    // ---- DMA side: the unit being staged (one ahead of the one being multiplied)
+    int x_ly[XK], x_lx[XK], x_voff[XK];
+#pragma unroll
+    for (int k = 0; k < XK; ++k) {
+        const int row = (wv + 4 * k) * 16 + (lane >> 2);
+        x_ly[k] = row / PW;
+        x_lx[k] = row - x_ly[k] * PW;
+        x_voff[k] = 0;
+    }
+    int j_n = 0, ct_n = 0, tile_n = 0;                               // layer, channel tile, pixel tile
+    int Hi = 0, Wi = 0, IC = 0, OC = 0, Hb = 0, Wb = 0, tiles_x = 1, tiles_y = 1, ntiles = 1, n_ict = 1, nct = 1;
+    unsigned ximg = 0, gimg = 0;
+    int ic0_n = 0, oc0_n = 0, run_n = 0;
+    bool bias_wave_n = false;
+    auto load_job = [&](int j) __attribute__((always_inline)) {
+        const SkJob& q = g.job[j];
+        Hi = q.Hi; Wi = q.Wi; IC = q.IC; OC = q.OC; Hb = q.Hb; Wb = q.Wb;
+        tiles_x = q.tiles_x; tiles_y = q.tiles_y; ntiles = q.ntiles; n_ict = q.n_ict; nct = q.nct;
+        ximg = (unsigned)Hi * Wi * IC * 2;
+        gimg = (unsigned)Hb * Wb * OC * 2;
+#pragma unroll
+        for (int k = 0; k < XK; ++k) x_voff[k] = ((x_ly[k] * Wi + x_lx[k]) * IC) * 2 + (lane & 3) * 16;
+    };
+    auto set_ct = [&](int j, int ct) __attribute__((always_inline)) {
+        ic0_n = (ct % n_ict) * 64;
+        oc0_n = (ct / n_ict) * 64;
+        run_n = g.job[j].run_base + ct;
+        bias_wave_n = g.job[j].gb != nullptr && it == 0 && ic0_n == 0;
+    };
+    int n_t = 0, by_t = 0, bx_t = 0, ox0_t = 0, xorg_t = 0;
+    bool bias_next = false;
+    i32x4 rs_xt = make_rsrc(g.job[0].srcs.x[0], 0), rs_gt = rs_xt;
+    auto tile_setup = [&](int j, int tile) __attribute__((always_inline)) {
+        const SkJob& q = g.job[j];
+        int b = tile;
+        const int tile_x = b % tiles_x;
+        b /= tiles_x;
+        const int tile_y = b % tiles_y;
+        const int src = wgrad_source(q.srcs, b / tiles_y, n_t);
+        bias_next = bias_wave_n && ((q.srcs.bias_mask >> src) & 1u);
+        by_t = tile_y * TH;
+        bx_t = tile_x * TW;
+        const int oy0 = S2 ? 2 * by_t : by_t - 1;
+        ox0_t = S2 ? 2 * bx_t : bx_t - 1;
+        rs_xt = make_rsrc(reinterpret_cast<const unsigned char*>(q.srcs.x[src]) + (size_t)n_t * ximg, ximg);
+        rs_gt = make_rsrc(reinterpret_cast<const unsigned char*>(q.srcs.gy[src]) + (size_t)n_t * gimg, gimg);
+        xorg_t = ((oy0 * Wi + ox0_t) * IC + ic0_n) * 2;
+    };
+    auto issue_piece = [&](int q, int bufi) __attribute__((always_inline)) {
+        const unsigned a_x = a_base + bufi * BUF, a_g = a_x + 2 * XPL;
+        if (q < 2 * XK) {
+            const int k = q >> 1, pl = q & 1;
+            const bool in = (wv + 4 * k) * 16 + (lane >> 2) < PH * PW && (unsigned)(ox0_t + x_lx[k]) < (unsigned)Wi;
+            unsigned v = in ? (unsigned)(xorg_t + x_voff[k]) : 0x80000000u;
+            if (pl && in) v += 64;
+            lds_dma16(a_x + pl * XPL + (wv + 4 * k) * 1024, v, rs_xt);
+        } else {
+            const int k = (q - 2 * XK) >> 1, pl = (q - 2 * XK) & 1;
+            const int pix = (wv + 4 * k) * 16 + (lane >> 2);
+            const int gy_ = by_t + pix / TW, gx_ = bx_t + pix % TW;
+            const bool in = gy_ < Hb && gx_ < Wb;
+            unsigned v = in ? (unsigned)(((gy_ * Wb + gx_) * OC + oc0_n) * 2 + (lane & 3) * 16) : 0x80000000u;
+            if (pl && in) v += 64;
+            lds_dma16(a_g + pl * GPL + (wv + 4 * k) * 1024, v, rs_gt);
+        }
+    };
+
+    // ---- MFMA side (identical to conv_wgrad_bf16_2x2_kernel)
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float accb = 0.f;
+    bool do_bias = false;
+    constexpr int XR = S2 ? 5 : 3;
+    constexpr int NG = NP / 16;
+    uint2 fb[2][2], fx[2][3][XR];
+    auto load_group = [&](int gi, int fbuf, const unsigned char* xpl, const unsigned char* gpl) __attribute__((always_inline)) {
+        const int ty = (gi * 16) / TW, tx0 = (gi * 16) % TW + 8 * hi;
+        const unsigned char* gp = gpl + (ty * TW + tx0 + t_row) * 64 + t_col;
+        fb[fbuf][0] = lds_tr16(gp);
+        fb[fbuf][1] = lds_tr16(gp + 4 * 64);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const unsigned char* xp = xpl + (((ty * S + ky) * PW + tx0 * S) + t_row * S) * 64 + t_col;
+            if (!S2) {
+                fx[fbuf][ky][0] = lds_tr16(xp); fx[fbuf][ky][1] = lds_tr16(xp + 4 * 64); fx[fbuf][ky][2] = lds_tr16(xp + 8 * 64);
+            } else {
+                fx[fbuf][ky][0] = lds_tr16(xp); fx[fbuf][ky][1] = lds_tr16(xp + 8 * 64); fx[fbuf][ky][2] = lds_tr16(xp + 16 * 64);
+                fx[fbuf][ky][3] = lds_tr16(xp + 64); fx[fbuf][ky][4] = lds_tr16(xp + 9 * 64);
+            }
+        }
+    };
+    auto compute_group = [&](int fbuf) __attribute__((always_inline)) {
+        const uint2 b0 = fb[fbuf][0], b1 = fb[fbuf][1];
+        const bf16x8 bfrag = mk_frag(b0.x, b0.y, b1.x, b1.y);
+        if (do_bias) { add_bf16_pair(accb, b0.x); add_bf16_pair(accb, b0.y); add_bf16_pair(accb, b1.x); add_bf16_pair(accb, b1.y); }
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            if (!S2) {
+                const uint2 d0 = fx[fbuf][ky][0], d1 = fx[fbuf][ky][1], d2 = fx[fbuf][ky][2];
+                acc[ky * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk_frag(d0.x, d0.y, d1.x, d1.y), bfrag, acc[ky * 3 + 0], 0, 0, 0);
+                acc[ky * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk_frag(shr16(d0.y, d0.x), shr16(d1.x, d0.y), shr16(d1.y, d1.x), shr16(d2.x, d1.y)), bfrag, acc[ky * 3 + 1], 0, 0, 0);
+                acc[ky * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk_frag(d0.y, d1.x, d1.y, d2.x), bfrag, acc[ky * 3 + 2], 0, 0, 0);
+            } else {
+                const uint2 e0 = fx[fbuf][ky][0], e1 = fx[fbuf][ky][1], e2 = fx[fbuf][ky][2], o0 = fx[fbuf][ky][3], o1 = fx[fbuf][ky][4];
+                acc[ky * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk_frag(e0.x, e0.y, e1.x, e1.y), bfrag, acc[ky * 3 + 0], 0, 0, 0);
+                acc[ky * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk_frag(o0.x, o0.y, o1.x, o1.y), bfrag, acc[ky * 3 + 1], 0, 0, 0);
+                acc[ky * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk_frag(shr16(e0.y, e0.x), shr16(e1.x, e0.y), shr16(e1.y, e1.x), shr16(e2.x, e1.y)), bfrag, acc[ky * 3 + 2], 0, 0, 0);
+            }
+        }
+    };
+
+    // ---- first unit of the block
+    while (j_n + 1 < g.njobs && U0 >= g.job[j_n + 1].unit_base) ++j_n;
+    load_job(j_n);
+    ct_n = (U0 - g.job[j_n].unit_base) / ntiles;
+    tile_n = (U0 - g.job[j_n].unit_base) - ct_n * ntiles;
+    set_ct(j_n, ct_n);
+    tile_setup(j_n, tile_n);
+#pragma unroll
+    for (int q = 0; q < NPIECE; ++q) issue_piece(q, 0);
+
+    constexpr int PPG = (NPIECE + NG - 1) / NG;
+    int buf = 0;
+    for (int u = U0; u < U1; ++u) {
+        const bool more = u + 1 < U1;
+        wait_vmcnt(0);
+        block_barrier();
+        // the unit being multiplied: what the DMA side was set to when it was issued
+        do_bias = bias_next;
+        const int run_c = run_n;
+        const bool bias_wave_c = bias_wave_n;
+        bool leave = !more;   // does the block's range leave the run after this unit?
+        if (more) {
+            if (++tile_n == ntiles) {
+                tile_n = 0;
+                leave = true;
+                if (++ct_n == nct) { ct_n = 0; ++j_n; load_job(j_n); }
+                set_ct(j_n, ct_n);
+            }
+            tile_setup(j_n, tile_n);
+        }
+        const unsigned char* const xpl = lds_raw + buf * BUF + it * XPL;
+        const unsigned char* const gpl = lds_raw + buf * BUF + 2 * XPL + ot * GPL;
+        load_group(0, 0, xpl, gpl);
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi) {
+            if (gi + 1 < NG) load_group(gi + 1, (gi + 1) & 1, xpl, gpl);
+            if (more) {
+#pragma unroll
+                for (int q = gi * PPG; q < (gi + 1) * PPG && q < NPIECE; ++q) issue_piece(q, buf ^ 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            compute_group(gi & 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        block_barrier();
+        buf ^= 1;
+        if (leave) {   // partial (block + run): [tap][ic 64][oc 64] + 64 bias sums; lane = (oc j = l31, ic i = (r&3) + 8(r>>2) + 4hi)
+            float* const dst0 = part + (long)(blockIdx.x + run_c) * GS_SK_PSTRIDE;
+            if (bias_wave_c) {
+                const float tot = accb + __shfl_xor(accb, 32, 64);
+                if (hi == 0) dst0[9 * 4096 + ot * 32 + l31] = tot;
+            }
+            accb = 0.f;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                float* dst = dst0 + (t * 64 + it * 32) * 64 + ot * 32 + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    dst[((r & 3) + 8 * (r >> 2) + 4 * hi) * 64] = acc[t][r];
+                    acc[t][r] = 0.f;
+                }
+            }
+        }
+    }
+}
+
+// folds the partials of every run of a group into the gradients: grid (37, runs), a thread owns 4 consecutive output channels
+__global__ __launch_bounds__(256) void wgrad_sk_reduce_kernel(const SkGroup g, const float* __restrict__ part) {
+    const int r = blockIdx.y;
+    int j = 0;
+    while (j + 1 < g.njobs && r >= g.job[j + 1].run_base) ++j;
+    const SkJob& q = g.job[j];
+    const int ct = r - q.run_base;
+    const int ic0 = (ct % q.n_ict) * 64, oc0 = (ct / q.n_ict) * 64;
+    const long s0 = (long)q.unit_base + (long)ct * q.ntiles;
+    const int b0 = sk_block_of(s0, g.nblocks, g.total_units), b1 = sk_block_of(s0 + q.ntiles - 1, g.nblocks, g.total_units);
+    const int e = blockIdx.x * 256 + threadIdx.x;   // quad index inside the partial
+    if (e >= GS_SK_PSTRIDE / 4) return;
+    const bool is_bias = e >= 9 * 1024;
+    if (is_bias && !(q.gb && ic0 == 0)) return;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int b = b0; b <= b1; ++b) {
+        const float4 a = *reinterpret_cast<const float4*>(part + (long)(b + r) * GS_SK_PSTRIDE + (long)e * 4);
+        s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+    }
+    if (is_bias) {
+        float4* o = reinterpret_cast<float4*>(q.gb + oc0 + (e - 9 * 1024) * 4);
+        const float4 old = q.accumulate ? *o : make_float4(0.f, 0.f, 0.f, 0.f);
+        *o = make_float4(old.x + s.x, old.y + s.y, old.z + s.z, old.w + s.w);
+        return;
+    }
+    const int t = e >> 10, i = (e >> 4) & 63, j4 = (e & 15) * 4;
+    const float al = q.alpha;
+    if (!q.transpose) {
+        float4* o = reinterpret_cast<float4*>(q.gw + ((long)t * q.ICld + ic0 + i) * q.OC + oc0 + j4);
+        const float4 old = q.accumulate ? *o : make_float4(0.f, 0.f, 0.f, 0.f);
+        *o = make_float4(old.x + s.x * al, old.y + s.y * al, old.z + s.z * al, old.w + s.w * al);
+    } else {
+        const float v[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float* o = q.gw + ((long)t * q.OC + oc0 + j4 + c) * q.IC + ic0 + i;
+            *o = q.accumulate ? *o + v[c] * al : v[c] * al;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------ dispatch
 
 static int g_num_cus = 0;
@@ -1407,6 +1658,88 @@ int run_wgrad_mfma(int mode, const WgradSrcs& srcs, int nsrc, float* gw, float* 
     }
     GS_CHECK_LAUNCH();
     wgrad_reduce_launch(part, gw, gb, nslices, 9, IC, OC, alpha, transpose, accumulate, st, defer);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---- grouped weight gradients: planning and launch of one (mode, tile width) group
+bool wgrad_sk_supported(int mode, int dtype, int IC, int OC) { return wgrad_2x2(mode, dtype, IC, OC); }
+// Always 32-wide tiles: a 16-wide image leaves half of a tile's columns empty either way (a 2 x 16 image fills 1/8 of a 16 x 16 tile
+// and 1/8 of an 8 x 32 one), and with one width all layers of a conv mode share ONE group.  (GS_SK_TW16: separate groups, for measurements.)
+int wgrad_sk_tile_width(int Wb) {
+    static const bool tw16 = getenv("GS_SK_TW16") != nullptr;
+    return (Wb >= 32 || !tw16) ? 32 : 16;
+}
+// fills the tiling of job q (its srcs / channel counts / image sizes already set; N = images of all sources)
+void wgrad_sk_job_geometry(int mode, int tw, int N, SkJob& q) {
+    const int np = mode == MODE_S2 ? 64 : 256;
+    const int th = np / tw;
+    q.tiles_x = cdiv(q.Wb, tw);
+    q.tiles_y = cdiv(q.Hb, th);
+    q.ntiles = N * q.tiles_x * q.tiles_y;
+    q.n_ict = q.IC / 64;
+    q.nct = q.n_ict * (q.OC / 64);
+}
+// unit / run numbering and the block count of a group whose jobs carry their geometry
+void wgrad_sk_plan(int mode, SkGroup& g) {
+    long units = 0;
+    int runs = 0;
+    for (int j = 0; j < g.njobs; ++j) {
+        g.job[j].unit_base = (int)units;
+        g.job[j].run_base = runs;
+        units += (long)g.job[j].nct * g.job[j].ntiles;
+        runs += g.job[j].nct;
+    }
+    g.total_units = (int)units;
+    g.total_runs = runs;
+    // a unit is 2.4 us of MFMAs (stride 1: 144 per wave) or ~2.5 us of patch staging (stride 2: 36 MFMAs under a 4-5x larger patch); a block
+    // needs a few of them to amortise its prologue and its flush (measured: scripts/run_sk.sh)
+    static const int upb_env = getenv("GS_SK_UNITS_PER_BLOCK") ? atoi(getenv("GS_SK_UNITS_PER_BLOCK")) : 0;
+    static const int upb2_env = getenv("GS_SK_UNITS_PER_BLOCK_S2") ? atoi(getenv("GS_SK_UNITS_PER_BLOCK_S2")) : 0;
+    const int upb = mode == MODE_S2 ? (upb2_env > 0 ? upb2_env : 4) : (upb_env > 0 ? upb_env : 2);
+    long nb = units / upb;
+    if (nb > num_cus()) nb = num_cus();
+    if (nb < 1) nb = 1;
+    g.nblocks = (int)nb;
+}
+size_t wgrad_sk_bytes(const SkGroup& g) { return align256((size_t)(g.nblocks + g.total_runs) * GS_SK_PSTRIDE * sizeof(float)); }
+
+int run_wgrad_sk(int mode, int tw, const SkGroup& g, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (g.njobs < 1 || g.njobs > GS_SK_MAX_JOBS) return fail(GS_ERR_ARG, "conv wgrad group: %d jobs", g.njobs);
+    if (ws_bytes < wgrad_sk_bytes(g)) return fail(GS_ERR_WORKSPACE, "conv wgrad group: workspace %zu < %zu", ws_bytes, wgrad_sk_bytes(g));
+    if ((long)g.total_units <= 0) return 0;
+    float* part = reinterpret_cast<float*>(ws);
+    double flops = 0.0, bytes = 0.0;
+    int images = 0;
+    for (int j = 0; j < g.njobs; ++j) {
+        const SkJob& q = g.job[j];
+        const int N = q.srcs.n_end[GS_WGRAD_MAX_SRC - 1];
+        images += N;
+        flops += 2.0 * 9.0 * (double)N * q.Hb * q.Wb * q.IC * q.OC;
+        bytes += ((double)N * q.Hi * q.Wi * q.IC + (double)N * q.Hb * q.Wb * q.OC) * 2.0 + 9.0 * q.IC * q.OC * 4.0;
+    }
+    {
+        // kind 20 + mode: a GROUP of weight gradients (N = layers, Hb = tile width, Wb = blocks, IC = units, OC = runs)
+        ProfScope ps(st, flops, bytes, 20 + mode, g.njobs, tw, g.nblocks, g.total_units, g.total_runs, images, 1);
+#define GS_WGSK(M, TWV)                                                                                                 \
+    do {                                                                                                                \
+        constexpr int np_ = (M == MODE_S2 ? 64 : 256), th_ = np_ / TWV;                                                 \
+        constexpr int lds_ = 2 * (2 * ((((patch_dim<M>(th_) * patch_dim<M>(TWV) + 15) / 16 + 3) / 4) * 4096 + np_ * 64));  \
+        auto kern_ = conv_wgrad_bf16_2x2_sk_kernel<M, TWV>;                                                             \
+        static bool set_ = false;                                                                                       \
+        if (!set_) {                                                                                                    \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern_), hipFuncAttributeMaxDynamicSharedMemorySize, lds_) != hipSuccess) \
+                return fail(GS_ERR_HIP, "conv wgrad group: cannot reserve %d bytes of dynamic LDS", lds_);              \
+            set_ = true;                                                                                                \
+        }                                                                                                               \
+        hipLaunchKernelGGL(kern_, dim3((unsigned)g.nblocks), dim3(256), lds_, st, g, part);                             \
+    } while (0)
+        if (mode == MODE_S1) { if (tw == 32) GS_WGSK(MODE_S1, 32); else GS_WGSK(MODE_S1, 16); }
+        else { if (tw == 32) GS_WGSK(MODE_S2, 32); else GS_WGSK(MODE_S2, 16); }
+#undef GS_WGSK
+    }
+    GS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(wgrad_sk_reduce_kernel, dim3((GS_SK_PSTRIDE / 4 + 255) / 256, (unsigned)g.total_runs), dim3(256), 0, st, g, part);
     GS_CHECK_LAUNCH();
     return 0;
 }

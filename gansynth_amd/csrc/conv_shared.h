@@ -24,6 +24,32 @@ __device__ __forceinline__ int wgrad_source(const WgradSrcs& s, int nn, int& n_l
     return src;
 }
 
+// ---- grouped weight gradients (gs_conv_wgrad_jobs): the 64 x 64 channel-tile kernel run ONCE over the layers of a backward pass that
+// share its instantiation (conv mode, tile width).  The work of the group is one list of units -- (layer, channel tile, pixel tile), in that
+// order -- cut into equal contiguous ranges, one per block (a "stream-K" schedule).  A block keeps its accumulators across the pixel
+// tiles of one (layer, channel tile) RUN and writes a partial only where its range leaves the run: partials = blocks + runs per
+// launch instead of blocks per LAYER, and the summation order of a run (ascending block index) is a function of the shapes alone.
+#define GS_SK_MAX_JOBS 16
+#define GS_SK_PSTRIDE (9 * 64 * 64 + 64)   // floats of one partial: 9 taps of a 64 x 64 tile + 64 bias sums
+struct SkJob {
+    WgradSrcs srcs;
+    float* gw;                      // [9][IC][OC] (or [9][OC][IC] when transpose), fp32
+    float* gb;                      // optional [OC]
+    float alpha;
+    int transpose, accumulate;
+    int Hi, Wi, IC, OC, Hb, Wb;     // kernel-role geometry (input side / gradient side)
+    int ICld;                       // input-channel rows of the stored variable (IC, or more when gw is a channel slice of a wider one)
+    int tiles_x, tiles_y, ntiles;   // pixel tiles over the images of all sources
+    int n_ict, nct;                 // IC / 64, channel tiles (IC / 64) * (OC / 64)
+    int unit_base, run_base;        // first unit / first run of the layer inside the group
+};
+struct SkGroup {
+    int njobs, total_units, total_runs, nblocks;
+    SkJob job[GS_SK_MAX_JOBS];
+};
+// block that owns unit u when block b owns [b * total / nb, (b + 1) * total / nb)
+__host__ __device__ inline int sk_block_of(long u, long nb, long total) { return (int)(((u + 1) * nb - 1) / total); }
+
 // ------------------------------------------------------------------------------ weight prep
 // Re-lays the fp32 HWIO master weight into the kernel operand Wp[tap][OCk][ICk] (ICk contiguous,
 // storage type T, no scaling -- alpha is applied to the fp32 accumulators).

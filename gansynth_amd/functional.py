@@ -192,7 +192,23 @@ class _WeightSlice(Function):
 
 
 def weight_slice(w, lo, hi):
-    return _WeightSlice.apply(w, lo, hi)
+    t = _WeightSlice.apply(w, lo, hi)
+    t._gs_slice_of = (w, lo, hi)   # lets the conv's backward add its gradient straight into that slice of w.grad (_slice_target)
+    return t
+
+
+def _slice_target(wref, x, gy, kind):
+    """w.grad[:, :, lo:hi, :] (a strided view) when `wref` is a channel slice of a variable and the kernel layer can add a conv
+    weight gradient into such a view (deferred, grouped layers: kernels.wgrad_slice_target_ok); None otherwise -- the gradient
+    then goes back through _WeightSlice.backward."""
+    src = getattr(wref, "_gs_slice_of", None)
+    K = _K()
+    if src is None or not isinstance(kind, _ConvKind) or not hasattr(K, "wgrad_slice_target_ok"):
+        return None
+    if not K.wgrad_slice_target_ok(x, gy.shape[1], kind.ksize, kind.stride):
+        return None
+    g = _accum_target(src[0])
+    return None if g is None else g[:, :, src[1]:src[2], :]
 
 
 # ---- "premasked" gradients ------------------------------------------------------------------------------------------------
@@ -256,6 +272,8 @@ class _Bilinear(Function):
         gw = None
         if ctx.needs_input_grad[1] and _want_params():
             tgt = _accum_target(ctx.wref)
+            if tgt is None:
+                tgt = _slice_target(ctx.wref, x, gy, ctx.kind)
             if tgt is not None:
                 ctx.kind.bwd_weight(x, gy, ctx.alpha, out=tgt)
             else:
@@ -279,6 +297,8 @@ class _BilinearBwdData(Function):
         g_w = None
         if ctx.needs_input_grad[1]:
             tgt = _accum_target(ctx.wref)
+            if tgt is None:
+                tgt = _slice_target(ctx.wref, ggx, gy, ctx.kind)
             if tgt is not None:   # second-order term of the penalty, added straight into w.grad
                 ctx.kind.bwd_weight(ggx, gy, ctx.alpha, out=tgt)
             else:

@@ -9,6 +9,7 @@ The autograd layer (functional.py) talks to the module-level `K` object; tests m
 an emulation to check the autograd algebra on CPU, the product never does.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -183,6 +184,12 @@ class HipKernels(object):
         if self._pending is None:
             self._pending = {}
 
+    def wgrad_slice_target_ok(self, x, co, ksize, stride):
+        """May a conv weight gradient be added into a CHANNEL SLICE w.grad[:, :, lo:hi, :] of a wider variable (a strided `out`)?
+        Only while gradients are deferred and for the layers gs_conv_wgrad_jobs runs grouped (bf16, 3x3, >= 64 channels both sides)."""
+        return (self._pending is not None and not os.environ.get("GS_NO_WGRAD_GROUPS") and x.dtype == torch.bfloat16 and ksize == 3
+                and x.shape[1] % 64 == 0 and co % 64 == 0)
+
     def _defer_wgrad(self, key, x, gy, out, bias_out):
         grp = self._pending.setdefault(key, {"out": out, "bias": None, "src": []})
         if bias_out is not None:
@@ -211,7 +218,9 @@ class HipKernels(object):
         return self._flush_groups(groups)
 
     def _flush_groups(self, groups):
-        pend, keep = [], []
+        """One gs_conv_wgrad_jobs call for every recorded layer of `groups`: the library groups the layers by kernel
+        instantiation (one stream-K launch + one fold per group) and batches the rest."""
+        jobs, keep = [], []
         for key, grp in groups.items():
             kind, ksize, stride, alpha = key[0], key[2], key[3], key[4]
             out, bias, src = grp["out"], grp["bias"], grp["src"]
@@ -220,29 +229,27 @@ class HipKernels(object):
             dt = _dt(src[0][0])
             for i in range(0, len(src), _lib.WGRAD_MAX_SOURCES):
                 part = src[i:i + _lib.WGRAD_MAX_SOURCES]
-                k = len(part)
-                xs = (ctypes.c_void_p * k)(*[p[0].data_ptr() for p in part])
-                gys = (ctypes.c_void_p * k)(*[p[1].data_ptr() for p in part])
-                ns = (ctypes.c_int * k)(*[p[0].shape[0] for p in part])
-                n, ntot = part[0][0].shape[0], sum(p[0].shape[0] for p in part)
-                mask = sum(1 << j for j, p in enumerate(part) if p[2])
-                d = _lib.GsWgradReduce()
-                if kind == "conv":
-                    ws = _ws(self.lib.gs_conv2d_workspace_bytes(_lib.CONV_BWD_WEIGHT, ntot, h, wd, ci, co, ksize, stride, dt), out.device)
-                    _lib.check(self.lib.gs_conv2d_bwd_weight_bias_multi(xs, gys, ns, k, mask, out.data_ptr(), None if (bias is None or not mask) else bias.data_ptr(),
-                                                                        n, h, wd, ci, co, ksize, stride, float(alpha), 1, dt, ws.data_ptr(), ws.numel(),
-                                                                        ctypes.addressof(d), _stream()), "gs_conv2d_bwd_weight_bias_multi")
-                else:
-                    ws = _ws(self.lib.gs_conv2d_transpose_s2_workspace_bytes(_lib.CONV_BWD_WEIGHT, ntot, h, wd, ci, co, dt), out.device)
-                    _lib.check(self.lib.gs_conv2d_transpose_s2_bwd_weight_multi(xs, gys, ns, k, out.data_ptr(), n, h, wd, ci, co, float(alpha), 1, dt,
-                                                                                ws.data_ptr(), ws.numel(), ctypes.addressof(d), _stream()),
-                               "gs_conv2d_transpose_s2_bwd_weight_multi")
-                if d.nslices > 0:
-                    pend.append(d)
-                    keep.append(ws)
-        if pend:
-            arr = (_lib.GsWgradReduce * len(pend))(*pend)
-            _lib.check(self.lib.gs_wgrad_reduce_batch(ctypes.cast(arr, ctypes.c_void_p), len(pend), _stream()), "gs_wgrad_reduce_batch")
+                jb = _lib.GsWgradJob()
+                for s_, (x, gy, wb) in enumerate(part):
+                    jb.x[s_], jb.gy[s_], jb.n[s_] = x.data_ptr(), gy.data_ptr(), x.shape[0]
+                jb.nsrc = len(part)
+                jb.bias_mask = sum(1 << j for j, p in enumerate(part) if p[2]) if kind == "conv" else 0
+                jb.gw = out.data_ptr()
+                jb.gb = bias.data_ptr() if (kind == "conv" and bias is not None and jb.bias_mask) else None
+                jb.h, jb.w, jb.ci, jb.co, jb.ksize, jb.stride = h, wd, ci, co, ksize, stride
+                jb.transposed = 0 if kind == "conv" else 1
+                jb.alpha, jb.accumulate, jb.dtype = float(alpha), 1, dt
+                if not out.is_contiguous():   # [:, :, lo:hi, :] of a wider variable's gradient (wgrad_slice_target_ok)
+                    assert kind == "conv" and out.stride(3) == 1 and out.stride(2) == co and out.stride(1) % co == 0 and out.stride(0) == ksize * out.stride(1)
+                    jb.gw_ci_stride = out.stride(1) // co
+                jobs.append(jb)
+                keep.append(part)
+        if jobs:
+            arr = (_lib.GsWgradJob * len(jobs))(*jobs)
+            ptr = ctypes.cast(arr, ctypes.c_void_p)
+            nb = self.lib.gs_conv_wgrad_jobs_workspace_bytes(ptr, len(jobs))
+            ws = _ws(nb, groups[next(iter(groups))]["out"].device)
+            _lib.check(self.lib.gs_conv_wgrad_jobs(ptr, len(jobs), ws.data_ptr(), ws.numel(), _stream()), "gs_conv_wgrad_jobs")
         return sum(len(g["src"]) for g in groups.values())   # (workspaces and sources die here: later launches are stream-ordered behind)
 
     # ------------------------------------------------------------------------------- conv
@@ -344,6 +351,7 @@ class HipKernels(object):
         if out is not None and self._pending is not None:
             self._defer_wgrad(("conv", out.data_ptr(), ksize, stride, float(alpha), tuple(x.shape[1:]), tuple(gy.shape[1:]), x.dtype), x, gy, out, bias_out)
             return gw
+        assert out is None or out.is_contiguous(), "a channel-slice target needs deferred gradients (wgrad_slice_target_ok)"
         nb = self.lib.gs_conv2d_workspace_bytes(_lib.CONV_BWD_WEIGHT, n, h, wd, ci, co, ksize, stride, _dt(x))
         ws = _ws(nb, x.device)
         _lib.check(self.lib.gs_conv2d_bwd_weight_bias(x.data_ptr(), gy.data_ptr(), gw.data_ptr(), None if bias_out is None else bias_out.data_ptr(),

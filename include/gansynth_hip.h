@@ -181,6 +181,31 @@ int gs_conv2d_transpose_s2_bwd_weight_multi(const void* const* xs, const void* c
                                             int w, int ci, int co, float alpha, int accumulate, int dtype, void* ws, size_t ws_bytes,
                                             GsWgradReduce* pending, void* stream);
 
+/* Every conv weight gradient of a backward pass in ONE call -- where `minimize` asks for the gradients of all variables of a
+ * network at once (models.py:81-89).  A job is one layer: up to GS_WGRAD_MAX_SOURCES (x, gy) pairs with n[s] images each, as in
+ * gs_conv2d_bwd_weight_bias_multi (conv: h, w = input size) / gs_conv2d_transpose_s2_bwd_weight_multi (transposed = 1: h, w = the
+ * transposed conv's input size; no bias).  bf16 layers with >= 64 channels on both sides are grouped by kernel instantiation and each
+ * group runs as one stream-K launch over the pixel tiles of all its layers + one fold: partials = blocks + (layer, channel tile)
+ * runs per GROUP instead of blocks per layer, summed in a fixed order (deterministic).  Other layers take the per-layer path with
+ * their reductions batched at the end.  Jobs that add into the same gw are applied in list order.  `jobs` is a host array. */
+typedef struct GsWgradJob {
+    const void* x[GS_WGRAD_MAX_SOURCES];
+    const void* gy[GS_WGRAD_MAX_SOURCES];
+    int32_t n[GS_WGRAD_MAX_SOURCES];
+    int32_t nsrc;
+    uint32_t bias_mask;     /* which pairs contribute to gb */
+    float* gw;              /* [k][k][ci][co] fp32 */
+    float* gb;              /* optional [co] */
+    int32_t h, w, ci, co, ksize, stride, transposed;
+    float alpha;
+    int32_t accumulate, dtype;
+    int32_t gw_ci_stride;   /* 0, or the input-channel count of the stored variable when gw is the slice [:, :, lo:lo+ci, :] of a
+                             * wider one (the 257-channel conv of the last discriminator block, networks.py:174-176): element
+                             * (t, i, o) lives at gw[(t * gw_ci_stride + i) * co + o].  Grouped (stream-K) layers only. */
+} GsWgradJob;
+size_t gs_conv_wgrad_jobs_workspace_bytes(const GsWgradJob* jobs, int njobs);
+int gs_conv_wgrad_jobs(const GsWgradJob* jobs, int njobs, void* ws, size_t ws_bytes, void* stream);
+
 /* Refreshing many prepared weight operands in one launch (after an optimizer step: ~60 conv maps, one kernel instead of
  * one re-layout launch in front of each conv).  A descriptor names the fp32 HWIO master weight, the persistent workspace
  * of one (weight, map) pair and the map: GS_PREP_* below, (ci, co, ksize, stride) of the variable, activation dtype.

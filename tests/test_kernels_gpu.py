@@ -524,6 +524,46 @@ def test_multi_source_weight_gradient_matches_oracle(K, E, dtype):
             close(gb, E.channel_sum(gys[0]) + E.channel_sum(gys[2]), rel=1e-4, name="multi wgrad bias (sources 0 and 2)")
 
 
+def test_grouped_weight_gradients_match_oracle(K, E):
+    """gs_conv_wgrad_jobs: the >= 64-channel bf16 layers of a backward pass run as stream-K groups (one launch per conv mode and
+    tile width over the pixel tiles of ALL their layers, blocks crossing layer and channel-tile boundaries) -- every gradient
+    against the CPU restatement: layers of different sizes in one group, several sources with different image counts and bias
+    masks, the transposed conv (swapped sides, transposed store), 16-wide tiles, more layers than a group holds and a layer
+    whose sources come in two jobs adding into one gradient."""
+    dtype = torch.bfloat16
+    layers = [("conv", [3, 2], 64, 64, 8, 64, 1), ("conv", [2], 128, 64, 16, 96, 1), ("conv", [1, 1, 2], 64, 128, 6, 40, 1), ("conv", [2], 256, 256, 4, 32, 1),
+              ("conv", [2, 2], 64, 128, 16, 64, 2), ("conv", [3], 128, 128, 8, 128, 2), ("conv", [2], 64, 64, 2, 16, 1), ("conv", [2, 1], 128, 64, 4, 16, 1),
+              ("conv", [2], 64, 64, 4, 32, 2), ("convT", [2, 1], 128, 64, 8, 32, 2), ("convT", [2], 64, 64, 2, 16, 2),
+              ("conv", [1, 1, 1, 1, 1, 1], 64, 64, 8, 32, 1)]
+    layers = layers + [("conv", [1], 64, 64, 8, 32 + 32 * i, 1) for i in range(18)]   # one mode / width: more than GS_SK_MAX_JOBS layers
+    K.defer_wgrad_reductions()
+    want, got = [], []
+    for li, (kind, ns, ci, co, h, w, st) in enumerate(layers):
+        gw = torch.full((3, 3, ci, co), 0.25, device="cuda")
+        gb = torch.full((co,), -0.5, device="cuda") if kind == "conv" else None
+        ref_w, ref_b = torch.full((3, 3, ci, co), 0.25), (torch.full((co,), -0.5) if kind == "conv" else None)
+        for si, n in enumerate(ns):
+            x = rnd(n, ci, h, w, seed=100 * li + si).to(dtype).float()
+            if kind == "conv":
+                gy = rnd(n, co, h // st, w // st, seed=100 * li + 50 + si).to(dtype).float()
+                with_b = si != 1
+                K.conv2d_bwd_weight(dev(x, dtype), dev(gy, dtype), 3, st, 0.3, out=gw, bias_out=gb if with_b else None)
+                ref_w += E.conv2d_bwd_weight(x, gy, 3, st, 0.3)
+                if with_b:
+                    ref_b += E.channel_sum(gy)
+            else:
+                gy = rnd(n, co, 2 * h, 2 * w, seed=100 * li + 50 + si).to(dtype).float()
+                K.conv2d_transpose_bwd_weight(dev(x, dtype), dev(gy, dtype), 0.3, out=gw)
+                ref_w += E.conv2d_transpose_bwd_weight(x, gy, 0.3)
+        want.append((ref_w, ref_b))
+        got.append((gw, gb))
+    assert K.flush_wgrad_reductions() == sum(len(l[1]) for l in layers)
+    for li, ((rw, rb), (gw, gb)) in enumerate(zip(want, got)):
+        close(gw, rw, rel=1e-4, name=f"grouped wgrad layer {li} {layers[li]}")
+        if rb is not None:
+            close(gb, rb, rel=1e-4, name=f"grouped wgrad bias layer {li}")
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("case", [("conv", 2, 32, 32, 8, 128), ("conv", 8, 64, 64, 64, 512), ("conv", 2, 64, 64, 8, 64), ("conv", 2, 256, 256, 4, 32),
                                   ("convT", 2, 64, 32, 8, 64), ("convT", 8, 128, 64, 32, 256), ("convT", 2, 256, 256, 4, 32)])
