@@ -783,7 +783,9 @@ __device__ inline void add_bf16_pair(float& acc, unsigned int a) {
     asm volatile("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(acc) : "v"(a), "v"(0x3F803F80u));
 }
 
-template <int MODE, int TW>
+// OT = 2: the block owns TWO 32-channel output tiles (a 32 x 64 pair): the patch is staged and its fragments are read once for both --
+// the 32 -> 64 stride-2 layer of the top of the pyramid re-staged its (4-5x larger) patch for each of its two output tiles.
+template <int MODE, int TW, int OT = 1>
 __global__ __launch_bounds__(192) void conv_wgrad_bf16_kernel(
     const WgradSrcs srcs, float* __restrict__ part,
     int N, int Hi, int Wi, int IC, int OC, int Hb, int Wb, int tiles_x, int tiles_y, int ntiles, int nslices, int with_bias) {
@@ -792,30 +794,34 @@ __global__ __launch_bounds__(192) void conv_wgrad_bf16_kernel(
     constexpr int TH = NP / TW;
     constexpr int PH = patch_dim<MODE>(TH), PW = patch_dim<MODE>(TW);
     constexpr int S = S2 ? 2 : 1;
-    constexpr int XCH = PH * PW * 4, GCH = NP * 4;          // 16-byte chunks to stage
+    constexpr int XCH = PH * PW * 4, GCH = NP * 4 * OT;     // 16-byte chunks to stage (gradient tile: OT planes of 32 channels)
     constexpr int XIT = (XCH + 191) / 192, GIT = (GCH + 191) / 192;
-    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[(PH * PW + NP) * 64];
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[(PH * PW + NP * OT) * 64];
     unsigned char* const lx_ = lds_raw;
     unsigned char* const lg_ = lds_raw + PH * PW * 64;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6, hi = lane >> 5, l31 = lane & 31;
     const int n_ict = IC / 32;
-    const int ic0 = (blockIdx.x % n_ict) * 32, oc0 = (blockIdx.x / n_ict) * 32;
+    const int ic0 = (blockIdx.x % n_ict) * 32, oc0 = (blockIdx.x / n_ict) * 32 * OT;
     const int slice = blockIdx.y;
     // transposing-read supplier role of this lane: pixel row (lane & 15) >> 2 of the 4-row block, channel quad
     const int t_row = (lane & 15) >> 2;
     const int t_col = (((lane >> 4) & 1) * 16 + (lane & 3) * 4) * 2;  // byte offset inside the 64-byte row
 
-    f32x16 acc[3];
+    f32x16 acc[OT][3];
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
+    for (int o = 0; o < OT; ++o)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[o][t][r] = 0.f;
     // bias gradient = sum over pixels of gy: the gradient fragment of a lane is 8 pixels of its output channel, four packed
     // dot-2 adds per pixel group fold them into one register; done by the first wave of the blocks of input-channel tile 0
     const bool bias_wave = with_bias && wv == 0 && ic0 == 0;
-    float accb = 0.f;
+    float accb[OT];
+#pragma unroll
+    for (int o = 0; o < OT; ++o) accb[o] = 0.f;
 
     for (int tile = slice; tile < ntiles; tile += nslices) {
         int b = tile;
@@ -844,8 +850,8 @@ __global__ __launch_bounds__(192) void conv_wgrad_bf16_kernel(
         }
 #pragma unroll
         for (int it = 0; it < GIT; ++it) {
-            const int c = tid + 192 * it;
-            const int pix = c >> 2, part4 = c & 3;
+            const int c = tid + 192 * it;   // chunk c of LDS plane c / (NP * 4): pixel (c >> 2) % NP, channels 32 plane + 8 (c & 3)
+            const int pix = (c >> 2) % NP, part4 = (c & 3) + 4 * (c / (NP * 4));
             const int gy_ = by + pix / TW, gx_ = bx + pix % TW;
             const bool ok = c < GCH && gy_ < Hb && gx_ < Wb;
             gok |= ok ? (1u << it) : 0u;
@@ -867,37 +873,54 @@ __global__ __launch_bounds__(192) void conv_wgrad_bf16_kernel(
 #pragma unroll 2
         for (int g = 0; g < NP / 16; ++g) {
             const int ty = (g * 16) / TW, tx0 = (g * 16) % TW + 8 * hi;
-            const unsigned char* gp = lg_ + (ty * TW + tx0 + t_row) * 64 + t_col;
-            const uint2 b0 = lds_tr16(gp), b1 = lds_tr16(gp + 4 * 64);
-            const bf16x8 bfrag = mk_frag(b0.x, b0.y, b1.x, b1.y);
-            if (do_bias) { add_bf16_pair(accb, b0.x); add_bf16_pair(accb, b0.y); add_bf16_pair(accb, b1.x); add_bf16_pair(accb, b1.y); }
+            bf16x8 bfrag[OT];
+#pragma unroll
+            for (int o = 0; o < OT; ++o) {
+                const unsigned char* gp = lg_ + o * NP * 64 + (ty * TW + tx0 + t_row) * 64 + t_col;
+                const uint2 b0 = lds_tr16(gp), b1 = lds_tr16(gp + 4 * 64);
+                bfrag[o] = mk_frag(b0.x, b0.y, b1.x, b1.y);
+                if (do_bias) { add_bf16_pair(accb[o], b0.x); add_bf16_pair(accb[o], b0.y); add_bf16_pair(accb[o], b1.x); add_bf16_pair(accb[o], b1.y); }
+            }
             const unsigned char* xp = lx_ + (((ty * S + wv) * PW + tx0 * S) + t_row * S) * 64 + t_col;
             if (!S2) {
                 const uint2 d0 = lds_tr16(xp), d1 = lds_tr16(xp + 4 * 64), d2 = lds_tr16(xp + 8 * 64);
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk_frag(d0.x, d0.y, d1.x, d1.y), bfrag, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk_frag(shr16(d0.y, d0.x), shr16(d1.x, d0.y), shr16(d1.y, d1.x), shr16(d2.x, d1.y)), bfrag, acc[1], 0, 0, 0);
-                acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk_frag(d0.y, d1.x, d1.y, d2.x), bfrag, acc[2], 0, 0, 0);
+                const bf16x8 a0 = mk_frag(d0.x, d0.y, d1.x, d1.y), a1 = mk_frag(shr16(d0.y, d0.x), shr16(d1.x, d0.y), shr16(d1.y, d1.x), shr16(d2.x, d1.y)),
+                             a2 = mk_frag(d0.y, d1.x, d1.y, d2.x);
+#pragma unroll
+                for (int o = 0; o < OT; ++o) {
+                    acc[o][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bfrag[o], acc[o][0], 0, 0, 0);
+                    acc[o][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bfrag[o], acc[o][1], 0, 0, 0);
+                    acc[o][2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, bfrag[o], acc[o][2], 0, 0, 0);
+                }
             } else {
                 // even columns 2(p)+0 / +2 share a 9-pixel window; odd columns 2(p)+1 are their own 8-pixel window
                 const uint2 e0 = lds_tr16(xp), e1 = lds_tr16(xp + 8 * 64), e2 = lds_tr16(xp + 16 * 64);
                 const uint2 o0 = lds_tr16(xp + 64), o1 = lds_tr16(xp + 9 * 64);
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk_frag(e0.x, e0.y, e1.x, e1.y), bfrag, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk_frag(o0.x, o0.y, o1.x, o1.y), bfrag, acc[1], 0, 0, 0);
-                acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk_frag(shr16(e0.y, e0.x), shr16(e1.x, e0.y), shr16(e1.y, e1.x), shr16(e2.x, e1.y)), bfrag, acc[2], 0, 0, 0);
+                const bf16x8 a0 = mk_frag(e0.x, e0.y, e1.x, e1.y), a1 = mk_frag(o0.x, o0.y, o1.x, o1.y),
+                             a2 = mk_frag(shr16(e0.y, e0.x), shr16(e1.x, e0.y), shr16(e1.y, e1.x), shr16(e2.x, e1.y));
+#pragma unroll
+                for (int o = 0; o < OT; ++o) {
+                    acc[o][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bfrag[o], acc[o][0], 0, 0, 0);
+                    acc[o][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bfrag[o], acc[o][1], 0, 0, 0);
+                    acc[o][2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, bfrag[o], acc[o][2], 0, 0, 0);
+                }
             }
         }
     }
     // ---- each wave owns its 3 taps: D[ic i][oc j], lane = (j = l31, i = (r&3) + 8(r>>2) + 4hi)
     const long pstride = 9L * IC * OC + (with_bias ? OC : 0);   // fp32 elements per slice: 9 taps (+ the bias row)
-    if (bias_wave) {   // the two lane halves hold different pixels of the same channel
-        const float tot = accb + __shfl_xor(accb, 32, 64);
-        if (hi == 0) part[(long)slice * pstride + 9L * IC * OC + oc0 + l31] = tot;
-    }
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx) {
-        float* dst = part + (long)slice * pstride + (((long)wv * 3 + kx) * IC + ic0) * OC + oc0 + l31;
+    for (int o = 0; o < OT; ++o) {
+        if (bias_wave) {   // the two lane halves hold different pixels of the same channel
+            const float tot = accb[o] + __shfl_xor(accb[o], 32, 64);
+            if (hi == 0) part[(long)slice * pstride + 9L * IC * OC + oc0 + o * 32 + l31] = tot;
+        }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dst[(long)((r & 3) + 8 * (r >> 2) + 4 * hi) * OC] = acc[kx][r];
+        for (int kx = 0; kx < 3; ++kx) {
+            float* dst = part + (long)slice * pstride + (((long)wv * 3 + kx) * IC + ic0) * OC + oc0 + o * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dst[(long)((r & 3) + 8 * (r >> 2) + 4 * hi) * OC] = acc[o][kx][r];
+        }
     }
 }
 
@@ -1288,8 +1311,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_2x2_sk_kernel(const SkGro
     }
 }
 
-// folds the partials of every run of a group into the gradients: grid (37, runs), a thread owns 4 consecutive output channels
+// folds the partials of every run of a group into the gradients: grid (145, runs); block = 64 consecutive quads of the partial
+// (1 KiB per partial: whole DRAM bursts) x 4 partial lanes, a thread keeps four partials in flight; fixed order -> deterministic
 __global__ __launch_bounds__(256) void wgrad_sk_reduce_kernel(const SkGroup g, const float* __restrict__ part) {
+    constexpr int L = 4, EPB = 64;
+    __shared__ float4 red[256];
     const int r = blockIdx.y;
     int j = 0;
     while (j + 1 < g.njobs && r >= g.job[j + 1].run_base) ++j;
@@ -1298,16 +1324,43 @@ __global__ __launch_bounds__(256) void wgrad_sk_reduce_kernel(const SkGroup g, c
     const int ic0 = (ct % q.n_ict) * 64, oc0 = (ct / q.n_ict) * 64;
     const long s0 = (long)q.unit_base + (long)ct * q.ntiles;
     const int b0 = sk_block_of(s0, g.nblocks, g.total_units), b1 = sk_block_of(s0 + q.ntiles - 1, g.nblocks, g.total_units);
-    const int e = blockIdx.x * 256 + threadIdx.x;   // quad index inside the partial
-    if (e >= GS_SK_PSTRIDE / 4) return;
+    const int e = blockIdx.x * EPB + (threadIdx.x % EPB);   // quad index inside the partial
+    const int sl = threadIdx.x / EPB;
+    const bool live = e < GS_SK_PSTRIDE / 4;
     const bool is_bias = e >= 9 * 1024;
-    if (is_bias && !(q.gb && ic0 == 0)) return;
+    if (blockIdx.x * EPB >= 9 * 1024 && !(q.gb && ic0 == 0)) return;   // (the bias quads are the last, whole block)
+    const float* const base = part + (long)r * GS_SK_PSTRIDE + (long)e * 4;
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+    if (live) {
+        int b = b0 + sl;
+        for (; b + 3 * L <= b1; b += 4 * L) {
+            const float4 v0 = *reinterpret_cast<const float4*>(base + (long)b * GS_SK_PSTRIDE);
+            const float4 v1 = *reinterpret_cast<const float4*>(base + (long)(b + L) * GS_SK_PSTRIDE);
+            const float4 v2 = *reinterpret_cast<const float4*>(base + (long)(b + 2 * L) * GS_SK_PSTRIDE);
+            const float4 v3 = *reinterpret_cast<const float4*>(base + (long)(b + 3 * L) * GS_SK_PSTRIDE);
+            a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+            a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+            a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
+            a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
+        }
+        for (; b <= b1; b += L) {
+            const float4 v0 = *reinterpret_cast<const float4*>(base + (long)b * GS_SK_PSTRIDE);
+            a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+        }
+    }
+    a0.x += a2.x; a0.y += a2.y; a0.z += a2.z; a0.w += a2.w;
+    a1.x += a3.x; a1.y += a3.y; a1.z += a3.z; a1.w += a3.w;
+    red[threadIdx.x] = make_float4(a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w);
+    __syncthreads();
+    if (sl != 0 || !live) return;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int b = b0; b <= b1; ++b) {
-        const float4 a = *reinterpret_cast<const float4*>(part + (long)(b + r) * GS_SK_PSTRIDE + (long)e * 4);
-        s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+#pragma unroll
+    for (int k = 0; k < L; ++k) {
+        const float4 v = red[threadIdx.x + k * EPB];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
     if (is_bias) {
+        if (!(q.gb && ic0 == 0)) return;
         float4* o = reinterpret_cast<float4*>(q.gb + oc0 + (e - 9 * 1024) * 4);
         const float4 old = q.accumulate ? *o : make_float4(0.f, 0.f, 0.f, 0.f);
         *o = make_float4(old.x + s.x, old.y + s.y, old.z + s.z, old.w + s.w);
@@ -1570,6 +1623,11 @@ int run_igemm(int mode, int variant, const void* x, const float* w_hwio, void* y
 
 // ---- weight gradient (fp32 MFMA path)
 static bool wgrad_2x2(int mode, int dtype, int IC, int OC) { (void)mode; return dtype == GS_BF16 && IC % 64 == 0 && OC % 64 == 0; }
+// thin bf16 layers whose output side has a multiple of 64 channels: 32 x 64 pairs per block (conv_wgrad_bf16_kernel<.., 2>)
+static bool wgrad_thin_pairs(int mode, int dtype, int IC, int OC) {
+    static const bool off = getenv("GS_NO_THIN_PAIRS") != nullptr;   // measurement knob
+    return !off && dtype == GS_BF16 && !wgrad_2x2(mode, dtype, IC, OC) && OC % 64 == 0;
+}
 static void wgrad_geometry(int mode, int dtype, int N, int Hb, int Wb, int IC, int OC, int* tw, int* tiles_x, int* tiles_y,
                            int* ntiles, int* nslices) {
     int np = (mode == MODE_S2 ? 64 : 128) * (dtype == GS_BF16 ? 2 : 1);
@@ -1582,6 +1640,7 @@ static void wgrad_geometry(int mode, int dtype, int N, int Hb, int Wb, int IC, i
     int pairs = (IC / 32) * (OC / 32);
     int target = dtype == GS_BF16 ? 768 : 512;
     if (wgrad_2x2(mode, dtype, IC, OC)) { pairs /= 4; target = 256; }   // 64 x 64 tiles, double-buffered: one block of 4 waves per CU
+    else if (wgrad_thin_pairs(mode, dtype, IC, OC)) pairs /= 2;
     int ns = target / pairs;
     if (ns < 1) ns = 1;
     if (ns > *ntiles) ns = *ntiles;
@@ -1627,8 +1686,14 @@ int run_wgrad_mfma(int mode, const WgradSrcs& srcs, int nsrc, float* gw, float* 
             GS_WG_ALL(float);
         } else {
 #define GS_WGB(M, TWV)                                                                                                  \
-    hipLaunchKernelGGL((conv_wgrad_bf16_kernel<M, TWV>), grid, dim3(192), 0, st, srcs,                                  \
-                       part, N, Hi, Wi, IC, OC, Hb, Wb, tiles_x, tiles_y, ntiles, nslices, with_bias)
+    do {                                                                                                                \
+        if (wgrad_thin_pairs(mode, dtype, IC, OC))                                                                      \
+            hipLaunchKernelGGL((conv_wgrad_bf16_kernel<M, TWV, 2>), dim3((IC / 32) * (OC / 64), nslices), dim3(192), 0, st, srcs, \
+                               part, N, Hi, Wi, IC, OC, Hb, Wb, tiles_x, tiles_y, ntiles, nslices, with_bias);         \
+        else                                                                                                            \
+            hipLaunchKernelGGL((conv_wgrad_bf16_kernel<M, TWV>), grid, dim3(192), 0, st, srcs,                          \
+                               part, N, Hi, Wi, IC, OC, Hb, Wb, tiles_x, tiles_y, ntiles, nslices, with_bias);         \
+    } while (0)
 #define GS_WGB2(M, TWV)                                                                                                 \
     do {                                                                                                                \
         constexpr int np_ = (M == MODE_S2 ? 64 : 256), th_ = np_ / TWV;                                                 \
@@ -1739,7 +1804,7 @@ int run_wgrad_sk(int mode, int tw, const SkGroup& g, void* ws, size_t ws_bytes, 
 #undef GS_WGSK
     }
     GS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(wgrad_sk_reduce_kernel, dim3((GS_SK_PSTRIDE / 4 + 255) / 256, (unsigned)g.total_runs), dim3(256), 0, st, g, part);
+    hipLaunchKernelGGL(wgrad_sk_reduce_kernel, dim3((GS_SK_PSTRIDE / 4 + 63) / 64, (unsigned)g.total_runs), dim3(256), 0, st, g, part);
     GS_CHECK_LAUNCH();
     return 0;
 }
