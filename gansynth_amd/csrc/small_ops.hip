@@ -126,11 +126,13 @@ __global__ __launch_bounds__(256) void dense_bwd_data_wide_kernel(const T* __res
 
 
 // ---- fast paths (vector loads; the generic kernels above remain for odd shapes) ------------------------------------
-constexpr int FB = 8;   // batch rows per pass of the fast kernels
+// batch rows per pass of the fast kernels: 8, 16 or 24 (FB template parameter) -- the discriminator's 16- and 24-row calls read the
+// weight matrix once instead of two or three times
+static int fast_rows(int b) { return b <= 8 ? 8 : (b <= 16 ? 16 : 24); }
 // y[b][o] = alpha * sum_i x[b][i] w[i][o], in % 4 == 0, out % 32 == 0.  Block = 8 column threads (float4: 32 columns) x 32 row
 // lanes; a row lane takes 4 consecutive rows per pass (one 8/16-byte load of x per batch row).  Row lanes are folded with
 // xor-shuffles inside a wave and through LDS across the 4 waves; with ksplit == 1 the result is written directly.
-template <typename T>
+template <typename T, int FB>
 __global__ __launch_bounds__(256) void dense_fwd_fast_kernel(const T* __restrict__ x, const float* __restrict__ w, float* __restrict__ part,
                                                              T* __restrict__ y, int b0, int nb, int in, int out, int b_total, int ipb, float alpha) {
     __shared__ float red[4][FB][32];
@@ -145,6 +147,7 @@ __global__ __launch_bounds__(256) void dense_fwd_fast_kernel(const T* __restrict
     for (int b = 0; b < FB; ++b)
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[b][e] = 0.f;
+#pragma unroll 2
     for (int i = i0 + 4 * r; i < i1; i += 128) {
         float4 wv[4];
 #pragma unroll
@@ -195,7 +198,7 @@ __global__ __launch_bounds__(256) void dense_fwd_fast_kernel(const T* __restrict
 // gx[b][i] = alpha * sum_o gy[b][o] w[i][o], out % 256 == 0: WPR waves per weight row (1: a wave per row; 4: the block's four
 // waves split a long row -- the generator's 512 x 8192 dense has only 512 rows, a wave per row is 128 blocks of 32 serial
 // trips), 16 bytes of w per lane per pass.
-template <typename T, int WPR>
+template <typename T, int WPR, int FB>
 __global__ __launch_bounds__(256) void dense_bwd_data_fast_kernel(const T* __restrict__ gy, const float* __restrict__ w, T* __restrict__ gx,
                                                                   int b0, int nb, int in, int out, float alpha) {
     __shared__ float red[4][FB];
@@ -206,6 +209,7 @@ __global__ __launch_bounds__(256) void dense_bwd_data_fast_kernel(const T* __res
 #pragma unroll
     for (int b = 0; b < FB; ++b) acc[b] = 0.f;
     const float* wr = w + (long)(i < in ? i : in - 1) * out;
+#pragma unroll 4
     for (int o = (sub * 64 + lane) * 4; o < out; o += 256 * WPR) {
         const float4 wv = *reinterpret_cast<const float4*>(wr + o);
 #pragma unroll
@@ -531,12 +535,14 @@ extern "C" int gs_dense_fwd(const void* x, const float* w, void* y, int b, int i
     hipStream_t st = as_stream(stream);
     float* part = (float*)ws;
     const bool fast = dense_fwd_fast_ok(in, out);
-    const int step = fast ? FB : DENSE_BT;
+    const int step = fast ? fast_rows(b) : DENSE_BT;
     for (int b0 = 0; b0 < b; b0 += step) {
         const int nb = b - b0 < step ? b - b0 : step;
         if (fast) {
-            GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dense_fwd_fast_kernel<T>), dim3(out / 32, ks), dim3(256), 0, st, (const T*)x, w,
-                                                        ks > 1 ? part : nullptr, (T*)y, b0, nb, in, out, b, ipb, alpha));
+#define GS_DFF(FBV) GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dense_fwd_fast_kernel<T, FBV>), dim3(out / 32, ks), dim3(256), 0, st, (const T*)x, w, \
+                                                                ks > 1 ? part : nullptr, (T*)y, b0, nb, in, out, b, ipb, alpha))
+            if (step == 8) GS_DFF(8); else if (step == 16) GS_DFF(16); else GS_DFF(24);
+#undef GS_DFF
         } else {
             GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dense_fwd_kernel<T>), dim3(cdiv(out, 64), ks), dim3(256), 0, st, (const T*)x, w, part, b0, nb, in, out, b, ipb));
         }
@@ -552,15 +558,17 @@ extern "C" int gs_dense_fwd(const void* x, const float* w, void* y, int b, int i
 extern "C" int gs_dense_bwd_data(const void* gy, const float* w, void* gx, int b, int in, int out, float alpha, int dtype, void* stream) {
     GS_CHECK_ARG(b > 0 && in > 0 && out > 0, "dense_bwd_data: bad args");
     hipStream_t st = as_stream(stream);
-    const int step = out % 256 == 0 ? FB : DENSE_BT;
+    const int step = out % 256 == 0 ? fast_rows(b) : DENSE_BT;
     for (int b0 = 0; b0 < b; b0 += step) {
         const int nb = b - b0 < step ? b - b0 : step;
         if (out % 256 == 0) {
+#define GS_DBF(WPRV, FBV, GRID) GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dense_bwd_data_fast_kernel<T, WPRV, FBV>), dim3(GRID), dim3(256), 0, st, (const T*)gy, w, (T*)gx, b0, nb, in, out, alpha))
             if (in <= 1024 && out >= 1024) {   // few long rows: the whole block on one row
-                GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dense_bwd_data_fast_kernel<T, 4>), dim3(in), dim3(256), 0, st, (const T*)gy, w, (T*)gx, b0, nb, in, out, alpha));
+                if (step == 8) GS_DBF(4, 8, in); else if (step == 16) GS_DBF(4, 16, in); else GS_DBF(4, 24, in);
             } else {
-                GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dense_bwd_data_fast_kernel<T, 1>), dim3(cdiv(in, 4)), dim3(256), 0, st, (const T*)gy, w, (T*)gx, b0, nb, in, out, alpha));
+                if (step == 8) GS_DBF(1, 8, cdiv(in, 4)); else if (step == 16) GS_DBF(1, 16, cdiv(in, 4)); else GS_DBF(1, 24, cdiv(in, 4));
             }
+#undef GS_DBF
         } else if (out >= 2048) {
             GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dense_bwd_data_wide_kernel<T>), dim3(in), dim3(256), 0, st, (const T*)gy, w, (T*)gx, b0, nb, in, out, alpha));
         } else {

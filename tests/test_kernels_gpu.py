@@ -98,7 +98,8 @@ def test_conv2d_transpose_three_maps(K, E, case):
     close(K.conv2d_transpose_bwd_weight(dev(x), dev(gy), alpha), E.conv2d_transpose_bwd_weight(x, gy, alpha), name="bwd_weight")
 
 
-@pytest.mark.parametrize("b,i,o", [(8, 512, 8192), (8, 8192, 256), (8, 256, 61), (4, 32, 40), (20, 100, 70)])
+@pytest.mark.parametrize("b,i,o", [(8, 512, 8192), (8, 8192, 256), (8, 256, 61), (4, 32, 40), (20, 100, 70), (16, 8192, 256), (24, 8192, 256), (13, 512, 8192),
+                                   (24, 512, 8192), (30, 8192, 256)])
 def test_dense(K, E, b, i, o):
     x, w, gy = rnd(b, i, seed=1), rnd(i, o, seed=2), rnd(b, o, seed=3)
     alpha = float(np.sqrt(2.0 / i))
