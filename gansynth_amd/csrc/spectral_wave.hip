@@ -109,7 +109,7 @@ __device__ __forceinline__ float quad_mov(float x) {
 __device__ __forceinline__ float atan2_poly(float y, float x) {
     const float ax = fabsf(x), ay = fabsf(y);
     const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
-    const float t = mn * __builtin_amdgcn_rcpf(mx);
+    const float t = mn * __builtin_amdgcn_rcpf(fmaxf(mx, 1.0e-30f));   // (0, 0): t = 0 -> angle 0, like np.angle
     const float s = t * t;
     float r = -0.00405456405133009f;
     r = fmaf(r, s, 0.021862946450710297f);
@@ -122,7 +122,6 @@ __device__ __forceinline__ float atan2_poly(float y, float x) {
     r *= t;
     r = ay > ax ? 1.57079637050628662f - r : r;
     r = x < 0.f ? 3.14159274101257324f - r : r;
-    r = mx == 0.f ? 0.f : r;
     return copysignf(r, y);
 }
 
@@ -310,18 +309,17 @@ __global__ __launch_bounds__(64 * SW_WAVES) void stft_wave_kernel(const float* _
     const bool exch = MODE == 1 && edge != nullptr && runs % SW_WAVES == 0;
     const bool from_left = exch && wid != 0 && t0 > 0;                               // my first frame's IF is written by wave wid - 1
     const bool to_right = exch && wid != SW_WAVES - 1 && t1 < TT;                    // I write the IF of frame t1 (wave wid + 1's first)
-    auto wrapped = [&](float d) __attribute__((always_inline)) {                      // spectral_ops.py:21-33 on one difference
-        const float x = d + pi;
-        float md = fmaf(-floorf(x * 0.15915494309189535f), two_pi, x);   // floor-mod(d + pi, 2 pi) (exact: one fma)
-        if (md < 0.f) md += two_pi;
-        if (md >= two_pi) md -= two_pi;
-        md -= pi;
-        if (md == -pi && d > 0.f) md = pi;
-        return md;
+    // spectral_ops.py:21-33 on one difference: floor-mod(d + pi, 2 pi) - pi, with -pi -> pi for d > 0.  Evaluated as d - 2 pi rint(d / 2 pi)
+    // (one exact fma): the same value wherever the reference's own fp32 evaluation is more than an ulp of 2 pi away from the cut (rint's
+    // ties -- d an odd multiple of pi -- give pi for d = pi and -pi for d = -pi like the reference); 3 instructions instead of 13,
+    // 16 times per frame and lane.
+    auto wrapped = [&](float d) __attribute__((always_inline)) {
+        return fmaf(-__builtin_rintf(d * 0.15915494309189535f), two_pi, d);
     };
     const int tfirst = (MODE == 1 && t0 > 0 && !from_left) ? t0 - 1 : t0;
     for (int t = tfirst; t < t1; ++t) {
         const bool lead = t < t0;                       // frame t0 - 1: only its mel phases are needed
+        const float inv_two_pi_live = t == 0 ? 0.f : 0.15915494309189535f;   // (scalar: rint(d * 0) = 0 leaves frame 0 unwrapped)
         const int base = t * step - front_pad;
         const bool silent = base + 2048 <= 0 || base >= wave_len;   // entirely inside the padding: spectrum exactly 0
         if (!silent) {
@@ -367,8 +365,13 @@ __global__ __launch_bounds__(64 * SW_WAVES) void stft_wave_kernel(const float* _
                 for (int e = 0; e < SW_SHAPE[j]; ++e) {   // ascending bins: the order of the oracle's dot product over the non-zeros
                     const float2 w2 = lds_ld(reinterpret_cast<const float2*>(wj + 128 * e));
                     const float2 xa = lds_ld(ma + e), xb = lds_ld(mb + e);
-                    am0 = fmaf(w2.x, xa.x, am0); ap0 = fmaf(w2.x, xa.y, ap0);
-                    am1 = fmaf(w2.y, xb.x, am1); ap1 = fmaf(w2.y, xb.y, ap1);
+                    if (e == 0) {   // (0 + w x = w x exactly: no zeroed accumulators)
+                        am0 = w2.x * xa.x; ap0 = w2.x * xa.y;
+                        am1 = w2.y * xb.x; ap1 = w2.y * xb.y;
+                    } else {
+                        am0 = fmaf(w2.x, xa.x, am0); ap0 = fmaf(w2.x, xa.y, ap0);
+                        am1 = fmaf(w2.y, xb.x, am1); ap1 = fmaf(w2.y, xb.y, ap1);
+                    }
                 }
             }
             off += 128 * SW_SHAPE[j];
@@ -377,8 +380,10 @@ __global__ __launch_bounds__(64 * SW_WAVES) void stft_wave_kernel(const float* _
             const float ap[2] = {ap0, ap1};
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                const float md = wrapped(ap[e] - prev[2 * j + e]);
-                vif[e] = (t == 0 ? ap[e] : md) * 0.31830988618379069f;   // (a run's first frame in exchange mode: placeholder, see below)
+                // frame 0: the unwrapped phase itself.  prev is 0 there; `first` (wave-uniform, 0 or 1) cancels the wrap of that one frame
+                // without a select per bin: ap - 2 pi rint(ap / 2 pi) * (1 - first)
+                const float d = ap[e] - prev[2 * j + e];
+                vif[e] = fmaf(-__builtin_rintf(d * inv_two_pi_live), two_pi, d) * 0.31830988618379069f;   // (a run's first frame in exchange mode: placeholder, see below)
                 prev[2 * j + e] = ap[e];
             }
             if (from_left && t == t0)
