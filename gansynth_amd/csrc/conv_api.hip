@@ -308,38 +308,81 @@ __device__ __host__ inline void prep_plan(int map, int ci, int co, int ksize, in
     }
     *store_f32 = !mfma || dtype == GS_F32;
 }
+// One 64 x 64 (ci x co) tile of one tap per trip, staged through LDS so that both sides move whole 256-byte rows: the forward operand
+// is the TRANSPOSE of the stored [ci][co] slab (a thread-per-element gather read it with a stride of co floats: 31 us per launch for the
+// ~20 MB of a network, now bandwidth-bound); the data-gradient operands are (tap-flipped) copies.
 static __global__ __launch_bounds__(256) void weight_prep_batch_kernel(const GsPrepDesc* __restrict__ descs) {
+    __shared__ float tile[64][65];
     const GsPrepDesc d = descs[blockIdx.y];
     int variant;
     bool f32;
     prep_plan(d.map, d.ci, d.co, d.ksize, d.dtype, &variant, &f32);
     if (d.map == GS_PREP_CONV_BWD_DATA && d.stride == 2) variant = 2;
     const int taps = d.ksize * d.ksize, ci = d.ci, co = d.co;
-    const long total = (long)taps * ci * co;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-        long dst;
-        float v;
+    const int tci = (ci + 63) >> 6, tco = (co + 63) >> 6;
+    const int ntiles = taps * tci * tco;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;   // 16 x 16 threads, 4 consecutive elements each
+    for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        const int t = tl / (tci * tco), r = tl % (tci * tco);
+        const int i0 = (r / tco) * 64, o0 = (r % tco) * 64;
+        const float* src = d.w_hwio + (long)t * ci * co;
         if (variant == 0) {
-            const int c_i = idx % ci;
-            const int c_o = (idx / ci) % co;
-            const int t = idx / ((long)ci * co);
-            dst = idx;
-            v = d.w_hwio[((long)t * ci + c_i) * co + c_o];
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {   // rows i0 + ty + 16 k, columns o0 + 4 tx ..
+                const int i = i0 + ty + 16 * k, o = o0 + 4 * tx;
+                float v[4] = {0.f, 0.f, 0.f, 0.f};
+                if (i < ci) {
+                    if (o + 3 < co && (co & 3) == 0) { const float4 q = *reinterpret_cast<const float4*>(src + (long)i * co + o); v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w; }
+                    else { for (int e = 0; e < 4; ++e) if (o + e < co) v[e] = src[(long)i * co + o + e]; }
+                }
+                for (int e = 0; e < 4; ++e) tile[ty + 16 * k][4 * tx + e] = v[e];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {   // output rows o0 + ty + 16 k, 4 consecutive input channels i0 + 4 tx ..
+                const int o = o0 + ty + 16 * k, i = i0 + 4 * tx;
+                if (o >= co) continue;
+                float v[4];
+                for (int e = 0; e < 4; ++e) v[e] = tile[4 * tx + e][ty + 16 * k];
+                const long dst = ((long)t * co + o) * ci + i;
+                if (i + 3 < ci && (ci & 3) == 0) {
+                    if (f32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(d.ws) + dst) = make_float4(v[0], v[1], v[2], v[3]);
+                    else *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(d.ws) + dst) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                } else {
+                    for (int e = 0; e < 4; ++e)
+                        if (i + e < ci) {
+                            if (f32) reinterpret_cast<float*>(d.ws)[dst + e] = v[e];
+                            else reinterpret_cast<bf16_t*>(d.ws)[dst + e] = f32_to_bf16(v[e]);
+                        }
+                }
+            }
         } else {
-            const int t = idx / ((long)ci * co);
-            const long rem = idx % ((long)ci * co);
             const int tt = variant == 1 ? taps - 1 - t : t;
-            dst = (long)tt * ci * co + rem;
-            v = d.w_hwio[idx];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = i0 + ty + 16 * k, o = o0 + 4 * tx;
+                if (i >= ci) continue;
+                const long so = (long)i * co + o, dst = (long)tt * ci * co + so;
+                if (o + 3 < co && (co & 3) == 0) {
+                    const float4 q = *reinterpret_cast<const float4*>(src + so);
+                    if (f32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(d.ws) + dst) = q;
+                    else *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(d.ws) + dst) = make_uint2(pack_bf16x2(q.x, q.y), pack_bf16x2(q.z, q.w));
+                } else {
+                    for (int e = 0; e < 4; ++e)
+                        if (o + e < co) {
+                            if (f32) reinterpret_cast<float*>(d.ws)[dst + e] = src[so + e];
+                            else reinterpret_cast<bf16_t*>(d.ws)[dst + e] = f32_to_bf16(src[so + e]);
+                        }
+                }
+            }
         }
-        if (f32) reinterpret_cast<float*>(d.ws)[dst] = v;
-        else reinterpret_cast<bf16_t*>(d.ws)[dst] = f32_to_bf16(v);
     }
 }
 
 extern "C" int gs_weight_prep_batch(const GsPrepDesc* descs, int n, void* stream) {
     GS_CHECK_ARG(descs != nullptr && n > 0 && n <= 65535, "weight_prep_batch: bad args");
-    hipLaunchKernelGGL(weight_prep_batch_kernel, dim3(64, n), dim3(256), 0, as_stream(stream), descs);
+    hipLaunchKernelGGL(weight_prep_batch_kernel, dim3(48, n), dim3(256), 0, as_stream(stream), descs);
     GS_CHECK_LAUNCH();
     return 0;
 }
