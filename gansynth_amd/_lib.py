@@ -102,7 +102,7 @@ class GsWgradReduce(ctypes.Structure):
     """include/gansynth_hip.h: one pending slice reduction of a weight gradient."""
     _fields_ = [("partials", c_void_p), ("gw", c_void_p), ("gb", c_void_p), ("nslices", ctypes.c_int32), ("taps", ctypes.c_int32),
                 ("ic", ctypes.c_int32), ("oc", ctypes.c_int32), ("alpha", c_float), ("transpose", ctypes.c_int32),
-                ("accumulate", ctypes.c_int32)]
+                ("accumulate", ctypes.c_int32), ("ic_ld", ctypes.c_int32)]
 
 
 class GsWgradJob(ctypes.Structure):

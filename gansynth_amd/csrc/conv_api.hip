@@ -791,7 +791,7 @@ extern "C" int gs_wgrad_reduce_batch(const GsWgradReduce* pending, int n, void* 
 namespace gs {
 struct JobPlan {
     std::vector<std::pair<int, SkGroup>> groups;   // (mode * 64 + tile width, group), in launch order
-    std::vector<int> single;                      // jobs on the per-layer path
+    std::vector<GsWgradJob> single;               // jobs on the per-layer path (one source each where the layer has no multi-source kernel)
     std::vector<size_t> single_off;               // their workspace offsets
     size_t group_bytes = 0, total_bytes = 0;
 };
@@ -846,8 +846,23 @@ static int plan_jobs(const GsWgradJob* jobs, int njobs, JobPlan& plan) {
             q.ICld = jb.gw_ci_stride > 0 ? jb.gw_ci_stride : IC;
             wgrad_sk_job_geometry(mode, tw, total, q);
         } else {
-            GS_CHECK_ARG(jb.gw_ci_stride == 0 || jb.gw_ci_stride == jb.ci, "conv_wgrad_jobs: job %d: a channel-slice target needs a grouped (bf16, >= 64-channel, 3x3) layer", i);
-            plan.single.push_back(i);
+            // layers without a multi-source kernel (direct / thin kernels, fp32 bias sums): one single-source job per pair, each with its own
+            // partials so that every slice reduction can stay pending
+            const bool mfma = jb.ksize == 3 && (jb.transposed ? wgrad_mfma_supported(jb.co, jb.ci, jb.dtype) : wgrad_mfma_supported(jb.ci, jb.co, jb.dtype));
+            const bool multi = mfma && (!jb.gb || wgrad_mfma_has_bias(jb.dtype));
+            if (jb.nsrc == 1 || multi) {
+                plan.single.push_back(jb);
+            } else {
+                for (int sidx = 0; sidx < jb.nsrc; ++sidx) {
+                    GsWgradJob one = jb;
+                    one.nsrc = 1;
+                    one.x[0] = jb.x[sidx]; one.gy[0] = jb.gy[sidx]; one.n[0] = jb.n[sidx];
+                    one.bias_mask = (jb.bias_mask >> sidx) & 1u;
+                    if (!one.bias_mask) one.gb = nullptr;
+                    if (sidx > 0) one.accumulate = 1;
+                    plan.single.push_back(one);
+                }
+            }
         }
     }
     for (auto& kg : plan.groups) {
@@ -856,8 +871,7 @@ static int plan_jobs(const GsWgradJob* jobs, int njobs, JobPlan& plan) {
         if (b > plan.group_bytes) plan.group_bytes = b;
     }
     size_t off = plan.group_bytes;
-    for (int i : plan.single) {
-        const GsWgradJob& jb = jobs[i];
+    for (const GsWgradJob& jb : plan.single) {
         const int total = job_total_images(jb);
         plan.single_off.push_back(off);
         off += jb.transposed ? gs_conv2d_transpose_s2_workspace_bytes(GS_CONV_BWD_WEIGHT, total, jb.h, jb.w, jb.ci, jb.co, jb.dtype)
@@ -886,10 +900,11 @@ extern "C" int gs_conv_wgrad_jobs(const GsWgradJob* jobs, int njobs, void* ws, s
         if (int e = run_wgrad_sk(kg.first / 64, kg.first % 64, kg.second, ws, plan.group_bytes, st)) return e;
     std::vector<GsWgradReduce> pend;
     for (size_t k = 0; k < plan.single.size(); ++k) {
-        const GsWgradJob& jb = jobs[plan.single[k]];
+        const GsWgradJob& jb = plan.single[k];
         unsigned char* jws = reinterpret_cast<unsigned char*>(ws) + plan.single_off[k];
         const size_t jbytes = (k + 1 < plan.single.size() ? plan.single_off[k + 1] : plan.total_bytes) - plan.single_off[k];
         GsWgradReduce d;
+        memset(&d, 0, sizeof(d));
         int rc;
         if (jb.transposed)
             rc = gs_conv2d_transpose_s2_bwd_weight_multi(jb.x, jb.gy, jb.n, jb.nsrc, jb.gw, jb.n[0], jb.h, jb.w, jb.ci, jb.co, jb.alpha, jb.accumulate, jb.dtype, jws, jbytes, &d, stream);
@@ -897,6 +912,10 @@ extern "C" int gs_conv_wgrad_jobs(const GsWgradJob* jobs, int njobs, void* ws, s
             rc = gs_conv2d_bwd_weight_bias_multi(jb.x, jb.gy, jb.n, jb.nsrc, jb.bias_mask, jb.gw, jb.gb, jb.n[0], jb.h, jb.w, jb.ci, jb.co, jb.ksize, jb.stride, jb.alpha,
                                                  jb.accumulate, jb.dtype, jws, jbytes, &d, stream);
         if (rc) return rc;
+        if (jb.gw_ci_stride > jb.ci) {   // a channel-slice target: only the pending (batched) fold knows the row stride
+            if (d.nslices <= 0 || d.transpose) return fail(GS_ERR_UNSUPPORTED, "conv_wgrad_jobs: a %d -> %d layer cannot add into a channel slice", jb.ci, jb.co);
+            d.ic_ld = jb.gw_ci_stride;
+        }
         if (d.nslices > 0) pend.push_back(d);
     }
     if (!pend.empty()) return gs_wgrad_reduce_batch(pend.data(), (int)pend.size(), stream);

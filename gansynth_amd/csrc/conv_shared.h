@@ -212,7 +212,13 @@ static __global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const Re
     const float alpha = d.alpha;
     float* __restrict__ gw = d.gw;
     if (!d.transpose) {
-        float4* o = reinterpret_cast<float4*>(gw + e);
+        long dst = e;
+        if (d.ic_ld > ic) {   // channel slice of a wider variable: tap t starts at t * ic_ld * oc (a quad never straddles taps: ic * oc % 4 == 0)
+            const long per_tap = (long)ic * oc;
+            const long tp = e / per_tap;
+            dst = tp * d.ic_ld * oc + (e - tp * per_tap);
+        }
+        float4* o = reinterpret_cast<float4*>(gw + dst);
         const float4 old = accumulate ? *o : make_float4(0.f, 0.f, 0.f, 0.f);
         *o = make_float4(old.x + s[0] * alpha, old.y + s[1] * alpha, old.z + s[2] * alpha, old.w + s[3] * alpha);
     } else {
@@ -235,7 +241,7 @@ static inline void wgrad_reduce_launch(float* part, float* gw, float* gb, int ns
     if (defer && vec) {   // phase 2 is left to gs_wgrad_reduce_batch
         defer->partials = part; defer->gw = gw; defer->gb = gb;
         defer->nslices = nslices; defer->taps = taps; defer->ic = ic; defer->oc = oc;
-        defer->alpha = alpha; defer->transpose = transpose; defer->accumulate = accumulate;
+        defer->alpha = alpha; defer->transpose = transpose; defer->accumulate = accumulate; defer->ic_ld = 0;
         return;
     }
     if (!vec) {

@@ -186,9 +186,13 @@ class HipKernels(object):
 
     def wgrad_slice_target_ok(self, x, co, ksize, stride):
         """May a conv weight gradient be added into a CHANNEL SLICE w.grad[:, :, lo:hi, :] of a wider variable (a strided `out`)?
-        Only while gradients are deferred and for the layers gs_conv_wgrad_jobs runs grouped (bf16, 3x3, >= 64 channels both sides)."""
-        return (self._pending is not None and not os.environ.get("GS_NO_WGRAD_GROUPS") and x.dtype == torch.bfloat16 and ksize == 3
-                and x.shape[1] % 64 == 0 and co % 64 == 0)
+        Only while gradients are deferred, for the layers gs_conv_wgrad_jobs runs grouped (bf16, 3x3, >= 64 channels both sides) and
+        for the 1-input-channel plane conv of the direct kernel."""
+        if self._pending is None or os.environ.get("GS_NO_WGRAD_GROUPS") or ksize != 3:
+            return False
+        if x.shape[1] == 1 and stride == 1 and co % 4 == 0:   # the 1-channel direct kernel: its slice reduction stays pending, the batched fold takes the stride
+            return True
+        return x.dtype == torch.bfloat16 and x.shape[1] % 64 == 0 and co % 64 == 0
 
     def _defer_wgrad(self, key, x, gy, out, bias_out):
         grp = self._pending.setdefault(key, {"out": out, "bias": None, "src": []})

@@ -160,6 +160,7 @@ typedef struct GsWgradReduce {
     int32_t nslices, taps, ic, oc;
     float alpha;
     int32_t transpose, accumulate;
+    int32_t ic_ld;         /* 0, or the input-channel rows of the stored variable when gw is a channel slice of a wider one (not with transpose) */
 } GsWgradReduce;
 int gs_conv2d_bwd_weight_bias_partial(const void* x, const void* gy, float* gw_hwio, float* gb, int n, int h, int w, int ci, int co,
                                       int ksize, int stride, float alpha, int accumulate, int dtype, void* ws, size_t ws_bytes,
@@ -201,7 +202,8 @@ typedef struct GsWgradJob {
     int32_t accumulate, dtype;
     int32_t gw_ci_stride;   /* 0, or the input-channel count of the stored variable when gw is the slice [:, :, lo:lo+ci, :] of a
                              * wider one (the 257-channel conv of the last discriminator block, networks.py:174-176): element
-                             * (t, i, o) lives at gw[(t * gw_ci_stride + i) * co + o].  Grouped (stream-K) layers only. */
+                             * (t, i, o) lives at gw[(t * gw_ci_stride + i) * co + o].  Grouped (stream-K) layers and layers whose slice reduction stays
+                             * pending (the 1-channel direct kernel). */
 } GsWgradJob;
 size_t gs_conv_wgrad_jobs_workspace_bytes(const GsWgradJob* jobs, int njobs);
 int gs_conv_wgrad_jobs(const GsWgradJob* jobs, int njobs, void* ws, size_t ws_bytes, void* stream);

@@ -558,7 +558,22 @@ def test_grouped_weight_gradients_match_oracle(K, E):
                 ref_w += E.conv2d_transpose_bwd_weight(x, gy, 0.3)
         want.append((ref_w, ref_b))
         got.append((gw, gb))
-    assert K.flush_wgrad_reductions() == sum(len(l[1]) for l in layers)
+    # the 257-input-channel conv evaluated on two channel slices of one variable (networks.py:174-176): both slice gradients are
+    # added straight into their rows of the variable's gradient (a strided target), the 64-channel slice by the grouped kernel,
+    # the 1-channel one by the direct kernel's pending reduction -- two sources each
+    parent = torch.full((3, 3, 65, 64), 0.125, device="cuda")
+    ref_parent = torch.full((3, 3, 65, 64), 0.125)
+    extra = 0
+    for lo, hi in ((0, 64), (64, 65)):
+        assert K.wgrad_slice_target_ok(torch.empty(1, hi - lo, 1, 1, dtype=dtype), 64, 3, 1)
+        for si in range(2):
+            x = rnd(2, hi - lo, 4, 32, seed=900 + 10 * lo + si).to(dtype).float()
+            gy = rnd(2, 64, 4, 32, seed=950 + 10 * lo + si).to(dtype).float()
+            K.conv2d_bwd_weight(dev(x, dtype), dev(gy, dtype), 3, 1, 0.3, out=parent[:, :, lo:hi, :])
+            ref_parent[:, :, lo:hi, :] += E.conv2d_bwd_weight(x, gy, 3, 1, 0.3)
+            extra += 1
+    assert K.flush_wgrad_reductions() == sum(len(l[1]) for l in layers) + extra
+    close(parent, ref_parent, rel=1e-4, name="channel-slice targets of one variable")
     for li, ((rw, rb), (gw, gb)) in enumerate(zip(want, got)):
         close(gw, rw, rel=1e-4, name=f"grouped wgrad layer {li} {layers[li]}")
         if rb is not None:
