@@ -149,6 +149,15 @@ struct ConvP {
 #define GS_TR(slot) do { } while (0)
 #endif
 
+// compile-time loop: f(std::integral_constant<int, 0>) ... f(std::integral_constant<int, N - 1>)
+template <int N, int I = 0, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<N, I + 1>(f);
+    }
+}
+
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 // one LDS-DMA piece: 64 lanes x 16 bytes -> LDS[lds_addr + 16*lane].  M0 is written and consumed inside the statement and
@@ -924,6 +933,68 @@ __global__ __launch_bounds__(192) void conv_wgrad_bf16_kernel(
     }
 }
 
+// One 16-pixel group of the 64 x 64-tile weight-gradient kernels: 9 MFMAs (3 kernel rows x 3 taps) against the gradient fragment, with the
+// OTHER work of the wave interleaved between them -- the fragment reads of the next group (2 gradient + 9 / 15 input reads), the
+// v_alignbit windows of the shifted taps, the DMA pieces of the next tile.  A wave issues in order and a 32x32x16 MFMA occupies the
+// pipe for 32 cycles, so only what is issued right behind an MFMA runs in its shadow; with the reads and the DMA issue in front of the
+// nine MFMAs of a group (round 1) the pipe idled half of the time (measured: 9.7 K cycles per 4.6 K-cycle unit).
+//   needs in scope: fb[2][2], fx[2][3][XR], acc[9], accb, do_bias, S2, S, PW, TW, NG, XR, hi, t_row, t_col, issue_piece
+#ifndef GS_WGABL_NOFRAG
+#define GS_WGABL_NOFRAG 0   // timing ablations (results wrong): no fragment reads / no DMA of the next tile / no MFMAs
+#endif
+#ifndef GS_WGABL_NODMA
+#define GS_WGABL_NODMA 0
+#endif
+#define GS_WG_GROUP_STEP(GI, MORE, XPL, GPL, NBUF)                                                                                  \
+    do {                                                                                                                            \
+        constexpr int cur_ = (GI) & 1, nxt_ = cur_ ^ 1;                                                                             \
+        constexpr bool pre_ = (GI) + 1 < NG;                                                                                        \
+        constexpr int NR_ = 2 + 3 * XR;                 /* fragment reads of the next group */                                      \
+        constexpr int RPS_ = (NR_ + 8) / 9;             /* ... per MFMA slot */                                                     \
+        const int nty_ = (((GI) + 1) * 16) / TW, ntx0_ = (((GI) + 1) * 16) % TW + 8 * hi;                                           \
+        const unsigned char* const ngp_ = (GPL) + (nty_ * TW + ntx0_ + t_row) * 64 + t_col;                                         \
+        auto next_read_ = [&](int r) __attribute__((always_inline)) {                                                               \
+            if (r < 2) { fb[nxt_][r] = lds_tr16(ngp_ + r * 4 * 64); return; }                                                       \
+            const int ky = (r - 2) / XR, k = (r - 2) % XR;                                                                          \
+            const unsigned char* xp = (XPL) + (((nty_ * S + ky) * PW + ntx0_ * S) + t_row * S) * 64 + t_col;                        \
+            const int off = !S2 ? k * 4 * 64 : (k < 3 ? k * 8 * 64 : 64 + (k - 3) * 8 * 64);                                       \
+            fx[nxt_][ky][k] = lds_tr16(xp + off);                                                                                   \
+        };                                                                                                                          \
+        auto slot_ = [&](int m) __attribute__((always_inline)) {                                                                    \
+            if (pre_ && !GS_WGABL_NOFRAG) {                                                                                         \
+                _Pragma("unroll") for (int r = m * RPS_; r < (m + 1) * RPS_ && r < NR_; ++r) next_read_(r);                         \
+            }                                                                                                                       \
+            if ((MORE) && !GS_WGABL_NODMA) {                                                                                        \
+                _Pragma("unroll") for (int q = (GI) * PPG; q < ((GI) + 1) * PPG && q < NPIECE; ++q)                                 \
+                    if ((q - (GI) * PPG) * 9 / PPG == m) issue_piece(q, NBUF);                                                      \
+            }                                                                                                                       \
+            __builtin_amdgcn_sched_barrier(0);                                                                                      \
+        };                                                                                                                          \
+        const uint2 b0_ = fb[cur_][0], b1_ = fb[cur_][1];                                                                           \
+        const bf16x8 bfrag_ = mk_frag(b0_.x, b0_.y, b1_.x, b1_.y);                                                                  \
+        if (do_bias) { add_bf16_pair(accb, b0_.x); add_bf16_pair(accb, b0_.y); add_bf16_pair(accb, b1_.x); add_bf16_pair(accb, b1_.y); } \
+        _Pragma("unroll") for (int ky = 0; ky < 3; ++ky) {                                                                          \
+            if (!S2) {                                                                                                              \
+                const uint2 d0 = fx[cur_][ky][0], d1 = fx[cur_][ky][1], d2 = fx[cur_][ky][2];                                       \
+                acc[ky * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk_frag(d0.x, d0.y, d1.x, d1.y), bfrag_, acc[ky * 3 + 0], 0, 0, 0); \
+                slot_(ky * 3 + 0);                                                                                                  \
+                acc[ky * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk_frag(shr16(d0.y, d0.x), shr16(d1.x, d0.y), shr16(d1.y, d1.x), shr16(d2.x, d1.y)), bfrag_, acc[ky * 3 + 1], 0, 0, 0); \
+                slot_(ky * 3 + 1);                                                                                                  \
+                acc[ky * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk_frag(d0.y, d1.x, d1.y, d2.x), bfrag_, acc[ky * 3 + 2], 0, 0, 0); \
+                slot_(ky * 3 + 2);                                                                                                  \
+            } else {                                                                                                                \
+                /* even columns 2(p)+0 / +2 share a 9-pixel window; odd columns 2(p)+1 are their own 8-pixel window */              \
+                const uint2 e0 = fx[cur_][ky][0], e1 = fx[cur_][ky][1], e2 = fx[cur_][ky][2], o0 = fx[cur_][ky][3], o1 = fx[cur_][ky][4]; \
+                acc[ky * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk_frag(e0.x, e0.y, e1.x, e1.y), bfrag_, acc[ky * 3 + 0], 0, 0, 0); \
+                slot_(ky * 3 + 0);                                                                                                  \
+                acc[ky * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk_frag(o0.x, o0.y, o1.x, o1.y), bfrag_, acc[ky * 3 + 1], 0, 0, 0); \
+                slot_(ky * 3 + 1);                                                                                                  \
+                acc[ky * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk_frag(shr16(e0.y, e0.x), shr16(e1.x, e0.y), shr16(e1.y, e1.x), shr16(e2.x, e1.y)), bfrag_, acc[ky * 3 + 2], 0, 0, 0); \
+                slot_(ky * 3 + 2);                                                                                                  \
+            }                                                                                                                       \
+        }                                                                                                                           \
+    } while (0)
+
 // 64 x 64 (input x output channel) tiles per block for layers with >= 64 channels on both sides: the four 32 x 32 pairs of
 // the tile share ONE staged copy of the input patch and of the gradient tile (a 32 x 32 block re-stages the patch for every
 // output tile and the gradients for every input tile: twice the L2 -> LDS stream per MFMA, and that stream is what bounds the
@@ -1073,17 +1144,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_2x2_kernel(
         const unsigned char* const xpl = lds_raw + buf * BUF + it * XPL;
         const unsigned char* const gpl = lds_raw + buf * BUF + 2 * XPL + ot * GPL;
         load_group(0, 0, xpl, gpl);
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            if (g + 1 < NG) load_group(g + 1, (g + 1) & 1, xpl, gpl);
-            if (more) {
-#pragma unroll
-                for (int q = g * PPG; q < (g + 1) * PPG && q < NPIECE; ++q) issue_piece(q, buf ^ 1);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            compute_group(g & 1);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<NG>([&](auto gc) __attribute__((always_inline)) { GS_WG_GROUP_STEP(decltype(gc)::value, more, xpl, gpl, buf ^ 1); });
         block_barrier();  // every wave is done with this buffer: the next iteration may overwrite it
         buf ^= 1;
     }
@@ -1105,8 +1167,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_2x2_kernel(
 // unit list; the pipeline (DMA of unit u+1 under the MFMAs of unit u) runs straight across run and layer boundaries -- the MFMA
 // side only sees staged LDS tiles, whatever layer they came from -- and the accumulators are flushed to partial `b + run` where the
 // block's range leaves a run.
-template <int MODE, int TW>
-__global__ __launch_bounds__(256) void conv_wgrad_bf16_2x2_sk_kernel(const SkGroup g, float* __restrict__ part) {
+// SPEC: 8 waves -- waves 0-3 multiply (fragment reads, MFMAs, flushes), waves 4-7 (one beside each on its SIMD) stage: they own the tile
+// descriptors and issue every DMA piece.  A wave issues one instruction per ~5 cycles; a group of 9 MFMAs (288 pipe cycles) leaves ~57
+// issue slots and the reads, v_alignbit windows and DMA pieces of a group need ~75: measured 145 us with everything on four waves,
+// 105 us with neither reads nor DMA (scripts/bench_wgrad_group.py with the GS_WGABL_* builds).
+template <int MODE, int TW, bool SPEC>
+__global__ __launch_bounds__(SPEC ? 512 : 256) void conv_wgrad_bf16_2x2_sk_kernel(const SkGroup g, float* __restrict__ part) {
     constexpr bool S2 = MODE == MODE_S2;
     constexpr int NP = S2 ? 64 : 256;
     constexpr int TH = NP / TW;
@@ -1123,7 +1189,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_2x2_sk_kernel(const SkGro
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wv8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = SPEC && wv8 >= 4, issuer = !SPEC || loader, computer = !SPEC || !loader;
+    const int wv = wv8 & 3;   // index within the role
     const int it = wv >> 1, ot = wv & 1;
     const int t_row = (lane & 15) >> 2;
     const int t_col = (((lane >> 4) & 1) * 16 + (lane & 3) * 4) * 2;
@@ -1163,21 +1231,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_2x2_sk_kernel(const SkGro
     int n_t = 0, by_t = 0, bx_t = 0, ox0_t = 0, xorg_t = 0;
     bool bias_next = false;
     i32x4 rs_xt = make_rsrc(g.job[0].srcs.x[0], 0), rs_gt = rs_xt;
-    auto tile_setup = [&](int j, int tile) __attribute__((always_inline)) {
+    // pixel-tile coordinates of the unit being staged, advanced incrementally (three runtime divisions per unit cost more issue
+    // slots than a group of MFMAs leaves)
+    int tx_n = 0, ty_n = 0, img_n = 0;
+    auto tile_setup = [&](int j) __attribute__((always_inline)) {
         const SkJob& q = g.job[j];
-        int b = tile;
-        const int tile_x = b % tiles_x;
-        b /= tiles_x;
-        const int tile_y = b % tiles_y;
-        const int src = wgrad_source(q.srcs, b / tiles_y, n_t);
+        const int src = wgrad_source(q.srcs, img_n, n_t);
         bias_next = bias_wave_n && ((q.srcs.bias_mask >> src) & 1u);
-        by_t = tile_y * TH;
-        bx_t = tile_x * TW;
-        const int oy0 = S2 ? 2 * by_t : by_t - 1;
-        ox0_t = S2 ? 2 * bx_t : bx_t - 1;
-        rs_xt = make_rsrc(reinterpret_cast<const unsigned char*>(q.srcs.x[src]) + (size_t)n_t * ximg, ximg);
-        rs_gt = make_rsrc(reinterpret_cast<const unsigned char*>(q.srcs.gy[src]) + (size_t)n_t * gimg, gimg);
-        xorg_t = ((oy0 * Wi + ox0_t) * IC + ic0_n) * 2;
+        if (issuer) {
+            by_t = ty_n * TH;
+            bx_t = tx_n * TW;
+            const int oy0 = S2 ? 2 * by_t : by_t - 1;
+            ox0_t = S2 ? 2 * bx_t : bx_t - 1;
+            rs_xt = make_rsrc(reinterpret_cast<const unsigned char*>(q.srcs.x[src]) + (size_t)n_t * ximg, ximg);
+            rs_gt = make_rsrc(reinterpret_cast<const unsigned char*>(q.srcs.gy[src]) + (size_t)n_t * gimg, gimg);
+            xorg_t = ((oy0 * Wi + ox0_t) * IC + ic0_n) * 2;
+        }
     };
     auto issue_piece = [&](int q, int bufi) __attribute__((always_inline)) {
         const unsigned a_x = a_base + bufi * BUF, a_g = a_x + 2 * XPL;
@@ -1186,7 +1255,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_2x2_sk_kernel(const SkGro
             const bool in = (wv + 4 * k) * 16 + (lane >> 2) < PH * PW && (unsigned)(ox0_t + x_lx[k]) < (unsigned)Wi;
             unsigned v = in ? (unsigned)(xorg_t + x_voff[k]) : 0x80000000u;
             if (pl && in) v += 64;
-            lds_dma16(a_x + pl * XPL + (wv + 4 * k) * 1024, v, rs_xt);
+            lds_dma16(__builtin_amdgcn_readfirstlane(a_x + pl * XPL + (wv + 4 * k) * 1024), v, rs_xt);
         } else {
             const int k = (q - 2 * XK) >> 1, pl = (q - 2 * XK) & 1;
             const int pix = (wv + 4 * k) * 16 + (lane >> 2);
@@ -1194,7 +1263,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_2x2_sk_kernel(const SkGro
             const bool in = gy_ < Hb && gx_ < Wb;
             unsigned v = in ? (unsigned)(((gy_ * Wb + gx_) * OC + oc0_n) * 2 + (lane & 3) * 16) : 0x80000000u;
             if (pl && in) v += 64;
-            lds_dma16(a_g + pl * GPL + (wv + 4 * k) * 1024, v, rs_gt);
+            lds_dma16(__builtin_amdgcn_readfirstlane(a_g + pl * GPL + (wv + 4 * k) * 1024), v, rs_gt);
         }
     };
 
@@ -1250,16 +1319,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_2x2_sk_kernel(const SkGro
     load_job(j_n);
     ct_n = (U0 - g.job[j_n].unit_base) / ntiles;
     tile_n = (U0 - g.job[j_n].unit_base) - ct_n * ntiles;
+    tx_n = tile_n % tiles_x;
+    ty_n = (tile_n / tiles_x) % tiles_y;
+    img_n = tile_n / (tiles_x * tiles_y);
     set_ct(j_n, ct_n);
-    tile_setup(j_n, tile_n);
+    tile_setup(j_n);
+    if (issuer) {
 #pragma unroll
-    for (int q = 0; q < NPIECE; ++q) issue_piece(q, 0);
+        for (int q = 0; q < NPIECE; ++q) issue_piece(q, 0);
+    }
 
     constexpr int PPG = (NPIECE + NG - 1) / NG;
     int buf = 0;
     for (int u = U0; u < U1; ++u) {
         const bool more = u + 1 < U1;
-        wait_vmcnt(0);
+        if (issuer) wait_vmcnt(0);
         block_barrier();
         // the unit being multiplied: what the DMA side was set to when it was issued
         do_bias = bias_next;
@@ -1267,31 +1341,40 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_2x2_sk_kernel(const SkGro
         const bool bias_wave_c = bias_wave_n;
         bool leave = !more;   // does the block's range leave the run after this unit?
         if (more) {
+            if (++tx_n == tiles_x) {
+                tx_n = 0;
+                if (++ty_n == tiles_y) { ty_n = 0; ++img_n; }
+            }
             if (++tile_n == ntiles) {
                 tile_n = 0;
+                tx_n = ty_n = img_n = 0;
                 leave = true;
                 if (++ct_n == nct) { ct_n = 0; ++j_n; load_job(j_n); }
                 set_ct(j_n, ct_n);
             }
-            tile_setup(j_n, tile_n);
+            tile_setup(j_n);
         }
         const unsigned char* const xpl = lds_raw + buf * BUF + it * XPL;
         const unsigned char* const gpl = lds_raw + buf * BUF + 2 * XPL + ot * GPL;
-        load_group(0, 0, xpl, gpl);
+        if (SPEC) {
+            if (loader) {
+                if (more) {
 #pragma unroll
-        for (int gi = 0; gi < NG; ++gi) {
-            if (gi + 1 < NG) load_group(gi + 1, (gi + 1) & 1, xpl, gpl);
-            if (more) {
-#pragma unroll
-                for (int q = gi * PPG; q < (gi + 1) * PPG && q < NPIECE; ++q) issue_piece(q, buf ^ 1);
+                    for (int q = 0; q < NPIECE; ++q) issue_piece(q, buf ^ 1);
+                }
+            } else {
+                load_group(0, 0, xpl, gpl);
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<NG>([&](auto gc) __attribute__((always_inline)) { GS_WG_GROUP_STEP(decltype(gc)::value, false, xpl, gpl, buf ^ 1); });
             }
+        } else {
+            load_group(0, 0, xpl, gpl);
             __builtin_amdgcn_sched_barrier(0);
-            compute_group(gi & 1);
-            __builtin_amdgcn_sched_barrier(0);
+            static_for<NG>([&](auto gc) __attribute__((always_inline)) { GS_WG_GROUP_STEP(decltype(gc)::value, more, xpl, gpl, buf ^ 1); });
         }
         block_barrier();
         buf ^= 1;
-        if (leave) {   // partial (block + run): [tap][ic 64][oc 64] + 64 bias sums; lane = (oc j = l31, ic i = (r&3) + 8(r>>2) + 4hi)
+        if (leave && computer) {   // partial (block + run): [tap][ic 64][oc 64] + 64 bias sums; lane = (oc j = l31, ic i = (r&3) + 8(r>>2) + 4hi)
             float* const dst0 = part + (long)(blockIdx.x + run_c) * GS_SK_PSTRIDE;
             if (bias_wave_c) {
                 const float tot = accb + __shfl_xor(accb, 32, 64);
@@ -1786,21 +1869,33 @@ int run_wgrad_sk(int mode, int tw, const SkGroup& g, void* ws, size_t ws_bytes, 
     {
         // kind 20 + mode: a GROUP of weight gradients (N = layers, Hb = tile width, Wb = blocks, IC = units, OC = runs)
         ProfScope ps(st, flops, bytes, 20 + mode, g.njobs, tw, g.nblocks, g.total_units, g.total_runs, images, 1);
-#define GS_WGSK(M, TWV)                                                                                                 \
+#define GS_WGSK(M, TWV, SP)                                                                                              \
     do {                                                                                                                \
         constexpr int np_ = (M == MODE_S2 ? 64 : 256), th_ = np_ / TWV;                                                 \
         constexpr int lds_ = 2 * (2 * ((((patch_dim<M>(th_) * patch_dim<M>(TWV) + 15) / 16 + 3) / 4) * 4096 + np_ * 64));  \
-        auto kern_ = conv_wgrad_bf16_2x2_sk_kernel<M, TWV>;                                                             \
+        auto kern_ = conv_wgrad_bf16_2x2_sk_kernel<M, TWV, SP>;                                                         \
         static bool set_ = false;                                                                                       \
         if (!set_) {                                                                                                    \
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern_), hipFuncAttributeMaxDynamicSharedMemorySize, lds_) != hipSuccess) \
                 return fail(GS_ERR_HIP, "conv wgrad group: cannot reserve %d bytes of dynamic LDS", lds_);              \
             set_ = true;                                                                                                \
         }                                                                                                               \
-        hipLaunchKernelGGL(kern_, dim3((unsigned)g.nblocks), dim3(256), lds_, st, g, part);                             \
+        hipLaunchKernelGGL(kern_, dim3((unsigned)g.nblocks), dim3(SP ? 512 : 256), lds_, st, g, part);                  \
     } while (0)
-        if (mode == MODE_S1) { if (tw == 32) GS_WGSK(MODE_S1, 32); else GS_WGSK(MODE_S1, 16); }
-        else { if (tw == 32) GS_WGSK(MODE_S2, 32); else GS_WGSK(MODE_S2, 16); }
+        // Wave-specialised variant (4 compute + 4 staging waves): OFF by default (GS_SK_SPEC=1 / 2: on for both modes / stride 1 only).
+        // Measured (scripts/bench_wgrad_group.py, the discriminator's layers, 16 images, launch + fold): stride 1 186 -> 175 us in isolation,
+        // stride 2 (bound by the L2 -> LDS rate of its 4-5x larger patch; the staging waves start a tile's DMA only after the barrier)
+        // 131 -> 168 us -- but the whole captured step LOSES 0.14 ms with the stride-1 groups specialised (6.83 -> 6.97 ms, three
+        // alternating runs on one box) although their own eager timings improve by 7-12 us: kept for measurements only.
+        static const int spec_env = getenv("GS_SK_SPEC") ? atoi(getenv("GS_SK_SPEC")) : 0;
+        const bool spec = spec_env == 1 || (spec_env == 2 && mode == MODE_S1);
+        if (spec) {
+            if (mode == MODE_S1) { if (tw == 32) GS_WGSK(MODE_S1, 32, true); else GS_WGSK(MODE_S1, 16, true); }
+            else { if (tw == 32) GS_WGSK(MODE_S2, 32, true); else GS_WGSK(MODE_S2, 16, true); }
+        } else {
+            if (mode == MODE_S1) { if (tw == 32) GS_WGSK(MODE_S1, 32, false); else GS_WGSK(MODE_S1, 16, false); }
+            else { if (tw == 32) GS_WGSK(MODE_S2, 32, false); else GS_WGSK(MODE_S2, 16, false); }
+        }
 #undef GS_WGSK
     }
     GS_CHECK_LAUNCH();
