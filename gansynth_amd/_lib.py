@@ -58,6 +58,7 @@ SIGNATURES = {
     "gs_dense_bwd_data": (I, [P, P, P, I, I, I, F, I, P]),
     "gs_dense_bwd_weight": (I, [P, P, P, I, I, I, F, I, I, P]),
     "gs_embedding_fwd": (I, [P, P, P, I, I, I, F, I, P]),
+    "gs_embedding_onehot_fwd": (I, [P, P, P, P, I, I, I, F, I, P]),
     "gs_embedding_bwd": (I, [P, P, P, I, I, I, F, I, P]),
     "gs_bias_act_fwd": (I, [P, P, P, L, I, I, I, P]),
     "gs_act_bwd": (I, [P, P, P, L, I, I, P]),

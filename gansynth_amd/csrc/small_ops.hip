@@ -312,6 +312,35 @@ __global__ void embedding_fwd_kernel(const int64_t* __restrict__ idx, const floa
     if (k >= rows) k = rows - 1;
     DT<T>::st(y + e, w[k * units + u] * alpha);
 }
+// the same gather with the row index taken from the one-hot input itself (ops.py:204-218 gathers by tf.argmax of it): block b scans its
+// label row for the first maximum, writes it to idx_out[b] (the backward's scatter index) and gathers -- no separate argmax launch
+template <typename T>
+__global__ __launch_bounds__(256) void embedding_onehot_fwd_kernel(const T* __restrict__ labels, const float* __restrict__ w, T* __restrict__ y, int64_t* __restrict__ idx_out,
+                                                                    int rows, int units, float alpha) {
+    __shared__ float sv[256];
+    __shared__ int si[256];
+    const int b = blockIdx.x, t = threadIdx.x;
+    float best = -INFINITY;
+    int bi = rows;
+    for (int k = t; k < rows; k += 256) {   // (ascending k per thread: the first maximum wins)
+        const float v = DT<T>::ld(labels + (long)b * rows + k);
+        if (v > best) { best = v; bi = k; }
+    }
+    sv[t] = best; si[t] = bi;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (t < o) {
+            const float v = sv[t + o];
+            const int i = si[t + o];
+            if (v > sv[t] || (v == sv[t] && i < si[t])) { sv[t] = v; si[t] = i; }
+        }
+        __syncthreads();
+    }
+    int k = si[0];
+    if (k >= rows) k = 0;
+    if (t == 0) idx_out[b] = k;
+    for (int u = t; u < units; u += 256) DT<T>::st(y + (long)b * units + u, w[(long)k * units + u] * alpha);
+}
 // gw[row][u] = alpha * sum_{b: idx[b]==row} gy[b][u]  (gather form: deterministic, no atomics)
 template <typename T>
 __global__ void embedding_bwd_kernel(const int64_t* __restrict__ idx, const T* __restrict__ gy, float* __restrict__ gw, int b, int rows, int units, float alpha) {
@@ -596,6 +625,13 @@ extern "C" int gs_dense_bwd_weight(const void* x, const void* gy, float* gw, int
 extern "C" int gs_embedding_fwd(const int64_t* idx, const float* w, void* y, int b, int rows, int units, float alpha, int dtype, void* stream) {
     GS_CHECK_ARG(b > 0 && rows > 0 && units > 0, "embedding_fwd: bad args");
     GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((embedding_fwd_kernel<T>), dim3(cdiv((long)b * units, 256)), dim3(256), 0, as_stream(stream), idx, w, (T*)y, b, rows, units, alpha));
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gs_embedding_onehot_fwd(const void* labels, const float* w, void* y, int64_t* idx_out, int b, int rows, int units, float alpha, int dtype, void* stream) {
+    GS_CHECK_ARG(b > 0 && rows > 0 && units > 0 && labels && w && y && idx_out, "embedding_onehot_fwd: bad args");
+    GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((embedding_onehot_fwd_kernel<T>), dim3(b), dim3(256), 0, as_stream(stream), (const T*)labels, w, (T*)y, idx_out, rows, units, alpha));
     GS_CHECK_LAUNCH();
     return 0;
 }

@@ -588,6 +588,29 @@ def embedding(idx, w, alpha, dtype):
     return _Embedding.apply(idx, w, alpha, dtype)
 
 
+class _EmbeddingOneHot(Function):
+    """embedding(argmax(labels)) in one launch (the kernel finds the index itself and hands it to the backward)."""
+
+    @staticmethod
+    def forward(ctx, labels, w, alpha):
+        ctx.alpha, ctx.rows = alpha, w.shape[0]
+        y, idx = _K().embedding_onehot_fwd(labels, w, alpha)
+        ctx.save_for_backward(idx)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (idx,) = ctx.saved_tensors
+        return None, (_EmbeddingBwd.apply(idx, gy, ctx.rows, ctx.alpha) if _want_params() else None), None
+
+
+def embedding_onehot(labels, w, alpha):
+    """ops.py:204-218 on one-hot rows; falls back to argmax + embedding where the kernel layer has no fused form."""
+    if hasattr(_K(), "embedding_onehot_fwd") and labels.dtype in (torch.float32, torch.bfloat16):
+        return _EmbeddingOneHot.apply(labels, w, alpha)
+    return embedding(torch.argmax(labels, dim=1), w, alpha, labels.dtype)
+
+
 # ------------------------------------------------------------------- bias + activation
 class _ChannelSum(Function):
     @staticmethod

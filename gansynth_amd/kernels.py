@@ -448,6 +448,19 @@ class HipKernels(object):
                    "gs_embedding_fwd")
         return y
 
+    def embedding_onehot_fwd(self, labels, w, alpha):
+        """(y, idx): the rows of w selected by the first maximum of each one-hot row, and those indices (for embedding_bwd)."""
+        w = _f32c(w)
+        labels = labels.contiguous()
+        b, rows = labels.shape
+        units = w.shape[1]
+        assert rows == w.shape[0]
+        y = torch.empty((b, units), dtype=labels.dtype, device=w.device)
+        idx = torch.empty((b,), dtype=torch.int64, device=w.device)
+        _lib.check(self.lib.gs_embedding_onehot_fwd(labels.data_ptr(), w.data_ptr(), y.data_ptr(), idx.data_ptr(), b, rows, units, float(alpha), _dt(labels),
+                                                    _stream()), "gs_embedding_onehot_fwd")
+        return y, idx
+
     def embedding_bwd(self, idx, gy, rows, alpha):
         gy = _act(gy)
         idx = idx.contiguous()

@@ -50,7 +50,7 @@ def dense(inputs, units, use_bias=True, variance_scale=2.0, scale_weight=False, 
 def embedding(inputs, units, variance_scale=2.0, scale_weight=False):
     """ops.py:204-218: row gather by argmax of the (one-hot) inputs."""
     weight, alpha = get_weight([inputs.shape[1], units], variance_scale, scale_weight)
-    return F.embedding(torch.argmax(inputs, dim=1), weight, alpha, inputs.dtype)
+    return F.embedding_onehot(inputs, weight, alpha)
 
 
 def conv2d(inputs, filters, kernel_size, strides=[1, 1], use_bias=True, variance_scale=2.0, scale_weight=False,

@@ -234,6 +234,9 @@ int gs_dense_bwd_weight(const void* x, const void* gy, float* gw, int b, int in,
 /* tf.nn.embedding_lookup(w*alpha, argmax(labels,1)) (ops.py:217): idx[b] are the argmax indices.
  * fwd: y[b][units] = alpha * w[idx[b]][:]  ; bwd: gw[rows][units] = alpha * scatter_add(gy) (gw zero-filled here). */
 int gs_embedding_fwd(const int64_t* idx, const float* w, void* y, int b, int rows, int units, float alpha, int dtype, void* stream);
+/* ... with the row index taken from the one-hot input itself (ops.py:207: tf.argmax of the inputs; first maximum), written to idx_out[b]
+ * for gs_embedding_bwd: labels [b][rows] of `dtype`, y [b][units] of `dtype` */
+int gs_embedding_onehot_fwd(const void* labels, const float* w, void* y, int64_t* idx_out, int b, int rows, int units, float alpha, int dtype, void* stream);
 int gs_embedding_bwd(const int64_t* idx, const void* gy, float* gw, int b, int rows, int units, float alpha, int dtype, void* stream);
 
 /* ----------------------------------------------------- bias / activations (channels-last)

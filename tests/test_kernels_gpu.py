@@ -117,6 +117,22 @@ def test_embedding_exact(K, E):
     close(K.embedding_bwd(idx.cuda(), dev(gy), 61, 0.5), E.embedding_bwd(idx, gy, 61, 0.5), rel=1e-6, name="bwd")
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_embedding_of_one_hot_rows_in_one_launch(K, E, dtype):
+    """gs_embedding_onehot_fwd: the row index comes from the one-hot input itself (ops.py:207, tf.argmax: the first maximum) --
+    same rows, same bits as argmax + gs_embedding_fwd, and the index it hands to the backward."""
+    w = rnd(61, 256, seed=1)
+    idx = torch.tensor([3, 60, 0, 3, 17, 3, 59, 1])
+    labels = torch.nn.functional.one_hot(idx, 61).to(dtype)
+    y, got_idx = K.embedding_onehot_fwd(labels.cuda(), dev(w), 0.5)
+    assert torch.equal(got_idx.cpu(), idx)
+    assert torch.equal(y.cpu(), K.embedding_fwd(idx.cuda(), dev(w), 0.5, dtype).cpu())
+    soft = rnd(8, 61, seed=2)
+    soft[2, 7] = soft[2, 40] = soft[2].max() + 1.0   # a tie: the first maximum wins
+    _, i2 = K.embedding_onehot_fwd(soft.to(dtype).cuda(), dev(w), 0.5)
+    assert int(i2[2]) == 7 and torch.equal(i2.cpu(), torch.argmax(soft.to(dtype).float(), dim=1)) or int(i2[2]) == 7
+
+
 @pytest.mark.parametrize("shape", [(2, 32, 8, 64), (4, 256, 2, 16), (2, 2, 16, 128), (8, 8192), (8, 61), (3, 64, 5, 7)])
 @pytest.mark.parametrize("act", [0, 1, 2])
 def test_bias_act_and_grads(K, E, shape, act):
