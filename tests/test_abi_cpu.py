@@ -50,3 +50,50 @@ def test_no_silent_fallback_without_device():
             kernels.get()
     finally:
         kernels._K = old
+
+
+def _job(_lib, ci, co, h, w, n=(8,), stride=1, transposed=0, dtype=None, ksize=3, bias=False, gw=0x1000, stride_ci=0):
+    jb = _lib.GsWgradJob()
+    for i, k in enumerate(n):
+        jb.x[i], jb.gy[i], jb.n[i] = 0x100000 * (i + 1), 0x200000 * (i + 1), k   # (never dereferenced: planning is host arithmetic)
+    jb.nsrc, jb.bias_mask, jb.gw, jb.gb = len(n), (1 if bias else 0), gw, (0x3000 if bias else None)
+    jb.h, jb.w, jb.ci, jb.co, jb.ksize, jb.stride, jb.transposed = h, w, ci, co, ksize, stride, transposed
+    jb.alpha, jb.accumulate, jb.dtype, jb.gw_ci_stride = 0.5, 1, (_lib.GS_BF16 if dtype is None else dtype), stride_ci
+    return jb
+
+
+def test_weight_gradient_job_planning_without_gpu():
+    """gs_conv_wgrad_jobs_workspace_bytes is pure host planning: the >= 64-channel bf16 layers of one conv mode share ONE set of
+    stream-K partials (blocks + runs, 147.7 KB each) whatever their number, other layers keep their per-layer partials, bad jobs
+    are refused (0 bytes + an error message)."""
+    import ctypes
+    from gansynth_amd import _lib
+    lib = _lib.load()
+
+    def nbytes(jobs):
+        arr = (_lib.GsWgradJob * len(jobs))(*jobs)
+        return lib.gs_conv_wgrad_jobs_workspace_bytes(ctypes.cast(arr, ctypes.c_void_p), len(jobs))
+
+    part = (9 * 64 * 64 + 64) * 4
+    layers = [(256, 256, 4, 32), (256, 256, 8, 64), (256, 256, 16, 128), (128, 128, 32, 256), (64, 64, 64, 512)]
+    grouped = nbytes([_job(_lib, ci, co, h, w, n=(8, 8), gw=0x1000 * (i + 1)) for i, (ci, co, h, w) in enumerate(layers)])
+    runs = sum((ci // 64) * (co // 64) for ci, co, _, _ in layers)
+    assert grouped == (256 + runs) * part                     # one group: 256 blocks + one partial per (layer, channel tile) run
+    single = sum(lib.gs_conv2d_workspace_bytes(_lib.CONV_BWD_WEIGHT, 16, h, w, ci, co, 3, 1, _lib.GS_BF16) for ci, co, h, w in layers)
+    assert grouped * 3 < single                               # ... against blocks x partial per LAYER
+    # a second conv mode is a second group, run after the first on the same workspace: the maximum, not the sum
+    both = nbytes([_job(_lib, 64, 64, 64, 512), _job(_lib, 64, 128, 64, 512, stride=2, gw=0x2000), _job(_lib, 128, 64, 32, 256, stride=2, transposed=1, gw=0x4000)])
+    assert both == max(nbytes([_job(_lib, 64, 64, 64, 512)]), nbytes([_job(_lib, 64, 128, 64, 512, stride=2), _job(_lib, 128, 64, 32, 256, stride=2, transposed=1, gw=0x4000)]))
+    # thin / fp32 / 1x1 layers: per-layer partials, added behind the group's
+    thin = nbytes([_job(_lib, 32, 32, 128, 1024)])
+    assert thin == lib.gs_conv2d_workspace_bytes(_lib.CONV_BWD_WEIGHT, 8, 128, 1024, 32, 32, 3, 1, _lib.GS_BF16)
+    assert nbytes([_job(_lib, 64, 64, 64, 512), _job(_lib, 32, 32, 128, 1024, gw=0x2000)]) == nbytes([_job(_lib, 64, 64, 64, 512)]) + thin
+    f32 = nbytes([_job(_lib, 64, 64, 8, 64, dtype=_lib.GS_F32)])
+    assert f32 == lib.gs_conv2d_workspace_bytes(_lib.CONV_BWD_WEIGHT, 8, 8, 64, 64, 64, 3, 1, _lib.GS_F32)
+    # layers without a multi-source kernel are planned one pair at a time
+    assert nbytes([_job(_lib, 1, 256, 2, 16, n=(8, 8, 8))]) == 3 * nbytes([_job(_lib, 1, 256, 2, 16)])
+    # refused: no sources, a biased transposed conv, a slice stride below the channel count
+    assert nbytes([_job(_lib, 64, 64, 8, 64, n=())]) == 0 and b"sources" in lib.gs_last_error()
+    assert nbytes([_job(_lib, 64, 64, 8, 64, stride=2, transposed=1, bias=True)]) == 0 and b"transposed" in lib.gs_last_error()
+    assert nbytes([_job(_lib, 64, 64, 8, 64, stride_ci=32)]) == 0 and b"gw_ci_stride" in lib.gs_last_error()
+    assert lib.gs_conv_wgrad_jobs(None, 0, None, 0, None) == 0
