@@ -416,6 +416,30 @@ def test_training_driver_visits_every_growing_regime_and_resumes(gpu_store, tmp_
     assert tuple(wav.shape) == (4, 1024) and torch.isfinite(wav).all()
 
 
+def test_generate_vs_oracle(gpu_store):
+    """models.py:232-250 end to end: latents + labels -> generator -> (log-mel, IF) images -> waveforms, the HIP path (MFMA convs,
+    gs_mel_if_to_waveform) against the oracle (torch-CPU generator + numpy inverse) on the same parameters.  1e-3 of the peak is
+    the contract; the phases are a cumulative sum over the frames, so image differences of 1e-5 arrive as ~1e-4."""
+    from gansynth_amd.utils import Dict
+    from oracle import spectral_np as S
+    pg, opg, model = make(1.0, gpu_store, full=False)
+    lat, lab, _ = R.synthetic_batch(4, rank=0)
+    gp, dp = opg.init_params(seed=3, bias_std=0.1)
+    model._build(cuda(lat), cuda(lab))
+    gpu_store.load_state_dict({**gp, **dp})
+    P = dict(waveform_length=1024, sample_rate=16000, spectrogram_shape=[16, 128], overlap=0.75)
+    model.spectral_params = Dict(P)
+    wav = model.generate(cuda(lat), cuda(lab)).cpu().numpy()
+    with torch.no_grad():
+        img = opg.generator(gp, lat, lab).numpy()
+    ref = S.convert_to_waveform(img[:, 0], img[:, 1], **P)
+    assert wav.shape == ref.shape == (4, 1024)
+    for a, b in zip(wav, ref):
+        scale = np.abs(b).max()
+        assert scale > 0 and np.abs(a - b).max() / scale < 1e-3, np.abs(a - b).max() / scale
+        assert S.cross_correlation(a, b) > 0.99999
+
+
 def test_hipgraph_replay_in_a_fade_in_regime(gpu_store):
     """Graphs are captured in every growing regime: the fade-in weight is read from device memory (gs_axpby_dev), so the replayed
     step follows a growing_level that changes every iteration; a regime change re-captures.  Same losses / parameters as eager
