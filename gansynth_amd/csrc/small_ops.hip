@@ -26,11 +26,13 @@ __global__ __launch_bounds__(256) void dense_fwd_kernel(const T* __restrict__ x,
 #pragma unroll
     for (int b = 0; b < DENSE_BT; ++b) acc[b] = 0.f;
     if (col < out) {
+#pragma unroll 4
         for (int i = i0 + sub; i < i1; i += 4) {
             const float wv = w[(long)i * out + col];
+            // (unconditional loads -- rows past nb re-read the last valid row, their sums are never written: a per-row `if (b < nb) load`
+            //  makes hipcc branch around every load and drain vmcnt(0) each time, 13 us for the 256 -> 61 logits layer)
 #pragma unroll
-            for (int b = 0; b < DENSE_BT; ++b)
-                if (b < nb) acc[b] += DT<T>::ld(x + (long)(b0 + b) * in + i) * wv;
+            for (int b = 0; b < DENSE_BT; ++b) acc[b] += DT<T>::ld(x + (long)(b0 + (b < nb ? b : nb - 1)) * in + i) * wv;
         }
     }
 #pragma unroll
@@ -71,11 +73,11 @@ __global__ __launch_bounds__(256) void dense_bwd_data_kernel(const T* __restrict
 #pragma unroll
     for (int b = 0; b < DENSE_BT; ++b) acc[b] = 0.f;
     const float* wr = w + (long)i * out;
+#pragma unroll 2
     for (int o = lane; o < out; o += 64) {
         const float wv = wr[o];
 #pragma unroll
-        for (int b = 0; b < DENSE_BT; ++b)
-            if (b < nb) acc[b] += DT<T>::ld(gy + (long)(b0 + b) * out + o) * wv;
+        for (int b = 0; b < DENSE_BT; ++b) acc[b] += DT<T>::ld(gy + (long)(b0 + (b < nb ? b : nb - 1)) * out + o) * wv;   // (unconditional, see dense_fwd_kernel)
     }
 #pragma unroll
     for (int b = 0; b < DENSE_BT; ++b) {
