@@ -1107,26 +1107,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_2x2_kernel(
             }
         }
     };
-    auto compute_group = [&](int fbuf) __attribute__((always_inline)) {
-        const uint2 b0 = fb[fbuf][0], b1 = fb[fbuf][1];
-        const bf16x8 bfrag = mk_frag(b0.x, b0.y, b1.x, b1.y);
-        if (do_bias) { add_bf16_pair(accb, b0.x); add_bf16_pair(accb, b0.y); add_bf16_pair(accb, b1.x); add_bf16_pair(accb, b1.y); }
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            if (!S2) {
-                const uint2 d0 = fx[fbuf][ky][0], d1 = fx[fbuf][ky][1], d2 = fx[fbuf][ky][2];
-                acc[ky * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk_frag(d0.x, d0.y, d1.x, d1.y), bfrag, acc[ky * 3 + 0], 0, 0, 0);
-                acc[ky * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk_frag(shr16(d0.y, d0.x), shr16(d1.x, d0.y), shr16(d1.y, d1.x), shr16(d2.x, d1.y)), bfrag, acc[ky * 3 + 1], 0, 0, 0);
-                acc[ky * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk_frag(d0.y, d1.x, d1.y, d2.x), bfrag, acc[ky * 3 + 2], 0, 0, 0);
-            } else {
-                // even columns 2(p)+0 / +2 share a 9-pixel window; odd columns 2(p)+1 are their own 8-pixel window
-                const uint2 e0 = fx[fbuf][ky][0], e1 = fx[fbuf][ky][1], e2 = fx[fbuf][ky][2], o0 = fx[fbuf][ky][3], o1 = fx[fbuf][ky][4];
-                acc[ky * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk_frag(e0.x, e0.y, e1.x, e1.y), bfrag, acc[ky * 3 + 0], 0, 0, 0);
-                acc[ky * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk_frag(o0.x, o0.y, o1.x, o1.y), bfrag, acc[ky * 3 + 1], 0, 0, 0);
-                acc[ky * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk_frag(shr16(e0.y, e0.x), shr16(e1.x, e0.y), shr16(e1.y, e1.x), shr16(e2.x, e1.y)), bfrag, acc[ky * 3 + 2], 0, 0, 0);
-            }
-        }
-    };
 
     int buf = 0;
     if (slice < ntiles) {
@@ -1291,25 +1271,6 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void conv_wgrad_bf16_2x2_sk_kerne
             } else {
                 fx[fbuf][ky][0] = lds_tr16(xp); fx[fbuf][ky][1] = lds_tr16(xp + 8 * 64); fx[fbuf][ky][2] = lds_tr16(xp + 16 * 64);
                 fx[fbuf][ky][3] = lds_tr16(xp + 64); fx[fbuf][ky][4] = lds_tr16(xp + 9 * 64);
-            }
-        }
-    };
-    auto compute_group = [&](int fbuf) __attribute__((always_inline)) {
-        const uint2 b0 = fb[fbuf][0], b1 = fb[fbuf][1];
-        const bf16x8 bfrag = mk_frag(b0.x, b0.y, b1.x, b1.y);
-        if (do_bias) { add_bf16_pair(accb, b0.x); add_bf16_pair(accb, b0.y); add_bf16_pair(accb, b1.x); add_bf16_pair(accb, b1.y); }
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            if (!S2) {
-                const uint2 d0 = fx[fbuf][ky][0], d1 = fx[fbuf][ky][1], d2 = fx[fbuf][ky][2];
-                acc[ky * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk_frag(d0.x, d0.y, d1.x, d1.y), bfrag, acc[ky * 3 + 0], 0, 0, 0);
-                acc[ky * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk_frag(shr16(d0.y, d0.x), shr16(d1.x, d0.y), shr16(d1.y, d1.x), shr16(d2.x, d1.y)), bfrag, acc[ky * 3 + 1], 0, 0, 0);
-                acc[ky * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk_frag(d0.y, d1.x, d1.y, d2.x), bfrag, acc[ky * 3 + 2], 0, 0, 0);
-            } else {
-                const uint2 e0 = fx[fbuf][ky][0], e1 = fx[fbuf][ky][1], e2 = fx[fbuf][ky][2], o0 = fx[fbuf][ky][3], o1 = fx[fbuf][ky][4];
-                acc[ky * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk_frag(e0.x, e0.y, e1.x, e1.y), bfrag, acc[ky * 3 + 0], 0, 0, 0);
-                acc[ky * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk_frag(o0.x, o0.y, o1.x, o1.y), bfrag, acc[ky * 3 + 1], 0, 0, 0);
-                acc[ky * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mk_frag(shr16(e0.y, e0.x), shr16(e1.x, e0.y), shr16(e1.y, e1.x), shr16(e2.x, e1.y)), bfrag, acc[ky * 3 + 2], 0, 0, 0);
             }
         }
     };
