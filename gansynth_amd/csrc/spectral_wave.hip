@@ -259,7 +259,8 @@ __global__ __launch_bounds__(64 * SW_WAVES) void stft_wave_kernel(const float* _
     float2* s_twu = reinterpret_cast<float2*>(smem + SW_LDS_TWU);
     float2* s_twc = reinterpret_cast<float2*>(smem + SW_LDS_TWC);   // [q][lane] = W_1024^(lane KPOS(q))
     float* s_hann = reinterpret_cast<float*>(smem + SW_LDS_HANN);   // w[0..1024]; w[i] = w[2048 - i] beyond
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (scalar: the run bookkeeping and its branches stay on the scalar unit)
     float2* buf = reinterpret_cast<float2*>(smem + SW_LDS_BUF) + wid * SW_BUF;
     for (int i = threadIdx.x; i < 1024; i += 64 * SW_WAVES) {
         if (SW_TABLES_IN_LDS) {
