@@ -10,13 +10,14 @@ A `tf.train.Saver` checkpoint of the reference graph (models.py:123-130) holds, 
 The TF tensor-bundle container cannot be written without TensorFlow; the same names, shapes and layouts are stored in a
 `.safetensors` file; `scripts/tf_checkpoint_convert.py` copies a TF checkpoint into that container (and back) on a machine
 that has TensorFlow -- the only format gap (INTEGRATION.md).  `optimizer_steps[_1]` is an extra key (the exponent t itself);
-a converted TF checkpoint lacks it and t is recovered from beta2_power = beta2^(t+1).  Not implemented:
-keep_checkpoint_every_n_hours=12 (models.py:127) -- only max_to_keep=10.
+a converted TF checkpoint lacks it and t is recovered from beta2_power = beta2^(t+1).
+Retention follows the reference's Saver: max_to_keep=10 and keep_checkpoint_every_n_hours=12 (models.py:126-127), see save().
 """
 import glob
 import math
 import os
 import re
+import time
 
 import torch
 
@@ -93,19 +94,36 @@ def load_state_dict(model, state, strict=True):
     return missing
 
 
-def save(model, model_dir, keep=10):
-    """`model_dir/model.ckpt-<global_step>.safetensors` (+ a `checkpoint` text file naming the latest, like tf.train.Saver);
-    keeps the newest `keep` files (max_to_keep=10, models.py:126)."""
+def save(model, model_dir, keep=10, keep_every_n_hours=12.0, now=None):
+    """`model_dir/model.ckpt-<global_step>.safetensors` (+ a `checkpoint` text file naming the latest, like tf.train.Saver).
+    Retention as tf.train.Saver(max_to_keep=10, keep_checkpoint_every_n_hours=12) (models.py:123-130): the newest `keep` files stay;
+    a file that falls out of that window is deleted UNLESS it was written later than the saver's next keep-forever time, in which
+    case it is kept for good (its name goes to `checkpoints_kept`) and that time moves `keep_every_n_hours` on.  `now`: clock
+    override for tests."""
     if save_file is None:
         raise RuntimeError("checkpoint: the safetensors package is not importable")
+    now = time.time() if now is None else now
     os.makedirs(model_dir, exist_ok=True)
     path = os.path.join(model_dir, f"model.ckpt-{model.global_step}.safetensors")
     save_file({k: v.contiguous() for k, v in state_dict(model).items()}, path)
     with open(os.path.join(model_dir, "checkpoint"), "w") as f:
         f.write(f'model_checkpoint_path: "{os.path.basename(path)}"\n')
-    old = sorted(glob.glob(os.path.join(model_dir, "model.ckpt-*.safetensors")), key=lambda p: int(re.findall(r"ckpt-(\d+)", p)[-1]))
+    saver = model.__dict__.setdefault("_saver_state", {"next_keep": now + keep_every_n_hours * 3600.0 if keep_every_n_hours else None, "times": {}})
+    saver["times"][os.path.basename(path)] = now
+    kept_file = os.path.join(model_dir, "checkpoints_kept")
+    kept = set(open(kept_file).read().split()) if os.path.exists(kept_file) else set()
+    old = sorted((p for p in glob.glob(os.path.join(model_dir, "model.ckpt-*.safetensors")) if os.path.basename(p) not in kept),
+                 key=lambda p: int(re.findall(r"ckpt-(\d+)", p)[-1]))
     for p in old[:-keep] if keep else []:
-        os.remove(p)
+        name = os.path.basename(p)
+        written = saver["times"].get(name)
+        if saver["next_keep"] is not None and written is not None and written > saver["next_keep"]:
+            kept.add(name)
+            saver["next_keep"] += keep_every_n_hours * 3600.0
+            with open(kept_file, "w") as f:
+                f.write("\n".join(sorted(kept)) + "\n")
+        else:
+            os.remove(p)
     return path
 
 

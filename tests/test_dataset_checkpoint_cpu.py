@@ -2,6 +2,7 @@
 TensorFlow) and checkpoints keyed by the reference's variable names."""
 import json
 import os
+import re
 import struct
 import wave
 
@@ -196,3 +197,27 @@ def test_checkpoint_round_trip_resumes_bit_identically(cpu_backend, tmp_path):
     assert checkpoint.load_state_dict(third, tf_like, strict=True) == []
     assert (third.g_params.t, third.d_params.t, third.global_step) == (4, 4, 4)
     assert torch.equal(third.g_params.flat, straight.g_params.flat)
+
+
+def test_checkpoint_retention_follows_the_saver(cpu_backend, tmp_path):
+    """tf.train.Saver(max_to_keep=10, keep_checkpoint_every_n_hours=12) (models.py:123-130): the newest `keep` files stay; a file
+    leaving that window survives only if it was written after the saver's next keep-forever time, which then moves 12 h on."""
+    from gansynth_amd import checkpoint, variables
+    from gansynth_amd.models import GANSynth
+    from gansynth_amd.networks import PGGAN
+    from gansynth_amd.utils import Dict
+    from oracle import torch_ref as R
+    variables.set_default_store(variables.VariableStore(device="cpu", seed=0))
+    pg = PGGAN(min_resolution=[2, 16], max_resolution=[4, 32], min_channels=8, max_channels=16, growing_level=1.0)
+    model = GANSynth(pg.generator, pg.discriminator, None, None, None, Dict(R.DEFAULT_HYPER))
+    model._build(torch.zeros(4, 16), torch.zeros(4, 5))
+    hour = 3600.0
+    for step, t in enumerate([0, 1, 2, 13, 14, 15, 16, 27], start=1):   # hours since the first save
+        model.global_step = step
+        checkpoint.save(model, str(tmp_path), keep=2, keep_every_n_hours=12.0, now=1000.0 + t * hour)
+    left = sorted(int(re.findall(r"ckpt-(\d+)", f)[-1]) for f in os.listdir(tmp_path) if f.endswith(".safetensors"))
+    # window = {7, 8}; step 4 (hour 13 > 12) was kept for good when it left the window, then the mark moved to hour 24:
+    # steps 5, 6 (hours 14, 15) were deleted; step 8 (hour 27) is still inside the window
+    assert left == [4, 7, 8], left
+    assert open(os.path.join(tmp_path, "checkpoints_kept")).read().split() == ["model.ckpt-4.safetensors"]
+    assert checkpoint.latest(str(tmp_path)).endswith("model.ckpt-8.safetensors")
