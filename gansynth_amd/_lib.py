@@ -57,6 +57,9 @@ SIGNATURES = {
     "gs_dense_fwd": (I, [P, P, P, I, I, I, F, I, P, Z, P]),
     "gs_dense_bwd_data": (I, [P, P, P, I, I, I, F, I, P]),
     "gs_dense_bwd_weight": (I, [P, P, P, I, I, I, F, I, I, P]),
+    "gs_dense_fwd_nhwc": (I, [P, P, P, I, I, I, I, F, I, P, Z, P]),
+    "gs_dense_bwd_data_nhwc": (I, [P, P, P, I, I, I, I, F, I, P]),
+    "gs_dense_bwd_weight_nhwc": (I, [P, P, P, I, I, I, I, F, I, I, P]),
     "gs_embedding_fwd": (I, [P, P, P, I, I, I, F, I, P]),
     "gs_embedding_onehot_fwd": (I, [P, P, P, P, I, I, I, F, I, P]),
     "gs_embedding_bwd": (I, [P, P, P, I, I, I, F, I, P]),

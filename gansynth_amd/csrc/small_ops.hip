@@ -128,6 +128,11 @@ __global__ __launch_bounds__(256) void dense_bwd_data_wide_kernel(const T* __res
 
 
 // ---- fast paths (vector loads; the generic kernels above remain for odd shapes) ------------------------------------
+// Input side in channels-last order (rc, rhw != 0): x / gx are the memory of a channels-last [b][hw][c] activation while the weight
+// rows follow tf.layers.flatten of NCHW (row = c * hw + p, networks.py:185-186).  Weight rows are read and written whole, so the
+// flatten is a ROW INDEX MAP inside the kernels: no NCHW copy of the activation, no copy of its gradient back.
+__device__ __forceinline__ long dense_row(int r, int rc, int rhw) { return rc ? (long)(r % rc) * rhw + r / rc : (long)r; }
+
 // batch rows per pass of the fast kernels: 8, 16 or 24 (FB template parameter) -- the discriminator's 16- and 24-row calls read the
 // weight matrix once instead of two or three times
 static int fast_rows(int b) { return b <= 8 ? 8 : (b <= 16 ? 16 : 24); }
@@ -136,7 +141,7 @@ static int fast_rows(int b) { return b <= 8 ? 8 : (b <= 16 ? 16 : 24); }
 // xor-shuffles inside a wave and through LDS across the 4 waves; with ksplit == 1 the result is written directly.
 template <typename T, int FB>
 __global__ __launch_bounds__(256) void dense_fwd_fast_kernel(const T* __restrict__ x, const float* __restrict__ w, float* __restrict__ part,
-                                                             T* __restrict__ y, int b0, int nb, int in, int out, int b_total, int ipb, float alpha) {
+                                                             T* __restrict__ y, int b0, int nb, int in, int out, int b_total, int ipb, float alpha, int rc, int rhw) {
     __shared__ float red[4][FB][32];
     const int tid = threadIdx.x;
     const int c = tid & 7, r = tid >> 3;           // column thread, row lane (0..31)
@@ -153,7 +158,7 @@ __global__ __launch_bounds__(256) void dense_fwd_fast_kernel(const T* __restrict
     for (int i = i0 + 4 * r; i < i1; i += 128) {
         float4 wv[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) wv[k] = *reinterpret_cast<const float4*>(w + (long)(i + k) * out + col);
+        for (int k = 0; k < 4; ++k) wv[k] = *reinterpret_cast<const float4*>(w + dense_row(i + k, rc, rhw) * out + col);
         // (loads are unconditional -- rows past nb re-read the last valid row and their sums are never written: a per-row
         //  `if (b < nb) load` makes hipcc branch around every load and drain vmcnt(0) each time)
 #pragma unroll
@@ -202,7 +207,7 @@ __global__ __launch_bounds__(256) void dense_fwd_fast_kernel(const T* __restrict
 // trips), 16 bytes of w per lane per pass.
 template <typename T, int WPR, int FB>
 __global__ __launch_bounds__(256) void dense_bwd_data_fast_kernel(const T* __restrict__ gy, const float* __restrict__ w, T* __restrict__ gx,
-                                                                  int b0, int nb, int in, int out, float alpha) {
+                                                                  int b0, int nb, int in, int out, float alpha, int rc, int rhw) {
     __shared__ float red[4][FB];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int i = blockIdx.x * (4 / WPR) + wv / WPR;
@@ -210,7 +215,7 @@ __global__ __launch_bounds__(256) void dense_bwd_data_fast_kernel(const T* __res
     float acc[FB];
 #pragma unroll
     for (int b = 0; b < FB; ++b) acc[b] = 0.f;
-    const float* wr = w + (long)(i < in ? i : in - 1) * out;
+    const float* wr = w + dense_row(i < in ? i : in - 1, rc, rhw) * out;
 #pragma unroll 4
     for (int o = (sub * 64 + lane) * 4; o < out; o += 256 * WPR) {
         const float4 wv = *reinterpret_cast<const float4*>(wr + o);
@@ -247,7 +252,7 @@ __global__ __launch_bounds__(256) void dense_bwd_data_fast_kernel(const T* __res
 constexpr int DENSE_WR = 16;
 template <typename T>
 __global__ __launch_bounds__(256) void dense_bwd_weight_fast_kernel(const T* __restrict__ x, const T* __restrict__ gy, float* __restrict__ gw,
-                                                                    int b, int in, int out, float alpha, int accumulate) {
+                                                                    int b, int in, int out, float alpha, int accumulate, int rc, int rhw) {
     __shared__ float xs[DENSE_BT][DENSE_WR];
     const int tid = threadIdx.x;
     const int ct = tid & 63, rl = tid >> 6;
@@ -270,7 +275,7 @@ __global__ __launch_bounds__(256) void dense_bwd_weight_fast_kernel(const T* __r
             const float xv = xs[bb][rr];
             o[0] += xv * g[bb][0]; o[1] += xv * g[bb][1]; o[2] += xv * g[bb][2]; o[3] += xv * g[bb][3];
         }
-        float4* dst = reinterpret_cast<float4*>(gw + (long)(r0 + rr) * out + col);
+        float4* dst = reinterpret_cast<float4*>(gw + dense_row(r0 + rr, rc, rhw) * out + col);
         if (accumulate) {
             const float4 old = *dst;
             o[0] += old.x; o[1] += old.y; o[2] += old.z; o[3] += old.w;
@@ -557,9 +562,11 @@ extern "C" size_t gs_dense_fwd_workspace_bytes(int b, int in, int out) {
     return (size_t)ks * b * out * sizeof(float);
 }
 
-extern "C" int gs_dense_fwd(const void* x, const float* w, void* y, int b, int in, int out, float alpha, int dtype,
-                            void* ws, size_t ws_bytes, void* stream) {
+static int dense_fwd_impl(const void* x, const float* w, void* y, int b, int in, int out, float alpha, int dtype,
+                          void* ws, size_t ws_bytes, void* stream, int rc, int rhw) {
     GS_CHECK_ARG(b > 0 && in > 0 && out > 0, "dense_fwd: bad args");
+    GS_CHECK_ARG(rc == 0 || (rc > 0 && rhw > 0 && rc * rhw == in), "dense_fwd: a %d x %d channels-last input is not %d wide", rc, rhw, in);
+    if (rc && !dense_fwd_fast_ok(in, out)) return fail(GS_ERR_UNSUPPORTED, "dense_fwd: channels-last input needs in %% 4 == 0 and out %% 32 == 0");
     int ks, ipb;
     dense_split(in, out, &ks, &ipb);
     if (ws_bytes < (size_t)ks * b * out * sizeof(float)) return fail(GS_ERR_WORKSPACE, "dense_fwd: workspace too small");
@@ -571,7 +578,7 @@ extern "C" int gs_dense_fwd(const void* x, const float* w, void* y, int b, int i
         const int nb = b - b0 < step ? b - b0 : step;
         if (fast) {
 #define GS_DFF(FBV) GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dense_fwd_fast_kernel<T, FBV>), dim3(out / 32, ks), dim3(256), 0, st, (const T*)x, w, \
-                                                                ks > 1 ? part : nullptr, (T*)y, b0, nb, in, out, b, ipb, alpha))
+                                                                ks > 1 ? part : nullptr, (T*)y, b0, nb, in, out, b, ipb, alpha, rc, rhw))
             if (step == 8) GS_DFF(8); else if (step == 16) GS_DFF(16); else GS_DFF(24);
 #undef GS_DFF
         } else {
@@ -585,15 +592,25 @@ extern "C" int gs_dense_fwd(const void* x, const float* w, void* y, int b, int i
     GS_CHECK_LAUNCH();
     return 0;
 }
+extern "C" int gs_dense_fwd(const void* x, const float* w, void* y, int b, int in, int out, float alpha, int dtype,
+                            void* ws, size_t ws_bytes, void* stream) {
+    return dense_fwd_impl(x, w, y, b, in, out, alpha, dtype, ws, ws_bytes, stream, 0, 0);
+}
+extern "C" int gs_dense_fwd_nhwc(const void* x, const float* w, void* y, int b, int c, int hw, int out, float alpha, int dtype,
+                                 void* ws, size_t ws_bytes, void* stream) {
+    return dense_fwd_impl(x, w, y, b, c * hw, out, alpha, dtype, ws, ws_bytes, stream, c, hw);
+}
 
-extern "C" int gs_dense_bwd_data(const void* gy, const float* w, void* gx, int b, int in, int out, float alpha, int dtype, void* stream) {
+static int dense_bwd_data_impl(const void* gy, const float* w, void* gx, int b, int in, int out, float alpha, int dtype, void* stream, int rc, int rhw) {
     GS_CHECK_ARG(b > 0 && in > 0 && out > 0, "dense_bwd_data: bad args");
+    GS_CHECK_ARG(rc == 0 || (rc > 0 && rhw > 0 && rc * rhw == in), "dense_bwd_data: a %d x %d channels-last input is not %d wide", rc, rhw, in);
+    if (rc && out % 256 != 0) return fail(GS_ERR_UNSUPPORTED, "dense_bwd_data: channels-last input needs out %% 256 == 0");
     hipStream_t st = as_stream(stream);
     const int step = out % 256 == 0 ? fast_rows(b) : DENSE_BT;
     for (int b0 = 0; b0 < b; b0 += step) {
         const int nb = b - b0 < step ? b - b0 : step;
         if (out % 256 == 0) {
-#define GS_DBF(WPRV, FBV, GRID) GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dense_bwd_data_fast_kernel<T, WPRV, FBV>), dim3(GRID), dim3(256), 0, st, (const T*)gy, w, (T*)gx, b0, nb, in, out, alpha))
+#define GS_DBF(WPRV, FBV, GRID) GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dense_bwd_data_fast_kernel<T, WPRV, FBV>), dim3(GRID), dim3(256), 0, st, (const T*)gy, w, (T*)gx, b0, nb, in, out, alpha, rc, rhw))
             if (in <= 1024 && out >= 1024) {   // few long rows: the whole block on one row
                 if (step == 8) GS_DBF(4, 8, in); else if (step == 16) GS_DBF(4, 16, in); else GS_DBF(4, 24, in);
             } else {
@@ -610,18 +627,33 @@ extern "C" int gs_dense_bwd_data(const void* gy, const float* w, void* gx, int b
     return 0;
 }
 
-extern "C" int gs_dense_bwd_weight(const void* x, const void* gy, float* gw, int b, int in, int out, float alpha, int accumulate, int dtype, void* stream) {
+extern "C" int gs_dense_bwd_data(const void* gy, const float* w, void* gx, int b, int in, int out, float alpha, int dtype, void* stream) {
+    return dense_bwd_data_impl(gy, w, gx, b, in, out, alpha, dtype, stream, 0, 0);
+}
+extern "C" int gs_dense_bwd_data_nhwc(const void* gy, const float* w, void* gx, int b, int c, int hw, int out, float alpha, int dtype, void* stream) {
+    return dense_bwd_data_impl(gy, w, gx, b, c * hw, out, alpha, dtype, stream, c, hw);
+}
+
+static int dense_bwd_weight_impl(const void* x, const void* gy, float* gw, int b, int in, int out, float alpha, int accumulate, int dtype, void* stream, int rc, int rhw) {
     GS_CHECK_ARG(b > 0 && in > 0 && out > 0, "dense_bwd_weight: bad args");
+    GS_CHECK_ARG(rc == 0 || (rc > 0 && rhw > 0 && rc * rhw == in), "dense_bwd_weight: a %d x %d channels-last input is not %d wide", rc, rhw, in);
+    if (rc && !(out % 256 == 0 && b <= DENSE_BT)) return fail(GS_ERR_UNSUPPORTED, "dense_bwd_weight: channels-last input needs out %% 256 == 0 and batch <= %d", DENSE_BT);
     const long n = (long)in * out;
     if (out % 256 == 0 && b <= DENSE_BT) {
         GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dense_bwd_weight_fast_kernel<T>), dim3(out / 256, cdiv(in, DENSE_WR)), dim3(256), 0, as_stream(stream),
-                                                    (const T*)x, (const T*)gy, gw, b, in, out, alpha, accumulate));
+                                                    (const T*)x, (const T*)gy, gw, b, in, out, alpha, accumulate, rc, rhw));
         GS_CHECK_LAUNCH();
         return 0;
     }
     GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dense_bwd_weight_kernel<T>), dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), (const T*)x, (const T*)gy, gw, b, in, out, alpha, accumulate));
     GS_CHECK_LAUNCH();
     return 0;
+}
+extern "C" int gs_dense_bwd_weight(const void* x, const void* gy, float* gw, int b, int in, int out, float alpha, int accumulate, int dtype, void* stream) {
+    return dense_bwd_weight_impl(x, gy, gw, b, in, out, alpha, accumulate, dtype, stream, 0, 0);
+}
+extern "C" int gs_dense_bwd_weight_nhwc(const void* x, const void* gy, float* gw, int b, int c, int hw, int out, float alpha, int accumulate, int dtype, void* stream) {
+    return dense_bwd_weight_impl(x, gy, gw, b, c * hw, out, alpha, accumulate, dtype, stream, c, hw);
 }
 
 extern "C" int gs_embedding_fwd(const int64_t* idx, const float* w, void* y, int b, int rows, int units, float alpha, int dtype, void* stream) {

@@ -131,6 +131,20 @@ class _DenseKind(object):
         return _K().dense_bwd_weight(x, gy, alpha, out=out)
 
 
+class _DenseFlatKind(object):
+    """tf.matmul on tf.layers.flatten(x) of an NCHW activation (networks.py:185-186) with x kept in channels-last memory: the three
+    maps take / return the 4-D activation, the flatten is a row map inside the kernels (gs_dense_*_nhwc)."""
+
+    def fwd(self, x, w, alpha):
+        return _K().dense_fwd_nhwc(x, w, alpha)
+
+    def bwd_data(self, gy, w, x_shape, alpha):
+        return _K().dense_bwd_data_nhwc(gy, w, x_shape, alpha)
+
+    def bwd_weight(self, x, gy, alpha, out=None):
+        return _K().dense_bwd_weight_nhwc(x, gy, alpha, out=out)
+
+
 # ---- gradients w.r.t. data only -------------------------------------------------------------------------------------------
 # tf.gradients(ys, xs) (models.py:47,60: the R1 penalty differentiates w.r.t. the real images, the mode-seeking term w.r.t. the
 # latents) only builds what xs needs.  torch.autograd.grad(..., inputs) prunes nodes, but inside a node a custom Function is
@@ -251,6 +265,8 @@ def _kind(key):
             _KINDS[key] = _ConvKind(key[1], key[2])
         elif key[0] == "convT":
             _KINDS[key] = _ConvTransposeKind()
+        elif key[0] == "dense_flat":
+            _KINDS[key] = _DenseFlatKind()
         else:
             _KINDS[key] = _DenseKind()
     return _KINDS[key]
@@ -555,6 +571,15 @@ def conv2d_transpose(x, w, alpha):
 
 def dense(x, w, alpha):
     return _Bilinear.apply(x, w, _kind(("dense",)), alpha)
+
+
+def dense_of_flattened(x, w, alpha):
+    """dense(tf.layers.flatten(x), w) for a 4-D activation: without the NCHW copy where the kernel layer can read the channels-last
+    memory directly, the plain reshape + dense otherwise."""
+    K = _K()
+    if hasattr(K, "dense_nhwc_ok") and x.dim() == 4 and K.dense_nhwc_ok(x, w.shape[1]):
+        return _Bilinear.apply(x, w, _kind(("dense_flat",)), alpha)
+    return dense(x.reshape(x.shape[0], -1), w, alpha)
 
 
 # --------------------------------------------------------------------------- embedding

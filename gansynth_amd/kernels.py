@@ -438,6 +438,42 @@ class HipKernels(object):
                                                 0 if out is None else 1, _dt(x), _stream()), "gs_dense_bwd_weight")
         return gw
 
+    # the dense layer behind tf.layers.flatten of an NCHW activation (networks.py:185-186), fed with the channels-last activation
+    # itself: x is [n, c, h, w] in channels-last memory, w stays [c * h * w, out] in the reference's row order
+    @staticmethod
+    def dense_nhwc_ok(x, out, batch_for_weight=None):
+        if os.environ.get("GS_NO_DENSE_NHWC"):   # measurement knob: the flatten copy + the plain kernels
+            return False
+        return x.dim() == 4 and x.is_contiguous(memory_format=CL) and out % 256 == 0 and (x.shape[1] * x.shape[2] * x.shape[3]) % 4 == 0 and x.shape[0] <= 16
+
+    def dense_fwd_nhwc(self, x, w, alpha):
+        x, w = _act(x), _f32c(w)
+        b, c, h, wd = x.shape
+        o = w.shape[1]
+        y = torch.empty((b, o), dtype=x.dtype, device=x.device)
+        ws = _ws(self.lib.gs_dense_fwd_workspace_bytes(b, c * h * wd, o), x.device)
+        _lib.check(self.lib.gs_dense_fwd_nhwc(x.data_ptr(), w.data_ptr(), y.data_ptr(), b, c, h * wd, o, float(alpha), _dt(x),
+                                              ws.data_ptr(), ws.numel(), _stream()), "gs_dense_fwd_nhwc")
+        return y
+
+    def dense_bwd_data_nhwc(self, gy, w, x_shape, alpha):
+        gy, w = _act(gy), _f32c(w)
+        b, c, h, wd = x_shape
+        o = gy.shape[1]
+        gx = torch.empty((b, c, h, wd), dtype=gy.dtype, device=gy.device, memory_format=CL)
+        _lib.check(self.lib.gs_dense_bwd_data_nhwc(gy.data_ptr(), w.data_ptr(), gx.data_ptr(), b, c, h * wd, o, float(alpha), _dt(gy), _stream()),
+                   "gs_dense_bwd_data_nhwc")
+        return gx
+
+    def dense_bwd_weight_nhwc(self, x, gy, alpha, out=None):
+        x, gy = _act(x), _act(gy)
+        b, c, h, wd = x.shape
+        o = gy.shape[1]
+        gw = torch.empty((c * h * wd, o), dtype=torch.float32, device=x.device) if out is None else out
+        _lib.check(self.lib.gs_dense_bwd_weight_nhwc(x.data_ptr(), gy.data_ptr(), gw.data_ptr(), b, c, h * wd, o, float(alpha),
+                                                     0 if out is None else 1, _dt(x), _stream()), "gs_dense_bwd_weight_nhwc")
+        return gw
+
     def embedding_fwd(self, idx, w, alpha, dtype):
         w = _f32c(w)
         idx = idx.contiguous()

@@ -159,7 +159,7 @@ class PGGAN(object):
                                 F.conv2d(stddev, F.weight_slice(weight, c, c + 1), 3, 1, alpha), 1.0, 1.0)
                     x = F.bias_act(y, bias, ops._ACT["leaky_relu"])
                 with variable_scope("dense"):
-                    x = x.reshape(x.shape[0], -1)  # tf.layers.flatten of NCHW: channel-major
+                    # tf.layers.flatten of NCHW (channel-major) happens inside ops.dense (4-D input)
                     features = ops.dense(x, units=self.channels(depth - 1), use_bias=True, variance_scale=2.0,
                                          scale_weight=True, activation="leaky_relu")
                 with variable_scope("logits"):

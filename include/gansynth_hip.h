@@ -230,6 +230,15 @@ int gs_dense_fwd(const void* x, const float* w, void* y, int b, int in, int out,
 int gs_dense_bwd_data(const void* gy, const float* w, void* gx, int b, int in, int out, float alpha, int dtype, void* stream);
 int gs_dense_bwd_weight(const void* x, const void* gy, float* gw, int b, int in, int out, float alpha, int accumulate, int dtype,
                         void* stream);
+/* The same three maps with the INPUT side in channels-last memory: x / gx are the [b][hw][c] memory of an activation whose
+ * tf.layers.flatten (NCHW: column c * hw + p, networks.py:185) feeds the layer, w stays [c * hw][out] as stored.  The flatten is a
+ * row-index map inside the kernels -- no NCHW copy of the activation, no copy of its gradient back.  Vector-path shapes only
+ * (out % 256 == 0, batch <= 16 for bwd_weight; GS_ERR_UNSUPPORTED otherwise). */
+int gs_dense_fwd_nhwc(const void* x, const float* w, void* y, int b, int c, int hw, int out, float alpha, int dtype,
+                      void* ws, size_t ws_bytes, void* stream);
+int gs_dense_bwd_data_nhwc(const void* gy, const float* w, void* gx, int b, int c, int hw, int out, float alpha, int dtype, void* stream);
+int gs_dense_bwd_weight_nhwc(const void* x, const void* gy, float* gw, int b, int c, int hw, int out, float alpha, int accumulate,
+                             int dtype, void* stream);
 
 /* tf.nn.embedding_lookup(w*alpha, argmax(labels,1)) (ops.py:217): idx[b] are the argmax indices.
  * fwd: y[b][units] = alpha * w[idx[b]][:]  ; bwd: gw[rows][units] = alpha * scatter_add(gy) (gw zero-filled here). */

@@ -110,6 +110,27 @@ def test_dense(K, E, b, i, o):
     close(K.dense_bwd_weight(dev(x), dev(gy), alpha), E.dense_bwd_weight(x, gy, alpha), name="bwd_weight")
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("b,c,h,w,o", [(8, 256, 2, 16, 256), (4, 64, 2, 16, 256), (16, 256, 2, 16, 512)])
+def test_dense_of_a_flattened_channels_last_activation(K, E, b, c, h, w, o, dtype):
+    """gs_dense_*_nhwc: dense(tf.layers.flatten(x)) with x left in channels-last memory (the flatten is a row map inside the kernels)
+    -- all three maps against the plain entry points on the explicitly flattened (channel-major) copy."""
+    x4 = rnd(b, c, h, w, seed=1).to(dtype).float()
+    wt, gy = rnd(c * h * w, o, seed=2), rnd(b, o, seed=3).to(dtype).float()
+    alpha = float(np.sqrt(2.0 / (c * h * w)))
+    x_cl = dev(x4, dtype)                      # channels-last device tensor
+    assert K.dense_nhwc_ok(x_cl, o)
+    flat = x4.reshape(b, -1)                   # NCHW flatten: column c * hw + p
+    close(K.dense_fwd_nhwc(x_cl, dev(wt), alpha), E.dense_fwd(flat, wt, alpha), rel=2e-2 if dtype == torch.bfloat16 else 1e-3, name="fwd")
+    gx = K.dense_bwd_data_nhwc(dev(gy, dtype), dev(wt), (b, c, h, w), alpha)
+    assert gx.shape == (b, c, h, w) and gx.is_contiguous(memory_format=torch.channels_last)
+    close(gx.float().cpu().reshape(b, -1), E.dense_bwd_data(gy, wt, alpha), rel=2e-2 if dtype == torch.bfloat16 else 1e-3, name="bwd_data")
+    close(K.dense_bwd_weight_nhwc(x_cl, dev(gy, dtype), alpha), E.dense_bwd_weight(flat, gy, alpha), name="bwd_weight")
+    acc = torch.full((c * h * w, o), 0.5, device="cuda")
+    K.dense_bwd_weight_nhwc(x_cl, dev(gy, dtype), alpha, out=acc)
+    close(acc, E.dense_bwd_weight(flat, gy, alpha) + 0.5, name="bwd_weight +=")
+
+
 def test_embedding_exact(K, E):
     w = rnd(61, 256, seed=1)
     idx = torch.tensor([3, 60, 0, 3, 17, 3, 59, 1])
