@@ -72,6 +72,8 @@ SIGNATURES = {
     "gs_pixel_norm_fwd": (I, [P, P, L, I, F, I, P]),
     "gs_pixel_norm_bwd": (I, [P, P, P, L, I, F, I, P]),
     "gs_pixel_norm_bwd_fused": (I, [P, P, P, P, L, I, F, I, I, I, P]),
+    "gs_pixel_norm_bwd_bias_workspace_bytes": (Z, [L, I, I]),
+    "gs_pixel_norm_bwd_fused_bias": (I, [P, P, P, P, P, L, I, F, I, I, I, I, P, Z, P]),
     "gs_pixel_norm_bwd_bwd_fused": (I, [P, P, P, P, P, L, I, F, I, I, P]),
     "gs_pixel_norm_bwd_bwd": (I, [P, P, P, P, L, I, F, I, P]),
     "gs_upscale2d": (I, [P, P, I, I, I, I, I, I, F, I, P]),

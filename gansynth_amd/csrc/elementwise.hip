@@ -299,10 +299,12 @@ template <typename T, int E> __device__ inline void pn_st(T* p, const float* o) 
     if constexpr (E == Wide<T>::N) st_wide<T>(p, o);
     else st4(p, *reinterpret_cast<const float(*)[4]>(o));
 }
-template <typename T, int MODE, int E, int P, int U>
+// BS (MODE 1 only): also the per-channel sums of the written gradient as one partial row per block, bsum[block][c] -- the bias gradient
+// of the conv block that produced x (z = act(conv + bias)), folded afterwards by channel_sum_finalize: no second pass over the gradient.
+template <typename T, int MODE, int E, int P, int U, bool BS = false>
 __global__ __launch_bounds__(256) void pixel_norm_kernel(const T* __restrict__ a0, const T* __restrict__ a1, const T* __restrict__ a2,
                                                          T* __restrict__ out, long p, int c, float eps, int act, int pre,
-                                                         const T* __restrict__ addend, T* __restrict__ out2) {
+                                                         const T* __restrict__ addend, T* __restrict__ out2, float* __restrict__ bsum = nullptr) {
     // x is itself the output of an activation in the generator blocks (conv -> act -> norm), and the passes around this
     // kernel fold into it:
     //   act    (MODE 1): the result is multiplied by act'(.) through x  -> gradient w.r.t. the PRE-activation
@@ -319,6 +321,13 @@ __global__ __launch_bounds__(256) void pixel_norm_kernel(const T* __restrict__ a
     const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
     const float invc = 1.f / (float)c;
     const T* const xbase = MODE == 0 ? a0 : (MODE == 1 ? a1 : a2);
+    float bs[BS ? P : 1][BS ? E : 1];   // this lane's channels, summed over its rows
+    if (BS) {
+#pragma unroll
+        for (int k = 0; k < P; ++k)
+#pragma unroll
+            for (int e = 0; e < E; ++e) bs[k][e] = 0.f;
+    }
     auto dact = [&](int kind, float xv) __attribute__((always_inline)) {   // act'(.) through the activation output
         return kind == GS_ACT_LRELU ? (xv > 0.f ? 1.f : 0.2f) : (kind == GS_ACT_TANH ? 1.f - xv * xv : 1.f);
     };
@@ -375,6 +384,10 @@ __global__ __launch_bounds__(256) void pixel_norm_kernel(const T* __restrict__ a
 #pragma unroll
                     for (int e = 0; e < E; ++e) o[e] = (r * (av[u][k][e] - xv[u][k][e] * r * q) + ad[e]) * dact(act, xv[u][k][e]);
                     if (ok[u]) pn_st<T, E>(out + off[u] + k * L * E, o);
+                    if (BS && ok[u]) {
+#pragma unroll
+                        for (int e = 0; e < E; ++e) bs[k][e] += o[e];
+                    }
                 }
             } else {
                 float sa = 0.f, sp = 0.f, sq = 0.f;
@@ -412,6 +425,26 @@ __global__ __launch_bounds__(256) void pixel_norm_kernel(const T* __restrict__ a
                 }
             }
         }
+    }
+    if constexpr (BS) {
+        __shared__ float bred[4][P * 64 * E];   // [wave][channel]
+#pragma unroll
+        for (int k = 0; k < P; ++k)
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                float v = bs[k][e];
+                for (int o = L; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);   // the lanes that own the same channels (other rows)
+                bs[k][e] = v;
+            }
+        const int wv = threadIdx.x >> 6;
+        if (lane < L) {
+#pragma unroll
+            for (int k = 0; k < P; ++k)
+#pragma unroll
+                for (int e = 0; e < E; ++e) bred[wv][k * L * E + sub * E + e] = bs[k][e];
+        }
+        __syncthreads();
+        for (int ch = threadIdx.x; ch < c; ch += 256) bsum[(long)blockIdx.x * c + ch] = bred[0][ch] + bred[1][ch] + bred[2][ch] + bred[3][ch];
     }
 }
 
@@ -665,18 +698,23 @@ extern "C" int gs_act_bwd_bias(const void* g, const void* y, void* gx, float* gb
     return channel_sum_finalize(part, gb, nparts, c, accumulate, st);
 }
 
-template <typename T, int MODE>
+static int pixel_norm_grid(long p, int c, int wn) {
+    const int E = c % wn == 0 ? wn : 4;
+    const int vecs = c / E, L = vecs < 64 ? vecs : 64, P = vecs / L;
+    const int U = P == 1 ? 2 : 1;
+    const long rows_per_block = 4L * (64 / L) * U;
+    return ew_grid((p + rows_per_block - 1) / rows_per_block * 256);
+}
+template <typename T, int MODE, bool BS = false>
 static void pixel_norm_launch_t(const void* a0, const void* a1, const void* a2, void* out, long p, int c, float eps, int act, int pre, const void* addend,
-                                void* out2, hipStream_t st) {
+                                void* out2, hipStream_t st, float* bsum = nullptr) {
     constexpr int WN = Wide<T>::N;
     const int E = c % WN == 0 ? WN : 4;
     const int vecs = c / E, L = vecs < 64 ? vecs : 64, P = vecs / L;   // P in {1, 2, 4}
-    const int U = P == 1 ? 2 : 1;
-    const long rows_per_block = 4L * (64 / L) * U;
-    dim3 grid(ew_grid((p + rows_per_block - 1) / rows_per_block * 256));
+    dim3 grid(pixel_norm_grid(p, c, WN));
 #define GS_PN(EE, PP, UU)                                                                                                          \
-    hipLaunchKernelGGL((pixel_norm_kernel<T, MODE, EE, PP, UU>), grid, dim3(256), 0, st, (const T*)a0, (const T*)a1, (const T*)a2, (T*)out, p, c, eps, \
-                       act, pre, (const T*)addend, (T*)out2)
+    hipLaunchKernelGGL((pixel_norm_kernel<T, MODE, EE, PP, UU, BS>), grid, dim3(256), 0, st, (const T*)a0, (const T*)a1, (const T*)a2, (T*)out, p, c, eps, \
+                       act, pre, (const T*)addend, (T*)out2, bsum)
     if (E == WN) {
         if (P == 1) GS_PN(WN, 1, 2); else if (P == 2) GS_PN(WN, 2, 1); else GS_PN(WN, 4, 1);
     } else {
@@ -707,6 +745,23 @@ extern "C" int gs_pixel_norm_bwd_fused(const void* g, const void* x, const void*
                                        int dtype, void* stream) {
     GS_CHECK_ARG(pn_act_ok(pre_act) && pn_act_ok(post_act), "pixel_norm_bwd_fused: bad activation %d / %d", pre_act, post_act);
     return pixel_norm_launch(1, g, x, nullptr, gx, p, c, eps, dtype, stream, post_act, pre_act, addend);
+}
+// ... and the per-channel sums of gx on the side (gb (+)= sum over pixels: the bias gradient of the conv block that produced x)
+extern "C" size_t gs_pixel_norm_bwd_bias_workspace_bytes(int64_t p, int c, int dtype) {
+    const int nb = pixel_norm_grid((long)p, c, dtype == GS_F32 ? 4 : 8);
+    return (size_t)(nb + cdiv(nb, CS_SLAB)) * c * sizeof(float);
+}
+extern "C" int gs_pixel_norm_bwd_fused_bias(const void* g, const void* x, const void* addend, void* gx, float* gb, int64_t p, int c, float eps, int pre_act,
+                                            int post_act, int accumulate, int dtype, void* ws, size_t ws_bytes, void* stream) {
+    GS_CHECK_ARG(pn_act_ok(pre_act) && pn_act_ok(post_act), "pixel_norm_bwd_fused_bias: bad activation %d / %d", pre_act, post_act);
+    GS_CHECK_ARG(p > 0 && c >= 4 && c <= 1024 && (c & (c - 1)) == 0 && gb && g && x && gx, "pixel_norm_bwd_fused_bias: bad args (c=%d)", c);
+    if (ws_bytes < gs_pixel_norm_bwd_bias_workspace_bytes(p, c, dtype)) return fail(GS_ERR_WORKSPACE, "pixel_norm_bwd_fused_bias: workspace too small");
+    hipStream_t st = as_stream(stream);
+    float* part = (float*)ws;
+    const int nb = pixel_norm_grid((long)p, c, dtype == GS_F32 ? 4 : 8);
+    GS_DISPATCH_DTYPE(dtype, (pixel_norm_launch_t<T, 1, true>(g, x, nullptr, gx, (long)p, c, eps, post_act, pre_act, addend, nullptr, st, part)));
+    GS_CHECK_LAUNCH();
+    return channel_sum_finalize(part, gb, nb, c, accumulate, st);
 }
 extern "C" int gs_pixel_norm_bwd_bwd_fused(const void* gg, const void* g, const void* x, void* out, void* out_g, int64_t p, int c, float eps, int pre_act,
                                            int dtype, void* stream) {

@@ -481,6 +481,7 @@ class _PnActBwd(Function):
 
 
 _FUSE_NORM_EPILOGUE = not __import__("os").environ.get("GS_NO_NORM_EPILOGUE")   # A/B switch for measurements
+_NORM_BWD_BIAS = not __import__("os").environ.get("GS_NO_NORM_BWD_BIAS")      # A/B switch: bias sums inside the norm's backward
 
 
 class _ConvBiasActNorm(Function):
@@ -521,14 +522,21 @@ class _ConvBiasActNorm(Function):
             gw = _BilinearBwdWeight.apply(x, gy, ctx.kind, ctx.alpha).to(w.dtype) if want_w else None
             gb = _ChannelSum.apply(gy) if want_b else None
             return gx, gw, gb, None, None, None, None
+        tw = _accum_target(ctx.wref) if want_w else None
+        tb = _accum_target(ctx.bref) if want_b else None
+        bias_done = False
         if g_y is None:
             gy = _K().act_bwd(g_z, z, ctx.act)
+        elif tb is not None and not getattr(ctx.kind, "bias_in_wgrad", False) and _NORM_BWD_BIAS and getattr(_K(), "norm_bwd_sums_bias", False):
+            # (blocks whose weight-gradient kernel carries no bias row -- the transposed convs: the norm's backward sums its own result)
+            gy = _K().pixel_norm_bwd(g_y, z, ctx.eps, act=ctx.act, addend=g_z, bias_out=tb)
+            bias_done = True
         else:
             gy = _K().pixel_norm_bwd(g_y, z, ctx.eps, act=ctx.act, addend=g_z)
         gx = _BilinearBwdData.apply(gy, w, x.shape, ctx.kind, ctx.alpha) if ctx.needs_input_grad[0] else None
         gw = gb = None
-        tw = _accum_target(ctx.wref) if want_w else None
-        tb = _accum_target(ctx.bref) if want_b else None
+        if bias_done:
+            want_b = False
         if tw is not None and tb is not None and getattr(ctx.kind, "bias_in_wgrad", False):
             ctx.kind.bwd_weight(x, gy, ctx.alpha, out=tw, bias_out=tb)
             return gx, None, None, None, None, None, None

@@ -561,8 +561,11 @@ class HipKernels(object):
         _lib.check(self.lib.gs_pixel_norm_fwd(x.data_ptr(), y.data_ptr(), p, c, float(eps), _dt(x), _stream()), "gs_pixel_norm_fwd")
         return y
 
-    def pixel_norm_bwd(self, g, x, eps, act=0, pre_act=0, addend=None):
-        """gx = (pixel_norm_bwd(g * pre_act'(x), x) + addend) * act'(x)   (x: an activation output; see gs_pixel_norm_bwd_fused)."""
+    norm_bwd_sums_bias = True   # pixel_norm_bwd(bias_out=...) exists (functional._ConvBiasActNorm)
+
+    def pixel_norm_bwd(self, g, x, eps, act=0, pre_act=0, addend=None, bias_out=None):
+        """gx = (pixel_norm_bwd(g * pre_act'(x), x) + addend) * act'(x)   (x: an activation output; see gs_pixel_norm_bwd_fused).
+        `bias_out` (fp32 [c], contiguous): the same pass adds sum_pixels gx into it."""
         x = _act(x)
         g = _match(g, x)
         p, c = _rows_cols(x)
@@ -571,6 +574,12 @@ class HipKernels(object):
         if addend is not None:
             addend = _match(addend, x)
             ap = addend.data_ptr()
+        if bias_out is not None:
+            assert bias_out.dtype == torch.float32 and bias_out.is_contiguous() and bias_out.numel() == c
+            ws = _ws(self.lib.gs_pixel_norm_bwd_bias_workspace_bytes(p, c, _dt(x)), x.device)
+            _lib.check(self.lib.gs_pixel_norm_bwd_fused_bias(g.data_ptr(), x.data_ptr(), ap, gx.data_ptr(), bias_out.data_ptr(), p, c, float(eps), int(pre_act),
+                                                             int(act), 1, _dt(x), ws.data_ptr(), ws.numel(), _stream()), "gs_pixel_norm_bwd_fused_bias")
+            return gx
         _lib.check(self.lib.gs_pixel_norm_bwd_fused(g.data_ptr(), x.data_ptr(), ap, gx.data_ptr(), p, c, float(eps), int(pre_act), int(act), _dt(x),
                                                     _stream()), "gs_pixel_norm_bwd_fused")
         return gx

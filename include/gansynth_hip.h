@@ -279,6 +279,12 @@ int gs_pixel_norm_bwd(const void* g, const void* x, void* gx, int64_t p, int c, 
  *                  -- both gradients of a differentiated norm-backward node from one pass over gg, g, x */
 int gs_pixel_norm_bwd_fused(const void* g, const void* x, const void* addend, void* gx, int64_t p, int c, float eps, int pre_act, int post_act,
                             int dtype, void* stream);
+/* ... the same pass also sums its result over the pixels: gb[c] (+)= sum_p gx[p][c] -- the bias gradient of the block
+ * z = act(conv + bias) whose output x is (networks.py:80-87: conv_transpose -> bias -> leaky_relu -> pixel_norm); one partial row per block
+ * in ws, folded in a fixed order */
+size_t gs_pixel_norm_bwd_bias_workspace_bytes(int64_t p, int c, int dtype);
+int gs_pixel_norm_bwd_fused_bias(const void* g, const void* x, const void* addend, void* gx, float* gb, int64_t p, int c, float eps, int pre_act,
+                                 int post_act, int accumulate, int dtype, void* ws, size_t ws_bytes, void* stream);
 int gs_pixel_norm_bwd_bwd_fused(const void* gg, const void* g, const void* x, void* out, void* out_g, int64_t p, int c, float eps, int pre_act,
                                 int dtype, void* stream);
 int gs_pixel_norm_bwd_bwd(const void* gg, const void* g, const void* x, void* out, int64_t p, int c, float eps, int dtype, void* stream);

@@ -504,6 +504,26 @@ def test_pixel_norm_gradient_forms_pair_up_at_full_size(K, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(8, 32, 128, 1024), (2, 64, 16, 128), (3, 256, 4, 32), (2, 512, 2, 16)])
+def test_pixel_norm_backward_sums_its_result_for_the_bias(K, shape, dtype):
+    """gs_pixel_norm_bwd_fused_bias: the norm's backward (with the activation derivative and the second gradient folded in) also
+    adds sum_pixels of its result into the bias gradient -- the same gradient as the plain call, the same sums as gs_channel_sum
+    of it (fp32 accumulation of the unrounded values: equal to bf16 rounding of the summands)."""
+    g_ = torch.Generator(device="cuda").manual_seed(11)
+    z = torch.nn.functional.leaky_relu(torch.randn(*shape, device="cuda", generator=g_), 0.2).to(dtype).contiguous(memory_format=torch.channels_last)
+    g = torch.randn(*shape, device="cuda", generator=g_).to(dtype).contiguous(memory_format=torch.channels_last)
+    add = torch.randn(*shape, device="cuda", generator=g_).to(dtype).contiguous(memory_format=torch.channels_last)
+    plain = K.pixel_norm_bwd(g, z, 1e-8, act=1, addend=add)
+    gb = torch.full((shape[1],), 0.75, device="cuda")
+    fused = K.pixel_norm_bwd(g, z, 1e-8, act=1, addend=add, bias_out=gb)
+    assert torch.equal(plain, fused)
+    ref = plain.double().sum(dim=(0, 2, 3)) + 0.75
+    scale = float(plain.double().abs().sum(dim=(0, 2, 3)).max())
+    tol = (1e-5 if dtype == torch.float32 else 4e-3) * scale   # (bf16: the reference sums ROUNDED values, the kernel the unrounded ones)
+    assert float((gb.double() - ref).abs().max()) <= tol, (float((gb.double() - ref).abs().max()), scale)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_deferred_weight_gradient_reductions_match_immediate_ones(K, dtype):
     """Deferred weight gradients (gs_*_bwd_weight*_multi + gs_wgrad_reduce_batch): the (x, gy) pairs of a layer contracted by one
     launch and the slice partials of all layers folded together -- equal (to fp32 rounding) to one immediate call per pair,
