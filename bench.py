@@ -135,6 +135,34 @@ def spectral_bench(batch=256, iters=1000, warmup=300, cpu=True):
     return out
 
 
+def inverse_bench(batch=256, iters=50, warmup=10):
+    """(log-mel, IF) images [256, 2, 128, 1024] -> waveforms [256, 64000] (spectral_ops.py:97-149): exp / cumulative phase,
+    the pinv(mel) contraction of magnitude and phase as one fp32-MFMA GEMM (phases reach ~1e3 rad, so the contraction keeps fp32),
+    polar -> inverse FFT -> overlap-add.  The GEMM dominates: MFMA-bound."""
+    import numpy as np
+    from gansynth_amd import spectral_ops as G
+    P = dict(waveform_length=64000, sample_rate=16000, spectrogram_shape=[128, 1024], overlap=0.75)
+    rng = np.random.default_rng(4001)
+    x = torch.from_numpy(np.clip(rng.normal(0.0, 0.1, (batch, 64000)), -1, 1).astype(np.float32)).cuda()
+    img = G.convert_to_images(x, **P)
+    for _ in range(warmup):
+        G.convert_images_to_waveform(img, **P)
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        G.convert_images_to_waveform(img, **P)
+    e.record()
+    torch.cuda.synchronize()
+    ms = s.elapsed_time(e) / iters
+    flops = 2.0 * 2.0 * batch * 128 * 1024 * 1024   # [2 * batch * 128, 1024] x [1024, 1024]: magnitude and phase rows stacked
+    achieved = flops / (ms * 1e-3) / 1e12
+    return {"workload": "%d x (log-mel, IF) [2, 128, 1024] -> 64000-sample waveforms, fp32 (spectral_ops.py:97-149)" % batch,
+            "value": batch / (ms * 1e-3), "unit": "examples/sec", "ms_per_batch": ms, "dtype": "f32",
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK["f32"], "unit": "TFLOP/s", "frac": achieved / PEAK["f32"],
+                         "note": "whole call (prep + GEMM + iFFT + overlap-add) against the GEMM's algorithmic FLOPs; the GEMM alone is ~70 % of the call (profiles/r02_j_inverse_kernel_stats.md)"}}
+
+
 _KIND = {0: "conv3x3 s1", 1: "conv3x3 s2", 2: "conv3x3 transposed s2", 10: "wgrad conv3x3 s1", 11: "wgrad conv3x3 s2", 12: "wgrad transposed (as s2)"}
 
 
@@ -335,6 +363,7 @@ def main():
         }
         if world == 1 and not args.no_spectral:
             out["spectral"] = spectral_bench(cpu=not args.no_cpu_baseline)
+            out["spectral_inverse"] = inverse_bench()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
