@@ -137,8 +137,10 @@ def spectral_bench(batch=256, iters=1000, warmup=300, cpu=True):
 
 def inverse_bench(batch=256, iters=50, warmup=10):
     """(log-mel, IF) images [256, 2, 128, 1024] -> waveforms [256, 64000] (spectral_ops.py:97-149): exp / cumulative phase,
-    the pinv(mel) contraction of magnitude and phase as one fp32-MFMA GEMM (phases reach ~1e3 rad, so the contraction keeps fp32),
-    polar -> inverse FFT -> overlap-add.  The GEMM dominates: MFMA-bound."""
+    the pinv(mel) contraction of magnitude and phase as ONE GEMM at fp32 accuracy (phases reach ~1e3 rad): every operand is the exact
+    sum of three bf16 numbers and six bf16 MFMAs keep the partial products down to 2^-16 (gemm_bf16x6_kernel), then
+    polar -> inverse FFT -> overlap-add.  The GEMM dominates: MFMA-bound; `frac` prices the call against the fp32 MFMA peak the
+    contraction would otherwise run on."""
     import numpy as np
     from gansynth_amd import spectral_ops as G
     P = dict(waveform_length=64000, sample_rate=16000, spectrogram_shape=[128, 1024], overlap=0.75)
@@ -160,7 +162,7 @@ def inverse_bench(batch=256, iters=50, warmup=10):
     return {"workload": "%d x (log-mel, IF) [2, 128, 1024] -> 64000-sample waveforms, fp32 (spectral_ops.py:97-149)" % batch,
             "value": batch / (ms * 1e-3), "unit": "examples/sec", "ms_per_batch": ms, "dtype": "f32",
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK["f32"], "unit": "TFLOP/s", "frac": achieved / PEAK["f32"],
-                         "note": "whole call (prep + GEMM + iFFT + overlap-add) against the GEMM's algorithmic FLOPs; the GEMM alone is ~70 % of the call (profiles/r02_j_inverse_kernel_stats.md)"}}
+                         "note": "whole call (prep + GEMM + iFFT + overlap-add) against the GEMM's algorithmic FLOPs; the GEMM alone is ~60 % of the call (profiles/r02_q_inverse_kernel_stats.md: 864 us on the split-bf16 kernel, 1405 us on the exact-fp32 MFMA kernel of r02_j)"}}
 
 
 _KIND = {0: "conv3x3 s1", 1: "conv3x3 s2", 2: "conv3x3 transposed s2", 10: "wgrad conv3x3 s1", 11: "wgrad conv3x3 s2", 12: "wgrad transposed (as s2)"}

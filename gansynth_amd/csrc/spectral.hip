@@ -169,8 +169,20 @@ __global__ void if_unwrap_kernel(gs_spectral_plan p, const float* __restrict__ m
 
 // ------------------------------------------------------------------------------ inverse
 // images -> mel_mag = exp(lm*10.05 - 3.76), mel_phase = cumsum(IF*pi) over time (spectral_ops.py:107-111)
+// `split` (optional): the same two matrices stacked ([mel_mag; mel_phase], M = 2 x batch x time_steps rows) as three bf16 planes
+// [3][M][nbins] whose sum is the fp32 value exactly -- the A operand of gemm_bf16x6_kernel
+__device__ __forceinline__ void split3_store(unsigned short* __restrict__ split, long plane_elems, long idx, float v) {
+    const unsigned a = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)v);
+    const float r1 = v - __uint_as_float(a << 16);
+    const unsigned b = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)r1);
+    const unsigned c = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)(r1 - __uint_as_float(b << 16)));
+    split[idx] = (unsigned short)a;
+    split[plane_elems + idx] = (unsigned short)b;
+    split[2 * plane_elems + idx] = (unsigned short)c;
+}
 template <typename T>
-__global__ void inv_prep_kernel(gs_spectral_plan p, const T* __restrict__ images, float* __restrict__ mel_mag, float* __restrict__ mel_phase, int batch) {
+__global__ void inv_prep_kernel(gs_spectral_plan p, const T* __restrict__ images, float* __restrict__ mel_mag, float* __restrict__ mel_phase, int batch,
+                                unsigned short* __restrict__ split) {
     const int H = p.nbins, TT = p.time_steps;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= batch * H) return;
@@ -182,8 +194,14 @@ __global__ void inv_prep_kernel(gs_spectral_plan p, const T* __restrict__ images
         const float lm = DT<T>::ld(images + o * 2) * 10.05f + (-3.76f);
         const float fi = DT<T>::ld(images + o * 2 + 1) * 1.0f + 0.0f;
         cum += fi * pi;
-        mel_mag[o] = expf(lm);
-        mel_phase[o] = cum;
+        if (split) {
+            const long plane = 2L * batch * TT * H;
+            split3_store(split, plane, o, expf(lm));
+            split3_store(split, plane, (long)batch * TT * H + o, cum);
+        } else {
+            mel_mag[o] = expf(lm);
+            mel_phase[o] = cum;
+        }
     }
 }
 
@@ -281,6 +299,94 @@ static __global__ __launch_bounds__(256) void gemm_f32_128_kernel(const float* _
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
         }
     }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                C[(long)row * N + n0 + wn + 32 * j + l31] = acc[i][j][r];
+            }
+}
+
+// The same contraction on the bf16 MFMA with fp32-level accuracy: every fp32 operand is the exact sum of three bf16 numbers
+// (a = a1 + a2 + a3 with a1 = bf16(a), a2 = bf16(a - a1), a3 = bf16(a - a1 - a2): 24 bits of mantissa), and the product keeps the six
+// partial products down to 2^-16 of the leading one: a1 b1, a1 b2, a2 b1, a1 b3, a3 b1, a2 b2 -- each exact in the fp32 accumulator,
+// the dropped ones (a2 b3, a3 b2, a3 b3) below 2^-24.  Six v_mfma_f32_32x32x16_bf16 (2.5 PF / 6 = 417 TF/s of fp32-grade work) against
+// one fp32 MFMA (157 TF/s).  The unwrapped phases reach ~1e3 rad before cos / sin, so plain bf16 (or a two-term split) would not do.
+// A comes pre-split from inv_prep_kernel (three planes [3][M][K] bf16), B from plan creation ([3][N][K], k contiguous): the GEMM itself
+// only moves 16-byte chunks and issues MFMAs (splitting A inside the GEMM cost ~150 VALU instructions per K step and wave: measured
+// slower than the fp32 kernel).
+// 128 x 128 block tile, 4 waves of 64 x 64, K step 32; LDS rows of 32 k (64 B) padded to 80 B: conflict-free 16-byte fragment reads.
+#define GX_ROW 80
+static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_bf16x6_kernel(const unsigned short* __restrict__ Asplit, const unsigned short* __restrict__ Bsplit,
+                                                                                                               float* __restrict__ C, int M, int N, int K) {
+    __shared__ __attribute__((aligned(16))) unsigned char As[3][128][GX_ROW];
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[3][128][GX_ROW];
+    typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, hi = lane >> 5, l31 = lane & 31;
+    const int nb = N / 128;
+    const int m0 = (blockIdx.x / nb) * 128, n0 = (blockIdx.x % nb) * 128;
+    const int wm = (wv >> 1) * 64, wn = (wv & 1) * 64;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // staging: both operands are three planes of [128 rows][32 k] bf16 per step = 3 x 512 16-byte chunks each, 6 + 6 per thread
+    // (chunk c = tid + 256 j: plane c >> 9, row (c & 511) >> 2, 16-byte part c & 3); the next step's chunks wait in registers
+#define GX_SRC(BASE, LD0, ROW0, J) ((BASE) + ((long)((tid + 256 * (J)) >> 9) * (LD0) + (ROW0) + (((tid + 256 * (J)) & 511) >> 2)) * K + ((tid + 256 * (J)) & 3) * 8)
+#define GX_DST(BUF, J) (&BUF[(tid + 256 * (J)) >> 9][((tid + 256 * (J)) & 511) >> 2][((tid + 256 * (J)) & 3) * 16])
+    const unsigned short *pa0 = GX_SRC(Asplit, M, m0, 0), *pa1 = GX_SRC(Asplit, M, m0, 1), *pa2 = GX_SRC(Asplit, M, m0, 2), *pa3 = GX_SRC(Asplit, M, m0, 3),
+                         *pa4 = GX_SRC(Asplit, M, m0, 4), *pa5 = GX_SRC(Asplit, M, m0, 5);
+    const unsigned short *pb0 = GX_SRC(Bsplit, N, n0, 0), *pb1 = GX_SRC(Bsplit, N, n0, 1), *pb2 = GX_SRC(Bsplit, N, n0, 2), *pb3 = GX_SRC(Bsplit, N, n0, 3),
+                         *pb4 = GX_SRC(Bsplit, N, n0, 4), *pb5 = GX_SRC(Bsplit, N, n0, 5);
+    uint4 ra0, ra1, ra2, ra3, ra4, ra5, rb0, rb1, rb2, rb3, rb4, rb5;
+#define GX_LD(P, K0) (*reinterpret_cast<const uint4*>((P) + (K0)))
+#define GX_LOAD_STEP(K0)                                                                                                         \
+    do {                                                                                                                         \
+        ra0 = GX_LD(pa0, K0); ra1 = GX_LD(pa1, K0); ra2 = GX_LD(pa2, K0); ra3 = GX_LD(pa3, K0); ra4 = GX_LD(pa4, K0); ra5 = GX_LD(pa5, K0); \
+        rb0 = GX_LD(pb0, K0); rb1 = GX_LD(pb1, K0); rb2 = GX_LD(pb2, K0); rb3 = GX_LD(pb3, K0); rb4 = GX_LD(pb4, K0); rb5 = GX_LD(pb5, K0); \
+    } while (0)
+    GX_LOAD_STEP(0);
+    for (int k0 = 0; k0 < K; k0 += 32) {
+        __syncthreads();   // the previous step's fragment reads are done
+        *reinterpret_cast<uint4*>(GX_DST(As, 0)) = ra0; *reinterpret_cast<uint4*>(GX_DST(As, 1)) = ra1; *reinterpret_cast<uint4*>(GX_DST(As, 2)) = ra2;
+        *reinterpret_cast<uint4*>(GX_DST(As, 3)) = ra3; *reinterpret_cast<uint4*>(GX_DST(As, 4)) = ra4; *reinterpret_cast<uint4*>(GX_DST(As, 5)) = ra5;
+        *reinterpret_cast<uint4*>(GX_DST(Bs, 0)) = rb0; *reinterpret_cast<uint4*>(GX_DST(Bs, 1)) = rb1; *reinterpret_cast<uint4*>(GX_DST(Bs, 2)) = rb2;
+        *reinterpret_cast<uint4*>(GX_DST(Bs, 3)) = rb3; *reinterpret_cast<uint4*>(GX_DST(Bs, 4)) = rb4; *reinterpret_cast<uint4*>(GX_DST(Bs, 5)) = rb5;
+        __syncthreads();
+        if (k0 + 32 < K) GX_LOAD_STEP(k0 + 32);   // the next step's global loads fly under this step's MFMAs
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            bf16x8_t af[2][3], bfr[2][3];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    af[i][pl] = *reinterpret_cast<const bf16x8_t*>(&As[pl][wm + 32 * i + l31][kb * 32 + hi * 16]);
+                    bfr[i][pl] = *reinterpret_cast<const bf16x8_t*>(&Bs[pl][wn + 32 * i + l31][kb * 32 + hi * 16]);
+                }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {   // small terms first
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bfr[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[j][2], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bfr[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bfr[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[j][0], acc[i][j], 0, 0, 0);
+                }
+        }
+    }
+#undef GX_LOAD_STEP
+#undef GX_LD
+#undef GX_DST
+#undef GX_SRC
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -442,6 +548,28 @@ extern "C" int gs_spectral_plan_create(gs_spectral_plan** out, int frame_length,
     if (mel_pinv) {
         GS_HIP_OK(hipMalloc(&p->pinv, (size_t)H * H * sizeof(float)));
         GS_HIP_OK(hipMemcpy(p->pinv, mel_pinv, (size_t)H * H * sizeof(float), hipMemcpyHostToDevice));
+        // the three bf16 planes of pinv (exact: hi + mid + lo = the fp32 value), transposed to [n][k] for gemm_bf16x6_kernel
+        auto rne = [](float v) -> unsigned short {
+            unsigned u; memcpy(&u, &v, 4);
+            if ((u & 0x7f800000u) == 0x7f800000u) return (unsigned short)(u >> 16);
+            u += 0x7fffu + ((u >> 16) & 1u);
+            return (unsigned short)(u >> 16);
+        };
+        auto widen = [](unsigned short h) -> float { unsigned u = (unsigned)h << 16; float f; memcpy(&f, &u, 4); return f; };
+        std::vector<unsigned short> planes((size_t)3 * H * H);
+        for (int k = 0; k < H; ++k)
+            for (int n = 0; n < H; ++n) {
+                const float v = mel_pinv[(size_t)k * H + n];
+                const unsigned short h1 = rne(v);
+                const float r1 = v - widen(h1);
+                const unsigned short h2 = rne(r1);
+                const unsigned short h3 = rne(r1 - widen(h2));
+                planes[((size_t)0 * H + n) * H + k] = h1;
+                planes[((size_t)1 * H + n) * H + k] = h2;
+                planes[((size_t)2 * H + n) * H + k] = h3;
+            }
+        GS_HIP_OK(hipMalloc(&p->pinv_split, planes.size() * sizeof(unsigned short)));
+        GS_HIP_OK(hipMemcpy(p->pinv_split, planes.data(), planes.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
     }
     *out = p;
     return 0;
@@ -451,6 +579,7 @@ extern "C" int gs_spectral_plan_destroy(gs_spectral_plan* p) {
     if (!p) return 0;
     hipFree(p->hann); hipFree(p->inv_window); hipFree(p->tw); hipFree(p->twp); hipFree(p->mel_idx); hipFree(p->mel_val);
     if (p->pinv) hipFree(p->pinv);
+    if (p->pinv_split) hipFree(p->pinv_split);
     if (p->fast) { hipFree(p->tw1k); hipFree(p->mel_lo); hipFree(p->mel_w); }
     delete p;
     return 0;
@@ -508,7 +637,8 @@ extern "C" int gs_stft_mel_if_fwd(const gs_spectral_plan* p, const float* wave, 
 extern "C" size_t gs_mel_if_to_waveform_workspace_bytes(const gs_spectral_plan* p, int batch) {
     if (!p) return 0;
     const size_t rows = (size_t)batch * p->time_steps;
-    return (4 * rows * p->nbins + rows * p->frame_length) * sizeof(float);
+    // [mel_mag; mel_phase] (as two fp32 matrices, or as three bf16 planes of the stacked pair: 12 bytes per element pair), [mag; phase], frames
+    return (5 * rows * p->nbins + rows * p->frame_length) * sizeof(float);
 }
 
 extern "C" int gs_mel_if_to_waveform(const gs_spectral_plan* p, const void* images, int batch, int wave_len, int front_pad, float* wave,
@@ -521,14 +651,20 @@ extern "C" int gs_mel_if_to_waveform(const gs_spectral_plan* p, const void* imag
     const int H = p->nbins;
     float* mel_mag = (float*)ws;
     float* mel_ph = mel_mag + rows * H;
-    float* mag = mel_ph + rows * H;
+    float* mag = mel_mag + 3 * rows * H;
     float* ph = mag + rows * H;
     float* frames = ph + rows * H;
-    GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((inv_prep_kernel<T>), dim3(cdiv((long)batch * H, 256)), dim3(256), 0, st, *p, (const T*)images, mel_mag, mel_ph, batch));
+    static const bool no_split = getenv("GS_INVERSE_FP32_GEMM") != nullptr;   // measurement knob: the exact-fp32 MFMA kernel
+    const bool split = (2 * rows) % 128 == 0 && H % 128 == 0 && H % 32 == 0 && p->pinv_split && !no_split;
+    // (the three bf16 planes of the stacked pair take 3 x 2 x rows x H x 2 bytes = the first 3 rows x H floats of the workspace)
+    unsigned short* a_split = split ? reinterpret_cast<unsigned short*>(mel_mag) : nullptr;
+    GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((inv_prep_kernel<T>), dim3(cdiv((long)batch * H, 256)), dim3(256), 0, st, *p, (const T*)images, mel_mag, mel_ph, batch, a_split));
     GS_CHECK_LAUNCH();
     // [mel_mag; mel_phase] @ pinv(mel) -> [mag; phase]: the two contractions of spectral_ops.py:123,125 share the matrix and are
     // stacked in the workspace, so they are ONE GEMM with 2 x rows
-    if ((2 * rows) % 128 == 0 && H % 128 == 0) {
+    if (split) {
+        hipLaunchKernelGGL(gemm_bf16x6_kernel, dim3((unsigned)((2 * rows / 128) * (H / 128))), dim3(256), 0, st, a_split, p->pinv_split, mag, (int)(2 * rows), H, H);
+    } else if ((2 * rows) % 128 == 0 && H % 128 == 0) {
         hipLaunchKernelGGL(gemm_f32_128_kernel, dim3((unsigned)((2 * rows / 128) * (H / 128))), dim3(256), 0, st, mel_mag, p->pinv, mag, (int)(2 * rows), H, H);
     } else {
         dim3 gg(cdiv(H, 64), cdiv(2 * rows, 64));

@@ -11,6 +11,7 @@ struct gs_spectral_plan {
     int* mel_idx;       // [maxnz][nbins] ELL by mel column, entry-major (lanes = consecutive mel bins read consecutive words)
     float* mel_val;     // [maxnz][nbins]
     float* pinv;        // [nbins][nbins] or nullptr
+    unsigned short* pinv_split;   // [3][nbins (n)][nbins (k)] bf16: pinv = plane 0 + plane 1 + plane 2 exactly (gemm_bf16x6_kernel), or nullptr
     float* inv_window;  // [frame_length]
     // wave-per-frame path (nbins == 1024, every mel column's non-zeros form one run, run lengths per block as the kernel expects), else fast == 0
     int fast;
