@@ -360,26 +360,32 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2
         *reinterpret_cast<uint4*>(GX_DST(Bs, 3)) = rb3; *reinterpret_cast<uint4*>(GX_DST(Bs, 4)) = rb4; *reinterpret_cast<uint4*>(GX_DST(Bs, 5)) = rb5;
         __syncthreads();
         if (k0 + 32 < K) GX_LOAD_STEP(k0 + 32);   // the next step's global loads fly under this step's MFMAs
+        // fragments of k block 1 are read between the MFMAs of k block 0 (a wave issues in order: reads in front of the MFMAs of
+        // their own block leave the pipe idle for an LDS round trip per block)
+        bf16x8_t fr[2][12];   // [k block][0..5: A (row tile i, plane pl) = 3 i + pl | 6..11: B (column tile j, plane pl)]
+        auto rd = [&](int kb, int q) __attribute__((always_inline)) {
+            const int t = q % 6, i = t / 3, pl = t % 3;
+            fr[kb][q] = q < 6 ? *reinterpret_cast<const bf16x8_t*>(&As[pl][wm + 32 * i + l31][kb * 32 + hi * 16])
+                              : *reinterpret_cast<const bf16x8_t*>(&Bs[pl][wn + 32 * i + l31][kb * 32 + hi * 16]);
+        };
+#pragma unroll
+        for (int q = 0; q < 12; ++q) rd(0, q);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
-            bf16x8_t af[2][3], bfr[2][3];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) {
-                    af[i][pl] = *reinterpret_cast<const bf16x8_t*>(&As[pl][wm + 32 * i + l31][kb * 32 + hi * 16]);
-                    bfr[i][pl] = *reinterpret_cast<const bf16x8_t*>(&Bs[pl][wn + 32 * i + l31][kb * 32 + hi * 16]);
-                }
+                for (int j = 0; j < 2; ++j) {
+                    // (a1 + a2 + a3)(b1 + b2 + b3) down to 2^-16: small terms first
+                    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {   // small terms first
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bfr[j][0], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[j][2], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bfr[j][1], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bfr[j][0], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[j][1], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[j][0], acc[i][j], 0, 0, 0);
+                    for (int t = 0; t < 6; ++t) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[kb][3 * i + PA[t]], fr[kb][6 + 3 * j + PB[t]], acc[i][j], 0, 0, 0);
+                        const int slot = (i * 2 + j) * 6 + t;   // 24 MFMAs of the block: one read of the next block after every second one
+                        if (kb == 0 && (slot & 1) == 1) rd(1, slot >> 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
         }
     }
