@@ -677,8 +677,13 @@ extern "C" int gs_mel_if_to_waveform(const gs_spectral_plan* p, const void* imag
         hipLaunchKernelGGL(gemm_f32_kernel, gg, dim3(256), 0, st, mel_mag, p->pinv, mag, (int)(2 * rows), H, H);
     }
     GS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(istft_kernel, dim3(p->time_steps, batch), dim3(256), 0, st, *p, mag, ph, frames);
-    GS_CHECK_LAUNCH();
+    static const bool no_wave = getenv("GS_INVERSE_BLOCK_FFT") != nullptr;   // measurement knob: the block-per-frame radix-2 kernel
+    if (p->fast && H == 1024 && !no_wave) {
+        if (int e = launch_istft_wave(p, mag, ph, frames, rows, st)) return e;
+    } else {
+        hipLaunchKernelGGL(istft_kernel, dim3(p->time_steps, batch), dim3(256), 0, st, *p, mag, ph, frames);
+        GS_CHECK_LAUNCH();
+    }
     hipLaunchKernelGGL(overlap_add_kernel, dim3(cdiv((long)batch * wave_len, 256)), dim3(256), 0, st, *p, frames, wave, batch, wave_len, front_pad);
     GS_CHECK_LAUNCH();
     return 0;

@@ -143,10 +143,9 @@ __device__ __forceinline__ void load_frame(const float* __restrict__ wv, int wav
     }
 }
 
-// One frame: windowed samples v (consumed) -> buf[k] = (|X[k]|, arg X[k]) for bins k = 1..1024 (this wave's LDS buffer).
-//   s_twc: W_1024^(lane * KPOS(q)) as [q][lane];  s_twf: W_64^k (k < 64);  s_twu: W_2048^k (k < 512), all in LDS
-__device__ __forceinline__ void frame_to_magphase(float2 (&v)[16], const float2* s_twc, const float2* s_twf, const float2 (&twu)[8],
-                                                  float2* buf, int lane) {
+// 1024-point forward DFT of one wave: v[j] = z[lane + 64 j] (consumed) -> Z[k] in this wave's LDS buffer at P(k) = k + 4 (k >> 8).
+//   s_twc: W_1024^(lane * KPOS(q)) as [q][lane];  s_twf: W_64^k (k < 64), both in LDS
+__device__ __forceinline__ void fft1024_to_lds(float2 (&v)[16], const float2* s_twc, const float2* s_twf, float2* buf, int lane) {
     // B: DFT over j, twiddle W_1024^(l k1)
     dft16(v);
 #pragma unroll
@@ -193,6 +192,13 @@ __device__ __forceinline__ void frame_to_magphase(float2 (&v)[16], const float2*
 #pragma unroll
         for (int q = 0; q < 16; ++q) dst[16 * KPOS(q)] = v[q];
     }
+}
+
+// One frame: windowed samples v (consumed) -> buf[k] = (|X[k]|, arg X[k]) for bins k = 1..1024 (this wave's LDS buffer).
+//   s_twu: W_2048^k (k < 512) in LDS, the lane's eight in twu
+__device__ __forceinline__ void frame_to_magphase(float2 (&v)[16], const float2* s_twc, const float2* s_twf, const float2 (&twu)[8],
+                                                  float2* buf, int lane) {
+    fft1024_to_lds(v, s_twc, s_twf, buf, lane);
     // I: untangle the packed real FFT on pairs (ka, 1024 - ka), ka = lane + 64 i; (mag, phase) of bin k goes to buf[k], in
     // place over Z.  Half A (i = 4..7) reads P in [260, 780] and writes [256, 511] + [513, 768]; half B (i = 0..3) reads
     // [0, 255] + [781, 1035] + P(0), untouched by A's writes, and writes [1, 255] + 512 + [769, 1024].  Within a half every
@@ -432,6 +438,128 @@ static int set_lds(KernT kern, size_t bytes) {
     if (bytes > 65536 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
         return fail(GS_ERR_HIP, "stft_wave: cannot reserve %zu bytes of LDS", bytes);
     done = true;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ inverse
+// (magnitude, phase) [frames][1024] -> windowed time frames [frames][2048] (spectral_ops.py:128-149 before the overlap-add): the same
+// wave-per-frame machinery run backwards.  irfft of the 1025-bin spectrum X (DC = 0, X[k] = mag e^{i phase}) as a packed 1024-point
+// complex transform: Z[k] = E[k] + i W_2048^{-k} D[k] with E / D the half sum / half difference of X[k] and conj X[1024 - k];
+// z = IFFT(Z) = conj(FFT(conj Z)) reuses fft1024_to_lds; frame[2n] = Re z[n], frame[2n+1] = Im z[n], times 1/1024 and the inverse
+// window.  A lane builds Z on the pairs (ka, 1024 - ka), ka = lane + 64 i -- its own FFT inputs for i < 8 -- and hands the upper
+// half to the lanes that need it through the wave's LDS buffer.
+//
+// sin / cos of phases that reach ~1e3 rad: three-constant Cody-Waite reduction by pi/2 (each step one exact fma) and the Cephes
+// single-precision polynomials on [-pi/4, pi/4]: 1e-7 absolute for |x| < 1e4, ~25 instructions for the pair.
+__device__ __forceinline__ void sincos_reduced(float x, float& sn, float& cs) {
+    const float k = __builtin_rintf(x * 0.63661977236758138f);
+    float r = fmaf(-k, 1.57079637050628662f, x);       // fl(pi/2)
+    r = fmaf(-k, -4.371138828673793e-08f, r);          // fl(pi/2 - fl(pi/2))
+    r = fmaf(-k, -1.7151245100058819e-15f, r);         // and the next 24 bits
+    const float s = r * r;
+    float ps = -1.9515295891e-4f;
+    ps = fmaf(ps, s, 8.3321608736e-3f);
+    ps = fmaf(ps, s, -1.6666654611e-1f);
+    const float sr = fmaf(r * s, ps, r);
+    float pc = 2.443315711809948e-5f;
+    pc = fmaf(pc, s, -1.388731625493765e-3f);
+    pc = fmaf(pc, s, 4.166664568298827e-2f);
+    pc = fmaf(pc, s, -0.5f);
+    const float cr = fmaf(pc, s, 1.0f);
+    const int q = (int)k & 3;
+    const float a = (q & 1) ? cr : sr, b = (q & 1) ? sr : cr;   // q odd: sin <- cos, cos <- sin
+    sn = (q & 2) ? -a : a;
+    cs = ((q + 1) & 2) ? -b : b;
+}
+
+#define SWI_LDS_TWF 0
+#define SWI_LDS_TWC (SWI_LDS_TWF + 64 * 8)
+#define SWI_LDS_WIN (SWI_LDS_TWC + 16 * 64 * 8)
+#define SWI_LDS_BUF (SWI_LDS_WIN + 2048 * 4)
+#define SWI_LDS_TOTAL (SWI_LDS_BUF + SW_WAVES * SW_BUF * 8)
+
+__global__ __launch_bounds__(64 * SW_WAVES) void istft_wave_kernel(const float2* __restrict__ tw1k, const float2* __restrict__ twp, const float* __restrict__ inv_window,
+                                                                   const float* __restrict__ mag, const float* __restrict__ phase, float* __restrict__ frames,
+                                                                   long nframes) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2* s_twf = reinterpret_cast<float2*>(smem + SWI_LDS_TWF);
+    float2* s_twc = reinterpret_cast<float2*>(smem + SWI_LDS_TWC);
+    float* s_win = reinterpret_cast<float*>(smem + SWI_LDS_WIN);
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float2* buf = reinterpret_cast<float2*>(smem + SWI_LDS_BUF) + wid * SW_BUF;
+    for (int i = threadIdx.x; i < 2048; i += 64 * SW_WAVES) {
+        s_win[i] = inv_window[i] * (1.0f / 1024.0f);   // (x 1/1024: the transform below is unnormalised)
+        if (i < 64) s_twf[i] = tw1k[16 * i];
+        if (i < 1024) s_twc[i] = tw1k[(i & 63) * KPOS(i >> 6)];
+    }
+    __syncthreads();   // the only block-level barrier
+    float2 twu[8];     // e^{+2 pi i ka / 2048}, ka = lane + 64 i
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { const float2 t = twp[lane + 64 * i]; twu[i] = make_float2(t.x, -t.y); }
+    for (long f = (long)blockIdx.x * SW_WAVES + wid; f < nframes; f += (long)gridDim.x * SW_WAVES) {
+        const float* mg = mag + f * 1024;     // bin k at index k - 1
+        const float* ph = phase + f * 1024;
+        float2 v[16];
+        float ma[8], pa[8], mb[8], pb[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int ka = lane + 64 * i;
+            const bool dc = i == 0 && lane == 0;   // ka = 0: X[0] = 0, its partner is the Nyquist bin (real part only)
+            ma[i] = dc ? 0.f : mg[ka - 1 + (dc ? 1 : 0)];
+            pa[i] = dc ? 0.f : ph[ka - 1 + (dc ? 1 : 0)];
+            mb[i] = mg[1023 - ka];
+            pb[i] = ph[1023 - ka];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int ka = lane + 64 * i;
+            const bool dc = i == 0 && lane == 0;
+            float sa, ca, sb, cb;
+            sincos_reduced(pa[i], sa, ca);
+            sincos_reduced(pb[i], sb, cb);
+            const float2 xk = make_float2(ma[i] * ca, ma[i] * sa);                       // X[ka]
+            const float2 xc = make_float2(mb[i] * cb, dc ? 0.f : mb[i] * sb);            // X[1024 - ka]
+            const float2 w = twu[i];
+            // Z[ka] = E + i W D,  E = (X[ka] + conj X[1024-ka]) / 2,  D = (X[ka] - conj X[1024-ka]) / 2
+            const float2 e = make_float2(0.5f * (xk.x + xc.x), 0.5f * (xk.y - xc.y));
+            const float2 d = make_float2(0.5f * (xk.x - xc.x), 0.5f * (xk.y + xc.y));
+            const float2 o = cmulw(w, d);
+            v[i] = make_float2(e.x - o.y, -(e.y + o.x));                                  // conj Z[ka]: this lane's input m = ka
+            // Z[1024 - ka]: the roles of the two bins swap, W_2048^{-(1024 - ka)} = -conj(W_2048^{-ka})
+            const float2 e2 = make_float2(e.x, -e.y);
+            const float2 d2 = make_float2(-d.x, d.y);
+            const float2 o2 = cmulw(make_float2(-w.x, w.y), d2);
+            if (!dc) buf[1024 - ka] = make_float2(e2.x - o2.y, -(e2.y + o2.x));            // conj Z[kb], natural order (no bin 1024)
+        }
+        if (lane == 0) {   // Z[512] = conj X[512]: its own partner
+            float s5, c5;
+            sincos_reduced(ph[511], s5, c5);
+            buf[512] = make_float2(mg[511] * c5, mg[511] * s5);                           // conj Z[512] = X[512]
+        }
+#pragma unroll
+        for (int j = 8; j < 16; ++j) v[j] = lds_ld(buf + lane + 64 * j);
+        __builtin_amdgcn_sched_barrier(0);
+        fft1024_to_lds(v, s_twc, s_twf, buf, lane);                                      // U = FFT(conj Z) at P(k)
+        float* fr = frames + f * 2048;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int n = lane + 64 * i;
+            const float2 u = lds_ld(buf + n + 4 * (n >> 8));
+            const float2 wn = *reinterpret_cast<const float2*>(s_win + 2 * n);
+            *reinterpret_cast<float2*>(fr + 2 * n) = make_float2(u.x * wn.x, -u.y * wn.y);   // z[n] = conj U[n]
+        }
+    }
+}
+
+int launch_istft_wave(const gs_spectral_plan* p, const float* mag, const float* phase, float* frames, long nframes, hipStream_t st) {
+    auto kern = istft_wave_kernel;
+    if (int e = set_lds(kern, SWI_LDS_TOTAL)) return e;
+    long blocks = (nframes + SW_WAVES - 1) / SW_WAVES;
+    if (blocks > 256) blocks = 256;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * SW_WAVES), SWI_LDS_TOTAL, st, (const float2*)p->tw1k, (const float2*)p->twp, (const float*)p->inv_window,
+                       mag, phase, frames, nframes);
+    GS_CHECK_LAUNCH();
     return 0;
 }
 
