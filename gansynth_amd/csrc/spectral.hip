@@ -678,6 +678,9 @@ extern "C" int gs_mel_if_to_waveform(const gs_spectral_plan* p, const void* imag
     }
     GS_CHECK_LAUNCH();
     static const bool no_wave = getenv("GS_INVERSE_BLOCK_FFT") != nullptr;   // measurement knob: the block-per-frame radix-2 kernel
+    static const bool no_ola = getenv("GS_INVERSE_SEPARATE_OLA") != nullptr;   // measurement knob: frames through memory + the gather kernel
+    if (p->fast && H == 1024 && !no_wave && !no_ola && istft_wave_ola_ok(p, wave_len, front_pad))
+        return launch_istft_wave_ola(p, mag, ph, wave, batch, wave_len, front_pad, st);   // overlap-add and crop inside: done
     if (p->fast && H == 1024 && !no_wave) {
         if (int e = launch_istft_wave(p, mag, ph, frames, rows, st)) return e;
     } else {

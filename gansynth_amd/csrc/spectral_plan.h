@@ -30,6 +30,8 @@ size_t stft_wave_edge_bytes(const gs_spectral_plan* p, int batch);
 int launch_stft_wave_fused(const gs_spectral_plan* p, const float* wave, int batch, int wave_len, int front_pad, void* images, int dtype,
                            void* ws, size_t ws_bytes, hipStream_t st);
 int launch_istft_wave(const gs_spectral_plan* p, const float* mag, const float* phase, float* frames, long nframes, hipStream_t st);
+bool istft_wave_ola_ok(const gs_spectral_plan* p, int wave_len, int front_pad);
+int launch_istft_wave_ola(const gs_spectral_plan* p, const float* mag, const float* phase, float* wave, int batch, int wave_len, int front_pad, hipStream_t st);
 int launch_stft_wave_magphase(const gs_spectral_plan* p, const float* wave, int batch, int wave_len, int front_pad, float* mag, float* phase,
                               hipStream_t st);
 }  // namespace gs

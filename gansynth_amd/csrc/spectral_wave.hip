@@ -478,9 +478,17 @@ __device__ __forceinline__ void sincos_reduced(float x, float& sn, float& cs) {
 #define SWI_LDS_BUF (SWI_LDS_WIN + 2048 * 4)
 #define SWI_LDS_TOTAL (SWI_LDS_BUF + SW_WAVES * SW_BUF * 8)
 
+// OLA: the overlap-add (hop 512 = a quarter frame) and the front-padding crop happen here too, frames never reach memory.  Block =
+// example, wave w = run w of its frames (SW_WAVES runs).  A lane keeps the running sum of the current 2048-sample window as 16
+// sample pairs (n = lane + 64 i); a hop moves a pair from slot i to slot i - 4 of the SAME lane, so after adding frame t the four
+// lowest slots are the finished segment t.  The first three segments of a run still miss the previous run's frames: they wait in
+// registers until the wave on the left has parked the three unfinished segments of ITS window in its (now idle) LDS buffer -- a fixed
+// two-term sum, no atomics, no pre-zeroed output.
+#define SWI_LDS_FLAG SWI_LDS_TOTAL
+template <bool OLA>
 __global__ __launch_bounds__(64 * SW_WAVES) void istft_wave_kernel(const float2* __restrict__ tw1k, const float2* __restrict__ twp, const float* __restrict__ inv_window,
                                                                    const float* __restrict__ mag, const float* __restrict__ phase, float* __restrict__ frames,
-                                                                   long nframes) {
+                                                                   long nframes, int TT, float* __restrict__ wave, int wave_len, int front_pad) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2* s_twf = reinterpret_cast<float2*>(smem + SWI_LDS_TWF);
     float2* s_twc = reinterpret_cast<float2*>(smem + SWI_LDS_TWC);
@@ -493,11 +501,36 @@ __global__ __launch_bounds__(64 * SW_WAVES) void istft_wave_kernel(const float2*
         if (i < 64) s_twf[i] = tw1k[16 * i];
         if (i < 1024) s_twc[i] = tw1k[(i & 63) * KPOS(i >> 6)];
     }
+    volatile int* s_flag = reinterpret_cast<volatile int*>(smem + SWI_LDS_FLAG);
+    if (OLA && threadIdx.x < 16) s_flag[threadIdx.x] = 0;
     __syncthreads();   // the only block-level barrier
     float2 twu[8];     // e^{+2 pi i ka / 2048}, ka = lane + 64 i
 #pragma unroll
     for (int i = 0; i < 8; ++i) { const float2 t = twp[lane + 64 * i]; twu[i] = make_float2(t.x, -t.y); }
-    for (long f = (long)blockIdx.x * SW_WAVES + wid; f < nframes; f += (long)gridDim.x * SW_WAVES) {
+    // OLA: run wid of example blockIdx.x, frames [t0, t1) (the first TT % SW_WAVES runs have one frame more); else a grid-stride walk
+    const int rq = TT / SW_WAVES, rrem = TT % SW_WAVES;
+    const int t0 = OLA ? wid * rq + min(wid, rrem) : 0;
+    const int t1 = OLA ? t0 + rq + (wid < rrem ? 1 : 0) : 0;
+    float2 acc[16], head[12];
+    if (OLA) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) head[i] = make_float2(0.f, 0.f);
+    }
+    float* const wv_out = OLA ? wave + (long)blockIdx.x * wave_len : nullptr;
+    auto store_segment = [&](int h, const float2& a, const float2& b, const float2& c, const float2& d) __attribute__((always_inline)) {
+        const float2 q[4] = {a, b, c, d};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int sidx = h * 512 + 2 * (lane + 64 * i) - front_pad;   // (front_pad and wave_len are even: a pair never straddles the crop)
+            if (sidx >= 0 && sidx < wave_len) *reinterpret_cast<float2*>(wv_out + sidx) = q[i];
+        }
+    };
+    const long f_begin = OLA ? (long)blockIdx.x * TT + t0 : (long)blockIdx.x * SW_WAVES + wid;
+    const long f_end = OLA ? (long)blockIdx.x * TT + t1 : nframes;
+    const long f_step = OLA ? 1 : (long)gridDim.x * SW_WAVES;
+    for (long f = f_begin; f < f_end; f += f_step) {
         const float* mg = mag + f * 1024;     // bin k at index k - 1
         const float* ph = phase + f * 1024;
         float2 v[16];
@@ -541,24 +574,80 @@ __global__ __launch_bounds__(64 * SW_WAVES) void istft_wave_kernel(const float2*
         for (int j = 8; j < 16; ++j) v[j] = lds_ld(buf + lane + 64 * j);
         __builtin_amdgcn_sched_barrier(0);
         fft1024_to_lds(v, s_twc, s_twf, buf, lane);                                      // U = FFT(conj Z) at P(k)
-        float* fr = frames + f * 2048;
+        float* fr = OLA ? nullptr : frames + f * 2048;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int n = lane + 64 * i;
             const float2 u = lds_ld(buf + n + 4 * (n >> 8));
             const float2 wn = *reinterpret_cast<const float2*>(s_win + 2 * n);
-            *reinterpret_cast<float2*>(fr + 2 * n) = make_float2(u.x * wn.x, -u.y * wn.y);   // z[n] = conj U[n]
+            const float2 val = make_float2(u.x * wn.x, -u.y * wn.y);   // z[n] = conj U[n]
+            if (OLA) { acc[i].x += val.x; acc[i].y += val.y; }
+            else *reinterpret_cast<float2*>(fr + 2 * n) = val;
+        }
+        if (OLA) {
+            const int t = (int)(f - (long)blockIdx.x * TT), k = t - t0;
+            if (t0 > 0 && k < 3) {   // still missing the left neighbour's frames
+#pragma unroll
+                for (int kk = 0; kk < 3; ++kk)
+                    if (k == kk) { head[4 * kk] = acc[0]; head[4 * kk + 1] = acc[1]; head[4 * kk + 2] = acc[2]; head[4 * kk + 3] = acc[3]; }
+            } else {
+                store_segment(t, acc[0], acc[1], acc[2], acc[3]);
+            }
+#pragma unroll
+            for (int i = 0; i < 12; ++i) acc[i] = acc[i + 4];
+#pragma unroll
+            for (int i = 12; i < 16; ++i) acc[i] = make_float2(0.f, 0.f);
+        }
+    }
+    if (OLA) {
+        // the three unfinished segments t1 .. t1 + 2 of this run's window: final for the last run, else parked for the wave on the right
+        if (t1 >= TT) {
+#pragma unroll
+            for (int g = 0; g < 3; ++g) store_segment(t1 + g, acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 12; ++i) buf[64 * i + lane] = acc[i];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) s_flag[wid] = 1;
+        }
+        if (t0 > 0) {
+            while (s_flag[wid - 1] == 0) __builtin_amdgcn_s_sleep(4);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const float2* left = reinterpret_cast<const float2*>(smem + SWI_LDS_BUF) + (wid - 1) * SW_BUF;
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                float2 q[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float2 l = left[64 * (4 * g + i) + lane];
+                    q[i] = make_float2(head[4 * g + i].x + l.x, head[4 * g + i].y + l.y);
+                }
+                store_segment(t0 + g, q[0], q[1], q[2], q[3]);
+            }
         }
     }
 }
 
 int launch_istft_wave(const gs_spectral_plan* p, const float* mag, const float* phase, float* frames, long nframes, hipStream_t st) {
-    auto kern = istft_wave_kernel;
-    if (int e = set_lds(kern, SWI_LDS_TOTAL)) return e;
+    auto kern = istft_wave_kernel<false>;
+    if (int e = set_lds(kern, SWI_LDS_TOTAL + 64)) return e;
     long blocks = (nframes + SW_WAVES - 1) / SW_WAVES;
     if (blocks > 256) blocks = 256;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * SW_WAVES), SWI_LDS_TOTAL, st, (const float2*)p->tw1k, (const float2*)p->twp, (const float*)p->inv_window,
-                       mag, phase, frames, nframes);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * SW_WAVES), SWI_LDS_TOTAL + 64, st, (const float2*)p->tw1k, (const float2*)p->twp,
+                       (const float*)p->inv_window, mag, phase, frames, nframes, 0, (float*)nullptr, 0, 0);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+// frames of a whole example per block, overlap-add and crop included: needs >= 3 frames per run and even crop offsets
+bool istft_wave_ola_ok(const gs_spectral_plan* p, int wave_len, int front_pad) {
+    return p->frame_length == 2048 && p->frame_step == 512 && p->time_steps >= 3 * SW_WAVES && (wave_len & 1) == 0 && (front_pad & 1) == 0;
+}
+int launch_istft_wave_ola(const gs_spectral_plan* p, const float* mag, const float* phase, float* wave, int batch, int wave_len, int front_pad, hipStream_t st) {
+    auto kern = istft_wave_kernel<true>;
+    if (int e = set_lds(kern, SWI_LDS_TOTAL + 64)) return e;
+    hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(64 * SW_WAVES), SWI_LDS_TOTAL + 64, st, (const float2*)p->tw1k, (const float2*)p->twp,
+                       (const float*)p->inv_window, mag, phase, (float*)nullptr, (long)batch * p->time_steps, p->time_steps, wave, wave_len, front_pad);
     GS_CHECK_LAUNCH();
     return 0;
 }
