@@ -265,11 +265,12 @@ static __global__ __launch_bounds__(256) void gemm_f32_128_kernel(const float* _
     const int b_row = tid >> 5, b_col = (tid & 31) * 4;
     const float* ap = A + (long)(m0 + a_row) * K + 4 * a_kq;
     const float* bp = B + (long)b_row * N + n0 + b_col;
-    float4 ra[2], rb[2];
+    typedef float f4_t __attribute__((ext_vector_type(4)));   // (native vectors: arrays of HIP's float4 struct stay in memory)
+    f4_t ra[2], rb[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        ra[i] = *reinterpret_cast<const float4*>(ap + (long)(64 * i) * K);
-        rb[i] = *reinterpret_cast<const float4*>(bp + (long)(8 * i) * N);
+        ra[i] = *reinterpret_cast<const f4_t*>(ap + (long)(64 * i) * K);
+        rb[i] = *reinterpret_cast<const f4_t*>(bp + (long)(8 * i) * N);
     }
     for (int k0 = 0; k0 < K; k0 += 16) {
         __syncthreads();   // the previous step's fragment reads are done
@@ -279,14 +280,14 @@ static __global__ __launch_bounds__(256) void gemm_f32_128_kernel(const float* _
             As[4 * a_kq + 1][a_row + 64 * i] = ra[i].y;
             As[4 * a_kq + 2][a_row + 64 * i] = ra[i].z;
             As[4 * a_kq + 3][a_row + 64 * i] = ra[i].w;
-            *reinterpret_cast<float4*>(&Bs[b_row + 8 * i][b_col]) = rb[i];
+            *reinterpret_cast<f4_t*>(&Bs[b_row + 8 * i][b_col]) = rb[i];
         }
         __syncthreads();
         if (k0 + 16 < K) {   // the next step's global loads fly under this step's MFMAs
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                ra[i] = *reinterpret_cast<const float4*>(ap + (long)(64 * i) * K + k0 + 16);
-                rb[i] = *reinterpret_cast<const float4*>(bp + (long)(k0 + 16 + 8 * i) * N);
+                ra[i] = *reinterpret_cast<const f4_t*>(ap + (long)(64 * i) * K + k0 + 16);
+                rb[i] = *reinterpret_cast<const f4_t*>(bp + (long)(k0 + 16 + 8 * i) * N);
             }
         }
 #pragma unroll
@@ -320,88 +321,101 @@ static __global__ __launch_bounds__(256) void gemm_f32_128_kernel(const float* _
 // slower than the fp32 kernel).
 // 128 x 128 block tile, 4 waves of 64 x 64, K step 32; LDS rows of 32 k (64 B) padded to 80 B: conflict-free 16-byte fragment reads.
 #define GX_ROW 80
-static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_bf16x6_kernel(const unsigned short* __restrict__ Asplit, const unsigned short* __restrict__ Bsplit,
-                                                                                                               float* __restrict__ C, int M, int N, int K) {
+// Block tile 128 x (64 NJ): NJ = 2 -> 128 x 128, two blocks per CU; NJ = 4 -> 128 x 256, one block per CU (92 KB of LDS) and half
+// the passes over A, the big operand (6 bytes per element: with 128 x 128 tiles the kernel moved 6.4 GB through L2 in its 0.85 ms).
+template <int NJ>
+static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NJ == 4 ? 1 : 2, NJ == 4 ? 1 : 2)))
+void gemm_bf16x6_kernel(const unsigned short* __restrict__ Asplit, const unsigned short* __restrict__ Bsplit, float* __restrict__ C, int M, int N, int K) {
+    constexpr int BN = 64 * NJ;            // block columns; a wave owns 64 rows x (32 NJ) columns
+    constexpr int BCH = 3 * BN * 4 / 256;  // 16-byte chunks of B per thread and step
     __shared__ __attribute__((aligned(16))) unsigned char As[3][128][GX_ROW];
-    __shared__ __attribute__((aligned(16))) unsigned char Bs[3][128][GX_ROW];
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[3][BN][GX_ROW];
     typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, hi = lane >> 5, l31 = lane & 31;
-    const int nb = N / 128;
-    const int m0 = (blockIdx.x / nb) * 128, n0 = (blockIdx.x % nb) * 128;
-    const int wm = (wv >> 1) * 64, wn = (wv & 1) * 64;
-    f32x16 acc[2][2];
+    const int nb = N / BN;
+    const int m0 = (blockIdx.x / nb) * 128, n0 = (blockIdx.x % nb) * BN;
+    const int wm = (wv >> 1) * 64, wn = (wv & 1) * (32 * NJ);
+    f32x16 acc[2][NJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    // staging: both operands are three planes of [128 rows][32 k] bf16 per step = 3 x 512 16-byte chunks each, 6 + 6 per thread
-    // (chunk c = tid + 256 j: plane c >> 9, row (c & 511) >> 2, 16-byte part c & 3); the next step's chunks wait in registers
-#define GX_SRC(BASE, LD0, ROW0, J) ((BASE) + ((long)((tid + 256 * (J)) >> 9) * (LD0) + (ROW0) + (((tid + 256 * (J)) & 511) >> 2)) * K + ((tid + 256 * (J)) & 3) * 8)
-#define GX_DST(BUF, J) (&BUF[(tid + 256 * (J)) >> 9][((tid + 256 * (J)) & 511) >> 2][((tid + 256 * (J)) & 3) * 16])
-    const unsigned short *pa0 = GX_SRC(Asplit, M, m0, 0), *pa1 = GX_SRC(Asplit, M, m0, 1), *pa2 = GX_SRC(Asplit, M, m0, 2), *pa3 = GX_SRC(Asplit, M, m0, 3),
-                         *pa4 = GX_SRC(Asplit, M, m0, 4), *pa5 = GX_SRC(Asplit, M, m0, 5);
-    const unsigned short *pb0 = GX_SRC(Bsplit, N, n0, 0), *pb1 = GX_SRC(Bsplit, N, n0, 1), *pb2 = GX_SRC(Bsplit, N, n0, 2), *pb3 = GX_SRC(Bsplit, N, n0, 3),
-                         *pb4 = GX_SRC(Bsplit, N, n0, 4), *pb5 = GX_SRC(Bsplit, N, n0, 5);
-    uint4 ra0, ra1, ra2, ra3, ra4, ra5, rb0, rb1, rb2, rb3, rb4, rb5;
-#define GX_LD(P, K0) (*reinterpret_cast<const uint4*>((P) + (K0)))
-#define GX_LOAD_STEP(K0)                                                                                                         \
-    do {                                                                                                                         \
-        ra0 = GX_LD(pa0, K0); ra1 = GX_LD(pa1, K0); ra2 = GX_LD(pa2, K0); ra3 = GX_LD(pa3, K0); ra4 = GX_LD(pa4, K0); ra5 = GX_LD(pa5, K0); \
-        rb0 = GX_LD(pb0, K0); rb1 = GX_LD(pb1, K0); rb2 = GX_LD(pb2, K0); rb3 = GX_LD(pb3, K0); rb4 = GX_LD(pb4, K0); rb5 = GX_LD(pb5, K0); \
-    } while (0)
-    GX_LOAD_STEP(0);
+    // staging: three planes of [rows][32 k] bf16 per operand and step, as 16-byte chunks (chunk c: plane c / (4 rows), row (c % (4 rows)) >> 2,
+    // part c & 3); the next step's chunks wait in registers
+    // (plain unrolled code on purpose: pointer arrays and conditionally updated register arrays end up in scratch / promoted LDS)
+    typedef unsigned u4_t __attribute__((ext_vector_type(4)));   // (native vectors: arrays of HIP's uint4 struct stay in memory)
+    u4_t ra[6], rb[BCH];
+    const unsigned short* const abase = Asplit + (long)m0 * K;
+    const unsigned short* const bbase = Bsplit + (long)n0 * K;
+#define GX_AOFF(J) (((long)((tid + 256 * (J)) / 512) * M + (((tid + 256 * (J)) % 512) >> 2)) * K + ((tid + 256 * (J)) & 3) * 8)
+#define GX_BOFF(J) (((long)((tid + 256 * (J)) / (4 * BN)) * N + (((tid + 256 * (J)) % (4 * BN)) >> 2)) * K + ((tid + 256 * (J)) & 3) * 8)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) ra[j] = *reinterpret_cast<const u4_t*>(abase + GX_AOFF(j));
+#pragma unroll
+    for (int j = 0; j < BCH; ++j) rb[j] = *reinterpret_cast<const u4_t*>(bbase + GX_BOFF(j));
     for (int k0 = 0; k0 < K; k0 += 32) {
         __syncthreads();   // the previous step's fragment reads are done
-        *reinterpret_cast<uint4*>(GX_DST(As, 0)) = ra0; *reinterpret_cast<uint4*>(GX_DST(As, 1)) = ra1; *reinterpret_cast<uint4*>(GX_DST(As, 2)) = ra2;
-        *reinterpret_cast<uint4*>(GX_DST(As, 3)) = ra3; *reinterpret_cast<uint4*>(GX_DST(As, 4)) = ra4; *reinterpret_cast<uint4*>(GX_DST(As, 5)) = ra5;
-        *reinterpret_cast<uint4*>(GX_DST(Bs, 0)) = rb0; *reinterpret_cast<uint4*>(GX_DST(Bs, 1)) = rb1; *reinterpret_cast<uint4*>(GX_DST(Bs, 2)) = rb2;
-        *reinterpret_cast<uint4*>(GX_DST(Bs, 3)) = rb3; *reinterpret_cast<uint4*>(GX_DST(Bs, 4)) = rb4; *reinterpret_cast<uint4*>(GX_DST(Bs, 5)) = rb5;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int c = tid + 256 * j;
+            *reinterpret_cast<u4_t*>(&As[c / 512][(c % 512) >> 2][(c & 3) * 16]) = ra[j];
+        }
+#pragma unroll
+        for (int j = 0; j < BCH; ++j) {
+            const int c = tid + 256 * j;
+            *reinterpret_cast<u4_t*>(&Bs[c / (4 * BN)][(c % (4 * BN)) >> 2][(c & 3) * 16]) = rb[j];
+        }
         __syncthreads();
-        if (k0 + 32 < K) GX_LOAD_STEP(k0 + 32);   // the next step's global loads fly under this step's MFMAs
+        {   // the next step's global loads fly under this step's MFMAs (the last step re-reads its own: unconditional)
+            const int kn = k0 + 32 < K ? k0 + 32 : k0;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) ra[j] = *reinterpret_cast<const u4_t*>(abase + GX_AOFF(j) + kn);
+#pragma unroll
+            for (int j = 0; j < BCH; ++j) rb[j] = *reinterpret_cast<const u4_t*>(bbase + GX_BOFF(j) + kn);
+        }
         // fragments of k block 1 are read between the MFMAs of k block 0 (a wave issues in order: reads in front of the MFMAs of
         // their own block leave the pipe idle for an LDS round trip per block)
-        bf16x8_t fr[2][12];   // [k block][0..5: A (row tile i, plane pl) = 3 i + pl | 6..11: B (column tile j, plane pl)]
+        constexpr int NF = 6 + 3 * NJ;   // fragments of a k block: A (row tile i, plane pl) = 3 i + pl | B (column tile j, plane pl) = 6 + 3 j + pl
+        bf16x8_t fr[2][NF];
         auto rd = [&](int kb, int q) __attribute__((always_inline)) {
-            const int t = q % 6, i = t / 3, pl = t % 3;
+            const int t = q < 6 ? q : q - 6, i = t / 3, pl = t % 3;
             fr[kb][q] = q < 6 ? *reinterpret_cast<const bf16x8_t*>(&As[pl][wm + 32 * i + l31][kb * 32 + hi * 16])
                               : *reinterpret_cast<const bf16x8_t*>(&Bs[pl][wn + 32 * i + l31][kb * 32 + hi * 16]);
         };
 #pragma unroll
-        for (int q = 0; q < 12; ++q) rd(0, q);
+        for (int q = 0; q < NF; ++q) rd(0, q);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
+            // (a1 + a2 + a3)(b1 + b2 + b3) down to 2^-16, small terms first; the term loop is the OUTER one so that consecutive MFMAs go to
+            // different accumulators (six in a row into one accumulator wait for each other's result)
+            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int t = 0; t < 6; ++t)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    // (a1 + a2 + a3)(b1 + b2 + b3) down to 2^-16: small terms first
-                    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int t = 0; t < 6; ++t) {
+                    for (int j = 0; j < NJ; ++j) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[kb][3 * i + PA[t]], fr[kb][6 + 3 * j + PB[t]], acc[i][j], 0, 0, 0);
-                        const int slot = (i * 2 + j) * 6 + t;   // 24 MFMAs of the block: one read of the next block after every second one
-                        if (kb == 0 && (slot & 1) == 1) rd(1, slot >> 1);
+                        const int slot = (t * 2 + i) * NJ + j;   // 12 NJ MFMAs of the block: one read of the next block after every second one
+                        if (kb == 0 && (slot & 1) == 1 && (slot >> 1) < NF) rd(1, slot >> 1);
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                }
         }
     }
-#undef GX_LOAD_STEP
-#undef GX_LD
-#undef GX_DST
-#undef GX_SRC
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hi;
                 C[(long)row * N + n0 + wn + 32 * j + l31] = acc[i][j][r];
             }
+#undef GX_AOFF
+#undef GX_BOFF
 }
 
 // one workgroup per (frame, example): spectrum from (mag, phase), DC = 0 (spectral_ops.py:128-131), packed inverse
@@ -669,7 +683,13 @@ extern "C" int gs_mel_if_to_waveform(const gs_spectral_plan* p, const void* imag
     // [mel_mag; mel_phase] @ pinv(mel) -> [mag; phase]: the two contractions of spectral_ops.py:123,125 share the matrix and are
     // stacked in the workspace, so they are ONE GEMM with 2 x rows
     if (split) {
-        hipLaunchKernelGGL(gemm_bf16x6_kernel, dim3((unsigned)((2 * rows / 128) * (H / 128))), dim3(256), 0, st, a_split, p->pinv_split, mag, (int)(2 * rows), H, H);
+        // 128 x 128 tiles, two blocks per CU (GS_INVERSE_GEMM_256: 128 x 256 tiles, one block per CU -- half the passes over A, but
+        // measured 1 % SLOWER: the kernel is not L2-bound, it sits at the ~0.95 PFLOP/s every bf16 MFMA kernel of this build reaches)
+        static const bool wide = getenv("GS_INVERSE_GEMM_256") != nullptr;
+        if (H % 256 == 0 && wide)
+            hipLaunchKernelGGL(gemm_bf16x6_kernel<4>, dim3((unsigned)((2 * rows / 128) * (H / 256))), dim3(256), 0, st, a_split, p->pinv_split, mag, (int)(2 * rows), H, H);
+        else
+            hipLaunchKernelGGL(gemm_bf16x6_kernel<2>, dim3((unsigned)((2 * rows / 128) * (H / 128))), dim3(256), 0, st, a_split, p->pinv_split, mag, (int)(2 * rows), H, H);
     } else if ((2 * rows) % 128 == 0 && H % 128 == 0) {
         hipLaunchKernelGGL(gemm_f32_128_kernel, dim3((unsigned)((2 * rows / 128) * (H / 128))), dim3(256), 0, st, mel_mag, p->pinv, mag, (int)(2 * rows), H, H);
     } else {
