@@ -162,7 +162,8 @@ def inverse_bench(batch=256, iters=50, warmup=10):
     return {"workload": "%d x (log-mel, IF) [2, 128, 1024] -> 64000-sample waveforms, fp32 (spectral_ops.py:97-149)" % batch,
             "value": batch / (ms * 1e-3), "unit": "examples/sec", "ms_per_batch": ms, "dtype": "f32",
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK["f32"], "unit": "TFLOP/s", "frac": achieved / PEAK["f32"],
-                         "note": "whole call (prep + GEMM + iFFT + overlap-add) against the GEMM's algorithmic FLOPs; the GEMM alone is ~80 % of the call (profiles/r02_q_inverse_kernel_stats.md; ~860 us on the split-bf16 kernel, ~1090 us on the exact-fp32 MFMA kernel)"}}
+                         "executed_bf16_tflops": 4.5 * achieved, "executed_bf16_frac": 4.5 * achieved / PEAK["bf16"],
+                         "note": "whole call (prep + GEMM + iFFT + overlap-add) against the GEMM's algorithmic FLOPs and the fp32 MFMA peak; the contraction runs on the bf16 MFMA as partial products of bf16 splits (six for the phase rows, three for the magnitude rows: 4.5 bf16 MFMAs per algorithmic one = executed_bf16_*); the two GEMM launches are ~73 % of the call (profiles/r02_t_inverse_kernel_stats.md: 394 + 222 us; 758 us with six terms everywhere, ~1090 us on the exact-fp32 MFMA kernel)"}}
 
 
 _KIND = {0: "conv3x3 s1", 1: "conv3x3 s2", 2: "conv3x3 transposed s2", 10: "wgrad conv3x3 s1", 11: "wgrad conv3x3 s2", 12: "wgrad transposed (as s2)"}

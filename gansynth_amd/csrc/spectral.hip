@@ -171,6 +171,7 @@ __global__ void if_unwrap_kernel(gs_spectral_plan p, const float* __restrict__ m
 // images -> mel_mag = exp(lm*10.05 - 3.76), mel_phase = cumsum(IF*pi) over time (spectral_ops.py:107-111)
 // `split` (optional): the same two matrices stacked ([mel_mag; mel_phase], M = 2 x batch x time_steps rows) as three bf16 planes
 // [3][M][nbins] whose sum is the fp32 value exactly -- the A operand of gemm_bf16x6_kernel
+template <bool THIRD = true>
 __device__ __forceinline__ void split3_store(unsigned short* __restrict__ split, long plane_elems, long idx, float v) {
     const unsigned a = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)v);
     const float r1 = v - __uint_as_float(a << 16);
@@ -178,11 +179,11 @@ __device__ __forceinline__ void split3_store(unsigned short* __restrict__ split,
     const unsigned c = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)(r1 - __uint_as_float(b << 16)));
     split[idx] = (unsigned short)a;
     split[plane_elems + idx] = (unsigned short)b;
-    split[2 * plane_elems + idx] = (unsigned short)c;
+    if (THIRD) split[2 * plane_elems + idx] = (unsigned short)c;
 }
 template <typename T>
 __global__ void inv_prep_kernel(gs_spectral_plan p, const T* __restrict__ images, float* __restrict__ mel_mag, float* __restrict__ mel_phase, int batch,
-                                unsigned short* __restrict__ split) {
+                                unsigned short* __restrict__ split, int mag_planes) {
     const int H = p.nbins, TT = p.time_steps;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= batch * H) return;
@@ -196,7 +197,8 @@ __global__ void inv_prep_kernel(gs_spectral_plan p, const T* __restrict__ images
         cum += fi * pi;
         if (split) {
             const long plane = 2L * batch * TT * H;
-            split3_store(split, plane, o, expf(lm));
+            if (mag_planes == 3) split3_store(split, plane, o, expf(lm));
+            else split3_store<false>(split, plane, o, expf(lm));   // (the magnitude rows' contraction reads two planes)
             split3_store(split, plane, (long)batch * TT * H + o, cum);
         } else {
             mel_mag[o] = expf(lm);
@@ -323,17 +325,19 @@ static __global__ __launch_bounds__(256) void gemm_f32_128_kernel(const float* _
 #define GX_ROW 80
 // Block tile 128 x (64 NJ): NJ = 2 -> 128 x 128, two blocks per CU; NJ = 4 -> 128 x 256, one block per CU (92 KB of LDS) and half
 // the passes over A, the big operand (6 bytes per element: with 128 x 128 tiles the kernel moved 6.4 GB through L2 in its 0.85 ms).
-template <int NJ>
-static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NJ == 4 ? 1 : 2, NJ == 4 ? 1 : 2)))
-void gemm_bf16x6_kernel(const unsigned short* __restrict__ Asplit, const unsigned short* __restrict__ Bsplit, float* __restrict__ C, int M, int N, int K) {
+// NP = planes used: 3 -> all six partial products (fp32 accuracy: the phase rows); 2 -> a1 b1 + a1 b2 + a2 b1 (2^-16 relative per
+// product: the magnitude rows, whose contract is 1e-3 relative) at half the MFMAs and two thirds of the operand traffic.
+template <int NJ, int NP>
+static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NJ == 4 ? 1 : 2, NJ == 4 ? 1 : (NP == 2 ? 3 : 2))))
+void gemm_bf16x6_kernel(const unsigned short* __restrict__ Asplit, const unsigned short* __restrict__ Bsplit, float* __restrict__ C, int M, int N, int K, int m_begin) {
     constexpr int BN = 64 * NJ;            // block columns; a wave owns 64 rows x (32 NJ) columns
-    constexpr int BCH = 3 * BN * 4 / 256;  // 16-byte chunks of B per thread and step
-    __shared__ __attribute__((aligned(16))) unsigned char As[3][128][GX_ROW];
-    __shared__ __attribute__((aligned(16))) unsigned char Bs[3][BN][GX_ROW];
+    constexpr int ACH = NP * 2, BCH = NP * BN * 4 / 256;  // 16-byte chunks of A / B per thread and step
+    __shared__ __attribute__((aligned(16))) unsigned char As[NP][128][GX_ROW];
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[NP][BN][GX_ROW];
     typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, hi = lane >> 5, l31 = lane & 31;
     const int nb = N / BN;
-    const int m0 = (blockIdx.x / nb) * 128, n0 = (blockIdx.x % nb) * BN;
+    const int m0 = m_begin + (blockIdx.x / nb) * 128, n0 = (blockIdx.x % nb) * BN;
     const int wm = (wv >> 1) * 64, wn = (wv & 1) * (32 * NJ);
     f32x16 acc[2][NJ];
 #pragma unroll
@@ -346,19 +350,19 @@ void gemm_bf16x6_kernel(const unsigned short* __restrict__ Asplit, const unsigne
     // part c & 3); the next step's chunks wait in registers
     // (plain unrolled code on purpose: pointer arrays and conditionally updated register arrays end up in scratch / promoted LDS)
     typedef unsigned u4_t __attribute__((ext_vector_type(4)));   // (native vectors: arrays of HIP's uint4 struct stay in memory)
-    u4_t ra[6], rb[BCH];
-    const unsigned short* const abase = Asplit + (long)m0 * K;
+    u4_t ra[ACH], rb[BCH];
+    const unsigned short* const abase = Asplit + (long)m0 * K;   // (plane stride M x K: M counts ALL rows of A)
     const unsigned short* const bbase = Bsplit + (long)n0 * K;
 #define GX_AOFF(J) (((long)((tid + 256 * (J)) / 512) * M + (((tid + 256 * (J)) % 512) >> 2)) * K + ((tid + 256 * (J)) & 3) * 8)
 #define GX_BOFF(J) (((long)((tid + 256 * (J)) / (4 * BN)) * N + (((tid + 256 * (J)) % (4 * BN)) >> 2)) * K + ((tid + 256 * (J)) & 3) * 8)
 #pragma unroll
-    for (int j = 0; j < 6; ++j) ra[j] = *reinterpret_cast<const u4_t*>(abase + GX_AOFF(j));
+    for (int j = 0; j < ACH; ++j) ra[j] = *reinterpret_cast<const u4_t*>(abase + GX_AOFF(j));
 #pragma unroll
     for (int j = 0; j < BCH; ++j) rb[j] = *reinterpret_cast<const u4_t*>(bbase + GX_BOFF(j));
     for (int k0 = 0; k0 < K; k0 += 32) {
         __syncthreads();   // the previous step's fragment reads are done
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {
+        for (int j = 0; j < ACH; ++j) {
             const int c = tid + 256 * j;
             *reinterpret_cast<u4_t*>(&As[c / 512][(c % 512) >> 2][(c & 3) * 16]) = ra[j];
         }
@@ -371,17 +375,17 @@ void gemm_bf16x6_kernel(const unsigned short* __restrict__ Asplit, const unsigne
         {   // the next step's global loads fly under this step's MFMAs (the last step re-reads its own: unconditional)
             const int kn = k0 + 32 < K ? k0 + 32 : k0;
 #pragma unroll
-            for (int j = 0; j < 6; ++j) ra[j] = *reinterpret_cast<const u4_t*>(abase + GX_AOFF(j) + kn);
+            for (int j = 0; j < ACH; ++j) ra[j] = *reinterpret_cast<const u4_t*>(abase + GX_AOFF(j) + kn);
 #pragma unroll
             for (int j = 0; j < BCH; ++j) rb[j] = *reinterpret_cast<const u4_t*>(bbase + GX_BOFF(j) + kn);
         }
         // fragments of k block 1 are read between the MFMAs of k block 0 (a wave issues in order: reads in front of the MFMAs of
         // their own block leave the pipe idle for an LDS round trip per block)
-        constexpr int NF = 6 + 3 * NJ;   // fragments of a k block: A (row tile i, plane pl) = 3 i + pl | B (column tile j, plane pl) = 6 + 3 j + pl
+        constexpr int NF = 2 * NP + NP * NJ;   // fragments of a k block: A (row tile i, plane pl) = NP i + pl | B (column tile j, plane pl) = 2 NP + NP j + pl
         bf16x8_t fr[2][NF];
         auto rd = [&](int kb, int q) __attribute__((always_inline)) {
-            const int t = q < 6 ? q : q - 6, i = t / 3, pl = t % 3;
-            fr[kb][q] = q < 6 ? *reinterpret_cast<const bf16x8_t*>(&As[pl][wm + 32 * i + l31][kb * 32 + hi * 16])
+            const int t = q < 2 * NP ? q : q - 2 * NP, i = t / NP, pl = t % NP;
+            fr[kb][q] = q < 2 * NP ? *reinterpret_cast<const bf16x8_t*>(&As[pl][wm + 32 * i + l31][kb * 32 + hi * 16])
                               : *reinterpret_cast<const bf16x8_t*>(&Bs[pl][wn + 32 * i + l31][kb * 32 + hi * 16]);
         };
 #pragma unroll
@@ -392,15 +396,18 @@ void gemm_bf16x6_kernel(const unsigned short* __restrict__ Asplit, const unsigne
             // (a1 + a2 + a3)(b1 + b2 + b3) down to 2^-16, small terms first; the term loop is the OUTER one so that consecutive MFMAs go to
             // different accumulators (six in a row into one accumulator wait for each other's result)
             constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+            constexpr int T0 = NP == 3 ? 0 : 3;   // two planes: the last three terms
 #pragma unroll
-            for (int t = 0; t < 6; ++t)
+            for (int t = T0; t < 6; ++t)
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[kb][3 * i + PA[t]], fr[kb][6 + 3 * j + PB[t]], acc[i][j], 0, 0, 0);
-                        const int slot = (t * 2 + i) * NJ + j;   // 12 NJ MFMAs of the block: one read of the next block after every second one
-                        if (kb == 0 && (slot & 1) == 1 && (slot >> 1) < NF) rd(1, slot >> 1);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[kb][NP * i + PA[t]], fr[kb][2 * NP + NP * j + PB[t]], acc[i][j], 0, 0, 0);
+                        constexpr int NM = (6 - T0) * 2 * NJ;           // MFMAs of the block: the NF reads of the next one spread evenly among them
+                        const int slot = ((t - T0) * 2 + i) * NJ + j;
+                        if (kb == 0)
+                            for (int r = slot * NF / NM; r < (slot + 1) * NF / NM; ++r) rd(1, r);
                         __builtin_amdgcn_sched_barrier(0);
                     }
         }
@@ -678,7 +685,9 @@ extern "C" int gs_mel_if_to_waveform(const gs_spectral_plan* p, const void* imag
     const bool split = (2 * rows) % 128 == 0 && H % 128 == 0 && H % 32 == 0 && p->pinv_split && !no_split;
     // (the three bf16 planes of the stacked pair take 3 x 2 x rows x H x 2 bytes = the first 3 rows x H floats of the workspace)
     unsigned short* a_split = split ? reinterpret_cast<unsigned short*>(mel_mag) : nullptr;
-    GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((inv_prep_kernel<T>), dim3(cdiv((long)batch * H, 256)), dim3(256), 0, st, *p, (const T*)images, mel_mag, mel_ph, batch, a_split));
+    static const bool full_mag = getenv("GS_INVERSE_MAG_6TERMS") != nullptr;   // measurement knob: six terms for the magnitude rows too
+    const bool two = split && rows % 128 == 0 && !full_mag;   // magnitude rows [0, rows): two planes, three terms
+    GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((inv_prep_kernel<T>), dim3(cdiv((long)batch * H, 256)), dim3(256), 0, st, *p, (const T*)images, mel_mag, mel_ph, batch, a_split, two ? 2 : 3));
     GS_CHECK_LAUNCH();
     // [mel_mag; mel_phase] @ pinv(mel) -> [mag; phase]: the two contractions of spectral_ops.py:123,125 share the matrix and are
     // stacked in the workspace, so they are ONE GEMM with 2 x rows
@@ -686,10 +695,22 @@ extern "C" int gs_mel_if_to_waveform(const gs_spectral_plan* p, const void* imag
         // 128 x 128 tiles, two blocks per CU (GS_INVERSE_GEMM_256: 128 x 256 tiles, one block per CU -- half the passes over A, but
         // measured 1 % SLOWER: the kernel is not L2-bound, it sits at the ~0.95 PFLOP/s every bf16 MFMA kernel of this build reaches)
         static const bool wide = getenv("GS_INVERSE_GEMM_256") != nullptr;
-        if (H % 256 == 0 && wide)
-            hipLaunchKernelGGL(gemm_bf16x6_kernel<4>, dim3((unsigned)((2 * rows / 128) * (H / 256))), dim3(256), 0, st, a_split, p->pinv_split, mag, (int)(2 * rows), H, H);
-        else
-            hipLaunchKernelGGL(gemm_bf16x6_kernel<2>, dim3((unsigned)((2 * rows / 128) * (H / 128))), dim3(256), 0, st, a_split, p->pinv_split, mag, (int)(2 * rows), H, H);
+        const int M2 = (int)(2 * rows);
+        const unsigned gw = (unsigned)(H / (wide && H % 256 == 0 ? 256 : 128));
+        const unsigned blocks_mag = (unsigned)(rows / 128) * gw, blocks_all = (unsigned)(2 * rows / 128) * gw;
+        if (H % 256 == 0 && wide) {
+            if (two) {
+                hipLaunchKernelGGL((gemm_bf16x6_kernel<4, 2>), dim3(blocks_mag), dim3(256), 0, st, a_split, p->pinv_split, mag, M2, H, H, 0);
+                hipLaunchKernelGGL((gemm_bf16x6_kernel<4, 3>), dim3(blocks_mag), dim3(256), 0, st, a_split, p->pinv_split, mag, M2, H, H, (int)rows);
+            } else {
+                hipLaunchKernelGGL((gemm_bf16x6_kernel<4, 3>), dim3(blocks_all), dim3(256), 0, st, a_split, p->pinv_split, mag, M2, H, H, 0);
+            }
+        } else if (two) {
+            hipLaunchKernelGGL((gemm_bf16x6_kernel<2, 2>), dim3(blocks_mag), dim3(256), 0, st, a_split, p->pinv_split, mag, M2, H, H, 0);
+            hipLaunchKernelGGL((gemm_bf16x6_kernel<2, 3>), dim3(blocks_mag), dim3(256), 0, st, a_split, p->pinv_split, mag, M2, H, H, (int)rows);
+        } else {
+            hipLaunchKernelGGL((gemm_bf16x6_kernel<2, 3>), dim3(blocks_all), dim3(256), 0, st, a_split, p->pinv_split, mag, M2, H, H, 0);
+        }
     } else if ((2 * rows) % 128 == 0 && H % 128 == 0) {
         hipLaunchKernelGGL(gemm_f32_128_kernel, dim3((unsigned)((2 * rows / 128) * (H / 128))), dim3(256), 0, st, mel_mag, p->pinv, mag, (int)(2 * rows), H, H);
     } else {
