@@ -25,15 +25,31 @@ class RcclComm(object):
         import torch.distributed as dist
         self.lib = kernels.get().lib
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        # Every rank runs the same sequence of launcher-side collectives whatever fails locally (a rank that raised before its
+        # peers' broadcast would leave them waiting): errors are collected, agreed on with a MIN all-reduce, and raised together.
         ident = (ctypes.c_ubyte * 128)()
+        error = None
         if self.rank == 0:
-            _lib.check(self.lib.gs_comm_unique_id(ident), "gs_comm_unique_id")
+            try:
+                _lib.check(self.lib.gs_comm_unique_id(ident), "gs_comm_unique_id")
+            except Exception as e:   # noqa: BLE001 -- reported below, on every rank
+                error = e
         carrier = torch.tensor(list(ident), dtype=torch.uint8, device=device)
         dist.broadcast(carrier, 0)   # the 128-byte id travels over the launcher's own process group
         ident = (ctypes.c_ubyte * 128)(*carrier.cpu().tolist())
         self.handle = ctypes.c_void_p()
-        with torch.cuda.device(device):
-            _lib.check(self.lib.gs_comm_init(ctypes.byref(self.handle), self.rank, self.world, ident), "gs_comm_init")
+        if error is None:
+            try:
+                with torch.cuda.device(device):
+                    _lib.check(self.lib.gs_comm_init(ctypes.byref(self.handle), self.rank, self.world, ident), "gs_comm_init")
+            except Exception as e:   # noqa: BLE001
+                error = e
+        ok = torch.tensor([0 if error is not None else 1], dtype=torch.int32, device=device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            self.close()
+            raise RuntimeError("RCCL communicator of libgansynth_hip.so could not be created on every rank (rank %d: %s)"
+                               % (self.rank, error if error is not None else "ok here, failed on a peer"))
 
     def all_reduce_(self, tensor):
         assert tensor.dtype == torch.float32 and tensor.is_contiguous() and tensor.is_cuda
@@ -60,4 +76,11 @@ def create(device):
         return None
     if dist.get_backend() != "nccl" or not hasattr(kernels.get(), "lib") or kernels.get().lib is None:
         return None
-    return RcclComm(device)
+    try:
+        return RcclComm(device)
+    except RuntimeError as e:
+        # Agreed on by all ranks (see RcclComm.__init__).  The job continues on torch.distributed's own RCCL communicator -- the same
+        # library, its collectives on the communicator's stream instead of the backward's -- and says so.
+        import sys
+        print("gansynth_amd.comm: %s; falling back to torch.distributed (nccl = RCCL) collectives" % e, file=sys.stderr, flush=True)
+        return None
