@@ -69,6 +69,9 @@ SIGNATURES = {
     "gs_tanh_bwd_bwd": (I, [P, P, P, P, L, I, P]),
     "gs_channel_sum_workspace_bytes": (Z, [L, I]),
     "gs_channel_sum": (I, [P, P, L, I, I, I, P, Z, P]),
+    "gs_bias_partial_rows": (I, [I, L, I, I]),
+    "gs_channel_fold_batch_workspace_bytes": (Z, [P, I]),
+    "gs_channel_fold_batch": (I, [P, I, P, Z, P]),
     "gs_pixel_norm_fwd": (I, [P, P, L, I, F, I, P]),
     "gs_pixel_norm_bwd": (I, [P, P, P, L, I, F, I, P]),
     "gs_pixel_norm_bwd_fused": (I, [P, P, P, P, L, I, F, I, I, I, P]),
@@ -109,6 +112,16 @@ class GsWgradReduce(ctypes.Structure):
     _fields_ = [("partials", c_void_p), ("gw", c_void_p), ("gb", c_void_p), ("nslices", ctypes.c_int32), ("taps", ctypes.c_int32),
                 ("ic", ctypes.c_int32), ("oc", ctypes.c_int32), ("alpha", c_float), ("transpose", ctypes.c_int32),
                 ("accumulate", ctypes.c_int32), ("ic_ld", ctypes.c_int32)]
+
+
+SUM_PARTIALS = 2   # GS_SUM_PARTIALS
+BIAS_FROM_CHANNEL_SUM, BIAS_FROM_ACT_BWD, BIAS_FROM_PIXEL_NORM_BWD = 0, 1, 2
+
+
+class GsFoldJob(ctypes.Structure):
+    """include/gansynth_hip.h: one pending fold of bias-gradient partial rows for gs_channel_fold_batch."""
+    _fields_ = [("part", c_void_p), ("out", c_void_p), ("nparts", ctypes.c_int32), ("c", ctypes.c_int32), ("accumulate", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]
 
 
 class GsWgradJob(ctypes.Structure):

@@ -267,6 +267,119 @@ static int channel_sum_finalize(float* part, float* out, int nparts, int c, int 
     GS_CHECK_LAUNCH();
     return 0;
 }
+// ---- deferred folds.  A backward pass has ~25 bias gradients whose producers (act_bwd_sum, the pixel-norm backward, channel_sum)
+// leave one partial row per block; folding each right behind its producer costs one or two 3-us launches plus the gap between
+// kernels every time.  With GS_SUM_PARTIALS in `accumulate` a producer only writes its partial rows (ws = the caller's own
+// buffer of gs_bias_partial_rows x c floats, kept until the fold) and gs_channel_fold_batch folds ALL of them in one launch
+// (two when a producer left more than CS_SLAB rows), in the order and association channel_sum_finalize uses: same bits.
+#define GS_FOLD_HEADS 32
+#define GS_FOLD_SRCS 48
+struct FoldSrc {
+    const float* part;
+    int nparts, per;
+};
+struct FoldHead {   // one target: its sources are folded one after the other by the same block (call order: (out + t1) + t2 like the immediate folds)
+    float* out;
+    int c, accumulate, blk0, chblocks, src0, nsrc;
+};
+struct FoldBatch {
+    FoldHead h[GS_FOLD_HEADS];
+    FoldSrc s[GS_FOLD_SRCS];
+    int n;
+};
+static __global__ __launch_bounds__(256) void channel_fold_batch_kernel(const FoldBatch b) {
+    __shared__ float red[256];
+    int k = 0;
+    while (k + 1 < b.n && (int)blockIdx.x >= b.h[k + 1].blk0) ++k;
+    float* const out = b.h[k].out;
+    const int c = b.h[k].c, src0 = b.h[k].src0, nsrc = b.h[k].nsrc;
+    const int local = (int)blockIdx.x - b.h[k].blk0, chb = local % b.h[k].chblocks, slab = local / b.h[k].chblocks;
+    const int ch = chb * 32 + (threadIdx.x & 31);
+    const int pl = threadIdx.x >> 5;
+    float acc = 0.f;
+    if (pl == 0 && ch < c && b.h[k].accumulate) acc = out[(long)slab * c + ch];
+    for (int i = 0; i < nsrc; ++i) {
+        const float* const part = b.s[src0 + i].part;
+        const int nparts = b.s[src0 + i].nparts, per = b.s[src0 + i].per;
+        const int k0 = slab * per;
+        int k1 = k0 + per;
+        if (k1 > nparts) k1 = nparts;
+        float s = 0.f;
+        if (ch < c)
+            for (int r = k0 + pl; r < k1; r += 8) s += part[(long)r * c + ch];
+        if (i) __syncthreads();
+        red[threadIdx.x] = s;
+        __syncthreads();
+        if (pl == 0 && ch < c) {
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t += red[q * 32 + threadIdx.x];
+            acc = (i || b.h[k].accumulate) ? acc + t : t;
+        }
+    }
+    if (pl == 0 && ch < c) out[(long)slab * c + ch] = acc;
+}
+struct FoldTarget {
+    float* out;
+    int c, accumulate;
+    std::vector<FoldSrc> src;
+};
+static int fold_launch(const std::vector<FoldTarget>& targets, hipStream_t st) {
+    size_t i = 0;
+    while (i < targets.size()) {
+        FoldBatch b;
+        b.n = 0;
+        int blocks = 0, nsrc = 0;
+        while (i < targets.size() && b.n < GS_FOLD_HEADS && nsrc + (int)targets[i].src.size() <= GS_FOLD_SRCS) {
+            const FoldTarget& t = targets[i];
+            FoldHead& h = b.h[b.n++];
+            h.out = t.out; h.c = t.c; h.accumulate = t.accumulate; h.blk0 = blocks; h.chblocks = cdiv(t.c, 32); h.src0 = nsrc; h.nsrc = (int)t.src.size();
+            for (const FoldSrc& q : t.src) b.s[nsrc++] = q;
+            blocks += h.chblocks * cdiv(t.src[0].nparts, t.src[0].per);   // (several slabs: single-source targets only)
+            ++i;
+        }
+        if (b.n == 0) return fail(GS_ERR_UNSUPPORTED, "channel_fold_batch: %zu folds into one target (at most %d)", targets[i].src.size(), GS_FOLD_SRCS);
+        hipLaunchKernelGGL(channel_fold_batch_kernel, dim3((unsigned)blocks), dim3(256), 0, st, b);
+    }
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" size_t gs_channel_fold_batch_workspace_bytes(const GsFoldJob* jobs, int njobs) {
+    size_t rows = 0;
+    for (int i = 0; jobs && i < njobs; ++i)
+        if (jobs[i].nparts > CS_SLAB) rows += (size_t)cdiv(jobs[i].nparts, CS_SLAB) * jobs[i].c;
+    return rows * sizeof(float);
+}
+extern "C" int gs_channel_fold_batch(const GsFoldJob* jobs, int njobs, void* ws, size_t ws_bytes, void* stream) {
+    GS_CHECK_ARG(jobs && njobs > 0, "channel_fold_batch: no jobs");
+    if (ws_bytes < gs_channel_fold_batch_workspace_bytes(jobs, njobs)) return fail(GS_ERR_WORKSPACE, "channel_fold_batch: workspace too small");
+    std::vector<FoldTarget> first, second;
+    float* part2 = (float*)ws;
+    for (int i = 0; i < njobs; ++i) {
+        const GsFoldJob& j = jobs[i];
+        GS_CHECK_ARG(j.part && j.out && j.nparts > 0 && j.c > 0, "channel_fold_batch: bad job %d", i);
+        FoldSrc src{j.part, j.nparts, j.nparts};
+        if (j.nparts > CS_SLAB) {   // slab sums first (their own rows of ws), then the fold of those
+            const int nsplit = cdiv(j.nparts, CS_SLAB);
+            first.push_back(FoldTarget{part2, j.c, 0, {FoldSrc{j.part, j.nparts, CS_SLAB}}});
+            src = FoldSrc{part2, nsplit, nsplit};
+            part2 += (size_t)nsplit * j.c;
+        }
+        size_t t = 0;
+        while (t < second.size() && second[t].out != j.out) ++t;   // jobs into one target: folded in call order by the same blocks
+        if (t == second.size()) second.push_back(FoldTarget{j.out, j.c, j.accumulate ? 1 : 0, {}});
+        GS_CHECK_ARG(second[t].c == j.c, "channel_fold_batch: job %d adds %d channels into a target of %d", i, j.c, second[t].c);
+        GS_CHECK_ARG(second[t].src.empty() || j.accumulate, "channel_fold_batch: job %d overwrites a target an earlier job wrote", i);
+        second[t].src.push_back(src);
+    }
+    hipStream_t st = as_stream(stream);
+    if (!first.empty())
+        if (int e = fold_launch(first, st)) return e;
+    return fold_launch(second, st);
+}
+// rows of partials a producer leaves with GS_SUM_PARTIALS (0: it writes the sums itself, nothing to fold)
+extern "C" int gs_bias_partial_rows(int producer, int64_t p, int c, int dtype);
+
 // few rows, many channels (dense-layer biases: [batch][8192]): a thread per channel, no partials
 template <typename T>
 __global__ __launch_bounds__(256) void channel_sum_rows_kernel(const T* __restrict__ g, float* __restrict__ out, int p, int c, int accumulate) {
@@ -662,17 +775,20 @@ extern "C" size_t gs_channel_sum_workspace_bytes(int64_t p, int c) {
 
 extern "C" int gs_channel_sum(const void* g, float* out, int64_t p, int c, int accumulate, int dtype, void* ws, size_t ws_bytes, void* stream) {
     GS_CHECK_ARG(p > 0 && c > 0, "channel_sum: bad args");
+    const bool partials_only = (accumulate & GS_SUM_PARTIALS) != 0;
+    accumulate &= 1;
     if (p <= 64 && c >= 256) {
         GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((channel_sum_rows_kernel<T>), dim3(cdiv(c, 256)), dim3(256), 0, as_stream(stream), (const T*)g, out, (int)p, c, accumulate));
         GS_CHECK_LAUNCH();
         return 0;
     }
     const int nparts = channel_sum_parts(p, c);
-    if (ws_bytes < gs_channel_sum_workspace_bytes(p, c)) return fail(GS_ERR_WORKSPACE, "channel_sum: workspace too small");
+    if (ws_bytes < (partials_only ? (size_t)nparts * c * sizeof(float) : gs_channel_sum_workspace_bytes(p, c))) return fail(GS_ERR_WORKSPACE, "channel_sum: workspace too small");
     hipStream_t st = as_stream(stream);
     float* part = (float*)ws;
     GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((channel_sum_kernel<T>), dim3(nparts), dim3(256), 0, st, (const T*)g, part, (long)p, c));
     GS_CHECK_LAUNCH();
+    if (partials_only) return 0;
     return channel_sum_finalize(part, out, nparts, c, accumulate, st);
 }
 
@@ -686,8 +802,10 @@ extern "C" int gs_act_bwd_bias(const void* g, const void* y, void* gx, float* gb
         if (int e = gs_act_bwd(g, y, gx, p * c, act, dtype, stream)) return e;
         return gs_channel_sum(gx, gb, p, c, accumulate, dtype, ws, ws_bytes, stream);
     }
+    const bool partials_only = (accumulate & GS_SUM_PARTIALS) != 0;
+    accumulate &= 1;
     const int nparts = channel_sum_parts(p, c);
-    if (ws_bytes < gs_channel_sum_workspace_bytes(p, c)) return fail(GS_ERR_WORKSPACE, "act_bwd_bias: workspace too small");
+    if (ws_bytes < (partials_only ? (size_t)nparts * c * sizeof(float) : gs_channel_sum_workspace_bytes(p, c))) return fail(GS_ERR_WORKSPACE, "act_bwd_bias: workspace too small");
     hipStream_t st = as_stream(stream);
     float* part = (float*)ws;
     GS_DISPATCH_DTYPE(dtype, {
@@ -695,6 +813,7 @@ extern "C" int gs_act_bwd_bias(const void* g, const void* y, void* gx, float* gb
         else hipLaunchKernelGGL((act_bwd_sum_kernel<T, 2>), dim3(nparts), dim3(256), 0, st, (const T*)g, (const T*)y, (T*)gx, part, (long)p, c);
     });
     GS_CHECK_LAUNCH();
+    if (partials_only) return 0;
     return channel_sum_finalize(part, gb, nparts, c, accumulate, st);
 }
 
@@ -755,13 +874,27 @@ extern "C" int gs_pixel_norm_bwd_fused_bias(const void* g, const void* x, const 
                                             int post_act, int accumulate, int dtype, void* ws, size_t ws_bytes, void* stream) {
     GS_CHECK_ARG(pn_act_ok(pre_act) && pn_act_ok(post_act), "pixel_norm_bwd_fused_bias: bad activation %d / %d", pre_act, post_act);
     GS_CHECK_ARG(p > 0 && c >= 4 && c <= 1024 && (c & (c - 1)) == 0 && gb && g && x && gx, "pixel_norm_bwd_fused_bias: bad args (c=%d)", c);
-    if (ws_bytes < gs_pixel_norm_bwd_bias_workspace_bytes(p, c, dtype)) return fail(GS_ERR_WORKSPACE, "pixel_norm_bwd_fused_bias: workspace too small");
+    const bool partials_only = (accumulate & GS_SUM_PARTIALS) != 0;
+    accumulate &= 1;
+    const int nb = pixel_norm_grid((long)p, c, dtype == GS_F32 ? 4 : 8);
+    if (ws_bytes < (partials_only ? (size_t)nb * c * sizeof(float) : gs_pixel_norm_bwd_bias_workspace_bytes(p, c, dtype)))
+        return fail(GS_ERR_WORKSPACE, "pixel_norm_bwd_fused_bias: workspace too small");
     hipStream_t st = as_stream(stream);
     float* part = (float*)ws;
-    const int nb = pixel_norm_grid((long)p, c, dtype == GS_F32 ? 4 : 8);
     GS_DISPATCH_DTYPE(dtype, (pixel_norm_launch_t<T, 1, true>(g, x, nullptr, gx, (long)p, c, eps, post_act, pre_act, addend, nullptr, st, part)));
     GS_CHECK_LAUNCH();
+    if (partials_only) return 0;
     return channel_sum_finalize(part, gb, nb, c, accumulate, st);
+}
+extern "C" int gs_bias_partial_rows(int producer, int64_t p, int c, int dtype) {
+    if (p <= 0 || c <= 0) return 0;
+    const bool act_fast = !((c & 3) != 0 || c > 1024 || 256 % (c >> 2) != 0);   // gs_act_bwd_bias's one-pass shapes
+    switch (producer) {
+        case GS_BIAS_FROM_CHANNEL_SUM: return (p <= 64 && c >= 256) ? 0 : channel_sum_parts(p, c);
+        case GS_BIAS_FROM_ACT_BWD: return (!act_fast && p <= 64 && c >= 256) ? 0 : channel_sum_parts(p, c);
+        case GS_BIAS_FROM_PIXEL_NORM_BWD: return (c >= 4 && c <= 1024 && (c & (c - 1)) == 0) ? pixel_norm_grid((long)p, c, dtype == GS_F32 ? 4 : 8) : 0;
+        default: return 0;
+    }
 }
 extern "C" int gs_pixel_norm_bwd_bwd_fused(const void* gg, const void* g, const void* x, void* out, void* out_g, int64_t p, int c, float eps, int pre_act,
                                            int dtype, void* stream) {

@@ -78,6 +78,7 @@ class HipKernels(object):
         self._wcache = {}         # (weight ptr, map tag) -> (persistent workspace holding the re-laid operand, stamp)
         self._prep_tables = {}    # tuple of cache keys -> device table of GsPrepDesc rows (refresh_weights)
         self._derived = {}        # (parent weight ptr, lo, hi) -> [contiguous slice buffer, stamp, parent, lo, hi] (derived_slice)
+        self._folds = None        # deferred bias-gradient folds while deferring: [(partial rows, out, nparts, c)]
         self._pending = None      # deferred weight gradients while deferring: {layer key: {out, bias, [(x, gy, with bias)]}}
 
     # --------------------------------------------------------- prepared-weight workspaces
@@ -183,6 +184,31 @@ class HipKernels(object):
         only after the flush; x and gy are kept alive (and must not be written) until then."""
         if self._pending is None:
             self._pending = {}
+            self._folds = None if os.environ.get("GS_NO_DEFERRED_FOLDS") else []
+
+    def _partial_rows(self, producer, p, c, dt, out):
+        """While gradients are deferred: a buffer of its own for the partial rows of a bias gradient that is ADDED into `out` (a
+        variable's .grad, only read after the flush) -- the producer then skips its fold and flush_wgrad_reductions() folds all
+        of them in one launch (gs_channel_fold_batch).  None: fold right away."""
+        if self._folds is None or out is None:
+            return None
+        rows = self.lib.gs_bias_partial_rows(producer, p, c, dt)
+        if rows <= 0:
+            return None
+        part = torch.empty((rows * c,), dtype=torch.float32, device=out.device)
+        self._folds.append((part, out, rows, c))
+        return part
+
+    def _flush_folds(self):
+        folds, self._folds = self._folds, None
+        if not folds:
+            return
+        arr = (_lib.GsFoldJob * len(folds))()
+        for jb, (part, out, rows, c) in zip(arr, folds):
+            jb.part, jb.out, jb.nparts, jb.c, jb.accumulate = part.data_ptr(), out.data_ptr(), rows, c, 1
+        ptr = ctypes.cast(arr, ctypes.c_void_p)
+        ws = _ws(max(self.lib.gs_channel_fold_batch_workspace_bytes(ptr, len(folds)), 256), folds[0][1].device)
+        _lib.check(self.lib.gs_channel_fold_batch(ptr, len(folds), ws.data_ptr(), ws.numel(), _stream()), "gs_channel_fold_batch")
 
     def wgrad_slice_target_ok(self, x, co, ksize, stride):
         """May a conv weight gradient be added into a CHANNEL SLICE w.grad[:, :, lo:hi, :] of a wider variable (a strided `out`)?
@@ -206,6 +232,7 @@ class HipKernels(object):
         order); each group is contracted and folded before the next one starts and `on_group_done(group)` is called right after
         its last launch -- the data-parallel trainer puts that bucket's all-reduce on the wire there."""
         groups, self._pending = self._pending, None
+        self._flush_folds()   # (bias gradients first: they belong to the same buckets as the weights folded below)
         if not groups:
             return 0
         if group_of is not None:
@@ -532,9 +559,11 @@ class HipKernels(object):
         p, c = _rows_cols(y)
         gx = torch.empty_like(y)
         gb = torch.empty((c,), dtype=torch.float32, device=y.device) if out is None else out
-        ws = _ws(self.lib.gs_channel_sum_workspace_bytes(p, c), y.device)
-        _lib.check(self.lib.gs_act_bwd_bias(g.data_ptr(), y.data_ptr(), gx.data_ptr(), gb.data_ptr(), p, c, act, 0 if out is None else 1,
-                                            _dt(y), ws.data_ptr(), ws.numel(), _stream()), "gs_act_bwd_bias")
+        part = self._partial_rows(_lib.BIAS_FROM_ACT_BWD, p, c, _dt(y), out)
+        ws = part if part is not None else _ws(self.lib.gs_channel_sum_workspace_bytes(p, c), y.device)
+        flags = (0 if out is None else 1) | (_lib.SUM_PARTIALS if part is not None else 0)
+        _lib.check(self.lib.gs_act_bwd_bias(g.data_ptr(), y.data_ptr(), gx.data_ptr(), gb.data_ptr(), p, c, act, flags,
+                                            _dt(y), ws.data_ptr(), ws.numel() * ws.element_size(), _stream()), "gs_act_bwd_bias")
         return gx, gb
 
     def tanh_bwd_bwd(self, gg, g, y):
@@ -549,8 +578,10 @@ class HipKernels(object):
         g = _act(g)
         p, c = _rows_cols(g)
         res = torch.empty((c,), dtype=torch.float32, device=g.device) if out is None else out
-        ws = _ws(self.lib.gs_channel_sum_workspace_bytes(p, c), g.device)
-        _lib.check(self.lib.gs_channel_sum(g.data_ptr(), res.data_ptr(), p, c, 0 if out is None else 1, _dt(g), ws.data_ptr(), ws.numel(),
+        part = self._partial_rows(_lib.BIAS_FROM_CHANNEL_SUM, p, c, _dt(g), out)
+        ws = part if part is not None else _ws(self.lib.gs_channel_sum_workspace_bytes(p, c), g.device)
+        flags = (0 if out is None else 1) | (_lib.SUM_PARTIALS if part is not None else 0)
+        _lib.check(self.lib.gs_channel_sum(g.data_ptr(), res.data_ptr(), p, c, flags, _dt(g), ws.data_ptr(), ws.numel() * ws.element_size(),
                                            _stream()), "gs_channel_sum")
         return res
 
@@ -576,9 +607,11 @@ class HipKernels(object):
             ap = addend.data_ptr()
         if bias_out is not None:
             assert bias_out.dtype == torch.float32 and bias_out.is_contiguous() and bias_out.numel() == c
-            ws = _ws(self.lib.gs_pixel_norm_bwd_bias_workspace_bytes(p, c, _dt(x)), x.device)
+            part = self._partial_rows(_lib.BIAS_FROM_PIXEL_NORM_BWD, p, c, _dt(x), bias_out)
+            ws = part if part is not None else _ws(self.lib.gs_pixel_norm_bwd_bias_workspace_bytes(p, c, _dt(x)), x.device)
             _lib.check(self.lib.gs_pixel_norm_bwd_fused_bias(g.data_ptr(), x.data_ptr(), ap, gx.data_ptr(), bias_out.data_ptr(), p, c, float(eps), int(pre_act),
-                                                             int(act), 1, _dt(x), ws.data_ptr(), ws.numel(), _stream()), "gs_pixel_norm_bwd_fused_bias")
+                                                             int(act), 1 | (_lib.SUM_PARTIALS if part is not None else 0), _dt(x), ws.data_ptr(),
+                                                             ws.numel() * ws.element_size(), _stream()), "gs_pixel_norm_bwd_fused_bias")
             return gx
         _lib.check(self.lib.gs_pixel_norm_bwd_fused(g.data_ptr(), x.data_ptr(), ap, gx.data_ptr(), p, c, float(eps), int(pre_act), int(act), _dt(x),
                                                     _stream()), "gs_pixel_norm_bwd_fused")

@@ -262,6 +262,23 @@ int gs_act_bwd_bias(const void* g, const void* y, void* gx, float* gb, int64_t p
 int gs_tanh_bwd_bwd(const void* gg, const void* g, const void* y, void* out, int64_t numel, int dtype, void* stream);
 size_t gs_channel_sum_workspace_bytes(int64_t p, int c);
 int gs_channel_sum(const void* g, float* out, int64_t p, int c, int accumulate, int dtype, void* ws, size_t ws_bytes, void* stream);
+/* Deferred folds of the bias gradients (the variable gradients of models.py:81-89 are only read after the whole backward).  With
+ * GS_SUM_PARTIALS or-ed into `accumulate`, gs_channel_sum / gs_act_bwd_bias / gs_pixel_norm_bwd_fused_bias leave their per-block
+ * partial rows in `ws` (the caller's own buffer of gs_bias_partial_rows(...) x c floats, alive until the fold) and do not touch
+ * gb; gs_channel_fold_batch then folds every pending gradient in ONE launch (two when a producer left more than 64 rows), in
+ * the order the immediate fold uses (bit-identical).  gs_bias_partial_rows == 0: that shape is summed directly whatever the flag. */
+#define GS_SUM_PARTIALS 2
+enum { GS_BIAS_FROM_CHANNEL_SUM = 0, GS_BIAS_FROM_ACT_BWD = 1, GS_BIAS_FROM_PIXEL_NORM_BWD = 2 };
+typedef struct GsFoldJob {
+    const float* part; /* [nparts][c] partial rows */
+    float* out;        /* [c] */
+    int32_t nparts, c;
+    int32_t accumulate; /* 1: out += sum */
+    int32_t reserved;
+} GsFoldJob;
+int gs_bias_partial_rows(int producer, int64_t p, int c, int dtype);
+size_t gs_channel_fold_batch_workspace_bytes(const GsFoldJob* jobs, int njobs);
+int gs_channel_fold_batch(const GsFoldJob* jobs, int njobs, void* ws, size_t ws_bytes, void* stream);
 
 /* pixel_normalization (ops.py:330-333): y = x / sqrt(mean_c(x^2) + eps), per row p over c.
  *   bwd      : gx = r*(g - y*mean_c(y*g)),  r = rsqrt(mean_c(x^2)+eps)

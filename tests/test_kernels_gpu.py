@@ -524,6 +524,63 @@ def test_pixel_norm_backward_sums_its_result_for_the_bias(K, shape, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_deferred_bias_gradient_folds_match_immediate_ones(K, dtype):
+    """GS_SUM_PARTIALS + gs_channel_fold_batch: while the trainer defers its parameter gradients, the three producers of a bias
+    gradient (activation backward, pixel-norm backward, plain channel sum) only leave their partial rows and ONE launch folds all of
+    them at the flush (two when a producer left more than 64 rows) -- the same bits as folding each behind its producer, repeated
+    targets accumulate in call order, shapes that are summed directly stay direct."""
+    shapes = [(8, 32, 128, 256), (2, 64, 16, 128), (3, 256, 4, 32), (2, 512, 2, 16), (8, 256, 2, 16), (2, 32, 32, 256)]
+    g_ = torch.Generator(device="cuda").manual_seed(12)
+    work = []
+    for shape in shapes + shapes[:2]:
+        z = torch.nn.functional.leaky_relu(torch.randn(*shape, device="cuda", generator=g_), 0.2).to(dtype).contiguous(memory_format=torch.channels_last)
+        g = torch.randn(*shape, device="cuda", generator=g_).to(dtype).contiguous(memory_format=torch.channels_last)
+        work.append((z, g))
+    dense = torch.randn(8, 8192, device="cuda", generator=g_).to(dtype)   # few rows, many channels: summed directly, nothing to fold
+
+    def run(deferred):
+        tgt = {}
+        outs = []
+        if deferred:
+            K.defer_wgrad_reductions()
+        for i, (z, g) in enumerate(work):
+            c = z.shape[1]
+            for kind in range(3):
+                gb = tgt.setdefault((kind, tuple(z.shape)), torch.full((c,), 0.5 + kind, device="cuda"))
+                if kind == 0:
+                    outs.append(K.act_bwd_bias(g, z, 1, out=gb)[0])
+                elif kind == 1:
+                    outs.append(K.pixel_norm_bwd(g, z, 1e-8, act=1, bias_out=gb))
+                else:
+                    K.channel_sum(g, out=gb)
+        gd = torch.full((8192,), 0.25, device="cuda")
+        K.channel_sum(dense, out=gd)
+        if deferred:
+            from gansynth_amd import _lib as L
+            dt = L.GS_F32 if dtype == torch.float32 else L.GS_BF16
+            producer = {0: L.BIAS_FROM_ACT_BWD, 1: L.BIAS_FROM_PIXEL_NORM_BWD, 2: L.BIAS_FROM_CHANNEL_SUM}
+            rows = {k: K.lib.gs_bias_partial_rows(producer[k[0]], k[1][0] * k[1][2] * k[1][3], k[1][1], dt) for k in tgt}
+            assert len(K._folds) == sum(1 for (z, g) in work for kind in range(3) if rows[(kind, tuple(z.shape))] > 0) >= 2 * len(work)
+            assert any(r > 64 for r in rows.values()) and any(0 < r <= 64 for r in rows.values())   # both fold depths
+            for k, v in tgt.items():   # untouched until the flush (shapes that are summed directly: already complete)
+                assert rows[k] == 0 or float((v - (0.5 + k[0])).abs().max()) == 0.0, k
+            K.flush_wgrad_reductions()
+            assert K._folds is None
+        return tgt, outs, gd
+
+    t0, o0, d0 = run(False)
+    t1, o1, d1 = run(True)
+    assert torch.equal(d0, d1)
+    for a, b in zip(o0, o1):
+        assert torch.equal(a, b)
+    for k in t0:
+        assert torch.equal(t0[k], t1[k]), k
+    z, g = work[0]
+    ref = g.double().sum(dim=(0, 2, 3)) + work[len(shapes)][1].double().sum(dim=(0, 2, 3)) + 2.5   # the repeated shape: two sums on top of the initial 2.5
+    assert float((t1[(2, tuple(z.shape))].double() - ref).abs().max()) <= 1e-4 * float(g.double().abs().sum(dim=(0, 2, 3)).max())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_deferred_weight_gradient_reductions_match_immediate_ones(K, dtype):
     """Deferred weight gradients (gs_*_bwd_weight*_multi + gs_wgrad_reduce_batch): the (x, gy) pairs of a layer contracted by one
     launch and the slice partials of all layers folded together -- equal (to fp32 rounding) to one immediate call per pair,
