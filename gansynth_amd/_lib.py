@@ -88,9 +88,9 @@ SIGNATURES = {
     "gs_axpby_dev": (I, [P, P, P, L, P, I, I, I, P]),
     "gs_sumsq_rows_workspace_bytes": (Z, [I]),
     "gs_sumsq_rows": (I, [P, P, I, L, I, P, Z, P]),
-    "gs_row_scale": (I, [P, P, P, I, L, I, P]),
+    "gs_row_scale": (I, [P, P, F, P, I, L, I, P]),
     "gs_weight_prep_batch": (I, [P, I, P]),
-    "gs_gan_d_loss": (I, [P, P, P, P, I, I, P, P, P, I, P]),
+    "gs_gan_d_loss": (I, [P, P, P, P, F, I, I, P, P, P, P, I, P]),
     "gs_gan_g_loss": (I, [P, P, P, F, F, I, I, P, P, P, I, P]),
     "gs_adam_tf_step": (I, [P, P, P, P, L, F, F, F, F, F, P]),
     "gs_spectral_plan_create": (I, [POINTER(c_void_p), I, I, I, P, P]),

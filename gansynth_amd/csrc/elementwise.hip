@@ -649,10 +649,10 @@ static __global__ __launch_bounds__(64) void sumsq_rows_final_kernel(const float
     if (threadIdx.x == 0) out[blockIdx.x] = s;
 }
 template <typename T>
-__global__ void row_scale_kernel(const T* __restrict__ x, const float* __restrict__ s, T* __restrict__ out, int rows, long cols) {
+__global__ void row_scale_kernel(const T* __restrict__ x, const float* __restrict__ s, T* __restrict__ out, int rows, long cols, float alpha) {
     const long nvec = ((long)rows * cols) >> 2;  // cols % 4 == 0 checked by the caller
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
-        const float f = s[(i * 4) / cols];
+        const float f = alpha * s[(i * 4) / cols];
         float v[4];
         ld4(x + i * 4, v);
         v[0] *= f; v[1] *= f; v[2] *= f; v[3] *= f;
@@ -940,10 +940,10 @@ extern "C" int gs_sumsq_rows(const void* x, float* out, int rows, int64_t cols, 
     return 0;
 }
 
-extern "C" int gs_row_scale(const void* x, const float* s, void* out, int rows, int64_t cols, int dtype, void* stream) {
+extern "C" int gs_row_scale(const void* x, const float* s, float alpha, void* out, int rows, int64_t cols, int dtype, void* stream) {
     GS_CHECK_ARG(rows > 0 && cols > 0 && cols % 4 == 0, "row_scale: cols must be a multiple of 4");
     const long nvec = ((long)rows * cols) >> 2;
-    GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((row_scale_kernel<T>), dim3(ew_grid(nvec)), dim3(256), 0, as_stream(stream), (const T*)x, s, (T*)out, rows, (long)cols));
+    GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((row_scale_kernel<T>), dim3(ew_grid(nvec)), dim3(256), 0, as_stream(stream), (const T*)x, s, (T*)out, rows, (long)cols, alpha));
     GS_CHECK_LAUNCH();
     return 0;
 }

@@ -480,8 +480,8 @@ __device__ inline float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
 // tf.gather_nd(logits, tf.where(labels)), models.py:39-40).  g_real = d L_D / d real_logits etc.
 template <typename T>
 __global__ __launch_bounds__(256) void gan_d_loss_kernel(const T* __restrict__ rl, const T* __restrict__ fl, const T* __restrict__ lab,
-                                                         const float* __restrict__ pen, int n, int c, float* __restrict__ loss,
-                                                         T* __restrict__ g_real, T* __restrict__ g_fake) {
+                                                         const float* __restrict__ pen, float pen_w, int n, int c, float* __restrict__ loss,
+                                                         T* __restrict__ g_real, T* __restrict__ g_fake, float* __restrict__ g_pen) {
     __shared__ float red[4];
     __shared__ float sr[1024], sf[1024];
     const float inv_n = 1.f / (float)n;
@@ -493,7 +493,8 @@ __global__ __launch_bounds__(256) void gan_d_loss_kernel(const T* __restrict__ r
             r += DT<T>::ld(rl + (long)i * c + k) * l;
             f += DT<T>::ld(fl + (long)i * c + k) * l;
         }
-        part += softplus_f(-r) + softplus_f(f) + (pen ? pen[i] : 0.f);
+        part += softplus_f(-r) + softplus_f(f) + (pen ? pen_w * pen[i] : 0.f);
+        if (g_pen) g_pen[i] = pen_w * inv_n;
         sr[i] = -sigmoid_f(-r) * inv_n;   // d mean / d r_i
         sf[i] = sigmoid_f(f) * inv_n;     // d mean / d f_i
     }
@@ -537,11 +538,11 @@ __global__ __launch_bounds__(256) void gan_g_loss_kernel(const T* __restrict__ f
 
 using namespace gs;
 
-extern "C" int gs_gan_d_loss(const void* real_logits, const void* fake_logits, const void* labels, const float* penalty, int n, int c, float* loss,
-                             void* g_real, void* g_fake, int dtype, void* stream) {
+extern "C" int gs_gan_d_loss(const void* real_logits, const void* fake_logits, const void* labels, const float* penalty, float penalty_weight, int n, int c,
+                             float* loss, void* g_real, void* g_fake, float* g_penalty, int dtype, void* stream) {
     GS_CHECK_ARG(n > 0 && n <= 1024 && c > 0 && real_logits && fake_logits && labels && loss && g_real && g_fake, "gan_d_loss: bad args (batch %d <= 1024)", n);
     GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gan_d_loss_kernel<T>), dim3(1), dim3(256), 0, as_stream(stream), (const T*)real_logits, (const T*)fake_logits,
-                                                (const T*)labels, penalty, n, c, loss, (T*)g_real, (T*)g_fake));
+                                                (const T*)labels, penalty, penalty_weight, n, c, loss, (T*)g_real, (T*)g_fake, penalty ? g_penalty : nullptr));
     GS_CHECK_LAUNCH();
     return 0;
 }

@@ -876,25 +876,46 @@ def axpby(a, b, ca, cb):
 
 
 # ------------------------------------------------------------------------------ GAN losses
+_UNIT = {}
+
+
+def unit_seed(device):
+    """The constant 1.0 (fp32 scalar, one per device) the trainer seeds its losses with (torch.autograd.backward(loss, unit_seed)):
+    a loss head that is handed THIS tensor returns its stored gradients as they are instead of scaling them by a device scalar
+    (three to five launches per loss).  Created outside stream capture (models.GANSynth does, when it is built)."""
+    key = str(torch.device(device))
+    t = _UNIT.get(key)
+    if t is None:
+        t = _UNIT[key] = torch.ones((), dtype=torch.float32, device=device)
+    return t
+
+
+def _is_unit(g):
+    t = _UNIT.get(str(g.device))
+    return t is not None and g.dim() == 0 and g.dtype == torch.float32 and g.data_ptr() == t.data_ptr()
+
+
 class _GanDLoss(Function):
     """L_D = mean(softplus(-r) + softplus(f) + penalty) with r / f the label logits (models.py:39-49, 65): loss and gradients in
     one launch; the backward scales the stored gradients by the incoming scalar.  First order only (the second-order terms of the
     step live in `penalty`'s own graph)."""
 
     @staticmethod
-    def forward(ctx, real_logits, fake_logits, labels, penalty):
-        loss, g_real, g_fake = _K().gan_d_loss(real_logits, fake_logits, labels, penalty)
-        ctx.save_for_backward(g_real, g_fake)
-        ctx.n, ctx.has_penalty = real_logits.shape[0], penalty is not None
+    def forward(ctx, real_logits, fake_logits, labels, penalty, penalty_weight):
+        loss, g_real, g_fake, g_pen = _K().gan_d_loss(real_logits, fake_logits, labels, penalty, penalty_weight)
+        ctx.has_penalty = penalty is not None
+        ctx.save_for_backward(g_real, g_fake, g_pen if ctx.has_penalty else g_real)
         return loss
 
     @staticmethod
     @once_differentiable
     def backward(ctx, g):
-        g_real, g_fake = ctx.saved_tensors
-        gp = (g / ctx.n).expand(ctx.n) if ctx.has_penalty and ctx.needs_input_grad[3] else None
+        g_real, g_fake, g_pen = ctx.saved_tensors
+        want_pen = ctx.has_penalty and ctx.needs_input_grad[3]
+        if _is_unit(g):   # the trainer's seed: d loss / d loss = 1
+            return (g_real if ctx.needs_input_grad[0] else None, g_fake if ctx.needs_input_grad[1] else None, None, g_pen if want_pen else None, None)
         return (g_real * g.to(g_real.dtype) if ctx.needs_input_grad[0] else None,
-                g_fake * g.to(g_fake.dtype) if ctx.needs_input_grad[1] else None, None, gp)
+                g_fake * g.to(g_fake.dtype) if ctx.needs_input_grad[1] else None, None, g_pen * g if want_pen else None, None)
 
 
 class _GanGLoss(Function):
@@ -911,12 +932,15 @@ class _GanGLoss(Function):
     @once_differentiable
     def backward(ctx, g):
         g_fake, g_sumsq = ctx.saved_tensors
-        return (g_fake * g.to(g_fake.dtype) if ctx.needs_input_grad[0] else None, None,
-                g_sumsq * g if ctx.has_ms and ctx.needs_input_grad[2] else None, None, None)
+        want_ms = ctx.has_ms and ctx.needs_input_grad[2]
+        if _is_unit(g):
+            return (g_fake if ctx.needs_input_grad[0] else None, None, g_sumsq if want_ms else None, None, None)
+        return (g_fake * g.to(g_fake.dtype) if ctx.needs_input_grad[0] else None, None, g_sumsq * g if want_ms else None, None, None)
 
 
-def gan_d_loss(real_logits, fake_logits, labels, penalty):
-    return _GanDLoss.apply(real_logits, fake_logits, labels, penalty)
+def gan_d_loss(real_logits, fake_logits, labels, penalty, penalty_weight=1.0):
+    """mean(softplus(-r) + softplus(f) + penalty_weight * penalty)."""
+    return _GanDLoss.apply(real_logits, fake_logits, labels, penalty, float(penalty_weight))
 
 
 def gan_g_loss(fake_logits, labels, sumsq, weight, eps):
@@ -936,7 +960,7 @@ class _SumSqRows(Function):
     @once_differentiable
     def backward(ctx, g):
         (x,) = ctx.saved_tensors
-        return _K().row_scale(x, 2.0 * g)
+        return _K().row_scale(x, g, 2.0)
 
 
 def sumsq_rows(x):

@@ -693,28 +693,31 @@ class HipKernels(object):
         _lib.check(self.lib.gs_sumsq_rows(x.data_ptr(), out.data_ptr(), rows, x.numel() // rows, _dt(x), ws.data_ptr(), ws.numel(), _stream()), "gs_sumsq_rows")
         return out
 
-    def row_scale(self, x, s):
+    def row_scale(self, x, s, alpha=1.0):
+        """out[r] = alpha * s[r] * x[r]."""
         x = _act(x)
         s = _f32c(s)
         rows = x.shape[0]
         out = torch.empty_like(x)
-        _lib.check(self.lib.gs_row_scale(x.data_ptr(), s.data_ptr(), out.data_ptr(), rows, x.numel() // rows, _dt(x), _stream()), "gs_row_scale")
+        _lib.check(self.lib.gs_row_scale(x.data_ptr(), s.data_ptr(), float(alpha), out.data_ptr(), rows, x.numel() // rows, _dt(x), _stream()), "gs_row_scale")
         return out
 
-    def gan_d_loss(self, real_logits, fake_logits, labels, penalty):
-        """(loss, g_real_logits, g_fake_logits): mean of softplus(-r) + softplus(f) + penalty and its gradients, one launch."""
+    def gan_d_loss(self, real_logits, fake_logits, labels, penalty, penalty_weight=1.0):
+        """(loss, g_real_logits, g_fake_logits, g_penalty): mean of softplus(-r) + softplus(f) + penalty_weight * penalty and its gradients, one launch."""
         real_logits, fake_logits = _act(real_logits), _act(fake_logits)
         labels = _match(labels, real_logits)
         n, c = real_logits.shape
         loss = torch.empty((), dtype=torch.float32, device=real_logits.device)
         g_real, g_fake = torch.empty_like(real_logits), torch.empty_like(fake_logits)
-        pp = None
+        pp = g_pen = None
         if penalty is not None:
             penalty = _f32c(penalty)
             pp = penalty.data_ptr()
-        _lib.check(self.lib.gs_gan_d_loss(real_logits.data_ptr(), fake_logits.data_ptr(), labels.data_ptr(), pp, n, c, loss.data_ptr(), g_real.data_ptr(),
-                                          g_fake.data_ptr(), _dt(real_logits), _stream()), "gs_gan_d_loss")
-        return loss, g_real, g_fake
+            g_pen = torch.empty((n,), dtype=torch.float32, device=real_logits.device)
+        _lib.check(self.lib.gs_gan_d_loss(real_logits.data_ptr(), fake_logits.data_ptr(), labels.data_ptr(), pp, float(penalty_weight), n, c, loss.data_ptr(),
+                                          g_real.data_ptr(), g_fake.data_ptr(), None if g_pen is None else g_pen.data_ptr(), _dt(real_logits), _stream()),
+                   "gs_gan_d_loss")
+        return loss, g_real, g_fake, g_pen
 
     def gan_g_loss(self, fake_logits, labels, sumsq, weight, eps):
         """(loss, g_fake_logits, g_sumsq): mean of softplus(-f) + weight / (sumsq + eps) and its gradients, one launch."""

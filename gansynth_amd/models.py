@@ -236,7 +236,9 @@ class GANSynth(object):
                     (real_gradients,) = torch.autograd.grad(raw, real_images, grad_outputs=labels.to(raw.dtype), create_graph=True)
                 else:
                     (real_gradients,) = torch.autograd.grad(real_logits.sum(), real_images, create_graph=True)
-            penalty = F.sumsq_rows(real_gradients) * hp.real_gradient_penalty_weight
+            penalty = F.sumsq_rows(real_gradients)
+            if not fused:   # (the fused loss kernel takes the weight itself: no scaling launch, forward or backward)
+                penalty = penalty * hp.real_gradient_penalty_weight
         if hp.get("fake_gradient_penalty_weight", 0.0):
             raise NotImplementedError("fake_gradient_penalty_weight is 0 in the reference configuration (gan_synth_main.py:87)")
         return (raw, penalty) if fused else (TF.softplus(-real_logits), penalty)
@@ -247,7 +249,7 @@ class GANSynth(object):
             fake_images = self.generator(latents, labels)
         _, fake_logits = self.discriminator(fake_images, labels)
         if fused:
-            return F.gan_d_loss(real_part, fake_logits, labels, penalty)
+            return F.gan_d_loss(real_part, fake_logits, labels, penalty, self.hyper_params.real_gradient_penalty_weight or 1.0)
         fake_logits = self._label_logits(fake_logits, labels)
         losses = real_part + TF.softplus(fake_logits)
         if penalty is not None:
@@ -358,7 +360,10 @@ class GANSynth(object):
                    and not getattr(self, "_warming_up", False))
         launched = []
         try:
-            loss.backward()
+            if loss.is_cuda and loss.dim() == 0 and loss.dtype == torch.float32 and not self._capturing_fresh_seed(loss.device):
+                torch.autograd.backward(loss, grad_tensors=F.unit_seed(loss.device))   # (the loss heads recognise the seed: functional.unit_seed)
+            else:
+                loss.backward()
         finally:
             if deferring:
                 if overlap:   # contract the layers bucket by bucket; a finished bucket goes on the wire under the next one's kernels
@@ -373,6 +378,16 @@ class GANSynth(object):
     @staticmethod
     def _capturing():
         return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+
+    def _capturing_fresh_seed(self, device):
+        """True when the constant seed of this device would have to be CREATED inside a stream capture (its memory would belong
+        to that graph's pool): then the plain loss.backward() runs."""
+        if str(torch.device(device)) in F._UNIT:
+            return False
+        if self._capturing():
+            return True
+        F.unit_seed(device)
+        return False
 
     def _forward_backward(self, which, *inputs):
         """Gradients of one run into the flat gradient buffer; returns the (detached) mean loss.

@@ -330,15 +330,15 @@ int gs_axpby_dev(const void* a, const void* b, void* out, int64_t numel, const f
  * row_scale: out[r][j] = s[r] * x[r][j]  (its gradient, s fp32). */
 size_t gs_sumsq_rows_workspace_bytes(int rows);
 int gs_sumsq_rows(const void* x, float* out, int rows, int64_t cols, int dtype, void* ws, size_t ws_bytes, void* stream);
-int gs_row_scale(const void* x, const float* s, void* out, int rows, int64_t cols, int dtype, void* stream);
+int gs_row_scale(const void* x, const float* s, float alpha, void* out, int rows, int64_t cols, int dtype, void* stream);   /* out[r][:] = alpha s[r] x[r][:] */
 
 /* The two GAN losses (models.py:39-65) with their gradients, one launch each.  logits / labels [n][c] in the activation dtype,
  * labels one-hot (real_logit_i = sum_c logits[i][c] * labels[i][c] = tf.gather_nd(logits, tf.where(labels))):
- *   L_D = mean_i [ softplus(-r_i) + softplus(f_i) + penalty_i ]     penalty: optional, already weighted (R1 term), fp32 [n]
+ *   L_D = mean_i [ softplus(-r_i) + softplus(f_i) + penalty_weight penalty_i ]     penalty: optional (R1 term: sum of squared gradients per example), fp32 [n]
  *   L_G = mean_i [ softplus(-f_i) + weight / (sumsq_i + eps) ]       sumsq: optional, sum((d sum(G(z)) / d z_i)^2), fp32 [n]
- * loss: fp32 scalar; g_*: d loss / d logits ([n][c], activation dtype), g_sumsq: d L_G / d sumsq (fp32 [n]); d L_D / d penalty = 1/n. */
-int gs_gan_d_loss(const void* real_logits, const void* fake_logits, const void* labels, const float* penalty, int n, int c, float* loss,
-                  void* g_real, void* g_fake, int dtype, void* stream);
+ * loss: fp32 scalar; g_*: d loss / d logits ([n][c], activation dtype), g_sumsq: d L_G / d sumsq (fp32 [n]); g_penalty: d L_D / d penalty = penalty_weight / n (fp32 [n], written when penalty is given). */
+int gs_gan_d_loss(const void* real_logits, const void* fake_logits, const void* labels, const float* penalty, float penalty_weight, int n, int c,
+                  float* loss, void* g_real, void* g_fake, float* g_penalty, int dtype, void* stream);
 int gs_gan_g_loss(const void* fake_logits, const void* labels, const float* sumsq, float weight, float eps, int n, int c, float* loss,
                   void* g_fake, float* g_sumsq, int dtype, void* stream);
 

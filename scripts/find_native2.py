@@ -17,6 +17,7 @@ class Log(TorchDispatchMode):
     def __init__(self):
         super().__init__()
         self.agg = collections.Counter()
+        self.seq = []
 
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
         name = str(func)
@@ -26,6 +27,11 @@ class Log(TorchDispatchMode):
                 st = [f for f in traceback.extract_stack() if "gansynth_amd" in f.filename]
                 where = " <- ".join("%s:%d" % (os.path.basename(f.filename), f.lineno) for f in st[-3:]) if st else "(engine)"
                 self.agg[(name, str(shapes)[:70], where)] += 1
+                self.seq.append((name, str(shapes)[:70], where))
+        else:
+            st = [f for f in traceback.extract_stack() if "gansynth_amd" in f.filename]
+            if st:
+                self.seq.append(("  .. " + name, "", " <- ".join("%s:%d(%s)" % (os.path.basename(f.filename), f.lineno, f.name) for f in st[-2:])))
         return func(*args, **(kwargs or {}))
 
 
@@ -46,3 +52,12 @@ torch.cuda.synchronize()
 for (name, shapes, where), n in sorted(log.agg.items(), key=lambda kv: (kv[0][2], kv[0][0])):
     print("%3d x %-28s %-72s %s" % (n, name.replace("aten.", ""), shapes, where))
 print("total", sum(log.agg.values()))
+# what runs right behind each op issued by the autograd engine itself (gradient accumulation of a tensor with several consumers)?
+for i, ent in enumerate(log.seq):
+    if ent[2] == "(engine)" and ("add" in ent[0] or "clone" in ent[0]):
+        print("ENGINE", ent[0], ent[1])
+        for e in log.seq[max(0, i - 2):i]:
+            print("      before:", e)
+        for e in log.seq[i + 1:i + 4]:
+            print("      after: ", e)
+

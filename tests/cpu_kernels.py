@@ -208,8 +208,8 @@ class CpuEmuKernels(object):
     def sumsq_rows(self, x):
         return x.detach().float().pow(2).reshape(x.shape[0], -1).sum(dim=1)
 
-    def row_scale(self, x, s):
-        return x.detach() * s.detach().to(x.dtype).view(-1, *([1] * (x.dim() - 1)))
+    def row_scale(self, x, s, alpha=1.0):
+        return x.detach() * (alpha * s.detach()).to(x.dtype).view(-1, *([1] * (x.dim() - 1)))
 
     def adam_tf_step(self, p, g, m, v, lr_t, beta1, beta2, eps, grad_scale=1.0, refresh=True):
         with torch.no_grad():

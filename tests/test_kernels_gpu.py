@@ -218,6 +218,7 @@ def test_axpby_sumsq_rowscale(K, E):
     close(K.sumsq_rows(dev(x)), E.sumsq_rows(x), rel=1e-5)
     s = rnd(8, seed=4)
     close(K.row_scale(dev(x), dev(s)), E.row_scale(x, s), rel=1e-6)
+    close(K.row_scale(dev(x), dev(s), 2.0), 2.0 * E.row_scale(x, s), rel=1e-6)
 
 
 def test_adam_tf_step(K, E):
@@ -750,14 +751,16 @@ def test_gan_losses_in_one_launch(K, dtype):
     lab = torch.nn.functional.one_hot(torch.randint(0, c, (n,), generator=g), c).float()
     pen = (torch.rand(n, generator=g) * 2).requires_grad_(True)
     ssq = (torch.rand(n, generator=g) * 1e-3).requires_grad_(True)
-    ld = (TF.softplus(-(real * lab).sum(1)) + TF.softplus((fake * lab).sum(1)) + pen).mean()
+    ld = (TF.softplus(-(real * lab).sum(1)) + TF.softplus((fake * lab).sum(1)) + 5.0 * pen).mean()
     g_real, g_fake, g_pen = torch.autograd.grad(ld, [real, fake, pen])
-    loss, kr, kf = K.gan_d_loss(dev(real.detach(), dtype), dev(fake.detach(), dtype), dev(lab, dtype), pen.detach().cuda())
+    loss, kr, kf, kp = K.gan_d_loss(dev(real.detach(), dtype), dev(fake.detach(), dtype), dev(lab, dtype), pen.detach().cuda(), 5.0)
+    close(kp, g_pen, rel=1e-6, name="d loss: d/d penalty")
+    assert K.gan_d_loss(dev(real.detach(), dtype), dev(fake.detach(), dtype), dev(lab, dtype), None)[3] is None
     tol = 1e-5 if dtype == torch.float32 else 1e-2
     assert abs(float(loss) - float(ld.detach())) <= 1e-5 * abs(float(ld.detach()))
     close(kr, g_real, rel=tol, name="d loss: d/d real logits")
     close(kf, g_fake, rel=tol, name="d loss: d/d fake logits")
-    assert torch.allclose(g_pen, torch.full((n,), 1.0 / n))
+    assert torch.allclose(g_pen, torch.full((n,), 5.0 / n))
     lg = (TF.softplus(-(fake * lab).sum(1)) + 0.1 / (ssq + 1e-6)).mean()
     g_fake2, g_ssq = torch.autograd.grad(lg, [fake, ssq])
     loss, kf, ks = K.gan_g_loss(dev(fake.detach(), dtype), dev(lab, dtype), ssq.detach().cuda(), 0.1, 1e-6)
