@@ -82,7 +82,7 @@ SIGNATURES = {
     "gs_upscale2d": (I, [P, P, I, I, I, I, I, I, F, I, P]),
     "gs_blocksum2d": (I, [P, P, I, I, I, I, I, I, F, I, P]),
     "gs_batch_stddev_fwd": (I, [P, P, I, I, I, F, I, P]),
-    "gs_batch_stddev_bwd": (I, [P, P, P, I, I, I, F, I, P]),
+    "gs_batch_stddev_bwd": (I, [P, P, P, P, I, I, I, F, I, P]),
     "gs_batch_stddev_bwd_bwd": (I, [P, P, P, P, P, I, I, I, F, I, P]),
     "gs_axpby": (I, [P, P, P, L, F, F, I, P]),
     "gs_axpby_dev": (I, [P, P, P, L, P, I, I, I, P]),

@@ -403,10 +403,12 @@ __global__ __launch_bounds__(BS_NT) void batch_stddev_fwd_kernel(const T* __rest
     }
 }
 
-// gx_i = gs_j * d_i / (4 sigma N),  gs_j = sum over members/pixels of gy
+// gx_i = gs_j * d_i / (4 sigma N) (+ addend_i),  gs_j = sum over members/pixels of gy
+// addend (optional): the OTHER gradient into x -- x feeds the statistic and the conv beside it (networks.py:174-176), the sum of the two
+// gradients is formed here instead of by one more pass
 template <typename T, int VN>
-__global__ __launch_bounds__(BS_NT) void batch_stddev_bwd_kernel(const T* __restrict__ gy, const T* __restrict__ x, T* __restrict__ gx,
-                                                                 int M, int hw, int c, float eps) {
+__global__ __launch_bounds__(BS_NT) void batch_stddev_bwd_kernel(const T* __restrict__ gy, const T* __restrict__ x, const T* __restrict__ addend,
+                                                                 T* __restrict__ gx, int M, int hw, int c, float eps) {
     __shared__ float red[BS_NT / 64];
     const int j = blockIdx.x;
     const long npos = (long)hw * c;
@@ -426,6 +428,13 @@ __global__ __launch_bounds__(BS_NT) void batch_stddev_bwd_kernel(const T* __rest
             const float inv = coef / sqrtf(0.25f * var + eps);
 #pragma unroll
             for (int i = 0; i < 4; ++i) o[i][e] = (v[i][e] - mu) * inv;
+        }
+        if (addend) {
+            bs_load<T, VN>(addend, M, j, pos, npos, v);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int e = 0; e < VN; ++e) o[i][e] += v[i][e];
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) bs_st<T, VN>(gx + ((long)(i * M + j)) * npos + pos, o[i]);
@@ -688,11 +697,11 @@ extern "C" int gs_batch_stddev_fwd(const void* x, void* y, int b, int hw, int c,
     return 0;
 }
 
-extern "C" int gs_batch_stddev_bwd(const void* gy, const void* x, void* gx, int b, int hw, int c, float eps, int dtype, void* stream) {
+extern "C" int gs_batch_stddev_bwd(const void* gy, const void* x, const void* addend, void* gx, int b, int hw, int c, float eps, int dtype, void* stream) {
     GS_CHECK_ARG(b > 0 && b % 4 == 0 && hw > 0 && c > 0, "batch_stddev_bwd: bad args");
     GS_DISPATCH_DTYPE(dtype, {
-        if (((long)hw * c) % Wide<T>::N == 0) hipLaunchKernelGGL((batch_stddev_bwd_kernel<T, Wide<T>::N>), dim3(b / 4), dim3(BS_NT), 0, as_stream(stream), (const T*)gy, (const T*)x, (T*)gx, b / 4, hw, c, eps);
-        else hipLaunchKernelGGL((batch_stddev_bwd_kernel<T, 1>), dim3(b / 4), dim3(BS_NT), 0, as_stream(stream), (const T*)gy, (const T*)x, (T*)gx, b / 4, hw, c, eps);
+        if (((long)hw * c) % Wide<T>::N == 0) hipLaunchKernelGGL((batch_stddev_bwd_kernel<T, Wide<T>::N>), dim3(b / 4), dim3(BS_NT), 0, as_stream(stream), (const T*)gy, (const T*)x, (const T*)addend, (T*)gx, b / 4, hw, c, eps);
+        else hipLaunchKernelGGL((batch_stddev_bwd_kernel<T, 1>), dim3(b / 4), dim3(BS_NT), 0, as_stream(stream), (const T*)gy, (const T*)x, (const T*)addend, (T*)gx, b / 4, hw, c, eps);
     });
     GS_CHECK_LAUNCH();
     return 0;

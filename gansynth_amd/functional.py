@@ -786,22 +786,47 @@ class _BatchStddev(Function):
 
 
 class _BatchStddevBwd(Function):
+    """batch_stddev_bwd(gy, x) + addend (the other gradient into x, when the statistic was taken with a tap)."""
+
     @staticmethod
-    def forward(ctx, gy, x, eps):
+    def forward(ctx, gy, x, eps, addend=None):
         ctx.eps = eps
         ctx.save_for_backward(gy, x)
-        return _K().batch_stddev_bwd(gy, x, eps)
+        return _K().batch_stddev_bwd(gy, x, eps, addend=addend)
 
     @staticmethod
     @once_differentiable
     def backward(ctx, ggx):
         gy, x = ctx.saved_tensors
         ggy, gx2 = _K().batch_stddev_bwd_bwd(ggx, gy, x, ctx.eps)
-        return ggy, gx2, None
+        return ggy, gx2, None, (ggx if ctx.needs_input_grad[3] else None)
 
 
 def batch_stddev(x, eps):
     return _BatchStddev.apply(x, eps)
+
+
+class _BatchStddevTap(Function):
+    """(x, batch_stddev(x)) with x passed through: the caller hands the FIRST output to whatever else consumes x (the conv beside the
+    statistic, networks.py:174-176), so that x has one consumer in the graph and the two gradients into it are summed inside the
+    statistic's backward kernel instead of by the autograd engine (one launch per backward pass through the block)."""
+
+    @staticmethod
+    def forward(ctx, x, eps):
+        ctx.eps = eps
+        ctx.save_for_backward(x)
+        return x.view_as(x), _K().batch_stddev_fwd(x, eps)
+
+    @staticmethod
+    def backward(ctx, gx, gs):
+        (x,) = ctx.saved_tensors
+        if gs is None:
+            return gx, None
+        return _BatchStddevBwd.apply(gs, x, ctx.eps, gx), None
+
+
+def batch_stddev_tap(x, eps):
+    return _BatchStddevTap.apply(x, eps)
 
 
 # --------------------------------------------------------------------------------- lerp
@@ -866,9 +891,13 @@ class _Axpby(Function):
     @staticmethod
     def backward(ctx, g):
         ca, cb = ctx.c
-        ga = _Axpby.apply(g, g, ca, _coef_zero(ca)) if ctx.needs_input_grad[0] else None
-        gb = _Axpby.apply(g, g, _coef_zero(cb), cb) if ctx.needs_input_grad[1] else None
-        return ga, gb, None, None
+
+        def scaled(coef, first):   # (a plain 1.0: the gradient itself, no launch)
+            if isinstance(coef, float) and coef == 1.0:
+                return g
+            return _Axpby.apply(g, g, coef, _coef_zero(coef)) if first else _Axpby.apply(g, g, _coef_zero(coef), coef)
+
+        return (scaled(ca, True) if ctx.needs_input_grad[0] else None, scaled(cb, False) if ctx.needs_input_grad[1] else None, None, None)
 
 
 def axpby(a, b, ca, cb):

@@ -651,12 +651,17 @@ class HipKernels(object):
         _lib.check(self.lib.gs_batch_stddev_fwd(x.data_ptr(), y.data_ptr(), n, h * w, c, float(eps), _dt(x), _stream()), "gs_batch_stddev_fwd")
         return y
 
-    def batch_stddev_bwd(self, gy, x, eps):
+    def batch_stddev_bwd(self, gy, x, eps, addend=None):
+        """d batch_stddev(x) / d x applied to gy, plus `addend` (another gradient into x) in the same pass."""
         x = _act(x)
         n, c, h, w = x.shape
         gy = _act(gy.to(x.dtype))
         gx = torch.empty_like(x)
-        _lib.check(self.lib.gs_batch_stddev_bwd(gy.data_ptr(), x.data_ptr(), gx.data_ptr(), n, h * w, c, float(eps), _dt(x), _stream()),
+        ap = None
+        if addend is not None:
+            addend = _match(addend, x)
+            ap = addend.data_ptr()
+        _lib.check(self.lib.gs_batch_stddev_bwd(gy.data_ptr(), x.data_ptr(), ap, gx.data_ptr(), n, h * w, c, float(eps), _dt(x), _stream()),
                    "gs_batch_stddev_bwd")
         return gx
 

@@ -151,7 +151,7 @@ class PGGAN(object):
                 # networks.py:174-184: conv(concat([x, batch_stddev(x)])).  The 257-channel conv is
                 # evaluated as conv(x; w[:,:,:c]) + conv(stddev; w[:,:,c:]) -- same variable, same
                 # fan-in scale, no 257-wide tensor (257 is not an MFMA-friendly K).
-                stddev = ops.batch_stddev(x)
+                x, stddev = ops.batch_stddev_tap(x)   # (x through the tap: one consumer, the two gradients summed in one kernel)
                 with variable_scope("conv"):
                     weight, alpha = ops.get_weight([3, 3, c + 1, c], 2.0, True)
                     bias = ops.get_bias([c])

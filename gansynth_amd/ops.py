@@ -121,6 +121,18 @@ def batch_stddev(inputs, groups=4, epsilon=1.0e-12):
     return F.batch_stddev(inputs, epsilon)
 
 
+def batch_stddev_tap(inputs, groups=4, epsilon=1.0e-12):
+    """(inputs, batch_stddev(inputs)): ops.py:336-348 for a caller that also feeds `inputs` to another op -- it uses the returned
+    alias there, and the backward sums the two gradients into `inputs` in the statistic's own kernel (functional._BatchStddevTap)."""
+    if groups != 4:
+        raise ValueError("batch_stddev: the reference graph uses groups=4 (networks.py:174)")
+    if inputs.shape[0] % groups:
+        raise ValueError(f"batch_stddev: batch {inputs.shape[0]} is not a multiple of groups={groups} (ops.py:341)")
+    if not hasattr(F, "batch_stddev_tap"):
+        return inputs, F.batch_stddev(inputs, epsilon)
+    return F.batch_stddev_tap(inputs, epsilon)
+
+
 def leaky_relu(inputs):
     """tf.nn.leaky_relu (alpha 0.2)."""
     return F.bias_act(inputs, None, ACT_LRELU)

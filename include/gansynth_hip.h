@@ -316,7 +316,8 @@ int gs_blocksum2d(const void* x, void* y, int n, int h, int w, int c, int fy, in
 /* batch_stddev (ops.py:336-348), groups = 4: x [b][h][w][c] -> y [b][h][w][1], b % 4 == 0.
  *   bwd: gx from gy ; bwd_bwd: (ggy, gx2) = gradients of <ggx, bwd(gy, x)> w.r.t. gy and x. */
 int gs_batch_stddev_fwd(const void* x, void* y, int b, int hw, int c, float eps, int dtype, void* stream);
-int gs_batch_stddev_bwd(const void* gy, const void* x, void* gx, int b, int hw, int c, float eps, int dtype, void* stream);
+/* (addend, optional: the other gradient into x -- that of the conv beside the statistic, networks.py:174-176 -- added in the same pass) */
+int gs_batch_stddev_bwd(const void* gy, const void* x, const void* addend, void* gx, int b, int hw, int c, float eps, int dtype, void* stream);
 int gs_batch_stddev_bwd_bwd(const void* ggx, const void* gy, const void* x, void* ggy, void* gx2,
                             int b, int hw, int c, float eps, int dtype, void* stream);
 

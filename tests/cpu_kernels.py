@@ -188,11 +188,11 @@ class CpuEmuKernels(object):
     def batch_stddev_fwd(self, x, eps):
         return R.batch_stddev(x.detach(), 4, eps)
 
-    def batch_stddev_bwd(self, gy, x, eps):
+    def batch_stddev_bwd(self, gy, x, eps, addend=None):
         with torch.enable_grad():
             xx = x.detach().clone().requires_grad_(True)
             (gx,) = torch.autograd.grad(R.batch_stddev(xx, 4, eps), xx, gy.detach())
-        return gx
+        return gx if addend is None else gx + addend.detach()
 
     def batch_stddev_bwd_bwd(self, ggx, gy, x, eps):
         with torch.enable_grad():

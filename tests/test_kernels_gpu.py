@@ -204,6 +204,7 @@ def test_batch_stddev_all_orders(K, E, b, c, h, w):
     eps = 1e-12
     close(K.batch_stddev_fwd(dev(x), eps), E.batch_stddev_fwd(x, eps), rel=1e-5, name="fwd")
     close(K.batch_stddev_bwd(dev(gy), dev(x), eps), E.batch_stddev_bwd(gy, x, eps), rel=1e-4, name="bwd")
+    close(K.batch_stddev_bwd(dev(gy), dev(x), eps, addend=dev(0.5 * x)), E.batch_stddev_bwd(gy, x, eps, addend=0.5 * x), rel=1e-4, name="bwd + addend")
     ggy, gx2 = K.batch_stddev_bwd_bwd(dev(ggx), dev(gy), dev(x), eps)
     rggy, rgx2 = E.batch_stddev_bwd_bwd(ggx, gy, x, eps)
     close(ggy, rggy, rel=1e-4, name="bwd_bwd.ggy")
