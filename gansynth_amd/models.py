@@ -265,7 +265,7 @@ class GANSynth(object):
         fake_images = self.generator(latents, labels)
         mode_seeking = None
         if hp.mode_seeking_loss_weight:
-            ones = torch.ones_like(fake_images)  # tf.gradients(ys) sums ys
+            ones = self._ones_like(fake_images)  # tf.gradients(ys) sums ys
             with F.data_grads_only():   # tf.gradients(fake_images, [latents]) (models.py:60)
                 (latent_gradients,) = torch.autograd.grad(fake_images, latents, grad_outputs=ones, create_graph=True)
             if fused:
@@ -378,6 +378,18 @@ class GANSynth(object):
     @staticmethod
     def _capturing():
         return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+
+    def _ones_like(self, t):
+        """A constant all-ones tensor of t's shape, layout and dtype, filled once (never written afterwards; a fill created inside a
+        stream capture would belong to that graph's pool, so there the plain ones_like runs)."""
+        cache = self.__dict__.setdefault("_ones_cache", {})
+        key = (tuple(t.shape), tuple(t.stride()), t.dtype, str(t.device))
+        ones = cache.get(key)
+        if ones is None:
+            ones = torch.ones_like(t)
+            if not self._capturing():
+                cache[key] = ones
+        return ones
 
     def _capturing_fresh_seed(self, device):
         """True when the constant seed of this device would have to be CREATED inside a stream capture (its memory would belong
