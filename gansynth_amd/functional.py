@@ -191,13 +191,16 @@ class _WeightSlice(Function):
     @staticmethod
     def forward(ctx, w, lo, hi):
         ctx.lo, ctx.hi, ctx.wref = lo, hi, w
-        K = _K()
+        ctx.set_materialize_grads(False)   # (the convs add their gradients into the slice of w.grad themselves and hand None back: without this
+        K = _K()                           #  the engine calls backward with zeros -- a fill and a strided add of nothing per slice and pass)
         if _DERIVED_SLICES and hasattr(K, "derived_slice"):   # persistent copy, refreshed with the parameter (kernels.derived_slice)
             return K.derived_slice(w, lo, hi)
         return w[:, :, lo:hi, :].contiguous()
 
     @staticmethod
     def backward(ctx, g):
+        if g is None:
+            return None, None, None
         tgt = _accum_target(ctx.wref)
         if tgt is not None:
             tgt[:, :, ctx.lo:ctx.hi, :].add_(g)
@@ -359,6 +362,8 @@ class _BwdDataMasked(Function):
         g_w = None
         if ctx.needs_input_grad[1]:
             tgt = _accum_target(ctx.wref)
+            if tgt is None:
+                tgt = _slice_target(ctx.wref, t, gy, ctx.kind)
             if tgt is not None:   # second-order term of the penalty, added straight into w.grad
                 ctx.kind.bwd_weight(t, gy, ctx.alpha, out=tgt)
             else:
