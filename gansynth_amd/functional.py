@@ -819,6 +819,7 @@ class _BatchStddevTap(Function):
     @staticmethod
     def forward(ctx, x, eps):
         ctx.eps = eps
+        ctx.set_materialize_grads(False)
         ctx.save_for_backward(x)
         return x.view_as(x), _K().batch_stddev_fwd(x, eps)
 
@@ -827,7 +828,7 @@ class _BatchStddevTap(Function):
         (x,) = ctx.saved_tensors
         if gs is None:
             return gx, None
-        return _BatchStddevBwd.apply(gs, x, ctx.eps, gx), None
+        return _BatchStddevBwd.apply(gs, x, ctx.eps, gx), None   # (gx None: the statistic's gradient alone)
 
 
 def batch_stddev_tap(x, eps):
