@@ -40,6 +40,27 @@ def test_argument_validation_without_gpu():
     assert lib.gs_conv2d_fwd(None, None, None, 1, 7, 8, 32, 32, 3, 2, 1.0, 0, 0, None, 0, None) == -1
 
 
+def test_bias_fold_planning_without_gpu():
+    """Host arithmetic of the deferred bias folds (GS_SUM_PARTIALS / gs_channel_fold_batch): rows a producer leaves, the second-level
+    workspace, argument checks -- no launch."""
+    import ctypes
+    from gansynth_amd import _lib
+    lib = _lib.load()
+    rows = lib.gs_bias_partial_rows
+    assert rows(_lib.BIAS_FROM_CHANNEL_SUM, 8, 8192, _lib.GS_BF16) == 0            # few rows, many channels: summed directly
+    assert rows(_lib.BIAS_FROM_CHANNEL_SUM, 8 * 128 * 1024, 32, _lib.GS_BF16) == 2048   # capped
+    assert 0 < rows(_lib.BIAS_FROM_ACT_BWD, 8 * 2 * 16, 256, _lib.GS_BF16) <= 64
+    assert rows(_lib.BIAS_FROM_PIXEL_NORM_BWD, 8 * 2 * 16, 48, _lib.GS_BF16) == 0  # not a power of two: the entry point refuses it
+    assert rows(_lib.BIAS_FROM_PIXEL_NORM_BWD, 8 * 128 * 1024, 32, _lib.GS_BF16) > 64
+    jobs = (_lib.GsFoldJob * 3)()
+    for jb, (n, c) in zip(jobs, [(2048, 32), (16, 256), (65, 64)]):
+        jb.part, jb.out, jb.nparts, jb.c, jb.accumulate = 0x1000, 0x2000, n, c, 1
+    ptr = ctypes.cast(jobs, ctypes.c_void_p)
+    assert lib.gs_channel_fold_batch_workspace_bytes(ptr, 3) == (32 * 32 + 2 * 64) * 4   # slab sums of the jobs with more than 64 rows
+    assert lib.gs_channel_fold_batch(ptr, 0, None, 0, None) == -1
+    assert lib.gs_channel_fold_batch(ptr, 3, None, 0, None) != 0 and b"workspace" in lib.gs_last_error()
+
+
 @pytest.mark.skipif(torch.cuda.is_available(), reason="only meaningful on a GPU-less host")
 def test_no_silent_fallback_without_device():
     from gansynth_amd import kernels, _lib
