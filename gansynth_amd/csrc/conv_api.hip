@@ -131,11 +131,30 @@ __global__ __launch_bounds__(256) void thin_expand_kernel(const T* __restrict__ 
     const int groups = OC / WN;
     const int oc0 = (threadIdx.x % groups) * WN;
     float wr[WN][IC], br[WN];
+    {   // this lane's WN x IC weights and WN biases: contiguous floats, fetched as 16-byte vectors (a scalar load each made the prologue of
+        // a block cost as much as its pixels: 22.8 us at 4096 blocks, 51 us at 16384, scripts/bench_thin.py)
+        typedef float f4_t __attribute__((ext_vector_type(4)));
+        float flat[WN * IC];
+        if constexpr ((WN * IC) % 4 == 0) {
 #pragma unroll
-    for (int v = 0; v < WN; ++v) {
-        br[v] = bias ? bias[oc0 + v] : 0.f;
+            for (int q = 0; q < WN * IC / 4; ++q) {
+                const f4_t t = *reinterpret_cast<const f4_t*>(wp + (long)oc0 * IC + 4 * q);
+                flat[4 * q] = t.x; flat[4 * q + 1] = t.y; flat[4 * q + 2] = t.z; flat[4 * q + 3] = t.w;
+            }
+        } else {
 #pragma unroll
-        for (int i = 0; i < IC; ++i) wr[v][i] = wp[(oc0 + v) * IC + i] * alpha;
+            for (int q = 0; q < WN * IC; ++q) flat[q] = wp[(long)oc0 * IC + q];
+        }
+#pragma unroll
+        for (int v = 0; v < WN; ++v)
+#pragma unroll
+            for (int i = 0; i < IC; ++i) wr[v][i] = flat[v * IC + i] * alpha;
+#pragma unroll
+        for (int q = 0; q < WN / 4; ++q) {
+            f4_t t = {0.f, 0.f, 0.f, 0.f};
+            if (bias) t = *reinterpret_cast<const f4_t*>(bias + oc0 + 4 * q);
+            br[4 * q] = t.x; br[4 * q + 1] = t.y; br[4 * q + 2] = t.z; br[4 * q + 3] = t.w;
+        }
     }
     const long ppb = 256 / groups;  // pixels per block pass
     const long stride = (long)gridDim.x * ppb;
@@ -151,19 +170,26 @@ __global__ __launch_bounds__(256) void thin_expand_kernel(const T* __restrict__ 
         }
         st_wide<T>(y + px * OC + oc0, o);
     };
+    auto ldpix = [&](long px, float* xv) __attribute__((always_inline)) {
+        if constexpr (IC == 2 && sizeof(T) == 2) {   // both colour channels of a pixel in one 4-byte load
+            const unsigned u = *reinterpret_cast<const unsigned*>(x + px * 2);
+            xv[0] = __uint_as_float(u << 16);
+            xv[1] = __uint_as_float(u & 0xffff0000u);
+        } else {
+#pragma unroll
+            for (int i = 0; i < IC; ++i) xv[i] = DT<T>::ld(x + px * IC + i);
+        }
+    };
     for (; pix + 3 * stride < P; pix += 4 * stride) {   // four pixels per trip (loads first)
         float xv[4][IC];
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-#pragma unroll
-            for (int i = 0; i < IC; ++i) xv[k][i] = DT<T>::ld(x + (pix + k * stride) * IC + i);
+        for (int k = 0; k < 4; ++k) ldpix(pix + k * stride, xv[k]);
 #pragma unroll
         for (int k = 0; k < 4; ++k) one(pix + k * stride, xv[k]);
     }
     for (; pix < P; pix += stride) {
         float xv[IC];
-#pragma unroll
-        for (int i = 0; i < IC; ++i) xv[i] = DT<T>::ld(x + pix * IC + i);
+        ldpix(pix, xv);
         one(pix, xv);
     }
 }
@@ -183,7 +209,44 @@ __global__ __launch_bounds__(256) void thin_reduce_kernel(const T* __restrict__ 
         for (int i = 0; i < WN; ++i) wr[v][i] = wp[v * IC + l * WN + i] * alpha;
     const long ppb = 256 / L;
     const long npass = (P + (long)gridDim.x * ppb - 1) / ((long)gridDim.x * ppb);  // same trip count for every lane (shuffles)
-    for (long k = 0; k < npass; ++k) {
+    float bv[OC];
+#pragma unroll
+    for (int v = 0; v < OC; ++v) bv[v] = bias ? bias[v] : 0.f;
+    auto finish = [&](long pix, float* a) __attribute__((always_inline)) {
+        for (int o = L >> 1; o > 0; o >>= 1)
+#pragma unroll
+            for (int v = 0; v < OC; ++v) a[v] += __shfl_xor(a[v], o, 64);
+        if (pix < P && l == 0) {
+            if constexpr (OC == 2 && sizeof(T) == 2) {   // both colour channels of a pixel in one 4-byte store
+                *reinterpret_cast<unsigned*>(y + pix * 2) = pack_bf16x2(thin_act(a[0] + bv[0], act), thin_act(a[1] + bv[1], act));
+            } else {
+#pragma unroll
+                for (int v = 0; v < OC; ++v) DT<T>::st(y + pix * OC + v, thin_act(a[v] + bv[v], act));
+            }
+        }
+    };
+    constexpr int U = 4;   // pixels per trip: their loads go out together
+    long k = 0;
+    for (; k + U <= npass; k += U) {
+        float xv[U][WN], a[U][OC];
+        long pix[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            pix[u] = ((k + u) * gridDim.x + blockIdx.x) * ppb + threadIdx.x / L;
+            ld_wide<T>(x + (pix[u] < P ? pix[u] : 0) * IC + l * WN, xv[u]);   // (clamped: the loads stay unconditional)
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int v = 0; v < OC; ++v) {
+                a[u][v] = 0.f;
+#pragma unroll
+                for (int i = 0; i < WN; ++i) a[u][v] += xv[u][i] * wr[v][i];
+            }
+            finish(pix[u], a[u]);
+        }
+    }
+    for (; k < npass; ++k) {
         const long pix = (k * gridDim.x + blockIdx.x) * ppb + threadIdx.x / L;
         float a[OC];
 #pragma unroll
@@ -196,13 +259,7 @@ __global__ __launch_bounds__(256) void thin_reduce_kernel(const T* __restrict__ 
 #pragma unroll
                 for (int i = 0; i < WN; ++i) a[v] += xv[i] * wr[v][i];
         }
-        for (int o = L >> 1; o > 0; o >>= 1)
-#pragma unroll
-            for (int v = 0; v < OC; ++v) a[v] += __shfl_xor(a[v], o, 64);
-        if (pix < P && l == 0) {
-#pragma unroll
-            for (int v = 0; v < OC; ++v) DT<T>::st(y + pix * OC + v, thin_act(a[v] + (bias ? bias[v] : 0.f), act));
-        }
+        finish(pix, a);
     }
 }
 
@@ -255,7 +312,9 @@ static int run_direct(int mode, int ks, int variant, const void* x, const float*
     const int wn = dtype == GS_F32 ? 4 : 8;
     if (ks == 1 && mode == MODE_S1 && ICk <= 4 && OCk % wn == 0 && 256 % (OCk / wn) == 0) {   // colour -> features
         long nb = cdiv(P * (OCk / wn), 256);
-        if (nb > 4096) nb = 4096;
+        // (2048 blocks: 18.5 us for the 67 MB of the top level against 19.4 at 4096 and 23.0 at 8192 -- every block pays the weight prologue)
+        static const long te_cap = getenv("GS_THIN_EXPAND_BLOCKS") ? atol(getenv("GS_THIN_EXPAND_BLOCKS")) : 2048;
+        if (nb > te_cap) nb = te_cap;
         const unsigned grid = (unsigned)nb;
 #define GS_TE(TT, ICV) hipLaunchKernelGGL((thin_expand_kernel<TT, ICV>), dim3(grid), dim3(256), 0, st, (const TT*)x, wp, bias, (TT*)y, P, OCk, alpha, act)
 #define GS_TE_ALL(TT) do { if (ICk == 1) GS_TE(TT, 1); else if (ICk == 2) GS_TE(TT, 2); else if (ICk == 3) GS_TE(TT, 3); else GS_TE(TT, 4); } while (0)
@@ -270,7 +329,8 @@ static int run_direct(int mode, int ks, int variant, const void* x, const float*
     const int lanes = ICk / wn;
     if (ks == 1 && mode == MODE_S1 && OCk <= 4 && ICk % wn == 0 && lanes <= 64 && (lanes & (lanes - 1)) == 0) {  // features -> colour
         long nb = cdiv(P * lanes, 256);
-        if (nb > 4096) nb = 4096;
+        static const long tr_cap = getenv("GS_THIN_REDUCE_BLOCKS") ? atol(getenv("GS_THIN_REDUCE_BLOCKS")) : 4096;
+        if (nb > tr_cap) nb = tr_cap;
         const unsigned grid = (unsigned)nb;
 #define GS_TR(TT, OCV) hipLaunchKernelGGL((thin_reduce_kernel<TT, OCV>), dim3(grid), dim3(256), 0, st, (const TT*)x, wp, bias, (TT*)y, P, ICk, alpha, act)
 #define GS_TR_ALL(TT) do { if (OCk == 1) GS_TR(TT, 1); else if (OCk == 2) GS_TR(TT, 2); else if (OCk == 3) GS_TR(TT, 3); else GS_TR(TT, 4); } while (0)
