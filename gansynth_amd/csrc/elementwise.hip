@@ -13,7 +13,8 @@ namespace gs {
 
 static inline int ew_grid(long nvec) {
     long g = (nvec + 255) / 256;
-    if (g > 8192) g = 8192;  // grid-stride the rest (256 CUs x 8 blocks x 4)
+    static const long cap = getenv("GS_EW_GRID_CAP") ? atol(getenv("GS_EW_GRID_CAP")) : 8192;   // (measurement knob)
+    if (g > cap) g = cap;  // grid-stride the rest (256 CUs x 8 blocks x 4)
     if (g < 1) g = 1;
     return (int)g;
 }
@@ -817,12 +818,17 @@ extern "C" int gs_act_bwd_bias(const void* g, const void* y, void* gx, float* gb
     return channel_sum_finalize(part, gb, nparts, c, accumulate, st);
 }
 
-static int pixel_norm_grid(long p, int c, int wn) {
+static int pixel_norm_grid(long p, int c, int wn, bool bias_sums = false) {
     const int E = c % wn == 0 ? wn : 4;
     const int vecs = c / E, L = vecs < 64 ? vecs : 64, P = vecs / L;
     const int U = P == 1 ? 2 : 1;
     const long rows_per_block = 4L * (64 / L) * U;
-    return ew_grid((p + rows_per_block - 1) / rows_per_block * 256);
+    int g = ew_grid((p + rows_per_block - 1) / rows_per_block * 256);
+    if (bias_sums) {   // every block ends with a cross-lane + LDS fold of its channel sums and one partial row: as many trips per block as
+        static const int cap = getenv("GS_PN_BIAS_GRID_CAP") ? atoi(getenv("GS_PN_BIAS_GRID_CAP")) : 1024;   // the plain pass has blocks
+        if (g > cap) g = cap;   // (top level, 32 channels: 61.5 us at 8192 blocks, 50.5 at 1024 -- 42.3 without the sums; scripts/bench_ew.py)
+    }
+    return g;
 }
 template <typename T, int MODE, bool BS = false>
 static void pixel_norm_launch_t(const void* a0, const void* a1, const void* a2, void* out, long p, int c, float eps, int act, int pre, const void* addend,
@@ -830,7 +836,7 @@ static void pixel_norm_launch_t(const void* a0, const void* a1, const void* a2, 
     constexpr int WN = Wide<T>::N;
     const int E = c % WN == 0 ? WN : 4;
     const int vecs = c / E, L = vecs < 64 ? vecs : 64, P = vecs / L;   // P in {1, 2, 4}
-    dim3 grid(pixel_norm_grid(p, c, WN));
+    dim3 grid(pixel_norm_grid(p, c, WN, BS));
 #define GS_PN(EE, PP, UU)                                                                                                          \
     hipLaunchKernelGGL((pixel_norm_kernel<T, MODE, EE, PP, UU, BS>), grid, dim3(256), 0, st, (const T*)a0, (const T*)a1, (const T*)a2, (T*)out, p, c, eps, \
                        act, pre, (const T*)addend, (T*)out2, bsum)
@@ -867,7 +873,7 @@ extern "C" int gs_pixel_norm_bwd_fused(const void* g, const void* x, const void*
 }
 // ... and the per-channel sums of gx on the side (gb (+)= sum over pixels: the bias gradient of the conv block that produced x)
 extern "C" size_t gs_pixel_norm_bwd_bias_workspace_bytes(int64_t p, int c, int dtype) {
-    const int nb = pixel_norm_grid((long)p, c, dtype == GS_F32 ? 4 : 8);
+    const int nb = pixel_norm_grid((long)p, c, dtype == GS_F32 ? 4 : 8, true);
     return (size_t)(nb + cdiv(nb, CS_SLAB)) * c * sizeof(float);
 }
 extern "C" int gs_pixel_norm_bwd_fused_bias(const void* g, const void* x, const void* addend, void* gx, float* gb, int64_t p, int c, float eps, int pre_act,
@@ -876,7 +882,7 @@ extern "C" int gs_pixel_norm_bwd_fused_bias(const void* g, const void* x, const 
     GS_CHECK_ARG(p > 0 && c >= 4 && c <= 1024 && (c & (c - 1)) == 0 && gb && g && x && gx, "pixel_norm_bwd_fused_bias: bad args (c=%d)", c);
     const bool partials_only = (accumulate & GS_SUM_PARTIALS) != 0;
     accumulate &= 1;
-    const int nb = pixel_norm_grid((long)p, c, dtype == GS_F32 ? 4 : 8);
+    const int nb = pixel_norm_grid((long)p, c, dtype == GS_F32 ? 4 : 8, true);
     if (ws_bytes < (partials_only ? (size_t)nb * c * sizeof(float) : gs_pixel_norm_bwd_bias_workspace_bytes(p, c, dtype)))
         return fail(GS_ERR_WORKSPACE, "pixel_norm_bwd_fused_bias: workspace too small");
     hipStream_t st = as_stream(stream);
@@ -892,7 +898,7 @@ extern "C" int gs_bias_partial_rows(int producer, int64_t p, int c, int dtype) {
     switch (producer) {
         case GS_BIAS_FROM_CHANNEL_SUM: return (p <= 64 && c >= 256) ? 0 : channel_sum_parts(p, c);
         case GS_BIAS_FROM_ACT_BWD: return (!act_fast && p <= 64 && c >= 256) ? 0 : channel_sum_parts(p, c);
-        case GS_BIAS_FROM_PIXEL_NORM_BWD: return (c >= 4 && c <= 1024 && (c & (c - 1)) == 0) ? pixel_norm_grid((long)p, c, dtype == GS_F32 ? 4 : 8) : 0;
+        case GS_BIAS_FROM_PIXEL_NORM_BWD: return (c >= 4 && c <= 1024 && (c & (c - 1)) == 0) ? pixel_norm_grid((long)p, c, dtype == GS_F32 ? 4 : 8, true) : 0;
         default: return 0;
     }
 }
