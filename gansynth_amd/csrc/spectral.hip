@@ -693,7 +693,9 @@ extern "C" int gs_mel_if_to_waveform(const gs_spectral_plan* p, const void* imag
     // stacked in the workspace, so they are ONE GEMM with 2 x rows
     if (split) {
         // 128 x 128 tiles, two blocks per CU (GS_INVERSE_GEMM_256: 128 x 256 tiles, one block per CU -- half the passes over A, but
-        // measured 1 % SLOWER: the kernel is not L2-bound, it sits at the ~0.95 PFLOP/s every bf16 MFMA kernel of this build reaches)
+        // measured 1 % SLOWER: the kernel is not L2-bound.  PMC (profiles/r02_u_inverse_pmc.txt): the MFMA pipe is busy 54 % of the phase rows'
+        // launch and 34 % of the magnitude rows'; the loop is 48 MFMAs + 24 ds_read_b128 + 12 global loads + 12 ds_write_b128 + 2 barriers, and
+        // the two barriers of the single-buffered LDS tile are what the second block of the CU does not fully cover)
         static const bool wide = getenv("GS_INVERSE_GEMM_256") != nullptr;
         const int M2 = (int)(2 * rows);
         const unsigned gw = (unsigned)(H / (wide && H % 256 == 0 ? 256 : 128));
