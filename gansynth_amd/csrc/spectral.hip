@@ -337,7 +337,16 @@ void gemm_bf16x6_kernel(const unsigned short* __restrict__ Asplit, const unsigne
     typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, hi = lane >> 5, l31 = lane & 31;
     const int nb = N / BN;
-    const int m0 = m_begin + (blockIdx.x / nb) * 128, n0 = (blockIdx.x % nb) * BN;
+    // XCD-aware tile order: block b runs on XCD b % 8, and the nb column tiles of one 128-row slab of A (the big operand: 0.8 MB per slab
+    // and plane set) must meet in ONE XCD's L2 -- with the plain order they sat on eight XCDs and A crossed the fabric eight times
+    // (1.9 GB fetched per launch for 0.2 GB of operands, 4.8 TB/s: the kernel was HBM-bound, profiles/r02_u_inverse_pmc_traffic.json)
+    int mblk = blockIdx.x / nb, nblk = blockIdx.x % nb;
+    if (((gridDim.x / nb) & 7) == 0) {
+        const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+        mblk = (loc / nb) * 8 + xcd;
+        nblk = loc % nb;
+    }
+    const int m0 = m_begin + mblk * 128, n0 = nblk * BN;
     const int wm = (wv >> 1) * 64, wn = (wv & 1) * (32 * NJ);
     f32x16 acc[2][NJ];
 #pragma unroll
