@@ -1,8 +1,8 @@
 """Headline benchmark: G+D training step images/sec at 128x1024x2 (log-mel + IF), fully grown.
 
-    python bench.py --gpus N --steps K --warmup W            (N=1)
+    python bench.py --gpus N --steps K --warmup W            (any N: for N > 1 without a launcher it starts its N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W     (N>1, one rank per GPU, RCCL)
+        --master-port P bench.py --gpus N --steps K --warmup W     (N>1 under a launcher: one rank per GPU, RCCL)
 
 One step = one reference iteration (models.py:191-192): a discriminator update then a generator
 update, each on its own synthetic batch of `--batch` (default 8) examples per GPU, inputs already
@@ -125,13 +125,18 @@ def spectral_bench(batch=256, iters=1000, warmup=300, cpu=True):
                         "kernel": "stft_wave_kernel<float, 1> (framing + Hann + 2048-point real FFT + |.| / atan2 + mel gather + log / IF per wave)",
                         "note": "the kernel is LDS-pipe / VALU bound, not HBM bound (profiles/r02_*_spectral_pmc.txt); frac is against the HBM roof SURVEY.md 8(d) prescribes"}}
     if cpu:
-        from oracle import spectral_np as S
-        n = 16
-        t0 = time.time()
-        S.convert_to_spectrogram(w[:n], **P)
-        dt = time.time() - t0
-        out["cpu_baseline"] = {"value": n / dt, "unit": "examples/sec", "cores": 1, "kind": "port", "cpu_model": cpu_model(),
-                               "sample": "%d of the %d waveforms through the numpy oracle (oracle/spectral_np.py, fp32, one thread)" % (n, batch)}
+        # the same workload (all `batch` waveforms) on the host's own cores -- the numpy oracle in one worker process
+        # per core (oracle/cpu_bench.py; its own interpreter, so that the pool is forked from a process without HIP state)
+        import subprocess
+        res = subprocess.run([sys.executable, "-m", "oracle.cpu_bench", "--examples", str(batch)], cwd=ROOT, capture_output=True, text=True, timeout=600)
+        if res.returncode == 0:
+            r = json.loads(res.stdout.strip().splitlines()[-1])
+            out["cpu_baseline"] = {"value": r["examples"] / r["seconds"], "unit": "examples/sec", "cores": r["procs"], "host_cores": r["host_cores"],
+                                   "kind": "port", "cpu_model": cpu_model(), "seconds": r["seconds"],
+                                   "sample": "all %d waveforms through the numpy oracle (oracle/spectral_np.py, fp32), %d worker processes of one thread each "
+                                             "(oracle/cpu_bench.py), timed after one warm-up example per worker" % (r["examples"], r["procs"])}
+        else:
+            out["cpu_baseline"] = {"error": (res.stderr or res.stdout)[-300:]}
     return out
 
 
@@ -139,8 +144,8 @@ def inverse_bench(batch=256, iters=50, warmup=10):
     """(log-mel, IF) images [256, 2, 128, 1024] -> waveforms [256, 64000] (spectral_ops.py:97-149): exp / cumulative phase,
     the pinv(mel) contraction of magnitude and phase as ONE GEMM at fp32 accuracy (phases reach ~1e3 rad): every operand is the exact
     sum of three bf16 numbers and six bf16 MFMAs keep the partial products down to 2^-16 (gemm_bf16x6_kernel), then
-    polar -> inverse FFT -> overlap-add.  The GEMM dominates: MFMA-bound; `frac` prices the call against the fp32 MFMA peak the
-    contraction would otherwise run on."""
+    polar -> inverse FFT -> overlap-add.  The GEMM dominates: MFMA-bound; `roofline` prices the bf16 products the MFMA pipe
+    executes against the dense bf16 peak (never above 1); the algorithmic fp32 rate of the call is a separate field."""
     import numpy as np
     from gansynth_amd import spectral_ops as G
     P = dict(waveform_length=64000, sample_rate=16000, spectrogram_shape=[128, 1024], overlap=0.75)
@@ -158,12 +163,44 @@ def inverse_bench(batch=256, iters=50, warmup=10):
     torch.cuda.synchronize()
     ms = s.elapsed_time(e) / iters
     flops = 2.0 * 2.0 * batch * 128 * 1024 * 1024   # [2 * batch * 128, 1024] x [1024, 1024]: magnitude and phase rows stacked
-    achieved = flops / (ms * 1e-3) / 1e12
-    return {"workload": "%d x (log-mel, IF) [2, 128, 1024] -> 64000-sample waveforms, fp32 (spectral_ops.py:97-149)" % batch,
-            "value": batch / (ms * 1e-3), "unit": "examples/sec", "ms_per_batch": ms, "dtype": "f32",
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK["f32"], "unit": "TFLOP/s", "frac": achieved / PEAK["f32"],
-                         "executed_bf16_tflops": 4.5 * achieved, "executed_bf16_frac": 4.5 * achieved / PEAK["bf16"],
-                         "note": "whole call (prep + GEMM + iFFT + overlap-add) against the GEMM's algorithmic FLOPs and the fp32 MFMA peak; the contraction runs on the bf16 MFMA as partial products of bf16 splits (six for the phase rows, three for the magnitude rows: 4.5 bf16 MFMAs per algorithmic one = executed_bf16_*); the two GEMM launches are ~73 % of the call (profiles/r02_t_inverse_kernel_stats.md: 394 + 222 us; 758 us with six terms everywhere, ~1090 us on the exact-fp32 MFMA kernel)"}}
+    # The contraction runs on the bf16 MFMA as partial products of bf16 splits of fp32 operands: six per algorithmic multiply-add on the
+    # phase rows, three on the magnitude rows.  The roofline prices what the MFMA pipe EXECUTES (4.5 bf16 products per algorithmic
+    # one on average) against the dense bf16 peak, per GEMM launch (HIP events of the library's own profiler around the two launches).
+    from gansynth_amd import kernels
+    K = kernels.get()
+    gemm = None
+    K.prof_enable(True)   # (library profiler: HIP event pairs around the GEMM launches, on their stream)
+    for _ in range(20):
+        G.convert_images_to_waveform(img, **P)
+    torch.cuda.synchronize()
+    recs = [r for r in K.prof_records() if r[3][0] in (30, 31, 32)]
+    K.prof_collect()
+    K.prof_enable(False)
+    if recs:
+        by_kind = {}
+        for r_ms, _, _, d in recs:
+            by_kind.setdefault(d[0], []).append(r_ms)
+        gemm = {{30: "magnitude_ms", 31: "phase_ms", 32: "all_rows_ms"}[k]: sum(v) / len(v) for k, v in by_kind.items()}
+        executed = sum(r[1] for r in recs) / 20.0
+    else:
+        executed = 4.5 * flops
+    out = {"workload": "%d x (log-mel, IF) [2, 128, 1024] -> 64000-sample waveforms, fp32 (spectral_ops.py:97-149)" % batch,
+           "value": batch / (ms * 1e-3), "unit": "examples/sec", "ms_per_batch": ms, "dtype": "f32 results from bf16 x3 split operands on the bf16 MFMA",
+           "algorithmic_tflops_whole_call": flops / (ms * 1e-3) / 1e12}
+    if gemm:
+        g_ms = sum(gemm.values())
+        ach = executed / (g_ms * 1e-3) / 1e12
+        out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK["bf16"], "unit": "TFLOP/s", "frac": ach / PEAK["bf16"],
+                           "kernel": "gemm_bf16x6_kernel (the two GEMM launches: phase rows 6 products, magnitude rows 3)",
+                           "avg_launch_ms": g_ms / len(gemm), "gemm_ms": gemm, "gemm_share_of_call": g_ms / ms,
+                           "executed_flops_per_call": executed, "algorithmic_flops_per_call": flops,
+                           "note": "achieved = executed bf16 MFMA FLOPs of the two GEMM launches / their HIP-event time; the algorithmic (fp32) rate of the whole call is algorithmic_tflops_whole_call"}
+    else:
+        ach = executed / (ms * 1e-3) / 1e12
+        out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK["bf16"], "unit": "TFLOP/s", "frac": ach / PEAK["bf16"],
+                           "executed_flops_per_call": executed, "algorithmic_flops_per_call": flops,
+                           "note": "executed bf16 MFMA FLOPs (4.5 per algorithmic one) over the WHOLE call (prep + 2 GEMM launches + iFFT / overlap-add)"}
+    return out
 
 
 _KIND = {0: "conv3x3 s1", 1: "conv3x3 s2", 2: "conv3x3 transposed s2", 10: "wgrad conv3x3 s1", 11: "wgrad conv3x3 s2", 12: "wgrad transposed (as s2)"}
@@ -240,11 +277,42 @@ def main():
     ap.add_argument("--no-spectral", action="store_true", help="skip the configs[3] (waveform -> mel + IF) leg")
     ap.add_argument("--no-launch-count", action="store_true", help="skip the torch.profiler count of kernel launches per iteration")
     ap.add_argument("--spectral-only", action="store_true", help="run only the configs[3] leg and print its object")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="no device work: the ranks only rendezvous (gloo), prove the launch plumbing and print one JSON line (CPU test of the self-launch)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves -- the same command the driver would use
+        # (one process per GPU, LOCAL_RANK pins rank -> GPU below); rank 0's single JSON line is this process's stdout too.
+        import socket
+        import subprocess
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus, "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=env))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.launch_check:
+        if args.gpus != world:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+        if world > 1:
+            torch.distributed.init_process_group("gloo")
+            t = torch.tensor([rank, local_rank, 1], dtype=torch.int64)
+            torch.distributed.all_reduce(t)
+            torch.distributed.barrier()
+            torch.distributed.destroy_process_group()
+        else:
+            t = torch.tensor([0, 0, 1])
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": world, "ranks_joined": int(t[2]), "rank_sum": int(t[0]), "local_rank_sum": int(t[1])}), flush=True)
+        return
     torch.cuda.set_device(local_rank)
     if args.spectral_only:
         print(json.dumps(spectral_bench(cpu=not args.no_cpu_baseline)), flush=True)
@@ -335,7 +403,7 @@ def main():
             traffic = json.load(open(pmcs[-1]))["avg_hbm_bytes_per_launch"]
         out = {
             "metric": "G+D step images/sec at 128x1024x2 mel+IF",
-            "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "unit": "images/sec", "n_gpus": world, "rccl_ranks": world if distributed else 0, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[1]: fully grown PGGAN 128x1024x2 G+D iteration (D update + G update, "

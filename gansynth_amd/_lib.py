@@ -26,6 +26,7 @@ SIGNATURES = {
     "gs_prof_collect": (I, [POINTER(c_int), POINTER(c_double), POINTER(c_double)]),
     "gs_prof_roofline": (I, [ctypes.c_double, ctypes.c_double, P, P, P]),
     "gs_prof_records": (I, [I, P, P, P, P, P]),
+    "gs_comm_available": (I, []),
     "gs_comm_unique_id": (I, [P]),
     "gs_comm_init": (I, [POINTER(P), I, I, P]),
     "gs_comm_destroy": (I, [P]),

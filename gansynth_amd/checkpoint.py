@@ -10,7 +10,8 @@ A `tf.train.Saver` checkpoint of the reference graph (models.py:123-130) holds, 
 The TF tensor-bundle container cannot be written without TensorFlow; the same names, shapes and layouts are stored in a
 `.safetensors` file; `scripts/tf_checkpoint_convert.py` copies a TF checkpoint into that container (and back) on a machine
 that has TensorFlow -- the only format gap (INTEGRATION.md).  `optimizer_steps[_1]` is an extra key (the exponent t itself);
-a converted TF checkpoint lacks it and t is recovered from beta2_power = beta2^(t+1).
+a converted TF checkpoint lacks it and t is global_step (both optimizers step once per iteration; beta2_power = beta2^(t+1)
+underflows in float32 past ~10 k steps and only cross-checks it).
 Retention follows the reference's Saver: max_to_keep=10 and keep_checkpoint_every_n_hours=12 (models.py:126-127), see save().
 """
 import glob
@@ -72,12 +73,20 @@ def load_state_dict(model, state, strict=True):
         key = "optimizer_steps" + suffix
         if key in state:
             params.t = int(state[key])
-        elif "beta2_power" + suffix in state:
-            # a checkpoint converted from a real tf.train.Saver file has only TF's own accumulators: beta2_power = beta2^(t+1)
+        elif "global_step" in state:
+            # a checkpoint converted from a real tf.train.Saver file has only TF's own accumulators.  Both optimizers are applied
+            # exactly once per iteration (models.py:81-88, 191-192), so t IS global_step.  beta2_power = beta2^(t+1) (float32)
+            # cannot give it back in general: 0.99^(t+1) is denormal past ~8.7 k steps and exactly 0 past ~10.3 k, where a
+            # log() recovery would restart the bias correction (a 10x learning-rate dip); it only serves as a cross-check while
+            # it is still a normal float.
+            params.t = int(state["global_step"])
             hp = model.hyper_params
             b2 = float(hp.generator_beta2 if suffix == "" else hp.discriminator_beta2)
-            p2 = float(state["beta2_power" + suffix])
-            params.t = max(0, int(round(math.log(p2) / math.log(b2))) - 1) if 0.0 < p2 < 1.0 and 0.0 < b2 < 1.0 else 0
+            p2 = float(state.get("beta2_power" + suffix, 0.0))
+            if 1.2e-38 < p2 < 1.0 and 0.0 < b2 < 1.0:
+                t_log = int(round(math.log(p2) / math.log(b2))) - 1
+                if abs(t_log - params.t) > max(2, int(1e-3 * params.t)):
+                    raise ValueError(f"checkpoint: beta2_power{suffix} = {p2:g} says {t_log} optimizer steps, global_step says {params.t}")
         else:
             missing.append(key)
     if "global_step" in state:
@@ -98,7 +107,9 @@ def save(model, model_dir, keep=10, keep_every_n_hours=12.0, now=None):
     """`model_dir/model.ckpt-<global_step>.safetensors` (+ a `checkpoint` text file naming the latest, like tf.train.Saver).
     Retention as tf.train.Saver(max_to_keep=10, keep_checkpoint_every_n_hours=12) (models.py:123-130): the newest `keep` files stay;
     a file that falls out of that window is deleted UNLESS it was written later than the saver's next keep-forever time, in which
-    case it is kept for good (its name goes to `checkpoints_kept`) and that time moves `keep_every_n_hours` on.  `now`: clock
+    case it is kept for good (its name goes to `checkpoints_kept`) and that time moves `keep_every_n_hours` on.  Unlike a Saver
+    object, which forgets everything at a restart, the keep-forever clock is persisted (`checkpoints_keep_clock`) and files of earlier
+    sessions compete with their modification times, so that a job restarted often still keeps long-term checkpoints.  `now`: clock
     override for tests."""
     if save_file is None:
         raise RuntimeError("checkpoint: the safetensors package is not importable")
@@ -108,20 +119,30 @@ def save(model, model_dir, keep=10, keep_every_n_hours=12.0, now=None):
     save_file({k: v.contiguous() for k, v in state_dict(model).items()}, path)
     with open(os.path.join(model_dir, "checkpoint"), "w") as f:
         f.write(f'model_checkpoint_path: "{os.path.basename(path)}"\n')
-    saver = model.__dict__.setdefault("_saver_state", {"next_keep": now + keep_every_n_hours * 3600.0 if keep_every_n_hours else None, "times": {}})
-    saver["times"][os.path.basename(path)] = now
-    kept_file = os.path.join(model_dir, "checkpoints_kept")
+    kept_file, clock_file = os.path.join(model_dir, "checkpoints_kept"), os.path.join(model_dir, "checkpoints_keep_clock")
     kept = set(open(kept_file).read().split()) if os.path.exists(kept_file) else set()
+    saver = model.__dict__.setdefault("_saver_state", {"next_keep": None, "times": {}})
+    if saver["next_keep"] is None and keep_every_n_hours:
+        # the keep-forever clock survives restarts (a job restarted more often than every keep_every_n_hours would otherwise never
+        # keep a long-term checkpoint)
+        saver["next_keep"] = float(open(clock_file).read()) if os.path.exists(clock_file) else now + keep_every_n_hours * 3600.0
+        with open(clock_file, "w") as f:
+            f.write(repr(saver["next_keep"]))
+    saver["times"][os.path.basename(path)] = now
     old = sorted((p for p in glob.glob(os.path.join(model_dir, "model.ckpt-*.safetensors")) if os.path.basename(p) not in kept),
                  key=lambda p: int(re.findall(r"ckpt-(\d+)", p)[-1]))
     for p in old[:-keep] if keep else []:
         name = os.path.basename(p)
         written = saver["times"].get(name)
-        if saver["next_keep"] is not None and written is not None and written > saver["next_keep"]:
+        if written is None:   # written by an earlier session of this run: its modification time stands in
+            written = os.path.getmtime(p)
+        if saver["next_keep"] is not None and written > saver["next_keep"]:
             kept.add(name)
             saver["next_keep"] += keep_every_n_hours * 3600.0
             with open(kept_file, "w") as f:
                 f.write("\n".join(sorted(kept)) + "\n")
+            with open(clock_file, "w") as f:
+                f.write(repr(saver["next_keep"]))
         else:
             os.remove(p)
     return path

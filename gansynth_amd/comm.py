@@ -26,24 +26,31 @@ class RcclComm(object):
         self.lib = kernels.get().lib
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         # Every rank runs the same sequence of launcher-side collectives whatever fails locally (a rank that raised before its
-        # peers' broadcast would leave them waiting): errors are collected, agreed on with a MIN all-reduce, and raised together.
+        # peers' broadcast would leave them waiting): errors are collected, agreed on with MIN all-reduces, and raised together.
+        # ncclCommInitRank BLOCKS until all `world` ranks have entered it, so the ranks agree that every one of them can (librccl
+        # resolvable, rank 0 produced an id) BEFORE anyone calls it -- a rank that skipped it would hang its peers inside it.
         ident = (ctypes.c_ubyte * 128)()
         error = None
-        if self.rank == 0:
-            try:
+        try:
+            _lib.check(self.lib.gs_comm_available(), "gs_comm_available")
+            if self.rank == 0:
                 _lib.check(self.lib.gs_comm_unique_id(ident), "gs_comm_unique_id")
-            except Exception as e:   # noqa: BLE001 -- reported below, on every rank
-                error = e
+        except Exception as e:   # noqa: BLE001 -- reported below, on every rank
+            error = e
         carrier = torch.tensor(list(ident), dtype=torch.uint8, device=device)
         dist.broadcast(carrier, 0)   # the 128-byte id travels over the launcher's own process group
         ident = (ctypes.c_ubyte * 128)(*carrier.cpu().tolist())
         self.handle = ctypes.c_void_p()
-        if error is None:
-            try:
-                with torch.cuda.device(device):
-                    _lib.check(self.lib.gs_comm_init(ctypes.byref(self.handle), self.rank, self.world, ident), "gs_comm_init")
-            except Exception as e:   # noqa: BLE001
-                error = e
+        ready = torch.tensor([0 if error is not None else 1], dtype=torch.int32, device=device)
+        dist.all_reduce(ready, op=dist.ReduceOp.MIN)
+        if int(ready.item()) == 0:
+            raise RuntimeError("RCCL cannot be used by libgansynth_hip.so on every rank (rank %d: %s)"
+                               % (self.rank, error if error is not None else "ok here, failed on a peer"))
+        try:
+            with torch.cuda.device(device):
+                _lib.check(self.lib.gs_comm_init(ctypes.byref(self.handle), self.rank, self.world, ident), "gs_comm_init")
+        except Exception as e:   # noqa: BLE001
+            error = e
         ok = torch.tensor([0 if error is not None else 1], dtype=torch.int32, device=device)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if int(ok.item()) == 0:

@@ -8,7 +8,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result $GS_EXTRA_F
 pids=()
 for f in conv_igemm conv_api elementwise small_ops spectral spectral_wave; do
   [ -f $f.hip ] || continue
-  if [ ! -f obj/$f.o ] || [ $f.hip -nt obj/$f.o ] || [ gs_common.h -nt obj/$f.o ] || [ conv_shared.h -nt obj/$f.o ] || [ spectral_plan.h -nt obj/$f.o ] || [ ../../include/gansynth_hip.h -nt obj/$f.o ]; then
+  if [ ! -f obj/$f.o ] || [ $f.hip -nt obj/$f.o ] || [ gs_common.h -nt obj/$f.o ] || [ gs_prof.h -nt obj/$f.o ] || [ conv_shared.h -nt obj/$f.o ] || [ spectral_plan.h -nt obj/$f.o ] || [ ../../include/gansynth_hip.h -nt obj/$f.o ]; then
     EXTRA=""
     # MFMA accumulators in VGPRs (hipcc otherwise parks them in AGPRs and every epilogue value costs a v_accvgpr_read)
     [ $f = conv_igemm ] && EXTRA="-mllvm -amdgpu-mfma-vgpr-form $GS_IGEMM_FLAGS"
@@ -18,7 +18,7 @@ for f in conv_igemm conv_api elementwise small_ops spectral spectral_wave; do
     pids+=($!)
   fi
 done
-if [ ! -f obj/core.o ] || [ core.cpp -nt obj/core.o ] || [ gs_common.h -nt obj/core.o ]; then
+if [ ! -f obj/core.o ] || [ core.cpp -nt obj/core.o ] || [ gs_common.h -nt obj/core.o ] || [ gs_prof.h -nt obj/core.o ]; then
   ( hipcc $FLAGS -x hip -c core.cpp -o obj/core.o ) &
   pids+=($!)
 fi

@@ -58,6 +58,8 @@ struct gs_comm {
     int rank, world;
 };
 
+extern "C" int gs_comm_available(void) { return load_rccl(); }
+
 extern "C" int gs_comm_unique_id(void* id128) {
     GS_CHECK_ARG(id128, "gs_comm_unique_id: null buffer");
     if (int e = load_rccl()) return e;

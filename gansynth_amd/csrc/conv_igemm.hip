@@ -16,6 +16,7 @@
 // ops.py:269-276 (plus the tf.gradients of both, models.py:47,60,81-89).
 #include <type_traits>
 #include "conv_shared.h"
+#include "gs_prof.h"
 
 extern "C" int gs_pixel_norm_fwd(const void* x, void* y, int64_t p, int c, float eps, int dtype, void* stream);
 
@@ -25,43 +26,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-
-// --------------------------------------------------------------------------- profiling hooks
-struct ProfState {
-    bool on = false;
-    static constexpr int MAXEV = 8192;
-    hipEvent_t ev[MAXEV][2];
-    int created = 0;
-    int used = 0;
-    double flops = 0.0;
-    double lflops[MAXEV], lbytes[MAXEV];   // per launch: algorithmic flops and bytes (operands read once + result written once)
-    int ldesc[MAXEV][8];                   // per launch: {kind, N, Hb, Wb, IC, OC, masked, fused norm}; kind = conv mode, +10 for weight gradients
-};
-static ProfState g_prof;
-
-struct ProfScope {
-    hipStream_t s;
-    int idx = -1;
-    ProfScope(hipStream_t st, double flops, double bytes, int kind, int N, int Hb, int Wb, int IC, int OC, int masked, int norm) : s(st) {
-        if (!g_prof.on || g_prof.used >= ProfState::MAXEV) return;
-        idx = g_prof.used++;
-        g_prof.lflops[idx] = flops;
-        g_prof.lbytes[idx] = bytes;
-        const int d[8] = {kind, N, Hb, Wb, IC, OC, masked, norm};
-        for (int i = 0; i < 8; ++i) g_prof.ldesc[idx][i] = d[i];
-        if (kind >= 10) flops = 0.0;   // (the family totals of gs_prof_collect count the implicit-GEMM launches only)
-        if (idx >= g_prof.created) {
-            hipEventCreate(&g_prof.ev[idx][0]);
-            hipEventCreate(&g_prof.ev[idx][1]);
-            g_prof.created = idx + 1;
-        }
-        g_prof.flops += flops;
-        hipEventRecord(g_prof.ev[idx][0], s);
-    }
-    ~ProfScope() {
-        if (idx >= 0) hipEventRecord(g_prof.ev[idx][1], s);
-    }
-};
 
 // ------------------------------------------------------------------------------- MFMA traits
 template <typename T> struct Mma;

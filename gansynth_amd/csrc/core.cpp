@@ -1,9 +1,11 @@
 // Error reporting, version and device check for libgansynth_hip.so.
 #include <stdarg.h>
 #include "gs_common.h"
+#include "gs_prof.h"
 
 namespace gs {
 thread_local char g_err[512] = "";
+ProfState g_prof;
 
 int fail(int code, const char* fmt, ...) {
     va_list ap;

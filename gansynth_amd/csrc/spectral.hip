@@ -11,6 +11,7 @@
 //  inverse         exp / cumsum prep, dense pinv(mel) contraction on fp32 MFMA (this one IS a
 //                  dense GEMM), packed inverse FFT, windowed overlap-add.
 #include "gs_common.h"
+#include "gs_prof.h"
 #include "spectral_plan.h"
 
 #include <math.h>
@@ -717,9 +718,19 @@ extern "C" int gs_mel_if_to_waveform(const gs_spectral_plan* p, const void* imag
                 hipLaunchKernelGGL((gemm_bf16x6_kernel<4, 3>), dim3(blocks_all), dim3(256), 0, st, a_split, p->pinv_split, mag, M2, H, H, 0);
             }
         } else if (two) {
-            hipLaunchKernelGGL((gemm_bf16x6_kernel<2, 2>), dim3(blocks_mag), dim3(256), 0, st, a_split, p->pinv_split, mag, M2, H, H, 0);
-            hipLaunchKernelGGL((gemm_bf16x6_kernel<2, 3>), dim3(blocks_mag), dim3(256), 0, st, a_split, p->pinv_split, mag, M2, H, H, (int)rows);
+            // (profiling records: kind 30 = magnitude rows, three bf16 products per multiply-add; 31 = phase rows, six; 32 = all rows, six.
+            //  flops = EXECUTED bf16 MFMA flops, bytes = operand planes read once + fp32 result written once)
+            const double half = 2.0 * (double)rows * H * H;
+            {
+                ProfScope ps(st, 3.0 * half, (double)rows * H * 4 + 2.0 * H * H * 2 + (double)rows * H * 4, 30, batch, p->time_steps, H, H, H, 0, 0);
+                hipLaunchKernelGGL((gemm_bf16x6_kernel<2, 2>), dim3(blocks_mag), dim3(256), 0, st, a_split, p->pinv_split, mag, M2, H, H, 0);
+            }
+            {
+                ProfScope ps(st, 6.0 * half, (double)rows * H * 6 + 3.0 * H * H * 2 + (double)rows * H * 4, 31, batch, p->time_steps, H, H, H, 0, 0);
+                hipLaunchKernelGGL((gemm_bf16x6_kernel<2, 3>), dim3(blocks_mag), dim3(256), 0, st, a_split, p->pinv_split, mag, M2, H, H, (int)rows);
+            }
         } else {
+            ProfScope ps(st, 12.0 * (double)rows * H * H, 2.0 * rows * H * 6 + 3.0 * H * H * 2 + 2.0 * rows * H * 4, 32, batch, p->time_steps, H, H, H, 0, 0);
             hipLaunchKernelGGL((gemm_bf16x6_kernel<2, 3>), dim3(blocks_all), dim3(256), 0, st, a_split, p->pinv_split, mag, M2, H, H, 0);
         }
     } else if ((2 * rows) % 128 == 0 && H % 128 == 0) {

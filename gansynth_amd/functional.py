@@ -532,7 +532,8 @@ class _ConvBiasActNorm(Function):
         bias_done = False
         if g_y is None:
             gy = _K().act_bwd(g_z, z, ctx.act)
-        elif tb is not None and not getattr(ctx.kind, "bias_in_wgrad", False) and _NORM_BWD_BIAS and getattr(_K(), "norm_bwd_sums_bias", False):
+        elif (tb is not None and not getattr(ctx.kind, "bias_in_wgrad", False) and _NORM_BWD_BIAS and getattr(_K(), "norm_bwd_sums_bias", False)
+              and _K().norm_bwd_bias_ok(z.shape[1], z.dtype)):   # (other channel counts, e.g. 48 or 96: plain backward + channel_sum below)
             # (blocks whose weight-gradient kernel carries no bias row -- the transposed convs: the norm's backward sums its own result)
             gy = _K().pixel_norm_bwd(g_y, z, ctx.eps, act=ctx.act, addend=g_z, bias_out=tb)
             bias_done = True

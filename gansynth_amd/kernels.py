@@ -238,7 +238,9 @@ class HipKernels(object):
         if group_of is not None:
             tagged = {}
             for key, grp in groups.items():
-                tagged.setdefault(group_of(grp["out"].data_ptr()), []).append((key, grp))
+                # a deferred layer writes its weight gradient AND (through the same launches) its bias gradient: it runs with the
+                # EARLIER of their two buckets, or that one would go on the wire before the job has added into it
+                tagged.setdefault(completion_group(group_of, grp["out"], grp["bias"]), []).append((key, grp))
             order = sorted((g for g in tagged if g is not None)) + ([None] if None in tagged else [])
             n = 0
             for g in order:
@@ -594,6 +596,11 @@ class HipKernels(object):
 
     norm_bwd_sums_bias = True   # pixel_norm_bwd(bias_out=...) exists (functional._ConvBiasActNorm)
 
+    def norm_bwd_bias_ok(self, c, dtype=torch.float32):
+        """Can pixel_norm_bwd(bias_out=...) take rows of `c` channels?  (gs_pixel_norm_bwd_fused_bias: a power of two in 4..1024 --
+        the library's own answer: gs_bias_partial_rows is 0 for the shapes that kernel rejects.)"""
+        return self.lib.gs_bias_partial_rows(_lib.BIAS_FROM_PIXEL_NORM_BWD, 1, int(c), GS_F32 if dtype == torch.float32 else GS_BF16) > 0
+
     def pixel_norm_bwd(self, g, x, eps, act=0, pre_act=0, addend=None, bias_out=None):
         """gx = (pixel_norm_bwd(g * pre_act'(x), x) + addend) * act'(x)   (x: an activation output; see gs_pixel_norm_bwd_fused).
         `bias_out` (fp32 [c], contiguous): the same pass adds sum_pixels gx into it."""
@@ -775,6 +782,16 @@ class HipKernels(object):
         n, ms, fl = ctypes.c_int(0), ctypes.c_double(0.0), ctypes.c_double(0.0)
         self.lib.gs_prof_collect(ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl))
         return n.value, ms.value, fl.value
+
+
+def completion_group(group_of, *targets):
+    """The group (gradient bucket, in completion order) a deferred job runs in when it adds into several `targets` (a layer's weight
+    gradient and, from the same launches, its bias gradient): the EARLIEST of their groups.  Buckets go on the wire in index order,
+    bucket i right after the jobs of group i -- so a job must have run by the time the first bucket it touches is sent (the later
+    ones are sent after it anyway).  (Also used by the CPU emulation of the tests.)"""
+    tags = [group_of(t.data_ptr()) for t in targets if t is not None]
+    tags = [t for t in tags if t is not None]
+    return min(tags) if tags else None
 
 
 def _match(t, ref):

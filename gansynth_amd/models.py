@@ -31,6 +31,7 @@ _DEFER_REDUCTIONS = not __import__("os").environ.get("GS_NO_DEFERRED_REDUCE")   
 _FUSED_LOSSES = not __import__("os").environ.get("GS_NO_FUSED_LOSSES")
 _PIPELINE = bool(__import__("os").environ.get("GS_PIPELINE"))   # opt-in, see GANSynth.pipeline
 _PIPE_SIDE = {"0": False, "1": True}.get(__import__("os").environ.get("GS_PIPE_SIDE", ""))
+_GRAPH_ALLREDUCE = not __import__("os").environ.get("GS_NO_GRAPH_ALLREDUCE")   # A/B switch: the gradient all-reduce as a node of the captured graph
 
 
 class _quiet_gc(object):
@@ -131,6 +132,8 @@ class GANSynth(object):
         self._inflight = None                   # (params, [(bucket, work)]) all-reduces launched during the eager backward's tail
         self._comm = None                       # comm.RcclComm: the gradient all-reduce on the backward's own stream (HIP + nccl only)
         self._peeked = None                     # a batch fetched ahead of the first step (train: eager build / restore)
+        self._run_reduced = False               # the last _run replayed a graph that contains its own gradient all-reduce
+        self._captured_reduce = False
         self.global_step = 0
         self.g_params = None
         self.d_params = None
@@ -220,9 +223,10 @@ class GANSynth(object):
     # mirror images, ~50 torch launches per iteration -- as ONE kernel per loss (gs_gan_d_loss / gs_gan_g_loss: value and
     # gradients); `_b` then returns the mean loss itself instead of the per-sample losses.  The public *_losses methods keep
     # the per-sample form of the reference.
-    @staticmethod
-    def _fused_losses():
-        return _FUSED_LOSSES and hasattr(kernels.get(), "gan_d_loss")
+    def _fused_losses(self):
+        # (the one-launch discriminator loss carries ONE penalty term: with the optional penalty on the generator distribution,
+        # models.py:50-54 -- weight 0 in the shipped configuration -- the per-sample algebra runs instead)
+        return _FUSED_LOSSES and hasattr(kernels.get(), "gan_d_loss") and not self.hyper_params.get("fake_gradient_penalty_weight", 0.0)
 
     def _d_losses_a(self, labels, real_images, fused=False):
         hp = self.hyper_params
@@ -239,21 +243,27 @@ class GANSynth(object):
             penalty = F.sumsq_rows(real_gradients)
             if not fused:   # (the fused loss kernel takes the weight itself: no scaling launch, forward or backward)
                 penalty = penalty * hp.real_gradient_penalty_weight
-        if hp.get("fake_gradient_penalty_weight", 0.0):
-            raise NotImplementedError("fake_gradient_penalty_weight is 0 in the reference configuration (gan_synth_main.py:87)")
         return (raw, penalty) if fused else (TF.softplus(-real_logits), penalty)
 
     def _d_losses_b(self, part_a, latents, labels, fused=False):
         real_part, penalty = part_a
+        hp = self.hyper_params
+        fake_weight = hp.get("fake_gradient_penalty_weight", 0.0)
         with torch.no_grad():  # var_list is the discriminator's only: no generator backward (models.py:86-89)
             fake_images = self.generator(latents, labels)
+        if fake_weight:   # tf.gradients(fake_logits, [fake_images]) (models.py:51): the images are the point of differentiation
+            fake_images = fake_images.detach().requires_grad_(True)
         _, fake_logits = self.discriminator(fake_images, labels)
         if fused:
-            return F.gan_d_loss(real_part, fake_logits, labels, penalty, self.hyper_params.real_gradient_penalty_weight or 1.0)
+            return F.gan_d_loss(real_part, fake_logits, labels, penalty, hp.real_gradient_penalty_weight or 1.0)
         fake_logits = self._label_logits(fake_logits, labels)
         losses = real_part + TF.softplus(fake_logits)
         if penalty is not None:
             losses = losses + penalty
+        if fake_weight:   # zero-centred gradient penalty on the generator distribution (models.py:50-54): the R1 kernels on the fake batch
+            with F.data_grads_only():
+                (fake_gradients,) = torch.autograd.grad(fake_logits.sum(), fake_images, create_graph=True)
+            losses = losses + F.sumsq_rows(fake_gradients) * fake_weight
         return losses
 
     def discriminator_losses(self, latents, labels, real_images):
@@ -373,6 +383,11 @@ class GANSynth(object):
                     K.flush_wgrad_reductions()
         if launched:
             self._inflight = (params, launched)
+        if self.distributed and self._comm is not None and _GRAPH_ALLREDUCE and self._capturing() and not getattr(self, "_pipe_capture", False):
+            # Same-stream RCCL is capturable: the all-reduce of this run's flat gradient becomes the LAST NODE of the run's hipGraph, so
+            # a replayed run hands over reduced gradients and no eager collective launch sits between the replay and the update.
+            self._reduce(params)
+            self._captured_reduce = True
         return loss.detach()
 
     @staticmethod
@@ -431,6 +446,7 @@ class GANSynth(object):
     def _run(self, which, *inputs):
         self._join_updates()
         owner = getattr(self.generator, "__self__", None)
+        self._run_reduced = False
         if not self._graphable():
             self._graphs.clear()
             return self._forward_backward(which, *inputs)
@@ -455,6 +471,10 @@ class GANSynth(object):
                 try:
                     with torch.cuda.stream(side):  # one eager pass on a side stream (allocator / lazy-init warm-up)
                         self._forward_backward(which, *static)
+                        if self.distributed and self._comm is not None and _GRAPH_ALLREDUCE:
+                            # RCCL sets up its channels on the first collective of a kind: not capturable, so one eager all-reduce
+                            # of the buffers the graph will reduce (every rank does the same; the gradients are dead values here)
+                            self._reduce(self.d_params if which == "d" else self.g_params)
                 finally:
                     self._warming_up = False
                 torch.cuda.current_stream().wait_stream(side)
@@ -462,23 +482,25 @@ class GANSynth(object):
                 # (kernels.adam_tf_step): bring them up to date now so that the captured graph holds no re-layout launches
                 K.refresh_weights()
                 graph = torch.cuda.CUDAGraph()
+                self._captured_reduce = False
                 with _quiet_gc(), torch.cuda.graph(graph):
                     loss = self._forward_backward(which, *static)
             finally:
                 owner.fade_weight = None   # (only captured launches use the table; eager callers keep passing the number)
-            entry = (graph, static, loss)
+            entry = (graph, static, loss, self._captured_reduce)
             self._graphs[which] = entry
-        graph, static, loss = entry
+        graph, static, loss, reduced = entry
         for dst, src in zip(static, inputs):
             dst.copy_(src)
         graph.replay()
+        self._run_reduced = reduced   # (the replay already summed the gradients over the ranks: _apply goes straight to the update)
         return loss
 
     def discriminator_step(self, latents, labels, real_images):
         self._ensure_built(latents, labels)
         hp = self.hyper_params
         loss = self._run("d", latents, labels, real_images)
-        self._apply(self.d_params, hp.discriminator_learning_rate, hp.discriminator_beta1, hp.discriminator_beta2)
+        self._apply(self.d_params, hp.discriminator_learning_rate, hp.discriminator_beta1, hp.discriminator_beta2, reduced=self._run_reduced)
         self.discriminator_loss = loss
         return self.discriminator_loss
 
@@ -486,7 +508,7 @@ class GANSynth(object):
         self._ensure_built(latents, labels)
         hp = self.hyper_params
         loss = self._run("g", latents, labels)
-        self._apply(self.g_params, hp.generator_learning_rate, hp.generator_beta1, hp.generator_beta2)
+        self._apply(self.g_params, hp.generator_learning_rate, hp.generator_beta1, hp.generator_beta2, reduced=self._run_reduced)
         self.global_step += 1  # models.py:84
         self.generator_loss = loss
         return self.generator_loss
@@ -517,12 +539,16 @@ class GANSynth(object):
             self._part_b(which, self._part_a(which, *sa), *sb)
         torch.cuda.current_stream().wait_stream(side)
         K.refresh_weights()   # (see _run: the captured graphs hold no re-layout launches)
-        ga = torch.cuda.CUDAGraph()
-        with _quiet_gc(), torch.cuda.graph(ga):
-            part_a = self._part_a(which, *sa)
-        gb = torch.cuda.CUDAGraph()
-        with _quiet_gc(), torch.cuda.graph(gb, pool=ga.pool()):
-            loss = self._part_b(which, part_a, *sb)
+        self._pipe_capture = True   # (the pipelined step launches its reductions itself, on the side stream: none inside these graphs)
+        try:
+            ga = torch.cuda.CUDAGraph()
+            with _quiet_gc(), torch.cuda.graph(ga):
+                part_a = self._part_a(which, *sa)
+            gb = torch.cuda.CUDAGraph()
+            with _quiet_gc(), torch.cuda.graph(gb, pool=ga.pool()):
+                loss = self._part_b(which, part_a, *sb)
+        finally:
+            self._pipe_capture = False
         return {"a": ga, "b": gb, "sa": sa, "sb": sb, "loss": loss}
 
     def _pipelined_ok(self):

@@ -61,12 +61,15 @@ int gs_prof_records(int max_records, int* n, double* ms, double* flops, double* 
  * gan_synth_main.py:91-98).  One process per GPU.  A communicator wraps ncclCommInitRank of RCCL (resolved at run
  * time from the librccl.so.1 the process already has, none needed on one GPU); the collectives run ON THE CALLER'S STREAM, i.e.
  * ordered behind the backward that produced the gradients and ahead of gs_adam_tf_step, with no cross-stream event.
+ *   gs_comm_available   0 when librccl can be resolved in this process (no communicator is created): lets every rank agree that the
+ *                       blocking gs_comm_init will be entered by ALL of them before any of them enters it
  *   gs_comm_unique_id   rank 0 fills 128 bytes (ncclGetUniqueId) and ships them to the other ranks by any means
  *   gs_comm_init        every rank, same id; binds to the current HIP device
  *   gs_allreduce_sum_f32 / gs_broadcast_f32   in place, fp32 (the flat gradient / parameter buffers of models.py:67-89's two
  *                       optimizers; the 1 / world averaging is gs_adam_tf_step's grad_scale) */
 #define GS_COMM_ID_BYTES 128
 typedef struct gs_comm gs_comm;
+int gs_comm_available(void);
 int gs_comm_unique_id(void* id128);
 int gs_comm_init(gs_comm** out, int rank, int world, const void* id128);
 int gs_comm_destroy(gs_comm* comm);

@@ -324,10 +324,12 @@ DEFAULT_HYPER = dict(
 
 
 def discriminator_loss(pggan, g_params, d_params, latents, labels, real_images, hyper=DEFAULT_HYPER):
-    """models.py:25,33-49,65 -- the subgraph discriminator_train_op evaluates."""
+    """models.py:25,33-54,65 -- the subgraph discriminator_train_op evaluates."""
     with torch.no_grad():
         fake_images = pggan.generator(g_params, latents, labels)
     real_images = real_images.detach().requires_grad_(True)
+    if hyper.get("fake_gradient_penalty_weight", 0.0):
+        fake_images = fake_images.detach().requires_grad_(True)
     _, real_logits = pggan.discriminator(d_params, real_images, labels)
     _, fake_logits = pggan.discriminator(d_params, fake_images, labels)
     real_logits = (real_logits * labels).sum(dim=1)  # gather_nd(where(one_hot))
@@ -336,6 +338,9 @@ def discriminator_loss(pggan, g_params, d_params, latents, labels, real_images, 
     if hyper["real_gradient_penalty_weight"]:
         (grads,) = torch.autograd.grad(real_logits.sum(), real_images, create_graph=True)
         losses = losses + grads.pow(2).sum(dim=(1, 2, 3)) * hyper["real_gradient_penalty_weight"]
+    if hyper.get("fake_gradient_penalty_weight", 0.0):   # models.py:50-54
+        (grads,) = torch.autograd.grad(fake_logits.sum(), fake_images, create_graph=True)
+        losses = losses + grads.pow(2).sum(dim=(1, 2, 3)) * hyper["fake_gradient_penalty_weight"]
     return losses.mean()
 
 

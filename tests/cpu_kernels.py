@@ -33,12 +33,13 @@ class CpuEmuKernels(object):
         if not pending:
             return 0
         if group_of is None:
-            for _, fn in pending:
+            for _, _, fn in pending:
                 fn()
             return len(pending)
+        from gansynth_amd.kernels import completion_group
         tagged = {}
-        for out, fn in pending:
-            tagged.setdefault(group_of(out.data_ptr()), []).append(fn)
+        for out, bias_out, fn in pending:
+            tagged.setdefault(completion_group(group_of, out, bias_out), []).append(fn)
         for g in sorted(k for k in tagged if k is not None) + ([None] if None in tagged else []):
             for fn in tagged[g]:
                 fn()
@@ -85,7 +86,7 @@ class CpuEmuKernels(object):
         if out is not None and self._pending is not None:
             x, gy = x.detach(), gy.detach()
             pending, self._pending = self._pending, None
-            pending.append((out, lambda: self.conv2d_bwd_weight(x, gy, ksize, stride, alpha, out=out, bias_out=bias_out)))
+            pending.append((out, bias_out, lambda: self.conv2d_bwd_weight(x, gy, ksize, stride, alpha, out=out, bias_out=bias_out)))
             self._pending = pending
             return out
         ci, co = x.shape[1], gy.shape[1]
@@ -107,7 +108,7 @@ class CpuEmuKernels(object):
         if out is not None and self._pending is not None:
             x, gy = x.detach(), gy.detach()
             pending, self._pending = self._pending, None
-            pending.append((out, lambda: self.conv2d_transpose_bwd_weight(x, gy, alpha, out=out)))
+            pending.append((out, None, lambda: self.conv2d_transpose_bwd_weight(x, gy, alpha, out=out)))
             self._pending = pending
             return out
         shape = (3, 3, x.shape[1], gy.shape[1])

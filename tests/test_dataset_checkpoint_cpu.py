@@ -190,13 +190,22 @@ def test_checkpoint_round_trip_resumes_bit_identically(cpu_backend, tmp_path):
     assert torch.equal(second.g_params.flat, straight.g_params.flat) and torch.equal(second.d_params.flat, straight.d_params.flat)
     assert torch.equal(second.g_params.v, straight.g_params.v)
     assert checkpoint.latest(str(tmp_path)).endswith("model.ckpt-4.safetensors")
-    # a checkpoint converted from a real tf.train.Saver file has no `optimizer_steps`: t comes back from beta2_power = beta2^(t+1)
+    # a checkpoint converted from a real tf.train.Saver file has no `optimizer_steps`: t is global_step (one apply per iteration)
     tf_like = {k: v for k, v in load_file(checkpoint.latest(str(tmp_path))).items() if not k.startswith("optimizer_steps")}
     third, _ = make(7)
     third._build(torch.zeros(4, 16), torch.zeros(4, 5))
     assert checkpoint.load_state_dict(third, tf_like, strict=True) == []
     assert (third.g_params.t, third.d_params.t, third.global_step) == (4, 4, 4)
     assert torch.equal(third.g_params.flat, straight.g_params.flat)
+    # ... also where float32 beta2_power has underflowed (0.99^(t+1) is denormal past ~8.7 k steps, 0 past ~10.3 k): no restart of
+    # the bias correction (lr_t would dip 10x); a beta2_power that contradicts global_step while still a normal float is an error
+    for steps in (9000, 20000):
+        late = dict(tf_like, global_step=torch.tensor(steps), beta2_power=torch.tensor(0.99 ** (steps + 1), dtype=torch.float32),
+                    beta2_power_1=torch.tensor(0.99 ** (steps + 1), dtype=torch.float32))
+        assert checkpoint.load_state_dict(third, late, strict=True) == []
+        assert (third.g_params.t, third.d_params.t, third.global_step) == (steps, steps, steps)
+    with pytest.raises(ValueError):
+        checkpoint.load_state_dict(third, dict(tf_like, global_step=torch.tensor(400)), strict=True)   # beta2_power says 4
 
 
 def test_checkpoint_retention_follows_the_saver(cpu_backend, tmp_path):
@@ -221,3 +230,16 @@ def test_checkpoint_retention_follows_the_saver(cpu_backend, tmp_path):
     assert left == [4, 7, 8], left
     assert open(os.path.join(tmp_path, "checkpoints_kept")).read().split() == ["model.ckpt-4.safetensors"]
     assert checkpoint.latest(str(tmp_path)).endswith("model.ckpt-8.safetensors")
+    # a RESTARTED job (new trainer object, nothing remembered in memory): the files of the earlier session compete with their
+    # modification times and the keep-forever clock (hour 24 by now) is read back -- step 8 (written at hour 27 by the first
+    # session) is kept for good when it leaves the window, step 7 (hour 16) is deleted
+    for f, t in ((7, 16), (8, 27)):
+        os.utime(os.path.join(tmp_path, f"model.ckpt-{f}.safetensors"), (1000.0 + t * hour,) * 2)
+    again = GANSynth(pg.generator, pg.discriminator, None, None, None, Dict(R.DEFAULT_HYPER))
+    again.g_params, again.d_params = model.g_params, model.d_params
+    for step, t in ((9, 28), (10, 29)):
+        again.global_step = step
+        checkpoint.save(again, str(tmp_path), keep=2, keep_every_n_hours=12.0, now=1000.0 + t * hour)
+    left = sorted(int(re.findall(r"ckpt-(\d+)", f)[-1]) for f in os.listdir(tmp_path) if f.endswith(".safetensors"))
+    assert left == [4, 8, 9, 10], left
+    assert open(os.path.join(tmp_path, "checkpoints_kept")).read().split() == ["model.ckpt-4.safetensors", "model.ckpt-8.safetensors"]

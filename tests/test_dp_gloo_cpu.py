@@ -52,13 +52,15 @@ def _worker(rank, world, port, out_dir, bucket_bytes):
     nd = len(model.d_params.buckets)
     model.generator_step(lat, lab)
     torch.save({"d": model.d_params.flat.clone(), "g": model.g_params.flat.clone(), "step": model.global_step,
-                "buckets": (nd, len(model.g_params.buckets)), "g_buckets": model.g_params.buckets},
+                "buckets": (nd, len(model.g_params.buckets)), "g_buckets": model.g_params.buckets,
+                "d_grad": model.d_params.grad.clone(), "g_grad": model.g_params.grad.clone(),   # (the all-reduced SUMS: Adam does not touch them)
+                "g_offsets": list(model.g_params._offsets)},
                os.path.join(out_dir, f"rank{rank}.pt"))
     torch.distributed.destroy_process_group()
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("world,bucket_bytes", [(2, 8 << 20), (4, 16 << 10)])
+@pytest.mark.parametrize("world,bucket_bytes", [(2, 8 << 20), (4, 16 << 10), (2, 4 << 10), (2, 8 << 10)])
 def test_gloo_ranks_match_gradient_average(world, bucket_bytes):
     """world 2 with one bucket per network (the whole flat gradient) and world 4 with 16 KiB buckets: the bucketed path -- buckets
     of whole tensors in completion order, each all-reduce launched from inside the backward's tail as its last gradient lands
@@ -77,6 +79,9 @@ def test_gloo_ranks_match_gradient_average(world, bucket_bytes):
         gb = r0["g_buckets"]
         assert gb[0][0] > gb[-1][0]   # generator: completion order = reverse of the variable order (its backward ends at the embedding)
         cover = sorted(gb)
+        if bucket_bytes < (16 << 10):   # some conv weight and its bias sit in different buckets
+            where = {name: next(i for i, (a, b) in enumerate(gb) if a <= off < b) for off, _, name in r0["g_offsets"]}
+            assert any(where[k] != where[k[:-len("weight")] + "bias"] for k in where if k.endswith("conv/weight")), where
         assert cover[0][0] == 0 and all(a[1] == b[0] for a, b in zip(cover, cover[1:])) and cover[-1][1] == r0["g"].numel()
 
 
@@ -102,6 +107,7 @@ def test_gloo_ranks_match_gradient_average(world, bucket_bytes):
                 loss.backward()
                 acc += params.grad
             params.grad.copy_(acc)
+            torch.testing.assert_close(r0[which + "_grad"], acc, rtol=1e-5, atol=1e-7)   # the reduced gradient itself, every element
             params.t += 1
             lr_t = 8e-4 * math.sqrt(1 - 0.99 ** params.t)
             kernels.get().adam_tf_step(params.flat, params.grad, params.m, params.v, lr_t, 0.0, 0.99, 1e-8, 1.0 / world)
@@ -157,7 +163,7 @@ def test_two_rank_resume_and_uneven_input():
     with tempfile.TemporaryDirectory() as model_dir:
         first = _run_train(2, model_dir, 2, [100, 100])
         assert [r["step"] for r in first] == [2, 2] and all(r["restored"] is None for r in first)
-        assert first[0]["files"] == ["checkpoint", "model.ckpt-2.safetensors"]            # written once, by rank 0
+        assert first[0]["files"] == ["checkpoint", "checkpoints_keep_clock", "model.ckpt-2.safetensors"]   # written once, by rank 0
         again = _run_train(2, model_dir, 3, [100, 100])
         assert all(r["restored"] is not None and r["restored"].endswith("model.ckpt-2.safetensors") for r in again)
         assert [r["step"] for r in again] == [3, 3] and all(r["t"] == (3, 3) for r in again)

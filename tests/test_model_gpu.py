@@ -85,6 +85,38 @@ def rel_l2(a, b):
     return float((a - b).norm() / (b.norm() + 1e-300))
 
 
+def check_adam_update(params, before, hip_grads, oracle_before, oracle_after, oracle_grads, hyper, which, strict_vs_oracle=True):
+    """The optimizer step as an UPDATE (p_after - p_before), not as parameters: weights are O(1) and the first TF-Adam step moves
+    every element by lr = 8e-4 (m = (1 - beta1) g, sqrt(v) = sqrt(1 - beta2) |g|, lr_t = lr sqrt(1 - beta2) / (1 - beta1): the step is
+    lr * sign(g) wherever sqrt(v) >> eps), so a comparison of the parameters themselves at 2e-3 of max|p| ~ 2 could not even see a
+    sign-flipped update.  (i) Against oracle.adam_tf_step applied to the HIP path's OWN gradients from the same starting point:
+    every element, 1e-3 of lr (about three fp32 ulps of a weight) -- the kernel's arithmetic inside the step (eps outside the bias
+    correction, the 1/world scale, m and v from zero).  (ii) Against the oracle's own update (its gradients): every element whose
+    oracle gradient is at least 1 % of its tensor's largest (there the sign cannot change within the gradient tolerance) and large
+    against eps, at 1e-2 of lr."""
+    lr, b1, b2 = hyper[which + "_learning_rate"], hyper[which + "_beta1"], hyper[which + "_beta2"]
+    lr_t = lr   # (the size of a first step, see above)
+    own = {k: v.cpu().clone() for k, v in before.items()}
+    grads = {k: hip_grads[k].cpu() for k in own}
+    R.adam_tf_step(own, grads, {k: torch.zeros_like(v) for k, v in own.items()}, {k: torch.zeros_like(v) for k, v in own.items()}, 1, lr, b1, b2)
+    worst_own = worst_ref = 0.0
+    for k, p in params.named.items():
+        upd = p.data.cpu() - before[k].cpu()
+        assert float(upd.abs().max()) <= 1.01 * lr_t + 2.5e-7 * float(before[k].abs().max()), (k, float(upd.abs().max()), lr_t)
+        d_own = float((upd - (own[k] - before[k].cpu())).abs().max())
+        worst_own = max(worst_own, d_own / lr_t)
+        assert d_own <= 1e-3 * lr_t + 2.5e-7 * float(before[k].abs().max()), f"{k}: update differs from TF-Adam on the same gradient by {d_own / lr_t:.3e} lr"
+        g = oracle_grads[k]
+        big = g.abs() >= max(1e-2 * float(g.abs().max()), 1e-5)   # (sqrt(v) = 0.1 |g| is then >= 100 eps: the element moves by ~lr)
+        if strict_vs_oracle and bool(big.any()):
+            ref = (oracle_after[k].detach() - oracle_before[k].detach())[big]
+            d_ref = float((upd[big] - ref).abs().max())
+            worst_ref = max(worst_ref, d_ref / lr_t)
+            assert d_ref <= 1e-2 * lr_t + 2.5e-7 * float(before[k].abs().max()), f"{k}: update differs from the oracle's by {d_ref / lr_t:.3e} lr"
+            assert float(ref.abs().min()) > 0.9 * lr_t   # (these elements did move by ~lr_t: the check above is not vacuous)
+    return worst_own, worst_ref
+
+
 def run_step_parity(pg, opg, model, store, batch, res, tol=1e-3, grad_tol=None, verbose=False, dtype=torch.float32,
                     flip_fraction=2e-5, flip_near=1e-4, metric=None):
     """One full iteration (D update then G update, each on its own batch) on the HIP path against the oracle: forward, both
@@ -118,6 +150,8 @@ def run_step_parity(pg, opg, model, store, batch, res, tol=1e-3, grad_tol=None, 
     assert relerr(feats, ofeats) < tol and relerr(logits, ologits) < tol
     stats = {}
     # ---- D run: G(z) (no grad), D(real) + R1 double-backward, D(fake); everything on the HIP path
+    d_before = {k: p.data.clone() for k, p in model.d_params.named.items()}
+    od_before = {k: t.detach().clone() for k, t in tr.d.items()}
     with F.activation_tap() as tap:
         d_loss = model.discriminator_step(cuda(lat), cuda(lab), cuda(real))
     d_grads = {k: p.grad.clone() for k, p in model.d_params.named.items()}
@@ -135,12 +169,14 @@ def run_step_parity(pg, opg, model, store, batch, res, tol=1e-3, grad_tol=None, 
     assert max(bad.values()) < grad_tol, sorted(bad.items(), key=lambda kv: -kv[1])[:5]
     zero = [k for k in od_grads if float(od_grads[k].abs().max()) == 0]
     assert all(float(d_grads[k].abs().max()) == 0 for k in zero)  # untaken branches: exactly zero gradient
-    for k, p in model.d_params.named.items():   # TF-Adam
-        assert globals()["relerr"](p.data, tr.d[k].data) < 2 * tol, k
+    stats["d_update"] = check_adam_update(model.d_params, d_before, d_grads, od_before, tr.d, od_grads, tr.hyper, "discriminator",
+                                          strict_vs_oracle=dtype == torch.float32)
     with torch.no_grad():   # the G run starts from identical discriminators (Adam's first step is sign-like: lr * g / |g|)
         for k, p in model.d_params.named.items():
             tr.d[k].copy_(p.data.cpu())
     # ---- G run: G(z) + mode-seeking double-backward, D(G(z)); everything on the HIP path
+    g_before = {k: p.data.clone() for k, p in model.g_params.named.items()}
+    og_before = {k: t.detach().clone() for k, t in tr.g.items()}
     with F.activation_tap() as tap:
         g_loss = model.generator_step(cuda(lat2), cuda(lab2))
     g_grads = {k: p.grad.clone() for k, p in model.g_params.named.items()}
@@ -158,8 +194,8 @@ def run_step_parity(pg, opg, model, store, batch, res, tol=1e-3, grad_tol=None, 
     assert max(bad.values()) < grad_tol, sorted(bad.items(), key=lambda kv: -kv[1])[:5]
     zero = [k for k in og_grads if float(og_grads[k].abs().max()) == 0]
     assert all(float(g_grads[k].abs().max()) == 0 for k in zero)
-    for k, p in model.g_params.named.items():   # TF-Adam
-        assert globals()["relerr"](p.data, tr.g[k].data) < 2 * tol, k
+    stats["g_update"] = check_adam_update(model.g_params, g_before, g_grads, og_before, tr.g, og_grads, tr.hyper, "generator",
+                                          strict_vs_oracle=dtype == torch.float32)
     assert model.global_step == 1
     if verbose:
         print("step parity:", stats)
@@ -414,6 +450,85 @@ def test_training_driver_visits_every_growing_regime_and_resumes(gpu_store, tmp_
     lab = torch.nn.functional.one_hot(torch.randint(0, 61, (4,)), 61).float().cuda()
     wav = again.generate(lat, lab)
     assert tuple(wav.shape) == (4, 1024) and torch.isfinite(wav).all()
+
+
+@pytest.mark.parametrize("graphs", [False, True])
+def test_train_trajectory_vs_oracle(graphs):
+    """The training driver against the oracle over SEVERAL iterations (models.py:189-194: per iteration one discriminator run and one
+    generator run on fresh batches, `global_step` bumped by the generator run only, growing_level = global_step / growing_steps,
+    gan_synth_main.py:51-54): six iterations of GANSynth.train() on the reduced PGGAN with growing_steps = 40, i.e. iteration 0 at the
+    2x16 stage, iterations 1-2 in the first fade-in, 3-5 in the second (two regime changes; with `graphs` each regime is captured
+    and replayed, the fade weight read from device memory), against oracle.torch_ref.Trainer driven by the same batches in the same
+    order.  Per iteration: both losses at 1e-3, global_step and growing_depth exact; at the end every parameter's accumulated
+    UPDATE (p_final - p_initial, six TF-Adam steps with carried m / v) at 1e-2 relative L2, untaken branches exactly unmoved."""
+    from gansynth_amd import variables
+    from gansynth_amd.models import GANSynth
+    from gansynth_amd.networks import PGGAN
+    from gansynth_amd.utils import Dict
+    growing_steps, total = 40, 6
+    kw = dict(min_resolution=[2, 16], max_resolution=[16, 128], min_channels=32, max_channels=64)
+    variables.set_default_store(variables.VariableStore(device="cuda"))
+    holder = {}
+    pg = PGGAN(growing_level=lambda: holder["m"].global_step / growing_steps, **kw)
+    opg = R.PGGAN(growing_level=lambda: holder["t"].global_step / growing_steps, **kw)
+    batches = [R.synthetic_batch(4, rank=i, image_shape=(2, 16, 128)) for i in range(2 * total)]   # (latents, labels, real images)
+    calls = {"real": 0, "fake": 0}
+
+    def real_input_fn():   # D run: images + labels of batch 2i; G run: the labels of batch 2i + 1 (models.GANSynth._next_inputs)
+        _, lab, real = batches[calls["real"]]
+        calls["real"] += 1
+        return cuda(real), cuda(lab)
+
+    def fake_input_fn():
+        lat = batches[calls["fake"]][0]
+        calls["fake"] += 1
+        return cuda(lat)
+
+    model = GANSynth(pg.generator, pg.discriminator, real_input_fn, fake_input_fn, None, Dict(R.DEFAULT_HYPER), use_graphs=graphs)
+    holder["m"] = model
+    gp, dp = opg.init_params(seed=0, bias_std=0.1)
+    model._build(cuda(batches[0][0]), cuda(batches[0][1]))
+    variables.default_store().load_state_dict({**gp, **dp})
+    tr = holder["t"] = R.Trainer(opg, gp, dp)
+    trace, orig = [], model.train_step
+
+    def step():
+        depth = pg.growing_depth
+        d_loss, g_loss = orig()
+        trace.append((depth, float(d_loss), float(g_loss), model.global_step))
+        return d_loss, g_loss
+
+    model.train_step = step
+    model.train(total_steps=total, log=None)
+    assert model.global_step == total and len(trace) == total and calls == {"real": 2 * total, "fake": 2 * total}
+    regimes = []
+    for i in range(total):
+        depth = opg.growing_depth
+        head = pg._head_depth(depth)
+        if not regimes or regimes[-1] != (head[0], head[1] is not None):
+            regimes.append((head[0], head[1] is not None))
+        od, _ = tr.d_step(batches[2 * i][0], batches[2 * i][1], batches[2 * i][2])
+        og, _ = tr.g_step(batches[2 * i + 1][0], batches[2 * i + 1][1])
+        h_depth, h_d, h_g, h_step = trace[i]
+        assert h_depth == depth and h_step == tr.global_step == i + 1, (i, h_depth, depth, h_step)
+        assert abs(h_d - float(od)) <= 1e-3 * max(1.0, abs(float(od))), f"iteration {i}: discriminator loss {h_d} vs oracle {float(od)}"
+        assert abs(h_g - float(og)) <= 1e-3 * max(1.0, abs(float(og))), f"iteration {i}: generator loss {h_g} vs oracle {float(og)}"
+    assert regimes == [(0, False), (1, True), (2, True)], regimes
+    assert model.d_params.t == tr.d_t == total and model.g_params.t == tr.g_t == total
+    worst = 0.0
+    for params, init, final in ((model.d_params, dp, tr.d), (model.g_params, gp, tr.g)):
+        for k, p in params.named.items():
+            ref = (final[k].detach() - init[k]).double()
+            upd = (p.data.cpu() - init[k]).double()
+            if float(ref.abs().max()) == 0.0:
+                assert float(upd.abs().max()) == 0.0, k   # a block no regime reached: untouched by six Adam steps
+                continue
+            err = float((upd - ref).norm() / ref.norm())
+            worst = max(worst, err)
+            assert err < 1e-2, f"{k}: accumulated update differs by {err:.3e} (relative L2)"
+    print(f"trajectory ({'graphs' if graphs else 'eager'}): worst accumulated-update error {worst:.2e}")
+    if graphs:
+        assert set(model._graphs) == {"d", "g"} and model._graph_key == (2, False)
 
 
 def test_generate_vs_oracle(gpu_store):
