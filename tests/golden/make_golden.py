@@ -51,6 +51,53 @@ def pggan_2x16():
     print("pggan_2x16_b4: d_loss", float(d_loss), "g_loss", float(g_loss))
 
 
+def sample_indices(numel, key, n=64):
+    """n fixed pseudo-random flat indices (logical NCHW order) into a tensor of `numel` elements."""
+    return np.random.default_rng(abs(hash_name(key)) % (2 ** 32)).integers(0, numel, size=n)
+
+
+def hash_name(name):
+    h = 2166136261
+    for ch in name.encode():
+        h = ((h ^ ch) * 16777619) % (2 ** 32)
+    return h
+
+
+def summarize(out, key, t):
+    """Per-tensor pin: float64 sum, sum of |.|, and 64 sampled elements (SURVEY.md 8c pin 2)."""
+    a = t.detach().double().flatten().numpy()
+    out["sum/" + key] = np.float64(a.sum())
+    out["sumabs/" + key] = np.float64(np.abs(a).sum())
+    out["samples/" + key] = a[sample_indices(a.size, key)].astype(np.float32)
+    out["numel/" + key] = np.int64(a.size)
+
+
+def full_forward_tensors(pg, gp, dp, lat, lab, real):
+    """{key: tensor} of one fully grown forward of both networks: the outputs and every leaky_relu OUTPUT in call order
+    (generator, then discriminator on the real images)."""
+    with torch.no_grad(), R.lrelu_tape("record") as rec:
+        fake = pg.generator(gp, lat, lab)
+        feats, logits = pg.discriminator(dp, real, lab)
+    tensors = {"generator/images": fake, "discriminator/features": feats, "discriminator/logits": logits}
+    for name, xs in rec.calls:
+        for i, x in enumerate(xs):
+            tensors["%s/leaky_relu_%02d" % (name, i)] = torch.nn.functional.leaky_relu(x, 0.2)
+    return tensors
+
+
+def pggan_full():
+    """SURVEY.md 8(c) pin 2: one fully grown 128x1024x2 forward of G and D at batch 4 (BASELINE.json configs[1] shapes), every
+    activation tensor as checksums + 64 sampled elements."""
+    pg = R.PGGAN([2, 16], [128, 1024], 32, 256, 1.0)
+    gp, dp = pg.init_params(seed=0, bias_std=0.1)
+    lat, lab, real = R.synthetic_batch(4, rank=0)
+    out = {}
+    for key, t in full_forward_tensors(pg, gp, dp, lat, lab, real).items():
+        summarize(out, key, t)
+    np.savez_compressed(os.path.join(HERE, "pggan_full_b4.npz"), **out)
+    print("pggan_full_b4:", len([k for k in out if k.startswith("sum/")]), "tensors")
+
+
 def spectral():
     wave = tone_and_noise()
     st = S.convert_to_spectrogram_stages(wave, **SPECTRAL)
@@ -69,4 +116,5 @@ def spectral():
 if __name__ == "__main__":
     torch.manual_seed(0)
     pggan_2x16()
+    pggan_full()
     spectral()

@@ -225,6 +225,22 @@ def test_fade_regimes_reduced_pggan(gpu_store, level):
     run_step_parity(pg, opg, model, gpu_store, 4, (16, 128))
 
 
+def test_channel_counts_that_are_not_powers_of_two(gpu_store):
+    """A PGGAN configured with 48 / 96 channels (networks.py:36-37 allows any min_channels << k): the transposed-conv blocks'
+    backward must not route the bias gradient through the fused pixel-norm kernel, which takes powers of two only
+    (kernels.norm_bwd_bias_ok), and the convs fall to the tile shapes / direct kernels that take these widths.  Full step parity."""
+    from gansynth_amd import kernels
+    from gansynth_amd.networks import PGGAN
+    from gansynth_amd.models import GANSynth
+    from gansynth_amd.utils import Dict
+    K = kernels.get()
+    assert K.norm_bwd_bias_ok(64) and K.norm_bwd_bias_ok(256, torch.bfloat16) and not K.norm_bwd_bias_ok(48) and not K.norm_bwd_bias_ok(96)
+    kw = dict(min_resolution=[2, 16], max_resolution=[8, 64], min_channels=48, max_channels=96)
+    pg, opg = PGGAN(growing_level=1.0, **kw), R.PGGAN(growing_level=1.0, **kw)
+    model = GANSynth(pg.generator, pg.discriminator, None, None, None, Dict(R.DEFAULT_HYPER))
+    run_step_parity(pg, opg, model, gpu_store, 4, (8, 64))
+
+
 def test_fully_grown_full_size_forward(gpu_store):
     """BASELINE.json configs[1] shape (128x1024x2, fully grown), forward of both networks, batch 4."""
     pg, opg, model = make(1.0, gpu_store)
@@ -240,6 +256,31 @@ def test_fully_grown_full_size_forward(gpu_store):
     assert fake.shape == (4, 2, 128, 1024)
     assert relerr(fake, ofake) < 1e-3
     assert relerr(feats, ofeats) < 1e-3 and relerr(logits, ologits) < 1e-3
+    # ... and against the committed full-size fixture (SURVEY.md 8c pin 2: float64 checksums + 64 sampled elements of the outputs and
+    # of every leaky_relu output of this very forward, generated by tests/golden/make_golden.py): the HIP path is pinned to a file,
+    # not only to an oracle run of the same session
+    from gansynth_amd import functional as F
+    from tests.golden import make_golden as MG
+    gold = np.load(os.path.join(GOLD, "pggan_full_b4.npz"))
+    with torch.no_grad(), F.activation_tap() as tap:
+        fake = pg.generator(cuda(lat), cuda(lab))
+        feats, logits = pg.discriminator(cuda(real), cuda(lab))
+    tensors = {"generator/images": fake, "discriminator/features": feats, "discriminator/logits": logits}
+    for name, zs in tap.calls:
+        for i, z in enumerate(zs):
+            tensors["%s/leaky_relu_%02d" % (name, i)] = z
+    keys = sorted(k[len("sum/"):] for k in gold.files if k.startswith("sum/"))
+    assert keys == sorted(tensors), (keys, sorted(tensors))
+    for key in keys:
+        a = tensors[key].detach().double().cpu().contiguous().flatten().numpy()   # logical NCHW order, like the oracle's
+        assert a.size == int(gold["numel/" + key]), key
+        sumabs = float(gold["sumabs/" + key])
+        assert abs(np.abs(a).sum() - sumabs) <= 1e-4 * sumabs, (key, np.abs(a).sum(), sumabs)
+        assert abs(a.sum() - float(gold["sum/" + key])) <= 1e-4 * sumabs, (key, a.sum(), float(gold["sum/" + key]))
+        want = gold["samples/" + key].astype(np.float64)
+        got = a[MG.sample_indices(a.size, key)]
+        rms = float(np.sqrt(np.mean(np.square(a))))
+        assert np.abs(got - want).max() <= 1e-3 * max(rms, np.abs(want).max()), (key, np.abs(got - want).max(), rms)
 
 
 def test_fully_grown_full_size_step_vs_oracle(gpu_store):

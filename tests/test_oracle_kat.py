@@ -126,3 +126,26 @@ def test_golden_fixtures_are_current():
     lat, lab, real = R.synthetic_batch(4, rank=0)
     fake = pg.generator(gp, lat, lab)
     assert np.abs(fake[:, :, ::64, ::64].detach().numpy() - g2["fake_2x16"]).max() < 1e-5
+
+
+def test_full_size_forward_fixture_is_current():
+    """SURVEY.md 8(c) pin 2: the fully grown 128x1024x2 forward of both networks at batch 4 -- the outputs and every leaky_relu
+    output, as float64 checksums + 64 sampled elements per tensor (tests/golden/pggan_full_b4.npz) -- freezes the full-size oracle
+    against edits.  (The GPU suite checks the HIP path against the same file.)"""
+    from tests.golden import make_golden as MG
+    gold = np.load(os.path.join(GOLD, "pggan_full_b4.npz"))
+    pg = R.PGGAN([2, 16], [128, 1024], 32, 256, 1.0)
+    gp, dp = pg.init_params(seed=0, bias_std=0.1)
+    lat, lab, real = R.synthetic_batch(4, rank=0)
+    tensors = MG.full_forward_tensors(pg, gp, dp, lat, lab, real)
+    keys = sorted(k[len("sum/"):] for k in gold.files if k.startswith("sum/"))
+    assert keys == sorted(tensors) and len(keys) == 32
+    assert tuple(tensors["generator/images"].shape) == (4, 2, 128, 1024)
+    for key in keys:
+        a = tensors[key].detach().double().flatten().numpy()
+        assert a.size == int(gold["numel/" + key])
+        assert abs(a.sum() - float(gold["sum/" + key])) <= 1e-6 * float(gold["sumabs/" + key]), key
+        assert abs(np.abs(a).sum() - float(gold["sumabs/" + key])) <= 1e-6 * float(gold["sumabs/" + key]), key
+        got = a[MG.sample_indices(a.size, key)]
+        assert np.abs(got - gold["samples/" + key]).max() <= 1e-5 * max(1.0, np.abs(gold["samples/" + key]).max()), key
+
