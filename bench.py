@@ -128,15 +128,26 @@ def spectral_bench(batch=256, iters=1000, warmup=300, cpu=True):
         # the same workload (all `batch` waveforms) on the host's own cores -- the numpy oracle in one worker process
         # per core (oracle/cpu_bench.py; its own interpreter, so that the pool is forked from a process without HIP state)
         import subprocess
-        res = subprocess.run([sys.executable, "-m", "oracle.cpu_bench", "--examples", str(batch)], cwd=ROOT, capture_output=True, text=True, timeout=600)
-        if res.returncode == 0:
+        host = os.cpu_count() or 1
+        best, err = None, None
+        for procs in sorted({host, max(1, host // 2), max(1, host // 4)}, reverse=True):   # all hardware threads, one per core pair, half of those
+            res = subprocess.run([sys.executable, "-m", "oracle.cpu_bench", "--examples", str(batch), "--procs", str(procs)], cwd=ROOT,
+                                 capture_output=True, text=True, timeout=600)
+            if res.returncode != 0:
+                err = (res.stderr or res.stdout)[-300:]
+                continue
             r = json.loads(res.stdout.strip().splitlines()[-1])
+            if best is None or r["seconds"] < best["seconds"]:
+                best = r
+        if best is not None:
+            r = best
             out["cpu_baseline"] = {"value": r["examples"] / r["seconds"], "unit": "examples/sec", "cores": r["procs"], "host_cores": r["host_cores"],
                                    "kind": "port", "cpu_model": cpu_model(), "seconds": r["seconds"],
                                    "sample": "all %d waveforms through the numpy oracle (oracle/spectral_np.py, fp32), %d worker processes of one thread each "
-                                             "(oracle/cpu_bench.py), timed after one warm-up example per worker" % (r["examples"], r["procs"])}
+                                             "(oracle/cpu_bench.py; the fastest of all / half / a quarter of the %d hardware threads), timed after one warm-up "
+                                             "example per worker" % (r["examples"], r["procs"], r["host_cores"])}
         else:
-            out["cpu_baseline"] = {"error": (res.stderr or res.stdout)[-300:]}
+            out["cpu_baseline"] = {"error": err}
     return out
 
 
@@ -296,6 +307,14 @@ def main():
                "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         raise SystemExit(subprocess.call(cmd, env=env))
 
+    # rank 0 prints exactly ONE line on stdout: whatever native libraries print there (RCCL's version banner ...) goes to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        os.write(json_fd, (json.dumps(obj) + "\n").encode())
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -311,11 +330,11 @@ def main():
         else:
             t = torch.tensor([0, 0, 1])
         if rank == 0:
-            print(json.dumps({"launch_check": True, "n_gpus": world, "ranks_joined": int(t[2]), "rank_sum": int(t[0]), "local_rank_sum": int(t[1])}), flush=True)
+            emit({"launch_check": True, "n_gpus": world, "ranks_joined": int(t[2]), "rank_sum": int(t[0]), "local_rank_sum": int(t[1])})
         return
     torch.cuda.set_device(local_rank)
     if args.spectral_only:
-        print(json.dumps(spectral_bench(cpu=not args.no_cpu_baseline)), flush=True)
+        emit(spectral_bench(cpu=not args.no_cpu_baseline))
         return
     distributed = world > 1 or bool(os.environ.get("GS_BENCH_FORCE_DIST"))  # (the env switch exercises the RCCL path on one GPU)
     if distributed:
@@ -437,7 +456,7 @@ def main():
             out["spectral_inverse"] = inverse_bench()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out), flush=True)
+        emit(out)
     if distributed:
         torch.distributed.destroy_process_group()
 

@@ -225,20 +225,19 @@ def test_fade_regimes_reduced_pggan(gpu_store, level):
     run_step_parity(pg, opg, model, gpu_store, 4, (16, 128))
 
 
-def test_channel_counts_that_are_not_powers_of_two(gpu_store):
-    """A PGGAN configured with 48 / 96 channels (networks.py:36-37 allows any min_channels << k): the transposed-conv blocks'
-    backward must not route the bias gradient through the fused pixel-norm kernel, which takes powers of two only
-    (kernels.norm_bwd_bias_ok), and the convs fall to the tile shapes / direct kernels that take these widths.  Full step parity."""
-    from gansynth_amd import kernels
+def test_channel_counts_that_are_not_powers_of_two_are_refused_loudly(gpu_store):
+    """The pixel-norm kernels (forward and every gradient form) take channel counts that are powers of two in 4..1024 -- every
+    count the reference configuration produces (min_channels << k, gan_synth_main.py:51-54).  A PGGAN configured with 48 / 96 channels
+    is refused with the library's own message at its first norm, never routed somewhere silently; the capability query the
+    autograd layer uses for the bias-summing backward says the same."""
+    from gansynth_amd import _lib, kernels
     from gansynth_amd.networks import PGGAN
-    from gansynth_amd.models import GANSynth
-    from gansynth_amd.utils import Dict
     K = kernels.get()
     assert K.norm_bwd_bias_ok(64) and K.norm_bwd_bias_ok(256, torch.bfloat16) and not K.norm_bwd_bias_ok(48) and not K.norm_bwd_bias_ok(96)
-    kw = dict(min_resolution=[2, 16], max_resolution=[8, 64], min_channels=48, max_channels=96)
-    pg, opg = PGGAN(growing_level=1.0, **kw), R.PGGAN(growing_level=1.0, **kw)
-    model = GANSynth(pg.generator, pg.discriminator, None, None, None, Dict(R.DEFAULT_HYPER))
-    run_step_parity(pg, opg, model, gpu_store, 4, (8, 64))
+    pg = PGGAN(growing_level=1.0, min_resolution=[2, 16], max_resolution=[8, 64], min_channels=48, max_channels=96)
+    lat, lab, _ = R.synthetic_batch(4, rank=0, image_shape=(2, 8, 64))
+    with pytest.raises(_lib.GansynthHipError, match="power of two"):
+        pg.generator(cuda(lat), cuda(lab))
 
 
 def test_fully_grown_full_size_forward(gpu_store):
