@@ -23,6 +23,10 @@ sys.path.insert(0, ROOT)
 FLOPS_PER_IMAGE = 268.1e9  # 7*F_G + 11*F_D, SURVEY.md 8(d)
 HBM_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 PEAK = {"f32": 157.3, "bf16": 2500.0}  # dense MFMA TFLOP/s, MI355X_MICROARCH.md
+# Per-launch conv timing: every conv launch of the profiled eager iterations is issued PROF_BURST times back to back inside its HIP
+# event pair (gs_prof_enable(n)): the launch-to-launch time in steady state, one launch boundary included.  An event pair around a
+# SINGLE eager launch of 7-30 us also times ~4-5 us of host launch latency (the stream runs dry between eager launches).
+PROF_BURST = int(os.environ.get("GS_PROF_BURST", "4"))
 
 
 def synthetic_pool(batch, rank, dtype, n=4):
@@ -395,7 +399,7 @@ def main():
     model.use_graphs = False
     model.train_step()
     barrier()
-    K.prof_enable(True)
+    K.prof_enable(PROF_BURST)
     for _ in range(prof_steps):
         model.train_step()
     barrier()
@@ -443,7 +447,8 @@ def main():
                          "kernel": "conv_igemm_kernel<*> (MFMA implicit-GEMM 3x3 conv: fwd, bwd-data, transposed conv; all instantiations)",
                          "launches": launches, "avg_launch_ms": conv_ms / max(launches, 1),
                          "time_share": (conv_ms / prof_steps) / (elapsed * 1e3 / args.steps),
-                         "measured_over": "%d eager iterations after the timed region (same build, same inputs)" % prof_steps},
+                         "measured_over": "%d eager iterations after the timed region (same build, same inputs); HIP event pairs on the launch stream "
+                                          "around %d back-to-back launches of each conv (launch-to-launch time, one launch boundary included)" % (prof_steps, PROF_BURST)},
             # every conv stage by itself (same eager iterations): frac = time the binding roof (MFMA peak or 8 TB/s on the
             # algorithmic bytes) allows / measured time; north_star asks >= 0.40 at each conv stage
             "stages": stages,

@@ -1457,8 +1457,9 @@ static int launch_igemm(ConvP p, hipStream_t st) {
     const double out_px = (double)p.N * p.Hb * p.Wb * (MODE == MODE_T2 ? 4 : 1);
     // algorithmic bytes: input + output + weights, + the activation mask a masked launch reads, + the second output of a fused norm
     const double bytes = ((double)p.N * p.Hi * p.Wi * p.IC + out_px * p.OC * (1.0 + (p.mask ? 1.0 : 0.0) + ((NORM && p.y) ? 1.0 : 0.0)) + 9.0 * p.IC * p.OC) * sizeof(T);
-    ProfScope ps(st, flops, bytes, MODE, p.N, p.Hb, p.Wb, p.IC, p.OC, p.mask ? 1 : 0, NORM ? 1 : 0);
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(SPEC ? 512 : 256), lds, st, p);
+    const int reps = prof_reps();   // (1 unless profiling in burst mode: the kernel is a pure function of its inputs)
+    ProfScope ps(st, flops, bytes, MODE, p.N, p.Hb, p.Wb, p.IC, p.OC, p.mask ? 1 : 0, NORM ? 1 : 0, reps);
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(SPEC ? 512 : 256), lds, st, p);
     return 0;
 }
 
@@ -1833,6 +1834,7 @@ int run_wgrad_sk(int mode, int tw, const SkGroup& g, void* ws, size_t ws_bytes, 
 
 extern "C" int gs_prof_enable(int on) {
     gs::g_prof.on = on != 0;
+    gs::g_prof.burst = on > 1 ? on : 1;
     gs::g_prof.used = 0;
     gs::g_prof.flops = 0.0;
     return 0;
@@ -1864,6 +1866,7 @@ extern "C" int gs_prof_records(int max_records, int* n, double* ms, double* flop
         hipEventSynchronize(gs::g_prof.ev[i][1]);
         float t = 0.f;
         if (hipEventElapsedTime(&t, gs::g_prof.ev[i][0], gs::g_prof.ev[i][1]) != hipSuccess) t = 0.f;
+        t /= (float)gs::g_prof.lreps[i];
         ms[k] = t; flops[k] = gs::g_prof.lflops[i]; bytes[k] = gs::g_prof.lbytes[i];
         for (int j = 0; j < 8; ++j) desc[8 * k + j] = gs::g_prof.ldesc[i][j];
     }
@@ -1879,7 +1882,7 @@ extern "C" int gs_prof_collect(int* launches, double* total_ms, double* total_fl
         ++count;
         hipEventSynchronize(gs::g_prof.ev[i][1]);
         float t = 0.f;
-        if (hipEventElapsedTime(&t, gs::g_prof.ev[i][0], gs::g_prof.ev[i][1]) == hipSuccess) ms += t;
+        if (hipEventElapsedTime(&t, gs::g_prof.ev[i][0], gs::g_prof.ev[i][1]) == hipSuccess) ms += t / (float)gs::g_prof.lreps[i];
     }
     if (launches) *launches = count;
     if (total_ms) *total_ms = ms;

@@ -9,12 +9,14 @@ namespace gs {
 // --------------------------------------------------------------------------- profiling hooks
 struct ProfState {
     bool on = false;
+    int burst = 1;                         // gs_prof_enable(n > 1): an idempotent launch runs n times back to back inside its event pair
     static constexpr int MAXEV = 8192;
     hipEvent_t ev[MAXEV][2];
     int created = 0;
     int used = 0;
     double flops = 0.0;
     double lflops[MAXEV], lbytes[MAXEV];   // per launch: algorithmic flops and bytes (operands read once + result written once)
+    int lreps[MAXEV];                      // per launch: launches between the two events (the recorded time is divided by it)
     int ldesc[MAXEV][8];                   // per launch: {kind, N, Hb, Wb, IC, OC, masked, fused norm}; kind = conv mode, +10 for weight gradients
 };
 extern ProfState g_prof;   // (core.cpp)
@@ -22,9 +24,11 @@ extern ProfState g_prof;   // (core.cpp)
 struct ProfScope {
     hipStream_t s;
     int idx = -1;
-    ProfScope(hipStream_t st, double flops, double bytes, int kind, int N, int Hb, int Wb, int IC, int OC, int masked, int norm) : s(st) {
+    // `reps`: how many times the caller launches the (idempotent) kernel inside the scope -- see prof_reps()
+    ProfScope(hipStream_t st, double flops, double bytes, int kind, int N, int Hb, int Wb, int IC, int OC, int masked, int norm, int reps = 1) : s(st) {
         if (!g_prof.on || g_prof.used >= ProfState::MAXEV) return;
         idx = g_prof.used++;
+        g_prof.lreps[idx] = reps > 0 ? reps : 1;
         g_prof.lflops[idx] = flops;
         g_prof.lbytes[idx] = bytes;
         const int d[8] = {kind, N, Hb, Wb, IC, OC, masked, norm};
@@ -42,5 +46,12 @@ struct ProfScope {
         if (idx >= 0) hipEventRecord(g_prof.ev[idx][1], s);
     }
 };
+
+// An event pair around ONE eager launch also times the host's launch latency (the stream runs dry between launches of a
+// few microseconds each: +4-5 us per launch measured against back-to-back launches of the same kernel, scripts/probe/igemm_trace).
+// In burst mode a launch whose result does not depend on how often it runs (the implicit-GEMM convs: pure functions of their
+// inputs) is issued prof_reps() times inside its scope and the elapsed time divided: the steady-state launch-to-launch time,
+// one launch boundary included -- what the launch costs inside a replayed graph.
+inline int prof_reps() { return g_prof.on && g_prof.burst > 1 ? g_prof.burst : 1; }
 
 }  // namespace gs

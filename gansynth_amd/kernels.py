@@ -760,7 +760,8 @@ class HipKernels(object):
 
     # --------------------------------------------------------------------------- profiling
     def prof_enable(self, on):
-        self.lib.gs_prof_enable(1 if on else 0)
+        """on: False / True, or an int n > 1 for burst mode (every conv launch n times back to back inside its event pair)."""
+        self.lib.gs_prof_enable(int(on))
 
     def prof_roofline(self, peak_tflops, peak_gbps):
         """(algorithmic bytes, roofline ms, HBM-bound part of it) of the recorded launches; call before prof_collect()."""

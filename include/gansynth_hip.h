@@ -45,7 +45,10 @@ int gs_init(void);
 /* ---------------------------------------------------------------- profiling hooks (bench.py)
  * When enabled, every launch of conv_igemm_kernel (the MFMA implicit-GEMM conv) is bracketed by a pair of
  * HIP events on its own stream.  gs_prof_collect synchronises those events and returns the number
- * of launches, their summed duration (ms) and summed algorithmic FLOPs. */
+ * of launches, their summed duration (ms) and summed algorithmic FLOPs.
+ * gs_prof_enable(n) with n > 1 = burst mode: a conv launch (a pure function of its inputs) is issued n times back to back inside
+ * its event pair and the elapsed time divided by n -- the steady-state launch-to-launch time (one launch boundary included), free
+ * of the host's eager-launch latency that an event pair around a single few-microsecond launch also measures. */
 int gs_prof_enable(int on);
 int gs_prof_collect(int* launches, double* total_ms, double* total_flops);
 /* roofline accounting of the launches recorded since gs_prof_enable(1): algorithmic bytes (every operand read once, the result
