@@ -94,6 +94,7 @@ SIGNATURES = {
     "gs_gan_d_loss": (I, [P, P, P, P, F, I, I, P, P, P, P, I, P]),
     "gs_gan_g_loss": (I, [P, P, P, F, F, I, I, P, P, P, I, P]),
     "gs_adam_tf_step": (I, [P, P, P, P, L, F, F, F, F, F, P]),
+    "gs_adam_tf_step_zero_grad": (I, [P, P, P, P, L, F, F, F, F, F, P]),
     "gs_spectral_plan_create": (I, [POINTER(c_void_p), I, I, I, P, P]),
     "gs_spectral_plan_destroy": (I, [P]),
     "gs_stft_fwd": (I, [P, P, I, I, I, P, P, P]),

@@ -662,7 +662,9 @@ __global__ void row_scale_kernel(const T* __restrict__ x, const float* __restric
 }
 
 // -------------------------------------------------------------------------------- Adam
-static __global__ void adam_tf_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+// ZERO: the gradient is cleared behind the update (the trainer's next run accumulates into it from zero: no separate fill pass)
+template <bool ZERO>
+static __global__ void adam_tf_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                       long n, float lr_t, float b1, float b2, float eps, float gs) {
     const long nvec = n >> 2;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
@@ -681,6 +683,7 @@ static __global__ void adam_tf_kernel(float* __restrict__ p, const float* __rest
         reinterpret_cast<float4*>(p)[i] = pv;
         reinterpret_cast<float4*>(m)[i] = mv;
         reinterpret_cast<float4*>(v)[i] = vv;
+        if (ZERO) reinterpret_cast<float4*>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     const long t = nvec * 4 + (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t < n) {
@@ -688,6 +691,7 @@ static __global__ void adam_tf_kernel(float* __restrict__ p, const float* __rest
         m[t] = b1 * m[t] + (1.f - b1) * gr;
         v[t] = b2 * v[t] + (1.f - b2) * gr * gr;
         p[t] -= lr_t * m[t] / (sqrtf(v[t]) + eps);
+        if (ZERO) g[t] = 0.f;
     }
 }
 
@@ -957,7 +961,17 @@ extern "C" int gs_row_scale(const void* x, const float* s, float alpha, void* ou
 extern "C" int gs_adam_tf_step(float* p, const float* g, float* m, float* v, int64_t numel, float lr_t, float beta1, float beta2,
                                float eps, float grad_scale, void* stream) {
     GS_CHECK_ARG(numel > 0, "adam: bad args");
-    hipLaunchKernelGGL(adam_tf_kernel, dim3(ew_grid((numel >> 2) + 4)), dim3(256), 0, as_stream(stream), p, g, m, v, (long)numel, lr_t, beta1, beta2, eps, grad_scale);
+    hipLaunchKernelGGL(adam_tf_kernel<false>, dim3(ew_grid((numel >> 2) + 4)), dim3(256), 0, as_stream(stream), p, const_cast<float*>(g), m, v, (long)numel, lr_t,
+                       beta1, beta2, eps, grad_scale);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gs_adam_tf_step_zero_grad(float* p, float* g, float* m, float* v, int64_t numel, float lr_t, float beta1, float beta2,
+                                         float eps, float grad_scale, void* stream) {
+    GS_CHECK_ARG(numel > 0, "adam: bad args");
+    hipLaunchKernelGGL(adam_tf_kernel<true>, dim3(ew_grid((numel >> 2) + 4)), dim3(256), 0, as_stream(stream), p, g, m, v, (long)numel, lr_t, beta1, beta2, eps,
+                       grad_scale);
     GS_CHECK_LAUNCH();
     return 0;
 }

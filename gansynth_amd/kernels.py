@@ -748,12 +748,14 @@ class HipKernels(object):
                                           _dt(fake_logits), _stream()), "gs_gan_g_loss")
         return loss, g_fake, g_sumsq
 
-    def adam_tf_step(self, p, g, m, v, lr_t, beta1, beta2, eps, grad_scale=1.0, refresh=True):
-        """`refresh=False`: the caller updates a buffer range by range (gradient buckets) and refreshes the operands once."""
+    def adam_tf_step(self, p, g, m, v, lr_t, beta1, beta2, eps, grad_scale=1.0, refresh=True, zero_grad=False):
+        """`refresh=False`: the caller updates a buffer range by range (gradient buckets) and refreshes the operands once.
+        `zero_grad`: g is cleared behind the update (the next run accumulates from zero without a fill pass)."""
         for t in (p, g, m, v):
             assert t.dtype == torch.float32 and t.is_contiguous()
-        _lib.check(self.lib.gs_adam_tf_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), float(lr_t), float(beta1),
-                                            float(beta2), float(eps), float(grad_scale), _stream()), "gs_adam_tf_step")
+        fn = self.lib.gs_adam_tf_step_zero_grad if zero_grad else self.lib.gs_adam_tf_step
+        _lib.check(fn(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), float(lr_t), float(beta1),
+                      float(beta2), float(eps), float(grad_scale), _stream()), "gs_adam_tf_step")
         if refresh:
             self.invalidate_weights(p)  # parameter values changed: cached kernel operands of that buffer are stale ...
             self.refresh_weights(p)     # ... and are rebuilt here in one launch

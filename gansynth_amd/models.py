@@ -73,6 +73,7 @@ class _FlatParams(object):
             p.data = self.flat[off:off + n].view(p.shape)
             p.grad = self.grad[off:off + n].view(p.shape)
         self.t = 0
+        self.grad_clean = True   # the flat gradient is all zeros (fresh buffer / cleared by the optimizer step)
         self.buckets = [(0, total)]
         self._offsets = list(zip(offs, sizes, self.named.keys()))
 
@@ -111,15 +112,27 @@ class _FlatParams(object):
 
     def zero_grad(self):
         self.grad.zero_()
+        self.grad_clean = False   # (about to be accumulated into)
         for p in self.named.values():
             if p.grad is None:
                 raise RuntimeError("parameter lost its flat gradient view")
+
+    def begin_run(self):
+        """Gradients of a run are accumulated in place from zero.  The previous optimizer step may have left the buffer cleared
+        (gs_adam_tf_step_zero_grad, `grad_clean`): then there is no fill pass."""
+        if self.grad_clean:
+            self.grad_clean = False
+            for p in self.named.values():
+                if p.grad is None:
+                    raise RuntimeError("parameter lost its flat gradient view")
+        else:
+            self.zero_grad()
 
 
 class GANSynth(object):
 
     def __init__(self, generator, discriminator, real_input_fn, fake_input_fn, spectral_params, hyper_params,
-                 dtype=torch.float32, store=None, distributed=False, use_graphs=False, bucket_bytes=None):
+                 dtype=torch.float32, store=None, distributed=False, use_graphs=False, bucket_bytes=None, keep_gradients=False):
         self.generator, self.discriminator = generator, discriminator
         self.real_input_fn, self.fake_input_fn = real_input_fn, fake_input_fn
         self.spectral_params, self.hyper_params = spectral_params, hyper_params
@@ -129,6 +142,9 @@ class GANSynth(object):
         self.world = torch.distributed.get_world_size() if self.distributed else 1
         self.rank = torch.distributed.get_rank() if self.distributed else 0
         self.bucket_bytes = None if bucket_bytes is None else int(bucket_bytes)   # gradient all-reduce granularity (None: see _build)
+        # False: the optimizer step clears the flat gradient it consumed (one pass less per run: the next run accumulates from zero);
+        # True: `p.grad` of every variable still holds the run's (all-reduced, unscaled) gradient after the step -- tests, inspection
+        self.keep_gradients = bool(keep_gradients)
         self._inflight = None                   # (params, [(bucket, work)]) all-reduces launched during the eager backward's tail
         self._comm = None                       # comm.RcclComm: the gradient all-reduce on the backward's own stream (HIP + nccl only)
         self._peeked = None                     # a batch fetched ahead of the first step (train: eager build / restore)
@@ -327,8 +343,10 @@ class GANSynth(object):
         params.t += 1
         lr_t = lr * math.sqrt(1.0 - beta2 ** params.t) / (1.0 - beta1 ** params.t)
         K = kernels.get()
+        zero = not self.keep_gradients
         if not self.distributed or reduced:
-            K.adam_tf_step(params.flat, params.grad, params.m, params.v, lr_t, beta1, beta2, 1.0e-8, 1.0 / self.world)
+            K.adam_tf_step(params.flat, params.grad, params.m, params.v, lr_t, beta1, beta2, 1.0e-8, 1.0 / self.world, zero_grad=zero)
+            params.grad_clean = zero
             return
         works = {}
         if self._inflight is not None and self._inflight[0] is params:
@@ -340,7 +358,8 @@ class GANSynth(object):
         for i, (a, b) in enumerate(params.buckets):
             works[i].wait()   # (stream-side wait: the host does not block)
             K.adam_tf_step(params.flat[a:b], params.grad[a:b], params.m[a:b], params.v[a:b], lr_t, beta1, beta2, 1.0e-8,
-                           1.0 / self.world, refresh=False)
+                           1.0 / self.world, refresh=False, zero_grad=zero)
+        params.grad_clean = zero   # (the buckets cover the whole buffer)
         K.invalidate_weights(params.flat)
         K.refresh_weights(params.flat)
 
@@ -349,11 +368,11 @@ class GANSynth(object):
         if which == "d":
             self.g_params.requires_grad_(False)
             self.d_params.requires_grad_(True)
-            self.d_params.zero_grad()
+            self.d_params.begin_run()
             return self._d_losses_a(*inputs, fused=self._fused_losses())        # (labels, real_images)
         self.g_params.requires_grad_(True)
         self.d_params.requires_grad_(False)
-        self.g_params.zero_grad()
+        self.g_params.begin_run()
         return self._g_losses_a(*inputs, fused=self._fused_losses())            # (latents, labels)
 
     def _part_b(self, which, part_a, *inputs):
@@ -478,6 +497,12 @@ class GANSynth(object):
                 finally:
                     self._warming_up = False
                 torch.cuda.current_stream().wait_stream(side)
+                # the warm-up pass left its gradients in the flat buffer and no optimizer step clears them: a graph that relies on the
+                # step's clearing (keep_gradients = False: no fill inside) must find the buffer as every later replay will
+                params_ = self.d_params if which == "d" else self.g_params
+                if not self.keep_gradients:
+                    params_.grad.zero_()
+                    params_.grad_clean = True
                 # the prepared weight operands live in persistent workspaces that the optimizer step refreshes eagerly
                 # (kernels.adam_tf_step): bring them up to date now so that the captured graph holds no re-layout launches
                 K.refresh_weights()

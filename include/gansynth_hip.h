@@ -354,6 +354,10 @@ int gs_gan_g_loss(const void* fake_logits, const void* labels, const float* sums
  *   lr_t = lr*sqrt(1-b2^t)/(1-b1^t) computed by the caller; grad_scale multiplies g first (1/world). */
 int gs_adam_tf_step(float* p, const float* g, float* m, float* v, int64_t numel, float lr_t, float beta1,
                     float beta2, float eps, float grad_scale, void* stream);
+/* the same step, and g is cleared behind it: tf.gradients starts every run from zero (models.py:81-89 builds the sums anew), the
+ * flat gradient buffers are accumulated into across a run, so the update hands the next run a zeroed buffer without a fill pass */
+int gs_adam_tf_step_zero_grad(float* p, float* g, float* m, float* v, int64_t numel, float lr_t, float beta1,
+                              float beta2, float eps, float grad_scale, void* stream);
 
 /* ------------------------------------------------------------------------------ spectral
  * spectral_ops.py:45-94.  Plan = immutable per-device tables (Hann window, twiddles, CSR mel matrix

@@ -24,7 +24,7 @@ def cuda(t):
 def run(dtype, hyper, d_flat=None):
     variables.set_default_store(variables.VariableStore(device="cuda"))
     pg, opg = PGGAN(growing_level=1.0, **kw), R.PGGAN(growing_level=1.0, **kw)
-    model = GANSynth(pg.generator, pg.discriminator, None, None, None, Dict(hyper), dtype=dtype)
+    model = GANSynth(pg.generator, pg.discriminator, None, None, None, Dict(hyper), dtype=dtype, keep_gradients=True)
     lat, lab, real = R.synthetic_batch(B, rank=0)
     lat2, lab2, _ = R.synthetic_batch(B, rank=1)
     gp, dp = opg.init_params(seed=0, bias_std=0.1)

@@ -212,12 +212,14 @@ class CpuEmuKernels(object):
     def row_scale(self, x, s, alpha=1.0):
         return x.detach() * (alpha * s.detach()).to(x.dtype).view(-1, *([1] * (x.dim() - 1)))
 
-    def adam_tf_step(self, p, g, m, v, lr_t, beta1, beta2, eps, grad_scale=1.0, refresh=True):
+    def adam_tf_step(self, p, g, m, v, lr_t, beta1, beta2, eps, grad_scale=1.0, refresh=True, zero_grad=False):
         with torch.no_grad():
             gr = g * grad_scale
             m.mul_(beta1).add_(gr, alpha=1 - beta1)
             v.mul_(beta2).addcmul_(gr, gr, value=1 - beta2)
             p.sub_(lr_t * m / (v.sqrt() + eps))
+            if zero_grad:
+                g.zero_()
 
 
 def self_conv(x, w, stride, alpha):

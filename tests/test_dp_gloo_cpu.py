@@ -46,7 +46,7 @@ def _init(rank, world, port):
 def _worker(rank, world, port, out_dir, bucket_bytes):
     _init(rank, world, port)
     pg, hyper, GANSynth = _setup()
-    model = GANSynth(pg.generator, pg.discriminator, None, None, None, hyper, distributed=True, bucket_bytes=bucket_bytes)
+    model = GANSynth(pg.generator, pg.discriminator, None, None, None, hyper, distributed=True, bucket_bytes=bucket_bytes, keep_gradients=True)
     lat, lab, img = _shard(rank)
     model.discriminator_step(lat, lab, img)
     nd = len(model.d_params.buckets)

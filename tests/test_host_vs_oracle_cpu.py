@@ -69,7 +69,7 @@ def test_losses_grads_and_adam_match_oracle(cpu_backend, level, fake_penalty):
     lat2, lab2, _ = _inputs(seed=1)
     gp, dp = _oracle_params(opg, 16, 5)
     hyper = Dict(R.DEFAULT_HYPER, fake_gradient_penalty_weight=fake_penalty)
-    model = GANSynth(pg.generator, pg.discriminator, None, None, None, hyper)
+    model = GANSynth(pg.generator, pg.discriminator, None, None, None, hyper, keep_gradients=True)
     model._build(lat, lab)
     variables.default_store().load_state_dict({**gp, **dp})
     tr = R.Trainer(opg, gp, dp, hyper)

@@ -27,7 +27,8 @@ def make(level, store, full=True, dtype=torch.float32):
     kw = dict(min_resolution=[2, 16], max_resolution=[128, 1024], min_channels=32, max_channels=256) if full else \
         dict(min_resolution=[2, 16], max_resolution=[16, 128], min_channels=32, max_channels=64)
     pg, opg = PGGAN(growing_level=level, **kw), R.PGGAN(growing_level=level, **kw)
-    model = GANSynth(pg.generator, pg.discriminator, None, None, None, Dict(R.DEFAULT_HYPER), dtype=dtype)
+    model = GANSynth(pg.generator, pg.discriminator, None, None, None, Dict(R.DEFAULT_HYPER), dtype=dtype,
+                     keep_gradients=True)   # (the parity tests read p.grad after the optimizer step)
     return pg, opg, model
 
 
@@ -380,6 +381,36 @@ def test_hipgraph_replay_equals_eager(gpu_store):
         _same_up_to_accumulation_order(a, b, f"loss {i}")
     _same_up_to_accumulation_order(out[False][1], out[True][1], "discriminator parameters")
     _same_up_to_accumulation_order(out[False][2], out[True][2], "generator parameters")
+
+
+@pytest.mark.parametrize("graphs", [False, True])
+def test_optimizer_step_clears_the_gradient_it_consumed(graphs):
+    """keep_gradients = False (the default): gs_adam_tf_step_zero_grad leaves the flat gradient cleared and the next run skips its fill
+    pass (no fill inside the captured graphs either).  Same parameters, bit for bit, as the trainer that keeps the gradients and
+    fills before every run; the buffers are all zeros after every step."""
+    from gansynth_amd import variables
+    out = {}
+    for keep in (True, False):
+        variables.set_default_store(variables.VariableStore(device="cuda"))
+        pg, opg, model = make(1.0, variables.default_store(), full=False)
+        model.keep_gradients, model.use_graphs = keep, graphs
+        gp, dp = opg.init_params(seed=0, bias_std=0.1)
+        for step in range(4):
+            lat, lab, real = R.synthetic_batch(4, rank=step, image_shape=(2, 16, 128))
+            if step == 0:
+                model._build(cuda(lat), cuda(lab))
+                variables.default_store().load_state_dict({**gp, **dp})
+            model.discriminator_step(cuda(lat), cuda(lab), cuda(real))
+            model.generator_step(cuda(lat), cuda(lab))
+            if not keep:
+                assert float(model.d_params.grad.abs().max()) == 0.0 and float(model.g_params.grad.abs().max()) == 0.0
+                assert model.d_params.grad_clean and model.g_params.grad_clean
+            else:
+                assert float(model.d_params.grad.abs().max()) > 0.0 and float(model.g_params.grad.abs().max()) > 0.0
+        out[keep] = (model.d_params.flat.clone(), model.g_params.flat.clone(), model.d_params.v.clone())
+    # (two trainers in one process may associate the fp32 sums of multi-consumer gradients differently, see _same_up_to_accumulation_order)
+    _same_up_to_accumulation_order(out[True][0], out[False][0], "discriminator parameters")
+    _same_up_to_accumulation_order(out[True][1], out[False][1], "generator parameters")
 
 
 def test_pipelined_train_step_equals_sequential(gpu_store):
