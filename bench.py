@@ -429,6 +429,11 @@ def main():
             "value": value, "unit": "images/sec", "n_gpus": world, "rccl_ranks": world if distributed else 0, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "parity_note": ("bf16 = storage dtype of activations (fp32 accumulation, fp32 master weights / Adam): the throughput dtype BASELINE.json configs[1] names.  "
+                            "The 1e-3 parity contract with the oracle is held by the fp32 path (--dtype f32; tests/test_model_gpu.py::test_fully_grown_full_size_step_vs_oracle); "
+                            "the bf16 path is checked against the oracle on its own leaky-relu pieces at 3e-2 relative L2 per gradient tensor "
+                            "(test_full_size_bf16_step_vs_oracle_on_its_linear_pieces)") if args.dtype == "bf16" else
+                           "fp32 storage and arithmetic: the dtype of the 1e-3 parity contract (tests/test_model_gpu.py)",
             "config": {"workload": "BASELINE.json configs[1]: fully grown PGGAN 128x1024x2 G+D iteration (D update + G update, "
                                    "R1 + mode-seeking), per-GPU batch %d, random-init weights" % args.batch,
                        "global_batch": global_batch, "parallelism": "dp%d" % world,

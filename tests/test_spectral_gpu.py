@@ -37,12 +37,37 @@ def if_conditioning(st64, margin=1e-3, cut=1e-4):
     md = np.mod(d + np.pi, 2 * np.pi) - np.pi
     on_cut = np.zeros(ph.shape, bool)
     on_cut[:, 1:] = np.pi - np.abs(md) < margin
-    lin, mag = st64["phase"], st64["magnitude"]
-    near = (np.pi - np.abs(lin) < cut) & (mag > 1e-6 * mag.max())
+    near = near_branch(st64, cut)
     hit = (near.astype(np.float64) @ (st64["mel"] != 0).astype(np.float64)) > 0          # [b, t, m]
     branch = hit.copy()
     branch[:, 1:] |= hit[:, :-1]
     return on_cut, branch
+
+
+def near_branch(st64, cut=1e-4):
+    """[b, t, k]: linear bin k of frame t (with magnitude) has |arg X| within `cut` of pi -- atan2 may land on either side."""
+    lin, mag = st64["phase"], st64["magnitude"]
+    return (np.pi - np.abs(lin) < cut) & (mag > 1e-6 * mag.max())
+
+
+def check_branch_bins(got, ref, st64, b, branch, where=None, tol=2e-3):
+    """The bins check_if leaves out are not unchecked: where a linear bin k sits on the atan2 branch cut at frame t or t - 1, the mel
+    phase of column m moves by +-2 pi w[k, m] (w = the mel weight) and IF = wrap(p[t] - p[t-1]) / pi by +-2 w[k, m] modulo 2.  Every
+    such bin must equal the oracle's value up to a signed sum of those quanta over the (few) hit bins of its column."""
+    import itertools
+    where = np.ones(ref.shape, bool) if where is None else where
+    near, mel = near_branch(st64)[b], st64["mel"]
+    ts, ms = np.nonzero(branch & where)
+    worst = 0.0
+    for t, m in zip(ts, ms):
+        ks = [k for k in np.nonzero(mel[:, m])[0] if near[t, k] or (t > 0 and near[t - 1, k])]
+        quanta = [2.0 * float(mel[k, m]) for k in ks]
+        # a bin on the cut at t AND t - 1 may flip at either frame or both: coefficients -2 .. 2 per hit bin (columns have <= 6 non-zeros)
+        best = min(abs(float(wrap2(np.float64(got[t, m] - ref[t, m] - sum(c * q for c, q in zip(cs, quanta))))))
+                   for cs in itertools.product((-2, -1, 0, 1, 2), repeat=len(quanta)))
+        worst = max(worst, best)
+        assert best < tol, (b, t, m, float(got[t, m]), float(ref[t, m]), quanta)
+    return len(ts), worst
 
 
 def check_if(got, ref, on_cut, branch, where=None, tol=1e-3, max_branch=2e-3):
@@ -106,6 +131,8 @@ def test_fused_vs_oracle_and_golden():
         prev_loud[1:] &= loud[:-1]                     # IF at t is a difference of the phases at t and t - 1
         # (a stationary tone keeps re-visiting the same phases: ~1 % of its audible bins sit on the atan2 branch, 3e-5 of the noise's)
         check_if(mi[i], st64["mel_if"][i], on_cut[i], branch[i], where=prev_loud, max_branch=3e-2 if i == 0 else 2e-3)
+        n_branch, _ = check_branch_bins(mi[i], st64["mel_if"][i], st64, i, branch[i] & ~on_cut[i], where=prev_loud)
+        assert i == 1 or n_branch > 0   # (the stationary tone does visit the cut: the check above ran)
     assert np.allclose(lm[:, :3], (np.log(1e-6) + 3.76) / 10.05, atol=1e-6) and np.all(mi[:, :3] == 0)
     gold = np.load(os.path.join(GOLD, "spectral_tone_noise.npz"))
     fr = gold["frames"]
