@@ -296,6 +296,50 @@ __global__ __launch_bounds__(256) void thin_single_kernel(const T* __restrict__ 
     if (lane == 0) DT<T>::st(y + pix, a * alpha);
 }
 
+// the same for 3x3 kernels with IC a multiple of 256: a lane owns 4 consecutive channels per 256-channel block and ALL its loads (9 taps x
+// IC / 256 blocks, inputs and weights) are issued before the first multiply -- the generic kernel above walks 9 x IC / 64 dependent
+// load pairs (11.6 us for the 256-channel stddev-plane gradient at 2 x 16: a pure latency chain)
+template <typename T, int NB>
+__global__ __launch_bounds__(256) void thin_single3_kernel(const T* __restrict__ x, const float* __restrict__ wp, T* __restrict__ y, int mode,
+                                                           int N, int Hi, int Wi, int Ho, int Wo, float alpha) {
+    constexpr int IC = 256 * NB;
+    const long pix = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (pix >= (long)N * Ho * Wo) return;
+    const int ox = pix % Wo;
+    const int oy = (pix / Wo) % Ho;
+    const int n = pix / ((long)Wo * Ho);
+    float xv[9][NB][4];
+    float4 wv[9][NB];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int ky = t / 3, kx = t % 3;
+        int iy, ix;
+        bool ok = true;
+        if (mode == MODE_S1) { iy = oy + ky - 1; ix = ox + kx - 1; }
+        else if (mode == MODE_S2) { iy = 2 * oy + ky; ix = 2 * ox + kx; }
+        else {
+            const int dy = oy - ky, dx = ox - kx;
+            ok = dy >= 0 && dx >= 0 && !(dy & 1) && !(dx & 1);
+            iy = dy >> 1; ix = dx >> 1;
+        }
+        ok = ok && iy >= 0 && iy < Hi && ix >= 0 && ix < Wi;
+        const T* xp = x + (((long)n * Hi + (ok ? iy : 0)) * Wi + (ok ? ix : 0)) * IC + 4 * lane;   // (clamped: the loads stay unconditional)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            ld4(xp + 256 * b, xv[t][b]);
+            wv[t][b] = ok ? *reinterpret_cast<const float4*>(wp + (long)t * IC + 256 * b + 4 * lane) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    float a = 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) a += xv[t][b][0] * wv[t][b].x + xv[t][b][1] * wv[t][b].y + xv[t][b][2] * wv[t][b].z + xv[t][b][3] * wv[t][b].w;
+    a = wave_sum(a);
+    if (lane == 0) DT<T>::st(y + pix, a * alpha);
+}
+
 // direct conv through the fp32 prepped weights living in ws; *fused is set when bias / act went into the same pass
 static int run_direct(int mode, int ks, int variant, const void* x, const float* w_hwio, void* y, int N, int Hi, int Wi,
                       int ICk, int OCk, int w_ci, int w_co, int Ho, int Wo, float alpha, int dtype, int w_prepared, void* ws,
@@ -339,6 +383,12 @@ static int run_direct(int mode, int ks, int variant, const void* x, const float*
 #undef GS_TR
         GS_CHECK_LAUNCH();
         if (fused) *fused = true;
+        return 0;
+    }
+    if (OCk == 1 && ICk == 256 && ks == 3) {
+        GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((thin_single3_kernel<T, 1>), dim3((unsigned)cdiv(P, 4)), dim3(256), 0, st, (const T*)x, wp, (T*)y, mode,
+                                                    N, Hi, Wi, Ho, Wo, alpha));
+        GS_CHECK_LAUNCH();
         return 0;
     }
     if (OCk == 1 && ICk >= 64) {
@@ -468,16 +518,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_direct_kernel(const T* __restr
         const long p0 = (long)slice * pps;
         long p1 = p0 + pps;
         if (p1 > npix) p1 = npix;
+        // (branch-free body, clamped addresses: unrolled, the loads of four pixels are in flight together -- with a `continue` per pixel the
+        //  loop was a chain of dependent load pairs: 10 us for the 256 pixels of the stddev-plane conv at 2 x 16)
+#pragma unroll 4
         for (long p = p0 + sub; p < p1; p += 4) {
-            const int px = p % Wb;
+            const int px = (int)(p % Wb);
             const long q = p / Wb;
-            const int py = q % Hb;
-            const int n = q / Hb;
+            const int py = (int)(q % Hb);
+            const int n = (int)(q / Hb);
             int iy, ix;
             if (mode == MODE_S1) { iy = py + ky - (ks >> 1); ix = px + kx - (ks >> 1); }
             else { iy = 2 * py + ky; ix = 2 * px + kx; }
-            if (iy < 0 || iy >= Hi || ix < 0 || ix >= Wi) continue;
-            acc += DT<T>::ld(x + (((long)n * Hi + iy) * Wi + ix) * IC + ic) * DT<T>::ld(gy + p * OC + oc);
+            const bool ok = iy >= 0 && iy < Hi && ix >= 0 && ix < Wi;
+            const float xv = DT<T>::ld(x + (((long)n * Hi + (ok ? iy : 0)) * Wi + (ok ? ix : 0)) * IC + ic);
+            const float gv = DT<T>::ld(gy + p * OC + oc);
+            acc += ok ? xv * gv : 0.f;
         }
     }
     red[tid] = acc;
