@@ -10,11 +10,15 @@ namespace gs {
 
 // from conv_igemm.hip
 bool igemm_supported(int ic, int oc, int dtype);
+bool igemm_normbwd_fused(int mode, int N, int Hb, int Wb, int IC, int OC, int dtype);
 bool wgrad_mfma_supported(int ic, int oc, int dtype);
 size_t igemm_prep_bytes(int ic, int oc, int dtype);
 int run_igemm(int mode, int variant, const void* x, const float* w_hwio, void* y, int N, int Hi, int Wi, int ICk,
               int OCk, int w_ci, int w_co, int Hb, int Wb, float alpha, const float* bias, int act, int dtype, int w_prepared,
-              void* ws, size_t ws_bytes, hipStream_t st, const void* mask = nullptr, int mask_act = 0, void* y2 = nullptr, float pn_eps = 0.f);
+              void* ws, size_t ws_bytes, hipStream_t st, const void* mask = nullptr, int mask_act = 0, void* y2 = nullptr, float pn_eps = 0.f,
+              const void* addend = nullptr, int normbwd = 0);
+extern "C" int gs_pixel_norm_bwd_fused(const void* g, const void* x, const void* addend, void* gx, int64_t p, int c, float eps, int pre_act, int post_act, int dtype,
+                                       void* stream);
 size_t wgrad_mfma_bytes(int mode, int dtype, int N, int Hb, int Wb, int IC, int OC);
 bool wgrad_mfma_has_bias(int dtype);
 int run_wgrad_mfma(int mode, const WgradSrcs& srcs, int nsrc, float* gw, float* gb, int N, int Hi, int Wi, int IC, int OC, int Hb,
@@ -1096,6 +1100,38 @@ extern "C" int gs_conv2d_transpose_s2_bwd_data(const void* gy, const float* w_hw
     if (igemm_supported(co, ci, dtype))
         return run_igemm(MODE_S2, 2, gy, w_hwio, gx, n, 2 * h, 2 * w, co, ci, ci, co, h, w, alpha, bias, act, dtype, w_prepared, ws, ws_bytes, st);
     return run_direct(MODE_S2, 3, 2, gy, w_hwio, gx, n, 2 * h, 2 * w, co, ci, ci, co, h, w, alpha, dtype, w_prepared, ws, ws_bytes, st);
+}
+
+// Data gradient of a conv whose INPUT was y = pixel_norm(z), z = act(...) the previous block's activation (networks.py:41-93: every
+// generator block ends conv -> leaky_relu -> pixel_norm), continued through that norm and activation in the conv's epilogue:
+//   gx = (pixel_norm_bwd(B^T(gy, w), z) + addend) * act'(z)       (addend: optional second gradient into z, same shape)
+// i.e. the gradient w.r.t. the previous block's pre-activation in ONE pass.  The epilogue form exists where a tile owns every channel of a
+// pixel (the 32- / 64-channel layers -- where the bytes are); other shapes run the plain data gradient and gs_pixel_norm_bwd_fused in place.
+extern "C" int gs_conv2d_bwd_data_pnbwd(const void* gy, const float* w_hwio, const void* z, const void* addend, int act, float eps, void* gx, int n, int h, int w,
+                                        int ci, int co, int ksize, int stride, float alpha, int dtype, int w_prepared, void* ws, size_t ws_bytes, void* stream) {
+    if (int e = check_conv_args(n, h, w, ci, co, ksize, stride, dtype)) return e;
+    GS_CHECK_ARG(z && gx && (act == GS_ACT_NONE || act == GS_ACT_LRELU), "conv2d_bwd_data_pnbwd: z is required, activation none or leaky relu (got %d)", act);
+    hipStream_t st = as_stream(stream);
+    if (stride == 1 && ksize == 3 && igemm_supported(co, ci, dtype))
+        return run_igemm(MODE_S1, 1, gy, w_hwio, gx, n, h, w, co, ci, ci, co, h, w, alpha, nullptr, GS_ACT_NONE, dtype, w_prepared, ws, ws_bytes, st, z, act, nullptr, eps, addend, 1);
+    if (int e = gs_conv2d_bwd_data_mask(gy, w_hwio, nullptr, 0, gx, n, h, w, ci, co, ksize, stride, alpha, dtype, w_prepared, ws, ws_bytes, stream)) return e;
+    return gs_pixel_norm_bwd_fused(gx, z, addend, gx, (int64_t)n * h * w * ci, ci, eps, GS_ACT_NONE, act, dtype, stream);
+}
+// 1 when the call above runs as ONE launch for this shape (the epilogue form), 0 when it is the conv + the norm's backward in place
+extern "C" int gs_conv2d_bwd_data_pnbwd_is_fused(int n, int h, int w, int ci, int co, int ksize, int stride, int transposed, int dtype) {
+    if (ksize != 3) return 0;
+    if (transposed) return stride == 2 && igemm_supported(co, ci, dtype) && igemm_normbwd_fused(MODE_S2, n, h, w, co, ci, dtype) ? 1 : 0;
+    return stride == 1 && igemm_supported(co, ci, dtype) && igemm_normbwd_fused(MODE_S1, n, h, w, co, ci, dtype) ? 1 : 0;
+}
+extern "C" int gs_conv2d_transpose_s2_bwd_data_pnbwd(const void* gy, const float* w_hwio, const void* z, const void* addend, int act, float eps, void* gx, int n,
+                                                     int h, int w, int ci, int co, float alpha, int dtype, int w_prepared, void* ws, size_t ws_bytes, void* stream) {
+    if (int e = check_conv_args(n, 2 * h, 2 * w, co, ci, 3, 2, dtype)) return e;
+    GS_CHECK_ARG(z && gx && (act == GS_ACT_NONE || act == GS_ACT_LRELU), "conv2d_transpose_s2_bwd_data_pnbwd: z is required, activation none or leaky relu (got %d)", act);
+    hipStream_t st = as_stream(stream);
+    if (igemm_supported(co, ci, dtype))
+        return run_igemm(MODE_S2, 2, gy, w_hwio, gx, n, 2 * h, 2 * w, co, ci, ci, co, h, w, alpha, nullptr, GS_ACT_NONE, dtype, w_prepared, ws, ws_bytes, st, z, act, nullptr, eps, addend, 1);
+    if (int e = gs_conv2d_transpose_s2_bwd_data(gy, w_hwio, gx, n, h, w, ci, co, alpha, dtype, w_prepared, ws, ws_bytes, stream)) return e;
+    return gs_pixel_norm_bwd_fused(gx, z, addend, gx, (int64_t)n * h * w * ci, ci, eps, GS_ACT_NONE, act, dtype, stream);
 }
 
 extern "C" int gs_conv2d_transpose_s2_bwd_weight_multi(const void* const* xs, const void* const* gys, const int* ns, int nsrc, float* gw_hwio, int n, int h,

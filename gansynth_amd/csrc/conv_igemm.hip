@@ -19,6 +19,8 @@
 #include "gs_prof.h"
 
 extern "C" int gs_pixel_norm_fwd(const void* x, void* y, int64_t p, int c, float eps, int dtype, void* stream);
+extern "C" int gs_pixel_norm_bwd_fused(const void* g, const void* x, const void* addend, void* gx, int64_t p, int c, float eps, int pre_act, int post_act, int dtype,
+                                       void* stream);
 
 namespace gs {
 
@@ -92,8 +94,14 @@ struct ConvP {
     int act;
     const void* mask;   // optional (data gradients): y *= mask_act'(.) expressed through the activation OUTPUT mask[..] (y's shape)
     int mask_act;
-    void* y2;           // optional (NORM kernels): y2 = pixel_norm(y) over the channels, y itself optional then
+    void* y2;           // optional (NORM == 1 kernels): y2 = pixel_norm(y) over the channels, y itself optional then
     float pn_eps;
+    // NORM == 2 kernels (data gradients): the conv result g is the gradient w.r.t. y = pixel_norm(z) of the PREVIOUS block; the epilogue turns it
+    // into the gradient w.r.t. that block's pre-activation, y = (pixel_norm_bwd(g, z) + addend) * mask_act'(z), with z = `mask` (the
+    // activation output, y's shape) and `addend` an optional second gradient into z (same shape): one pass instead of a conv + a 4-tensor
+    // elementwise pass
+    const void* addend;
+    int normbwd;        // host side: the caller asks for the NORM == 2 epilogue; cleared (and *norm_pending = 2) when the chosen kernel has none
     int* norm_pending;  // host side: set to 1 when the chosen kernel did not fuse the norm
     int N, Hi, Wi, IC, OC, Hb, Wb, tiles_x, tiles_y, nsp, noct, nch;
     float alpha;
@@ -167,8 +175,9 @@ __device__ __forceinline__ void block_barrier() {
 // ~5 cycles whatever it is (scripts/probe/valu_rate.hip), so in a 4-wave block the ~60 cycles of each DMA piece (offset arithmetic,
 // M0, the load) come ON TOP of the MFMAs of the stage -- measured 2260 ticks per stage for 1152 ticks of MFMA on the few-block layers
 // (scripts/probe/igemm_trace.hip); on their own wave they run under them.
-template <typename T, int MODE, int A, int B, int TW, int TG, bool RESIDENT, int D, bool NORM, int RB = 64, bool SPEC = false>
+template <typename T, int MODE, int A, int B, int TW, int TG, bool RESIDENT, int D, int NORM, int RB = 64, bool SPEC = false>
 __global__ __launch_bounds__(SPEC ? 512 : 256) void conv_igemm_kernel(const ConvP p) {
+    static_assert(NORM >= 0 && NORM <= 2, "NORM: 0 plain, 1 pixel norm of the result (forward blocks), 2 pixel-norm backward of the result (data gradients)");
     constexpr int NP = 128 * B;
     constexpr int TH = NP / TW;
     constexpr int PH = patch_dim<MODE>(TH), PW = patch_dim<MODE>(TW);
@@ -477,7 +486,7 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void conv_igemm_kernel(const Conv
                     const int Ho = MODE == MODE_T2 ? 2 * Hb : Hb, Wo = MODE == MODE_T2 ? 2 * Wb : Wb;
                     const float slope = p.act == GS_ACT_LRELU ? 0.2f : 1.f;
                     auto mask_factor = [&](float z) __attribute__((always_inline)) {
-                        return p.mask_act == GS_ACT_LRELU ? (z > 0.f ? 1.f : 0.2f) : 1.f - z * z;
+                        return p.mask_act == GS_ACT_LRELU ? (z > 0.f ? 1.f : 0.2f) : (p.mask_act == GS_ACT_TANH ? 1.f - z * z : 1.f);
                     };
                     // the 32 channels of tile a of one pixel: act(alpha * acc + bias); o[qd][e] = channel 8 qd + 4 hi + e
                     auto finish = [&](int ph, int a, int b, float (&o)[4][4]) __attribute__((always_inline)) {
@@ -572,7 +581,93 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void conv_igemm_kernel(const Conv
                             const int oy = MODE == MODE_T2 ? 2 * gy + (ph >> 1) : gy;
                             const int ox = MODE == MODE_T2 ? 2 * gx + (ph & 1) : gx;
                             const long off = (((long)n * Ho + oy) * Wo + ox) * OC + oc0;
-                            if constexpr (NORM) {
+                            if constexpr (NORM == 2) {
+                                // the block owns every channel of the pixel (OC == 32 A) and the accumulators are g = d L / d pixel_norm(z): finish
+                                // the previous block's backward here.  With r = rsqrt(mean z^2 + eps): gx = r (g - z r^2 mean(z g)), then + addend
+                                // and times act'(z).  Values are brought to the STORE layout first (bf16: the lane-half swap), where the lane's
+                                // 16 channels per 32-channel tile sit exactly like the 16-byte vectors of z / addend it fetches.
+                                constexpr int EV = 16 / NV;                    // values per 16-byte vector: 4 (fp32) or 8 (bf16)
+                                mvec_t zq[A][NV], aq[A][NV];
+                                mask_fetch(off, inside, zq);
+                                if (p.addend) {
+                                    const long base = inside ? off : 0;
+#pragma unroll
+                                    for (int a = 0; a < A; ++a)
+#pragma unroll
+                                        for (int v = 0; v < NV; ++v)
+                                            aq[a][v] = *reinterpret_cast<const mvec_t*>(reinterpret_cast<const T*>(p.addend) + base + a * 32 + v * (32 / NV) + hi * (16 / NV));
+                                }
+                                float gv[A][NV][EV], zv[A][NV][EV];
+                                float ssq = 0.f, szg = 0.f;
+#pragma unroll
+                                for (int a = 0; a < A; ++a) {
+                                    float o[4][4];
+                                    finish(ph, a, b, o);   // (no bias, no activation on a data gradient: alpha * acc)
+                                    if constexpr (SZ == 4) {
+#pragma unroll
+                                        for (int qd = 0; qd < 4; ++qd) {
+                                            const float4 z4 = zq[a][qd];
+                                            const float zz[4] = {z4.x, z4.y, z4.z, z4.w};
+#pragma unroll
+                                            for (int e = 0; e < 4; ++e) { gv[a][qd][e] = o[qd][e]; zv[a][qd][e] = zz[e]; }
+                                        }
+                                    } else {
+#pragma unroll
+                                        for (int qp = 0; qp < 2; ++qp) {
+#pragma unroll
+                                            for (int e = 0; e < 4; ++e) {
+                                                const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(o[2 * qp][e]), __float_as_uint(o[2 * qp + 1][e]), false, false);
+                                                gv[a][qp][e] = __uint_as_float(r[0]);
+                                                gv[a][qp][4 + e] = __uint_as_float(r[1]);
+                                            }
+                                            const uint4 z4 = zq[a][qp];
+                                            const unsigned zw[4] = {z4.x, z4.y, z4.z, z4.w};
+#pragma unroll
+                                            for (int e = 0; e < 4; ++e) { zv[a][qp][2 * e] = __uint_as_float(zw[e] << 16); zv[a][qp][2 * e + 1] = __uint_as_float(zw[e] & 0xffff0000u); }
+                                        }
+                                    }
+#pragma unroll
+                                    for (int v = 0; v < NV; ++v)
+#pragma unroll
+                                        for (int e = 0; e < EV; ++e) { ssq += zv[a][v][e] * zv[a][v][e]; szg += zv[a][v][e] * gv[a][v][e]; }
+                                }
+                                ssq += __shfl_xor(ssq, 32, 64);   // the partner lane of the other half holds the pixel's other channels
+                                szg += __shfl_xor(szg, 32, 64);
+                                const float inv_c = 1.f / (float)(32 * A);
+                                const float r = rsqrtf(ssq * inv_c + p.pn_eps);
+                                const float m = szg * inv_c * r * r;
+#pragma unroll
+                                for (int a = 0; a < A; ++a)
+#pragma unroll
+                                    for (int v = 0; v < NV; ++v) {
+                                        float out[EV], ad[EV];
+#pragma unroll
+                                        for (int e = 0; e < EV; ++e) ad[e] = 0.f;
+                                        if (p.addend) {
+                                            if constexpr (SZ == 4) {
+                                                const float4 a4 = aq[a][v];
+                                                ad[0] = a4.x; ad[1] = a4.y; ad[2] = a4.z; ad[3] = a4.w;
+                                            } else {
+                                                const uint4 a4 = aq[a][v];
+                                                const unsigned aw[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+                                                for (int e = 0; e < 4; ++e) { ad[2 * e] = __uint_as_float(aw[e] << 16); ad[2 * e + 1] = __uint_as_float(aw[e] & 0xffff0000u); }
+                                            }
+                                        }
+#pragma unroll
+                                        for (int e = 0; e < EV; ++e) out[e] = (r * (gv[a][v][e] - zv[a][v][e] * m) + ad[e]) * mask_factor(zv[a][v][e]);
+                                        if (inside) {
+                                            if constexpr (SZ == 4) {
+                                                st4(reinterpret_cast<float*>(y) + off + a * 32 + v * 8 + hi * 4, out);
+                                            } else {
+                                                uint4 w4;
+                                                w4.x = pack_bf16x2(out[0], out[1]); w4.y = pack_bf16x2(out[2], out[3]);
+                                                w4.z = pack_bf16x2(out[4], out[5]); w4.w = pack_bf16x2(out[6], out[7]);
+                                                *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(y) + off + a * 32 + v * 16 + hi * 8) = w4;
+                                            }
+                                        }
+                                    }
+                            } else if constexpr (NORM == 1) {
                                 // the block owns every channel of the pixel (OC == 32 A): pixel norm in the same pass.  The lane and its
                                 // partner in the other half hold the pixel's channels between them.
                                 float o[A][4][4], ssq = 0.f;
@@ -1410,7 +1505,7 @@ static int num_cus() {
 #ifndef GS_SMALL_D
 #define GS_SMALL_D 2   // stages in flight for the few-block ("small") configurations
 #endif
-template <typename T, int MODE, int A, int B, int TW, int TG, bool RESIDENT = false, int D = 2, bool NORM = false, int RB = 64, bool SPEC = false>
+template <typename T, int MODE, int A, int B, int TW, int TG, bool RESIDENT = false, int D = 2, int NORM = 0, int RB = 64, bool SPEC = false>
 static int launch_igemm(ConvP p, hipStream_t st) {
     constexpr int NP = 128 * B;
     constexpr int TH = NP / TW;
@@ -1432,7 +1527,14 @@ static int launch_igemm(ConvP p, hipStream_t st) {
     if ((size_t)p.Hi * p.Wi * p.IC * sizeof(T) >= (1ull << 31)) return fail(GS_ERR_UNSUPPORTED, "conv igemm: one image exceeds 2 GiB");
     if (lds > 160 * 1024) return fail(GS_ERR_UNSUPPORTED, "conv igemm: %zu bytes of LDS needed", lds);
     if (NORM && p.OC != OCT) return fail(GS_ERR_UNSUPPORTED, "conv igemm: fused pixel norm needs the whole channel range in one tile");
-    if (!NORM && p.y2) {   // the norm stays a separate pass: this launch leaves the activation where that pass will read it
+    if (NORM == 2 && p.OC != OCT) return fail(GS_ERR_UNSUPPORTED, "conv igemm: fused pixel-norm backward needs the whole channel range in one tile");
+    if (NORM != 2 && p.normbwd) {   // no fused form here: plain data gradient, the caller runs the norm's backward as its own pass
+        p.normbwd = 0;
+        p.mask = nullptr;
+        p.addend = nullptr;
+        if (p.norm_pending) *p.norm_pending = 2;
+    }
+    if (NORM != 1 && p.y2) {   // the norm stays a separate pass: this launch leaves the activation where that pass will read it
         if (!p.y) p.y = p.y2;
         p.y2 = nullptr;
         if (p.norm_pending) *p.norm_pending = 1;
@@ -1456,7 +1558,7 @@ static int launch_igemm(ConvP p, hipStream_t st) {
     const double flops = 2.0 * 9.0 * (double)p.N * p.Hb * p.Wb * p.IC * p.OC;
     const double out_px = (double)p.N * p.Hb * p.Wb * (MODE == MODE_T2 ? 4 : 1);
     // algorithmic bytes: input + output + weights, + the activation mask a masked launch reads, + the second output of a fused norm
-    const double bytes = ((double)p.N * p.Hi * p.Wi * p.IC + out_px * p.OC * (1.0 + (p.mask ? 1.0 : 0.0) + ((NORM && p.y) ? 1.0 : 0.0)) + 9.0 * p.IC * p.OC) * sizeof(T);
+    const double bytes = ((double)p.N * p.Hi * p.Wi * p.IC + out_px * p.OC * (1.0 + (p.mask ? 1.0 : 0.0) + ((NORM == 1 && p.y) ? 1.0 : 0.0) + ((NORM == 2 && p.addend) ? 1.0 : 0.0)) + 9.0 * p.IC * p.OC) * sizeof(T);
     const int reps = prof_reps();   // (1 unless profiling in burst mode: the kernel is a pure function of its inputs)
     ProfScope ps(st, flops, bytes, MODE, p.N, p.Hb, p.Wb, p.IC, p.OC, p.mask ? 1 : 0, NORM ? 1 : 0, reps);
     for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(SPEC ? 512 : 256), lds, st, p);
@@ -1495,6 +1597,7 @@ static int dispatch_igemm(ConvP p, hipStream_t st) {
     // 32- / 64-channel blocks actually use; everything else runs the plain kernel and the caller's separate norm pass (p.y2 = NULL
     // on return tells it so -- see run_igemm_t).
     const bool norm = p.y2 != nullptr;
+    const bool nbwd = p.normbwd != 0;   // (the three data-gradient shapes of the generator's 32- / 64-channel blocks below; anything else falls back)
     if constexpr (MODE == MODE_T2) {
         if (resident_ok && Wb >= 64) { if (norm) return launch_igemm<T, MODE, 1, 1, 64, 9, true, 1, true>(p, st); return launch_igemm<T, MODE, 1, 1, 64, 9, true, 1>(p, st); }
         // few blocks, each a serial chain of stages: 32-channel tiles double the number of busy CUs, 9-tap stages cut the
@@ -1528,7 +1631,10 @@ static int dispatch_igemm(ConvP p, hipStream_t st) {
         if (!a2) return launch_igemm<T, MODE, 1, 1, 32, 3>(p, st);
         // stride 2: the patch is 4.6x the output tile, so a 128-channel tile (the patch staged once for all of them) is worth
         // more than a second pixel tile as long as every CU still gets a block
-        if (OC == 64 && nch == 1 && Wb >= 32 && items64(1) >= cus) return launch_igemm<T, MODE, 2, 1, 32, 9, true, 1>(p, st);   // 36 KiB of weights: resident
+        if (OC == 64 && nch == 1 && Wb >= 32 && items64(1) >= cus) {   // 36 KiB of weights: resident
+            if (nbwd) return launch_igemm<T, MODE, 2, 1, 32, 9, true, 1, 2>(p, st);
+            return launch_igemm<T, MODE, 2, 1, 32, 9, true, 1>(p, st);
+        }
         if (OC % 128 == 0 && Wb >= 32 && (long)p.N * cdiv(p.Hb, 4) * cdiv(Wb, 32) * (OC / 128) >= cus) {
             if (spec_mask() & 4) return launch_igemm<T, MODE, 4, 1, 32, 3, false, 2, false, 64, true>(p, st);
             return launch_igemm<T, MODE, 4, 1, 32, 3>(p, st);
@@ -1539,7 +1645,11 @@ static int dispatch_igemm(ConvP p, hipStream_t st) {
         }
         return launch_igemm<T, MODE, 2, 1, 16, 3>(p, st);
     } else {
-        if (resident_ok && Wb >= 64) { if (norm) return launch_igemm<T, MODE, 1, 2, 64, 9, true, 1, true>(p, st); return launch_igemm<T, MODE, 1, 2, 64, 9, true, 1>(p, st); }
+        if (resident_ok && Wb >= 64) {
+            if (norm) return launch_igemm<T, MODE, 1, 2, 64, 9, true, 1, true>(p, st);
+            if (nbwd) return launch_igemm<T, MODE, 1, 2, 64, 9, true, 1, 2>(p, st);
+            return launch_igemm<T, MODE, 1, 2, 64, 9, true, 1>(p, st);
+        }
         if (small) {
             // 128-byte operand rows (whole cache lines per DMA row, half the stages): the few-block layers are bound by the L2 -> LDS
             // rate of a CU, not by its MFMAs
@@ -1560,6 +1670,7 @@ static int dispatch_igemm(ConvP p, hipStream_t st) {
         if (!a2) return launch_igemm<T, MODE, 1, 1, 32, 3>(p, st);
         if (Wb >= 32 && items64(2) >= 2 * cus) {
             if (norm && OC == 64) return launch_igemm<T, MODE, 2, 2, 32, 3, false, 1, true>(p, st);
+            if (nbwd && OC == 64) return launch_igemm<T, MODE, 2, 2, 32, 3, false, 1, 2>(p, st);
             if (spec_mask() & 2) return launch_igemm<T, MODE, 2, 2, 32, 3, false, 2, false, 64, true>(p, st);
             return launch_igemm<T, MODE, 2, 2, 32, 3, false, 1>(p, st);
         }
@@ -1583,6 +1694,25 @@ static int dispatch_igemm(ConvP p, hipStream_t st) {
     }
 }
 
+// does dispatch_igemm have the NORM == 2 (pixel-norm backward) epilogue for this data-gradient shape?  (mirrors its three branches)
+bool igemm_normbwd_fused(int mode, int N, int Hb, int Wb, int IC, int OC, int dtype) {
+    const int bk = dtype == GS_F32 ? 16 : 32;
+    if (IC % bk != 0 || OC % 32 != 0) return false;
+    const int nch = IC / bk;
+    const long cus = num_cus();
+    auto items64 = [&](int B_) { return (long)N * cdiv(Hb, 4 * B_) * cdiv(Wb, 32) * (OC / 64); };
+    if (mode == MODE_S1) {
+        if (OC == 32 && nch <= 2 && Wb >= 64) return true;
+        const bool small = items64(1) <= cus;
+        return !small && OC == 64 && Wb >= 32 && items64(2) >= 2 * cus;
+    }
+    if (mode == MODE_S2) {
+        const bool small = items64(1) <= cus;
+        return !small && OC == 64 && nch == 1 && Wb >= 32 && items64(1) >= cus;
+    }
+    return false;
+}
+
 bool igemm_supported(int ic, int oc, int dtype) {
     const int bk = dtype == GS_F32 ? 16 : 32;
     return ic % bk == 0 && oc % 32 == 0;
@@ -1597,7 +1727,8 @@ size_t igemm_prep_bytes(int ic, int oc, int dtype) {
 template <typename T>
 static int run_igemm_t(int mode, int variant, const void* x, const float* w_hwio, void* y, int N, int Hi, int Wi,
                        int ICk, int OCk, int w_ci, int w_co, int Hb, int Wb, float alpha, const float* bias, int act,
-                       int w_prepared, void* ws, size_t ws_bytes, hipStream_t st, const void* mask, int mask_act, void* y2, float pn_eps) {
+                       int w_prepared, void* ws, size_t ws_bytes, hipStream_t st, const void* mask, int mask_act, void* y2, float pn_eps,
+                       const void* addend, int normbwd) {
     const size_t need = (size_t)9 * w_ci * w_co * sizeof(T);
     if (ws_bytes < need) return fail(GS_ERR_WORKSPACE, "conv igemm: workspace %zu < %zu", ws_bytes, need);
     T* wp = reinterpret_cast<T*>(ws);
@@ -1610,12 +1741,17 @@ static int run_igemm_t(int mode, int variant, const void* x, const float* w_hwio
     p.N = N; p.Hi = Hi; p.Wi = Wi; p.IC = ICk; p.OC = OCk; p.Hb = Hb; p.Wb = Wb; p.alpha = alpha;
     int pending = 0;
     p.y2 = y2; p.pn_eps = pn_eps; p.norm_pending = &pending;
+    p.addend = normbwd ? addend : nullptr; p.normbwd = normbwd;
     int rc;
     if (mode == MODE_S1) rc = dispatch_igemm<T, MODE_S1>(p, st);
     else if (mode == MODE_S2) rc = dispatch_igemm<T, MODE_S2>(p, st);
     else rc = dispatch_igemm<T, MODE_T2>(p, st);
     if (rc) return rc;
     GS_CHECK_LAUNCH();
+    if (pending == 2) {   // no fused pixel-norm backward for this shape: y holds the plain data gradient g; the norm's backward runs in place
+        const long px = (long)N * Hb * Wb * (mode == MODE_T2 ? 4 : 1);
+        return gs_pixel_norm_bwd_fused(y, mask, addend, y, px, OCk, pn_eps, GS_ACT_NONE, mask_act, sizeof(T) == 4 ? GS_F32 : GS_BF16, st);
+    }
     if (pending) {   // y2 = pixel_norm(activation), the activation sitting in y (or in y2 itself when the caller keeps no copy)
         const long px = (long)N * Hb * Wb * (mode == MODE_T2 ? 4 : 1);
         return gs_pixel_norm_fwd(y ? y : y2, y2, px, OCk, pn_eps, sizeof(T) == 4 ? GS_F32 : GS_BF16, st);
@@ -1625,9 +1761,9 @@ static int run_igemm_t(int mode, int variant, const void* x, const float* w_hwio
 
 int run_igemm(int mode, int variant, const void* x, const float* w_hwio, void* y, int N, int Hi, int Wi, int ICk,
               int OCk, int w_ci, int w_co, int Hb, int Wb, float alpha, const float* bias, int act, int dtype, int w_prepared,
-              void* ws, size_t ws_bytes, hipStream_t st, const void* mask, int mask_act, void* y2, float pn_eps) {
+              void* ws, size_t ws_bytes, hipStream_t st, const void* mask, int mask_act, void* y2, float pn_eps, const void* addend, int normbwd) {
     GS_DISPATCH_DTYPE(dtype, return (run_igemm_t<T>(mode, variant, x, w_hwio, y, N, Hi, Wi, ICk, OCk, w_ci, w_co, Hb,
-                                                    Wb, alpha, bias, act, w_prepared, ws, ws_bytes, st, mask, mask_act, y2, pn_eps)));
+                                                    Wb, alpha, bias, act, w_prepared, ws, ws_bytes, st, mask, mask_act, y2, pn_eps, addend, normbwd)));
 }
 
 // ---- weight gradient (fp32 MFMA path)

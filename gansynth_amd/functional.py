@@ -89,6 +89,13 @@ class _ConvKind(object):
     def bwd_data_mask(self, gy, w, x_shape, alpha, mask, mask_act):
         return _K().conv2d_bwd_data(gy, w, x_shape, self.ksize, self.stride, alpha, mask=mask, mask_act=mask_act)
 
+    def bwd_data_pnbwd(self, gy, w, x_shape, alpha, z, eps, act, addend):
+        return _K().conv2d_bwd_data_pnbwd(gy, w, x_shape, self.ksize, self.stride, alpha, z, eps, act, addend=addend)
+
+    def bwd_data_pnbwd_is_fused(self, x_shape, co, dtype):
+        K = _K()
+        return hasattr(K, "bwd_data_pnbwd_is_fused") and K.bwd_data_pnbwd_is_fused(x_shape, co, self.ksize, self.stride, False, dtype)
+
     bias_in_wgrad = True   # the weight-gradient kernels can return the bias gradient of the block on the side
 
     def bwd_weight(self, x, gy, alpha, out=None, bias_out=None):
@@ -113,6 +120,13 @@ class _ConvTransposeKind(object):
 
     def bwd_data(self, gy, w, x_shape, alpha):
         return _K().conv2d_transpose_bwd_data(gy, w, alpha)
+
+    def bwd_data_pnbwd(self, gy, w, x_shape, alpha, z, eps, act, addend):
+        return _K().conv2d_transpose_bwd_data_pnbwd(gy, w, alpha, z, eps, act, addend=addend)
+
+    def bwd_data_pnbwd_is_fused(self, x_shape, co, dtype):
+        K = _K()
+        return hasattr(K, "bwd_data_pnbwd_is_fused") and K.bwd_data_pnbwd_is_fused(x_shape, co, 3, 2, True, dtype)
 
     def bwd_weight(self, x, gy, alpha, out=None):
         return _K().conv2d_transpose_bwd_weight(x, gy, alpha, out=out)
@@ -479,6 +493,8 @@ class _PnActBwd(Function):
         g, z = ctx.saved_tensors
         if ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:   # both from one pass over gg, g, z
             g_z, g_g = _K().pixel_norm_bwd_bwd(gg, g, z, ctx.eps, pre_act=ctx.act, with_g=True)
+            if _FUSE_NORM_BWD:
+                _GZ[z.data_ptr()] = g_z   # (see above: the consumer of pixel_norm(z) may add it in its data-gradient epilogue)
             return g_g, g_z, None, None
         g_g = _K().pixel_norm_bwd(gg, z, ctx.eps, pre_act=ctx.act) if ctx.needs_input_grad[0] else None
         g_z = _K().pixel_norm_bwd_bwd(gg, g, z, ctx.eps, pre_act=ctx.act) if ctx.needs_input_grad[1] else None
@@ -486,6 +502,23 @@ class _PnActBwd(Function):
 
 
 _FUSE_NORM_EPILOGUE = not __import__("os").environ.get("GS_NO_NORM_EPILOGUE")   # A/B switch for measurements
+_FUSE_NORM_BWD = not __import__("os").environ.get("GS_NO_NORM_BWD_EPILOGUE")  # A/B switch: the previous block's norm backward in the data-gradient epilogue
+
+# ---- the previous block's (activation -> pixel norm) backward inside the conv that produces its input gradient -----------------------
+# Plain backward of a generator block: g_y -> [pixel_norm_bwd(g_y, z) + g_z] * act'(z) -> data gradient conv -> g_y of the block before.
+# Where the conv's tile owns every channel of a pixel (the 32- / 64-channel layers) that elementwise pass (4 tensors) runs in the
+# epilogue of the conv of the block AFTER (gs_conv2d[_transpose_s2]_bwd_data_pnbwd).  The consumer does it when the caller promised
+# that its input feeds nothing else (`input_normed`, networks.py), the producer is a _ConvBiasActNorm node and the shape has the epilogue
+# form; it tells the producer through its ctx (`_gs_fused`) which incoming tensor is already the gradient w.r.t. its pre-activation.
+# g_z -- the gradient the second-order graph of the mode-seeking term sends into z -- belongs to the PRODUCER's inputs; its kernel
+# (_PnActBwd.backward) leaves it here as well, keyed by z's address, and it is always there in time: that kernel of block L runs before
+# the one of block L + 1, whose result the consumer's own backward waits for.  Cleared per backward pass (reset_fusion_state).
+_GZ = {}
+
+
+def reset_fusion_state():
+    _GZ.clear()
+
 _NORM_BWD_BIAS = not __import__("os").environ.get("GS_NO_NORM_BWD_BIAS")      # A/B switch: bias sums inside the norm's backward
 
 
@@ -496,9 +529,11 @@ class _ConvBiasActNorm(Function):
     norm-backward, add, activation-backward."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, kind, alpha, act, eps):
+    def forward(ctx, x, w, bias, kind, alpha, act, eps, input_normed=False):
         ctx.kind, ctx.alpha, ctx.act, ctx.eps, ctx.has_bias = kind, alpha, act, eps, bias is not None
         ctx.wref, ctx.bref = w, bias
+        ctx.input_normed = bool(input_normed)   # x is pixel_norm(.) out of a _ConvBiasActNorm node and feeds nothing but this conv (caller's promise)
+        ctx._gs_fused = None
         ctx.set_materialize_grads(False)   # an absent gradient for z must arrive as None, not as a tensor of zeros
         keep = any(ctx.needs_input_grad)   # no backward (the no-grad generator pass of the D run): the activation is not kept
         want_z = keep or activation_tap.active is not None
@@ -526,11 +561,17 @@ class _ConvBiasActNorm(Function):
             gx = _BilinearBwdData.apply(gy, w, x.shape, ctx.kind, ctx.alpha) if ctx.needs_input_grad[0] else None
             gw = _BilinearBwdWeight.apply(x, gy, ctx.kind, ctx.alpha).to(w.dtype) if want_w else None
             gb = _ChannelSum.apply(gy) if want_b else None
-            return gx, gw, gb, None, None, None, None
+            return gx, gw, gb, None, None, None, None, None
         tw = _accum_target(ctx.wref) if want_w else None
         tb = _accum_target(ctx.bref) if want_b else None
         bias_done = False
-        if g_y is None:
+        fused, ctx._gs_fused = ctx._gs_fused, None
+        if fused is not None and g_y is not None and g_y.data_ptr() == fused[0]:
+            # the consumer's data-gradient conv already went through this block's norm and activation (and added g_z if it had it)
+            gy = g_y
+            if g_z is not None and not fused[1]:
+                gy = _K().axpby(gy, _K().act_bwd(g_z, z, ctx.act), 1.0, 1.0)
+        elif g_y is None:
             gy = _K().act_bwd(g_z, z, ctx.act)
         elif (tb is not None and not getattr(ctx.kind, "bias_in_wgrad", False) and _NORM_BWD_BIAS and getattr(_K(), "norm_bwd_sums_bias", False)
               and _K().norm_bwd_bias_ok(z.shape[1], z.dtype)):   # (other channel counts, e.g. 48 or 96: plain backward + channel_sum below)
@@ -539,13 +580,23 @@ class _ConvBiasActNorm(Function):
             bias_done = True
         else:
             gy = _K().pixel_norm_bwd(g_y, z, ctx.eps, act=ctx.act, addend=g_z)
-        gx = _BilinearBwdData.apply(gy, w, x.shape, ctx.kind, ctx.alpha) if ctx.needs_input_grad[0] else None
+        gx = None
+        if ctx.needs_input_grad[0]:
+            prod = x.grad_fn if (_FUSE_NORM_BWD and ctx.input_normed and hasattr(ctx.kind, "bwd_data_pnbwd")) else None
+            if (prod is not None and isinstance(prod, _ConvBiasActNorm._backward_cls) and prod.act in (ACT_NONE, ACT_LRELU)
+                    and ctx.kind.bwd_data_pnbwd_is_fused(tuple(x.shape), gy.shape[1], gy.dtype)):
+                z_prev = prod.saved_tensors[2]
+                gz_prev = _GZ.pop(z_prev.data_ptr(), None)
+                gx = ctx.kind.bwd_data_pnbwd(gy, w, tuple(x.shape), ctx.alpha, z_prev, prod.eps, prod.act, gz_prev)
+                prod._gs_fused = (gx.data_ptr(), gz_prev is not None)
+            else:
+                gx = _BilinearBwdData.apply(gy, w, x.shape, ctx.kind, ctx.alpha)
         gw = gb = None
         if bias_done:
             want_b = False
         if tw is not None and tb is not None and getattr(ctx.kind, "bias_in_wgrad", False):
             ctx.kind.bwd_weight(x, gy, ctx.alpha, out=tw, bias_out=tb)
-            return gx, None, None, None, None, None, None
+            return gx, None, None, None, None, None, None, None
         if want_b:
             if tb is not None:
                 _K().channel_sum(gy, out=tb)
@@ -556,15 +607,15 @@ class _ConvBiasActNorm(Function):
                 ctx.kind.bwd_weight(x, gy, ctx.alpha, out=tw)
             else:
                 gw = ctx.kind.bwd_weight(x, gy, ctx.alpha).to(w.dtype)
-        return gx, gw, gb, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None
 
 
-def conv2d_bias_act_norm(x, w, bias, ksize, stride, alpha, act, eps):
-    return _ConvBiasActNorm.apply(x, w, bias, _kind(("conv", ksize, stride)), alpha, act, eps)[0]
+def conv2d_bias_act_norm(x, w, bias, ksize, stride, alpha, act, eps, input_normed=False):
+    return _ConvBiasActNorm.apply(x, w, bias, _kind(("conv", ksize, stride)), alpha, act, eps, input_normed)[0]
 
 
-def conv2d_transpose_bias_act_norm(x, w, bias, alpha, act, eps):
-    return _ConvBiasActNorm.apply(x, w, bias, _kind(("convT",)), alpha, act, eps)[0]
+def conv2d_transpose_bias_act_norm(x, w, bias, alpha, act, eps, input_normed=False):
+    return _ConvBiasActNorm.apply(x, w, bias, _kind(("convT",)), alpha, act, eps, input_normed)[0]
 
 
 def conv2d(x, w, ksize, stride, alpha):

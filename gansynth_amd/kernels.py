@@ -372,6 +372,49 @@ class HipKernels(object):
                                                     float(alpha), _dt(gy), prepared, ws.data_ptr(), ws.numel(), _stream()), "gs_conv2d_bwd_data_mask")
         return gx
 
+    def bwd_data_pnbwd_is_fused(self, x_shape, co, ksize, stride, transposed, dtype):
+        """Does conv2d[_transpose]_bwd_data_pnbwd run as ONE launch for a conv with input x_shape = (n, ci, h, w) and `co` output channels?"""
+        n, ci, h, wd = x_shape
+        return bool(self.lib.gs_conv2d_bwd_data_pnbwd_is_fused(int(n), int(h), int(wd), int(ci), int(co), int(ksize), int(stride), 1 if transposed else 0,
+                                                              GS_F32 if dtype == torch.float32 else GS_BF16))
+
+    def conv2d_bwd_data_pnbwd(self, gy, w, x_shape, ksize, stride, alpha, z, eps, act, addend=None):
+        """(pixel_norm_bwd(conv2d_bwd_data(gy, w), z) + addend) * act'(z): the data gradient continued through the previous block's pixel norm
+        and activation (z: that block's activation output, x_shape's shape) -- one launch where the conv tile owns all channels of a pixel."""
+        gy, w, z = _act(gy), _f32c(w), _act(z)
+        n, ci, h, wd = x_shape
+        co = w.shape[3]
+        assert tuple(z.shape) == (n, ci, h, wd) and z.dtype == gy.dtype
+        gx = _empty_like_act((n, ci, h, wd), gy)
+        nb = self.lib.gs_conv2d_workspace_bytes(_lib.CONV_BWD_DATA, n, h, wd, ci, co, ksize, stride, _dt(gy))
+        ws, prepared = self._weight_ws(w, ("bwd_data", ksize, stride, _dt(gy)), nb, (_lib.PREP_CONV_BWD_DATA, ci, co, ksize, stride, _dt(gy)))
+        ap = None
+        if addend is not None:
+            addend = _match(addend, z)
+            ap = addend.data_ptr()
+        _lib.check(self.lib.gs_conv2d_bwd_data_pnbwd(gy.data_ptr(), w.data_ptr(), z.data_ptr(), ap, int(act), float(eps), gx.data_ptr(), n, h, wd, ci, co, ksize,
+                                                     stride, float(alpha), _dt(gy), prepared, ws.data_ptr(), ws.numel(), _stream()), "gs_conv2d_bwd_data_pnbwd")
+        return gx
+
+    def conv2d_transpose_bwd_data_pnbwd(self, gy, w, alpha, z, eps, act, addend=None):
+        """The same behind a transposed conv (its data gradient is the stride-2 conv)."""
+        gy, w, z = _act(gy), _f32c(w), _act(z)
+        n, co, h2, w2 = gy.shape
+        ci = w.shape[2]
+        h, wd = h2 // 2, w2 // 2
+        assert tuple(z.shape) == (n, ci, h, wd) and z.dtype == gy.dtype
+        gx = _empty_like_act((n, ci, h, wd), gy)
+        nb = self.lib.gs_conv2d_transpose_s2_workspace_bytes(_lib.CONV_BWD_DATA, n, h, wd, ci, co, _dt(gy))
+        ws, prepared = self._weight_ws(w, ("t_bwd_data", _dt(gy)), nb, (_lib.PREP_CONVT_BWD_DATA, ci, co, 3, 2, _dt(gy)))
+        ap = None
+        if addend is not None:
+            addend = _match(addend, z)
+            ap = addend.data_ptr()
+        _lib.check(self.lib.gs_conv2d_transpose_s2_bwd_data_pnbwd(gy.data_ptr(), w.data_ptr(), z.data_ptr(), ap, int(act), float(eps), gx.data_ptr(), n, h, wd, ci, co,
+                                                                  float(alpha), _dt(gy), prepared, ws.data_ptr(), ws.numel(), _stream()),
+                   "gs_conv2d_transpose_s2_bwd_data_pnbwd")
+        return gx
+
     def conv2d_bwd_weight(self, x, gy, ksize, stride, alpha, out=None, bias_out=None):
         """gw (new tensor), or with `out` (fp32, contiguous) the gradient is ADDED into it inside the kernel.  With `bias_out`
         (needs `out`) the bias gradient sum_{n,h,w} gy is added into it by the same launches."""

@@ -388,6 +388,8 @@ class GANSynth(object):
         overlap = (self.distributed and deferring and len(params.buckets) > 1 and not self._capturing()
                    and not getattr(self, "_warming_up", False))
         launched = []
+        if hasattr(F, "reset_fusion_state"):
+            F.reset_fusion_state()   # (side-channel state of cross-node fusions is per backward pass)
         try:
             if loss.is_cuda and loss.dim() == 0 and loss.dtype == torch.float32 and not self._capturing_fresh_seed(loss.device):
                 torch.autograd.backward(loss, grad_tensors=F.unit_seed(loss.device))   # (the loss heads recognise the seed: functional.unit_seed)

@@ -71,7 +71,9 @@ class PGGAN(object):
         return depth, depth - growing_depth
 
     # ================================================================== generator
-    def _g_conv_block(self, x, depth):
+    def _g_conv_block(self, x, depth, sole_consumer=True):
+        """`sole_consumer`: x (the previous block's normalised output) feeds nothing but this block -- false at the fade-in junction, where
+        the low-resolution colour block reads it too (lets the backward fuse across the block boundary, ops.conv2d `input_normed`)."""
         c = self.channels(depth)
         with variable_scope(self._block_name("conv", depth)):
             if depth == self.min_depth:
@@ -85,12 +87,14 @@ class PGGAN(object):
                 with variable_scope("upscale_conv"):
                     x = ops.conv2d_transpose(x, filters=c, kernel_size=[3, 3], strides=[2, 2], use_bias=True,
                                              variance_scale=2.0, scale_weight=True, activation="leaky_relu",
-                                             pixel_norm_epsilon=PIXEL_NORM_EPS if _FUSE_NORM else None)   # conv -> leaky_relu -> pixel norm: one node
+                                             pixel_norm_epsilon=PIXEL_NORM_EPS if _FUSE_NORM else None,   # conv -> leaky_relu -> pixel norm: one node
+                                             input_normed=sole_consumer)
                     if not _FUSE_NORM:
                         x = ops.pixel_normalization(x)
             with variable_scope("conv"):
                 x = ops.conv2d(x, filters=c, kernel_size=[3, 3], use_bias=True, variance_scale=2.0, scale_weight=True,
-                               activation="leaky_relu", pixel_norm_epsilon=PIXEL_NORM_EPS if _FUSE_NORM else None)
+                               activation="leaky_relu", pixel_norm_epsilon=PIXEL_NORM_EPS if _FUSE_NORM else None,
+                               input_normed=depth != self.min_depth)   # (the upscale conv's output feeds this conv only)
                 if not _FUSE_NORM:
                     x = ops.pixel_normalization(x)
         return x
@@ -134,7 +138,7 @@ class PGGAN(object):
             for depth in range(self.min_depth, head):
                 x = self._g_conv_block(x, depth)
             full = self.resolution(self.max_depth)
-            middle = ops.upscale2d(self._g_color_block(self._g_conv_block(x, head), head), full // self.resolution(head))
+            middle = ops.upscale2d(self._g_color_block(self._g_conv_block(x, head, sole_consumer=fade is None), head), full // self.resolution(head))
             if fade is None:
                 return middle
             low = ops.upscale2d(self._g_color_block(x, head - 1), full // self.resolution(head - 1))

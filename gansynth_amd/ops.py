@@ -58,8 +58,10 @@ def embedding(inputs, units, variance_scale=2.0, scale_weight=False):
 
 
 def conv2d(inputs, filters, kernel_size, strides=[1, 1], use_bias=True, variance_scale=2.0, scale_weight=False,
-           activation=None, input_activation=None, pixel_norm_epsilon=None):
-    """ops.py:221-247 (NCHW, SAME).  `pixel_norm_epsilon`: also apply pixel_normalization(., epsilon) to the activated result
+           activation=None, input_activation=None, pixel_norm_epsilon=None, input_normed=False):
+    """ops.py:221-247 (NCHW, SAME).  `input_normed` (with pixel_norm_epsilon): the caller's promise that `inputs` is the pixel-normalised
+    output of such a fused block and feeds nothing but this conv -- its backward may then run that block's norm / activation backward in
+    the epilogue of this conv's data-gradient kernel (functional.py); results are unchanged.  `pixel_norm_epsilon`: also apply pixel_normalization(., epsilon) to the activated result
     (the generator's conv -> leaky_relu -> pixel_normalization, networks.py:80-87) as one autograd node.  `input_activation`: the caller's promise that `inputs` is the output of a conv block
     with that fused activation and feeds nothing but this conv -- the backward then folds the activation derivative into
     this conv's data-gradient kernel (functional.py, "premasked gradients"); results are unchanged.  "Nothing but" includes
@@ -71,21 +73,21 @@ def conv2d(inputs, filters, kernel_size, strides=[1, 1], use_bias=True, variance
     weight, alpha = get_weight([*kernel_size, inputs.shape[1], filters], variance_scale, scale_weight)
     bias = get_bias([filters]) if use_bias else None
     if pixel_norm_epsilon is not None:
-        return F.conv2d_bias_act_norm(inputs, weight, bias, kernel_size[0], strides[0], alpha, _ACT[activation], pixel_norm_epsilon)
+        return F.conv2d_bias_act_norm(inputs, weight, bias, kernel_size[0], strides[0], alpha, _ACT[activation], pixel_norm_epsilon, input_normed)
     if bias is not None or activation is not None:
         return F.conv2d_bias_act(inputs, weight, bias, kernel_size[0], strides[0], alpha, _ACT[activation], _ACT[input_activation])
     return F.conv2d(inputs, weight, kernel_size[0], strides[0], alpha)
 
 
 def conv2d_transpose(inputs, filters, kernel_size, strides=[1, 1], use_bias=True, variance_scale=2.0, scale_weight=False,
-                     activation=None, pixel_norm_epsilon=None):
+                     activation=None, pixel_norm_epsilon=None, input_normed=False):
     """ops.py:250-280 (NCHW, SAME, output = input * strides); 3x3 / stride 2 is the hot-path case."""
     if list(kernel_size) != [3, 3] or list(strides) != [2, 2]:
         raise ValueError("conv2d_transpose: the hot path is kernel 3x3, strides 2x2 (networks.py:71-79)")
     weight, alpha = get_weight([*kernel_size, inputs.shape[1], filters], variance_scale, scale_weight)
     bias = get_bias([filters]) if use_bias else None
     if pixel_norm_epsilon is not None:
-        return F.conv2d_transpose_bias_act_norm(inputs, weight, bias, alpha, _ACT[activation], pixel_norm_epsilon)
+        return F.conv2d_transpose_bias_act_norm(inputs, weight, bias, alpha, _ACT[activation], pixel_norm_epsilon, input_normed)
     if bias is not None or activation is not None:
         return F.conv2d_transpose_bias_act(inputs, weight, bias, alpha, _ACT[activation])
     return F.conv2d_transpose(inputs, weight, alpha)

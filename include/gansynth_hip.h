@@ -150,6 +150,16 @@ int gs_conv2d_transpose_s2_fwd_bias_act(const void* x, const float* w_hwio, cons
                                         size_t ws_bytes, void* stream);
 int gs_conv2d_transpose_s2_bwd_data(const void* gy, const float* w_hwio, void* gx, int n, int h, int w, int ci, int co,
                                     float alpha, int dtype, int w_prepared, void* ws, size_t ws_bytes, void* stream);
+/* Data gradient continued through the PREVIOUS block's pixel norm and activation (networks.py:41-93: conv -> leaky_relu -> pixel_norm;
+ * the backward tf.gradients builds for ops.py:330-333 behind ops.py:237-243 / 269-276), one pass where a tile owns all channels of a pixel:
+ *   gx = (pixel_norm_bwd(B^T(gy, w), z) + addend) * act'(z);  z: the previous block's activation output (gx's shape), addend: optional */
+int gs_conv2d_bwd_data_pnbwd(const void* gy, const float* w_hwio, const void* z, const void* addend, int act, float eps, void* gx, int n, int h, int w,
+                             int ci, int co, int ksize, int stride, float alpha, int dtype, int w_prepared, void* ws, size_t ws_bytes, void* stream);
+/* 1 when that call is one launch for the shape (n, h, w: the conv's INPUT side, i.e. gx / z; transposed: the s2 transposed conv), 0 when it
+ * runs as the plain data gradient followed by gs_pixel_norm_bwd_fused in place */
+int gs_conv2d_bwd_data_pnbwd_is_fused(int n, int h, int w, int ci, int co, int ksize, int stride, int transposed, int dtype);
+int gs_conv2d_transpose_s2_bwd_data_pnbwd(const void* gy, const float* w_hwio, const void* z, const void* addend, int act, float eps, void* gx, int n,
+                                          int h, int w, int ci, int co, float alpha, int dtype, int w_prepared, void* ws, size_t ws_bytes, void* stream);
 int gs_conv2d_transpose_s2_bwd_weight(const void* x, const void* gy, float* gw_hwio, int n, int h, int w, int ci, int co,
                                       float alpha, int accumulate, int dtype, void* ws, size_t ws_bytes, void* stream);
 

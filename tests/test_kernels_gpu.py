@@ -770,3 +770,45 @@ def test_gan_losses_in_one_launch(K, dtype):
     close(ks, g_ssq, rel=1e-5, name="g loss: d/d sumsq")
     loss, kf, ks = K.gan_g_loss(dev(fake.detach(), dtype), dev(lab, dtype), None, 0.0, 1e-6)
     assert ks is None and abs(float(loss) - float(TF.softplus(-(fake.detach() * lab).sum(1)).mean())) <= 1e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", [("conv", 8, 32, 32, 128, 1024), ("conv", 8, 64, 64, 64, 512), ("convT", 8, 64, 32, 64, 512),   # the three fused shapes
+                                  ("conv", 2, 32, 32, 8, 128), ("conv", 2, 64, 64, 8, 64), ("convT", 2, 64, 32, 8, 64), ("conv", 2, 256, 256, 4, 32),
+                                  ("convT", 2, 128, 64, 4, 32), ("conv", 1, 64, 64, 6, 40)])
+@pytest.mark.parametrize("with_addend", [False, True])
+def test_data_gradient_continued_through_the_previous_pixel_norm(K, case, dtype, with_addend):
+    """gs_conv2d[_transpose_s2]_bwd_data_pnbwd: (pixel_norm_bwd(B^T(gy, w), z) + addend) * leaky_relu'(z) in the conv's epilogue (the 32- /
+    64-channel full-size layers) or as conv + in-place norm backward (every other shape) against the two separate kernels, whose own
+    parity with the oracle is established above.  In bf16 the separate path rounds the intermediate gradient to bf16, the fused one
+    does not: compared at bf16 resolution of the tensor's scale; fp32 at 1e-5."""
+    kind, n, ci, co, h, w = case   # ci: channels of z / gx (the conv's input side), co: of gy
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    CL = torch.channels_last
+    z = torch.nn.functional.leaky_relu(torch.randn(n, ci, h, w, device="cuda", generator=gen), 0.2).to(dtype).contiguous(memory_format=CL)
+    wt = torch.randn(3, 3, ci, co, device="cuda", generator=gen)
+    oh, ow = (2 * h, 2 * w) if kind == "convT" else (h, w)
+    gy = torch.randn(n, co, oh, ow, device="cuda", generator=gen).to(dtype).contiguous(memory_format=CL)
+    add = (0.5 * torch.randn(n, ci, h, w, device="cuda", generator=gen)).to(dtype).contiguous(memory_format=CL) if with_addend else None
+    alpha, eps, act = 0.05, 1e-8, 1
+    if kind == "conv":
+        g = K.conv2d_bwd_data(gy, wt, (n, ci, h, w), 3, 1, alpha)
+        got = K.conv2d_bwd_data_pnbwd(gy, wt, (n, ci, h, w), 3, 1, alpha, z, eps, act, addend=add)
+    else:
+        g = K.conv2d_transpose_bwd_data(gy, wt, alpha)
+        got = K.conv2d_transpose_bwd_data_pnbwd(gy, wt, alpha, z, eps, act, addend=add)
+    ref = K.pixel_norm_bwd(g, z, eps, act=act, addend=add)
+    # float64 evaluation of the definition on the fp32 data gradient (independent of the norm kernels)
+    zz, gg = z.double(), K.conv2d_bwd_data(gy.float(), wt, (n, ci, h, w), 3, 1, alpha).double() if kind == "conv" else K.conv2d_transpose_bwd_data(gy.float(), wt, alpha).double()
+    r = torch.rsqrt((zz * zz).mean(dim=1, keepdim=True) + eps)
+    want = r * (gg - zz * r * r * (zz * gg).mean(dim=1, keepdim=True))
+    if add is not None:
+        want = want + add.double()
+    want = want * torch.where(zz > 0, 1.0, 0.2)
+    scale = float(want.abs().max())
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    assert float((got.double() - want).abs().max()) <= tol * scale, (float((got.double() - want).abs().max()), scale)
+    assert float((got.double() - ref.double()).abs().max()) <= (1e-5 if dtype == torch.float32 else 3e-2) * scale
+    if dtype == torch.bfloat16:   # one rounding instead of two: at least as close to the definition as the two-kernel path
+        assert float((got.double() - want).pow(2).mean()) <= 1.05 * float((ref.double() - want).pow(2).mean()) + 1e-12
+
