@@ -198,6 +198,84 @@ __global__ __launch_bounds__(256) void thin_expand_kernel(const T* __restrict__ 
     }
 }
 
+// The same map as a DATA GRADIENT continued through the pixel norm and activation of the block that produced the conv's input
+// (gs_conv2d_bwd_data_pnbwd for the colour block, networks.py:98-104): g[p][oc] = alpha * sum_ic x[p][ic] wp[oc][ic] is the gradient
+// w.r.t. pixel_norm(z); out = (r (g - z r^2 mean_c(z g)) + addend) * act'(z), r = rsqrt(mean_c z^2 + eps).  The OC / Wide::N lanes of
+// a pixel are neighbours in the wave: two xor-shuffle folds give the pixel's sums.  One pass instead of thin_expand + a 4-tensor norm pass.
+template <typename T, int IC>
+__global__ __launch_bounds__(256) void thin_expand_pnbwd_kernel(const T* __restrict__ x, const float* __restrict__ wp, const T* __restrict__ z,
+                                                                const T* __restrict__ addend, T* __restrict__ y, long P, int OC, float alpha, float eps, int act) {
+    constexpr int WN = Wide<T>::N;
+    const int groups = OC / WN;   // a power of two <= 64 dividing 256 (checked by the launcher)
+    const int oc0 = (threadIdx.x % groups) * WN;
+    float wr[WN][IC];
+#pragma unroll
+    for (int v = 0; v < WN; ++v)
+#pragma unroll
+        for (int i = 0; i < IC; ++i) wr[v][i] = wp[(long)(oc0 + v) * IC + i] * alpha;
+    const long ppb = 256 / groups;
+    const long stride = (long)gridDim.x * ppb;
+    const long npass = (P + stride - 1) / stride;   // same trip count for every lane (shuffles)
+    const float inv_c = 1.f / (float)OC;
+    for (long k = 0; k < npass; ++k) {
+        const long pix = (long)blockIdx.x * ppb + threadIdx.x / groups + k * stride;
+        const long px = pix < P ? pix : P - 1;      // (clamped: loads and shuffles stay unconditional)
+        float xv[IC], zv[WN], av[WN], g[WN];
+        if constexpr (IC == 2 && sizeof(T) == 2) {
+            const unsigned u = *reinterpret_cast<const unsigned*>(x + px * 2);
+            xv[0] = __uint_as_float(u << 16);
+            xv[1] = __uint_as_float(u & 0xffff0000u);
+        } else {
+#pragma unroll
+            for (int i = 0; i < IC; ++i) xv[i] = DT<T>::ld(x + px * IC + i);
+        }
+        ld_wide<T>(z + px * OC + oc0, zv);
+        if (addend) ld_wide<T>(addend + px * OC + oc0, av);
+        float ssq = 0.f, szg = 0.f;
+#pragma unroll
+        for (int v = 0; v < WN; ++v) {
+            float a = 0.f;
+#pragma unroll
+            for (int i = 0; i < IC; ++i) a += xv[i] * wr[v][i];
+            g[v] = a;
+            ssq += zv[v] * zv[v];
+            szg += zv[v] * a;
+        }
+        for (int o = groups >> 1; o > 0; o >>= 1) { ssq += __shfl_xor(ssq, o, 64); szg += __shfl_xor(szg, o, 64); }
+        const float r = rsqrtf(ssq * inv_c + eps);
+        const float m = szg * inv_c * r * r;
+        float out[WN];
+#pragma unroll
+        for (int v = 0; v < WN; ++v) {
+            float t = r * (g[v] - zv[v] * m);
+            if (addend) t += av[v];
+            out[v] = act == GS_ACT_LRELU ? (zv[v] > 0.f ? t : 0.2f * t) : t;
+        }
+        if (pix < P) st_wide<T>(y + pix * OC + oc0, out);
+    }
+}
+static bool thin_expand_pnbwd_ok(int ks, int ICk, int OCk, int dtype) {
+    const int wn = dtype == GS_F32 ? 4 : 8;
+    if (ks != 1 || ICk < 1 || ICk > 4 || OCk % wn != 0) return false;
+    const int groups = OCk / wn;
+    return groups >= 1 && groups <= 64 && (groups & (groups - 1)) == 0;
+}
+// x: the thin gradient [P][ICk], wp: fp32 [OCk][ICk] (bwd-data layout of the 1x1 kernel), z / addend / y: [P][OCk]
+static int run_thin_expand_pnbwd(const void* x, const float* wp, const void* z, const void* addend, void* y, long P, int ICk, int OCk, float alpha, float eps, int act,
+                                 int dtype, hipStream_t st) {
+    const int wn = dtype == GS_F32 ? 4 : 8;
+    long nb = cdiv(P * (OCk / wn), 256);
+    if (nb > 4096) nb = 4096;
+    const unsigned grid = (unsigned)nb;
+#define GS_TEP(TT, ICV) hipLaunchKernelGGL((thin_expand_pnbwd_kernel<TT, ICV>), dim3(grid), dim3(256), 0, st, (const TT*)x, wp, (const TT*)z, (const TT*)addend, (TT*)y, P, OCk, alpha, eps, act)
+#define GS_TEP_ALL(TT) do { if (ICk == 1) GS_TEP(TT, 1); else if (ICk == 2) GS_TEP(TT, 2); else if (ICk == 3) GS_TEP(TT, 3); else GS_TEP(TT, 4); } while (0)
+    GS_DISPATCH_DTYPE(dtype, GS_TEP_ALL(T));
+#undef GS_TEP_ALL
+#undef GS_TEP
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
 // many -> few channels: a pixel is read by L = IC / Wide::N lanes (a power of two <= 64), partial dots are folded with
 // xor-shuffles, lane 0 of the group writes the OC <= 4 results.  Weights stay in registers across the pixel loop.
 template <typename T, int OC>
@@ -1114,11 +1192,22 @@ extern "C" int gs_conv2d_bwd_data_pnbwd(const void* gy, const float* w_hwio, con
     hipStream_t st = as_stream(stream);
     if (stride == 1 && ksize == 3 && igemm_supported(co, ci, dtype))
         return run_igemm(MODE_S1, 1, gy, w_hwio, gx, n, h, w, co, ci, ci, co, h, w, alpha, nullptr, GS_ACT_NONE, dtype, w_prepared, ws, ws_bytes, st, z, act, nullptr, eps, addend, 1);
+    if (stride == 1 && thin_expand_pnbwd_ok(ksize, co, ci, dtype)) {   // the colour block (few -> many channels as a gradient): streaming, one pass
+        const long total = (long)ci * co;
+        if (ws_bytes < (size_t)total * 4) return fail(GS_ERR_WORKSPACE, "conv2d_bwd_data_pnbwd: workspace %zu < %zu", ws_bytes, (size_t)total * 4);
+        float* wp = reinterpret_cast<float*>(ws);
+        if (!w_prepared) {
+            hipLaunchKernelGGL((weight_prep_kernel<float>), dim3(cdiv(total, 256)), dim3(256), 0, st, w_hwio, wp, 1, ci, co, 1);
+            GS_CHECK_LAUNCH();
+        }
+        return run_thin_expand_pnbwd(gy, wp, z, addend, gx, (long)n * h * w, co, ci, alpha, eps, act, dtype, st);
+    }
     if (int e = gs_conv2d_bwd_data_mask(gy, w_hwio, nullptr, 0, gx, n, h, w, ci, co, ksize, stride, alpha, dtype, w_prepared, ws, ws_bytes, stream)) return e;
     return gs_pixel_norm_bwd_fused(gx, z, addend, gx, (int64_t)n * h * w * ci, ci, eps, GS_ACT_NONE, act, dtype, stream);
 }
 // 1 when the call above runs as ONE launch for this shape (the epilogue form), 0 when it is the conv + the norm's backward in place
 extern "C" int gs_conv2d_bwd_data_pnbwd_is_fused(int n, int h, int w, int ci, int co, int ksize, int stride, int transposed, int dtype) {
+    if (ksize == 1) return !transposed && stride == 1 && thin_expand_pnbwd_ok(1, co, ci, dtype) ? 1 : 0;
     if (ksize != 3) return 0;
     if (transposed) return stride == 2 && igemm_supported(co, ci, dtype) && igemm_normbwd_fused(MODE_S2, n, h, w, co, ci, dtype) ? 1 : 0;
     return stride == 1 && igemm_supported(co, ci, dtype) && igemm_normbwd_fused(MODE_S1, n, h, w, co, ci, dtype) ? 1 : 0;

@@ -423,10 +423,11 @@ class _ConvBiasAct(Function):
     """z = act(alpha * B(x, w) + bias) with the bias / activation fused into the GEMM epilogue."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, kind, alpha, act, in_act=ACT_NONE):
+    def forward(ctx, x, w, bias, kind, alpha, act, in_act=ACT_NONE, input_normed=False):
         ctx.kind, ctx.alpha, ctx.act, ctx.has_bias = kind, alpha, act, bias is not None
         ctx.wref, ctx.bref = w, bias
         ctx.in_act = in_act        # x is the single-consumer output of that activation (caller's promise)
+        ctx.input_normed = bool(input_normed)   # x is pixel_norm(.) out of a _ConvBiasActNorm node, this conv its only consumer (see _GZ)
         ctx._gs_act_out = act      # what consumers of z may fold into their own kernels
         ctx._gs_premasked = None
         z = kind.fwd_bias_act(x, w, bias, alpha, act)
@@ -444,6 +445,15 @@ class _ConvBiasAct(Function):
         def data_grad(gy):
             if not ctx.needs_input_grad[0]:
                 return None
+            if _FUSE_NORM_BWD and ctx.input_normed and not torch.is_grad_enabled() and hasattr(ctx.kind, "bwd_data_pnbwd"):
+                pn = x.grad_fn   # the generator block whose normalised output this conv reads: its norm / activation backward in this conv's data gradient
+                if (isinstance(pn, _ConvBiasActNorm._backward_cls) and pn.act in (ACT_NONE, ACT_LRELU)
+                        and ctx.kind.bwd_data_pnbwd_is_fused(tuple(x.shape), gy.shape[1], gy.dtype)):
+                    z_prev = pn.saved_tensors[2]
+                    gz_prev = _GZ.pop(z_prev.data_ptr(), None)
+                    gx_ = ctx.kind.bwd_data_pnbwd(gy, w, tuple(x.shape), ctx.alpha, z_prev, pn.eps, pn.act, gz_prev)
+                    pn._gs_fused = (gx_.data_ptr(), gz_prev is not None)
+                    return gx_
             prod = _premask_producer(x, ctx.in_act, differentiable=True) if hasattr(ctx.kind, "bwd_data_mask") else None
             if prod is None:
                 return _BilinearBwdData.apply(gy, w, x.shape, ctx.kind, ctx.alpha)
@@ -460,7 +470,7 @@ class _ConvBiasAct(Function):
                 gy = _ActBwd.apply(gz, z, act) if act != ACT_NONE else gz
                 gx = data_grad(gy)
                 ctx.kind.bwd_weight(x, gy, ctx.alpha, out=tw, bias_out=tb)
-                return gx, None, None, None, None, None, None
+                return gx, None, None, None, None, None, None, None
         gy, gb = _bias_act_backward(gz, z if act != ACT_NONE else None, act, ctx.bref if want_b else None, want_b)
         gx = data_grad(gy)
         gw = None
@@ -470,7 +480,7 @@ class _ConvBiasAct(Function):
                 ctx.kind.bwd_weight(x, gy, ctx.alpha, out=tgt)
             else:
                 gw = _BilinearBwdWeight.apply(x, gy, ctx.kind, ctx.alpha).to(w.dtype)
-        return gx, gw, gb, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None
 
 
 class _PnActBwd(Function):
@@ -622,8 +632,8 @@ def conv2d(x, w, ksize, stride, alpha):
     return _Bilinear.apply(x, w, _kind(("conv", ksize, stride)), alpha)
 
 
-def conv2d_bias_act(x, w, bias, ksize, stride, alpha, act, in_act=ACT_NONE):
-    return _ConvBiasAct.apply(x, w, bias, _kind(("conv", ksize, stride)), alpha, act, in_act)
+def conv2d_bias_act(x, w, bias, ksize, stride, alpha, act, in_act=ACT_NONE, input_normed=False):
+    return _ConvBiasAct.apply(x, w, bias, _kind(("conv", ksize, stride)), alpha, act, in_act, input_normed)
 
 
 def conv2d_transpose_bias_act(x, w, bias, alpha, act):

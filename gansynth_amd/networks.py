@@ -99,11 +99,12 @@ class PGGAN(object):
                     x = ops.pixel_normalization(x)
         return x
 
-    def _g_color_block(self, x, depth):
+    def _g_color_block(self, x, depth, sole_consumer=False):
+        """`sole_consumer`: x (a conv block's normalised output) feeds nothing but this colour block (true for the head block's own output)."""
         with variable_scope(self._block_name("color", depth)):
             with variable_scope("conv"):
                 return ops.conv2d(x, filters=2, kernel_size=[1, 1], use_bias=True, variance_scale=1.0, scale_weight=True,
-                                  activation="tanh")
+                                  activation="tanh", input_normed=sole_consumer and _FUSE_NORM)
 
     def _g_variables(self, latent_dim, num_labels):
         """Create every generator variable (all depths) in the reference's scopes."""
@@ -138,7 +139,7 @@ class PGGAN(object):
             for depth in range(self.min_depth, head):
                 x = self._g_conv_block(x, depth)
             full = self.resolution(self.max_depth)
-            middle = ops.upscale2d(self._g_color_block(self._g_conv_block(x, head, sole_consumer=fade is None), head), full // self.resolution(head))
+            middle = ops.upscale2d(self._g_color_block(self._g_conv_block(x, head, sole_consumer=fade is None), head, sole_consumer=True), full // self.resolution(head))
             if fade is None:
                 return middle
             low = ops.upscale2d(self._g_color_block(x, head - 1), full // self.resolution(head - 1))

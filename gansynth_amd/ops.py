@@ -75,7 +75,7 @@ def conv2d(inputs, filters, kernel_size, strides=[1, 1], use_bias=True, variance
     if pixel_norm_epsilon is not None:
         return F.conv2d_bias_act_norm(inputs, weight, bias, kernel_size[0], strides[0], alpha, _ACT[activation], pixel_norm_epsilon, input_normed)
     if bias is not None or activation is not None:
-        return F.conv2d_bias_act(inputs, weight, bias, kernel_size[0], strides[0], alpha, _ACT[activation], _ACT[input_activation])
+        return F.conv2d_bias_act(inputs, weight, bias, kernel_size[0], strides[0], alpha, _ACT[activation], _ACT[input_activation], input_normed)
     return F.conv2d(inputs, weight, kernel_size[0], strides[0], alpha)
 
 

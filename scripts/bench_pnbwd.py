@@ -21,17 +21,18 @@ def timed(fn, n=50):
     return e0.elapsed_time(e1) / n * 1e3
 
 
-for kind, n, ci, co, h, w in [("conv", 8, 32, 32, 128, 1024), ("conv", 8, 64, 64, 64, 512), ("convT", 8, 64, 32, 64, 512)]:
+for kind, n, ci, co, h, w in [("conv", 8, 32, 32, 128, 1024), ("conv", 8, 64, 64, 64, 512), ("convT", 8, 64, 32, 64, 512), ("conv1", 8, 32, 2, 128, 1024)]:
     z = torch.randn(n, ci, h, w, device="cuda").to(dt).contiguous(memory_format=CL)
     add = torch.randn(n, ci, h, w, device="cuda").to(dt).contiguous(memory_format=CL)
-    wt = torch.randn(3, 3, ci, co, device="cuda")
+    ks = 1 if kind == "conv1" else 3
+    wt = torch.randn(ks, ks, ci, co, device="cuda")
     K.register_param_buffer(wt)
     oh, ow = (2 * h, 2 * w) if kind == "convT" else (h, w)
     gy = torch.randn(n, co, oh, ow, device="cuda").to(dt).contiguous(memory_format=CL)
-    if kind == "conv":
-        sep = lambda: K.pixel_norm_bwd(K.conv2d_bwd_data(gy, wt, (n, ci, h, w), 3, 1, 0.05), z, 1e-8, act=1, addend=add)
-        fus = lambda: K.conv2d_bwd_data_pnbwd(gy, wt, (n, ci, h, w), 3, 1, 0.05, z, 1e-8, 1, addend=add)
-        conv = lambda: K.conv2d_bwd_data(gy, wt, (n, ci, h, w), 3, 1, 0.05)
+    if kind != "convT":
+        sep = lambda: K.pixel_norm_bwd(K.conv2d_bwd_data(gy, wt, (n, ci, h, w), ks, 1, 0.05), z, 1e-8, act=1, addend=add)
+        fus = lambda: K.conv2d_bwd_data_pnbwd(gy, wt, (n, ci, h, w), ks, 1, 0.05, z, 1e-8, 1, addend=add)
+        conv = lambda: K.conv2d_bwd_data(gy, wt, (n, ci, h, w), ks, 1, 0.05)
     else:
         sep = lambda: K.pixel_norm_bwd(K.conv2d_transpose_bwd_data(gy, wt, 0.05), z, 1e-8, act=1, addend=add)
         fus = lambda: K.conv2d_transpose_bwd_data_pnbwd(gy, wt, 0.05, z, 1e-8, 1, addend=add)

@@ -775,7 +775,8 @@ def test_gan_losses_in_one_launch(K, dtype):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("case", [("conv", 8, 32, 32, 128, 1024), ("conv", 8, 64, 64, 64, 512), ("convT", 8, 64, 32, 64, 512),   # the three fused shapes
                                   ("conv", 2, 32, 32, 8, 128), ("conv", 2, 64, 64, 8, 64), ("convT", 2, 64, 32, 8, 64), ("conv", 2, 256, 256, 4, 32),
-                                  ("convT", 2, 128, 64, 4, 32), ("conv", 1, 64, 64, 6, 40)])
+                                  ("convT", 2, 128, 64, 4, 32), ("conv", 1, 64, 64, 6, 40),
+                                  ("conv1", 8, 32, 2, 128, 1024), ("conv1", 2, 64, 2, 8, 64), ("conv1", 2, 256, 2, 4, 32), ("conv1", 3, 128, 2, 5, 7)])   # the colour block (1x1)
 @pytest.mark.parametrize("with_addend", [False, True])
 def test_data_gradient_continued_through_the_previous_pixel_norm(K, case, dtype, with_addend):
     """gs_conv2d[_transpose_s2]_bwd_data_pnbwd: (pixel_norm_bwd(B^T(gy, w), z) + addend) * leaky_relu'(z) in the conv's epilogue (the 32- /
@@ -786,20 +787,21 @@ def test_data_gradient_continued_through_the_previous_pixel_norm(K, case, dtype,
     gen = torch.Generator(device="cuda").manual_seed(11)
     CL = torch.channels_last
     z = torch.nn.functional.leaky_relu(torch.randn(n, ci, h, w, device="cuda", generator=gen), 0.2).to(dtype).contiguous(memory_format=CL)
-    wt = torch.randn(3, 3, ci, co, device="cuda", generator=gen)
+    ks = 1 if kind == "conv1" else 3
+    wt = torch.randn(ks, ks, ci, co, device="cuda", generator=gen)
     oh, ow = (2 * h, 2 * w) if kind == "convT" else (h, w)
     gy = torch.randn(n, co, oh, ow, device="cuda", generator=gen).to(dtype).contiguous(memory_format=CL)
     add = (0.5 * torch.randn(n, ci, h, w, device="cuda", generator=gen)).to(dtype).contiguous(memory_format=CL) if with_addend else None
     alpha, eps, act = 0.05, 1e-8, 1
-    if kind == "conv":
-        g = K.conv2d_bwd_data(gy, wt, (n, ci, h, w), 3, 1, alpha)
-        got = K.conv2d_bwd_data_pnbwd(gy, wt, (n, ci, h, w), 3, 1, alpha, z, eps, act, addend=add)
+    if kind != "convT":
+        g = K.conv2d_bwd_data(gy, wt, (n, ci, h, w), ks, 1, alpha)
+        got = K.conv2d_bwd_data_pnbwd(gy, wt, (n, ci, h, w), ks, 1, alpha, z, eps, act, addend=add)
     else:
         g = K.conv2d_transpose_bwd_data(gy, wt, alpha)
         got = K.conv2d_transpose_bwd_data_pnbwd(gy, wt, alpha, z, eps, act, addend=add)
     ref = K.pixel_norm_bwd(g, z, eps, act=act, addend=add)
     # float64 evaluation of the definition on the fp32 data gradient (independent of the norm kernels)
-    zz, gg = z.double(), K.conv2d_bwd_data(gy.float(), wt, (n, ci, h, w), 3, 1, alpha).double() if kind == "conv" else K.conv2d_transpose_bwd_data(gy.float(), wt, alpha).double()
+    zz, gg = z.double(), K.conv2d_bwd_data(gy.float(), wt, (n, ci, h, w), ks, 1, alpha).double() if kind != "convT" else K.conv2d_transpose_bwd_data(gy.float(), wt, alpha).double()
     r = torch.rsqrt((zz * zz).mean(dim=1, keepdim=True) + eps)
     want = r * (gg - zz * r * r * (zz * gg).mean(dim=1, keepdim=True))
     if add is not None:
