@@ -239,7 +239,8 @@ def per_stage(records, iterations, peak_tflops, dtype):
     for (kind, n, hb, wb, ic, oc, masked, norm), (cnt, ms, fl, by, srcs) in sorted(groups.items()):
         avg = ms / cnt
         t_mfma, t_hbm = fl / (peak_tflops * 1e12) * 1e3, by / (HBM_GBPS * 1e9) * 1e3
-        name = "%s %d->%d @ %dx%d x%d%s%s" % (_KIND.get(kind, str(kind)), ic, oc, hb, wb, n, " +mask" if masked else "", " +norm" if norm else "")
+        # (+mask: activation derivative in the epilogue; +norm: pixel norm of the result; both: the previous block's pixel-norm / activation BACKWARD)
+        name = "%s %d->%d @ %dx%d x%d%s" % (_KIND.get(kind, str(kind)), ic, oc, hb, wb, n, " +norm-bwd" if (masked and norm) else (" +mask" if masked else (" +norm" if norm else "")))
         if kind >= 20:   # gs_conv_wgrad_jobs group: (layers, tile width, blocks, units, runs) in the geometry slots
             name = "wgrad group %s, %d-wide tiles: %d layers, %d units on %d blocks, %d runs" % ("s1" if kind == 20 else "s2", hb, n, ic, wb, oc)
         row = {"stage": name,
