@@ -413,6 +413,41 @@ def test_optimizer_step_clears_the_gradient_it_consumed(graphs):
     _same_up_to_accumulation_order(out[True][1], out[False][1], "generator parameters")
 
 
+def test_norm_backward_rides_in_the_data_gradient_convs_at_full_size(gpu_store):
+    """BASELINE.json configs[1] shapes (batch 8, bf16, fully grown): in the generator run's plain backward the (leaky_relu -> pixel_norm)
+    backward of the four 32- / 64-channel blocks runs inside the data-gradient conv of the block after them (three implicit-GEMM epilogues
+    + the colour block's streaming pass) -- the calls are counted, their second-order addend is present, and the step equals the one with
+    the fusion switched off (functional._FUSE_NORM_BWD) up to bf16 rounding of the one intermediate tensor the fused path never stores."""
+    from gansynth_amd import functional as F, kernels, variables
+    K = kernels.get()
+    out = {}
+    for fuse in (True, False):
+        variables.set_default_store(variables.VariableStore(device="cuda", seed=0))
+        pg, opg, model = make(1.0, variables.default_store(), dtype=torch.bfloat16)
+        lat, lab, _ = R.synthetic_batch(8, rank=0)
+        c = lambda t: cuda(t).to(torch.bfloat16)
+        model._build(c(lat), c(lab))
+        calls = []
+        orig_a, orig_b, was = K.conv2d_bwd_data_pnbwd, K.conv2d_transpose_bwd_data_pnbwd, F._FUSE_NORM_BWD
+        K.conv2d_bwd_data_pnbwd = lambda *a, **k: (calls.append(("conv", a[2], k.get("addend") is not None)), orig_a(*a, **k))[1]
+        K.conv2d_transpose_bwd_data_pnbwd = lambda *a, **k: (calls.append(("convT", tuple(a[3].shape), k.get("addend") is not None)), orig_b(*a, **k))[1]
+        F._FUSE_NORM_BWD = fuse
+        try:
+            loss = float(model.generator_step(c(lat), c(lab)))
+        finally:
+            K.conv2d_bwd_data_pnbwd, K.conv2d_transpose_bwd_data_pnbwd, F._FUSE_NORM_BWD = orig_a, orig_b, was
+        out[fuse] = (loss, {k: p.grad.clone() for k, p in model.g_params.named.items()}, calls)
+    calls = out[True][2]
+    assert out[False][2] == []
+    shapes = sorted((kind, tuple(shape)[1:]) for kind, shape, _ in calls)
+    assert shapes == [("conv", (32, 128, 1024)), ("conv", (32, 128, 1024)), ("conv", (64, 64, 512)), ("convT", (64, 64, 512))], shapes
+    assert all(has_addend for _, _, has_addend in calls), calls   # the mode-seeking term's gradient into z reached every one of them
+    assert abs(out[True][0] - out[False][0]) <= 1e-6 * max(1.0, abs(out[False][0]))   # (same forward)
+    for k, g in out[False][1].items():
+        if float(g.abs().max()) > 0:
+            assert rel_l2(out[True][1][k], g) < 2e-2, (k, rel_l2(out[True][1][k], g))
+
+
 def test_pipelined_train_step_equals_sequential(gpu_store):
     """train_step with graphs runs every run as two graphs and moves the optimizer updates to a side stream (they overlap the
     other network's own part): same losses and parameters as the sequential eager iteration, step after step (up to the order
