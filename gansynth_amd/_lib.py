@@ -54,6 +54,9 @@ SIGNATURES = {
     "gs_conv2d_transpose_s2_fwd_bias_act": (I, [P, P, P, P, I, I, I, I, I, F, I, I, I, P, Z, P]),
     "gs_conv2d_transpose_s2_bwd_data": (I, [P, P, P, I, I, I, I, I, F, I, I, P, Z, P]),
     "gs_conv2d_bwd_data_pnbwd_is_fused": (I, [I, I, I, I, I, I, I, I, I]),
+    "gs_conv2d_fwd_pnbwdbwd_is_fused": (I, [I, I, I, I, I, I, I, I, I]),
+    "gs_conv2d_fwd_pnbwdbwd": (I, [P, P, P, P, I, F, P, P, I, I, I, I, I, I, I, F, I, I, P, Z, P]),
+    "gs_conv2d_transpose_s2_fwd_pnbwdbwd": (I, [P, P, P, P, I, F, P, P, I, I, I, I, I, F, I, I, P, Z, P]),
     "gs_conv2d_bwd_data_pnbwd": (I, [P, P, P, P, I, F, P, I, I, I, I, I, I, I, F, I, I, P, Z, P]),
     "gs_conv2d_transpose_s2_bwd_data_pnbwd": (I, [P, P, P, P, I, F, P, I, I, I, I, I, F, I, I, P, Z, P]),
     "gs_conv2d_transpose_s2_bwd_weight": (I, [P, P, P, I, I, I, I, I, F, I, I, P, Z, P]),

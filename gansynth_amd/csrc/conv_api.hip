@@ -10,7 +10,9 @@ namespace gs {
 
 // from conv_igemm.hip
 bool igemm_supported(int ic, int oc, int dtype);
-bool igemm_normbwd_fused(int mode, int N, int Hb, int Wb, int IC, int OC, int dtype);
+bool igemm_normbwd_fused(int mode, int N, int Hb, int Wb, int IC, int OC, int dtype, int form = 1);
+extern "C" int gs_pixel_norm_bwd_bwd_fused(const void* gg, const void* g, const void* x, void* out, void* out_g, int64_t p, int c, float eps, int pre_act,
+                                           int dtype, void* stream);
 bool wgrad_mfma_supported(int ic, int oc, int dtype);
 size_t igemm_prep_bytes(int ic, int oc, int dtype);
 int run_igemm(int mode, int variant, const void* x, const float* w_hwio, void* y, int N, int Hi, int Wi, int ICk,
@@ -1180,6 +1182,40 @@ extern "C" int gs_conv2d_transpose_s2_bwd_data(const void* gy, const float* w_hw
     return run_direct(MODE_S2, 3, 2, gy, w_hwio, gx, n, 2 * h, 2 * w, co, ci, ci, co, h, w, alpha, dtype, w_prepared, ws, ws_bytes, st);
 }
 
+// Second-order pass (the mode-seeking term differentiates the generator's backward, models.py:60): the forward conv applied to a cotangent gives
+// t = the gradient w.r.t. u = act'(z) pixel_norm_bwd(g, z), the first-order backward of the block whose activation z and incoming gradient g
+// are given.  Both gradients of that node in the conv's epilogue (h = t act'(z)):
+//   out_g = pixel_norm_bwd(h, z)                 (w.r.t. g)          out_z = d<h, pixel_norm_bwd(g, z)>/dz      (w.r.t. z)
+// where a tile owns all channels of a pixel; otherwise the conv into out_g and gs_pixel_norm_bwd_bwd_fused (out_g in place).
+extern "C" int gs_conv2d_fwd_pnbwdbwd(const void* x, const float* w_hwio, const void* g, const void* z, int act, float eps, void* out_g, void* out_z, int n, int h,
+                                      int w, int ci, int co, int ksize, int stride, float alpha, int dtype, int w_prepared, void* ws, size_t ws_bytes, void* stream) {
+    if (int e = check_conv_args(n, h, w, ci, co, ksize, stride, dtype)) return e;
+    GS_CHECK_ARG(g && z && out_g && out_z && (act == GS_ACT_NONE || act == GS_ACT_LRELU), "conv2d_fwd_pnbwdbwd: g, z and both outputs are required, activation none or leaky relu (got %d)", act);
+    hipStream_t st = as_stream(stream);
+    const int hb = h / stride, wb = w / stride;
+    if (ksize == 3 && igemm_supported(ci, co, dtype))
+        return run_igemm(stride == 2 ? MODE_S2 : MODE_S1, 0, x, w_hwio, out_g, n, h, w, ci, co, ci, co, hb, wb, alpha, nullptr, GS_ACT_NONE, dtype, w_prepared, ws, ws_bytes, st,
+                         z, act, out_z, eps, g, 2);
+    if (int e = gs_conv2d_fwd(x, w_hwio, out_g, n, h, w, ci, co, ksize, stride, alpha, dtype, w_prepared, ws, ws_bytes, stream)) return e;
+    return gs_pixel_norm_bwd_bwd_fused(out_g, g, z, out_z, out_g, (int64_t)n * hb * wb, co, eps, act, dtype, stream);
+}
+extern "C" int gs_conv2d_transpose_s2_fwd_pnbwdbwd(const void* x, const float* w_hwio, const void* g, const void* z, int act, float eps, void* out_g, void* out_z, int n,
+                                                   int h, int w, int ci, int co, float alpha, int dtype, int w_prepared, void* ws, size_t ws_bytes, void* stream) {
+    if (int e = check_conv_args(n, 2 * h, 2 * w, co, ci, 3, 2, dtype)) return e;
+    GS_CHECK_ARG(g && z && out_g && out_z && (act == GS_ACT_NONE || act == GS_ACT_LRELU), "conv2d_transpose_s2_fwd_pnbwdbwd: g, z and both outputs are required, activation none or leaky relu (got %d)", act);
+    hipStream_t st = as_stream(stream);
+    if (igemm_supported(ci, co, dtype))
+        return run_igemm(MODE_T2, 0, x, w_hwio, out_g, n, h, w, ci, co, ci, co, h, w, alpha, nullptr, GS_ACT_NONE, dtype, w_prepared, ws, ws_bytes, st, z, act, out_z, eps, g, 2);
+    if (int e = gs_conv2d_transpose_s2_fwd(x, w_hwio, out_g, n, h, w, ci, co, alpha, dtype, w_prepared, ws, ws_bytes, stream)) return e;
+    return gs_pixel_norm_bwd_bwd_fused(out_g, g, z, out_z, out_g, (int64_t)n * 4 * h * w, co, eps, act, dtype, stream);
+}
+// 1 when that call runs as one launch for the shape (n, h, w: the conv's input side)
+extern "C" int gs_conv2d_fwd_pnbwdbwd_is_fused(int n, int h, int w, int ci, int co, int ksize, int stride, int transposed, int dtype) {
+    if (ksize != 3 || !igemm_supported(ci, co, dtype)) return 0;
+    if (transposed) return stride == 2 && igemm_normbwd_fused(MODE_T2, n, h, w, ci, co, dtype, 2) ? 1 : 0;
+    return stride == 1 && igemm_normbwd_fused(MODE_S1, n, h, w, ci, co, dtype, 2) ? 1 : 0;
+}
+
 // Data gradient of a conv whose INPUT was y = pixel_norm(z), z = act(...) the previous block's activation (networks.py:41-93: every
 // generator block ends conv -> leaky_relu -> pixel_norm), continued through that norm and activation in the conv's epilogue:
 //   gx = (pixel_norm_bwd(B^T(gy, w), z) + addend) * act'(z)       (addend: optional second gradient into z, same shape)
@@ -1203,7 +1239,7 @@ extern "C" int gs_conv2d_bwd_data_pnbwd(const void* gy, const float* w_hwio, con
         return run_thin_expand_pnbwd(gy, wp, z, addend, gx, (long)n * h * w, co, ci, alpha, eps, act, dtype, st);
     }
     if (int e = gs_conv2d_bwd_data_mask(gy, w_hwio, nullptr, 0, gx, n, h, w, ci, co, ksize, stride, alpha, dtype, w_prepared, ws, ws_bytes, stream)) return e;
-    return gs_pixel_norm_bwd_fused(gx, z, addend, gx, (int64_t)n * h * w * ci, ci, eps, GS_ACT_NONE, act, dtype, stream);
+    return gs_pixel_norm_bwd_fused(gx, z, addend, gx, (int64_t)n * h * w, ci, eps, GS_ACT_NONE, act, dtype, stream);
 }
 // 1 when the call above runs as ONE launch for this shape (the epilogue form), 0 when it is the conv + the norm's backward in place
 extern "C" int gs_conv2d_bwd_data_pnbwd_is_fused(int n, int h, int w, int ci, int co, int ksize, int stride, int transposed, int dtype) {
@@ -1220,7 +1256,7 @@ extern "C" int gs_conv2d_transpose_s2_bwd_data_pnbwd(const void* gy, const float
     if (igemm_supported(co, ci, dtype))
         return run_igemm(MODE_S2, 2, gy, w_hwio, gx, n, 2 * h, 2 * w, co, ci, ci, co, h, w, alpha, nullptr, GS_ACT_NONE, dtype, w_prepared, ws, ws_bytes, st, z, act, nullptr, eps, addend, 1);
     if (int e = gs_conv2d_transpose_s2_bwd_data(gy, w_hwio, gx, n, h, w, ci, co, alpha, dtype, w_prepared, ws, ws_bytes, stream)) return e;
-    return gs_pixel_norm_bwd_fused(gx, z, addend, gx, (int64_t)n * h * w * ci, ci, eps, GS_ACT_NONE, act, dtype, stream);
+    return gs_pixel_norm_bwd_fused(gx, z, addend, gx, (int64_t)n * h * w, ci, eps, GS_ACT_NONE, act, dtype, stream);
 }
 
 extern "C" int gs_conv2d_transpose_s2_bwd_weight_multi(const void* const* xs, const void* const* gys, const int* ns, int nsrc, float* gw_hwio, int n, int h,

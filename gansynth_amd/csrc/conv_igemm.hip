@@ -21,6 +21,8 @@
 extern "C" int gs_pixel_norm_fwd(const void* x, void* y, int64_t p, int c, float eps, int dtype, void* stream);
 extern "C" int gs_pixel_norm_bwd_fused(const void* g, const void* x, const void* addend, void* gx, int64_t p, int c, float eps, int pre_act, int post_act, int dtype,
                                        void* stream);
+extern "C" int gs_pixel_norm_bwd_bwd_fused(const void* gg, const void* g, const void* x, void* out, void* out_g, int64_t p, int c, float eps, int pre_act,
+                                           int dtype, void* stream);
 
 namespace gs {
 
@@ -101,6 +103,9 @@ struct ConvP {
     // activation output, y's shape) and `addend` an optional second gradient into z (same shape): one pass instead of a conv + a 4-tensor
     // elementwise pass
     const void* addend;
+    // NORM == 3 kernels (second-order pass): the conv result t is the gradient w.r.t. u = act'(z) pixel_norm_bwd(g, z) (the first-order backward
+    // of a generator block, differentiated by the mode-seeking term).  With h = t act'(z): y = pixel_norm_bwd(h, z) (the gradient w.r.t. g) and
+    // y2 = d<h, pixel_norm_bwd(g, z)>/dz (the gradient w.r.t. z); z = `mask`, g = `addend`'s slot.  Same normbwd flag, value 2.
     int normbwd;        // host side: the caller asks for the NORM == 2 epilogue; cleared (and *norm_pending = 2) when the chosen kernel has none
     int* norm_pending;  // host side: set to 1 when the chosen kernel did not fuse the norm
     int N, Hi, Wi, IC, OC, Hb, Wb, tiles_x, tiles_y, nsp, noct, nch;
@@ -177,7 +182,8 @@ __device__ __forceinline__ void block_barrier() {
 // (scripts/probe/igemm_trace.hip); on their own wave they run under them.
 template <typename T, int MODE, int A, int B, int TW, int TG, bool RESIDENT, int D, int NORM, int RB = 64, bool SPEC = false>
 __global__ __launch_bounds__(SPEC ? 512 : 256) void conv_igemm_kernel(const ConvP p) {
-    static_assert(NORM >= 0 && NORM <= 2, "NORM: 0 plain, 1 pixel norm of the result (forward blocks), 2 pixel-norm backward of the result (data gradients)");
+    static_assert(NORM >= 0 && NORM <= 3, "NORM: 0 plain, 1 pixel norm of the result (forward blocks), 2 pixel-norm backward of the result (data gradients), "
+                                          "3 both gradients of a differentiated norm backward (second-order pass)");
     constexpr int NP = 128 * B;
     constexpr int TH = NP / TW;
     constexpr int PH = patch_dim<MODE>(TH), PW = patch_dim<MODE>(TW);
@@ -664,6 +670,94 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void conv_igemm_kernel(const Conv
                                                 w4.x = pack_bf16x2(out[0], out[1]); w4.y = pack_bf16x2(out[2], out[3]);
                                                 w4.z = pack_bf16x2(out[4], out[5]); w4.w = pack_bf16x2(out[6], out[7]);
                                                 *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(y) + off + a * 32 + v * 16 + hi * 8) = w4;
+                                            }
+                                        }
+                                    }
+                            } else if constexpr (NORM == 3) {
+                                // accumulators t = gradient w.r.t. u = M J(z) g (M = act'(z), J the norm's Jacobian).  h = M t;
+                                //   y  = J h                                   = r (h - z r^2 mean(h z))
+                                //   y2 = d<h, J g>/dz = -r^3 (mean(h g) z + mean(z g) h + mean(h z) g) + 3 r^5 mean(h z) mean(z g) z
+                                constexpr int EV = 16 / NV;
+                                mvec_t zq[A][NV], gq[A][NV];
+                                mask_fetch(off, inside, zq);
+                                {
+                                    const long base = inside ? off : 0;
+#pragma unroll
+                                    for (int a = 0; a < A; ++a)
+#pragma unroll
+                                        for (int v = 0; v < NV; ++v)
+                                            gq[a][v] = *reinterpret_cast<const mvec_t*>(reinterpret_cast<const T*>(p.addend) + base + a * 32 + v * (32 / NV) + hi * (16 / NV));
+                                }
+                                float hv[A][NV][EV], zv[A][NV][EV], gv[A][NV][EV];
+                                float ssq = 0.f, shg = 0.f, shz = 0.f, szg = 0.f;
+#pragma unroll
+                                for (int a = 0; a < A; ++a) {
+                                    float o[4][4];
+                                    finish(ph, a, b, o);   // (alpha * acc: no bias, no activation)
+                                    if constexpr (SZ == 4) {
+#pragma unroll
+                                        for (int qd = 0; qd < 4; ++qd) {
+                                            const float4 z4 = zq[a][qd], g4 = gq[a][qd];
+                                            const float zz[4] = {z4.x, z4.y, z4.z, z4.w}, g_[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+                                            for (int e = 0; e < 4; ++e) { hv[a][qd][e] = o[qd][e]; zv[a][qd][e] = zz[e]; gv[a][qd][e] = g_[e]; }
+                                        }
+                                    } else {
+#pragma unroll
+                                        for (int qp = 0; qp < 2; ++qp) {
+#pragma unroll
+                                            for (int e = 0; e < 4; ++e) {
+                                                const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(o[2 * qp][e]), __float_as_uint(o[2 * qp + 1][e]), false, false);
+                                                hv[a][qp][e] = __uint_as_float(r[0]);
+                                                hv[a][qp][4 + e] = __uint_as_float(r[1]);
+                                            }
+                                            const uint4 z4 = zq[a][qp], g4 = gq[a][qp];
+                                            const unsigned zw[4] = {z4.x, z4.y, z4.z, z4.w}, gw_[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+                                            for (int e = 0; e < 4; ++e) {
+                                                zv[a][qp][2 * e] = __uint_as_float(zw[e] << 16); zv[a][qp][2 * e + 1] = __uint_as_float(zw[e] & 0xffff0000u);
+                                                gv[a][qp][2 * e] = __uint_as_float(gw_[e] << 16); gv[a][qp][2 * e + 1] = __uint_as_float(gw_[e] & 0xffff0000u);
+                                            }
+                                        }
+                                    }
+#pragma unroll
+                                    for (int v = 0; v < NV; ++v)
+#pragma unroll
+                                        for (int e = 0; e < EV; ++e) {
+                                            const float zc = zv[a][v][e], gc = gv[a][v][e];
+                                            const float hc = hv[a][v][e] * mask_factor(zc);
+                                            hv[a][v][e] = hc;
+                                            ssq += zc * zc; shg += hc * gc; shz += hc * zc; szg += zc * gc;
+                                        }
+                                }
+                                ssq += __shfl_xor(ssq, 32, 64); shg += __shfl_xor(shg, 32, 64);
+                                shz += __shfl_xor(shz, 32, 64); szg += __shfl_xor(szg, 32, 64);
+                                const float inv_c = 1.f / (float)(32 * A);
+                                const float r = rsqrtf(ssq * inv_c + p.pn_eps);
+                                const float r2 = r * r, r3 = r2 * r;
+                                const float ma = shg * inv_c, mb = shz * inv_c, mm = szg * inv_c;
+                                const float kz = 3.f * r3 * r2 * mb * mm - r3 * ma;   // coefficient of z in y2
+#pragma unroll
+                                for (int a = 0; a < A; ++a)
+#pragma unroll
+                                    for (int v = 0; v < NV; ++v) {
+                                        float o1[EV], o2[EV];
+#pragma unroll
+                                        for (int e = 0; e < EV; ++e) {
+                                            const float zc = zv[a][v][e], gc = gv[a][v][e], hc = hv[a][v][e];
+                                            o1[e] = r * (hc - zc * r2 * mb);
+                                            o2[e] = kz * zc - r3 * (mm * hc + mb * gc);
+                                        }
+                                        if (inside) {
+                                            if constexpr (SZ == 4) {
+                                                st4(reinterpret_cast<float*>(y) + off + a * 32 + v * 8 + hi * 4, o1);
+                                                st4(reinterpret_cast<float*>(p.y2) + off + a * 32 + v * 8 + hi * 4, o2);
+                                            } else {
+                                                uint4 w4;
+                                                w4.x = pack_bf16x2(o1[0], o1[1]); w4.y = pack_bf16x2(o1[2], o1[3]); w4.z = pack_bf16x2(o1[4], o1[5]); w4.w = pack_bf16x2(o1[6], o1[7]);
+                                                *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(y) + off + a * 32 + v * 16 + hi * 8) = w4;
+                                                w4.x = pack_bf16x2(o2[0], o2[1]); w4.y = pack_bf16x2(o2[2], o2[3]); w4.z = pack_bf16x2(o2[4], o2[5]); w4.w = pack_bf16x2(o2[6], o2[7]);
+                                                *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.y2) + off + a * 32 + v * 16 + hi * 8) = w4;
                                             }
                                         }
                                     }
@@ -1527,14 +1621,16 @@ static int launch_igemm(ConvP p, hipStream_t st) {
     if ((size_t)p.Hi * p.Wi * p.IC * sizeof(T) >= (1ull << 31)) return fail(GS_ERR_UNSUPPORTED, "conv igemm: one image exceeds 2 GiB");
     if (lds > 160 * 1024) return fail(GS_ERR_UNSUPPORTED, "conv igemm: %zu bytes of LDS needed", lds);
     if (NORM && p.OC != OCT) return fail(GS_ERR_UNSUPPORTED, "conv igemm: fused pixel norm needs the whole channel range in one tile");
-    if (NORM == 2 && p.OC != OCT) return fail(GS_ERR_UNSUPPORTED, "conv igemm: fused pixel-norm backward needs the whole channel range in one tile");
-    if (NORM != 2 && p.normbwd) {   // no fused form here: plain data gradient, the caller runs the norm's backward as its own pass
+    if ((NORM == 2 || NORM == 3) && p.OC != OCT) return fail(GS_ERR_UNSUPPORTED, "conv igemm: fused pixel-norm backward needs the whole channel range in one tile");
+    if (!((NORM == 2 && p.normbwd == 1) || (NORM == 3 && p.normbwd == 2)) && p.normbwd) {
+        // no fused form here: plain conv, the caller runs the norm's backward kernel(s) as their own pass
+        if (p.norm_pending) *p.norm_pending = 1 + p.normbwd;   // 2: first-order form, 3: second-order form
         p.normbwd = 0;
         p.mask = nullptr;
         p.addend = nullptr;
-        if (p.norm_pending) *p.norm_pending = 2;
+        p.y2 = nullptr;
     }
-    if (NORM != 1 && p.y2) {   // the norm stays a separate pass: this launch leaves the activation where that pass will read it
+    if (NORM != 1 && NORM != 3 && p.y2) {   // the norm stays a separate pass: this launch leaves the activation where that pass will read it
         if (!p.y) p.y = p.y2;
         p.y2 = nullptr;
         if (p.norm_pending) *p.norm_pending = 1;
@@ -1558,7 +1654,7 @@ static int launch_igemm(ConvP p, hipStream_t st) {
     const double flops = 2.0 * 9.0 * (double)p.N * p.Hb * p.Wb * p.IC * p.OC;
     const double out_px = (double)p.N * p.Hb * p.Wb * (MODE == MODE_T2 ? 4 : 1);
     // algorithmic bytes: input + output + weights, + the activation mask a masked launch reads, + the second output of a fused norm
-    const double bytes = ((double)p.N * p.Hi * p.Wi * p.IC + out_px * p.OC * (1.0 + (p.mask ? 1.0 : 0.0) + ((NORM == 1 && p.y) ? 1.0 : 0.0) + ((NORM == 2 && p.addend) ? 1.0 : 0.0)) + 9.0 * p.IC * p.OC) * sizeof(T);
+    const double bytes = ((double)p.N * p.Hi * p.Wi * p.IC + out_px * p.OC * (1.0 + (p.mask ? 1.0 : 0.0) + ((NORM == 1 && p.y) ? 1.0 : 0.0) + ((NORM == 2 && p.addend) ? 1.0 : 0.0) + (NORM == 3 ? 2.0 : 0.0)) + 9.0 * p.IC * p.OC) * sizeof(T);
     const int reps = prof_reps();   // (1 unless profiling in burst mode: the kernel is a pure function of its inputs)
     ProfScope ps(st, flops, bytes, MODE, p.N, p.Hb, p.Wb, p.IC, p.OC, p.mask ? 1 : 0, NORM ? 1 : 0, reps);
     for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(SPEC ? 512 : 256), lds, st, p);
@@ -1596,10 +1692,15 @@ static int dispatch_igemm(ConvP p, hipStream_t st) {
     // Fused pixel norm (p.y2): only the configurations whose tile owns every channel of a pixel (OC = 32 A) and that the generator's
     // 32- / 64-channel blocks actually use; everything else runs the plain kernel and the caller's separate norm pass (p.y2 = NULL
     // on return tells it so -- see run_igemm_t).
-    const bool norm = p.y2 != nullptr;
-    const bool nbwd = p.normbwd != 0;   // (the three data-gradient shapes of the generator's 32- / 64-channel blocks below; anything else falls back)
+    const bool norm = p.y2 != nullptr && p.normbwd == 0;
+    const bool nbwd = p.normbwd == 1;   // (the three data-gradient shapes of the generator's 32- / 64-channel blocks below; anything else falls back)
+    const bool nbb = p.normbwd == 2;    // (second-order form: the forward-role shapes that have the NORM == 1 epilogue)
     if constexpr (MODE == MODE_T2) {
-        if (resident_ok && Wb >= 64) { if (norm) return launch_igemm<T, MODE, 1, 1, 64, 9, true, 1, true>(p, st); return launch_igemm<T, MODE, 1, 1, 64, 9, true, 1>(p, st); }
+        if (resident_ok && Wb >= 64) {
+            if (norm) return launch_igemm<T, MODE, 1, 1, 64, 9, true, 1, true>(p, st);
+            if (nbb) return launch_igemm<T, MODE, 1, 1, 64, 9, true, 1, 3>(p, st);
+            return launch_igemm<T, MODE, 1, 1, 64, 9, true, 1>(p, st);
+        }
         // few blocks, each a serial chain of stages: 32-channel tiles double the number of busy CUs, 9-tap stages cut the
         // barriers and DMA round trips of the chain to a third
         if (small) {
@@ -1622,6 +1723,7 @@ static int dispatch_igemm(ConvP p, hipStream_t st) {
         if (!a2) { if (Wb >= 32) return launch_igemm<T, MODE, 1, 1, 32, 3>(p, st); return launch_igemm<T, MODE, 1, 1, 16, 3>(p, st); }
         if (Wb >= 32) {
             if (norm && OC == 64) return launch_igemm<T, MODE, 2, 1, 32, 3, false, 2, true>(p, st);
+            if (nbb && OC == 64) return launch_igemm<T, MODE, 2, 1, 32, 3, false, 2, 3>(p, st);
             if (spec_mask() & 4) return launch_igemm<T, MODE, 2, 1, 32, 3, false, 2, false, 64, true>(p, st);
             return launch_igemm<T, MODE, 2, 1, 32, 3>(p, st);
         }
@@ -1648,6 +1750,7 @@ static int dispatch_igemm(ConvP p, hipStream_t st) {
         if (resident_ok && Wb >= 64) {
             if (norm) return launch_igemm<T, MODE, 1, 2, 64, 9, true, 1, true>(p, st);
             if (nbwd) return launch_igemm<T, MODE, 1, 2, 64, 9, true, 1, 2>(p, st);
+            if (nbb) return launch_igemm<T, MODE, 1, 2, 64, 9, true, 1, 3>(p, st);
             return launch_igemm<T, MODE, 1, 2, 64, 9, true, 1>(p, st);
         }
         if (small) {
@@ -1671,6 +1774,7 @@ static int dispatch_igemm(ConvP p, hipStream_t st) {
         if (Wb >= 32 && items64(2) >= 2 * cus) {
             if (norm && OC == 64) return launch_igemm<T, MODE, 2, 2, 32, 3, false, 1, true>(p, st);
             if (nbwd && OC == 64) return launch_igemm<T, MODE, 2, 2, 32, 3, false, 1, 2>(p, st);
+            if (nbb && OC == 64) return launch_igemm<T, MODE, 2, 2, 32, 3, false, 1, 3>(p, st);
             if (spec_mask() & 2) return launch_igemm<T, MODE, 2, 2, 32, 3, false, 2, false, 64, true>(p, st);
             return launch_igemm<T, MODE, 2, 2, 32, 3, false, 1>(p, st);
         }
@@ -1695,12 +1799,25 @@ static int dispatch_igemm(ConvP p, hipStream_t st) {
 }
 
 // does dispatch_igemm have the NORM == 2 (pixel-norm backward) epilogue for this data-gradient shape?  (mirrors its three branches)
-bool igemm_normbwd_fused(int mode, int N, int Hb, int Wb, int IC, int OC, int dtype) {
+// form 1: NORM == 2 (first order, data-gradient roles); form 2: NORM == 3 (second order, forward roles)
+bool igemm_normbwd_fused(int mode, int N, int Hb, int Wb, int IC, int OC, int dtype, int form) {
     const int bk = dtype == GS_F32 ? 16 : 32;
     if (IC % bk != 0 || OC % 32 != 0) return false;
     const int nch = IC / bk;
     const long cus = num_cus();
     auto items64 = [&](int B_) { return (long)N * cdiv(Hb, 4 * B_) * cdiv(Wb, 32) * (OC / 64); };
+    if (form == 2) {   // mirrors the NORM == 1 branches of dispatch_igemm
+        const bool small = items64(1) <= cus;
+        if (mode == MODE_T2) {
+            if (OC == 32 && nch <= 2 && Wb >= 64) return true;
+            return !small && OC == 64 && Wb >= 32;
+        }
+        if (mode == MODE_S1) {
+            if (OC == 32 && nch <= 2 && Wb >= 64) return true;
+            return !small && OC == 64 && Wb >= 32 && items64(2) >= 2 * cus;
+        }
+        return false;
+    }
     if (mode == MODE_S1) {
         if (OC == 32 && nch <= 2 && Wb >= 64) return true;
         const bool small = items64(1) <= cus;
@@ -1748,6 +1865,10 @@ static int run_igemm_t(int mode, int variant, const void* x, const float* w_hwio
     else rc = dispatch_igemm<T, MODE_T2>(p, st);
     if (rc) return rc;
     GS_CHECK_LAUNCH();
+    if (pending == 3) {   // second-order form without an epilogue: y holds t; both gradients from the norm's own kernel (y in place, y2)
+        const long px = (long)N * Hb * Wb * (mode == MODE_T2 ? 4 : 1);
+        return gs_pixel_norm_bwd_bwd_fused(y, addend, mask, y2, y, px, OCk, pn_eps, mask_act, sizeof(T) == 4 ? GS_F32 : GS_BF16, st);
+    }
     if (pending == 2) {   // no fused pixel-norm backward for this shape: y holds the plain data gradient g; the norm's backward runs in place
         const long px = (long)N * Hb * Wb * (mode == MODE_T2 ? 4 : 1);
         return gs_pixel_norm_bwd_fused(y, mask, addend, y, px, OCk, pn_eps, GS_ACT_NONE, mask_act, sizeof(T) == 4 ? GS_F32 : GS_BF16, st);

@@ -372,6 +372,41 @@ class HipKernels(object):
                                                     float(alpha), _dt(gy), prepared, ws.data_ptr(), ws.numel(), _stream()), "gs_conv2d_bwd_data_mask")
         return gx
 
+    def fwd_pnbwdbwd_is_fused(self, x_shape, co, ksize, stride, transposed, dtype):
+        """Does conv2d[_transpose]_fwd_pnbwdbwd run as ONE launch for a conv with input x_shape and `co` output channels?"""
+        n, ci, h, wd = x_shape
+        return bool(self.lib.gs_conv2d_fwd_pnbwdbwd_is_fused(int(n), int(h), int(wd), int(ci), int(co), int(ksize), int(stride), 1 if transposed else 0,
+                                                            GS_F32 if dtype == torch.float32 else GS_BF16))
+
+    def conv2d_fwd_pnbwdbwd(self, x, w, ksize, stride, alpha, g, z, eps, act):
+        """(out_z, out_g) = both gradients of u = act'(z) pixel_norm_bwd(g, z) contracted with t = conv2d_fwd(x, w): what pixel_norm_bwd_bwd(t, g, z,
+        pre_act=act, with_g=True) returns, from the conv's epilogue where its tile owns all channels of a pixel."""
+        x, w, g, z = _act(x), _f32c(w), _act(g), _act(z)
+        n, ci, h, wd = x.shape
+        co = w.shape[3]
+        out_g = _empty_like_act((n, co, h // stride, wd // stride), x)
+        assert g.shape == out_g.shape == z.shape and g.dtype == x.dtype == z.dtype
+        out_z = torch.empty_like(out_g)
+        nb = self.lib.gs_conv2d_workspace_bytes(_lib.CONV_FWD, n, h, wd, ci, co, ksize, stride, _dt(x))
+        ws, prepared = self._weight_ws(w, ("fwd", ksize, stride, _dt(x)), nb, (_lib.PREP_CONV_FWD, ci, co, ksize, stride, _dt(x)))
+        _lib.check(self.lib.gs_conv2d_fwd_pnbwdbwd(x.data_ptr(), w.data_ptr(), g.data_ptr(), z.data_ptr(), int(act), float(eps), out_g.data_ptr(), out_z.data_ptr(), n, h,
+                                                   wd, ci, co, ksize, stride, float(alpha), _dt(x), prepared, ws.data_ptr(), ws.numel(), _stream()), "gs_conv2d_fwd_pnbwdbwd")
+        return out_z, out_g
+
+    def conv2d_transpose_fwd_pnbwdbwd(self, x, w, alpha, g, z, eps, act):
+        x, w, g, z = _act(x), _f32c(w), _act(g), _act(z)
+        n, ci, h, wd = x.shape
+        co = w.shape[3]
+        out_g = _empty_like_act((n, co, 2 * h, 2 * wd), x)
+        assert g.shape == out_g.shape == z.shape and g.dtype == x.dtype == z.dtype
+        out_z = torch.empty_like(out_g)
+        nb = self.lib.gs_conv2d_transpose_s2_workspace_bytes(_lib.CONV_FWD, n, h, wd, ci, co, _dt(x))
+        ws, prepared = self._weight_ws(w, ("t_fwd", _dt(x)), nb, (_lib.PREP_CONVT_FWD, ci, co, 3, 2, _dt(x)))
+        _lib.check(self.lib.gs_conv2d_transpose_s2_fwd_pnbwdbwd(x.data_ptr(), w.data_ptr(), g.data_ptr(), z.data_ptr(), int(act), float(eps), out_g.data_ptr(),
+                                                                out_z.data_ptr(), n, h, wd, ci, co, float(alpha), _dt(x), prepared, ws.data_ptr(), ws.numel(), _stream()),
+                   "gs_conv2d_transpose_s2_fwd_pnbwdbwd")
+        return out_z, out_g
+
     def bwd_data_pnbwd_is_fused(self, x_shape, co, ksize, stride, transposed, dtype):
         """Does conv2d[_transpose]_bwd_data_pnbwd run as ONE launch for a conv with input x_shape = (n, ci, h, w) and `co` output channels?"""
         n, ci, h, wd = x_shape

@@ -150,6 +150,15 @@ int gs_conv2d_transpose_s2_fwd_bias_act(const void* x, const float* w_hwio, cons
                                         size_t ws_bytes, void* stream);
 int gs_conv2d_transpose_s2_bwd_data(const void* gy, const float* w_hwio, void* gx, int n, int h, int w, int ci, int co,
                                     float alpha, int dtype, int w_prepared, void* ws, size_t ws_bytes, void* stream);
+/* Second-order pass of the mode-seeking term (models.py:57-64: tf.gradients of tf.gradients(fake_images, [latents])): the conv applied to a cotangent
+ * yields t = the gradient w.r.t. u = act'(z) pixel_norm_bwd(g, z) (a block's first-order backward); with h = t act'(z) the epilogue writes
+ *   out_g = pixel_norm_bwd(h, z)   and   out_z = d<h, pixel_norm_bwd(g, z)>/dz      (g, z, out_g, out_z: the conv's output shape)
+ * in one pass where a tile owns all channels of a pixel (gs_conv2d_fwd_pnbwdbwd_is_fused), else as the conv + gs_pixel_norm_bwd_bwd_fused. */
+int gs_conv2d_fwd_pnbwdbwd(const void* x, const float* w_hwio, const void* g, const void* z, int act, float eps, void* out_g, void* out_z, int n, int h, int w,
+                           int ci, int co, int ksize, int stride, float alpha, int dtype, int w_prepared, void* ws, size_t ws_bytes, void* stream);
+int gs_conv2d_transpose_s2_fwd_pnbwdbwd(const void* x, const float* w_hwio, const void* g, const void* z, int act, float eps, void* out_g, void* out_z, int n,
+                                        int h, int w, int ci, int co, float alpha, int dtype, int w_prepared, void* ws, size_t ws_bytes, void* stream);
+int gs_conv2d_fwd_pnbwdbwd_is_fused(int n, int h, int w, int ci, int co, int ksize, int stride, int transposed, int dtype);
 /* Data gradient continued through the PREVIOUS block's pixel norm and activation (networks.py:41-93: conv -> leaky_relu -> pixel_norm;
  * the backward tf.gradients builds for ops.py:330-333 behind ops.py:237-243 / 269-276), one pass where a tile owns all channels of a pixel:
  *   gx = (pixel_norm_bwd(B^T(gy, w), z) + addend) * act'(z);  z: the previous block's activation output (gx's shape), addend: optional */

@@ -814,3 +814,42 @@ def test_data_gradient_continued_through_the_previous_pixel_norm(K, case, dtype,
     if dtype == torch.bfloat16:   # one rounding instead of two: at least as close to the definition as the two-kernel path
         assert float((got.double() - want).pow(2).mean()) <= 1.05 * float((ref.double() - want).pow(2).mean()) + 1e-12
 
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", [("conv", 8, 32, 32, 128, 1024), ("conv", 8, 64, 64, 64, 512), ("convT", 8, 64, 32, 64, 512),   # fused at full size
+                                  ("convT", 8, 128, 64, 32, 256), ("conv", 2, 32, 32, 8, 128), ("conv", 2, 8, 64, 8, 64), ("convT", 2, 16, 32, 8, 64),
+                                  ("conv", 2, 256, 256, 4, 32), ("convT", 2, 128, 64, 4, 32), ("conv", 1, 40, 64, 6, 40), ("conv", 3, 5, 8, 5, 7)])
+def test_second_order_norm_gradients_in_the_forward_conv(K, case, dtype):
+    """gs_conv2d[_transpose_s2]_fwd_pnbwdbwd: with t = conv(x, w) the cotangent of u = act'(z) pixel_norm_bwd(g, z), both gradients of that
+    node (w.r.t. g and w.r.t. z) from the conv's epilogue, against a float64 autograd evaluation of the definition on the fp32 conv output
+    and against the two-kernel path (conv, then gs_pixel_norm_bwd_bwd_fused).  bf16: compared at bf16 resolution of each tensor's scale."""
+    kind, n, ci, co, h, w = case
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    CL = torch.channels_last
+    x = torch.randn(n, ci, h, w, device="cuda", generator=gen).to(dtype).contiguous(memory_format=CL)
+    wt = torch.randn(3, 3, ci, co, device="cuda", generator=gen)
+    oh, ow = (2 * h, 2 * w) if kind == "convT" else (h, w)
+    z = torch.nn.functional.leaky_relu(torch.randn(n, co, oh, ow, device="cuda", generator=gen), 0.2).to(dtype).contiguous(memory_format=CL)
+    g = torch.randn(n, co, oh, ow, device="cuda", generator=gen).to(dtype).contiguous(memory_format=CL)
+    alpha, eps, act = 0.03, 1e-8, 1
+    if kind == "conv":
+        t = K.conv2d_fwd(x, wt, 3, 1, alpha)
+        t32 = K.conv2d_fwd(x.float(), wt, 3, 1, alpha)
+        got_z, got_g = K.conv2d_fwd_pnbwdbwd(x, wt, 3, 1, alpha, g, z, eps, act)
+    else:
+        t = K.conv2d_transpose_fwd(x, wt, alpha)
+        t32 = K.conv2d_transpose_fwd(x.float(), wt, alpha)
+        got_z, got_g = K.conv2d_transpose_fwd_pnbwdbwd(x, wt, alpha, g, z, eps, act)
+    ref_z, ref_g = K.pixel_norm_bwd_bwd(t, g, z, eps, pre_act=act, with_g=True)
+    zz, gg = z.double().requires_grad_(True), g.double().requires_grad_(True)
+    r = torch.rsqrt((zz * zz).mean(dim=1, keepdim=True) + eps)
+    u = r * (gg - zz * r * r * (zz * gg).mean(dim=1, keepdim=True)) * torch.where(zz > 0, 1.0, 0.2)
+    want_g, want_z = torch.autograd.grad((u * t32.double()).sum(), [gg, zz])
+    for name, got, ref, want in (("g", got_g, ref_g, want_g), ("z", got_z, ref_z, want_z)):
+        scale = float(want.abs().max())
+        err = float((got.double() - want).abs().max())
+        assert err <= (2e-5 if dtype == torch.float32 else 2e-2) * scale, (name, err, scale)
+        assert float((got.double() - ref.double()).abs().max()) <= (2e-5 if dtype == torch.float32 else 3e-2) * scale, name
+        if dtype == torch.bfloat16:
+            assert float((got.double() - want).pow(2).mean()) <= 1.05 * float((ref.double() - want).pow(2).mean()) + 1e-12, name
