@@ -96,6 +96,13 @@ class _ConvKind(object):
         K = _K()
         return hasattr(K, "bwd_data_pnbwd_is_fused") and K.bwd_data_pnbwd_is_fused(x_shape, co, self.ksize, self.stride, False, dtype)
 
+    def fwd_pnbwdbwd(self, x, w, alpha, g, z, eps, act):
+        return _K().conv2d_fwd_pnbwdbwd(x, w, self.ksize, self.stride, alpha, g, z, eps, act)
+
+    def fwd_pnbwdbwd_is_fused(self, x_shape, co, dtype):
+        K = _K()
+        return hasattr(K, "fwd_pnbwdbwd_is_fused") and K.fwd_pnbwdbwd_is_fused(x_shape, co, self.ksize, self.stride, False, dtype)
+
     bias_in_wgrad = True   # the weight-gradient kernels can return the bias gradient of the block on the side
 
     def bwd_weight(self, x, gy, alpha, out=None, bias_out=None):
@@ -127,6 +134,13 @@ class _ConvTransposeKind(object):
     def bwd_data_pnbwd_is_fused(self, x_shape, co, dtype):
         K = _K()
         return hasattr(K, "bwd_data_pnbwd_is_fused") and K.bwd_data_pnbwd_is_fused(x_shape, co, 3, 2, True, dtype)
+
+    def fwd_pnbwdbwd(self, x, w, alpha, g, z, eps, act):
+        return _K().conv2d_transpose_fwd_pnbwdbwd(x, w, alpha, g, z, eps, act)
+
+    def fwd_pnbwdbwd_is_fused(self, x_shape, co, dtype):
+        K = _K()
+        return hasattr(K, "fwd_pnbwdbwd_is_fused") and K.fwd_pnbwdbwd_is_fused(x_shape, co, 3, 2, True, dtype)
 
     def bwd_weight(self, x, gy, alpha, out=None):
         return _K().conv2d_transpose_bwd_weight(x, gy, alpha, out=out)
@@ -318,15 +332,27 @@ class _BilinearBwdData(Function):
     """gx = alpha * d<gy, B(x,w)>/dx   (linear in gy and in w)."""
 
     @staticmethod
-    def forward(ctx, gy, w, x_shape, kind, alpha):
+    def forward(ctx, gy, w, x_shape, kind, alpha, sole_consumer=False):
         ctx.kind, ctx.alpha, ctx.wref = kind, alpha, w
+        ctx.sole_consumer = bool(sole_consumer)   # gy comes straight out of a _PnActBwd node and feeds nothing else (caller's promise)
         ctx.save_for_backward(gy, w)
         return kind.bwd_data(gy, w, x_shape, alpha)
 
     @staticmethod
     def backward(ctx, ggx):
         gy, w = ctx.saved_tensors
-        g_gy = _Bilinear.apply(ggx, w, ctx.kind, ctx.alpha) if ctx.needs_input_grad[0] else None
+        g_gy = None
+        if ctx.needs_input_grad[0]:
+            pn = gy.grad_fn if (_FUSE_NORM_BWD2 and ctx.sole_consumer and not torch.is_grad_enabled() and hasattr(ctx.kind, "fwd_pnbwdbwd")) else None
+            if (pn is not None and isinstance(pn, _PnActBwd._backward_cls) and pn.needs_input_grad[0] and pn.needs_input_grad[1]
+                    and ctx.kind.fwd_pnbwdbwd_is_fused(tuple(ggx.shape), gy.shape[1], gy.dtype)):
+                # second-order pass: B(ggx, w) is the cotangent of that node's output, and both of its gradients come out of the conv's
+                # epilogue; the node finds them under the address of what it is handed (see _PnActBwd.backward)
+                g, z = pn.saved_tensors
+                g_z, g_gy = ctx.kind.fwd_pnbwdbwd(ggx, w, ctx.alpha, g, z, pn.eps, pn.act)
+                pn._gs_done = (g_gy.data_ptr(), g_z)
+            else:
+                g_gy = _Bilinear.apply(ggx, w, ctx.kind, ctx.alpha)
         g_w = None
         if ctx.needs_input_grad[1]:
             tgt = _accum_target(ctx.wref)
@@ -336,7 +362,7 @@ class _BilinearBwdData(Function):
                 ctx.kind.bwd_weight(ggx, gy, ctx.alpha, out=tgt)
             else:
                 g_w = _BilinearBwdWeight.apply(ggx, gy, ctx.kind, ctx.alpha).to(w.dtype)
-        return g_gy, g_w, None, None, None
+        return g_gy, g_w, None, None, None, None
 
 
 class _BwdDataMasked(Function):
@@ -494,6 +520,7 @@ class _PnActBwd(Function):
         if act != ACT_LRELU:
             raise NotImplementedError("_PnActBwd: piecewise-linear activations only (the tanh head has no pixel norm)")
         ctx.eps, ctx.act = eps, act
+        ctx._gs_done = None
         ctx.save_for_backward(g, z)
         return _K().pixel_norm_bwd(g, z, eps, act=act)
 
@@ -501,8 +528,12 @@ class _PnActBwd(Function):
     @once_differentiable
     def backward(ctx, gg):
         g, z = ctx.saved_tensors
+        done, ctx._gs_done = ctx._gs_done, None
         if ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:   # both from one pass over gg, g, z
-            g_z, g_g = _K().pixel_norm_bwd_bwd(gg, g, z, ctx.eps, pre_act=ctx.act, with_g=True)
+            if done is not None and gg.data_ptr() == done[0]:
+                g_g, g_z = gg, done[1]   # the conv that produced this node's cotangent already went through it (_BilinearBwdData.backward)
+            else:
+                g_z, g_g = _K().pixel_norm_bwd_bwd(gg, g, z, ctx.eps, pre_act=ctx.act, with_g=True)
             if _FUSE_NORM_BWD:
                 _GZ[z.data_ptr()] = g_z   # (see above: the consumer of pixel_norm(z) may add it in its data-gradient epilogue)
             return g_g, g_z, None, None
@@ -513,6 +544,7 @@ class _PnActBwd(Function):
 
 _FUSE_NORM_EPILOGUE = not __import__("os").environ.get("GS_NO_NORM_EPILOGUE")   # A/B switch for measurements
 _FUSE_NORM_BWD = not __import__("os").environ.get("GS_NO_NORM_BWD_EPILOGUE")  # A/B switch: the previous block's norm backward in the data-gradient epilogue
+_FUSE_NORM_BWD2 = not __import__("os").environ.get("GS_NO_NORM_BWD2_EPILOGUE")  # A/B switch: the norm's second-order kernel in the forward-on-cotangent conv
 
 # ---- the previous block's (activation -> pixel norm) backward inside the conv that produces its input gradient -----------------------
 # Plain backward of a generator block: g_y -> [pixel_norm_bwd(g_y, z) + g_z] * act'(z) -> data gradient conv -> g_y of the block before.
@@ -568,7 +600,8 @@ class _ConvBiasActNorm(Function):
             if g_z is not None:
                 extra = _ActBwd.apply(g_z, z, ctx.act)
                 gy = extra if gy is None else gy + extra
-            gx = _BilinearBwdData.apply(gy, w, x.shape, ctx.kind, ctx.alpha) if ctx.needs_input_grad[0] else None
+            sole = g_y is not None and g_z is None and not want_w and not want_b   # gy: straight out of _PnActBwd, into the data gradient only
+            gx = _BilinearBwdData.apply(gy, w, x.shape, ctx.kind, ctx.alpha, sole) if ctx.needs_input_grad[0] else None
             gw = _BilinearBwdWeight.apply(x, gy, ctx.kind, ctx.alpha).to(w.dtype) if want_w else None
             gb = _ChannelSum.apply(gy) if want_b else None
             return gx, gw, gb, None, None, None, None, None

@@ -448,6 +448,39 @@ def test_norm_backward_rides_in_the_data_gradient_convs_at_full_size(gpu_store):
             assert rel_l2(out[True][1][k], g) < 2e-2, (k, rel_l2(out[True][1][k], g))
 
 
+def test_second_order_norm_kernels_ride_in_the_cotangent_convs_at_full_size(gpu_store):
+    """Same shapes: in the second-order pass of the mode-seeking term (models.py:57-64) the convs run forward on cotangents, and where their
+    tile owns all channels of a pixel both gradients of the block's (leaky_relu -> pixel_norm) backward node come out of the conv's epilogue
+    (gs_conv2d[_transpose_s2]_fwd_pnbwdbwd) -- the four 32- / 64-channel layers; counted, and the step equals the one with the fusion
+    switched off (functional._FUSE_NORM_BWD2) up to bf16 rounding of the cotangent the fused path never stores."""
+    from gansynth_amd import functional as F, kernels, variables
+    K = kernels.get()
+    out = {}
+    for fuse in (True, False):
+        variables.set_default_store(variables.VariableStore(device="cuda", seed=0))
+        pg, opg, model = make(1.0, variables.default_store(), dtype=torch.bfloat16)
+        lat, lab, _ = R.synthetic_batch(8, rank=0)
+        c = lambda t: cuda(t).to(torch.bfloat16)
+        model._build(c(lat), c(lab))
+        calls = []
+        orig_a, orig_b, was = K.conv2d_fwd_pnbwdbwd, K.conv2d_transpose_fwd_pnbwdbwd, F._FUSE_NORM_BWD2
+        K.conv2d_fwd_pnbwdbwd = lambda *a, **k: (calls.append(("conv", tuple(a[6].shape))), orig_a(*a, **k))[1]
+        K.conv2d_transpose_fwd_pnbwdbwd = lambda *a, **k: (calls.append(("convT", tuple(a[4].shape))), orig_b(*a, **k))[1]
+        F._FUSE_NORM_BWD2 = fuse
+        try:
+            loss = float(model.generator_step(c(lat), c(lab)))
+        finally:
+            K.conv2d_fwd_pnbwdbwd, K.conv2d_transpose_fwd_pnbwdbwd, F._FUSE_NORM_BWD2 = orig_a, orig_b, was
+        out[fuse] = (loss, {k: p.grad.clone() for k, p in model.g_params.named.items()}, calls)
+    assert out[False][2] == []
+    shapes = sorted((kind, shape[1:]) for kind, shape in out[True][2])
+    assert shapes == [("conv", (32, 128, 1024)), ("conv", (64, 64, 512)), ("convT", (32, 128, 1024)), ("convT", (64, 64, 512))], shapes
+    assert abs(out[True][0] - out[False][0]) <= 1e-6 * max(1.0, abs(out[False][0]))
+    for k, g in out[False][1].items():
+        if float(g.abs().max()) > 0:
+            assert rel_l2(out[True][1][k], g) < 2e-2, (k, rel_l2(out[True][1][k], g))
+
+
 def test_pipelined_train_step_equals_sequential(gpu_store):
     """train_step with graphs runs every run as two graphs and moves the optimizer updates to a side stream (they overlap the
     other network's own part): same losses and parameters as the sequential eager iteration, step after step (up to the order
