@@ -150,6 +150,7 @@ class GANSynth(object):
         self._peeked = None                     # a batch fetched ahead of the first step (train: eager build / restore)
         self._run_reduced = False               # the last _run replayed a graph that contains its own gradient all-reduce
         self._captured_reduce = False
+        self._graph_allreduce = _GRAPH_ALLREDUCE   # cleared for the life of the model if a capture with the collective inside fails
         self.global_step = 0
         self.g_params = None
         self.d_params = None
@@ -404,12 +405,28 @@ class GANSynth(object):
                     K.flush_wgrad_reductions()
         if launched:
             self._inflight = (params, launched)
-        if self.distributed and self._comm is not None and _GRAPH_ALLREDUCE and self._capturing() and not getattr(self, "_pipe_capture", False):
+        if self.distributed and self._comm is not None and self._graph_allreduce and self._capturing() and not getattr(self, "_pipe_capture", False):
             # Same-stream RCCL is capturable: the all-reduce of this run's flat gradient becomes the LAST NODE of the run's hipGraph, so
             # a replayed run hands over reduced gradients and no eager collective launch sits between the replay and the update.
+            if __import__("os").environ.get("GS_TEST_FAIL_GRAPH_ALLREDUCE"):   # (test hook: the fallback below, exercised at world size 1)
+                raise RuntimeError("GS_TEST_FAIL_GRAPH_ALLREDUCE: simulated failure of a collective under stream capture")
             self._reduce(params)
             self._captured_reduce = True
         return loss.detach()
+
+    def _abandon_capture(self, which):
+        """State left behind by a _forward_backward that raised in the middle of a stream capture: deferred kernel-layer jobs, half-built
+        fusion hand-offs and the gradients the partial backward wrote."""
+        torch.cuda.synchronize()
+        K = kernels.get()
+        if hasattr(K, "drop_deferred"):
+            K.drop_deferred()
+        F.reset_fusion_state()
+        self._inflight = None
+        params = self.d_params if which == "d" else self.g_params
+        if not self.keep_gradients:   # (as before the first capture: a graph without a fill must find the buffer the way every replay will)
+            params.grad.zero_()
+            params.grad_clean = True
 
     @staticmethod
     def _capturing():
@@ -492,7 +509,7 @@ class GANSynth(object):
                 try:
                     with torch.cuda.stream(side):  # one eager pass on a side stream (allocator / lazy-init warm-up)
                         self._forward_backward(which, *static)
-                        if self.distributed and self._comm is not None and _GRAPH_ALLREDUCE:
+                        if self.distributed and self._comm is not None and self._graph_allreduce:
                             # RCCL sets up its channels on the first collective of a kind: not capturable, so one eager all-reduce
                             # of the buffers the graph will reduce (every rank does the same; the gradients are dead values here)
                             self._reduce(self.d_params if which == "d" else self.g_params)
@@ -510,8 +527,23 @@ class GANSynth(object):
                 K.refresh_weights()
                 graph = torch.cuda.CUDAGraph()
                 self._captured_reduce = False
-                with _quiet_gc(), torch.cuda.graph(graph):
-                    loss = self._forward_backward(which, *static)
+                try:
+                    with _quiet_gc(), torch.cuda.graph(graph):
+                        loss = self._forward_backward(which, *static)
+                except RuntimeError as e:
+                    if not (self.distributed and self._comm is not None and self._graph_allreduce):
+                        raise
+                    # The collective would not go into the graph (every rank runs the same launches, so every rank lands here): capture
+                    # the run without it -- the all-reduce then follows each replay eagerly on the same stream, as in round 2.
+                    import sys
+                    print("gansynth_amd.models: capturing the gradient all-reduce inside the %s run's graph failed (%s); "
+                          "it will run eagerly after each replay" % (which, str(e).splitlines()[0]), file=sys.stderr, flush=True)
+                    self._graph_allreduce = False
+                    self._captured_reduce = False
+                    self._abandon_capture(which)
+                    graph = torch.cuda.CUDAGraph()
+                    with _quiet_gc(), torch.cuda.graph(graph):
+                        loss = self._forward_backward(which, *static)
             finally:
                 owner.fade_weight = None   # (only captured launches use the table; eager callers keep passing the number)
             entry = (graph, static, loss, self._captured_reduce)

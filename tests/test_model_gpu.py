@@ -740,7 +740,7 @@ def test_distributed_step_on_rccl_world_size_1():
                             device_id=torch.device("cuda", 0))
     try:
         out = {}
-        for mode in ("plain", "dist", "dist+graphs", "dist+torch"):
+        for mode in ("plain", "dist", "dist+graphs", "dist+graphs, collective refused by the capture", "dist+torch"):
             variables.set_default_store(variables.VariableStore(device="cuda"))
             pg, opg, model = make(1.0, variables.default_store(), full=False)
             model.distributed, model.world, model.bucket_bytes = mode != "plain", 1, 16 << 10
@@ -748,7 +748,11 @@ def test_distributed_step_on_rccl_world_size_1():
                 os.environ["GS_TORCH_COLLECTIVES"] = "1"
             else:
                 os.environ.pop("GS_TORCH_COLLECTIVES", None)
-            model.use_graphs = mode == "dist+graphs"
+            if "refused" in mode:   # the all-reduce raises under stream capture: the run is captured again without it and reduced eagerly
+                os.environ["GS_TEST_FAIL_GRAPH_ALLREDUCE"] = "1"
+            else:
+                os.environ.pop("GS_TEST_FAIL_GRAPH_ALLREDUCE", None)
+            model.use_graphs = mode.startswith("dist+graphs")
             gp, dp = opg.init_params(seed=0, bias_std=0.1)
             losses = []
             for step in range(3):
@@ -759,16 +763,21 @@ def test_distributed_step_on_rccl_world_size_1():
                 losses.append(float(model.discriminator_step(cuda(lat), cuda(lab), cuda(real))))
                 losses.append(float(model.generator_step(cuda(lat), cuda(lab))))
             torch.cuda.synchronize()
-            out[mode] = (losses, model.d_params.flat.clone(), model.g_params.flat.clone(), len(model.g_params.buckets), model._comm is not None)
+            out[mode] = (losses, model.d_params.flat.clone(), model.g_params.flat.clone(), len(model.g_params.buckets), model._comm is not None,
+                         model._graph_allreduce, model._run_reduced)
         assert out["plain"][3] == 1 and out["dist"][3] > 4
         assert model._comm is None and out["dist"][4] and out["dist+graphs"][4]
-        for mode in ("dist", "dist+graphs", "dist+torch"):   # (two trainers in one process may associate fp32 gradient sums differently, see above)
+        assert out["dist+graphs"][5] and out["dist+graphs"][6]   # the replayed graph carried the all-reduce ...
+        refused = out["dist+graphs, collective refused by the capture"]
+        assert refused[4] and not refused[5] and not refused[6]   # ... and here it did not: reduced eagerly behind every replay
+        for mode in ("dist", "dist+graphs", "dist+graphs, collective refused by the capture", "dist+torch"):   # (two trainers in one process may associate fp32 gradient sums differently, see above)
             for i, (a, b) in enumerate(zip(out["plain"][0], out[mode][0])):
                 _same_up_to_accumulation_order(a, b, f"{mode}: loss {i}")
             _same_up_to_accumulation_order(out["plain"][1], out[mode][1], f"{mode}: discriminator parameters")
             _same_up_to_accumulation_order(out["plain"][2], out[mode][2], f"{mode}: generator parameters")
     finally:
         os.environ.pop("GS_TORCH_COLLECTIVES", None)
+        os.environ.pop("GS_TEST_FAIL_GRAPH_ALLREDUCE", None)
         dist.destroy_process_group()
 
 
