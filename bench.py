@@ -440,10 +440,18 @@ def main():
                        "global_batch": global_batch, "parallelism": "dp%d" % world,
                        "launch": "eager" if args.no_graphs else "hipGraph replay of fwd+bwd per run; all-reduce + Adam eager"},
             # The family mixes MFMA-bound launches (>= 64 channels) with HBM-bound ones (32 channels: 144 flop/byte, below the
-            # 312 flop/byte ridge).  "frac" follows the contract (achieved / MFMA peak over the whole family); "roof_frac" is the
-            # time the binding roof allows, summed per launch, over the measured time.
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK[args.dtype], "unit": "TFLOP/s",
-                         "frac": achieved / PEAK[args.dtype], "traffic": traffic,
+            # 312 flop/byte ridge; every launch with a fused norm / mask epilogue moves further that way).  The binding roof of the FAMILY
+            # is the one that owns the larger share of its summed per-launch roof time (`hbm_bound_share_of_roof`): achieved / peak / frac
+            # are quoted against that roof, both views are always there (`mfma_view`, `hbm_view`), and "roof_frac" is the time the
+            # binding roof of EACH launch allows, summed, over the measured time.
+            "roofline": {**({"bound": "hbm", "achieved": conv_bytes / (conv_ms * 1e-3) / 1e9 if conv_ms > 0 else 0.0, "peak": HBM_GBPS, "unit": "GB/s",
+                             "frac": (conv_bytes / (conv_ms * 1e-3) / 1e9 if conv_ms > 0 else 0.0) / HBM_GBPS}
+                            if roof_ms > 0 and roof_ms_hbm / roof_ms > 0.5 else
+                            {"bound": "mfma", "achieved": achieved, "peak": PEAK[args.dtype], "unit": "TFLOP/s", "frac": achieved / PEAK[args.dtype]}),
+                         "traffic": traffic,
+                         "mfma_view": {"achieved": achieved, "peak": PEAK[args.dtype], "unit": "TFLOP/s", "frac": achieved / PEAK[args.dtype]},
+                         "hbm_view": {"achieved": conv_bytes / (conv_ms * 1e-3) / 1e9 if conv_ms > 0 else 0.0, "peak": HBM_GBPS, "unit": "GB/s",
+                                      "frac": (conv_bytes / (conv_ms * 1e-3) / 1e9 if conv_ms > 0 else 0.0) / HBM_GBPS},
                          "traffic_source": "committed rocprofv3 PMC passes (profiles/r*_pmc_igemm_traffic.json: FETCH_SIZE x2 + WRITE_SIZE), not measured in this run",
                          "roof_frac": roof_ms / conv_ms if conv_ms > 0 else 0.0,
                          "hbm_bound_share_of_roof": roof_ms_hbm / roof_ms if roof_ms > 0 else 0.0,

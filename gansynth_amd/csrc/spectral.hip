@@ -328,13 +328,18 @@ static __global__ __launch_bounds__(256) void gemm_f32_128_kernel(const float* _
 // the passes over A, the big operand (6 bytes per element: with 128 x 128 tiles the kernel moved 6.4 GB through L2 in its 0.85 ms).
 // NP = planes used: 3 -> all six partial products (fp32 accuracy: the phase rows); 2 -> a1 b1 + a1 b2 + a2 b1 (2^-16 relative per
 // product: the magnitude rows, whose contract is 1e-3 relative) at half the MFMAs and two thirds of the operand traffic.
-template <int NJ, int NP>
-static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NJ == 4 ? 1 : 2, NJ == 4 ? 1 : (NP == 2 ? 3 : 2))))
+// KB = k blocks of 16 per staged step (2: 64-byte rows, the original; 4: 128-byte rows padded to 144 -- half the barriers per MFMA; fits two
+// blocks per CU only with two planes)
+template <int NJ, int NP, int KB = 2>
+static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NJ == 4 || (NP == 3 && KB == 4)) ? 1 : 2, (NJ == 4 || (NP == 3 && KB == 4)) ? 1 : (NP == 2 && KB == 2 ? 3 : 2))))
 void gemm_bf16x6_kernel(const unsigned short* __restrict__ Asplit, const unsigned short* __restrict__ Bsplit, float* __restrict__ C, int M, int N, int K, int m_begin) {
     constexpr int BN = 64 * NJ;            // block columns; a wave owns 64 rows x (32 NJ) columns
-    constexpr int ACH = NP * 2, BCH = NP * BN * 4 / 256;  // 16-byte chunks of A / B per thread and step
-    __shared__ __attribute__((aligned(16))) unsigned char As[NP][128][GX_ROW];
-    __shared__ __attribute__((aligned(16))) unsigned char Bs[NP][BN][GX_ROW];
+    constexpr int P = 2 * KB;              // 16-byte chunks per staged row
+    constexpr int ROW = 32 * KB + 16;      // LDS row bytes (80 / 144: conflict-free 16-byte fragment reads)
+    constexpr int KSTEP = 16 * KB;
+    constexpr int ACH = NP * 128 * P / 256, BCH = NP * BN * P / 256;  // 16-byte chunks of A / B per thread and step
+    __shared__ __attribute__((aligned(16))) unsigned char As[NP][128][ROW];
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[NP][BN][ROW];
     typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, hi = lane >> 5, l31 = lane & 31;
     const int nb = N / BN;
@@ -363,27 +368,27 @@ void gemm_bf16x6_kernel(const unsigned short* __restrict__ Asplit, const unsigne
     u4_t ra[ACH], rb[BCH];
     const unsigned short* const abase = Asplit + (long)m0 * K;   // (plane stride M x K: M counts ALL rows of A)
     const unsigned short* const bbase = Bsplit + (long)n0 * K;
-#define GX_AOFF(J) (((long)((tid + 256 * (J)) / 512) * M + (((tid + 256 * (J)) % 512) >> 2)) * K + ((tid + 256 * (J)) & 3) * 8)
-#define GX_BOFF(J) (((long)((tid + 256 * (J)) / (4 * BN)) * N + (((tid + 256 * (J)) % (4 * BN)) >> 2)) * K + ((tid + 256 * (J)) & 3) * 8)
+#define GX_AOFF(J) (((long)((tid + 256 * (J)) / (128 * P)) * M + (((tid + 256 * (J)) % (128 * P)) / P)) * K + ((tid + 256 * (J)) % P) * 8)
+#define GX_BOFF(J) (((long)((tid + 256 * (J)) / (P * BN)) * N + (((tid + 256 * (J)) % (P * BN)) / P)) * K + ((tid + 256 * (J)) % P) * 8)
 #pragma unroll
     for (int j = 0; j < ACH; ++j) ra[j] = *reinterpret_cast<const u4_t*>(abase + GX_AOFF(j));
 #pragma unroll
     for (int j = 0; j < BCH; ++j) rb[j] = *reinterpret_cast<const u4_t*>(bbase + GX_BOFF(j));
-    for (int k0 = 0; k0 < K; k0 += 32) {
+    for (int k0 = 0; k0 < K; k0 += KSTEP) {
         __syncthreads();   // the previous step's fragment reads are done
 #pragma unroll
         for (int j = 0; j < ACH; ++j) {
             const int c = tid + 256 * j;
-            *reinterpret_cast<u4_t*>(&As[c / 512][(c % 512) >> 2][(c & 3) * 16]) = ra[j];
+            *reinterpret_cast<u4_t*>(&As[c / (128 * P)][(c % (128 * P)) / P][(c % P) * 16]) = ra[j];
         }
 #pragma unroll
         for (int j = 0; j < BCH; ++j) {
             const int c = tid + 256 * j;
-            *reinterpret_cast<u4_t*>(&Bs[c / (4 * BN)][(c % (4 * BN)) >> 2][(c & 3) * 16]) = rb[j];
+            *reinterpret_cast<u4_t*>(&Bs[c / (P * BN)][(c % (P * BN)) / P][(c % P) * 16]) = rb[j];
         }
         __syncthreads();
         {   // the next step's global loads fly under this step's MFMAs (the last step re-reads its own: unconditional)
-            const int kn = k0 + 32 < K ? k0 + 32 : k0;
+            const int kn = k0 + KSTEP < K ? k0 + KSTEP : k0;
 #pragma unroll
             for (int j = 0; j < ACH; ++j) ra[j] = *reinterpret_cast<const u4_t*>(abase + GX_AOFF(j) + kn);
 #pragma unroll
@@ -395,14 +400,14 @@ void gemm_bf16x6_kernel(const unsigned short* __restrict__ Asplit, const unsigne
         bf16x8_t fr[2][NF];
         auto rd = [&](int kb, int q) __attribute__((always_inline)) {
             const int t = q < 2 * NP ? q : q - 2 * NP, i = t / NP, pl = t % NP;
-            fr[kb][q] = q < 2 * NP ? *reinterpret_cast<const bf16x8_t*>(&As[pl][wm + 32 * i + l31][kb * 32 + hi * 16])
-                              : *reinterpret_cast<const bf16x8_t*>(&Bs[pl][wn + 32 * i + l31][kb * 32 + hi * 16]);
+            fr[kb & 1][q] = q < 2 * NP ? *reinterpret_cast<const bf16x8_t*>(&As[pl][wm + 32 * i + l31][kb * 32 + hi * 16])
+                                  : *reinterpret_cast<const bf16x8_t*>(&Bs[pl][wn + 32 * i + l31][kb * 32 + hi * 16]);
         };
 #pragma unroll
         for (int q = 0; q < NF; ++q) rd(0, q);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+        for (int kb = 0; kb < KB; ++kb) {
             // (a1 + a2 + a3)(b1 + b2 + b3) down to 2^-16, small terms first; the term loop is the OUTER one so that consecutive MFMAs go to
             // different accumulators (six in a row into one accumulator wait for each other's result)
             constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
@@ -413,11 +418,11 @@ void gemm_bf16x6_kernel(const unsigned short* __restrict__ Asplit, const unsigne
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[kb][NP * i + PA[t]], fr[kb][2 * NP + NP * j + PB[t]], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[kb & 1][NP * i + PA[t]], fr[kb & 1][2 * NP + NP * j + PB[t]], acc[i][j], 0, 0, 0);
                         constexpr int NM = (6 - T0) * 2 * NJ;           // MFMAs of the block: the NF reads of the next one spread evenly among them
                         const int slot = ((t - T0) * 2 + i) * NJ + j;
-                        if (kb == 0)
-                            for (int r = slot * NF / NM; r < (slot + 1) * NF / NM; ++r) rd(1, r);
+                        if (kb + 1 < KB)
+                            for (int r = slot * NF / NM; r < (slot + 1) * NF / NM; ++r) rd(kb + 1, r);
                         __builtin_amdgcn_sched_barrier(0);
                     }
         }
@@ -697,6 +702,8 @@ extern "C" int gs_mel_if_to_waveform(const gs_spectral_plan* p, const void* imag
     unsigned short* a_split = split ? reinterpret_cast<unsigned short*>(mel_mag) : nullptr;
     static const bool full_mag = getenv("GS_INVERSE_MAG_6TERMS") != nullptr;   // measurement knob: six terms for the magnitude rows too
     const bool two = split && rows % 128 == 0 && !full_mag;   // magnitude rows [0, rows): two planes, three terms
+    // (two mel bins per thread with 4-byte plane stores and an unrolled time loop measured the same 121-124 us: 603 MB at ~5 TB/s, the chip's
+    //  mixed read / write rate -- the one-bin form stays)
     GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((inv_prep_kernel<T>), dim3(cdiv((long)batch * H, 256)), dim3(256), 0, st, *p, (const T*)images, mel_mag, mel_ph, batch, a_split, two ? 2 : 3));
     GS_CHECK_LAUNCH();
     // [mel_mag; mel_phase] @ pinv(mel) -> [mag; phase]: the two contractions of spectral_ops.py:123,125 share the matrix and are
@@ -723,11 +730,15 @@ extern "C" int gs_mel_if_to_waveform(const gs_spectral_plan* p, const void* imag
             const double half = 2.0 * (double)rows * H * H;
             {
                 ProfScope ps(st, 3.0 * half, (double)rows * H * 4 + 2.0 * H * H * 2 + (double)rows * H * 4, 30, batch, p->time_steps, H, H, H, 0, 0);
-                hipLaunchKernelGGL((gemm_bf16x6_kernel<2, 2>), dim3(blocks_mag), dim3(256), 0, st, a_split, p->pinv_split, mag, M2, H, H, 0);
+                static const int kb_mag = getenv("GS_INVERSE_GEMM_KB") ? atoi(getenv("GS_INVERSE_GEMM_KB")) : 4;
+                if (kb_mag == 4 && H % 64 == 0) hipLaunchKernelGGL((gemm_bf16x6_kernel<2, 2, 4>), dim3(blocks_mag), dim3(256), 0, st, a_split, p->pinv_split, mag, M2, H, H, 0);
+                else hipLaunchKernelGGL((gemm_bf16x6_kernel<2, 2>), dim3(blocks_mag), dim3(256), 0, st, a_split, p->pinv_split, mag, M2, H, H, 0);
             }
             {
                 ProfScope ps(st, 6.0 * half, (double)rows * H * 6 + 3.0 * H * H * 2 + (double)rows * H * 4, 31, batch, p->time_steps, H, H, H, 0, 0);
-                hipLaunchKernelGGL((gemm_bf16x6_kernel<2, 3>), dim3(blocks_mag), dim3(256), 0, st, a_split, p->pinv_split, mag, M2, H, H, (int)rows);
+                static const int kb_ph = getenv("GS_INVERSE_GEMM_KB3") ? atoi(getenv("GS_INVERSE_GEMM_KB3")) : 2;
+                if (kb_ph == 4 && H % 64 == 0) hipLaunchKernelGGL((gemm_bf16x6_kernel<2, 3, 4>), dim3(blocks_mag), dim3(256), 0, st, a_split, p->pinv_split, mag, M2, H, H, (int)rows);
+                else hipLaunchKernelGGL((gemm_bf16x6_kernel<2, 3>), dim3(blocks_mag), dim3(256), 0, st, a_split, p->pinv_split, mag, M2, H, H, (int)rows);
             }
         } else {
             ProfScope ps(st, 12.0 * (double)rows * H * H, 2.0 * rows * H * 6 + 3.0 * H * H * 2 + 2.0 * rows * H * 4, 32, batch, p->time_steps, H, H, H, 0, 0);
