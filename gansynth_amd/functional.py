@@ -872,34 +872,38 @@ def avg_pool(x, fy, fx):
 
 
 # ------------------------------------------------------------------------ batch stddev
+def _sub_kw(sub):
+    return {} if sub == 1 else {"sub": sub}   # (kernel layers without sub-batches keep their signatures)
+
+
 class _BatchStddev(Function):
     @staticmethod
-    def forward(ctx, x, eps):
-        ctx.eps = eps
+    def forward(ctx, x, eps, sub=1):
+        ctx.eps, ctx.sub = eps, sub
         ctx.save_for_backward(x)
-        return _K().batch_stddev_fwd(x, eps)
+        return _K().batch_stddev_fwd(x, eps, **_sub_kw(sub))
 
     @staticmethod
     def backward(ctx, gy):
         (x,) = ctx.saved_tensors
-        return _BatchStddevBwd.apply(gy, x, ctx.eps), None
+        return _BatchStddevBwd.apply(gy, x, ctx.eps, None, ctx.sub), None, None
 
 
 class _BatchStddevBwd(Function):
     """batch_stddev_bwd(gy, x) + addend (the other gradient into x, when the statistic was taken with a tap)."""
 
     @staticmethod
-    def forward(ctx, gy, x, eps, addend=None):
-        ctx.eps = eps
+    def forward(ctx, gy, x, eps, addend=None, sub=1):
+        ctx.eps, ctx.sub = eps, sub
         ctx.save_for_backward(gy, x)
-        return _K().batch_stddev_bwd(gy, x, eps, addend=addend)
+        return _K().batch_stddev_bwd(gy, x, eps, addend=addend, **_sub_kw(sub))
 
     @staticmethod
     @once_differentiable
     def backward(ctx, ggx):
         gy, x = ctx.saved_tensors
-        ggy, gx2 = _K().batch_stddev_bwd_bwd(ggx, gy, x, ctx.eps)
-        return ggy, gx2, None, (ggx if ctx.needs_input_grad[3] else None)
+        ggy, gx2 = _K().batch_stddev_bwd_bwd(ggx, gy, x, ctx.eps, **_sub_kw(ctx.sub))
+        return ggy, gx2, None, (ggx if ctx.needs_input_grad[3] else None), None
 
 
 def batch_stddev(x, eps):
@@ -909,25 +913,26 @@ def batch_stddev(x, eps):
 class _BatchStddevTap(Function):
     """(x, batch_stddev(x)) with x passed through: the caller hands the FIRST output to whatever else consumes x (the conv beside the
     statistic, networks.py:174-176), so that x has one consumer in the graph and the two gradients into it are summed inside the
-    statistic's backward kernel instead of by the autograd engine (one launch per backward pass through the block)."""
+    statistic's backward kernel instead of by the autograd engine (one launch per backward pass through the block).
+    `sub`: x is that many batches concatenated (the statistic within each)."""
 
     @staticmethod
-    def forward(ctx, x, eps):
-        ctx.eps = eps
+    def forward(ctx, x, eps, sub=1):
+        ctx.eps, ctx.sub = eps, sub
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(x)
-        return x.view_as(x), _K().batch_stddev_fwd(x, eps)
+        return x.view_as(x), _K().batch_stddev_fwd(x, eps, **_sub_kw(sub))
 
     @staticmethod
     def backward(ctx, gx, gs):
         (x,) = ctx.saved_tensors
         if gs is None:
-            return gx, None
-        return _BatchStddevBwd.apply(gs, x, ctx.eps, gx), None   # (gx None: the statistic's gradient alone)
+            return gx, None, None
+        return _BatchStddevBwd.apply(gs, x, ctx.eps, gx, ctx.sub), None, None   # (gx None: the statistic's gradient alone)
 
 
-def batch_stddev_tap(x, eps):
-    return _BatchStddevTap.apply(x, eps)
+def batch_stddev_tap(x, eps, sub_batches=1):
+    return _BatchStddevTap.apply(x, eps, int(sub_batches))
 
 
 # --------------------------------------------------------------------------------- lerp
@@ -1066,6 +1071,87 @@ class _GanGLoss(Function):
         if _is_unit(g):
             return (g_fake if ctx.needs_input_grad[0] else None, None, g_sumsq if want_ms else None, None, None)
         return (g_fake * g.to(g_fake.dtype) if ctx.needs_input_grad[0] else None, None, g_sumsq * g if want_ms else None, None, None)
+
+
+class _GanDLossPair(Function):
+    """_GanDLoss on ONE logits tensor holding the real batch's rows followed by the fake batch's (the discriminator tail run once over
+    both, models.GANSynth._d_losses_b): same kernel, the two gradients written into the halves of one tensor."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, penalty, penalty_weight):
+        n = logits.shape[0] // 2
+        g = torch.empty_like(logits)
+        loss, _, _, g_pen = _K().gan_d_loss(logits[:n], logits[n:], labels, penalty, penalty_weight, out=(g[:n], g[n:]))
+        ctx.has_penalty = penalty is not None
+        ctx.save_for_backward(g, g_pen if ctx.has_penalty else g)
+        return loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        g_logits, g_pen = ctx.saved_tensors
+        want_pen = ctx.has_penalty and ctx.needs_input_grad[2]
+        if _is_unit(g):
+            return g_logits if ctx.needs_input_grad[0] else None, None, g_pen if want_pen else None, None
+        return g_logits * g.to(g_logits.dtype) if ctx.needs_input_grad[0] else None, None, g_pen * g if want_pen else None, None
+
+
+def gan_d_loss_pair(logits, labels, penalty, penalty_weight=1.0):
+    return _GanDLossPair.apply(logits, labels, penalty, float(penalty_weight))
+
+
+def _cat2(a, b, like):
+    """[a; b] along the batch axis, either half absent = zeros."""
+    ref = a if a is not None else b
+    n = ref.shape[0]
+    out = torch.empty((2 * n,) + tuple(ref.shape[1:]), dtype=ref.dtype, device=ref.device,
+                      memory_format=torch.channels_last if ref.dim() == 4 else torch.contiguous_format)
+    for half, t in ((out[:n], a), (out[n:], b)):
+        if t is None:
+            half.zero_()
+        else:
+            half.copy_(t)
+    return out
+
+
+class _CatBatch(Function):
+    """Two activation batches as one (axis 0); the gradient comes back as the two contiguous halves.  Differentiable twice (the R1 penalty
+    differentiates the first-order pass through the junction): the backward of the split is this concatenation again, an absent half
+    being zeros."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.set_materialize_grads(False)
+        return _cat2(a, b, a)
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None:
+            return None, None
+        if torch.is_grad_enabled():
+            ga, gb = _SplitBatch.apply(g)
+        else:
+            n = g.shape[0] // 2
+            ga, gb = g[:n], g[n:]
+        return (ga if ctx.needs_input_grad[0] else None), (gb if ctx.needs_input_grad[1] else None)
+
+
+class _SplitBatch(Function):
+    @staticmethod
+    def forward(ctx, g):
+        ctx.set_materialize_grads(False)
+        n = g.shape[0] // 2
+        return g[:n], g[n:]
+
+    @staticmethod
+    def backward(ctx, gga, ggb):
+        if gga is None and ggb is None:
+            return None
+        return _cat2(gga, ggb, None)
+
+
+def cat_batch(a, b):
+    return _CatBatch.apply(a, b)
 
 
 def gan_d_loss(real_logits, fake_logits, labels, penalty, penalty_weight=1.0):

@@ -729,36 +729,44 @@ class HipKernels(object):
         return y
 
     # ------------------------------------------------------------------------ batch stddev
-    def batch_stddev_fwd(self, x, eps):
+    # (`sub`: x is `sub` batches concatenated along axis 0 -- the statistic of ops.py:336-348 within each: one call per sub-batch on its slab)
+    def batch_stddev_fwd(self, x, eps, sub=1):
         x = _act(x)
         n, c, h, w = x.shape
         y = _empty_like_act((n, 1, h, w), x)
-        _lib.check(self.lib.gs_batch_stddev_fwd(x.data_ptr(), y.data_ptr(), n, h * w, c, float(eps), _dt(x), _stream()), "gs_batch_stddev_fwd")
+        m, es = n // sub, x.element_size()
+        for s in range(sub):
+            _lib.check(self.lib.gs_batch_stddev_fwd(x.data_ptr() + s * m * c * h * w * es, y.data_ptr() + s * m * h * w * es, m, h * w, c, float(eps), _dt(x),
+                                                    _stream()), "gs_batch_stddev_fwd")
         return y
 
-    def batch_stddev_bwd(self, gy, x, eps, addend=None):
+    def batch_stddev_bwd(self, gy, x, eps, addend=None, sub=1):
         """d batch_stddev(x) / d x applied to gy, plus `addend` (another gradient into x) in the same pass."""
         x = _act(x)
         n, c, h, w = x.shape
         gy = _act(gy.to(x.dtype))
         gx = torch.empty_like(x)
-        ap = None
         if addend is not None:
             addend = _match(addend, x)
-            ap = addend.data_ptr()
-        _lib.check(self.lib.gs_batch_stddev_bwd(gy.data_ptr(), x.data_ptr(), ap, gx.data_ptr(), n, h * w, c, float(eps), _dt(x), _stream()),
-                   "gs_batch_stddev_bwd")
+        m, es = n // sub, x.element_size()
+        for s in range(sub):
+            ox, oy = s * m * c * h * w * es, s * m * h * w * es
+            _lib.check(self.lib.gs_batch_stddev_bwd(gy.data_ptr() + oy, x.data_ptr() + ox, None if addend is None else addend.data_ptr() + ox, gx.data_ptr() + ox,
+                                                    m, h * w, c, float(eps), _dt(x), _stream()), "gs_batch_stddev_bwd")
         return gx
 
-    def batch_stddev_bwd_bwd(self, ggx, gy, x, eps):
+    def batch_stddev_bwd_bwd(self, ggx, gy, x, eps, sub=1):
         x = _act(x)
         n, c, h, w = x.shape
         ggx = _match(ggx, x)
         gy = _act(gy.to(x.dtype))
         ggy = torch.empty_like(gy)
         gx2 = torch.empty_like(x)
-        _lib.check(self.lib.gs_batch_stddev_bwd_bwd(ggx.data_ptr(), gy.data_ptr(), x.data_ptr(), ggy.data_ptr(), gx2.data_ptr(),
-                                                    n, h * w, c, float(eps), _dt(x), _stream()), "gs_batch_stddev_bwd_bwd")
+        m, es = n // sub, x.element_size()
+        for s in range(sub):
+            ox, oy = s * m * c * h * w * es, s * m * h * w * es
+            _lib.check(self.lib.gs_batch_stddev_bwd_bwd(ggx.data_ptr() + ox, gy.data_ptr() + oy, x.data_ptr() + ox, ggy.data_ptr() + oy, gx2.data_ptr() + ox,
+                                                        m, h * w, c, float(eps), _dt(x), _stream()), "gs_batch_stddev_bwd_bwd")
         return ggy, gx2
 
     # ------------------------------------------------------------------- misc elementwise
@@ -792,13 +800,13 @@ class HipKernels(object):
         _lib.check(self.lib.gs_row_scale(x.data_ptr(), s.data_ptr(), float(alpha), out.data_ptr(), rows, x.numel() // rows, _dt(x), _stream()), "gs_row_scale")
         return out
 
-    def gan_d_loss(self, real_logits, fake_logits, labels, penalty, penalty_weight=1.0):
+    def gan_d_loss(self, real_logits, fake_logits, labels, penalty, penalty_weight=1.0, out=None):
         """(loss, g_real_logits, g_fake_logits, g_penalty): mean of softplus(-r) + softplus(f) + penalty_weight * penalty and its gradients, one launch."""
         real_logits, fake_logits = _act(real_logits), _act(fake_logits)
         labels = _match(labels, real_logits)
         n, c = real_logits.shape
         loss = torch.empty((), dtype=torch.float32, device=real_logits.device)
-        g_real, g_fake = torch.empty_like(real_logits), torch.empty_like(fake_logits)
+        g_real, g_fake = (torch.empty_like(real_logits), torch.empty_like(fake_logits)) if out is None else out
         pp = g_pen = None
         if penalty is not None:
             penalty = _f32c(penalty)

@@ -29,6 +29,7 @@ _PAD = 64  # floats; keeps every parameter view 256-byte aligned inside the flat
 
 _DEFER_REDUCTIONS = not __import__("os").environ.get("GS_NO_DEFERRED_REDUCE")   # A/B switches for measurements
 _FUSED_LOSSES = not __import__("os").environ.get("GS_NO_FUSED_LOSSES")
+_BATCH_D_TAIL = not __import__("os").environ.get("GS_NO_D_TAIL_BATCH")   # A/B switch: real + fake through the discriminator's tail as one batch
 _PIPELINE = bool(__import__("os").environ.get("GS_PIPELINE"))   # opt-in, see GANSynth.pipeline
 _PIPE_SIDE = {"0": False, "1": True}.get(__import__("os").environ.get("GS_PIPE_SIDE", ""))
 _GRAPH_ALLREDUCE = not __import__("os").environ.get("GS_NO_GRAPH_ALLREDUCE")   # A/B switch: the gradient all-reduce as a node of the captured graph
@@ -245,9 +246,22 @@ class GANSynth(object):
         # models.py:50-54 -- weight 0 in the shipped configuration -- the per-sample algebra runs instead)
         return _FUSED_LOSSES and hasattr(kernels.get(), "gan_d_loss") and not self.hyper_params.get("fake_gradient_penalty_weight", 0.0)
 
+    def _batched_tail(self, fused, images):
+        """The discriminator run sends the real and the fake batch through the latency-bound tail of the network (8x64 and below: a few
+        tens of blocks per launch on 256 CUs) as ONE batch of 2n -- half the launches there, forward and backward; the R1 pass seeds the
+        real rows only.  Needs the network in two pieces (networks.PGGAN.discriminator_trunk / _tail), the one-launch loss, and no
+        activation tap (the parity tests match recorded activations call by call with the oracle's two separate passes)."""
+        owner = getattr(self.discriminator, "__self__", None)
+        return (_BATCH_D_TAIL and fused and images.is_cuda and F.activation_tap.active is None and hasattr(owner, "discriminator_trunk")
+                and getattr(self.discriminator, "__func__", None) is getattr(type(owner), "discriminator", None)
+                and hasattr(kernels.get(), "lib"))
+
     def _d_losses_a(self, labels, real_images, fused=False):
         hp = self.hyper_params
         real_images = real_images.detach().requires_grad_(True)
+        if self._batched_tail(fused, real_images):   # part A is the real batch's trunk; everything else needs the fake batch beside it
+            owner = self.discriminator.__self__
+            return ("trunk", real_images) + tuple(owner.discriminator_trunk(real_images, labels.shape[1]))
         _, raw = self.discriminator(real_images, labels)
         real_logits = None if fused else self._label_logits(raw, labels)
         penalty = None
@@ -263,8 +277,10 @@ class GANSynth(object):
         return (raw, penalty) if fused else (TF.softplus(-real_logits), penalty)
 
     def _d_losses_b(self, part_a, latents, labels, fused=False):
-        real_part, penalty = part_a
         hp = self.hyper_params
+        if isinstance(part_a[0], str):   # ("trunk", ...): the batched-tail form of part A
+            return self._d_losses_b_batched(part_a, latents, labels)
+        real_part, penalty = part_a
         fake_weight = hp.get("fake_gradient_penalty_weight", 0.0)
         with torch.no_grad():  # var_list is the discriminator's only: no generator backward (models.py:86-89)
             fake_images = self.generator(latents, labels)
@@ -282,6 +298,28 @@ class GANSynth(object):
                 (fake_gradients,) = torch.autograd.grad(fake_logits.sum(), fake_images, create_graph=True)
             losses = losses + F.sumsq_rows(fake_gradients) * fake_weight
         return losses
+
+    def _d_losses_b_batched(self, part_a, latents, labels):
+        """models.py:39-54,65 with the two discriminator passes sharing their tail: logits of [real; fake] from one pass, the R1 term
+        (models.py:46-49) as the gradient of the real rows' label logits -- the cotangent of the fake rows is zero --, the loss and both
+        logit gradients from the one-launch kernel."""
+        hp = self.hyper_params
+        _, real_images, x_real, depth, fresh = part_a
+        owner = self.discriminator.__self__
+        with torch.no_grad():  # var_list is the discriminator's only: no generator backward (models.py:86-89)
+            fake_images = self.generator(latents, labels)
+        x_fake, depth_f, fresh_f = owner.discriminator_trunk(fake_images, labels.shape[1])
+        assert depth_f == depth and fresh_f == fresh
+        _, raw = owner.discriminator_tail(F.cat_batch(x_real, x_fake), depth, fresh, labels, sub_batches=2)
+        penalty = None
+        if hp.real_gradient_penalty_weight:
+            n = labels.shape[0]
+            seed = torch.zeros_like(raw)
+            seed[:n].copy_(labels)   # d sum_i real_logit_i / d logits: the one-hot labels on the real rows
+            with F.data_grads_only():   # tf.gradients(real_logits, [real_images]) (models.py:47): no parameter gradients on this pass
+                (real_gradients,) = torch.autograd.grad(raw, real_images, grad_outputs=seed, create_graph=True)
+            penalty = F.sumsq_rows(real_gradients)
+        return F.gan_d_loss_pair(raw, labels, penalty, hp.real_gradient_penalty_weight or 1.0)
 
     def discriminator_losses(self, latents, labels, real_images):
         return self._d_losses_b(self._d_losses_a(labels, real_images), latents, labels)

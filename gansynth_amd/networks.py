@@ -146,7 +146,7 @@ class PGGAN(object):
             return ops.lerp(low, middle, fade if self.fade_weight is None else self.fade_weight)
 
     # ============================================================== discriminator
-    def _d_conv_block(self, x, depth, num_labels, fresh_activation=False):
+    def _d_conv_block(self, x, depth, num_labels, fresh_activation=False, sub_batches=1):
         """`fresh_activation`: x is the leaky-relu output of the previous conv and feeds nothing but this block's first conv
         (true along the trunk, false after the fade-in lerp) -- lets the backward fold the activation derivative into the
         data-gradient kernel (ops.conv2d `input_activation`)."""
@@ -156,7 +156,7 @@ class PGGAN(object):
                 # networks.py:174-184: conv(concat([x, batch_stddev(x)])).  The 257-channel conv is
                 # evaluated as conv(x; w[:,:,:c]) + conv(stddev; w[:,:,c:]) -- same variable, same
                 # fan-in scale, no 257-wide tensor (257 is not an MFMA-friendly K).
-                x, stddev = ops.batch_stddev_tap(x)   # (x through the tap: one consumer, the two gradients summed in one kernel)
+                x, stddev = ops.batch_stddev_tap(x, sub_batches=sub_batches)   # (x through the tap: one consumer, the two gradients summed in one kernel)
                 with variable_scope("conv"):
                     weight, alpha = ops.get_weight([3, 3, c + 1, c], 2.0, True)
                     bias = ops.get_bias([c])
@@ -210,8 +210,19 @@ class PGGAN(object):
                         ops.get_weight([3, 3, c, self.channels(depth - 1)], 2.0, True)
                         ops.get_bias([self.channels(depth - 1)])
 
-    def discriminator(self, images, labels, name="discriminator", reuse=AUTO_REUSE):
-        num_labels = labels.shape[1]
+    # The discriminator in two pieces (same variables, same launches as `discriminator`):
+    #   trunk: colour block(s), the head block, the fade-in junction and the blocks down to `tail_top`
+    #   tail:  the blocks from `tail_top` (at most 8x64) down to the 2x16 block with its statistic, dense and logits
+    # Every launch of the tail is latency-bound at batch 8 (a few tens of blocks on 256 CUs), so the trainer runs the tails of the real and
+    # of the fake pass of a discriminator run as ONE pass over the concatenated batch (models.GANSynth._d_losses_b): `sub_batches` keeps
+    # the minibatch statistic per original batch (ops.py:336-348 on each half).
+    TAIL_LEVELS = int(__import__("os").environ.get("GS_D_TAIL_LEVELS", "3"))   # (measured: see DESIGN.md 6.3)
+
+    def _tail_top(self, head):
+        return max(self.min_depth, min(head - 1, self.min_depth + self.TAIL_LEVELS - 1))
+
+    def discriminator_trunk(self, images, num_labels, name="discriminator", reuse=AUTO_REUSE):
+        """-> (x, depth, fresh): the input of block `depth` (the first block of the tail)."""
         F.tap_begin("discriminator")
         with variable_scope(name, reuse=reuse):
             self._d_variables(num_labels)
@@ -222,13 +233,29 @@ class PGGAN(object):
                 return self._d_color_block(ops.downscale2d(images, full // self.resolution(depth)), depth)
 
             if head == self.min_depth:
-                return self._d_conv_block(from_images(head), head, num_labels)
+                return from_images(head), head, False
             low = from_images(head - 1) if fade is not None else None   # lerp(low(), middle(), .): low first, like networks.py:271-275
             x = self._d_conv_block(from_images(head), head, num_labels, fresh_activation=True)
             fresh = fade is None
             if fade is not None:
                 x = ops.lerp(low, x, fade if self.fade_weight is None else self.fade_weight)
-            for depth in range(head - 1, self.min_depth, -1):
+            top = self._tail_top(head)
+            for depth in range(head - 1, top, -1):
                 x = self._d_conv_block(x, depth, num_labels, fresh_activation=fresh)
                 fresh = True
-            return self._d_conv_block(x, self.min_depth, num_labels)   # (x also feeds batch_stddev there: never fused)
+            return x, top, fresh
+
+    def discriminator_tail(self, x, depth, fresh, labels, sub_batches=1, name="discriminator", reuse=AUTO_REUSE):
+        num_labels = labels.shape[1]
+        with variable_scope(name, reuse=reuse):
+            self._d_variables(num_labels)
+            head, _ = self._head_depth(self.growing_depth)
+            for d in range(depth, self.min_depth, -1):
+                x = self._d_conv_block(x, d, num_labels, fresh_activation=fresh)
+                fresh = True
+            # (x also feeds batch_stddev in the last block: never fused)
+            return self._d_conv_block(x, self.min_depth, num_labels, fresh_activation=False, sub_batches=sub_batches)
+
+    def discriminator(self, images, labels, name="discriminator", reuse=AUTO_REUSE):
+        x, depth, fresh = self.discriminator_trunk(images, labels.shape[1], name=name, reuse=reuse)
+        return self.discriminator_tail(x, depth, fresh, labels, name=name, reuse=reuse)

@@ -123,16 +123,17 @@ def batch_stddev(inputs, groups=4, epsilon=1.0e-12):
     return F.batch_stddev(inputs, epsilon)
 
 
-def batch_stddev_tap(inputs, groups=4, epsilon=1.0e-12):
+def batch_stddev_tap(inputs, groups=4, epsilon=1.0e-12, sub_batches=1):
     """(inputs, batch_stddev(inputs)): ops.py:336-348 for a caller that also feeds `inputs` to another op -- it uses the returned
-    alias there, and the backward sums the two gradients into `inputs` in the statistic's own kernel (functional._BatchStddevTap)."""
+    alias there, and the backward sums the two gradients into `inputs` in the statistic's own kernel (functional._BatchStddevTap).
+    `sub_batches`: `inputs` is that many batches concatenated along axis 0; the statistic is taken within each of them."""
     if groups != 4:
         raise ValueError("batch_stddev: the reference graph uses groups=4 (networks.py:174)")
-    if inputs.shape[0] % groups:
-        raise ValueError(f"batch_stddev: batch {inputs.shape[0]} is not a multiple of groups={groups} (ops.py:341)")
-    if not hasattr(F, "batch_stddev_tap"):
+    if inputs.shape[0] % (groups * sub_batches):
+        raise ValueError(f"batch_stddev: batch {inputs.shape[0]} / {sub_batches} is not a multiple of groups={groups} (ops.py:341)")
+    if sub_batches == 1 and not hasattr(F, "batch_stddev_tap"):
         return inputs, F.batch_stddev(inputs, epsilon)
-    return F.batch_stddev_tap(inputs, epsilon)
+    return F.batch_stddev_tap(inputs, epsilon, sub_batches)
 
 
 def leaky_relu(inputs):

@@ -26,6 +26,9 @@ class Log(TorchDispatchMode):
             if any(isinstance(a, torch.Tensor) and a.is_cuda for a in args) or "fill" in name or "zeros" in name:
                 st = [f for f in traceback.extract_stack() if "gansynth_amd" in f.filename]
                 where = " <- ".join("%s:%d" % (os.path.basename(f.filename), f.lineno) for f in st[-3:]) if st else "(engine)"
+                if not st:
+                    node = torch._C._current_autograd_node() if hasattr(torch._C, "_current_autograd_node") else None
+                    where = "(engine)" if node is None else "(engine) in " + node.name()
                 self.agg[(name, str(shapes)[:70], where)] += 1
                 self.seq.append((name, str(shapes)[:70], where))
         else:
@@ -54,10 +57,11 @@ for (name, shapes, where), n in sorted(log.agg.items(), key=lambda kv: (kv[0][2]
 print("total", sum(log.agg.values()))
 # what runs right behind each op issued by the autograd engine itself (gradient accumulation of a tensor with several consumers)?
 for i, ent in enumerate(log.seq):
-    if ent[2] == "(engine)" and ("add" in ent[0] or "clone" in ent[0]):
+    if ent[2].startswith("(engine)") and not ent[0].startswith("  .."):
         print("ENGINE", ent[0], ent[1])
-        for e in log.seq[max(0, i - 2):i]:
+        print("   ", ent[2])
+        for e in log.seq[max(0, i - 5):i]:
             print("      before:", e)
-        for e in log.seq[i + 1:i + 4]:
+        for e in log.seq[i + 1:i + 6]:
             print("      after: ", e)
 

@@ -481,6 +481,42 @@ def test_second_order_norm_kernels_ride_in_the_cotangent_convs_at_full_size(gpu_
             assert rel_l2(out[True][1][k], g) < 2e-2, (k, rel_l2(out[True][1][k], g))
 
 
+@pytest.mark.parametrize("full,dtype", [(False, torch.float32), (True, torch.bfloat16)])
+def test_discriminator_tail_over_real_and_fake_as_one_batch(gpu_store, full, dtype):
+    """The discriminator run sends [real; fake] through the network's latency-bound tail as ONE batch (models.GANSynth._d_losses_b_batched:
+    trunk per batch, networks.PGGAN.discriminator_tail with the minibatch statistic per half, the R1 seed on the real rows, the one-launch
+    loss on the stacked logits).  Same loss and the same gradient for every discriminator parameter as with the two separate passes
+    (models._BATCH_D_TAIL off) -- fp32 on the reduced network to accumulation-order accuracy, bf16 at full size to bf16 rounding of the
+    few tensors whose summation order changes (the weight gradients of the tail now sum 16 images in one source instead of 8 + 8)."""
+    from gansynth_amd import models, variables
+    out = {}
+    for batched in (True, False):
+        variables.set_default_store(variables.VariableStore(device="cuda", seed=0))
+        pg, opg, model = make(1.0, variables.default_store(), full=full, dtype=dtype)
+        shape = (2, 128, 1024) if full else (2, 16, 128)
+        lat, lab, real = R.synthetic_batch(8, rank=0, image_shape=shape)
+        c = lambda t: cuda(t).to(dtype)
+        model._build(c(lat), c(lab))
+        was = models._BATCH_D_TAIL
+        models._BATCH_D_TAIL = batched
+        try:
+            assert model._batched_tail(True, c(real)) == batched
+            loss = float(model.discriminator_step(c(lat), c(lab), c(real)))
+        finally:
+            models._BATCH_D_TAIL = was
+        out[batched] = (loss, {k: p.grad.clone() for k, p in model.d_params.named.items()})
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    assert abs(out[True][0] - out[False][0]) <= (1e-6 if dtype == torch.float32 else 2e-3) * max(1.0, abs(out[False][0])), (out[True][0], out[False][0])
+    compared = 0
+    for k, g in out[False][1].items():
+        if float(g.abs().max()) > 0:   # (the colour blocks of the levels below the head take no part in a fully grown pass)
+            compared += 1
+            assert rel_l2(out[True][1][k], g) < tol, (k, rel_l2(out[True][1][k], g))
+        else:
+            assert float(out[True][1][k].abs().max()) == 0, k
+    assert compared >= 14
+
+
 def test_pipelined_train_step_equals_sequential(gpu_store):
     """train_step with graphs runs every run as two graphs and moves the optimizer updates to a side stream (they overlap the
     other network's own part): same losses and parameters as the sequential eager iteration, step after step (up to the order
