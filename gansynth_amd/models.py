@@ -314,7 +314,7 @@ class GANSynth(object):
         penalty = None
         if hp.real_gradient_penalty_weight:
             n = labels.shape[0]
-            seed = torch.zeros_like(raw)
+            seed = self._zero_padded_rows(raw)   # (rows n..2n stay zero for the life of the buffer)
             seed[:n].copy_(labels)   # d sum_i real_logit_i / d logits: the one-hot labels on the real rows
             with F.data_grads_only():   # tf.gradients(real_logits, [real_images]) (models.py:47): no parameter gradients on this pass
                 (real_gradients,) = torch.autograd.grad(raw, real_images, grad_outputs=seed, create_graph=True)
@@ -481,6 +481,17 @@ class GANSynth(object):
             if not self._capturing():
                 cache[key] = ones
         return ones
+
+    def _zero_padded_rows(self, t):
+        """A tensor of t's shape whose rows the caller overwrites only in the upper half; zeroed once (same rule as _ones_like)."""
+        cache = self.__dict__.setdefault("_zero_cache", {})
+        key = (tuple(t.shape), t.dtype, str(t.device))
+        z = cache.get(key)
+        if z is None:
+            z = torch.zeros_like(t)
+            if not self._capturing():
+                cache[key] = z
+        return z
 
     def _capturing_fresh_seed(self, device):
         """True when the constant seed of this device would have to be CREATED inside a stream capture (its memory would belong
