@@ -33,6 +33,7 @@ class activation_tap(object):
 
     def __init__(self):
         self.calls = []
+        self.pair = None   # (call index of the real pass, of the fake pass) while one launch serves both (tap_pair)
 
     def __enter__(self):
         activation_tap.active = self
@@ -52,9 +53,38 @@ def tap_begin(name):
         activation_tap.active.calls.append((name, []))
 
 
+def tap_index():
+    """Index of the network call being recorded (None outside a tap)."""
+    return None if activation_tap.active is None else len(activation_tap.active.calls) - 1
+
+
+class tap_pair(object):
+    """While active, a recorded activation holds two batches (axis 0): its halves go to the calls `a` and `b` -- the discriminator's tail
+    run once over [real; fake] (models.GANSynth._d_losses_b_batched) still reads as the reference's two passes."""
+
+    def __init__(self, a, b):
+        self.pair = None if a is None or b is None else (a, b)
+
+    def __enter__(self):
+        if activation_tap.active is not None:
+            activation_tap.active.pair = self.pair
+        return self
+
+    def __exit__(self, *exc):
+        if activation_tap.active is not None:
+            activation_tap.active.pair = None
+        return False
+
+
 def _tap(z, act):
-    if activation_tap.active is not None and act == ACT_LRELU:
-        activation_tap.active.calls[-1][1].append(z.detach())
+    tap = activation_tap.active
+    if tap is not None and act == ACT_LRELU:
+        if tap.pair is not None:
+            n = z.shape[0] // 2
+            tap.calls[tap.pair[0]][1].append(z[:n].detach())
+            tap.calls[tap.pair[1]][1].append(z[n:].detach())
+        else:
+            tap.calls[-1][1].append(z.detach())
 
 
 # ------------------------------------------------------------------ bilinear map families

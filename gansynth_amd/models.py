@@ -249,10 +249,10 @@ class GANSynth(object):
     def _batched_tail(self, fused, images):
         """The discriminator run sends the real and the fake batch through the latency-bound tail of the network (8x64 and below: a few
         tens of blocks per launch on 256 CUs) as ONE batch of 2n -- half the launches there, forward and backward; the R1 pass seeds the
-        real rows only.  Needs the network in two pieces (networks.PGGAN.discriminator_trunk / _tail), the one-launch loss, and no
-        activation tap (the parity tests match recorded activations call by call with the oracle's two separate passes)."""
+        real rows only.  Needs the network in two pieces (networks.PGGAN.discriminator_trunk / _tail) and the one-launch loss.  (An
+        activation tap still sees two passes: functional.tap_pair.)"""
         owner = getattr(self.discriminator, "__self__", None)
-        return (_BATCH_D_TAIL and fused and images.is_cuda and F.activation_tap.active is None and hasattr(owner, "discriminator_trunk")
+        return (_BATCH_D_TAIL and fused and images.is_cuda and hasattr(owner, "discriminator_trunk")
                 and getattr(self.discriminator, "__func__", None) is getattr(type(owner), "discriminator", None)
                 and hasattr(kernels.get(), "lib"))
 
@@ -261,7 +261,7 @@ class GANSynth(object):
         real_images = real_images.detach().requires_grad_(True)
         if self._batched_tail(fused, real_images):   # part A is the real batch's trunk; everything else needs the fake batch beside it
             owner = self.discriminator.__self__
-            return ("trunk", real_images) + tuple(owner.discriminator_trunk(real_images, labels.shape[1]))
+            return ("trunk", real_images) + tuple(owner.discriminator_trunk(real_images, labels.shape[1])) + (F.tap_index(),)
         _, raw = self.discriminator(real_images, labels)
         real_logits = None if fused else self._label_logits(raw, labels)
         penalty = None
@@ -304,13 +304,14 @@ class GANSynth(object):
         (models.py:46-49) as the gradient of the real rows' label logits -- the cotangent of the fake rows is zero --, the loss and both
         logit gradients from the one-launch kernel."""
         hp = self.hyper_params
-        _, real_images, x_real, depth, fresh = part_a
+        _, real_images, x_real, depth, fresh, real_call = part_a
         owner = self.discriminator.__self__
         with torch.no_grad():  # var_list is the discriminator's only: no generator backward (models.py:86-89)
             fake_images = self.generator(latents, labels)
         x_fake, depth_f, fresh_f = owner.discriminator_trunk(fake_images, labels.shape[1])
         assert depth_f == depth and fresh_f == fresh
-        _, raw = owner.discriminator_tail(F.cat_batch(x_real, x_fake), depth, fresh, labels, sub_batches=2)
+        with F.tap_pair(real_call, F.tap_index()):
+            _, raw = owner.discriminator_tail(F.cat_batch(x_real, x_fake), depth, fresh, labels, sub_batches=2)
         penalty = None
         if hp.real_gradient_penalty_weight:
             n = labels.shape[0]
