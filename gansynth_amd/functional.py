@@ -1130,7 +1130,7 @@ def gan_d_loss_pair(logits, labels, penalty, penalty_weight=1.0):
     return _GanDLossPair.apply(logits, labels, penalty, float(penalty_weight))
 
 
-def _cat2(a, b, like):
+def _cat2(a, b):
     """[a; b] along the batch axis, either half absent = zeros."""
     ref = a if a is not None else b
     n = ref.shape[0]
@@ -1147,23 +1147,30 @@ def _cat2(a, b, like):
 class _CatBatch(Function):
     """Two activation batches as one (axis 0); the gradient comes back as the two contiguous halves.  Differentiable twice (the R1 penalty
     differentiates the first-order pass through the junction): the backward of the split is this concatenation again, an absent half
-    being zeros."""
+    being zeros.  Transparent to the premasked-gradient hand-off (see _premask_producer): when both halves are outputs of conv blocks with
+    the same fused activation, the junction presents that activation to its consumer and passes the consumer's mark on to both producers
+    -- the halves of an already masked gradient are already masked."""
 
     @staticmethod
-    def forward(ctx, a, b):
+    def forward(ctx, a, b, act, prods):
         ctx.set_materialize_grads(False)
-        return _cat2(a, b, a)
+        ctx._gs_act_out, ctx._prods, ctx._gs_premasked = act, prods, None
+        return _cat2(a, b)
 
     @staticmethod
     def backward(ctx, g):
         if g is None:
-            return None, None
+            return None, None, None, None
+        masked = _take_premasked(ctx, g)
         if torch.is_grad_enabled():
             ga, gb = _SplitBatch.apply(g)
         else:
             n = g.shape[0] // 2
             ga, gb = g[:n], g[n:]
-        return (ga if ctx.needs_input_grad[0] else None), (gb if ctx.needs_input_grad[1] else None)
+        if ctx._gs_act_out != ACT_NONE:   # (always rewritten: a mark left over from a pass that did not reach a producer must not survive)
+            for prod, half in zip(ctx._prods, (ga, gb)):
+                prod._gs_premasked = half.data_ptr() if masked else None
+        return (ga if ctx.needs_input_grad[0] else None), (gb if ctx.needs_input_grad[1] else None), None, None
 
 
 class _SplitBatch(Function):
@@ -1177,11 +1184,15 @@ class _SplitBatch(Function):
     def backward(ctx, gga, ggb):
         if gga is None and ggb is None:
             return None
-        return _cat2(gga, ggb, None)
+        return _cat2(gga, ggb)
 
 
 def cat_batch(a, b):
-    return _CatBatch.apply(a, b)
+    pa, pb = a.grad_fn, b.grad_fn
+    act = getattr(pa, "_gs_act_out", ACT_NONE)
+    if pa is None or pb is None or getattr(pb, "_gs_act_out", ACT_NONE) != act:
+        act = ACT_NONE
+    return _CatBatch.apply(a, b, act, (pa, pb))
 
 
 def gan_d_loss(real_logits, fake_logits, labels, penalty, penalty_weight=1.0):
