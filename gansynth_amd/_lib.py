@@ -55,6 +55,8 @@ SIGNATURES = {
     "gs_conv2d_transpose_s2_bwd_data": (I, [P, P, P, I, I, I, I, I, F, I, I, P, Z, P]),
     "gs_conv2d_bwd_data_pnbwd_is_fused": (I, [I, I, I, I, I, I, I, I, I]),
     "gs_conv2d_fwd_pnbwdbwd_is_fused": (I, [I, I, I, I, I, I, I, I, I]),
+    "gs_units_bias_act_to_nhwc": (I, [P, P, P, P, I, I, I, I, I, P]),
+    "gs_nhwc_act_bwd_to_units": (I, [P, P, P, I, I, I, I, I, P]),
     "gs_conv2d_fwd_pnbwdbwd": (I, [P, P, P, P, I, F, P, P, I, I, I, I, I, I, I, F, I, I, P, Z, P]),
     "gs_conv2d_transpose_s2_fwd_pnbwdbwd": (I, [P, P, P, P, I, F, P, P, I, I, I, I, I, F, I, I, P, Z, P]),
     "gs_conv2d_bwd_data_pnbwd": (I, [P, P, P, P, I, F, P, I, I, I, I, I, I, I, F, I, I, P, Z, P]),

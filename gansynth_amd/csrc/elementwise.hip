@@ -731,6 +731,59 @@ extern "C" int gs_act_bwd(const void* g, const void* y, void* gx, int64_t numel,
     return 0;
 }
 
+// The generator's first block (networks.py:41-56): dense -> reshape to [n, c, h, w] -> leaky_relu -> pixel_normalization.  The dense layer's
+// units are channel-major (unit u = ch * hw + p) while every activation of this library is channels-last ([n][p][ch]): the change of order
+// rides in the bias / activation pass instead of a copy of its own.
+//   units_to_nhwc:  z[n][p][ch] = act(y[n][u] + bias[u])            (mask == NULL: the forward)
+//                   z[n][p][ch] = y[n][u] * act'(mask[n][p][ch])    (mask given:  the backward of nhwc_to_units, second-order pass)
+//   nhwc_to_units:  gu[n][u] = g[n][p][ch] * act'(z[n][p][ch])      (the backward of the forward, in the units' order for the dense kernels)
+template <typename T>
+__global__ void units_to_nhwc_kernel(const T* __restrict__ y, const float* __restrict__ bias, const T* __restrict__ mask, T* __restrict__ z, long total, int c, int hw, int act) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;   // channels-last index: coalesced stores
+    if (i >= total) return;
+    const int ch = (int)(i % c);
+    const long r = i / c;
+    const int p = (int)(r % hw);
+    const long n = r / hw;
+    const long u = (long)ch * hw + p;
+    float v = DT<T>::ld(y + n * c * hw + u) + (bias ? bias[u] : 0.f);
+    if (mask) {
+        const float m = DT<T>::ld(mask + i);
+        v *= act == GS_ACT_LRELU ? (m > 0.f ? 1.f : 0.2f) : (act == GS_ACT_TANH ? 1.f - m * m : 1.f);
+    } else {
+        v = act == GS_ACT_LRELU ? fmaxf(v, 0.2f * v) : (act == GS_ACT_TANH ? tanhf(v) : v);
+    }
+    DT<T>::st(z + i, v);
+}
+template <typename T>
+__global__ void nhwc_to_units_kernel(const T* __restrict__ g, const T* __restrict__ zm, T* __restrict__ gu, long total, int c, int hw, int act) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;   // units index: coalesced stores
+    if (i >= total) return;
+    const long n = i / ((long)c * hw);
+    const int u = (int)(i - n * c * hw);
+    const int ch = u / hw, p = u - ch * hw;
+    const long src = (n * hw + p) * c + ch;
+    const float m = DT<T>::ld(zm + src);
+    const float f = act == GS_ACT_LRELU ? (m > 0.f ? 1.f : 0.2f) : (act == GS_ACT_TANH ? 1.f - m * m : 1.f);
+    DT<T>::st(gu + i, DT<T>::ld(g + src) * f);
+}
+extern "C" int gs_units_bias_act_to_nhwc(const void* y, const float* bias, const void* mask, void* z, int n, int c, int hw, int act, int dtype, void* stream) {
+    GS_CHECK_ARG(n > 0 && c > 0 && hw > 0 && y && z && act >= 0 && act <= 2, "units_bias_act_to_nhwc: bad args");
+    const long total = (long)n * c * hw;
+    GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((units_to_nhwc_kernel<T>), dim3((unsigned)cdiv(total, 256)), dim3(256), 0, as_stream(stream), (const T*)y, bias,
+                                                (const T*)mask, (T*)z, total, c, hw, act));
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int gs_nhwc_act_bwd_to_units(const void* g, const void* z, void* gu, int n, int c, int hw, int act, int dtype, void* stream) {
+    GS_CHECK_ARG(n > 0 && c > 0 && hw > 0 && g && z && gu && act >= 0 && act <= 2, "nhwc_act_bwd_to_units: bad args");
+    const long total = (long)n * c * hw;
+    GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((nhwc_to_units_kernel<T>), dim3((unsigned)cdiv(total, 256)), dim3(256), 0, as_stream(stream), (const T*)g, (const T*)z,
+                                                (T*)gu, total, c, hw, act));
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int gs_tanh_bwd_bwd(const void* gg, const void* g, const void* y, void* out, int64_t numel, int dtype, void* stream) {
     GS_CHECK_ARG(numel > 0, "tanh_bwd_bwd: bad args");
     GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((tanh_bwd_bwd_kernel<T>), dim3(ew_grid(numel)), dim3(256), 0, as_stream(stream),

@@ -828,6 +828,54 @@ class _ActBwd(Function):
         return g_g, g_z, None
 
 
+class _UnitsBiasActNHWC(Function):
+    """z = act(y + bias) with y the dense layer's units [n, c h w] (channel-major, networks.py:51-54) and z the channels-last activation
+    [n, c, h, w]: bias, activation and the change of order in one pass; the backward hands the dense kernels a gradient in the units' order."""
+
+    @staticmethod
+    def forward(ctx, y, bias, c, h, w, act):
+        z = _K().units_bias_act_to_nhwc(y, bias, c, h, w, act)
+        _tap(z, act)
+        ctx.act, ctx.has_bias, ctx.bref = act, bias is not None, bias
+        ctx.save_for_backward(z)
+        return z
+
+    @staticmethod
+    def backward(ctx, gz):
+        (z,) = ctx.saved_tensors
+        want_b = ctx.has_bias and ctx.needs_input_grad[1] and _want_params()
+        gu = _NHWCActBwdToUnits.apply(gz, z, ctx.act) if torch.is_grad_enabled() else _K().nhwc_act_bwd_to_units(gz, z, ctx.act)
+        _, gb = _bias_act_backward(gu, None, ACT_NONE, ctx.bref if want_b else None, want_b)
+        return (gu if ctx.needs_input_grad[0] else None), gb, None, None, None, None
+
+
+class _NHWCActBwdToUnits(Function):
+    """gu[n][u] = g[n][p][ch] act'(z[n][p][ch]); linear in g, and for the piecewise-linear activation constant in z."""
+
+    @staticmethod
+    def forward(ctx, g, z, act):
+        if act == ACT_TANH:
+            raise NotImplementedError("_NHWCActBwdToUnits: piecewise-linear activations only under create_graph")
+        ctx.act = act
+        ctx.save_for_backward(z)
+        return _K().nhwc_act_bwd_to_units(g, z, act)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, ggu):
+        (z,) = ctx.saved_tensors
+        n, c, h, w = z.shape
+        return (_K().units_bias_act_to_nhwc(ggu, None, c, h, w, ctx.act, mask=z) if ctx.needs_input_grad[0] else None), None, None
+
+
+def units_nhwc_ok():
+    return hasattr(_K(), "units_bias_act_to_nhwc") and not __import__("os").environ.get("GS_NO_UNITS_NHWC")
+
+
+def units_bias_act_nhwc(y, bias, c, h, w, act):
+    return _UnitsBiasActNHWC.apply(y, bias, int(c), int(h), int(w), act)
+
+
 def bias_act(x, bias, act):
     return _BiasAct.apply(x, bias, act)
 

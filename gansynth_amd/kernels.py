@@ -625,6 +625,30 @@ class HipKernels(object):
         _lib.check(self.lib.gs_bias_act_fwd(x.data_ptr(), bp, y.data_ptr(), p, c, act, _dt(x), _stream()), "gs_bias_act_fwd")
         return y
 
+    # the generator's first block: dense units (channel-major) <-> channels-last activation, in the bias / activation pass (gansynth_hip.h)
+    def units_bias_act_to_nhwc(self, y, bias, c, h, w, act, mask=None):
+        y = _act(y)
+        n = y.shape[0]
+        assert y.dim() == 2 and y.shape[1] == c * h * w
+        z = torch.empty((n, c, h, w), dtype=y.dtype, device=y.device, memory_format=CL)
+        bp = mp = None
+        if bias is not None:
+            bias = _f32c(bias)
+            bp = bias.data_ptr()
+        if mask is not None:
+            mask = _match(mask, z)
+            mp = mask.data_ptr()
+        _lib.check(self.lib.gs_units_bias_act_to_nhwc(y.data_ptr(), bp, mp, z.data_ptr(), n, c, h * w, int(act), _dt(y), _stream()), "gs_units_bias_act_to_nhwc")
+        return z
+
+    def nhwc_act_bwd_to_units(self, g, z, act):
+        z = _act(z)
+        g = _match(g, z)
+        n, c, h, w = z.shape
+        gu = torch.empty((n, c * h * w), dtype=z.dtype, device=z.device)
+        _lib.check(self.lib.gs_nhwc_act_bwd_to_units(g.data_ptr(), z.data_ptr(), gu.data_ptr(), n, c, h * w, int(act), _dt(z), _stream()), "gs_nhwc_act_bwd_to_units")
+        return gu
+
     def act_bwd(self, g, y, act):
         y = _act(y)
         g = _match(g, y)

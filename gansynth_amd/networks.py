@@ -78,11 +78,9 @@ class PGGAN(object):
         with variable_scope(self._block_name("conv", depth)):
             if depth == self.min_depth:
                 x = ops.pixel_normalization(x)
-                with variable_scope("dense"):
-                    x = ops.dense(x, units=c * int(self.resolution(depth).prod()), use_bias=True, variance_scale=2.0,
-                                  scale_weight=True)
-                    x = x.reshape(-1, c, *[int(r) for r in self.resolution(depth)])
-                    x = ops.pixel_normalization(ops.leaky_relu(x))
+                with variable_scope("dense"):   # dense -> reshape -> leaky_relu (networks.py:43-55), then the norm
+                    x = ops.dense_reshaped(x, c, self.resolution(depth), use_bias=True, variance_scale=2.0, scale_weight=True, activation="leaky_relu")
+                    x = ops.pixel_normalization(x)
             else:
                 with variable_scope("upscale_conv"):
                     x = ops.conv2d_transpose(x, filters=c, kernel_size=[3, 3], strides=[2, 2], use_bias=True,

@@ -51,6 +51,22 @@ def dense(inputs, units, use_bias=True, variance_scale=2.0, scale_weight=False, 
     return outputs
 
 
+def dense_reshaped(inputs, channels, resolution, use_bias=True, variance_scale=2.0, scale_weight=False, activation=None):
+    """dense (ops.py:183-201) -> tf.reshape to [-1, channels, *resolution] -> activation (networks.py:44-55): the dense layer's units are
+    channel-major, the activation comes out channels-last -- bias, activation and the reorder are one pass (functional._UnitsBiasActNHWC)
+    where the kernel layer has it, the three separate steps otherwise.  Same variables ("weight" [in, units], "bias" [units])."""
+    h, w = int(resolution[0]), int(resolution[1])
+    units = int(channels) * h * w
+    if not F.units_nhwc_ok():
+        x = dense(inputs, units=units, use_bias=use_bias, variance_scale=variance_scale, scale_weight=scale_weight)
+        x = x.reshape(-1, int(channels), h, w)
+        return F.bias_act(x, None, _ACT[activation]) if activation is not None else x
+    weight, alpha = get_weight([inputs.shape[1], units], variance_scale, scale_weight)
+    outputs = F.dense(inputs, weight, alpha)
+    bias = get_bias([units]) if use_bias else None
+    return F.units_bias_act_nhwc(outputs, bias, channels, h, w, _ACT[activation])
+
+
 def embedding(inputs, units, variance_scale=2.0, scale_weight=False):
     """ops.py:204-218: row gather by argmax of the (one-hot) inputs."""
     weight, alpha = get_weight([inputs.shape[1], units], variance_scale, scale_weight)

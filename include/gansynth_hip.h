@@ -281,6 +281,13 @@ int gs_embedding_bwd(const int64_t* idx, const void* gy, float* gw, int b, int r
  *   channel_sum: out[c] = sum_p g[p][c] (bias gradient, fp32 out) */
 int gs_bias_act_fwd(const void* x, const float* bias, void* y, int64_t p, int c, int act, int dtype, void* stream);
 int gs_act_bwd(const void* g, const void* y, void* gx, int64_t numel, int act, int dtype, void* stream);
+/* The generator's first block, networks.py:41-56 (dense -> tf.reshape to [n, c, h, w] -> leaky_relu): the dense layer's units are channel-major
+ * (unit u = ch * hw + p), activations here are channels-last -- the reorder rides in the bias / activation pass.
+ *   gs_units_bias_act_to_nhwc: z[n][p][ch] = act(y[n][u] + bias[u]) (mask NULL), or y[n][u] * act'(mask[n][p][ch]) (second-order pass)
+ *   gs_nhwc_act_bwd_to_units:  gu[n][u] = g[n][p][ch] * act'(z[n][p][ch])  (the backward, in the units' order for gs_dense_bwd_*) */
+int gs_units_bias_act_to_nhwc(const void* y, const float* bias, const void* mask, void* z, int n, int c, int hw, int act, int dtype, void* stream);
+int gs_nhwc_act_bwd_to_units(const void* g, const void* z, void* gu, int n, int c, int hw, int act, int dtype, void* stream);
+
 /* act_bwd and the bias gradient in one pass: gx = g*act'(y), gb[c] = sum_p gx[p][c] (ws: gs_channel_sum_workspace_bytes) */
 int gs_act_bwd_bias(const void* g, const void* y, void* gx, float* gb, int64_t p, int c, int act, int accumulate, int dtype,
                     void* ws, size_t ws_bytes, void* stream);

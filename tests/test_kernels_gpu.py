@@ -853,3 +853,27 @@ def test_second_order_norm_gradients_in_the_forward_conv(K, case, dtype):
         assert float((got.double() - ref.double()).abs().max()) <= (2e-5 if dtype == torch.float32 else 3e-2) * scale, name
         if dtype == torch.bfloat16:
             assert float((got.double() - want).pow(2).mean()) <= 1.05 * float((ref.double() - want).pow(2).mean()) + 1e-12, name
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(8, 256, 2, 16), (3, 5, 2, 3), (4, 64, 4, 32)])
+def test_dense_units_to_channels_last_in_the_activation_pass(K, shape, dtype):
+    """gs_units_bias_act_to_nhwc / gs_nhwc_act_bwd_to_units (networks.py:51-55: tf.reshape of the dense layer's channel-major units to
+    [n, c, h, w], leaky_relu) against the three separate steps written in torch: exact (a reorder, one add, one select)."""
+    n, c, h, w = shape
+    gen = torch.Generator(device="cuda").manual_seed(2)
+    y = torch.randn(n, c * h * w, device="cuda", generator=gen).to(dtype)
+    bias = torch.randn(c * h * w, device="cuda", generator=gen)
+    want = torch.nn.functional.leaky_relu((y.float() + bias).reshape(n, c, h, w), 0.2).to(dtype)
+    z = K.units_bias_act_to_nhwc(y, bias, c, h, w, 1)
+    assert z.is_contiguous(memory_format=torch.channels_last) and torch.equal(z, want)
+    assert torch.equal(K.units_bias_act_to_nhwc(y, None, c, h, w, 0), y.reshape(n, c, h, w))
+    g = torch.randn(n, c, h, w, device="cuda", generator=gen).to(dtype).contiguous(memory_format=torch.channels_last)
+    gu = K.nhwc_act_bwd_to_units(g, z, 1)
+    assert torch.equal(gu, (g.float() * torch.where(z > 0, 1.0, 0.2)).to(dtype).reshape(n, c * h * w))
+    ggu = torch.randn(n, c * h * w, device="cuda", generator=gen).to(dtype)
+    gg = K.units_bias_act_to_nhwc(ggu, None, c, h, w, 1, mask=z)   # the adjoint map (second-order pass)
+    assert torch.equal(gg, (ggu.float().reshape(n, c, h, w) * torch.where(z > 0, 1.0, 0.2)).to(dtype))
+    # <gu, ggu> == <g, gg>: the two maps are adjoint
+    a, b = float((gu.double() * ggu.double()).sum()), float((g.double() * gg.double()).sum())
+    assert abs(a - b) <= (1e-6 if dtype == torch.float32 else 2e-2) * max(1.0, abs(a))
