@@ -220,6 +220,24 @@ class data_grads_only(object):
         return False
 
 
+# A backward pass whose only clients are the parameters (the trainer's loss.backward(): tf.gradients(loss, var_list), models.py:67-89) has no
+# use for the gradient of a LEAF activation -- the real image batch, which requires grad for the R1 term's own pass: the colour block's data
+# gradient (67 MB read at 128x1024) is skipped there.
+_PARAMS_ONLY = False
+
+
+class params_only(object):
+    def __enter__(self):
+        global _PARAMS_ONLY
+        self.was, _PARAMS_ONLY = _PARAMS_ONLY, not __import__("os").environ.get("GS_NO_PARAMS_ONLY")
+        return self
+
+    def __exit__(self, *exc):
+        global _PARAMS_ONLY
+        _PARAMS_ONLY = self.was
+        return False
+
+
 def _want_params():
     return _PARAM_GRADS[-1]
 
@@ -501,6 +519,8 @@ class _ConvBiasAct(Function):
         def data_grad(gy):
             if not ctx.needs_input_grad[0]:
                 return None
+            if _PARAMS_ONLY and x.grad_fn is None and not torch.is_grad_enabled():
+                return None   # x is a leaf (the image batch of the R1 term) and this backward pass is after parameter gradients only
             if _FUSE_NORM_BWD and ctx.input_normed and not torch.is_grad_enabled() and hasattr(ctx.kind, "bwd_data_pnbwd"):
                 pn = x.grad_fn   # the generator block whose normalised output this conv reads: its norm / activation backward in this conv's data gradient
                 if (isinstance(pn, _ConvBiasActNorm._backward_cls) and pn.act in (ACT_NONE, ACT_LRELU)

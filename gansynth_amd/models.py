@@ -13,6 +13,7 @@ Adam launch, one all-reduce payload).  Data parallelism (new -- the reference is
 one process per GPU, gradients summed with torch.distributed all_reduce (backend "nccl" = RCCL
 over xGMI) and averaged inside the Adam kernel.
 """
+import contextlib
 import math
 from collections import OrderedDict
 
@@ -431,10 +432,11 @@ class GANSynth(object):
         if hasattr(F, "reset_fusion_state"):
             F.reset_fusion_state()   # (side-channel state of cross-node fusions is per backward pass)
         try:
-            if loss.is_cuda and loss.dim() == 0 and loss.dtype == torch.float32 and not self._capturing_fresh_seed(loss.device):
-                torch.autograd.backward(loss, grad_tensors=F.unit_seed(loss.device))   # (the loss heads recognise the seed: functional.unit_seed)
-            else:
-                loss.backward()
+            with (F.params_only() if hasattr(F, "params_only") else contextlib.nullcontext()):   # tf.gradients(loss, var_list): leaf activations want no gradient
+                if loss.is_cuda and loss.dim() == 0 and loss.dtype == torch.float32 and not self._capturing_fresh_seed(loss.device):
+                    torch.autograd.backward(loss, grad_tensors=F.unit_seed(loss.device))   # (the loss heads recognise the seed: functional.unit_seed)
+                else:
+                    loss.backward()
         finally:
             if deferring:
                 if overlap:   # contract the layers bucket by bucket; a finished bucket goes on the wire under the next one's kernels
