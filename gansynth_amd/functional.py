@@ -1278,6 +1278,8 @@ class _SumSqRows(Function):
 
     @staticmethod
     def forward(ctx, x):
+        if x.dim() == 2 and not x.is_contiguous():
+            x = x.contiguous()   # (a column slice of a wider gradient: one copy serves this pass and the backward's row_scale)
         ctx.save_for_backward(x)
         return _K().sumsq_rows(x)
 
