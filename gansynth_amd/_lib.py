@@ -12,7 +12,6 @@ LIB_PATH = os.path.join(_HERE, "libgansynth_hip.so")
 
 GS_F32, GS_BF16 = 0, 1
 ACT_NONE, ACT_LRELU, ACT_TANH = 0, 1, 2
-MASK_BITS = 0x100   # GS_MASK_BITS
 PREP_CONV_FWD, PREP_CONV_BWD_DATA, PREP_CONVT_FWD, PREP_CONVT_BWD_DATA = 0, 1, 2, 3
 CONV_FWD, CONV_BWD_DATA, CONV_BWD_WEIGHT = 0, 1, 2
 
@@ -56,10 +55,6 @@ SIGNATURES = {
     "gs_conv2d_transpose_s2_bwd_data": (I, [P, P, P, I, I, I, I, I, F, I, I, P, Z, P]),
     "gs_conv2d_bwd_data_pnbwd_is_fused": (I, [I, I, I, I, I, I, I, I, I]),
     "gs_conv2d_fwd_pnbwdbwd_is_fused": (I, [I, I, I, I, I, I, I, I, I]),
-    "gs_conv2d_sign_bits_ok": (I, [I, I, I, I, I]),
-    "gs_conv2d_bwd_data_mask_bits_ok": (I, [I, I, I, I, I]),
-    "gs_conv2d_fwd_mask_bits_ok": (I, [I, I, I, I, I]),
-    "gs_conv2d_fwd_bias_act_bits": (I, [P, P, P, P, P, I, I, I, I, I, I, I, F, I, I, I, P, Z, P]),
     "gs_units_bias_act_to_nhwc": (I, [P, P, P, P, I, I, I, I, I, P]),
     "gs_nhwc_act_bwd_to_units": (I, [P, P, P, I, I, I, I, I, P]),
     "gs_conv2d_fwd_pnbwdbwd": (I, [P, P, P, P, I, F, P, P, I, I, I, I, I, I, I, F, I, I, P, Z, P]),

@@ -18,7 +18,7 @@ size_t igemm_prep_bytes(int ic, int oc, int dtype);
 int run_igemm(int mode, int variant, const void* x, const float* w_hwio, void* y, int N, int Hi, int Wi, int ICk,
               int OCk, int w_ci, int w_co, int Hb, int Wb, float alpha, const float* bias, int act, int dtype, int w_prepared,
               void* ws, size_t ws_bytes, hipStream_t st, const void* mask = nullptr, int mask_act = 0, void* y2 = nullptr, float pn_eps = 0.f,
-              const void* addend = nullptr, int normbwd = 0, void* bits_out = nullptr);
+              const void* addend = nullptr, int normbwd = 0);
 extern "C" int gs_pixel_norm_bwd_fused(const void* g, const void* x, const void* addend, void* gx, int64_t p, int c, float eps, int pre_act, int post_act, int dtype,
                                        void* stream);
 size_t wgrad_mfma_bytes(int mode, int dtype, int N, int Hb, int Wb, int IC, int OC);
@@ -132,7 +132,7 @@ __device__ inline float thin_act(float v, int act) {
 // A thread keeps its Wide::N output channels (weights + bias in registers) and strides over pixels.
 template <typename T, int IC>
 __global__ __launch_bounds__(256) void thin_expand_kernel(const T* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
-                                                          T* __restrict__ y, long P, int OC, float alpha, int act, unsigned char* __restrict__ bits = nullptr) {
+                                                          T* __restrict__ y, long P, int OC, float alpha, int act) {
     constexpr int WN = Wide<T>::N;
     const int groups = OC / WN;
     const int oc0 = (threadIdx.x % groups) * WN;
@@ -175,17 +175,6 @@ __global__ __launch_bounds__(256) void thin_expand_kernel(const T* __restrict__ 
             o[v] = thin_act(a, act);
         }
         st_wide<T>(y + px * OC + oc0, o);
-        if constexpr (sizeof(T) == 2) {
-            // sign words of the result in the MFMA epilogue's layout (gansynth_hip.h): this lane's 8 channels are one BYTE of them -- channel
-            // group g = (oc0 / 8) % 4 of its 32-channel tile is the low (g < 2) or high byte of word g & 1
-            if (bits) {
-                unsigned sg = 0;
-#pragma unroll
-                for (int v = 0; v < WN; ++v) sg |= (o[v] > 0.f ? 1u : 0u) << v;
-                const int g = (oc0 >> 3) & 3;
-                bits[px * (OC >> 3) + (oc0 >> 5) * 4 + ((g & 1) << 1 | (g >> 1))] = (unsigned char)sg;
-            }
-        }
     };
     auto ldpix = [&](long px, float* xv) __attribute__((always_inline)) {
         if constexpr (IC == 2 && sizeof(T) == 2) {   // both colour channels of a pixel in one 4-byte load
@@ -438,7 +427,7 @@ __global__ __launch_bounds__(256) void thin_single3_kernel(const T* __restrict__
 // direct conv through the fp32 prepped weights living in ws; *fused is set when bias / act went into the same pass
 static int run_direct(int mode, int ks, int variant, const void* x, const float* w_hwio, void* y, int N, int Hi, int Wi,
                       int ICk, int OCk, int w_ci, int w_co, int Ho, int Wo, float alpha, int dtype, int w_prepared, void* ws,
-                      size_t ws_bytes, hipStream_t st, const float* bias = nullptr, int act = GS_ACT_NONE, bool* fused = nullptr, void* bits_out = nullptr) {
+                      size_t ws_bytes, hipStream_t st, const float* bias = nullptr, int act = GS_ACT_NONE, bool* fused = nullptr) {
     const long total = (long)ks * ks * w_ci * w_co;
     if (ws_bytes < (size_t)total * 4) return fail(GS_ERR_WORKSPACE, "conv direct: workspace %zu < %zu", ws_bytes, (size_t)total * 4);
     float* wp = reinterpret_cast<float*>(ws);
@@ -455,7 +444,7 @@ static int run_direct(int mode, int ks, int variant, const void* x, const float*
         static const long te_cap = getenv("GS_THIN_EXPAND_BLOCKS") ? atol(getenv("GS_THIN_EXPAND_BLOCKS")) : 2048;
         if (nb > te_cap) nb = te_cap;
         const unsigned grid = (unsigned)nb;
-#define GS_TE(TT, ICV) hipLaunchKernelGGL((thin_expand_kernel<TT, ICV>), dim3(grid), dim3(256), 0, st, (const TT*)x, wp, bias, (TT*)y, P, OCk, alpha, act, (unsigned char*)bits_out)
+#define GS_TE(TT, ICV) hipLaunchKernelGGL((thin_expand_kernel<TT, ICV>), dim3(grid), dim3(256), 0, st, (const TT*)x, wp, bias, (TT*)y, P, OCk, alpha, act)
 #define GS_TE_ALL(TT) do { if (ICk == 1) GS_TE(TT, 1); else if (ICk == 2) GS_TE(TT, 2); else if (ICk == 3) GS_TE(TT, 3); else GS_TE(TT, 4); } while (0)
         GS_DISPATCH_DTYPE(dtype, GS_TE_ALL(T));
 #undef GS_TE_ALL
@@ -826,37 +815,6 @@ extern "C" int gs_conv2d_fwd_bias_act(const void* x, const float* w_hwio, const 
     return conv2d_fwd_impl(x, w_hwio, bias, act, y, n, h, w, ci, co, ksize, stride, alpha, dtype, w_prepared, ws, ws_bytes, stream);
 }
 
-// Sign bits of a leaky-relu output (gansynth_hip.h, "sign-bit masks"): the forward conv writes them beside y, the masked convs of the backward
-// passes read them instead of y itself -- 1/16 of the bytes of the bf16 tensor.  MFMA path only (the epilogue's store layout defines the words).
-static bool thin_expand_bits_ok(int ci, int co, int ksize, int stride, int dtype) {   // the colour -> features conv (networks.py:231-242), bf16
-    return ksize == 1 && stride == 1 && dtype == GS_BF16 && ci <= 4 && co % 32 == 0 && 256 % (co / 8) == 0;
-}
-extern "C" int gs_conv2d_sign_bits_ok(int ci, int co, int ksize, int stride, int dtype) {
-    if (thin_expand_bits_ok(ci, co, ksize, stride, dtype)) return 1;
-    return ksize == 3 && (stride == 1 || stride == 2) && igemm_supported(ci, co, dtype) ? 1 : 0;
-}
-extern "C" int gs_conv2d_fwd_bias_act_bits(const void* x, const float* w_hwio, const float* bias, void* y, void* bits, int n, int h, int w, int ci, int co,
-                                           int ksize, int stride, float alpha, int act, int dtype, int w_prepared, void* ws, size_t ws_bytes, void* stream) {
-    if (int e = check_conv_args(n, h, w, ci, co, ksize, stride, dtype)) return e;
-    GS_CHECK_ARG(y && bits && act == GS_ACT_LRELU, "conv2d_fwd_bias_act_bits: y and bits are required, leaky relu only (got %d)", act);
-    if (!gs_conv2d_sign_bits_ok(ci, co, ksize, stride, dtype)) return fail(GS_ERR_UNSUPPORTED, "conv2d_fwd_bias_act_bits: %d -> %d, %dx%d / %d has no MFMA epilogue", ci, co, ksize, ksize, stride);
-    if (thin_expand_bits_ok(ci, co, ksize, stride, dtype)) {
-        bool fused = false;
-        if (int e = run_direct(MODE_S1, 1, 0, x, w_hwio, y, n, h, w, ci, co, ci, co, h, w, alpha, dtype, w_prepared, ws, ws_bytes, as_stream(stream), bias, act, &fused, bits)) return e;
-        return fused ? 0 : fail(GS_ERR_UNSUPPORTED, "conv2d_fwd_bias_act_bits: the colour block did not take its streaming kernel");
-    }
-    return run_igemm(stride == 2 ? MODE_S2 : MODE_S1, 0, x, w_hwio, y, n, h, w, ci, co, ci, co, h / stride, w / stride, alpha, bias, act, dtype, w_prepared, ws, ws_bytes,
-                     as_stream(stream), nullptr, 0, nullptr, 0.f, nullptr, 0, bits);
-}
-// does gs_conv2d_bwd_data_mask / gs_conv2d_fwd_mask take `mask_act | GS_MASK_BITS` for this layer (the mask applied in the MFMA epilogue)?
-static int mask_fuse_min_channels();
-extern "C" int gs_conv2d_bwd_data_mask_bits_ok(int ci, int co, int ksize, int stride, int dtype) {
-    return ksize == 3 && (stride == 1 || stride == 2) && ci >= mask_fuse_min_channels() && igemm_supported(co, ci, dtype) ? 1 : 0;
-}
-extern "C" int gs_conv2d_fwd_mask_bits_ok(int ci, int co, int ksize, int stride, int dtype) {
-    return ksize == 3 && (stride == 1 || stride == 2) && co >= mask_fuse_min_channels() && igemm_supported(ci, co, dtype) ? 1 : 0;
-}
-
 extern "C" int gs_act_bwd(const void* g, const void* y, void* gx, int64_t numel, int act, int dtype, void* stream);
 
 // y = conv2d(x, w) * mask_act'(.) through `mask` (an activation OUTPUT of y's shape): the second-order pass of the R1 penalty runs
@@ -865,9 +823,7 @@ extern "C" int gs_act_bwd(const void* g, const void* y, void* gx, int64_t numel,
 extern "C" int gs_conv2d_fwd_mask(const void* x, const float* w_hwio, const void* mask, int mask_act, void* y, int n, int h, int w, int ci, int co,
                                   int ksize, int stride, float alpha, int dtype, int w_prepared, void* ws, size_t ws_bytes, void* stream) {
     if (int e = check_conv_args(n, h, w, ci, co, ksize, stride, dtype)) return e;
-    GS_CHECK_ARG(mask == nullptr || mask_act == GS_ACT_LRELU || mask_act == GS_ACT_TANH || mask_act == (GS_ACT_LRELU | GS_MASK_BITS), "conv2d_fwd_mask: bad activation %d", mask_act);
-    if (mask && (mask_act & GS_MASK_BITS) && !gs_conv2d_fwd_mask_bits_ok(ci, co, ksize, stride, dtype))
-        return fail(GS_ERR_UNSUPPORTED, "conv2d_fwd_mask: sign-bit masks need the MFMA epilogue (gs_conv2d_fwd_mask_bits_ok)");
+    GS_CHECK_ARG(mask == nullptr || mask_act == GS_ACT_LRELU || mask_act == GS_ACT_TANH, "conv2d_fwd_mask: bad activation %d", mask_act);
     hipStream_t st = as_stream(stream);
     const int hb = h / stride, wb = w / stride;
     const int mode = stride == 2 ? MODE_S2 : MODE_S1;
@@ -894,9 +850,7 @@ extern "C" int gs_act_bwd(const void* g, const void* y, void* gx, int64_t numel,
 extern "C" int gs_conv2d_bwd_data_mask(const void* gy, const float* w_hwio, const void* mask, int mask_act, void* gx, int n, int h, int w, int ci, int co,
                                        int ksize, int stride, float alpha, int dtype, int w_prepared, void* ws, size_t ws_bytes, void* stream) {
     if (int e = check_conv_args(n, h, w, ci, co, ksize, stride, dtype)) return e;
-    GS_CHECK_ARG(mask == nullptr || mask_act == GS_ACT_LRELU || mask_act == GS_ACT_TANH || mask_act == (GS_ACT_LRELU | GS_MASK_BITS), "conv2d_bwd_data_mask: bad activation %d", mask_act);
-    if (mask && (mask_act & GS_MASK_BITS) && !gs_conv2d_bwd_data_mask_bits_ok(ci, co, ksize, stride, dtype))
-        return fail(GS_ERR_UNSUPPORTED, "conv2d_bwd_data_mask: sign-bit masks need the MFMA epilogue (gs_conv2d_bwd_data_mask_bits_ok)");
+    GS_CHECK_ARG(mask == nullptr || mask_act == GS_ACT_LRELU || mask_act == GS_ACT_TANH, "conv2d_bwd_data_mask: bad activation %d", mask_act);
     const float* bias = nullptr;
     const int act = GS_ACT_NONE;
     hipStream_t st = as_stream(stream);

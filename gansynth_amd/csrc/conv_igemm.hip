@@ -96,12 +96,6 @@ struct ConvP {
     int act;
     const void* mask;   // optional (data gradients): y *= mask_act'(.) expressed through the activation OUTPUT mask[..] (y's shape)
     int mask_act;
-    // Sign bits of a leaky-relu output instead of the output itself (the mask needs nothing else): one 16-bit word per (pixel, 32-channel tile,
-    // lane half), word index = element offset / 16 + 2 a + hi, bit k = the k-th of the 16 values the lane (pixel, hi) stores of that tile in
-    // this dtype's store layout (bf16: channel 16 (k / 8) + 8 hi + k % 8; fp32: channel 8 (k / 4) + 4 hi + k % 4).  `bits_out`: the forward
-    // conv writes them beside y; `mask_bits`: `mask` points to such words (1/16 of the bytes of the bf16 tensor they stand for).
-    void* bits_out;
-    int mask_bits;
     void* y2;           // optional (NORM == 1 kernels): y2 = pixel_norm(y) over the channels, y itself optional then
     float pn_eps;
     // NORM == 2 kernels (data gradients): the conv result g is the gradient w.r.t. y = pixel_norm(z) of the PREVIOUS block; the epilogue turns it
@@ -415,29 +409,6 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void conv_igemm_kernel(const Conv
     while (true) {
         int n, by, bx, oc0;
         item_coords(item, n, by, bx, oc0);
-        // sign-word masks: the item's words (one register per pixel group, phase and channel tile) are fetched HERE, a whole K loop ahead of
-        // the epilogue that uses them -- fetched there, like the 16-byte vectors of a tensor mask have to be, their round trip is exposed
-        // once per tile (measured: that, not the bytes, is what a masked conv costs over a plain one on the 32-channel layers)
-        unsigned mword[(!NORM) ? B * NPH : 1][A];
-        if constexpr (!NORM) {
-            if (computer && p.mask_bits) {
-                const int Ho_ = MODE == MODE_T2 ? 2 * Hb : Hb, Wo_ = MODE == MODE_T2 ? 2 * Wb : Wb;
-#pragma unroll
-                for (int b = 0; b < B; ++b) {
-                    const int q = (wv * B + b) * 32 + l31;
-                    const int gy = by + q / TW, gx = bx + q % TW;
-                    const bool in_ = gy < Hb && gx < Wb;
-#pragma unroll
-                    for (int ph = 0; ph < NPH; ++ph) {
-                        const int oy = MODE == MODE_T2 ? 2 * gy + (ph >> 1) : gy;
-                        const int ox = MODE == MODE_T2 ? 2 * gx + (ph & 1) : gx;
-                        const long off = in_ ? (((long)n * Ho_ + oy) * Wo_ + ox) * OC + oc0 : 0;
-#pragma unroll
-                        for (int a = 0; a < A; ++a) mword[b * NPH + ph][a] = reinterpret_cast<const unsigned short*>(p.mask)[(off >> 4) + 2 * a + hi];
-                    }
-                }
-            }
-        }
         for (int ch = 0; ch < NCH; ++ch) {
 #pragma unroll
             for (int tg = 0; tg < NTG; ++tg) {
@@ -511,18 +482,6 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void conv_igemm_kernel(const Conv
                     wait_vmcnt(younger);
 #endif
                 }
-                if constexpr (!NORM) {
-                    // the compiler's own wait for the item's sign words goes HERE, behind the counted wait of the item's first stage (everything
-                    // older than the stages still in flight has landed: it costs nothing).  Left to the first use in the epilogue it is a
-                    // vmcnt(0) that also waits for the DMA pieces of the stages issued since -- a full round trip per tile, which is what
-                    // the epilogue's own loads of a tensor mask cost.
-                    if (ch == 0 && tg == 0 && computer && p.mask_bits) {
-#pragma unroll
-                        for (int i = 0; i < B * NPH; ++i)
-#pragma unroll
-                            for (int a = 0; a < A; ++a) asm volatile("" : "+v"(mword[i][a]));
-                    }
-                }
                 // ---- epilogue of the item.  D[oc][pixel]: a lane holds oc = 8q + 4hi + (0..3) of pixel l31 per accumulator quad.
                 //      The store path sustains ~7 B/cycle/CU with 8-byte stores and twice that with 16-byte ones (measured with
                 //      the ablations of scripts/probe/igemm_trace.hip: the top-of-pyramid layers are bound by it), so a lane must
@@ -556,43 +515,22 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void conv_igemm_kernel(const Conv
                     constexpr int NV = SZ == 4 ? 4 : 2;              // mask vectors per 32-channel tile of a pixel
                     auto mask_fetch = [&](long off, bool inside, mvec_t (&mz)[A][NV]) __attribute__((always_inline)) {
                         const long base = inside ? off : 0;          // clamped: the loads stay unconditional
-                        if (!NORM && p.mask_bits) return;   // (sign words: fetched at the top of the item, applied in store())
 #pragma unroll
                         for (int a = 0; a < A; ++a)
 #pragma unroll
                             for (int v = 0; v < NV; ++v)
                                 mz[a][v] = *reinterpret_cast<const mvec_t*>(reinterpret_cast<const T*>(p.mask) + base + a * 32 + v * (32 / NV) + hi * (16 / NV));
                     };
-                    // factor of value k of a sign word: 1 where the bit is set, 0.2 where not -- v_bfe_i32 (0 / -1) and v_bfi_b32, two instructions
-                    auto word_factor = [&](unsigned wd, int k) __attribute__((always_inline)) {
-                        const unsigned m = (unsigned)__builtin_amdgcn_sbfe((int)wd, k, 1);
-                        return __uint_as_float((m & 0x3F800000u) | (~m & 0x3E4CCCCDu));
-                    };
-                    auto store = [&](T* dst, long off, int a, float (&o)[4][4], bool inside, const mvec_t* mz, unsigned wd = 0, bool by_word = false) __attribute__((always_inline)) {
-                        const bool emit = !NORM && p.bits_out != nullptr && dst == y;   // (sign words of the result beside it: see ConvP)
-                        unsigned sign = 0;
+                    auto store = [&](T* dst, long off, int a, float (&o)[4][4], bool inside, const mvec_t* mz) __attribute__((always_inline)) {
                         if constexpr (SZ == 4) {
 #pragma unroll
                             for (int qd = 0; qd < 4; ++qd) {
-                                if (by_word) {
-#pragma unroll
-                                    for (int e = 0; e < 4; ++e) o[qd][e] *= word_factor(wd, 4 * qd + e);
-                                } else if (mz) {
+                                if (mz) {
                                     const float4 zv = mz[qd];
-                                    if (p.mask_act == GS_ACT_LRELU) {   // (the common case by itself: compare, scale, select per value)
-                                        o[qd][0] = zv.x > 0.f ? o[qd][0] : 0.2f * o[qd][0]; o[qd][1] = zv.y > 0.f ? o[qd][1] : 0.2f * o[qd][1];
-                                        o[qd][2] = zv.z > 0.f ? o[qd][2] : 0.2f * o[qd][2]; o[qd][3] = zv.w > 0.f ? o[qd][3] : 0.2f * o[qd][3];
-                                    } else {
-                                        o[qd][0] *= mask_factor(zv.x); o[qd][1] *= mask_factor(zv.y); o[qd][2] *= mask_factor(zv.z); o[qd][3] *= mask_factor(zv.w);
-                                    }
-                                }
-                                if (emit) {
-#pragma unroll
-                                    for (int e = 0; e < 4; ++e) sign |= (o[qd][e] > 0.f ? 1u : 0u) << (4 * qd + e);
+                                    o[qd][0] *= mask_factor(zv.x); o[qd][1] *= mask_factor(zv.y); o[qd][2] *= mask_factor(zv.z); o[qd][3] *= mask_factor(zv.w);
                                 }
                                 if (inside) st4(reinterpret_cast<float*>(dst) + off + a * 32 + qd * 8 + hi * 4, o[qd]);
                             }
-                            if (emit && inside) reinterpret_cast<unsigned short*>(p.bits_out)[(off >> 4) + 2 * a + hi] = (unsigned short)sign;
                         } else {
 #pragma unroll
                             for (int qp = 0; qp < 2; ++qp) {
@@ -603,37 +541,18 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void conv_igemm_kernel(const Conv
                                     lo[e] = __uint_as_float(r[0]);
                                     hi4[e] = __uint_as_float(r[1]);
                                 }
-                                if (by_word) {
-#pragma unroll
-                                    for (int e = 0; e < 4; ++e) { lo[e] *= word_factor(wd, 8 * qp + e); hi4[e] *= word_factor(wd, 8 * qp + 4 + e); }
-                                } else if (mz) {   // the lane's 8 channels of the mask sit where its 16 bytes go
+                                if (mz) {   // the lane's 8 channels of the mask sit where its 16 bytes go
                                     const uint4 zv = mz[qp];
-                                    if (p.mask_act == GS_ACT_LRELU) {
-                                        // z > 0 on the packed pair: low half shifted up and compared as an integer, high half in place (>= 0x10000: sign
-                                        // clear, magnitude bits not all zero)
-#define GS_LR(V, Z) V = (int)((Z) << 16) > 0 ? V : 0.2f * V
-#define GS_HR(V, Z) V = (int)(Z) >= 0x10000 ? V : 0.2f * V
-                                        GS_LR(lo[0], zv.x); GS_HR(lo[1], zv.x); GS_LR(lo[2], zv.y); GS_HR(lo[3], zv.y);
-                                        GS_LR(hi4[0], zv.z); GS_HR(hi4[1], zv.z); GS_LR(hi4[2], zv.w); GS_HR(hi4[3], zv.w);
-#undef GS_LR
-#undef GS_HR
-                                    } else {
-                                        lo[0] *= mask_factor(__uint_as_float(zv.x << 16)); lo[1] *= mask_factor(__uint_as_float(zv.x & 0xffff0000u));
-                                        lo[2] *= mask_factor(__uint_as_float(zv.y << 16)); lo[3] *= mask_factor(__uint_as_float(zv.y & 0xffff0000u));
-                                        hi4[0] *= mask_factor(__uint_as_float(zv.z << 16)); hi4[1] *= mask_factor(__uint_as_float(zv.z & 0xffff0000u));
-                                        hi4[2] *= mask_factor(__uint_as_float(zv.w << 16)); hi4[3] *= mask_factor(__uint_as_float(zv.w & 0xffff0000u));
-                                    }
+                                    lo[0] *= mask_factor(__uint_as_float(zv.x << 16)); lo[1] *= mask_factor(__uint_as_float(zv.x & 0xffff0000u));
+                                    lo[2] *= mask_factor(__uint_as_float(zv.y << 16)); lo[3] *= mask_factor(__uint_as_float(zv.y & 0xffff0000u));
+                                    hi4[0] *= mask_factor(__uint_as_float(zv.z << 16)); hi4[1] *= mask_factor(__uint_as_float(zv.z & 0xffff0000u));
+                                    hi4[2] *= mask_factor(__uint_as_float(zv.w << 16)); hi4[3] *= mask_factor(__uint_as_float(zv.w & 0xffff0000u));
                                 }
                                 uint4 v;
                                 v.x = pack_bf16x2(lo[0], lo[1]); v.y = pack_bf16x2(lo[2], lo[3]);
                                 v.z = pack_bf16x2(hi4[0], hi4[1]); v.w = pack_bf16x2(hi4[2], hi4[3]);
-                                if (emit) {
-#pragma unroll
-                                    for (int e = 0; e < 4; ++e) sign |= ((lo[e] > 0.f ? 1u : 0u) << (8 * qp + e)) | ((hi4[e] > 0.f ? 1u : 0u) << (8 * qp + 4 + e));
-                                }
                                 if (inside) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(dst) + off + a * 32 + qp * 16 + hi * 8) = v;
                             }
-                            if (emit && inside) reinterpret_cast<unsigned short*>(p.bits_out)[(off >> 4) + 2 * a + hi] = (unsigned short)sign;
                         }
                     };
                     // all mask vectors of the tile in one go when they fit in 32 registers, else one (pixel group, phase) at a time
@@ -876,8 +795,7 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void conv_igemm_kernel(const Conv
                                     float o[4][4];
                                     finish(ph, a, b, o);
                                     const mvec_t* mz = MASK_ALL ? mz_all[MASK_ALL ? b * NPH + ph : 0][a] : mz_one[a];
-                                    if (p.mask_bits) store(y, off, a, o, inside, static_cast<const mvec_t*>(nullptr), mword[(!NORM) ? b * NPH + ph : 0][a], true);
-                                    else store(y, off, a, o, inside, p.mask ? mz : static_cast<const mvec_t*>(nullptr));
+                                    store(y, off, a, o, inside, p.mask ? mz : static_cast<const mvec_t*>(nullptr));
                                 }
                             }
                         }
@@ -1736,7 +1654,7 @@ static int launch_igemm(ConvP p, hipStream_t st) {
     const double flops = 2.0 * 9.0 * (double)p.N * p.Hb * p.Wb * p.IC * p.OC;
     const double out_px = (double)p.N * p.Hb * p.Wb * (MODE == MODE_T2 ? 4 : 1);
     // algorithmic bytes: input + output + weights, + the activation mask a masked launch reads, + the second output of a fused norm
-    const double bytes = ((double)p.N * p.Hi * p.Wi * p.IC + out_px * p.OC * (1.0 + (p.mask ? (p.mask_bits ? 1.0 / (8 * sizeof(T)) : 1.0) : 0.0) + (p.bits_out ? 1.0 / (8 * sizeof(T)) : 0.0) + ((NORM == 1 && p.y) ? 1.0 : 0.0) + ((NORM == 2 && p.addend) ? 1.0 : 0.0) + (NORM == 3 ? 2.0 : 0.0)) + 9.0 * p.IC * p.OC) * sizeof(T);
+    const double bytes = ((double)p.N * p.Hi * p.Wi * p.IC + out_px * p.OC * (1.0 + (p.mask ? 1.0 : 0.0) + ((NORM == 1 && p.y) ? 1.0 : 0.0) + ((NORM == 2 && p.addend) ? 1.0 : 0.0) + (NORM == 3 ? 2.0 : 0.0)) + 9.0 * p.IC * p.OC) * sizeof(T);
     const int reps = prof_reps();   // (1 unless profiling in burst mode: the kernel is a pure function of its inputs)
     ProfScope ps(st, flops, bytes, MODE, p.N, p.Hb, p.Wb, p.IC, p.OC, p.mask ? 1 : 0, NORM ? 1 : 0, reps);
     for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(SPEC ? 512 : 256), lds, st, p);
@@ -1927,7 +1845,7 @@ template <typename T>
 static int run_igemm_t(int mode, int variant, const void* x, const float* w_hwio, void* y, int N, int Hi, int Wi,
                        int ICk, int OCk, int w_ci, int w_co, int Hb, int Wb, float alpha, const float* bias, int act,
                        int w_prepared, void* ws, size_t ws_bytes, hipStream_t st, const void* mask, int mask_act, void* y2, float pn_eps,
-                       const void* addend, int normbwd, void* bits_out) {
+                       const void* addend, int normbwd) {
     const size_t need = (size_t)9 * w_ci * w_co * sizeof(T);
     if (ws_bytes < need) return fail(GS_ERR_WORKSPACE, "conv igemm: workspace %zu < %zu", ws_bytes, need);
     T* wp = reinterpret_cast<T*>(ws);
@@ -1936,10 +1854,7 @@ static int run_igemm_t(int mode, int variant, const void* x, const float* w_hwio
         hipLaunchKernelGGL((weight_prep_kernel<T>), dim3(cdiv(total, 256)), dim3(256), 0, st, w_hwio, wp, 9, w_ci, w_co, variant);
     ConvP p;
     memset(&p, 0, sizeof(p));
-    p.x = x; p.wp = wp; p.y = y; p.bias = bias; p.act = act; p.mask = mask; p.mask_act = mask_act & 0xff;
-    p.mask_bits = mask && (mask_act & GS_MASK_BITS) ? 1 : 0;
-    p.bits_out = bits_out;
-    if ((p.mask_bits || bits_out) && (y2 || normbwd)) return fail(GS_ERR_UNSUPPORTED, "conv igemm: sign-bit masks go with the plain epilogue only");
+    p.x = x; p.wp = wp; p.y = y; p.bias = bias; p.act = act; p.mask = mask; p.mask_act = mask_act;
     p.N = N; p.Hi = Hi; p.Wi = Wi; p.IC = ICk; p.OC = OCk; p.Hb = Hb; p.Wb = Wb; p.alpha = alpha;
     int pending = 0;
     p.y2 = y2; p.pn_eps = pn_eps; p.norm_pending = &pending;
@@ -1967,10 +1882,9 @@ static int run_igemm_t(int mode, int variant, const void* x, const float* w_hwio
 
 int run_igemm(int mode, int variant, const void* x, const float* w_hwio, void* y, int N, int Hi, int Wi, int ICk,
               int OCk, int w_ci, int w_co, int Hb, int Wb, float alpha, const float* bias, int act, int dtype, int w_prepared,
-              void* ws, size_t ws_bytes, hipStream_t st, const void* mask, int mask_act, void* y2, float pn_eps, const void* addend, int normbwd,
-              void* bits_out) {
+              void* ws, size_t ws_bytes, hipStream_t st, const void* mask, int mask_act, void* y2, float pn_eps, const void* addend, int normbwd) {
     GS_DISPATCH_DTYPE(dtype, return (run_igemm_t<T>(mode, variant, x, w_hwio, y, N, Hi, Wi, ICk, OCk, w_ci, w_co, Hb,
-                                                    Wb, alpha, bias, act, w_prepared, ws, ws_bytes, st, mask, mask_act, y2, pn_eps, addend, normbwd, bits_out)));
+                                                    Wb, alpha, bias, act, w_prepared, ws, ws_bytes, st, mask, mask_act, y2, pn_eps, addend, normbwd)));
 }
 
 // ---- weight gradient (fp32 MFMA path)

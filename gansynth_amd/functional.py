@@ -97,24 +97,11 @@ class _ConvKind(object):
     def fwd(self, x, w, alpha):
         return _K().conv2d_fwd(x, w, self.ksize, self.stride, alpha)
 
-    def fwd_bias_act(self, x, w, bias, alpha, act, want_bits=False):
-        if want_bits:
-            return _K().conv2d_fwd_bias_act(x, w, bias, self.ksize, self.stride, alpha, act, want_bits=True)
+    def fwd_bias_act(self, x, w, bias, alpha, act):
         return _K().conv2d_fwd_bias_act(x, w, bias, self.ksize, self.stride, alpha, act)
 
-    # sign-bit masks (include/gansynth_hip.h): the forward conv's leaky-relu output as one bit per element, for the masked convs of the backward
-    def sign_bits_ok(self, ci, co, dtype):
+    def fwd_mask(self, x, w, alpha, mask, mask_act):
         K = _K()
-        return _SIGN_BITS and hasattr(K, "sign_bits_ok") and K.sign_bits_ok(ci, co, self.ksize, self.stride, dtype)
-
-    def mask_bits_ok(self, role, ci, co, dtype):
-        K = _K()
-        return _SIGN_BITS and hasattr(K, "mask_bits_ok") and K.mask_bits_ok(role, ci, co, self.ksize, self.stride, dtype)
-
-    def fwd_mask(self, x, w, alpha, mask, mask_act, mask_bits=None):
-        K = _K()
-        if mask_bits is not None:
-            return K.conv2d_fwd_mask(x, w, self.ksize, self.stride, alpha, None, mask_act, mask_bits=mask_bits)
         if hasattr(K, "conv2d_fwd_mask"):
             return K.conv2d_fwd_mask(x, w, self.ksize, self.stride, alpha, mask, mask_act)
         return K.act_bwd(self.fwd(x, w, alpha), mask, mask_act)
@@ -129,9 +116,7 @@ class _ConvKind(object):
     def bwd_data(self, gy, w, x_shape, alpha):
         return _K().conv2d_bwd_data(gy, w, x_shape, self.ksize, self.stride, alpha)
 
-    def bwd_data_mask(self, gy, w, x_shape, alpha, mask, mask_act, mask_bits=None):
-        if mask_bits is not None:
-            return _K().conv2d_bwd_data(gy, w, x_shape, self.ksize, self.stride, alpha, mask_act=mask_act, mask_bits=mask_bits)
+    def bwd_data_mask(self, gy, w, x_shape, alpha, mask, mask_act):
         return _K().conv2d_bwd_data(gy, w, x_shape, self.ksize, self.stride, alpha, mask=mask, mask_act=mask_act)
 
     def bwd_data_pnbwd(self, gy, w, x_shape, alpha, z, eps, act, addend):
@@ -350,19 +335,6 @@ def _take_premasked(ctx, gz):
     return ptr is not None and ptr == gz.data_ptr()
 
 
-_SIGN_BITS = not __import__("os").environ.get("GS_NO_SIGN_BITS")   # A/B switch
-
-
-def _sign_bits_for(kind, role, x, ci, co, dtype):
-    """Sign words of the activation tensor x, left by the conv that produced it (_ConvBiasAct.forward), when this masked conv can read
-    them instead of x itself."""
-    fn = x.grad_fn
-    bits = getattr(fn, "_gs_sign_bits", None) if fn is not None else None
-    if bits is None or not hasattr(kind, "mask_bits_ok") or not kind.mask_bits_ok(role, ci, co, dtype):
-        return None
-    return bits
-
-
 _KINDS = {}
 
 
@@ -459,9 +431,6 @@ class _BwdDataMasked(Function):
         up = gy.grad_fn
         ctx._gs_up = up if (isinstance(up, _BwdDataMasked._backward_cls) and not _want_params() and hasattr(kind, "fwd_mask") and not _NO_PREMASK_GRAPH2) else None
         ctx._gs_gg_premasked = None
-        bits = _sign_bits_for(kind, "bwd_data", x, x.shape[1], gy.shape[1], gy.dtype)
-        if bits is not None:
-            return kind.bwd_data_mask(gy, w, x.shape, alpha, None, act, mask_bits=bits)
         return kind.bwd_data_mask(gy, w, x.shape, alpha, x, act)
 
     @staticmethod
@@ -474,9 +443,7 @@ class _BwdDataMasked(Function):
             t = _ActBwd.apply(gg, x, ctx.act)
         up = ctx._gs_up
         if up is not None and ctx.needs_input_grad[0] and not torch.is_grad_enabled():
-            ux = up.saved_tensors[2]
-            bits = _sign_bits_for(ctx.kind, "fwd", ux, t.shape[1], ux.shape[1], t.dtype)
-            g_gy = ctx.kind.fwd_mask(t, w, ctx.alpha, ux, up.act, mask_bits=bits) if bits is not None else ctx.kind.fwd_mask(t, w, ctx.alpha, ux, up.act)
+            g_gy = ctx.kind.fwd_mask(t, w, ctx.alpha, up.saved_tensors[2], up.act)
             up._gs_gg_premasked = g_gy.data_ptr()
         else:
             g_gy = _Bilinear.apply(t, w, ctx.kind, ctx.alpha) if ctx.needs_input_grad[0] else None
@@ -537,11 +504,7 @@ class _ConvBiasAct(Function):
         ctx.input_normed = bool(input_normed)   # x is pixel_norm(.) out of a _ConvBiasActNorm node, this conv its only consumer (see _GZ)
         ctx._gs_act_out = act      # what consumers of z may fold into their own kernels
         ctx._gs_premasked = None
-        ctx._gs_sign_bits = None   # sign words of z for the masked convs of the backward passes (when the kernel layer has them)
-        if act == ACT_LRELU and any(ctx.needs_input_grad) and hasattr(kind, "sign_bits_ok") and kind.sign_bits_ok(x.shape[1], w.shape[3], x.dtype):
-            z, ctx._gs_sign_bits = kind.fwd_bias_act(x, w, bias, alpha, act, want_bits=True)
-        else:
-            z = kind.fwd_bias_act(x, w, bias, alpha, act)
+        z = kind.fwd_bias_act(x, w, bias, alpha, act)
         _tap(z, act)
         ctx.save_for_backward(x, w, z)
         return z
@@ -573,8 +536,7 @@ class _ConvBiasAct(Function):
             if torch.is_grad_enabled():   # create_graph: the same fusion as a differentiable Function
                 gx_ = _BwdDataMasked.apply(gy, w, x, ctx.kind, ctx.alpha, ctx.in_act)
             else:
-                bits = _sign_bits_for(ctx.kind, "bwd_data", x, x.shape[1], gy.shape[1], gy.dtype)
-                gx_ = ctx.kind.bwd_data_mask(gy, w, x.shape, ctx.alpha, None if bits is not None else x, ctx.in_act, mask_bits=bits)
+                gx_ = ctx.kind.bwd_data_mask(gy, w, x.shape, ctx.alpha, x, ctx.in_act)
             prod._gs_premasked = gx_.data_ptr()
             return gx_
 

@@ -289,46 +289,24 @@ class HipKernels(object):
     def conv2d_fwd(self, x, w, ksize, stride, alpha):
         return self.conv2d_fwd_bias_act(x, w, None, ksize, stride, alpha, _lib.ACT_NONE)
 
-    def conv2d_fwd_mask(self, x, w, ksize, stride, alpha, mask, mask_act, mask_bits=None):
+    def conv2d_fwd_mask(self, x, w, ksize, stride, alpha, mask, mask_act):
         """conv2d_fwd(x, w) * mask_act'(.) through `mask` (an activation output of the result's shape) in one pass."""
-        x, w = _act(x), _f32c(w)
+        x, w, mask = _act(x), _f32c(w), _act(mask)
         n, ci, h, wd = x.shape
         co = w.shape[3]
         y = _empty_like_act((n, co, h // stride, wd // stride), x)
-        if mask_bits is not None:
-            assert mask_bits.dtype == torch.int16 and mask_bits.numel() * 16 == y.numel() and mask_bits.is_contiguous()
-            mask, mask_act = mask_bits, int(mask_act) | _lib.MASK_BITS
-        else:
-            mask = _act(mask)
-            assert mask.shape == y.shape and mask.dtype == y.dtype
+        assert mask.shape == y.shape and mask.dtype == y.dtype
         nb = self.lib.gs_conv2d_workspace_bytes(_lib.CONV_FWD, n, h, wd, ci, co, ksize, stride, _dt(x))
         ws, prepared = self._weight_ws(w, ("fwd", ksize, stride, _dt(x)), nb, (_lib.PREP_CONV_FWD, ci, co, ksize, stride, _dt(x)))
         _lib.check(self.lib.gs_conv2d_fwd_mask(x.data_ptr(), w.data_ptr(), mask.data_ptr(), int(mask_act), y.data_ptr(), n, h, wd, ci, co, ksize, stride,
                                                float(alpha), _dt(x), prepared, ws.data_ptr(), ws.numel(), _stream()), "gs_conv2d_fwd_mask")
         return y
 
-    # ---- sign-bit masks (gansynth_hip.h): the forward conv's leaky-relu output as one bit per element for the masked convs of the backward
-    def sign_bits_ok(self, ci, co, ksize, stride, dtype):
-        return not os.environ.get("GS_NO_SIGN_BITS") and bool(self.lib.gs_conv2d_sign_bits_ok(int(ci), int(co), int(ksize), int(stride), GS_F32 if dtype == torch.float32 else GS_BF16))
-
-    def mask_bits_ok(self, role, ci, co, ksize, stride, dtype):
-        fn = self.lib.gs_conv2d_bwd_data_mask_bits_ok if role == "bwd_data" else self.lib.gs_conv2d_fwd_mask_bits_ok
-        return bool(fn(int(ci), int(co), int(ksize), int(stride), GS_F32 if dtype == torch.float32 else GS_BF16))
-
-    def conv2d_fwd_bias_act(self, x, w, bias, ksize, stride, alpha, act, want_bits=False):
-        """want_bits: -> (y, sign words of y [n, ho, wo, co / 16] int16); the caller has asked sign_bits_ok."""
+    def conv2d_fwd_bias_act(self, x, w, bias, ksize, stride, alpha, act):
         x, w = _act(x), _f32c(w)
         n, ci, h, wd = x.shape
         co = w.shape[3]
         y = _empty_like_act((n, co, h // stride, wd // stride), x)
-        if want_bits:
-            nb = self.lib.gs_conv2d_workspace_bytes(_lib.CONV_FWD, n, h, wd, ci, co, ksize, stride, _dt(x))
-            ws, prepared = self._weight_ws(w, ("fwd", ksize, stride, _dt(x)), nb, (_lib.PREP_CONV_FWD, ci, co, ksize, stride, _dt(x)))
-            bits = torch.empty((n, h // stride, wd // stride, co // 16), dtype=torch.int16, device=x.device)
-            _lib.check(self.lib.gs_conv2d_fwd_bias_act_bits(x.data_ptr(), w.data_ptr(), None if bias is None else _f32c(bias).data_ptr(), y.data_ptr(), bits.data_ptr(),
-                                                            n, h, wd, ci, co, ksize, stride, float(alpha), act, _dt(x), prepared, ws.data_ptr(), ws.numel(), _stream()),
-                       "gs_conv2d_fwd_bias_act_bits")
-            return y, bits
         nb = self.lib.gs_conv2d_workspace_bytes(_lib.CONV_FWD, n, h, wd, ci, co, ksize, stride, _dt(x))
         ws, prepared = self._weight_ws(w, ("fwd", ksize, stride, _dt(x)), nb, (_lib.PREP_CONV_FWD, ci, co, ksize, stride, _dt(x)))
         bp = None
@@ -376,9 +354,9 @@ class HipKernels(object):
                                                                      ws.data_ptr(), ws.numel(), _stream()), "gs_conv2d_transpose_s2_fwd_bias_act_norm")
         return z, y
 
-    def conv2d_bwd_data(self, gy, w, x_shape, ksize, stride, alpha, mask=None, mask_act=0, mask_bits=None):
+    def conv2d_bwd_data(self, gy, w, x_shape, ksize, stride, alpha, mask=None, mask_act=0):
         """gx, or with `mask` (the conv's forward input, itself the output of activation `mask_act`) gx * act'(.): the data
-        gradient w.r.t. the previous layer's pre-activation in one pass.  `mask_bits`: that tensor's sign words instead (mask_bits_ok)."""
+        gradient w.r.t. the previous layer's pre-activation in one pass."""
         gy, w = _act(gy), _f32c(w)
         n, ci, h, wd = x_shape
         co = w.shape[3]
@@ -386,10 +364,7 @@ class HipKernels(object):
         nb = self.lib.gs_conv2d_workspace_bytes(_lib.CONV_BWD_DATA, n, h, wd, ci, co, ksize, stride, _dt(gy))
         ws, prepared = self._weight_ws(w, ("bwd_data", ksize, stride, _dt(gy)), nb, (_lib.PREP_CONV_BWD_DATA, ci, co, ksize, stride, _dt(gy)))
         mp = None
-        if mask_bits is not None:
-            assert mask_bits.dtype == torch.int16 and mask_bits.numel() * 16 == gx.numel() and mask_bits.is_contiguous()
-            mp, mask_act = mask_bits.data_ptr(), int(mask_act) | _lib.MASK_BITS
-        elif mask is not None:
+        if mask is not None:
             mask = _act(mask)
             assert mask.shape == gx.shape and mask.dtype == gx.dtype
             mp = mask.data_ptr()

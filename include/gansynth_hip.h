@@ -34,9 +34,6 @@ extern "C" {
 enum { GS_F32 = 0, GS_BF16 = 1 };
 enum { GS_OK = 0, GS_ERR_ARG = -1, GS_ERR_HIP = -2, GS_ERR_UNSUPPORTED = -3, GS_ERR_WORKSPACE = -4 };
 enum { GS_ACT_NONE = 0, GS_ACT_LRELU = 1, GS_ACT_TANH = 2 };
-/* or-ed into the `mask_act` of gs_conv2d_bwd_data_mask / gs_conv2d_fwd_mask: `mask` points to SIGN BITS of the leaky-relu output (see
- * gs_conv2d_fwd_bias_act_bits) instead of the output itself */
-enum { GS_MASK_BITS = 0x100 };
 /* which of the three bilinear conv maps a workspace query is for */
 enum { GS_CONV_FWD = 0, GS_CONV_BWD_DATA = 1, GS_CONV_BWD_WEIGHT = 2 };
 
@@ -125,18 +122,6 @@ int gs_conv2d_transpose_s2_fwd_bias_act_norm(const void* x, const float* w_hwio,
  * previous layer disappears).  mask NULL = gs_conv2d_bwd_data. */
 int gs_conv2d_bwd_data_mask(const void* gy, const float* w_hwio, const void* mask, int mask_act, void* gx, int n, int h, int w, int ci, int co,
                             int ksize, int stride, float alpha, int dtype, int w_prepared, void* ws, size_t ws_bytes, void* stream);
-/* Sign-bit masks.  The masked convs of the backward passes (tf.gradients through tf.nn.leaky_relu, ops.py:244-246 / networks.py:173-228) need
- * of the activation output only its sign: the forward conv can write, beside y, one 16-bit word per (pixel, 32-channel tile, half) --
- * word index = element offset / 16 + 2 tile + half, bit k = sign of the k-th of the 16 values that (pixel, half) owns in the MFMA epilogue's
- * store layout (bf16: channel 32 tile + 16 (k / 8) + 8 half + k % 8; fp32: 32 tile + 8 (k / 4) + 4 half + k % 4); [n h w co / 16] words.
- * gs_conv2d_bwd_data_mask / gs_conv2d_fwd_mask take them with mask_act = GS_ACT_LRELU | GS_MASK_BITS where *_mask_bits_ok says 1
- * (mask applied in the MFMA epilogue): 1/16 of the mask bytes of a bf16 tensor. */
-int gs_conv2d_sign_bits_ok(int ci, int co, int ksize, int stride, int dtype);
-int gs_conv2d_fwd_bias_act_bits(const void* x, const float* w_hwio, const float* bias, void* y, void* bits, int n, int h, int w, int ci, int co,
-                                int ksize, int stride, float alpha, int act, int dtype, int w_prepared, void* ws, size_t ws_bytes, void* stream);
-int gs_conv2d_bwd_data_mask_bits_ok(int ci, int co, int ksize, int stride, int dtype);
-int gs_conv2d_fwd_mask_bits_ok(int ci, int co, int ksize, int stride, int dtype);
-
 /* The same on the forward map: y = conv2d(x, w) * act'(.)|mask with mask of y's shape (the second-order pass of a gradient penalty
  * runs the convs forward on cotangents; each result meets the derivative of the activation that follows that conv). */
 int gs_conv2d_fwd_mask(const void* x, const float* w_hwio, const void* mask, int mask_act, void* y, int n, int h, int w, int ci, int co,

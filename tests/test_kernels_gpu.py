@@ -877,83 +877,3 @@ def test_dense_units_to_channels_last_in_the_activation_pass(K, shape, dtype):
     # <gu, ggu> == <g, gg>: the two maps are adjoint
     a, b = float((gu.double() * ggu.double()).sum()), float((g.double() * gg.double()).sum())
     assert abs(a - b) <= (1e-6 if dtype == torch.float32 else 2e-2) * max(1.0, abs(a))
-
-
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("case", [(8, 32, 32, 128, 1024, 1), (8, 32, 64, 128, 1024, 2), (8, 64, 64, 64, 512, 1), (2, 256, 256, 8, 64, 1), (2, 128, 256, 32, 64, 2),
-                                  (3, 64, 96, 6, 40, 1), (2, 32, 32, 5, 7, 1)])
-def test_sign_bit_masks(K, case, dtype):
-    """gs_conv2d_fwd_bias_act_bits writes, beside y, the sign of every element of the leaky-relu output as one bit (gansynth_hip.h: word and bit
-    order of the MFMA epilogue's store layout); gs_conv2d_bwd_data_mask / gs_conv2d_fwd_mask with GS_MASK_BITS give BIT-IDENTICAL results
-    to the same calls with the tensor itself as the mask."""
-    n, ci, co, h, w, stride = case
-    if dtype == torch.float32 and ci % 16 or dtype == torch.bfloat16 and ci % 32:
-        pytest.skip("no MFMA path")
-    gen = torch.Generator(device="cuda").manual_seed(9)
-    CL = torch.channels_last
-    x = torch.randn(n, ci, h, w, device="cuda", generator=gen).to(dtype).contiguous(memory_format=CL)
-    wt = torch.randn(3, 3, ci, co, device="cuda", generator=gen)
-    bias = torch.randn(co, device="cuda", generator=gen)
-    assert K.sign_bits_ok(ci, co, 3, stride, dtype)
-    y, bits = K.conv2d_fwd_bias_act(x, wt, bias, 3, stride, 0.05, 1, want_bits=True)
-    assert torch.equal(y, K.conv2d_fwd_bias_act(x, wt, bias, 3, stride, 0.05, 1))
-    # decode: word [pixel][2 tile + half], bit k
-    ho, wo = h // stride, w // stride
-    words = bits.view(n, ho, wo, co // 32, 2).to(torch.int32) & 0xffff
-    k = torch.arange(16, device="cuda")
-    if dtype == torch.bfloat16:
-        chan = lambda half: 16 * (k // 8) + 8 * half + k % 8
-    else:
-        chan = lambda half: 8 * (k // 4) + 4 * half + k % 4
-    sign = torch.zeros(n, ho, wo, co, dtype=torch.bool, device="cuda")
-    for half in (0, 1):
-        b = ((words[..., half].unsqueeze(-1) >> k) & 1).bool()                 # [n, ho, wo, tiles, 16]
-        idx = (32 * torch.arange(co // 32, device="cuda").unsqueeze(-1) + chan(half)).reshape(-1)
-        sign[..., idx] = b.reshape(n, ho, wo, -1)
-    assert torch.equal(sign, (y > 0).permute(0, 2, 3, 1))
-    # consumers: y as the mask of a data gradient INTO y's shape (the next conv's backward) and of a forward conv ONTO y's shape
-    for s2 in (1, 2):
-        if co % (16 if dtype == torch.float32 else 32) or not K.mask_bits_ok("bwd_data", co, 64, 3, s2, dtype):
-            continue
-        if ho % s2 or wo % s2:
-            continue
-        w2 = torch.randn(3, 3, co, 64, device="cuda", generator=gen)
-        gy = torch.randn(n, 64, ho // s2, wo // s2, device="cuda", generator=gen).to(dtype).contiguous(memory_format=CL)
-        a = K.conv2d_bwd_data(gy, w2, (n, co, ho, wo), 3, s2, 0.03, mask=y, mask_act=1)
-        b = K.conv2d_bwd_data(gy, w2, (n, co, ho, wo), 3, s2, 0.03, mask_act=1, mask_bits=bits)
-        assert torch.equal(a, b), ("bwd_data", s2)
-    if K.mask_bits_ok("fwd", ci, co, 3, stride, dtype):
-        t = torch.randn(n, ci, h, w, device="cuda", generator=gen).to(dtype).contiguous(memory_format=CL)
-        a = K.conv2d_fwd_mask(t, wt, 3, stride, 0.05, y, 1)
-        b = K.conv2d_fwd_mask(t, wt, 3, stride, 0.05, None, 1, mask_bits=bits)
-        assert torch.equal(a, b), "fwd_mask"
-
-
-@pytest.mark.parametrize("shape", [(8, 2, 32, 128, 1024), (2, 2, 64, 16, 128), (3, 1, 32, 5, 7)])
-def test_sign_bit_words_from_the_colour_block(K, shape):
-    """The discriminator's colour block (1x1, 2 -> 32 channels, leaky relu: networks.py:231-242) in bf16 writes the same sign words as the MFMA
-    epilogues -- the first 3x3 conv's masked data gradient reads them: same result as with the tensor as the mask."""
-    n, ci, co, h, w = shape
-    dtype = torch.bfloat16
-    gen = torch.Generator(device="cuda").manual_seed(4)
-    CL = torch.channels_last
-    x = torch.randn(n, ci, h, w, device="cuda", generator=gen).to(dtype).contiguous(memory_format=CL)
-    wt = torch.randn(1, 1, ci, co, device="cuda", generator=gen)
-    bias = torch.randn(co, device="cuda", generator=gen)
-    assert K.sign_bits_ok(ci, co, 1, 1, dtype)
-    y, bits = K.conv2d_fwd_bias_act(x, wt, bias, 1, 1, 0.7, 1, want_bits=True)
-    assert torch.equal(y, K.conv2d_fwd_bias_act(x, wt, bias, 1, 1, 0.7, 1))
-    words = bits.view(n, h, w, co // 32, 2).to(torch.int32) & 0xffff
-    k = torch.arange(16, device="cuda")
-    sign = torch.zeros(n, h, w, co, dtype=torch.bool, device="cuda")
-    for half in (0, 1):
-        b = ((words[..., half].unsqueeze(-1) >> k) & 1).bool()
-        idx = (32 * torch.arange(co // 32, device="cuda").unsqueeze(-1) + 16 * (k // 8) + 8 * half + k % 8).reshape(-1)
-        sign[..., idx] = b.reshape(n, h, w, -1)
-    assert torch.equal(sign, (y > 0).permute(0, 2, 3, 1))
-    w2 = torch.randn(3, 3, co, 32, device="cuda", generator=gen)
-    gy = torch.randn(n, 32, h, w, device="cuda", generator=gen).to(dtype).contiguous(memory_format=CL)
-    assert K.mask_bits_ok("bwd_data", co, 32, 3, 1, dtype)
-    a = K.conv2d_bwd_data(gy, w2, (n, co, h, w), 3, 1, 0.03, mask=y, mask_act=1)
-    b = K.conv2d_bwd_data(gy, w2, (n, co, h, w), 3, 1, 0.03, mask_act=1, mask_bits=bits)
-    assert torch.equal(a, b)
