@@ -527,7 +527,12 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void conv_igemm_kernel(const Conv
                             for (int qd = 0; qd < 4; ++qd) {
                                 if (mz) {
                                     const float4 zv = mz[qd];
-                                    o[qd][0] *= mask_factor(zv.x); o[qd][1] *= mask_factor(zv.y); o[qd][2] *= mask_factor(zv.z); o[qd][3] *= mask_factor(zv.w);
+                                    if (p.mask_act == GS_ACT_LRELU) {   // (the common case by itself: compare, scale, select per value)
+                                        o[qd][0] = zv.x > 0.f ? o[qd][0] : 0.2f * o[qd][0]; o[qd][1] = zv.y > 0.f ? o[qd][1] : 0.2f * o[qd][1];
+                                        o[qd][2] = zv.z > 0.f ? o[qd][2] : 0.2f * o[qd][2]; o[qd][3] = zv.w > 0.f ? o[qd][3] : 0.2f * o[qd][3];
+                                    } else {
+                                        o[qd][0] *= mask_factor(zv.x); o[qd][1] *= mask_factor(zv.y); o[qd][2] *= mask_factor(zv.z); o[qd][3] *= mask_factor(zv.w);
+                                    }
                                 }
                                 if (inside) st4(reinterpret_cast<float*>(dst) + off + a * 32 + qd * 8 + hi * 4, o[qd]);
                             }
@@ -543,10 +548,21 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void conv_igemm_kernel(const Conv
                                 }
                                 if (mz) {   // the lane's 8 channels of the mask sit where its 16 bytes go
                                     const uint4 zv = mz[qp];
-                                    lo[0] *= mask_factor(__uint_as_float(zv.x << 16)); lo[1] *= mask_factor(__uint_as_float(zv.x & 0xffff0000u));
-                                    lo[2] *= mask_factor(__uint_as_float(zv.y << 16)); lo[3] *= mask_factor(__uint_as_float(zv.y & 0xffff0000u));
-                                    hi4[0] *= mask_factor(__uint_as_float(zv.z << 16)); hi4[1] *= mask_factor(__uint_as_float(zv.z & 0xffff0000u));
-                                    hi4[2] *= mask_factor(__uint_as_float(zv.w << 16)); hi4[3] *= mask_factor(__uint_as_float(zv.w & 0xffff0000u));
+                                    if (p.mask_act == GS_ACT_LRELU) {
+                                        // z > 0 on the packed pair: low half shifted up and compared as an integer, high half in place (>= 0x10000: sign
+                                        // clear, magnitude bits not all zero); compare, scale, select per value
+#define GS_LR(V, Z) V = (int)((Z) << 16) > 0 ? V : 0.2f * V
+#define GS_HR(V, Z) V = (int)(Z) >= 0x10000 ? V : 0.2f * V
+                                        GS_LR(lo[0], zv.x); GS_HR(lo[1], zv.x); GS_LR(lo[2], zv.y); GS_HR(lo[3], zv.y);
+                                        GS_LR(hi4[0], zv.z); GS_HR(hi4[1], zv.z); GS_LR(hi4[2], zv.w); GS_HR(hi4[3], zv.w);
+#undef GS_LR
+#undef GS_HR
+                                    } else {
+                                        lo[0] *= mask_factor(__uint_as_float(zv.x << 16)); lo[1] *= mask_factor(__uint_as_float(zv.x & 0xffff0000u));
+                                        lo[2] *= mask_factor(__uint_as_float(zv.y << 16)); lo[3] *= mask_factor(__uint_as_float(zv.y & 0xffff0000u));
+                                        hi4[0] *= mask_factor(__uint_as_float(zv.z << 16)); hi4[1] *= mask_factor(__uint_as_float(zv.z & 0xffff0000u));
+                                        hi4[2] *= mask_factor(__uint_as_float(zv.w << 16)); hi4[3] *= mask_factor(__uint_as_float(zv.w & 0xffff0000u));
+                                    }
                                 }
                                 uint4 v;
                                 v.x = pack_bf16x2(lo[0], lo[1]); v.y = pack_bf16x2(lo[2], lo[3]);
