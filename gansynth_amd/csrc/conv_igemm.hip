@@ -109,6 +109,10 @@ struct ConvP {
     int normbwd;        // host side: the caller asks for the NORM == 2 epilogue; cleared (and *norm_pending = 2) when the chosen kernel has none
     int* norm_pending;  // host side: set to 1 when the chosen kernel did not fuse the norm
     int N, Hi, Wi, IC, OC, Hb, Wb, tiles_x, tiles_y, nsp, noct, nch;
+    // ceil(2^32 / d) for d = noct, tiles_x, tiles_y (0 for d = 1): item -> (image, tile row, tile column, channel tile) with one s_mul_hi_u32 per
+    // division instead of the ~20 scalar instructions of a signed division each -- on the 32-channel layers (36 MFMAs per tile) the tile's time
+    // IS its instruction count (a wave issues one instruction per ~5 cycles), and an item is decoded twice (issue cursor, compute side)
+    unsigned m_noct, m_tx, m_ty;
     float alpha;
 #ifdef GS_IGEMM_TRACE
     unsigned long long* trace;  // [block][64] shader-clock stamps of wave 0 (scripts/probe/igemm_trace.hip)
@@ -286,13 +290,16 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void conv_igemm_kernel(const Conv
     const unsigned a_wave = wv * 1024;
 
     auto item_coords = [&](int item, int& n, int& by, int& bx, int& oc0) __attribute__((always_inline)) {
-        const int sp = item / p.noct;
-        oc0 = (item - sp * p.noct) * OCT;
-        const int tile_x = sp % p.tiles_x;
-        const int r = sp / p.tiles_x;
-        by = (r % p.tiles_y) * TH;
+        // (exact: item < 2^21 and every divisor < 2^11, so item * (m d - 2^32) < 2^32)
+        const unsigned it = (unsigned)item;
+        const unsigned sp = p.m_noct ? __umulhi(it, p.m_noct) : it;
+        oc0 = (int)(it - sp * (unsigned)p.noct) * OCT;
+        const unsigned r = p.m_tx ? __umulhi(sp, p.m_tx) : sp;
+        const int tile_x = (int)(sp - r * (unsigned)p.tiles_x);
+        const unsigned nn = p.m_ty ? __umulhi(r, p.m_ty) : r;
+        by = (int)(r - nn * (unsigned)p.tiles_y) * TH;
         bx = tile_x * TW;
-        n = r / p.tiles_y;
+        n = (int)nn;
     };
 
     // ---- issue side: cursor over (item, chunk); the tap group is a compile-time value at every call site
@@ -1631,6 +1638,12 @@ static int launch_igemm(ConvP p, hipStream_t st) {
     p.nsp = p.N * p.tiles_x * p.tiles_y;
     p.noct = cdiv(p.OC, OCT);
     p.nch = p.IC / BK;
+    {   // reciprocals for the kernel's item decoding (see ConvP): exact while items < 2^21 and divisors < 2^11
+        auto magic = [](int d) { return d <= 1 ? 0u : (unsigned)(((1ull << 32) + (unsigned)d - 1) / (unsigned)d); };
+        if ((long)p.nsp * p.noct >= (1L << 21) || p.noct >= 2048 || p.tiles_x >= 2048 || p.tiles_y >= 2048)
+            return fail(GS_ERR_UNSUPPORTED, "conv igemm: %ld work items / %d x %d tiles exceed the item decoder's range", (long)p.nsp * p.noct, p.tiles_x, p.tiles_y);
+        p.m_noct = magic(p.noct); p.m_tx = magic(p.tiles_x); p.m_ty = magic(p.tiles_y);
+    }
     const int wbufs = RESIDENT ? p.nch : NWB;
     const size_t lds = (size_t)NPB * PBUF + (size_t)wbufs * WBUF + (size_t)((p.OC + 3) / 4) * 16 + 0;
     if (p.OC % OCT != 0) return fail(GS_ERR_UNSUPPORTED, "conv igemm: %d output channels with %d-wide tiles", p.OC, OCT);
