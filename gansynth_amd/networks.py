@@ -247,7 +247,6 @@ class PGGAN(object):
         num_labels = labels.shape[1]
         with variable_scope(name, reuse=reuse):
             self._d_variables(num_labels)
-            head, _ = self._head_depth(self.growing_depth)
             for d in range(depth, self.min_depth, -1):
                 x = self._d_conv_block(x, d, num_labels, fresh_activation=fresh)
                 fresh = True
