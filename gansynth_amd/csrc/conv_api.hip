@@ -131,8 +131,11 @@ __device__ inline float thin_act(float v, int act) {
 // few -> many channels: y[p][oc] = act(alpha * sum_ic x[p][ic] wp[oc][ic] + bias[oc]),  IC <= 4, OC % Wide::N == 0, 256 % (OC / N) == 0.
 // A thread keeps its Wide::N output channels (weights + bias in registers) and strides over pixels.
 template <typename T, int IC>
+// `mask` (optional, y's shape): y *= mask_act'(.) through that activation output -- the second-order pass of the R1 penalty runs the colour
+// block forward on a cotangent and the next node's first step is that multiplication (gs_conv2d_fwd_mask)
 __global__ __launch_bounds__(256) void thin_expand_kernel(const T* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
-                                                          T* __restrict__ y, long P, int OC, float alpha, int act) {
+                                                          T* __restrict__ y, long P, int OC, float alpha, int act,
+                                                          const T* __restrict__ mask = nullptr, int mask_act = 0) {
     constexpr int WN = Wide<T>::N;
     const int groups = OC / WN;
     const int oc0 = (threadIdx.x % groups) * WN;
@@ -173,6 +176,12 @@ __global__ __launch_bounds__(256) void thin_expand_kernel(const T* __restrict__ 
 #pragma unroll
             for (int i = 0; i < IC; ++i) a += xv[i] * wr[v][i];
             o[v] = thin_act(a, act);
+        }
+        if (mask) {
+            float mv[WN];
+            ld_wide<T>(mask + px * OC + oc0, mv);
+#pragma unroll
+            for (int v = 0; v < WN; ++v) o[v] *= mask_act == GS_ACT_LRELU ? (mv[v] > 0.f ? 1.f : 0.2f) : (mask_act == GS_ACT_TANH ? 1.f - mv[v] * mv[v] : 1.f);
         }
         st_wide<T>(y + px * OC + oc0, o);
     };
@@ -427,7 +436,8 @@ __global__ __launch_bounds__(256) void thin_single3_kernel(const T* __restrict__
 // direct conv through the fp32 prepped weights living in ws; *fused is set when bias / act went into the same pass
 static int run_direct(int mode, int ks, int variant, const void* x, const float* w_hwio, void* y, int N, int Hi, int Wi,
                       int ICk, int OCk, int w_ci, int w_co, int Ho, int Wo, float alpha, int dtype, int w_prepared, void* ws,
-                      size_t ws_bytes, hipStream_t st, const float* bias = nullptr, int act = GS_ACT_NONE, bool* fused = nullptr) {
+                      size_t ws_bytes, hipStream_t st, const float* bias = nullptr, int act = GS_ACT_NONE, bool* fused = nullptr,
+                      const void* mask = nullptr, int mask_act = 0, bool* mask_fused = nullptr) {
     const long total = (long)ks * ks * w_ci * w_co;
     if (ws_bytes < (size_t)total * 4) return fail(GS_ERR_WORKSPACE, "conv direct: workspace %zu < %zu", ws_bytes, (size_t)total * 4);
     float* wp = reinterpret_cast<float*>(ws);
@@ -444,12 +454,13 @@ static int run_direct(int mode, int ks, int variant, const void* x, const float*
         static const long te_cap = getenv("GS_THIN_EXPAND_BLOCKS") ? atol(getenv("GS_THIN_EXPAND_BLOCKS")) : 2048;
         if (nb > te_cap) nb = te_cap;
         const unsigned grid = (unsigned)nb;
-#define GS_TE(TT, ICV) hipLaunchKernelGGL((thin_expand_kernel<TT, ICV>), dim3(grid), dim3(256), 0, st, (const TT*)x, wp, bias, (TT*)y, P, OCk, alpha, act)
+#define GS_TE(TT, ICV) hipLaunchKernelGGL((thin_expand_kernel<TT, ICV>), dim3(grid), dim3(256), 0, st, (const TT*)x, wp, bias, (TT*)y, P, OCk, alpha, act, (const TT*)mask, mask_act)
 #define GS_TE_ALL(TT) do { if (ICk == 1) GS_TE(TT, 1); else if (ICk == 2) GS_TE(TT, 2); else if (ICk == 3) GS_TE(TT, 3); else GS_TE(TT, 4); } while (0)
         GS_DISPATCH_DTYPE(dtype, GS_TE_ALL(T));
 #undef GS_TE_ALL
 #undef GS_TE
         GS_CHECK_LAUNCH();
+        if (mask_fused) *mask_fused = mask != nullptr;
         if (fused) *fused = true;
         else if (bias || act != GS_ACT_NONE) return fail(GS_ERR_ARG, "conv direct: epilogue requested without a fused flag");
         return 0;
@@ -831,8 +842,11 @@ extern "C" int gs_conv2d_fwd_mask(const void* x, const float* w_hwio, const void
     int rc;
     if (ksize == 3 && igemm_supported(ci, co, dtype))
         rc = run_igemm(mode, 0, x, w_hwio, y, n, h, w, ci, co, ci, co, hb, wb, alpha, nullptr, GS_ACT_NONE, dtype, w_prepared, ws, ws_bytes, st, fused ? mask : nullptr, mask_act);
-    else
-        rc = run_direct(mode, ksize, 0, x, w_hwio, y, n, h, w, ci, co, ci, co, hb, wb, alpha, dtype, w_prepared, ws, ws_bytes, st);
+    else {   // (the colour block's streaming kernel applies the mask itself; the other direct kernels leave it to the pass below)
+        bool epi = false, mdone = false;
+        rc = run_direct(mode, ksize, 0, x, w_hwio, y, n, h, w, ci, co, ci, co, hb, wb, alpha, dtype, w_prepared, ws, ws_bytes, st, nullptr, GS_ACT_NONE, &epi, mask, mask_act, &mdone);
+        if (rc || !mask || mdone) return rc;
+    }
     if (rc || !mask || fused) return rc;
     return gs_act_bwd(y, mask, y, (int64_t)n * hb * wb * co, mask_act, dtype, stream);
 }

@@ -384,6 +384,9 @@ class _BilinearBwdData(Function):
         ctx.kind, ctx.alpha, ctx.wref = kind, alpha, w
         ctx.sole_consumer = bool(sole_consumer)   # gy comes straight out of a _PnActBwd node and feeds nothing else (caller's promise)
         ctx.save_for_backward(gy, w)
+        # (the end of the R1 pass's chain of _BwdDataMasked nodes -- the colour block's data gradient: see _BwdDataMasked.forward)
+        up = gy.grad_fn
+        ctx._gs_up = up if (isinstance(up, _BwdDataMasked._backward_cls) and not _want_params() and hasattr(kind, "fwd_mask") and not _NO_PREMASK_GRAPH2) else None
         return kind.bwd_data(gy, w, x_shape, alpha)
 
     @staticmethod
@@ -399,6 +402,10 @@ class _BilinearBwdData(Function):
                 g, z = pn.saved_tensors
                 g_z, g_gy = ctx.kind.fwd_pnbwdbwd(ggx, w, ctx.alpha, g, z, pn.eps, pn.act)
                 pn._gs_done = (g_gy.data_ptr(), g_z)
+            elif ctx._gs_up is not None and not torch.is_grad_enabled():
+                up = ctx._gs_up   # the node that produced gy multiplies its cotangent by its mask first: in this conv's epilogue instead
+                g_gy = ctx.kind.fwd_mask(ggx, w, ctx.alpha, up.saved_tensors[2], up.act)
+                up._gs_gg_premasked = g_gy.data_ptr()
             else:
                 g_gy = _Bilinear.apply(ggx, w, ctx.kind, ctx.alpha)
         g_w = None

@@ -877,3 +877,19 @@ def test_dense_units_to_channels_last_in_the_activation_pass(K, shape, dtype):
     # <gu, ggu> == <g, gg>: the two maps are adjoint
     a, b = float((gu.double() * ggu.double()).sum()), float((g.double() * gg.double()).sum())
     assert abs(a - b) <= (1e-6 if dtype == torch.float32 else 2e-2) * max(1.0, abs(a))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(8, 2, 32, 128, 1024), (2, 2, 64, 16, 128), (3, 1, 32, 5, 7), (2, 3, 8, 4, 4)])
+def test_colour_block_forward_with_the_next_node_s_mask(K, shape, dtype):
+    """gs_conv2d_fwd_mask on the 1x1 colour -> features conv (second-order pass of the R1 term): the streaming kernel multiplies by
+    leaky_relu'(.) through the mask itself -- same values as the conv followed by gs_act_bwd (one rounding instead of two in bf16)."""
+    n, ci, co, h, w = shape
+    gen = torch.Generator(device="cuda").manual_seed(6)
+    CL = torch.channels_last
+    x = torch.randn(n, ci, h, w, device="cuda", generator=gen).to(dtype).contiguous(memory_format=CL)
+    wt = torch.randn(1, 1, ci, co, device="cuda", generator=gen)
+    mask = torch.randn(n, co, h, w, device="cuda", generator=gen).to(dtype).contiguous(memory_format=CL)
+    got = K.conv2d_fwd_mask(x, wt, 1, 1, 0.7, mask, 1)
+    want = (K.conv2d_fwd(x.float(), wt, 1, 1, 0.7) * torch.where(mask.float() > 0, 1.0, 0.2)).cpu()
+    close(got, want, rel=1e-6 if dtype == torch.float32 else 1e-2, name="colour block fwd mask")
