@@ -48,3 +48,45 @@ def test_gpu_count_mismatch_is_an_error():
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--launch-check"], cwd=ROOT, env=env,
                          capture_output=True, text=True, timeout=300)
     assert res.returncode != 0 and "WORLD_SIZE=1" in (res.stderr + res.stdout)
+
+
+def test_bench_line_stays_parseable():
+    """The driver parses the LAST stdout line out of a bounded tail (round 3: a 20.7 KB line carrying the per-stage table came back
+    `parsed: null`).  Assemble the record from a canned measurement set -- the 59 stage rows of the committed round-3 run -- and
+    check the line is compact and carries the contract's members; the per-stage table goes to the detail object."""
+    import argparse
+    sys.path.insert(0, ROOT)
+    import bench
+    canned = json.loads(open(os.path.join(ROOT, "profiles", "r03_j_bf16_bench.json")).read().strip().splitlines()[-1])
+    stages = canned["stages"]
+    assert len(stages) >= 50
+    for r in stages:   # (rows of round 3 carry no strict byte count: the helper falls back to `mbytes`)
+        assert bench.strict_8d_bytes(r) == r["mbytes"]
+    args = argparse.Namespace(batch=8, steps=20, warmup=5, dtype="bf16", no_graphs=False)
+    legs = {"spectral": canned["spectral"], "spectral_inverse": canned["spectral_inverse"], "cpu_baseline": canned["cpu_baseline"]}
+    fam = (3021, 59.85, 2.97e13, 1.565e11, 21.8, 16.4)
+    out, detail = bench.assemble(args, 1, False, 0.1267, 5, fam, stages, {"total": 381, "hip_extension": 361, "torch_native_and_copies": 20},
+                                 0.69, 0.7, legs)
+    out["detail"] = "profiles/last_bench_detail.json"
+    line = bench.compact_line(out)
+    assert len(line) < 4096, len(line)
+    rec = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline"):
+        assert k in rec, k
+    assert "stages" not in rec and len(detail["stages"]) == len(stages)
+    rl = rec["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "frac_strict_8d"):
+        assert k in rl, k
+    assert abs(rl["frac"] - 21.8 / 59.85) < 1e-9              # the per-launch binding-roof figure
+    assert 0 < rl["frac_strict_8d"] <= 1.0
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in rec["cpu_baseline"], k
+    for leg in ("spectral", "spectral_inverse"):
+        assert set(rec[leg]) <= {"value", "unit", "roofline", "cpu_baseline"}
+        assert {"bound", "achieved", "peak", "frac"} <= set(rec[leg]["roofline"])
+    assert abs(rec["value"] - 8 * 20 / 0.1267) < 1e-6
+    # a record that would still be too long loses optional members, never the contract's
+    fat = dict(out, junk="x" * 10000)
+    rec2 = json.loads(bench.compact_line(fat))
+    assert "junk" not in rec2 and "roofline" in rec2 and "cpu_baseline" in rec2
