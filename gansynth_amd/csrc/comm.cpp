@@ -88,9 +88,25 @@ extern "C" int gs_comm_destroy(gs_comm* c) {
     return 0;
 }
 
+// World size 1 is the only one the development box has, and RCCL short-cuts a one-rank in-place all-reduce to nothing -- no node in a
+// captured graph, nothing to see in a timeline.  GS_COMM_MARKER_US=<n> (tests / profiles only) puts a stand-in there: one block that
+// occupies the stream for n microseconds (0: a no-op kernel), so that where the collective sits in a graph -- beside part A of the
+// other run, or on its critical path -- shows up as time.
+static __global__ void comm_marker_kernel(const float* data, long long ticks) {
+    const long long t0 = wall_clock64();   // (100 MHz constant clock)
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+    if (ticks < 0) const_cast<float*>(data)[0] = 0.f;   // (never: keeps the argument alive)
+}
+
 extern "C" int gs_allreduce_sum_f32(gs_comm* c, float* data, int64_t count, void* stream) {
     GS_CHECK_ARG(c && data && count >= 0, "gs_allreduce_sum_f32: bad arguments");
     if (count == 0) return 0;
+    if (c->world == 1) {
+        if (const char* us = getenv("GS_COMM_MARKER_US")) {
+            hipLaunchKernelGGL(comm_marker_kernel, dim3(1), dim3(64), 0, gs::as_stream(stream), data, (long long)(atof(us) * 100.0));
+            return 0;
+        }
+    }
     GS_NCCL_OK(g_rccl.AllReduce(data, data, (size_t)count, ncclFloat32, ncclSum, c->comm, gs::as_stream(stream)));
     return 0;
 }

@@ -33,6 +33,7 @@ _FUSED_LOSSES = not __import__("os").environ.get("GS_NO_FUSED_LOSSES")
 _BATCH_D_TAIL = not __import__("os").environ.get("GS_NO_D_TAIL_BATCH")   # A/B switch: real + fake through the discriminator's tail as one batch
 _PIPELINE = bool(__import__("os").environ.get("GS_PIPELINE"))   # opt-in, see GANSynth.pipeline
 _PIPE_SIDE = {"0": False, "1": True}.get(__import__("os").environ.get("GS_PIPE_SIDE", ""))
+_OVERLAP_REDUCE = not __import__("os").environ.get("GS_NO_OVERLAP_REDUCE")   # A/B switch: the all-reduce beside part A of the other run (forked graph branch)
 _GRAPH_ALLREDUCE = not __import__("os").environ.get("GS_NO_GRAPH_ALLREDUCE")   # A/B switch: the gradient all-reduce as a node of the captured graph
 
 
@@ -173,6 +174,11 @@ class GANSynth(object):
         self.pipeline = _PIPELINE
         self.pipe_side = None     # None: side stream iff data-parallel (see _train_step_pipelined)
         self._pipe = None
+        # Data parallel on our own RCCL communicator with graphs: train_step() runs the pipelined iteration with each gradient
+        # all-reduce as a FORKED BRANCH inside the other run's part-A graph (off the critical path; see "pipelined iteration").
+        self.overlap_reduce = _OVERLAP_REDUCE
+        self._pipe_capture = False
+        self._warming_up = False
 
     # ----------------------------------------------------------------------------- build
     def _build(self, latents, labels):
@@ -449,11 +455,38 @@ class GANSynth(object):
         if self.distributed and self._comm is not None and self._graph_allreduce and self._capturing() and not getattr(self, "_pipe_capture", False):
             # Same-stream RCCL is capturable: the all-reduce of this run's flat gradient becomes the LAST NODE of the run's hipGraph, so
             # a replayed run hands over reduced gradients and no eager collective launch sits between the replay and the update.
-            if __import__("os").environ.get("GS_TEST_FAIL_GRAPH_ALLREDUCE"):   # (test hook: the fallback below, exercised at world size 1)
-                raise RuntimeError("GS_TEST_FAIL_GRAPH_ALLREDUCE: simulated failure of a collective under stream capture")
-            self._reduce(params)
+            self._reduce_in_capture(params)
             self._captured_reduce = True
         return loss.detach()
+
+    def _reduce_in_capture(self, params):
+        """The gradient all-reduce issued while the current stream is being captured into a hipGraph (a method of its own so that a
+        test can make it raise and watch every rank fall back together)."""
+        self._reduce(params)
+
+    def _agree(self, ok):
+        """Data parallel: did EVERY rank succeed?  A rank-local failure (allocator, capture) must not leave one rank on a different
+        launch sequence than its peers -- their collectives would no longer pair up and the job would hang -- so the outcome of
+        anything that may fail locally is agreed on with an eager MIN all-reduce over the launcher's process group, outside any
+        capture, and every rank takes the same branch."""
+        if not self.distributed or self.world <= 1:
+            return bool(ok)
+        dev = self.g_params.flat.device
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+        return bool(flag.item())
+
+    def _give_up_graph_collectives(self, which, error):
+        """Every rank lands here together (see _agree): no collective inside captured graphs any more.  A capture that aborted with an
+        ncclAllReduce inside may have left our communicator unusable, so the eager collectives move to torch.distributed's own."""
+        import sys
+        print("gansynth_amd.models: capturing the gradient all-reduce inside the %s run's graph failed on some rank (here: %s); "
+              "it will run eagerly after each replay" % (which, "ok" if error is None else str(error).splitlines()[0]), file=sys.stderr, flush=True)
+        self._graph_allreduce = False
+        self._captured_reduce = False
+        if self.world > 1:
+            self._comm = None
+        self._abandon_capture(which)
 
     def _abandon_capture(self, which):
         """State left behind by a _forward_backward that raised in the middle of a stream capture: deferred kernel-layer jobs, half-built
@@ -550,6 +583,8 @@ class GANSynth(object):
                 self._lerp = F.DeviceLerp(self.g_params.flat.device)
             self._lerp.set(fade)   # (stream-ordered before the replay below)
         entry = self._graphs.get(which)
+        if entry is not None and entry[4] != self.keep_gradients:
+            entry = None   # (a graph captured without a gradient fill relies on the zeroing optimizer step behind every replay)
         if entry is None or any(a.shape != b.shape or a.dtype != b.dtype for a, b in zip(entry[1], inputs)):
             static = [t.detach().clone() for t in inputs]
             K = kernels.get()
@@ -579,28 +614,34 @@ class GANSynth(object):
                 K.refresh_weights()
                 graph = torch.cuda.CUDAGraph()
                 self._captured_reduce = False
+                with_collective = self.distributed and self._comm is not None and self._graph_allreduce
+                error = None
                 try:
                     with _quiet_gc(), torch.cuda.graph(graph):
                         loss = self._forward_backward(which, *static)
                 except RuntimeError as e:
-                    if not (self.distributed and self._comm is not None and self._graph_allreduce):
+                    if not with_collective:
                         raise
-                    # The collective would not go into the graph (every rank runs the same launches, so every rank lands here): capture
-                    # the run without it -- the all-reduce then follows each replay eagerly on the same stream, as in round 2.
-                    import sys
-                    print("gansynth_amd.models: capturing the gradient all-reduce inside the %s run's graph failed (%s); "
-                          "it will run eagerly after each replay" % (which, str(e).splitlines()[0]), file=sys.stderr, flush=True)
-                    self._graph_allreduce = False
-                    self._captured_reduce = False
-                    self._abandon_capture(which)
+                    error = e
+                if with_collective and not self._agree(error is None):
+                    # The collective would not go into the graph on SOME rank: every rank (agreed above, so that no rank keeps a graph
+                    # with the collective inside while a peer reduces eagerly) captures the run again without it -- the all-reduce
+                    # then follows each replay eagerly, as in round 2.
+                    self._give_up_graph_collectives(which, error)
                     graph = torch.cuda.CUDAGraph()
                     with _quiet_gc(), torch.cuda.graph(graph):
                         loss = self._forward_backward(which, *static)
             finally:
                 owner.fade_weight = None   # (only captured launches use the table; eager callers keep passing the number)
-            entry = (graph, static, loss, self._captured_reduce)
+            entry = (graph, static, loss, self._captured_reduce, self.keep_gradients)
             self._graphs[which] = entry
-        graph, static, loss, reduced = entry
+        graph, static, loss, reduced, _ = entry
+        if not self.keep_gradients:
+            params_ = self.d_params if which == "d" else self.g_params
+            if not params_.grad_clean:   # (a replay not preceded by the zeroing update: e.g. a run repeated without its optimizer step)
+                params_.grad.zero_()
+                params_.grad_clean = True
+            params_.grad_clean = False   # (what begin_run did at capture time: the replay accumulates into the buffer)
         for dst, src in zip(static, inputs):
             dst.copy_(src)
         graph.replay()
@@ -625,12 +666,30 @@ class GANSynth(object):
         return self.generator_loss
 
     # ------------------------------------------------------------------ pipelined iteration
+    # Every run as TWO graphs: part A (own network only) and part B (the rest), so that the optimizer update of the OTHER network --
+    # its gradient all-reduce above all -- can sit between them:
+    #     D.A | update G | D.B | G.A | update D | G.B
+    # Part A needs neither the gradients being reduced nor the parameters about to change.  Two ways to overlap the collective
+    # with part A:
+    #   (i) IN THE GRAPH (data parallel on our own RCCL communicator, the default there): the all-reduce of the other network's flat
+    #       gradient is a forked branch INSIDE graph A -- fork at the graph's root, join at its end -- so the collective node is off
+    #       the critical path of part A's kernels and there is no cross-stream event between replays (an event hop between a replay
+    #       and another stream costs 0.25-0.75 ms on this stack, scripts/cross_stream_cost.py).  Adam and the operand refresh stay
+    #       eager on the main stream behind graph A (lr_t is a by-value scalar; streaming kernels beside the persistent conv blocks
+    #       cost the main stream 5 %, measured).
+    #   (ii) SIDE STREAM (opt-in, GS_PIPELINE=1 with torch.distributed's collectives): the round-2 form.
     def _join_updates(self):
-        """A pipelined step leaves the generator's update pending (its all-reduce may still run on the side stream): apply it."""
+        """A pipelined step leaves the generator's update pending: apply it (reducing the gradient first when the all-reduce was
+        going to ride in the next discriminator graph)."""
         if self._pipe is not None and self._pipe.get("g_pending"):
             hp = self.hyper_params
-            self._pipe["g_pending"] = False
-            torch.cuda.current_stream().wait_event(self._pipe["g_reduced"])
+            P = self._pipe
+            P["g_pending"] = False
+            if P.get("g_unreduced"):
+                P["g_unreduced"] = False
+                self._reduce(self.g_params)
+            else:
+                torch.cuda.current_stream().wait_event(P["g_reduced"])
             self._apply(self.g_params, hp.generator_learning_rate, hp.generator_beta1, hp.generator_beta2, reduced=True)
 
     def synchronize(self):
@@ -639,57 +698,139 @@ class GANSynth(object):
         if torch.cuda.is_available():
             torch.cuda.synchronize()
 
-    def _capture_pair(self, which, a_inputs, b_inputs):
-        """Two graphs for one run: part A (own network) and part B (the rest), sharing one memory pool (replayed A, B, A, B ...)."""
+    def _overlap_in_graph(self):
+        """The gradient all-reduce as a forked branch of the other run's part-A graph: data parallel, own RCCL communicator, in-graph
+        collectives not refused (GS_NO_GRAPH_ALLREDUCE / a failed capture), not switched off (GS_NO_OVERLAP_REDUCE=1)."""
+        return self.distributed and self._comm is not None and self._graph_allreduce and self.overlap_reduce
+
+    def _capture_pair(self, which, a_inputs, b_inputs, reduce_params=None):
+        """Two graphs for one run: part A (own network) and part B (the rest), sharing one memory pool (replayed A, B, A, B ...).
+        `reduce_params`: the OTHER network's parameters, whose flat gradient is all-reduced on a forked branch of graph A."""
         K = kernels.get()
+        owner = getattr(self.generator, "__self__", None)
+        _, fade = self._regime()
         sa = [t.detach().clone() for t in a_inputs]
         sb = [t.detach().clone() for t in b_inputs]
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):  # one eager pass on a side stream (allocator / lazy-init warm-up)
-            self._part_b(which, self._part_a(which, *sa), *sb)
-        torch.cuda.current_stream().wait_stream(side)
-        K.refresh_weights()   # (see _run: the captured graphs hold no re-layout launches)
-        self._pipe_capture = True   # (the pipelined step launches its reductions itself, on the side stream: none inside these graphs)
+        params = self.d_params if which == "d" else self.g_params
+        owner.fade_weight = self._lerp if fade is not None else None   # the networks read the fade weight from the device table
+        self._pipe_capture = True   # (the pipelined step places its reductions itself: none at the end of part B)
         try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            self._warming_up = True
+            try:
+                with torch.cuda.stream(side):  # one eager pass on a side stream (allocator / lazy-init warm-up)
+                    self._part_b(which, self._part_a(which, *sa), *sb)
+                    if reduce_params is not None:   # RCCL sets up its channels on the first collective: not capturable (dead values here)
+                        self._reduce(reduce_params)
+            finally:
+                self._warming_up = False
+            torch.cuda.current_stream().wait_stream(side)
+            if not self.keep_gradients:   # the graphs hold no fill: they rely on the zeroing optimizer step behind every part B (see _run)
+                params.grad.zero_()
+                params.grad_clean = True
+            K.refresh_weights()   # (see _run: the captured graphs hold no re-layout launches)
             ga = torch.cuda.CUDAGraph()
             with _quiet_gc(), torch.cuda.graph(ga):
+                if reduce_params is not None:
+                    main = torch.cuda.current_stream()
+                    fork = torch.cuda.Stream()
+                    fork.wait_stream(main)            # fork at the root of the graph ...
+                    with torch.cuda.stream(fork):
+                        self._reduce_in_capture(reduce_params)
                 part_a = self._part_a(which, *sa)
+                if reduce_params is not None:
+                    main.wait_stream(fork)            # ... join at its end: the collective runs beside all of part A
             gb = torch.cuda.CUDAGraph()
             with _quiet_gc(), torch.cuda.graph(gb, pool=ga.pool()):
                 loss = self._part_b(which, part_a, *sb)
         finally:
             self._pipe_capture = False
-        return {"a": ga, "b": gb, "sa": sa, "sb": sb, "loss": loss}
+            owner.fade_weight = None
+        return {"a": ga, "b": gb, "sa": sa, "sb": sb, "loss": loss, "reduces": reduce_params is not None, "keep": self.keep_gradients}
 
     def _pipelined_ok(self):
-        return self.pipeline and self._graphable() and self._fully_grown()
+        if not self._graphable():
+            return False
+        if self._overlap_in_graph():
+            return True
+        return self.pipeline and self._fully_grown()
 
     def _train_step_pipelined(self, d_latents, d_labels, real_images, g_latents, g_labels):
-        """D.A | update G | D.B | G.A | update D | G.B, the gradient all-reduce of each update on a side stream under the part A
-        that follows it (part A needs neither the gradients being reduced nor the parameters about to change).  The Adam /
-        operand-refresh launches stay on the main stream: streaming kernels beside the persistent conv blocks cost the main
-        stream 5 % on one MI355X (measured), an all-reduce in flight is what the overlap is for.  Single GPU: no side stream."""
+        """D.A | update G | D.B | G.A | update D | G.B (see above)."""
         hp = self.hyper_params
         main = torch.cuda.current_stream()
         if self._pipe is None:
             ev = lambda: torch.cuda.Event()
-            self._pipe = {"side": torch.cuda.Stream(), "d_done": ev(), "g_done": ev(), "d_reduced": ev(), "g_reduced": ev(), "g_pending": False}
+            self._pipe = {"side": torch.cuda.Stream(), "d_done": ev(), "g_done": ev(), "d_reduced": ev(), "g_reduced": ev(), "g_pending": False,
+                          "g_unreduced": False, "key": None}
         P = self._pipe
-        use_side = self.pipe_side if self.pipe_side is not None else (self.distributed if _PIPE_SIDE is None else _PIPE_SIDE)
+        in_graph = self._overlap_in_graph()
+        use_side = (not in_graph) and (self.pipe_side if self.pipe_side is not None else (self.distributed if _PIPE_SIDE is None else _PIPE_SIDE))
+        head, fade = self._regime()
+        key = (head, fade is None, in_graph, self.keep_gradients)
+        if fade is not None:
+            if self._lerp is None:
+                self._lerp = F.DeviceLerp(self.g_params.flat.device)
+            self._lerp.set(fade)   # (stream-ordered before the replays below)
 
         def fresh(entry, a_inputs, b_inputs):
             return entry is None or any(x.shape != y.shape or x.dtype != y.dtype for x, y in zip(entry["sa"] + entry["sb"], list(a_inputs) + list(b_inputs)))
 
         d_in = ((d_labels, real_images), (d_latents, d_labels))
         g_in = ((g_latents, g_labels), (g_labels,))
-        if fresh(P.get("d"), *d_in) or fresh(P.get("g"), *g_in):
+        if P["key"] != key or fresh(P.get("d"), *d_in) or fresh(P.get("g"), *g_in):
             self._join_updates()
-            P["d"] = self._capture_pair("d", *d_in)
-            P["g"] = self._capture_pair("g", *g_in)
+            self._graphs.clear()
+            P.pop("d", None), P.pop("g", None)
+            error = None
+            try:
+                P["d"] = self._capture_pair("d", *d_in, reduce_params=self.g_params if in_graph else None)
+                P["g"] = self._capture_pair("g", *g_in, reduce_params=self.d_params if in_graph else None)
+            except RuntimeError as e:
+                if not in_graph:
+                    raise
+                error = e
+            if in_graph and not self._agree(error is None):
+                # some rank could not capture the collective: EVERY rank drops the in-graph form (agreed, so that the collective
+                # sequences of the ranks stay identical) and captures plain pairs; the reductions then run eagerly between replays
+                self._give_up_graph_collectives("d", error)
+                self._abandon_capture("g")
+                in_graph = False
+                use_side = self.pipe_side if self.pipe_side is not None else False
+                key = (head, fade is None, in_graph, self.keep_gradients)
+                P["d"] = self._capture_pair("d", *d_in)
+                P["g"] = self._capture_pair("g", *g_in)
+            P["key"] = key
         D, G = P["d"], P["g"]
         for dst, src in zip(D["sa"] + D["sb"] + G["sa"] + G["sb"], list(d_in[0]) + list(d_in[1]) + list(g_in[0]) + list(g_in[1])):
             dst.copy_(src)
+
+        def armed(params):
+            """A no-fill graph is about to accumulate into this buffer: it must be clean (the zeroing update behind the last part B)."""
+            if not self.keep_gradients:
+                if not params.grad_clean:
+                    params.grad.zero_()
+                params.grad_clean = False
+
+        if in_graph:
+            # D run.  Graph A = {D part A  ||  all-reduce of the generator's pending gradient}; then the generator's update (part B runs
+            # the generator), then part B.
+            armed(self.d_params)
+            D["a"].replay()
+            if P["g_pending"]:
+                P["g_pending"] = P["g_unreduced"] = False
+                self._apply(self.g_params, hp.generator_learning_rate, hp.generator_beta1, hp.generator_beta2, reduced=True)
+            D["b"].replay()
+            # G run.  Graph A = {G part A  ||  all-reduce of the discriminator's gradient}; the discriminator's update; part B runs it.
+            armed(self.g_params)
+            G["a"].replay()
+            self._apply(self.d_params, hp.discriminator_learning_rate, hp.discriminator_beta1, hp.discriminator_beta2, reduced=True)
+            G["b"].replay()
+            P["g_pending"] = P["g_unreduced"] = True   # reduced inside the next D graph (or eagerly by _join_updates)
+            self.global_step += 1  # models.py:84
+            self.discriminator_loss, self.generator_loss = D["loss"], G["loss"]
+            return D["loss"], G["loss"]
 
         def reduce_async(params, done, reduced):
             done.record(main)
@@ -703,17 +844,20 @@ class GANSynth(object):
                 reduced.record(main)
 
         # D run.  Part A reads the discriminator only: it runs under the all-reduce of the previous generator gradients.
+        armed(self.d_params)
         D["a"].replay()
         self._join_updates()                        # the generator's update; part B runs the generator
         D["b"].replay()
         reduce_async(self.d_params, P["d_done"], P["d_reduced"])
         # G run.  Part A reads the generator only: it runs under the all-reduce of the discriminator's gradients.
+        armed(self.g_params)
         G["a"].replay()
         main.wait_event(P["d_reduced"])
         self._apply(self.d_params, hp.discriminator_learning_rate, hp.discriminator_beta1, hp.discriminator_beta2, reduced=True)
         G["b"].replay()                             # runs the updated discriminator
         reduce_async(self.g_params, P["g_done"], P["g_reduced"])
         P["g_pending"] = True                       # applied before the next part B (or by _join_updates / synchronize)
+        P["g_unreduced"] = False
         self.global_step += 1  # models.py:84
         self.discriminator_loss, self.generator_loss = D["loss"], G["loss"]
         return D["loss"], G["loss"]

@@ -778,11 +778,12 @@ def test_gan_losses_in_one_launch(K, dtype):
                                   ("convT", 2, 128, 64, 4, 32), ("conv", 1, 64, 64, 6, 40),
                                   ("conv1", 8, 32, 2, 128, 1024), ("conv1", 2, 64, 2, 8, 64), ("conv1", 2, 256, 2, 4, 32), ("conv1", 3, 128, 2, 5, 7)])   # the colour block (1x1)
 @pytest.mark.parametrize("with_addend", [False, True])
-def test_data_gradient_continued_through_the_previous_pixel_norm(K, case, dtype, with_addend):
+def test_data_gradient_continued_through_the_previous_pixel_norm(K, E, case, dtype, with_addend):
     """gs_conv2d[_transpose_s2]_bwd_data_pnbwd: (pixel_norm_bwd(B^T(gy, w), z) + addend) * leaky_relu'(z) in the conv's epilogue (the 32- /
-    64-channel full-size layers) or as conv + in-place norm backward (every other shape) against the two separate kernels, whose own
-    parity with the oracle is established above.  In bf16 the separate path rounds the intermediate gradient to bf16, the fused one
-    does not: compared at bf16 resolution of the tensor's scale; fp32 at 1e-5."""
+    64-channel full-size layers) or as conv + in-place norm backward (every other shape).  Reference = the float64 definition of the norm
+    backward applied to the ORACLE-side data gradient (tests/cpu_kernels.py: torch-CPU autograd of oracle.torch_ref's conv on the same
+    inputs -- nothing of the HIP path feeds the reference); second, the two separate HIP kernels.  In bf16 the separate path rounds the
+    intermediate gradient to bf16, the fused one does not: compared at bf16 resolution of the tensor's scale; fp32 at 1e-5."""
     kind, n, ci, co, h, w = case   # ci: channels of z / gx (the conv's input side), co: of gy
     gen = torch.Generator(device="cuda").manual_seed(11)
     CL = torch.channels_last
@@ -800,8 +801,10 @@ def test_data_gradient_continued_through_the_previous_pixel_norm(K, case, dtype,
         g = K.conv2d_transpose_bwd_data(gy, wt, alpha)
         got = K.conv2d_transpose_bwd_data_pnbwd(gy, wt, alpha, z, eps, act, addend=add)
     ref = K.pixel_norm_bwd(g, z, eps, act=act, addend=add)
-    # float64 evaluation of the definition on the fp32 data gradient (independent of the norm kernels)
-    zz, gg = z.double(), K.conv2d_bwd_data(gy.float(), wt, (n, ci, h, w), ks, 1, alpha).double() if kind != "convT" else K.conv2d_transpose_bwd_data(gy.float(), wt, alpha).double()
+    # float64 evaluation of the definition on the oracle-side fp32 data gradient (independent of the HIP conv and of the norm kernels)
+    gg = (E.conv2d_bwd_data(gy.float().cpu(), wt.cpu(), (n, ci, h, w), ks, 1, alpha) if kind != "convT" else
+          E.conv2d_transpose_bwd_data(gy.float().cpu(), wt.cpu(), alpha)).cuda().double()
+    zz = z.double()
     r = torch.rsqrt((zz * zz).mean(dim=1, keepdim=True) + eps)
     want = r * (gg - zz * r * r * (zz * gg).mean(dim=1, keepdim=True))
     if add is not None:
@@ -820,10 +823,11 @@ def test_data_gradient_continued_through_the_previous_pixel_norm(K, case, dtype,
 @pytest.mark.parametrize("case", [("conv", 8, 32, 32, 128, 1024), ("conv", 8, 64, 64, 64, 512), ("convT", 8, 64, 32, 64, 512),   # fused at full size
                                   ("convT", 8, 128, 64, 32, 256), ("conv", 2, 32, 32, 8, 128), ("conv", 2, 8, 64, 8, 64), ("convT", 2, 16, 32, 8, 64),
                                   ("conv", 2, 256, 256, 4, 32), ("convT", 2, 128, 64, 4, 32), ("conv", 1, 40, 64, 6, 40), ("conv", 3, 5, 8, 5, 7)])
-def test_second_order_norm_gradients_in_the_forward_conv(K, case, dtype):
+def test_second_order_norm_gradients_in_the_forward_conv(K, E, case, dtype):
     """gs_conv2d[_transpose_s2]_fwd_pnbwdbwd: with t = conv(x, w) the cotangent of u = act'(z) pixel_norm_bwd(g, z), both gradients of that
-    node (w.r.t. g and w.r.t. z) from the conv's epilogue, against a float64 autograd evaluation of the definition on the fp32 conv output
-    and against the two-kernel path (conv, then gs_pixel_norm_bwd_bwd_fused).  bf16: compared at bf16 resolution of each tensor's scale."""
+    node (w.r.t. g and w.r.t. z) from the conv's epilogue, against a float64 autograd evaluation of the definition on the ORACLE-side fp32
+    conv output (tests/cpu_kernels.py: oracle.torch_ref's conv on the same inputs -- nothing of the HIP path feeds the reference) and against
+    the two-kernel path (conv, then gs_pixel_norm_bwd_bwd_fused).  bf16: compared at bf16 resolution of each tensor's scale."""
     kind, n, ci, co, h, w = case
     gen = torch.Generator(device="cuda").manual_seed(5)
     CL = torch.channels_last
@@ -835,11 +839,11 @@ def test_second_order_norm_gradients_in_the_forward_conv(K, case, dtype):
     alpha, eps, act = 0.03, 1e-8, 1
     if kind == "conv":
         t = K.conv2d_fwd(x, wt, 3, 1, alpha)
-        t32 = K.conv2d_fwd(x.float(), wt, 3, 1, alpha)
+        t32 = E.conv2d_fwd(x.float().cpu(), wt.cpu(), 3, 1, alpha).cuda()
         got_z, got_g = K.conv2d_fwd_pnbwdbwd(x, wt, 3, 1, alpha, g, z, eps, act)
     else:
         t = K.conv2d_transpose_fwd(x, wt, alpha)
-        t32 = K.conv2d_transpose_fwd(x.float(), wt, alpha)
+        t32 = E.conv2d_transpose_fwd(x.float().cpu(), wt.cpu(), alpha).cuda()
         got_z, got_g = K.conv2d_transpose_fwd_pnbwdbwd(x, wt, alpha, g, z, eps, act)
     ref_z, ref_g = K.pixel_norm_bwd_bwd(t, g, z, eps, pre_act=act, with_g=True)
     zz, gg = z.double().requires_grad_(True), g.double().requires_grad_(True)

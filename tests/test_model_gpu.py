@@ -20,14 +20,14 @@ def relerr(got, ref):
     return float((got - ref).abs().max()) / (float(ref.abs().max()) + 1e-30)
 
 
-def make(level, store, full=True, dtype=torch.float32):
+def make(level, store, full=True, dtype=torch.float32, hyper=None):
     from gansynth_amd.networks import PGGAN
     from gansynth_amd.models import GANSynth
     from gansynth_amd.utils import Dict
     kw = dict(min_resolution=[2, 16], max_resolution=[128, 1024], min_channels=32, max_channels=256) if full else \
         dict(min_resolution=[2, 16], max_resolution=[16, 128], min_channels=32, max_channels=64)
     pg, opg = PGGAN(growing_level=level, **kw), R.PGGAN(growing_level=level, **kw)
-    model = GANSynth(pg.generator, pg.discriminator, None, None, None, Dict(R.DEFAULT_HYPER), dtype=dtype,
+    model = GANSynth(pg.generator, pg.discriminator, None, None, None, Dict(hyper or R.DEFAULT_HYPER), dtype=dtype,
                      keep_gradients=True)   # (the parity tests read p.grad after the optimizer step)
     return pg, opg, model
 
@@ -119,7 +119,7 @@ def check_adam_update(params, before, hip_grads, oracle_before, oracle_after, or
 
 
 def run_step_parity(pg, opg, model, store, batch, res, tol=1e-3, grad_tol=None, verbose=False, dtype=torch.float32,
-                    flip_fraction=2e-5, flip_near=1e-4, metric=None):
+                    flip_fraction=2e-5, flip_near=1e-4, metric=None, hyper=None):
     """One full iteration (D update then G update, each on its own batch) on the HIP path against the oracle: forward, both
     losses, EVERY parameter gradient (first-order + the R1 / mode-seeking double-backward terms) and the TF-Adam update.
 
@@ -140,7 +140,7 @@ def run_step_parity(pg, opg, model, store, batch, res, tol=1e-3, grad_tol=None, 
     gp, dp = opg.init_params(seed=0, bias_std=0.1)
     model._build(cuda(lat), cuda(lab))
     store.load_state_dict({**gp, **dp})
-    tr = R.Trainer(opg, gp, dp)
+    tr = R.Trainer(opg, gp, dp, hyper or R.DEFAULT_HYPER)
     # forward
     with torch.no_grad():
         fake = pg.generator(cuda(lat), cuda(lab))
@@ -224,6 +224,23 @@ def test_fade_regimes_reduced_pggan(gpu_store, level):
     """2x16 .. 16x128 PGGAN (depth 3): level 0.12 -> depth 1 fade, 0.25 -> 2, 0.6 -> 3, 1.0 fully grown."""
     pg, opg, model = make(level, gpu_store, full=False)
     run_step_parity(pg, opg, model, gpu_store, 4, (16, 128))
+
+
+@pytest.mark.parametrize("level", [0.25, 1.0])
+def test_penalty_on_the_generator_distribution_vs_oracle(gpu_store, level):
+    """`fake_gradient_penalty_weight` (/root/reference models.py:50-54; 0 in gan_synth_main.py:87): the zero-centred penalty on
+    tf.gradients(fake_logits, [fake_images]), i.e. the R1 double-backward kernels on the FAKE batch, through the HIP path -- loss,
+    every discriminator gradient and the update against oracle.torch_ref at weight 1 (the per-sample loss algebra runs: the one-launch
+    loss kernel carries one penalty term).  The term is really there: the oracle's loss moves when it is switched off."""
+    hyper = dict(R.DEFAULT_HYPER, fake_gradient_penalty_weight=1.0)
+    pg, opg, model = make(level, gpu_store, full=False, hyper=hyper)
+    _, _, _, d_loss, _, _, _ = run_step_parity(pg, opg, model, gpu_store, 4, (16, 128), hyper=hyper)
+    lat, lab, real = R.synthetic_batch(4, rank=0, image_shape=(2, 16, 128))
+    gp, dp = opg.init_params(seed=0, bias_std=0.1)
+    off = float(R.discriminator_loss(opg, gp, dp, lat, lab, real, dict(hyper, fake_gradient_penalty_weight=0.0)).detach())
+    on = float(R.discriminator_loss(opg, gp, dp, lat, lab, real, hyper).detach())
+    assert on > off + 1e-4 * abs(off), (on, off)
+    assert abs(float(d_loss) - on) <= 1e-3 * max(1.0, abs(on))
 
 
 def test_channel_counts_that_are_not_powers_of_two_are_refused_loudly(gpu_store):
@@ -785,9 +802,9 @@ def test_distributed_step_on_rccl_world_size_1():
             else:
                 os.environ.pop("GS_TORCH_COLLECTIVES", None)
             if "refused" in mode:   # the all-reduce raises under stream capture: the run is captured again without it and reduced eagerly
-                os.environ["GS_TEST_FAIL_GRAPH_ALLREDUCE"] = "1"
-            else:
-                os.environ.pop("GS_TEST_FAIL_GRAPH_ALLREDUCE", None)
+                def refuse(params):
+                    raise RuntimeError("simulated failure of a collective under stream capture")
+                model._reduce_in_capture = refuse
             model.use_graphs = mode.startswith("dist+graphs")
             gp, dp = opg.init_params(seed=0, bias_std=0.1)
             losses = []
@@ -813,7 +830,106 @@ def test_distributed_step_on_rccl_world_size_1():
             _same_up_to_accumulation_order(out["plain"][2], out[mode][2], f"{mode}: generator parameters")
     finally:
         os.environ.pop("GS_TORCH_COLLECTIVES", None)
-        os.environ.pop("GS_TEST_FAIL_GRAPH_ALLREDUCE", None)
+        dist.destroy_process_group()
+
+
+def _dp_trainer(level, batches, full=False, dtype=torch.float32, distributed=True, graphs=True, keep=True):
+    from gansynth_amd import variables
+    variables.set_default_store(variables.VariableStore(device="cuda"))
+    pg, opg, model = make(level, variables.default_store(), full=full, dtype=dtype)
+    model.keep_gradients = keep
+    model.distributed, model.world, model.use_graphs = distributed, 1, graphs
+    cur = [0]
+
+    def real_input_fn():
+        lat, lab, real = batches[cur[0] % len(batches)]
+        return cuda(real).to(dtype), cuda(lab).to(dtype)
+
+    def fake_input_fn():
+        lat, _, _ = batches[cur[0] % len(batches)]
+        cur[0] += 1
+        return cuda(lat).to(dtype)
+
+    model.real_input_fn, model.fake_input_fn = real_input_fn, fake_input_fn
+    gp, dp = opg.init_params(seed=0, bias_std=0.1)
+    lat, lab, _ = batches[0]
+    model._build(cuda(lat).to(dtype), cuda(lab).to(dtype))
+    variables.default_store().load_state_dict({**gp, **dp})
+    return model
+
+
+def test_gradient_all_reduce_rides_beside_part_a_of_the_other_run():
+    """the all-reduce overlapped with compute.  Data parallel with graphs, train_step() runs every run as two
+    graphs and the all-reduce of the OTHER network's flat gradient is a forked branch of the part-A graph (models.GANSynth.
+    _capture_pair).  On the one rank this box has: (i) parameters after 4 iterations are bit-identical to the serial data-parallel
+    form (all-reduce as the last node of each run's graph, GS_NO_OVERLAP_REDUCE) in a fade-in regime and fully grown, with the
+    zeroing and the gradient-keeping optimizer step; a pending generator update is flushed by synchronize(); (ii) a capture failure
+    of the collective on ANY rank takes every rank to the eager form together (the agreement all-reduce is exercised with world 1);
+    (iii) WHERE the collective sits: RCCL short-cuts a one-rank all-reduce to nothing, so GS_COMM_MARKER_US puts a 1-block kernel
+    that holds its stream for 300 us in its place -- beside part A it must not lengthen the full-size iteration, on the critical path
+    (the serial form) it adds two of them."""
+    import time
+    import torch.distributed as dist
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % (29400 + (os.getpid() + 7) % 500), rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        os.environ.pop("GS_COMM_MARKER_US", None)
+        for level, keep in ((1.0, True), (1.0, False), (0.25, False)):
+            batches = [R.synthetic_batch(4, rank=i, image_shape=(2, 16, 128)) for i in range(6)]
+            out = {}
+            for mode in ("serial", "overlapped", "refused"):
+                model = _dp_trainer(level, batches, keep=keep)
+                model.overlap_reduce = mode != "serial"
+                if mode == "refused":
+                    def refuse(params):
+                        raise RuntimeError("simulated failure of a collective under stream capture")
+                    model._reduce_in_capture = refuse
+                for step in range(4):
+                    d_loss, g_loss = model.train_step()
+                assert model._comm is not None
+                if mode == "overlapped":
+                    P = model._pipe
+                    assert P is not None and P["d"]["reduces"] and P["g"]["reduces"] and P["g_pending"] and P["g_unreduced"]
+                elif mode == "refused":
+                    assert not model._graph_allreduce and not model._pipelined_ok()
+                else:
+                    assert model._pipe is None
+                model.synchronize()   # (applies the generator's pending update)
+                assert model._pipe is None or not model._pipe["g_pending"]
+                out[mode] = (float(d_loss), float(g_loss), model.d_params.flat.clone(), model.g_params.flat.clone(), model.global_step)
+            for mode in ("overlapped", "refused"):
+                assert out[mode][4] == out["serial"][4] == 4
+                _same_up_to_accumulation_order(out["serial"][0], out[mode][0], f"{mode} level {level}: D loss")
+                _same_up_to_accumulation_order(out["serial"][1], out[mode][1], f"{mode} level {level}: G loss")
+                _same_up_to_accumulation_order(out["serial"][2], out[mode][2], f"{mode} level {level}: discriminator parameters")
+                _same_up_to_accumulation_order(out["serial"][3], out[mode][3], f"{mode} level {level}: generator parameters")
+        # (iii) where the collective sits, as time: configs[1] itself (full size, bf16, batch 8), where part A of the discriminator run
+        # (the real batch's trunk) and of the generator run (forward + mode-seeking first-order pass) are each well over 300 us of kernels
+        batches = [R.synthetic_batch(8, rank=i, image_shape=(2, 128, 1024)) for i in range(3)]
+        ms = {}
+        for mode in ("serial", "overlapped"):
+            for marker in (0, 300):
+                os.environ["GS_COMM_MARKER_US"] = str(marker)
+                model = _dp_trainer(1.0, batches, full=True, dtype=torch.bfloat16, keep=False)
+                model.overlap_reduce = mode != "serial"
+                for _ in range(3):
+                    model.train_step()
+                model.synchronize()
+                best = 1e9
+                for _ in range(4):
+                    t0 = time.perf_counter()
+                    for _ in range(5):
+                        model.train_step()
+                    model.synchronize()
+                    best = min(best, (time.perf_counter() - t0) / 5 * 1e3)
+                ms[(mode, marker)] = best
+                del model
+        print("ms per iteration (mode, marker us):", {k: round(v, 3) for k, v in ms.items()})
+        assert ms[("serial", 300)] - ms[("serial", 0)] > 0.45          # two 300 us stand-ins on the critical path
+        assert ms[("overlapped", 300)] - ms[("overlapped", 0)] < 0.2   # beside part A: neither shows
+    finally:
+        os.environ.pop("GS_COMM_MARKER_US", None)
         dist.destroy_process_group()
 
 
