@@ -84,9 +84,16 @@ def load_state_dict(model, state, strict=True):
             b2 = float(hp.generator_beta2 if suffix == "" else hp.discriminator_beta2)
             p2 = float(state.get("beta2_power" + suffix, 0.0))
             if 1.2e-38 < p2 < 1.0 and 0.0 < b2 < 1.0:
+                # While beta2_power is still a normal float it IS the optimizer's own step count (beta2^(t+1)): take t from it -- a
+                # reference checkpoint written between the discriminator's and the generator's train op (OutOfRangeError after the
+                # first session.run of models.py:191-192) has t_D = global_step + 1, and optimizers that ran different numbers of
+                # steps stay loadable.  A disagreement with global_step beyond rounding is reported, not refused.
                 t_log = int(round(math.log(p2) / math.log(b2))) - 1
-                if abs(t_log - params.t) > max(2, int(1e-3 * params.t)):
-                    raise ValueError(f"checkpoint: beta2_power{suffix} = {p2:g} says {t_log} optimizer steps, global_step says {params.t}")
+                if abs(t_log - params.t) > max(1, int(1e-3 * params.t)):
+                    import warnings
+                    warnings.warn(f"checkpoint: beta2_power{suffix} = {p2:g} says {t_log} optimizer steps, global_step says {params.t}; "
+                                  f"using {t_log}")
+                params.t = max(t_log, 0)
         else:
             missing.append(key)
     if "global_step" in state:
@@ -125,7 +132,12 @@ def save(model, model_dir, keep=10, keep_every_n_hours=12.0, now=None):
     if saver["next_keep"] is None and keep_every_n_hours:
         # the keep-forever clock survives restarts (a job restarted more often than every keep_every_n_hours would otherwise never
         # keep a long-term checkpoint)
-        saver["next_keep"] = float(open(clock_file).read()) if os.path.exists(clock_file) else now + keep_every_n_hours * 3600.0
+        saver["next_keep"] = now + keep_every_n_hours * 3600.0
+        if os.path.exists(clock_file):
+            try:
+                saver["next_keep"] = float(open(clock_file).read())
+            except (OSError, ValueError):   # an empty / torn clock file (a job killed mid-write): start the clock again
+                pass
         with open(clock_file, "w") as f:
             f.write(repr(saver["next_keep"]))
     saver["times"][os.path.basename(path)] = now

@@ -1640,8 +1640,33 @@ static int launch_igemm(ConvP p, hipStream_t st) {
     p.nch = p.IC / BK;
     {   // reciprocals for the kernel's item decoding (see ConvP): exact while items < 2^21 and divisors < 2^11
         auto magic = [](int d) { return d <= 1 ? 0u : (unsigned)(((1ull << 32) + (unsigned)d - 1) / (unsigned)d); };
-        if ((long)p.nsp * p.noct >= (1L << 21) || p.noct >= 2048 || p.tiles_x >= 2048 || p.tiles_y >= 2048)
-            return fail(GS_ERR_UNSUPPORTED, "conv igemm: %ld work items / %d x %d tiles exceed the item decoder's range", (long)p.nsp * p.noct, p.tiles_x, p.tiles_y);
+        if (p.noct >= 2048 || p.tiles_x >= 2048 || p.tiles_y >= 2048)
+            return fail(GS_ERR_UNSUPPORTED, "conv igemm: %d channel tiles / %d x %d spatial tiles exceed the item decoder's range", p.noct, p.tiles_x, p.tiles_y);
+        static const long max_items = getenv("GS_IGEMM_MAX_ITEMS") ? atol(getenv("GS_IGEMM_MAX_ITEMS")) : (1L << 21);   // (tests lower it)
+        if ((long)p.nsp * p.noct >= max_items) {
+            // More work items than the reciprocal decoder is exact for (large-batch evaluation at full resolution): images are independent,
+            // so the batch runs as several launches of as many images as fit the range -- same kernel, same results.
+            const long per_image = (long)p.tiles_x * p.tiles_y * p.noct;
+            const int chunk = (int)((max_items - 1) / per_image);
+            if (chunk < 1) return fail(GS_ERR_UNSUPPORTED, "conv igemm: %ld work items per image exceed the item decoder's range", per_image);
+            const size_t in_img = (size_t)p.Hi * p.Wi * p.IC * sizeof(T);
+            const size_t out_img = (size_t)p.Hb * p.Wb * (MODE == MODE_T2 ? 4 : 1) * p.OC * sizeof(T);
+            auto adv = [](const void* q, size_t b) -> const void* { return q ? (const char*)q + b : nullptr; };
+            for (int n0 = 0; n0 < p.N; n0 += chunk) {
+                ConvP q = p;
+                q.N = p.N - n0 < chunk ? p.N - n0 : chunk;
+                q.x = adv(p.x, n0 * in_img);
+                q.y = const_cast<void*>(adv(p.y, n0 * out_img));
+                q.y2 = const_cast<void*>(adv(p.y2, n0 * out_img));
+                q.mask = adv(p.mask, n0 * out_img);
+                q.addend = adv(p.addend, n0 * out_img);
+                int pending = 0;
+                if (p.norm_pending) q.norm_pending = &pending;
+                if (int e = launch_igemm<T, MODE, A, B, TW, TG, RESIDENT, D, NORM, RB, SPEC>(q, st)) return e;
+                if (p.norm_pending && pending) *p.norm_pending = pending;
+            }
+            return 0;
+        }
         p.m_noct = magic(p.noct); p.m_tx = magic(p.tiles_x); p.m_ty = magic(p.tiles_y);
     }
     const int wbufs = RESIDENT ? p.nch : NWB;

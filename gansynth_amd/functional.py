@@ -401,10 +401,14 @@ class _BilinearBwdData(Function):
                 # epilogue; the node finds them under the address of what it is handed (see _PnActBwd.backward)
                 g, z = pn.saved_tensors
                 g_z, g_gy = ctx.kind.fwd_pnbwdbwd(ggx, w, ctx.alpha, g, z, pn.eps, pn.act)
+                if _CHECK_FUSION:
+                    _check_fused("fwd_pnbwdbwd", (g_z, g_gy), _K().pixel_norm_bwd_bwd(ctx.kind.fwd(ggx, w, ctx.alpha), g, z, pn.eps, pre_act=pn.act, with_g=True))
                 pn._gs_done = (g_gy.data_ptr(), g_z)
             elif ctx._gs_up is not None and not torch.is_grad_enabled():
                 up = ctx._gs_up   # the node that produced gy multiplies its cotangent by its mask first: in this conv's epilogue instead
                 g_gy = ctx.kind.fwd_mask(ggx, w, ctx.alpha, up.saved_tensors[2], up.act)
+                if _CHECK_FUSION:
+                    _check_fused("fwd_mask", g_gy, _K().act_bwd(ctx.kind.fwd(ggx, w, ctx.alpha), up.saved_tensors[2], up.act))
                 up._gs_gg_premasked = g_gy.data_ptr()
             else:
                 g_gy = _Bilinear.apply(ggx, w, ctx.kind, ctx.alpha)
@@ -444,13 +448,17 @@ class _BwdDataMasked(Function):
     def backward(ctx, gg):
         gy, w, x = ctx.saved_tensors
         pre, ctx._gs_gg_premasked = ctx._gs_gg_premasked, None
-        if pre is not None and pre == gg.data_ptr() and not torch.is_grad_enabled():
+        if pre is not None and pre != gg.data_ptr():
+            _handoff_broken("activation mask of the R1 chain in the producing conv")
+        if pre is not None and not torch.is_grad_enabled():
             t = gg                                   # the producer of gg already applied this node's mask
         else:
             t = _ActBwd.apply(gg, x, ctx.act)
         up = ctx._gs_up
         if up is not None and ctx.needs_input_grad[0] and not torch.is_grad_enabled():
             g_gy = ctx.kind.fwd_mask(t, w, ctx.alpha, up.saved_tensors[2], up.act)
+            if _CHECK_FUSION:
+                _check_fused("fwd_mask", g_gy, _K().act_bwd(ctx.kind.fwd(t, w, ctx.alpha), up.saved_tensors[2], up.act))
             up._gs_gg_premasked = g_gy.data_ptr()
         else:
             g_gy = _Bilinear.apply(t, w, ctx.kind, ctx.alpha) if ctx.needs_input_grad[0] else None
@@ -535,6 +543,8 @@ class _ConvBiasAct(Function):
                     z_prev = pn.saved_tensors[2]
                     gz_prev = _GZ.pop(z_prev.data_ptr(), None)
                     gx_ = ctx.kind.bwd_data_pnbwd(gy, w, tuple(x.shape), ctx.alpha, z_prev, pn.eps, pn.act, gz_prev)
+                    if _CHECK_FUSION:
+                        _check_fused("bwd_data_pnbwd", gx_, _K().pixel_norm_bwd(ctx.kind.bwd_data(gy, w, tuple(x.shape), ctx.alpha), z_prev, pn.eps, act=pn.act, addend=gz_prev))
                     pn._gs_fused = (gx_.data_ptr(), gz_prev is not None)
                     return gx_
             prod = _premask_producer(x, ctx.in_act, differentiable=True) if hasattr(ctx.kind, "bwd_data_mask") else None
@@ -587,13 +597,17 @@ class _PnActBwd(Function):
         g, z = ctx.saved_tensors
         done, ctx._gs_done = ctx._gs_done, None
         if ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:   # both from one pass over gg, g, z
-            if done is not None and gg.data_ptr() == done[0]:
+            if done is not None and gg.data_ptr() != done[0]:
+                _handoff_broken("second-order norm gradients in the forward-on-cotangent conv")
+            if done is not None:
                 g_g, g_z = gg, done[1]   # the conv that produced this node's cotangent already went through it (_BilinearBwdData.backward)
             else:
                 g_z, g_g = _K().pixel_norm_bwd_bwd(gg, g, z, ctx.eps, pre_act=ctx.act, with_g=True)
             if _FUSE_NORM_BWD:
                 _GZ[z.data_ptr()] = g_z   # (see above: the consumer of pixel_norm(z) may add it in its data-gradient epilogue)
             return g_g, g_z, None, None
+        if done is not None:
+            _handoff_broken("second-order norm gradients in the forward-on-cotangent conv")
         g_g = _K().pixel_norm_bwd(gg, z, ctx.eps, pre_act=ctx.act) if ctx.needs_input_grad[0] else None
         g_z = _K().pixel_norm_bwd_bwd(gg, g, z, ctx.eps, pre_act=ctx.act) if ctx.needs_input_grad[1] else None
         return g_g, g_z, None, None
@@ -617,6 +631,27 @@ _GZ = {}
 
 def reset_fusion_state():
     _GZ.clear()
+
+
+# The cross-node hand-offs above (and `_gs_done`, `_gs_gg_premasked`) rest on caller promises ("this tensor has ONE consumer").  A broken
+# promise shows as a marked node receiving a DIFFERENT tensor than the one its partner produced (autograd summed a second gradient into
+# it): that is an error, never a silent fallback -- the partner's tensor already went through this node's arithmetic.
+def _handoff_broken(what):
+    raise RuntimeError("gansynth_amd.functional: fused hand-off '%s' was prepared but the node received another tensor -- the single-consumer "
+                       "promise of the wiring (networks.py: input_normed / input_activation, functional: sole_consumer) does not hold" % what)
+
+
+# GS_CHECK_FUSION=1: every fused cross-node form also runs its unfused definition and the two are compared (debug mode).
+_CHECK_FUSION = bool(__import__("os").environ.get("GS_CHECK_FUSION"))
+
+
+def _check_fused(what, got, ref):
+    for g, r in zip(got if isinstance(got, (tuple, list)) else (got,), ref if isinstance(ref, (tuple, list)) else (ref,)):
+        scale = float(r.float().abs().max()) + 1e-30
+        err = float((g.float() - r.float()).abs().max()) / scale
+        tol = 1e-4 if g.dtype == torch.float32 else 4e-2
+        if not err <= tol:
+            raise RuntimeError("GS_CHECK_FUSION: %s differs from its unfused definition by %.3e of the tensor's scale" % (what, err))
 
 _NORM_BWD_BIAS = not __import__("os").environ.get("GS_NO_NORM_BWD_BIAS")      # A/B switch: bias sums inside the norm's backward
 
@@ -666,7 +701,9 @@ class _ConvBiasActNorm(Function):
         tb = _accum_target(ctx.bref) if want_b else None
         bias_done = False
         fused, ctx._gs_fused = ctx._gs_fused, None
-        if fused is not None and g_y is not None and g_y.data_ptr() == fused[0]:
+        if fused is not None and (g_y is None or g_y.data_ptr() != fused[0]):
+            _handoff_broken("previous block's norm backward in the data-gradient conv")
+        if fused is not None:
             # the consumer's data-gradient conv already went through this block's norm and activation (and added g_z if it had it)
             gy = g_y
             if g_z is not None and not fused[1]:
@@ -688,6 +725,8 @@ class _ConvBiasActNorm(Function):
                 z_prev = prod.saved_tensors[2]
                 gz_prev = _GZ.pop(z_prev.data_ptr(), None)
                 gx = ctx.kind.bwd_data_pnbwd(gy, w, tuple(x.shape), ctx.alpha, z_prev, prod.eps, prod.act, gz_prev)
+                if _CHECK_FUSION:
+                    _check_fused("bwd_data_pnbwd", gx, _K().pixel_norm_bwd(ctx.kind.bwd_data(gy, w, tuple(x.shape), ctx.alpha), z_prev, prod.eps, act=prod.act, addend=gz_prev))
                 prod._gs_fused = (gx.data_ptr(), gz_prev is not None)
             else:
                 gx = _BilinearBwdData.apply(gy, w, x.shape, ctx.kind, ctx.alpha)

@@ -444,6 +444,8 @@ class GANSynth(object):
                 else:
                     loss.backward()
         finally:
+            if hasattr(F, "reset_fusion_state"):
+                F.reset_fusion_state()   # (the hand-off table holds tensors of this pass -- of a graph's pool while capturing: not beyond it)
             if deferring:
                 if overlap:   # contract the layers bucket by bucket; a finished bucket goes on the wire under the next one's kernels
                     K.flush_wgrad_reductions(group_of=params.bucket_of,

@@ -204,8 +204,22 @@ def test_checkpoint_round_trip_resumes_bit_identically(cpu_backend, tmp_path):
                     beta2_power_1=torch.tensor(0.99 ** (steps + 1), dtype=torch.float32))
         assert checkpoint.load_state_dict(third, late, strict=True) == []
         assert (third.g_params.t, third.d_params.t, third.global_step) == (steps, steps, steps)
-    with pytest.raises(ValueError):
-        checkpoint.load_state_dict(third, dict(tf_like, global_step=torch.tensor(400)), strict=True)   # beta2_power says 4
+    # while beta2_power is a normal float it IS the optimizer's step count: a checkpoint written between the two train ops of an
+    # iteration (discriminator one step ahead, models.py:191-193) loads with t_D = global_step + 1 ...
+    ahead = dict(tf_like, beta2_power_1=torch.tensor(0.99 ** 6, dtype=torch.float32))
+    assert checkpoint.load_state_dict(third, ahead, strict=True) == []
+    assert (third.g_params.t, third.d_params.t, third.global_step) == (4, 5, 4)
+    # ... and one that contradicts global_step outright stays loadable, loudly (beta2_power says 4)
+    with pytest.warns(UserWarning, match="says 4 optimizer steps"):
+        checkpoint.load_state_dict(third, dict(tf_like, global_step=torch.tensor(400)), strict=True)
+    assert (third.g_params.t, third.d_params.t, third.global_step) == (4, 4, 400)
+    # a torn keep-forever clock file (a job killed mid-write) does not break the next save
+    third.global_step = 4
+    with open(os.path.join(str(tmp_path), "checkpoints_keep_clock"), "w") as f:
+        f.write("")
+    third.__dict__.pop("_saver_state", None)
+    checkpoint.save(third, str(tmp_path))
+    assert float(open(os.path.join(str(tmp_path), "checkpoints_keep_clock")).read()) > 0
 
 
 def test_checkpoint_retention_follows_the_saver(cpu_backend, tmp_path):

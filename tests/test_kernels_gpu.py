@@ -897,3 +897,44 @@ def test_colour_block_forward_with_the_next_node_s_mask(K, shape, dtype):
     got = K.conv2d_fwd_mask(x, wt, 1, 1, 0.7, mask, 1)
     want = (K.conv2d_fwd(x.float(), wt, 1, 1, 0.7) * torch.where(mask.float() > 0, 1.0, 0.2)).cpu()
     close(got, want, rel=1e-6 if dtype == torch.float32 else 1e-2, name="colour block fwd mask")
+
+
+_CHUNK_CHILD = r"""
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+from gansynth_amd import kernels
+K = kernels.HipKernels()
+d = torch.load(sys.argv[2])
+CL = torch.channels_last
+bad = []
+for name, (x, wt, mask, ref_fwd, ref_t, ref_bd) in d.items():
+    x, wt, mask = x.cuda().contiguous(memory_format=CL), wt.cuda(), mask.cuda().contiguous(memory_format=CL)
+    if not torch.equal(K.conv2d_fwd_bias_act(x, wt, None, 3, 1, 0.05, 1).cpu(), ref_fwd): bad.append(name + " fwd")
+    if not torch.equal(K.conv2d_transpose_fwd(x, wt, 0.05).cpu(), ref_t): bad.append(name + " transposed")
+    if not torch.equal(K.conv2d_bwd_data(x, wt, tuple(x.shape), 3, 1, 0.05, mask=mask, mask_act=1).cpu(), ref_bd): bad.append(name + " bwd_data+mask")
+print("BAD", bad) if bad else print("CHUNKED-OK", len(d))
+"""
+
+
+def test_batches_beyond_the_item_decoders_range_run_in_image_chunks(K, tmp_path):
+    """conv_igemm's division-free item decoder is exact below 2^21 work items; a larger launch (large-batch evaluation at full
+    resolution: >= 4096 images of 128x1024 at 32 channels) is cut into launches of as many whole images as fit.  The limit is lowered
+    (GS_IGEMM_MAX_ITEMS, read once per process: a child process) so that a small batch exercises it: forward (fused activation),
+    transposed conv and a masked data gradient, bf16 and fp32, bit-identical to the single launch."""
+    import subprocess
+    import sys
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    CL = torch.channels_last
+    d = {}
+    for name, dtype, (n, c, h, w) in (("bf16", torch.bfloat16, (7, 64, 8, 64)), ("f32", torch.float32, (5, 32, 8, 32)), ("bf16-32", torch.bfloat16, (6, 32, 16, 128))):
+        x = torch.randn(n, c, h, w, device="cuda", generator=gen).to(dtype).contiguous(memory_format=CL)
+        wt = torch.randn(3, 3, c, c, device="cuda", generator=gen)
+        mask = torch.randn(n, c, h, w, device="cuda", generator=gen).to(dtype).contiguous(memory_format=CL)
+        d[name] = (x.cpu(), wt.cpu(), mask.cpu(), K.conv2d_fwd_bias_act(x, wt, None, 3, 1, 0.05, 1).cpu(), K.conv2d_transpose_fwd(x, wt, 0.05).cpu(),
+                   K.conv2d_bwd_data(x, wt, tuple(x.shape), 3, 1, 0.05, mask=mask, mask_act=1).cpu())
+    path = str(tmp_path / "chunk_case.pt")
+    torch.save(d, path)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, "-c", _CHUNK_CHILD, root, path], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, GS_IGEMM_MAX_ITEMS="9"))
+    assert res.returncode == 0 and "CHUNKED-OK 3" in res.stdout, (res.stdout[-800:], res.stderr[-1500:])
