@@ -1327,6 +1327,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_2x2_kernel(
 // descriptors and issue every DMA piece.  A wave issues one instruction per ~5 cycles; a group of 9 MFMAs (288 pipe cycles) leaves ~57
 // issue slots and the reads, v_alignbit windows and DMA pieces of a group need ~75: measured 145 us with everything on four waves,
 // 105 us with neither reads nor DMA (scripts/bench_wgrad_group.py with the GS_WGABL_* builds).
+#ifndef GS_SK_FRONT_S1
+#define GS_SK_FRONT_S1 0
+#endif
+#ifndef GS_SK_FRONT_S2
+#define GS_SK_FRONT_S2 1   // measured same-box (scripts/ab_wgrad.sh, profiles/r04_c_ab_wgrad_front.txt): stride-2 flush 131 -> 121 / 183 -> 167 us (16 / 24 images); stride 1: no change at 4 or 8
+#endif
 template <int MODE, int TW, bool SPEC>
 __global__ __launch_bounds__(SPEC ? 512 : 256) void conv_wgrad_bf16_2x2_sk_kernel(const SkGroup g, float* __restrict__ part) {
     constexpr bool S2 = MODE == MODE_S2;
@@ -1466,7 +1472,12 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void conv_wgrad_bf16_2x2_sk_kerne
         for (int q = 0; q < NPIECE; ++q) issue_piece(q, 0);
     }
 
-    constexpr int PPG = (NPIECE + NG - 1) / NG;
+    // DMA pieces of the next unit per pixel group of this one.  GS_SK_FRONT_S1 / _S2 = k > 0: all of them within the first k groups, so that
+    // the last piece issued has the remaining groups' MFMAs between it and the wait at the top of the next unit (a piece issued in the
+    // last group meets that wait ~300 cycles later and the unit pays its whole L2 / HBM latency: SQ_WAIT_ANY 45 % of the stride-2 kernel's
+    // wave cycles, profiles/r04_a_wgrad_group_sq_pmc.txt)
+    constexpr int FRONT = S2 ? GS_SK_FRONT_S2 : GS_SK_FRONT_S1;
+    constexpr int PPG = FRONT > 0 ? (NPIECE + FRONT - 1) / FRONT : (NPIECE + NG - 1) / NG;
     int buf = 0;
     for (int u = U0; u < U1; ++u) {
         const bool more = u + 1 < U1;

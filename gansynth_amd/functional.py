@@ -646,6 +646,8 @@ _CHECK_FUSION = bool(__import__("os").environ.get("GS_CHECK_FUSION"))
 
 
 def _check_fused(what, got, ref):
+    if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+        return   # (the comparison reads values back: eager passes only -- every captured pass has an eager warm-up twin)
     for g, r in zip(got if isinstance(got, (tuple, list)) else (got,), ref if isinstance(ref, (tuple, list)) else (ref,)):
         scale = float(r.float().abs().max()) + 1e-30
         err = float((g.float() - r.float()).abs().max()) / scale

@@ -936,5 +936,5 @@ def test_batches_beyond_the_item_decoders_range_run_in_image_chunks(K, tmp_path)
     torch.save(d, path)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = subprocess.run([sys.executable, "-c", _CHUNK_CHILD, root, path], capture_output=True, text=True, timeout=600,
-                         env=dict(os.environ, GS_IGEMM_MAX_ITEMS="9"))
+                         env=dict(os.environ, GS_IGEMM_MAX_ITEMS="40"))
     assert res.returncode == 0 and "CHUNKED-OK 3" in res.stdout, (res.stdout[-800:], res.stderr[-1500:])
