@@ -1127,14 +1127,15 @@ __global__ __launch_bounds__(192) void conv_wgrad_bf16_kernel(
         constexpr bool pre_ = (GI) + 1 < NG;                                                                                        \
         constexpr int NR_ = 2 + 3 * XR;                 /* fragment reads of the next group */                                      \
         constexpr int RPS_ = (NR_ + 8) / 9;             /* ... per MFMA slot */                                                     \
-        const int nty_ = (((GI) + 1) * 16) / TW, ntx0_ = (((GI) + 1) * 16) % TW + 8 * hi;                                           \
-        const unsigned char* const ngp_ = (GPL) + (nty_ * TW + ntx0_ + t_row) * 64 + t_col;                                         \
+        constexpr int nty_ = (((GI) + 1) * 16) / TW, ntxc_ = (((GI) + 1) * 16) % TW;                                                \
+        const unsigned char* const ngp_ = g_ptr_((GPL), nty_, ntxc_);                                                               \
         auto next_read_ = [&](int r) __attribute__((always_inline)) {                                                               \
-            if (r < 2) { fb[nxt_][r] = lds_tr16(ngp_ + r * 4 * 64); return; }                                                       \
+            if (r < 2) { fb[nxt_][r] = lds_tr16(ngp_ + r * 4 * GROWB); return; }                                                    \
             const int ky = (r - 2) / XR, k = (r - 2) % XR;                                                                          \
-            const unsigned char* xp = (XPL) + (((nty_ * S + ky) * PW + ntx0_ * S) + t_row * S) * 64 + t_col;                        \
-            const int off = !S2 ? k * 4 * 64 : (k < 3 ? k * 8 * 64 : 64 + (k - 3) * 8 * 64);                                       \
-            fx[nxt_][ky][k] = lds_tr16(xp + off);                                                                                   \
+            if (!S2) { fx[nxt_][ky][k] = lds_tr16(x_ptr_((XPL), nty_, ky, ntxc_, 0) + k * 4 * XROWB); return; }                     \
+            /* stride 2: reads 0-2 = the even columns (rows +0, +8, +16), 3-4 = the odd ones (rows +1, +9) */                       \
+            fx[nxt_][ky][k] = k < 3 ? lds_tr16(x_ptr_((XPL), nty_, ky, ntxc_, 0) + k * 8 * XROWB)                                   \
+                                    : lds_tr16(x_ptr_((XPL), nty_, ky, ntxc_, 1) + (k - 3) * 8 * XROWB);                            \
         };                                                                                                                          \
         auto slot_ = [&](int m) __attribute__((always_inline)) {                                                                    \
             if (pre_ && !GS_WGABL_NOFRAG) {                                                                                         \
@@ -1267,19 +1268,28 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_2x2_kernel(
     constexpr int XR = S2 ? 5 : 3;
     constexpr int NG = NP / 16;
     uint2 fb[2][2], fx[2][3][XR];
+    // fragment addresses (GS_WG_GROUP_STEP): two 32-channel planes of 64-byte rows per side
+    constexpr int XROWB = 64, GROWB = 64;
+    auto x_ptr_ = [&](const unsigned char* xpl, int ty, int ky, int txc, int c) __attribute__((always_inline)) {
+        return xpl + (((ty * S + ky) * PW + (txc + 8 * hi) * S) + t_row * S + c) * 64 + t_col;
+    };
+    auto g_ptr_ = [&](const unsigned char* gpl, int ty, int txc) __attribute__((always_inline)) {
+        return gpl + (ty * TW + txc + 8 * hi + t_row) * 64 + t_col;
+    };
     auto load_group = [&](int g, int fbuf, const unsigned char* xpl, const unsigned char* gpl) __attribute__((always_inline)) {
-        const int ty = (g * 16) / TW, tx0 = (g * 16) % TW + 8 * hi;
-        const unsigned char* gp = gpl + (ty * TW + tx0 + t_row) * 64 + t_col;
+        const int ty = (g * 16) / TW, txc = (g * 16) % TW;
+        const unsigned char* gp = g_ptr_(gpl, ty, txc);
         fb[fbuf][0] = lds_tr16(gp);
-        fb[fbuf][1] = lds_tr16(gp + 4 * 64);
+        fb[fbuf][1] = lds_tr16(gp + 4 * GROWB);
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
-            const unsigned char* xp = xpl + (((ty * S + ky) * PW + tx0 * S) + t_row * S) * 64 + t_col;
+            const unsigned char* xp = x_ptr_(xpl, ty, ky, txc, 0);
             if (!S2) {
-                fx[fbuf][ky][0] = lds_tr16(xp); fx[fbuf][ky][1] = lds_tr16(xp + 4 * 64); fx[fbuf][ky][2] = lds_tr16(xp + 8 * 64);
+                fx[fbuf][ky][0] = lds_tr16(xp); fx[fbuf][ky][1] = lds_tr16(xp + 4 * XROWB); fx[fbuf][ky][2] = lds_tr16(xp + 8 * XROWB);
             } else {
-                fx[fbuf][ky][0] = lds_tr16(xp); fx[fbuf][ky][1] = lds_tr16(xp + 8 * 64); fx[fbuf][ky][2] = lds_tr16(xp + 16 * 64);
-                fx[fbuf][ky][3] = lds_tr16(xp + 64); fx[fbuf][ky][4] = lds_tr16(xp + 9 * 64);
+                const unsigned char* xo = x_ptr_(xpl, ty, ky, txc, 1);
+                fx[fbuf][ky][0] = lds_tr16(xp); fx[fbuf][ky][1] = lds_tr16(xp + 8 * XROWB); fx[fbuf][ky][2] = lds_tr16(xp + 16 * XROWB);
+                fx[fbuf][ky][3] = lds_tr16(xo); fx[fbuf][ky][4] = lds_tr16(xo + 8 * XROWB);
             }
         }
     };
@@ -1327,6 +1337,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_2x2_kernel(
 // descriptors and issue every DMA piece.  A wave issues one instruction per ~5 cycles; a group of 9 MFMAs (288 pipe cycles) leaves ~57
 // issue slots and the reads, v_alignbit windows and DMA pieces of a group need ~75: measured 145 us with everything on four waves,
 // 105 us with neither reads nor DMA (scripts/bench_wgrad_group.py with the GS_WGABL_* builds).
+#ifndef GS_SK_ROW128
+#define GS_SK_ROW128 1
+#endif
 #ifndef GS_SK_FRONT_S1
 #define GS_SK_FRONT_S1 0
 #endif
@@ -1340,12 +1353,20 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void conv_wgrad_bf16_2x2_sk_kerne
     constexpr int TH = NP / TW;
     constexpr int PH = patch_dim<MODE>(TH), PW = patch_dim<MODE>(TW);
     constexpr int S = S2 ? 2 : 1;
-    constexpr int XRG = (PH * PW + 15) / 16;
-    constexpr int GRG = NP / 16;
+    // Staged layout.  R128 (default): ONE plane per side with 128-byte rows = all 64 channels of a pixel, a DMA piece = 8 whole rows, i.e.
+    // whole 128-byte cache lines: the wave issues a piece every ~77 cycles instead of ~134 with the half-line rows of the two-plane
+    // layout (scripts/probe/dma_rate.hip), and a unit's time IS the issuing wave's serial sum -- MFMAs + ~13 cycles per transposing read
+    // + the DMA issue (model and counters: DESIGN.md 6.4).  The 32-channel half h of row r sits at (h ^ (r >> 1 & 1)) * 64, applied on
+    // the DMA's source side, so that the four rows of a transposing read (r .. r + 3) cover all 64 banks as the 64-byte rows did.
+    constexpr bool R128 = GS_SK_ROW128 != 0;
+    constexpr int XRG = R128 ? (PH * PW + 7) / 8 : (PH * PW + 15) / 16;   // DMA pieces (1 KiB) of the patch: of its one plane / of each of its two
+    constexpr int GRG = R128 ? NP / 8 : NP / 16;
     constexpr int XK = (XRG + 3) / 4, GK = GRG / 4;
-    constexpr int XPL = XK * 4096, GPL = NP * 64;
-    constexpr int BUF = 2 * XPL + 2 * GPL;
-    constexpr int NPIECE = 2 * XK + 2 * GK;
+    constexpr int XPL = R128 ? 0 : XK * 4096, GPL = R128 ? 0 : NP * 64;   // plane stride (two-plane layout)
+    constexpr int XT = R128 ? XK * 4096 : 2 * XK * 4096, GT = NP * 128;   // bytes of the staged patch / gradient tile
+    constexpr int BUF = XT + GT;
+    constexpr int NPIECE = R128 ? XK + GK : 2 * XK + 2 * GK;
+    constexpr int XROWB = R128 ? 128 : 64, GROWB = XROWB;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const unsigned a_base = (unsigned)(uintptr_t)lds_raw;
 
@@ -1362,13 +1383,16 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void conv_wgrad_bf16_2x2_sk_kerne
     if (U0 >= U1) return;
 
     // ---- DMA side: the unit being staged (one ahead of the one being multiplied)
-    int x_ly[XK], x_lx[XK], x_voff[XK];
+    constexpr int RPP = R128 ? 8 : 16;              // rows per piece
+    const int p_row = R128 ? lane >> 3 : lane >> 2;   // row of the piece this lane fetches 16 bytes of
+    int x_ly[XK], x_lx[XK], x_voff[XK], x_sw[XK];
 #pragma unroll
     for (int k = 0; k < XK; ++k) {
-        const int row = (wv + 4 * k) * 16 + (lane >> 2);
+        const int row = (wv + 4 * k) * RPP + p_row;
         x_ly[k] = row / PW;
         x_lx[k] = row - x_ly[k] * PW;
         x_voff[k] = 0;
+        x_sw[k] = R128 ? (((lane & 7) ^ (((row >> 1) & 1) << 2)) * 16) : (lane & 3) * 16;   // source bytes of the lane's 16-byte slot within the channel row
     }
     int j_n = 0, ct_n = 0, tile_n = 0;                               // layer, channel tile, pixel tile
     int Hi = 0, Wi = 0, IC = 0, OC = 0, Hb = 0, Wb = 0, tiles_x = 1, tiles_y = 1, ntiles = 1, n_ict = 1, nct = 1;
@@ -1382,7 +1406,7 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void conv_wgrad_bf16_2x2_sk_kerne
         ximg = (unsigned)Hi * Wi * IC * 2;
         gimg = (unsigned)Hb * Wb * OC * 2;
 #pragma unroll
-        for (int k = 0; k < XK; ++k) x_voff[k] = ((x_ly[k] * Wi + x_lx[k]) * IC) * 2 + (lane & 3) * 16;
+        for (int k = 0; k < XK; ++k) x_voff[k] = ((x_ly[k] * Wi + x_lx[k]) * IC) * 2 + x_sw[k];
     };
     auto set_ct = [&](int j, int ct) __attribute__((always_inline)) {
         ic0_n = (ct % n_ict) * 64;
@@ -1411,7 +1435,23 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void conv_wgrad_bf16_2x2_sk_kerne
         }
     };
     auto issue_piece = [&](int q, int bufi) __attribute__((always_inline)) {
-        const unsigned a_x = a_base + bufi * BUF, a_g = a_x + 2 * XPL;
+        const unsigned a_x = a_base + bufi * BUF, a_g = a_x + XT;
+        if (R128) {
+            if (q < XK) {
+                const int k = q;
+                const bool in = (wv + 4 * k) * 8 + p_row < PH * PW && (unsigned)(ox0_t + x_lx[k]) < (unsigned)Wi;
+                const unsigned v = in ? (unsigned)(xorg_t + x_voff[k]) : 0x80000000u;
+                lds_dma16(__builtin_amdgcn_readfirstlane(a_x + (wv + 4 * k) * 1024), v, rs_xt);
+            } else {
+                const int k = q - XK;
+                const int pix = (wv + 4 * k) * 8 + p_row;
+                const int gy_ = by_t + pix / TW, gx_ = bx_t + pix % TW;
+                const bool in = gy_ < Hb && gx_ < Wb;
+                const unsigned v = in ? (unsigned)(((gy_ * Wb + gx_) * OC + oc0_n) * 2 + (((lane & 7) ^ (((pix >> 1) & 1) << 2)) * 16)) : 0x80000000u;
+                lds_dma16(__builtin_amdgcn_readfirstlane(a_g + (wv + 4 * k) * 1024), v, rs_gt);
+            }
+            return;
+        }
         if (q < 2 * XK) {
             const int k = q >> 1, pl = q & 1;
             const bool in = (wv + 4 * k) * 16 + (lane >> 2) < PH * PW && (unsigned)(ox0_t + x_lx[k]) < (unsigned)Wi;
@@ -1429,7 +1469,7 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void conv_wgrad_bf16_2x2_sk_kerne
         }
     };
 
-    // ---- MFMA side (identical to conv_wgrad_bf16_2x2_kernel)
+    // ---- MFMA side (as conv_wgrad_bf16_2x2_kernel)
     f32x16 acc[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
@@ -1440,19 +1480,42 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void conv_wgrad_bf16_2x2_sk_kerne
     constexpr int XR = S2 ? 5 : 3;
     constexpr int NG = NP / 16;
     uint2 fb[2][2], fx[2][3][XR];
-    auto load_group = [&](int gi, int fbuf, const unsigned char* xpl, const unsigned char* gpl) __attribute__((always_inline)) {
-        const int ty = (gi * 16) / TW, tx0 = (gi * 16) % TW + 8 * hi;
-        const unsigned char* gp = gpl + (ty * TW + tx0 + t_row) * 64 + t_col;
+    // fragment addresses (GS_WG_GROUP_STEP).  R128: row r of the tile at r * 128, this wave's 32-channel half at ((half ^ bit 1 of r) << 6).
+    // Bit 1 of the row a lane reads is (a compile-time bit of the group / kernel row / column parity) ^ (a bit of t_row): everything that
+    // depends on the lane is folded into two offsets per side, the rest into the instruction's immediate offset.
+    //   stride 1: r = (ty + ky) PW + txc + 8 hi + t_row (+ 4 k),  PW = 34:  bit 1 = ((ty + ky) & 1) ^ (t_row >> 1)
+    //   stride 2: r = (2 ty + ky) PW + 2 txc + 16 hi + 2 t_row + c (+ 8 k),  PW = 65:  bit 1 = (((2 ty + ky + c) >> 1) & 1) ^ (t_row & 1)
+    //   gradient: r = ty TW + txc + 8 hi + t_row (+ 4 i):  bit 1 = t_row >> 1
+    static_assert(!R128 || (S2 ? PW % 4 == 1 : PW % 4 == 2), "the swizzle algebra below assumes PW = 34 (stride 1) / 65 (stride 2)");
+    const int xl_base = R128 ? (t_row * S + 8 * S * hi) * 128 + t_col : 0;
+    const int xl_sw = S2 ? (t_row & 1) : (t_row >> 1);
+    const int xlane[2] = {xl_base + (((it ^ xl_sw) & 1) << 6), xl_base + (((it ^ xl_sw ^ 1) & 1) << 6)};
+    const int glane = R128 ? (t_row + 8 * hi) * 128 + t_col + (((ot ^ (t_row >> 1)) & 1) << 6) : 0;
+    auto x_ptr_ = [&](const unsigned char* xt, int ty, int ky, int txc, int c) __attribute__((always_inline)) {
+        if (R128) {
+            const int a = S2 ? ((2 * ty + ky + c) >> 1) & 1 : (ty + ky) & 1;
+            return xt + ((ty * S + ky) * PW + txc * S + c) * 128 + xlane[a];
+        }
+        return xt + it * XPL + (((ty * S + ky) * PW + (txc + 8 * hi) * S) + t_row * S + c) * 64 + t_col;
+    };
+    auto g_ptr_ = [&](const unsigned char* gt, int ty, int txc) __attribute__((always_inline)) {
+        if (R128) return gt + (ty * TW + txc) * 128 + glane;
+        return gt + ot * GPL + (ty * TW + txc + 8 * hi + t_row) * 64 + t_col;
+    };
+    auto load_group = [&](int gi, int fbuf, const unsigned char* xt, const unsigned char* gt) __attribute__((always_inline)) {
+        const int ty = (gi * 16) / TW, txc = (gi * 16) % TW;
+        const unsigned char* gp = g_ptr_(gt, ty, txc);
         fb[fbuf][0] = lds_tr16(gp);
-        fb[fbuf][1] = lds_tr16(gp + 4 * 64);
+        fb[fbuf][1] = lds_tr16(gp + 4 * GROWB);
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
-            const unsigned char* xp = xpl + (((ty * S + ky) * PW + tx0 * S) + t_row * S) * 64 + t_col;
+            const unsigned char* xp = x_ptr_(xt, ty, ky, txc, 0);
             if (!S2) {
-                fx[fbuf][ky][0] = lds_tr16(xp); fx[fbuf][ky][1] = lds_tr16(xp + 4 * 64); fx[fbuf][ky][2] = lds_tr16(xp + 8 * 64);
+                fx[fbuf][ky][0] = lds_tr16(xp); fx[fbuf][ky][1] = lds_tr16(xp + 4 * XROWB); fx[fbuf][ky][2] = lds_tr16(xp + 8 * XROWB);
             } else {
-                fx[fbuf][ky][0] = lds_tr16(xp); fx[fbuf][ky][1] = lds_tr16(xp + 8 * 64); fx[fbuf][ky][2] = lds_tr16(xp + 16 * 64);
-                fx[fbuf][ky][3] = lds_tr16(xp + 64); fx[fbuf][ky][4] = lds_tr16(xp + 9 * 64);
+                const unsigned char* xo = x_ptr_(xt, ty, ky, txc, 1);
+                fx[fbuf][ky][0] = lds_tr16(xp); fx[fbuf][ky][1] = lds_tr16(xp + 8 * XROWB); fx[fbuf][ky][2] = lds_tr16(xp + 16 * XROWB);
+                fx[fbuf][ky][3] = lds_tr16(xo); fx[fbuf][ky][4] = lds_tr16(xo + 8 * XROWB);
             }
         }
     };
@@ -1502,8 +1565,8 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void conv_wgrad_bf16_2x2_sk_kerne
             }
             tile_setup(j_n);
         }
-        const unsigned char* const xpl = lds_raw + buf * BUF + it * XPL;
-        const unsigned char* const gpl = lds_raw + buf * BUF + 2 * XPL + ot * GPL;
+        const unsigned char* const xpl = lds_raw + buf * BUF;          // the staged patch / gradient tile (x_ptr_ / g_ptr_ pick this wave's half)
+        const unsigned char* const gpl = lds_raw + buf * BUF + XT;
         if (SPEC) {
             if (loader) {
                 if (more) {
@@ -2028,7 +2091,9 @@ int run_wgrad_mfma(int mode, const WgradSrcs& srcs, int nsrc, float* gw, float* 
 #define GS_WGB2(M, TWV)                                                                                                 \
     do {                                                                                                                \
         constexpr int np_ = (M == MODE_S2 ? 64 : 256), th_ = np_ / TWV;                                                 \
-        constexpr int lds_ = 2 * (2 * ((((patch_dim<M>(th_) * patch_dim<M>(TWV) + 15) / 16 + 3) / 4) * 4096 + np_ * 64));  \
+        constexpr int rows_ = patch_dim<M>(th_) * patch_dim<M>(TWV);                                                    \
+        constexpr int xt_ = GS_SK_ROW128 ? (((rows_ + 7) / 8 + 3) / 4) * 4096 : 2 * ((((rows_ + 15) / 16 + 3) / 4) * 4096);   \
+        constexpr int lds_ = 2 * (xt_ + np_ * 128);                                                                     \
         auto kern_ = conv_wgrad_bf16_2x2_kernel<M, TWV>;                                                                \
         static bool set_ = false;                                                                                       \
         if (!set_) {                                                                                                    \

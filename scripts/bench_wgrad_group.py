@@ -10,6 +10,8 @@ CL = torch.channels_last
 layers = [(256, 256, 4, 32), (256, 256, 8, 64), (256, 256, 16, 128), (128, 128, 32, 256), (64, 64, 64, 512)]
 if st == 2:
     layers = [(256, 256, 4, 32), (256, 256, 8, 64), (128, 256, 16, 128), (64, 128, 32, 256)]
+if len(sys.argv) > 3:   # explicit layers "ci,co,h,w;ci,co,h,w" (h, w = the gradient's size)
+    layers = [tuple(int(v) for v in l.split(",")) for l in sys.argv[3].split(";")]
 work = []
 for ci, co, h, w in layers:
     x = torch.randn(n, ci, h * st, w * st, device="cuda").to(torch.bfloat16).contiguous(memory_format=CL)
@@ -31,4 +33,4 @@ best = 1e9
 for _ in range(10):
     e0.record(); run(); e1.record(); torch.cuda.synchronize()
     best = min(best, e0.elapsed_time(e1))
-print("stride %d, %d images: %.1f us per flush (group launch + fold), %.0f TFLOP/s" % (st, n, best * 1e3, flops / (best * 1e-3) / 1e12))
+print("layers %s: " % (sys.argv[3] if len(sys.argv) > 3 else "default") + "stride %d, %d images: %.1f us per flush (group launch + fold), %.0f TFLOP/s" % (st, n, best * 1e3, flops / (best * 1e-3) / 1e12))
