@@ -247,6 +247,101 @@ __global__ __launch_bounds__(256) void dense_bwd_data_fast_kernel(const T* __res
     }
 }
 
+// The same map for MANY SHORT ROWS (the discriminator's 8192 x 256 dense: 8192 one-KiB weight rows) on the exact-fp32 MFMA
+// (v_mfma_f32_16x16x4_f32: an fmaf chain, bitwise): a wave per tile of 16 weight rows x 16 batch rows, K = out.  The wave-per-row
+// form above spends its time in cross-lane sums -- 16 wave reductions of 6 shuffle steps per KiB of weights, 21 us for 8.4 MB --
+// where the matrix core reduces in hardware.  Lane (n = lane & 15, kq = lane >> 4) feeds B[k][n] = w[row n][k] and A[m][k] = gy[m][k] with
+// m = lane & 15; step (j, e) of the K loop uses k = 16 j + 4 kq + e, so that a lane reads 16 contiguous bytes of its weight row per j
+// (the four lanes of a row 64 contiguous bytes) and 4 consecutive gradients.  D[m = 4 (lane >> 4) + r][n = lane & 15] = acc[r].
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+template <typename T>
+__global__ __launch_bounds__(256) void dense_bwd_data_mfma_kernel(const T* __restrict__ gy, const float* __restrict__ w, T* __restrict__ gx,
+                                                                  int b, int in, int out, float alpha, int rc, int rhw) {
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile * 16 >= in) return;
+    const int n = lane & 15, kq = lane >> 4;
+    const int row = tile * 16 + n;
+    const float* wr = w + dense_row(row < in ? row : in - 1, rc, rhw) * out + 4 * kq;
+    for (int m0 = 0; m0 < b; m0 += 16) {
+        const int m = m0 + n;   // (this lane's A row; rows past b re-read the last one, their results are never written)
+        const T* ar = gy + (long)(m < b ? m : b - 1) * out + 4 * kq;
+        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int k = 0; k < out; k += 16) {
+            const float4 bv = *reinterpret_cast<const float4*>(wr + k);
+            float av[4];
+            ld4(ar + k, av);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bv.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], bv.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], bv.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], bv.w, acc, 0, 0, 0);
+        }
+        if (row < in) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int mm = m0 + 4 * kq + r;
+                if (mm < b) DT<T>::st(gx + (long)mm * in + row, acc[r] * alpha);
+            }
+        }
+    }
+}
+
+// Forward of the same tall layer (in = 8192, out = 256, 8 or 16 batch rows): y[m][c] = sum_k x[m][k] w[k][c] on the exact-fp32 MFMA, K split
+// over waves (64 input rows each: 512 waves for the discriminator's dense), partial sums through `part[ks][b][out]` and the existing
+// finalize pass (fixed order: deterministic).  A wave owns 64 columns as four interleaved 16-column tiles -- tile e = columns 4 n + e --
+// so that a lane's B operands of the four tiles are ONE 16-byte load of weight row k (the 16 lanes of a kq group read 256 contiguous
+// bytes); lane (n, kq) takes k = k0 + 16 kq + 4 t + u.
+template <typename T>
+__global__ __launch_bounds__(256) void dense_fwd_mfma_kernel(const T* __restrict__ x, const float* __restrict__ w, float* __restrict__ part,
+                                                             int b, int in, int out, int rc, int rhw) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int ncg = out / 64;
+    const int cg = wave % ncg, ks = wave / ncg;
+    if (ks * 64 >= in) return;
+    const int n = lane & 15, kq = lane >> 4;
+    const int kb = ks * 64 + 16 * kq;   // this lane's 16 input rows
+    const float* wc = w + cg * 64 + 4 * n;
+    // all 16 weight loads of the lane go out before the first MFMA (a `rc ? mapped : plain` branch per row made hipcc wait for every load
+    // by itself: 16 serial memory latencies, 12-15 us); the row map is walked incrementally -- rc_ = "rows per column block", 1 << 30 when
+    // there is no map, so that row % rc_ = row and row / rc_ = 0
+    const int rc_ = rc ? rc : (1 << 30), rhw_ = rc ? rhw : 1;
+    int rem = kb % rc_, quo = kb / rc_;
+    float4 bv[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        bv[i] = *reinterpret_cast<const float4*>(wc + ((long)rem * rhw_ + quo) * out);
+        ++rem;
+        const bool wrap = rem == rc_;
+        rem = wrap ? 0 : rem;
+        quo += wrap ? 1 : 0;
+    }
+    for (int m0 = 0; m0 < b; m0 += 16) {
+        const int m = m0 + n;
+        const T* ar = x + (long)(m < b ? m : b - 1) * in + kb;
+        float av[4][4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) ld4(ar + 4 * t, av[t]);
+        f32x4_t acc[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float a = av[i >> 2][i & 3];
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[i].x, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[i].y, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[i].z, acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[i].w, acc[3], 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int mm = m0 + 4 * kq + r;
+            if (mm < b) *reinterpret_cast<float4*>(part + ((long)ks * b + mm) * out + cg * 64 + 4 * n) = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+        }
+    }
+}
+
 // gw[i][o] (+)= alpha * sum_b x[b][i] gy[b][o], out % 256 == 0, b <= DENSE_BT: a thread keeps its 4 columns of gy for every
 // batch row in registers and walks DENSE_WR rows of the weight matrix (16-byte stores).
 constexpr int DENSE_WR = 16;
@@ -285,7 +380,16 @@ __global__ __launch_bounds__(256) void dense_bwd_weight_fast_kernel(const T* __r
 }
 
 static bool dense_fwd_fast_ok(int in, int out) { return in % 4 == 0 && out % 32 == 0; }
+static bool dense_fwd_mfma_ok(int in, int out) {
+    static const bool no_mfma = getenv("GS_NO_DENSE_MFMA") != nullptr;   // A/B switch
+    return !no_mfma && in >= 2048 && in % 64 == 0 && out % 64 == 0 && out <= 1024;
+}
 static void dense_split(int in, int out, int* ksplit, int* ipb) {
+    if (dense_fwd_mfma_ok(in, out)) {   // tall layer on the fp32 MFMA: 64 input rows per wave
+        *ipb = 64;
+        *ksplit = in / 64;
+        return;
+    }
     if (dense_fwd_fast_ok(in, out)) {   // (out/32) x ksplit blocks should cover the chip twice; a split handles >= 128 rows
         const int tiles = out / 32;
         int ks = tiles >= 128 ? 1 : (512 + tiles - 1) / tiles;   // >= 128 column tiles: no split, no finalize launch
@@ -582,6 +686,14 @@ static int dense_fwd_impl(const void* x, const float* w, void* y, int b, int in,
     if (ws_bytes < (size_t)ks * b * out * sizeof(float)) return fail(GS_ERR_WORKSPACE, "dense_fwd: workspace too small");
     hipStream_t st = as_stream(stream);
     float* part = (float*)ws;
+    if (dense_fwd_mfma_ok(in, out)) {
+        GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dense_fwd_mfma_kernel<T>), dim3(cdiv((out / 64) * ks, 4)), dim3(256), 0, st, (const T*)x, w, part, b, in, out, rc, rhw));
+        GS_CHECK_LAUNCH();
+        const long n = (long)b * out;
+        GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dense_finalize_kernel<T>), dim3(cdiv(n, 64)), dim3(256), 0, st, part, (T*)y, n, ks, alpha));
+        GS_CHECK_LAUNCH();
+        return 0;
+    }
     const bool fast = dense_fwd_fast_ok(in, out);
     const int step = fast ? fast_rows(b) : DENSE_BT;
     for (int b0 = 0; b0 < b; b0 += step) {
@@ -616,6 +728,13 @@ static int dense_bwd_data_impl(const void* gy, const float* w, void* gx, int b, 
     GS_CHECK_ARG(rc == 0 || (rc > 0 && rhw > 0 && rc * rhw == in), "dense_bwd_data: a %d x %d channels-last input is not %d wide", rc, rhw, in);
     if (rc && out % 256 != 0) return fail(GS_ERR_UNSUPPORTED, "dense_bwd_data: channels-last input needs out %% 256 == 0");
     hipStream_t st = as_stream(stream);
+    static const bool no_mfma = getenv("GS_NO_DENSE_MFMA") != nullptr;   // A/B switch
+    if (!no_mfma && in >= 1024 && out % 16 == 0 && out <= 4096) {   // many short rows: a wave per 16 weight rows on the fp32 MFMA
+        GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dense_bwd_data_mfma_kernel<T>), dim3(cdiv(cdiv(in, 16), 4)), dim3(256), 0, st, (const T*)gy, w, (T*)gx,
+                                                    b, in, out, alpha, rc, rhw));
+        GS_CHECK_LAUNCH();
+        return 0;
+    }
     const int step = out % 256 == 0 ? fast_rows(b) : DENSE_BT;
     for (int b0 = 0; b0 < b; b0 += step) {
         const int nb = b - b0 < step ? b - b0 : step;
