@@ -43,6 +43,27 @@ __global__ __launch_bounds__(256) void dense_fwd_kernel(const T* __restrict__ x,
             part[((long)ks * b_total + b0 + b) * out + col] = red[0][b][tid] + red[1][b][tid] + red[2][b][tid] + red[3][b][tid];
     }
 }
+// Small layers (the 256 -> 61 logits, ops.py:183-201 on networks.py:186): one block per (64 columns, batch row), 4 row lanes folded through
+// LDS, the result written directly -- instead of 8 row-split blocks + a finalize launch (10 + 5 us for a 16 x 256 x 61 product).
+template <typename T>
+__global__ __launch_bounds__(256) void dense_fwd_small_kernel(const T* __restrict__ x, const float* __restrict__ w, T* __restrict__ y, int in, int out, float alpha) {
+    __shared__ float red[4][64];
+    const int c = threadIdx.x & 63, sub = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + c;
+    const int colc = col < out ? col : out - 1;   // (unconditional loads)
+    const T* xr = x + (long)blockIdx.y * in;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int i = sub;
+    for (; i + 12 < in; i += 16) {
+        const float w0 = w[(long)i * out + colc], w1 = w[(long)(i + 4) * out + colc], w2 = w[(long)(i + 8) * out + colc], w3 = w[(long)(i + 12) * out + colc];
+        a0 += DT<T>::ld(xr + i) * w0; a1 += DT<T>::ld(xr + i + 4) * w1; a2 += DT<T>::ld(xr + i + 8) * w2; a3 += DT<T>::ld(xr + i + 12) * w3;
+    }
+    for (; i < in; i += 4) a0 += DT<T>::ld(xr + i) * w[(long)i * out + colc];
+    red[sub][c] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (sub == 0 && col < out) DT<T>::st(y + (long)blockIdx.y * out + col, (red[0][c] + red[1][c] + red[2][c] + red[3][c]) * alpha);
+}
+
 // block = 64 elements x 4 split lanes (a narrow layer has few elements and up to 64 splits: a thread per element would walk them
 // as one chain in a handful of blocks)
 template <typename T>
@@ -599,17 +620,24 @@ __global__ __launch_bounds__(256) void gan_d_loss_kernel(const T* __restrict__ r
     __shared__ float sr[1024], sf[1024];
     const float inv_n = 1.f / (float)n;
     float part = 0.f;
-    for (int i = threadIdx.x; i < n; i += 256) {
+    // a WAVE per sample, its lanes over the classes (a thread per sample walked the 61 classes as one chain of dependent loads: 8-11 us for
+    // 16 samples)
+    const int lane = threadIdx.x & 63;
+    for (int i = threadIdx.x >> 6; i < n; i += 4) {
         float r = 0.f, f = 0.f;
-        for (int k = 0; k < c; ++k) {
+        for (int k = lane; k < c; k += 64) {
             const float l = DT<T>::ld(lab + (long)i * c + k);
             r += DT<T>::ld(rl + (long)i * c + k) * l;
             f += DT<T>::ld(fl + (long)i * c + k) * l;
         }
-        part += softplus_f(-r) + softplus_f(f) + (pen ? pen_w * pen[i] : 0.f);
-        if (g_pen) g_pen[i] = pen_w * inv_n;
-        sr[i] = -sigmoid_f(-r) * inv_n;   // d mean / d r_i
-        sf[i] = sigmoid_f(f) * inv_n;     // d mean / d f_i
+        r = wave_sum(r);
+        f = wave_sum(f);
+        if (lane == 0) {
+            part += softplus_f(-r) + softplus_f(f) + (pen ? pen_w * pen[i] : 0.f);
+            if (g_pen) g_pen[i] = pen_w * inv_n;
+            sr[i] = -sigmoid_f(-r) * inv_n;   // d mean / d r_i
+            sf[i] = sigmoid_f(f) * inv_n;     // d mean / d f_i
+        }
     }
     const float tot = block_sum<256>(part, red);
     if (threadIdx.x == 0) loss[0] = tot * inv_n;
@@ -630,15 +658,19 @@ __global__ __launch_bounds__(256) void gan_g_loss_kernel(const T* __restrict__ f
     __shared__ float sf[1024];
     const float inv_n = 1.f / (float)n;
     float part = 0.f;
-    for (int i = threadIdx.x; i < n; i += 256) {
+    const int lane = threadIdx.x & 63;
+    for (int i = threadIdx.x >> 6; i < n; i += 4) {   // a wave per sample (see gan_d_loss_kernel)
         float f = 0.f;
-        for (int k = 0; k < c; ++k) f += DT<T>::ld(fl + (long)i * c + k) * DT<T>::ld(lab + (long)i * c + k);
-        part += softplus_f(-f);
-        sf[i] = -sigmoid_f(-f) * inv_n;
-        if (ssq) {
-            const float d = ssq[i] + eps;
-            part += w / d;
-            g_ssq[i] = -w / (d * d) * inv_n;
+        for (int k = lane; k < c; k += 64) f += DT<T>::ld(fl + (long)i * c + k) * DT<T>::ld(lab + (long)i * c + k);
+        f = wave_sum(f);
+        if (lane == 0) {
+            part += softplus_f(-f);
+            sf[i] = -sigmoid_f(-f) * inv_n;
+            if (ssq) {
+                const float d = ssq[i] + eps;
+                part += w / d;
+                g_ssq[i] = -w / (d * d) * inv_n;
+            }
         }
     }
     const float tot = block_sum<256>(part, red);
@@ -686,6 +718,11 @@ static int dense_fwd_impl(const void* x, const float* w, void* y, int b, int in,
     if (ws_bytes < (size_t)ks * b * out * sizeof(float)) return fail(GS_ERR_WORKSPACE, "dense_fwd: workspace too small");
     hipStream_t st = as_stream(stream);
     float* part = (float*)ws;
+    if (!rc && in <= 1024 && out <= 256 && b <= 64) {   // small layer: direct, one launch
+        GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dense_fwd_small_kernel<T>), dim3(cdiv(out, 64), b), dim3(256), 0, st, (const T*)x, w, (T*)y, in, out, alpha));
+        GS_CHECK_LAUNCH();
+        return 0;
+    }
     if (dense_fwd_mfma_ok(in, out)) {
         GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dense_fwd_mfma_kernel<T>), dim3(cdiv((out / 64) * ks, 4)), dim3(256), 0, st, (const T*)x, w, part, b, in, out, rc, rhw));
         GS_CHECK_LAUNCH();
