@@ -64,6 +64,8 @@ SIGNATURES = {
     "gs_conv2d_transpose_s2_bwd_weight": (I, [P, P, P, I, I, I, I, I, F, I, I, P, Z, P]),
     "gs_dense_fwd_workspace_bytes": (Z, [I, I, I]),
     "gs_dense_fwd": (I, [P, P, P, I, I, I, F, I, P, Z, P]),
+    "gs_dense_fwd_bias_act": (I, [P, P, P, P, I, I, I, F, I, I, P, Z, P]),
+    "gs_dense_fwd_bias_act_nhwc": (I, [P, P, P, P, I, I, I, I, F, I, I, P, Z, P]),
     "gs_dense_bwd_data": (I, [P, P, P, I, I, I, F, I, P]),
     "gs_dense_bwd_weight": (I, [P, P, P, I, I, I, F, I, I, P]),
     "gs_dense_fwd_nhwc": (I, [P, P, P, I, I, I, I, F, I, P, Z, P]),

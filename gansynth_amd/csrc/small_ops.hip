@@ -7,6 +7,15 @@ namespace gs {
 
 constexpr int DENSE_BT = 16;  // batch rows held in registers per pass
 
+// epilogue of the fused forms (gs_dense_fwd_bias_act*): y = act(alpha * sum + bias[col]); bias may be NULL, act = GS_ACT_*
+__device__ __forceinline__ float dense_epilogue(float sum, float alpha, const float* __restrict__ bias, int col, int act) {
+    float v = sum * alpha;
+    if (bias) v += bias[col];
+    if (act == GS_ACT_LRELU) v = v > 0.f ? v : 0.2f * v;
+    else if (act == GS_ACT_TANH) v = tanhf(v);
+    return v;
+}
+
 // ---------------------------------------------------------------------------- dense fwd
 // y[b][o] = alpha * sum_i x[b][i] * w[i][o].  Block = 64 output columns x 4 i-lanes; grid.y
 // splits the reduction so that (out/64)*ksplit blocks cover the chip; partial sums go through
@@ -46,7 +55,8 @@ __global__ __launch_bounds__(256) void dense_fwd_kernel(const T* __restrict__ x,
 // Small layers (the 256 -> 61 logits, ops.py:183-201 on networks.py:186): one block per (64 columns, batch row), 4 row lanes folded through
 // LDS, the result written directly -- instead of 8 row-split blocks + a finalize launch (10 + 5 us for a 16 x 256 x 61 product).
 template <typename T>
-__global__ __launch_bounds__(256) void dense_fwd_small_kernel(const T* __restrict__ x, const float* __restrict__ w, T* __restrict__ y, int in, int out, float alpha) {
+__global__ __launch_bounds__(256) void dense_fwd_small_kernel(const T* __restrict__ x, const float* __restrict__ w, T* __restrict__ y, int in, int out, float alpha,
+                                                              const float* __restrict__ bias, int act) {
     __shared__ float red[4][64];
     const int c = threadIdx.x & 63, sub = threadIdx.x >> 6;
     const int col = blockIdx.x * 64 + c;
@@ -61,13 +71,14 @@ __global__ __launch_bounds__(256) void dense_fwd_small_kernel(const T* __restric
     for (; i < in; i += 4) a0 += DT<T>::ld(xr + i) * w[(long)i * out + colc];
     red[sub][c] = (a0 + a1) + (a2 + a3);
     __syncthreads();
-    if (sub == 0 && col < out) DT<T>::st(y + (long)blockIdx.y * out + col, (red[0][c] + red[1][c] + red[2][c] + red[3][c]) * alpha);
+    if (sub == 0 && col < out) DT<T>::st(y + (long)blockIdx.y * out + col, dense_epilogue(red[0][c] + red[1][c] + red[2][c] + red[3][c], alpha, bias, col, act));
 }
 
 // block = 64 elements x 4 split lanes (a narrow layer has few elements and up to 64 splits: a thread per element would walk them
 // as one chain in a handful of blocks)
 template <typename T>
-__global__ __launch_bounds__(256) void dense_finalize_kernel(const float* __restrict__ part, T* __restrict__ y, long n, int ksplit, float alpha) {
+__global__ __launch_bounds__(256) void dense_finalize_kernel(const float* __restrict__ part, T* __restrict__ y, long n, int ksplit, float alpha,
+                                                             const float* __restrict__ bias = nullptr, int act = 0, int out = 1) {
     __shared__ float red[4][64];
     const int e = threadIdx.x & 63, kl = threadIdx.x >> 6;
     const long i = (long)blockIdx.x * 64 + e;
@@ -79,7 +90,7 @@ __global__ __launch_bounds__(256) void dense_finalize_kernel(const float* __rest
     }
     red[kl][e] = s0 + s1;
     __syncthreads();
-    if (kl == 0 && i < n) DT<T>::st(y + i, (red[0][e] + red[1][e] + red[2][e] + red[3][e]) * alpha);
+    if (kl == 0 && i < n) DT<T>::st(y + i, dense_epilogue(red[0][e] + red[1][e] + red[2][e] + red[3][e], alpha, bias, (int)(i % out), act));
 }
 
 // ------------------------------------------------------------------------ dense bwd data
@@ -162,7 +173,8 @@ static int fast_rows(int b) { return b <= 8 ? 8 : (b <= 16 ? 16 : 24); }
 // xor-shuffles inside a wave and through LDS across the 4 waves; with ksplit == 1 the result is written directly.
 template <typename T, int FB>
 __global__ __launch_bounds__(256) void dense_fwd_fast_kernel(const T* __restrict__ x, const float* __restrict__ w, float* __restrict__ part,
-                                                             T* __restrict__ y, int b0, int nb, int in, int out, int b_total, int ipb, float alpha, int rc, int rhw) {
+                                                             T* __restrict__ y, int b0, int nb, int in, int out, int b_total, int ipb, float alpha, int rc, int rhw,
+                                                             const float* __restrict__ bias, int act) {
     __shared__ float red[4][FB][32];
     const int tid = threadIdx.x;
     const int c = tid & 7, r = tid >> 3;           // column thread, row lane (0..31)
@@ -219,7 +231,7 @@ __global__ __launch_bounds__(256) void dense_fwd_fast_kernel(const T* __restrict
         const float s = red[0][b][cc] + red[1][b][cc] + red[2][b][cc] + red[3][b][cc];
         const int o = blockIdx.x * 32 + cc;
         if (part) part[((long)blockIdx.y * b_total + b0 + b) * out + o] = s;
-        else DT<T>::st(y + (long)(b0 + b) * out + o, s * alpha);
+        else DT<T>::st(y + (long)(b0 + b) * out + o, dense_epilogue(s, alpha, bias, o, act));
     }
 }
 
@@ -709,7 +721,8 @@ extern "C" size_t gs_dense_fwd_workspace_bytes(int b, int in, int out) {
 }
 
 static int dense_fwd_impl(const void* x, const float* w, void* y, int b, int in, int out, float alpha, int dtype,
-                          void* ws, size_t ws_bytes, void* stream, int rc, int rhw) {
+                          void* ws, size_t ws_bytes, void* stream, int rc, int rhw, const float* bias = nullptr, int act = 0) {
+    GS_CHECK_ARG(act >= 0 && act <= 2, "dense_fwd: bad activation %d", act);
     GS_CHECK_ARG(b > 0 && in > 0 && out > 0, "dense_fwd: bad args");
     GS_CHECK_ARG(rc == 0 || (rc > 0 && rhw > 0 && rc * rhw == in), "dense_fwd: a %d x %d channels-last input is not %d wide", rc, rhw, in);
     if (rc && !dense_fwd_fast_ok(in, out)) return fail(GS_ERR_UNSUPPORTED, "dense_fwd: channels-last input needs in %% 4 == 0 and out %% 32 == 0");
@@ -719,7 +732,7 @@ static int dense_fwd_impl(const void* x, const float* w, void* y, int b, int in,
     hipStream_t st = as_stream(stream);
     float* part = (float*)ws;
     if (!rc && in <= 1024 && out <= 256 && b <= 64) {   // small layer: direct, one launch
-        GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dense_fwd_small_kernel<T>), dim3(cdiv(out, 64), b), dim3(256), 0, st, (const T*)x, w, (T*)y, in, out, alpha));
+        GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dense_fwd_small_kernel<T>), dim3(cdiv(out, 64), b), dim3(256), 0, st, (const T*)x, w, (T*)y, in, out, alpha, bias, act));
         GS_CHECK_LAUNCH();
         return 0;
     }
@@ -727,7 +740,7 @@ static int dense_fwd_impl(const void* x, const float* w, void* y, int b, int in,
         GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dense_fwd_mfma_kernel<T>), dim3(cdiv((out / 64) * ks, 4)), dim3(256), 0, st, (const T*)x, w, part, b, in, out, rc, rhw));
         GS_CHECK_LAUNCH();
         const long n = (long)b * out;
-        GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dense_finalize_kernel<T>), dim3(cdiv(n, 64)), dim3(256), 0, st, part, (T*)y, n, ks, alpha));
+        GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dense_finalize_kernel<T>), dim3(cdiv(n, 64)), dim3(256), 0, st, part, (T*)y, n, ks, alpha, bias, act, out));
         GS_CHECK_LAUNCH();
         return 0;
     }
@@ -737,7 +750,7 @@ static int dense_fwd_impl(const void* x, const float* w, void* y, int b, int in,
         const int nb = b - b0 < step ? b - b0 : step;
         if (fast) {
 #define GS_DFF(FBV) GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dense_fwd_fast_kernel<T, FBV>), dim3(out / 32, ks), dim3(256), 0, st, (const T*)x, w, \
-                                                                ks > 1 ? part : nullptr, (T*)y, b0, nb, in, out, b, ipb, alpha, rc, rhw))
+                                                                ks > 1 ? part : nullptr, (T*)y, b0, nb, in, out, b, ipb, alpha, rc, rhw, bias, act))
             if (step == 8) GS_DFF(8); else if (step == 16) GS_DFF(16); else GS_DFF(24);
 #undef GS_DFF
         } else {
@@ -747,9 +760,17 @@ static int dense_fwd_impl(const void* x, const float* w, void* y, int b, int in,
     }
     if (fast && ks == 1) return 0;
     const long n = (long)b * out;
-    GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dense_finalize_kernel<T>), dim3(cdiv(n, 64)), dim3(256), 0, st, part, (T*)y, n, ks, alpha));
+    GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dense_finalize_kernel<T>), dim3(cdiv(n, 64)), dim3(256), 0, st, part, (T*)y, n, ks, alpha, bias, act, out));
     GS_CHECK_LAUNCH();
     return 0;
+}
+extern "C" int gs_dense_fwd_bias_act(const void* x, const float* w, const float* bias, void* y, int b, int in, int out, float alpha, int act, int dtype,
+                                     void* ws, size_t ws_bytes, void* stream) {
+    return dense_fwd_impl(x, w, y, b, in, out, alpha, dtype, ws, ws_bytes, stream, 0, 0, bias, act);
+}
+extern "C" int gs_dense_fwd_bias_act_nhwc(const void* x, const float* w, const float* bias, void* y, int b, int c, int hw, int out, float alpha, int act, int dtype,
+                                          void* ws, size_t ws_bytes, void* stream) {
+    return dense_fwd_impl(x, w, y, b, c * hw, out, alpha, dtype, ws, ws_bytes, stream, c, hw, bias, act);
 }
 extern "C" int gs_dense_fwd(const void* x, const float* w, void* y, int b, int in, int out, float alpha, int dtype,
                             void* ws, size_t ws_bytes, void* stream) {

@@ -182,6 +182,11 @@ class _DenseKind(object):
     def fwd(self, x, w, alpha):
         return _K().dense_fwd(x, w, alpha)
 
+    def fwd_bias_act(self, x, w, bias, alpha, act):
+        if hasattr(_K(), "dense_fwd_bias_act"):
+            return _K().dense_fwd_bias_act(x, w, bias, alpha, act)
+        return _K().bias_act_fwd(_K().dense_fwd(x, w, alpha), bias, act)
+
     def bwd_data(self, gy, w, x_shape, alpha):
         return _K().dense_bwd_data(gy, w, alpha)
 
@@ -195,6 +200,11 @@ class _DenseFlatKind(object):
 
     def fwd(self, x, w, alpha):
         return _K().dense_fwd_nhwc(x, w, alpha)
+
+    def fwd_bias_act(self, x, w, bias, alpha, act):
+        if hasattr(_K(), "dense_fwd_bias_act"):
+            return _K().dense_fwd_bias_act(x, w, bias, alpha, act)
+        return _K().bias_act_fwd(_K().dense_fwd_nhwc(x, w, alpha), bias, act)
 
     def bwd_data(self, gy, w, x_shape, alpha):
         return _K().dense_bwd_data_nhwc(gy, w, x_shape, alpha)
@@ -777,6 +787,17 @@ def conv2d_transpose(x, w, alpha):
 
 def dense(x, w, alpha):
     return _Bilinear.apply(x, w, _kind(("dense",)), alpha)
+
+
+def dense_bias_act(x, w, bias, alpha, act):
+    """act(alpha * x @ w + bias) (ops.py:183-201 as one node: the bias / activation ride where the forward writes its result).  x: [b, in], or
+    a channels-last 4-D activation whose NCHW flatten feeds the layer (networks.py:185-186) where the kernel layer takes it as it is."""
+    K = _K()
+    if x.dim() == 4:
+        if hasattr(K, "dense_nhwc_ok") and K.dense_nhwc_ok(x, w.shape[1]):
+            return _ConvBiasAct.apply(x, w, bias, _kind(("dense_flat",)), alpha, act)
+        x = x.reshape(x.shape[0], -1)
+    return _ConvBiasAct.apply(x, w, bias, _kind(("dense",)), alpha, act)
 
 
 def dense_of_flattened(x, w, alpha):

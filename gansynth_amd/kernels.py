@@ -527,6 +527,25 @@ class HipKernels(object):
                                          ws.data_ptr(), ws.numel(), _stream()), "gs_dense_fwd")
         return y
 
+    def dense_fwd_bias_act(self, x, w, bias, alpha, act):
+        """act(alpha * x @ w + bias): bias / activation where the forward writes its result (x 2-D, or a channels-last 4-D activation
+        whose NCHW flatten feeds the layer)."""
+        x, w = _act(x), _f32c(w)
+        o = w.shape[1]
+        y = torch.empty((x.shape[0], o), dtype=x.dtype, device=x.device)
+        bp = None if bias is None else _f32c(bias).data_ptr()
+        if x.dim() == 4:
+            b, c, h, wd = x.shape
+            ws = _ws(self.lib.gs_dense_fwd_workspace_bytes(b, c * h * wd, o), x.device)
+            _lib.check(self.lib.gs_dense_fwd_bias_act_nhwc(x.data_ptr(), w.data_ptr(), bp, y.data_ptr(), b, c, h * wd, o, float(alpha), int(act), _dt(x),
+                                                           ws.data_ptr(), ws.numel(), _stream()), "gs_dense_fwd_bias_act_nhwc")
+        else:
+            b, i = x.shape
+            ws = _ws(self.lib.gs_dense_fwd_workspace_bytes(b, i, o), x.device)
+            _lib.check(self.lib.gs_dense_fwd_bias_act(x.data_ptr(), w.data_ptr(), bp, y.data_ptr(), b, i, o, float(alpha), int(act), _dt(x),
+                                                      ws.data_ptr(), ws.numel(), _stream()), "gs_dense_fwd_bias_act")
+        return y
+
     def dense_bwd_data(self, gy, w, alpha):
         gy, w = _act(gy), _f32c(w)
         b, o = gy.shape

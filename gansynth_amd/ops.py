@@ -41,14 +41,12 @@ def dense(inputs, units, use_bias=True, variance_scale=2.0, scale_weight=False, 
     """ops.py:183-201."""
     if inputs.dim() == 4:   # tf.layers.flatten of NCHW (networks.py:185) folded into the layer: no channel-major copy
         weight, alpha = get_weight([inputs.shape[1] * inputs.shape[2] * inputs.shape[3], units], variance_scale, scale_weight)
-        outputs = F.dense_of_flattened(inputs, weight, alpha)
     else:
         weight, alpha = get_weight([inputs.shape[1], units], variance_scale, scale_weight)
-        outputs = F.dense(inputs, weight, alpha)
     bias = get_bias([units]) if use_bias else None
-    if bias is not None or activation is not None:
-        outputs = F.bias_act(outputs, bias, _ACT[activation])
-    return outputs
+    if bias is not None or activation is not None:   # dense -> bias_add -> activation as one node (bias / activation where the forward writes)
+        return F.dense_bias_act(inputs, weight, bias, alpha, _ACT[activation])
+    return F.dense_of_flattened(inputs, weight, alpha) if inputs.dim() == 4 else F.dense(inputs, weight, alpha)
 
 
 def dense_reshaped(inputs, channels, resolution, use_bias=True, variance_scale=2.0, scale_weight=False, activation=None):

@@ -255,12 +255,20 @@ int gs_dense_fwd(const void* x, const float* w, void* y, int b, int in, int out,
 int gs_dense_bwd_data(const void* gy, const float* w, void* gx, int b, int in, int out, float alpha, int dtype, void* stream);
 int gs_dense_bwd_weight(const void* x, const void* gy, float* gw, int b, int in, int out, float alpha, int accumulate, int dtype,
                         void* stream);
+/* ops.py:183-201 as the reference calls it -- dense, bias_add, activation (networks.py:185-187: the discriminator's 8192 -> 256 dense
+ * + leaky_relu and its 256 -> 61 logits layer): y = act(alpha * x @ w + bias) with bias (may be NULL) and activation applied where the
+ * forward writes its result (the split-K finalize pass or the direct store): one or two launches instead of three.  fp32: the same
+ * operations in the same order as gs_dense_fwd + gs_bias_act_fwd (bit-identical); bf16: one rounding instead of two. */
+int gs_dense_fwd_bias_act(const void* x, const float* w, const float* bias, void* y, int b, int in, int out, float alpha, int act,
+                          int dtype, void* ws, size_t ws_bytes, void* stream);
 /* The same three maps with the INPUT side in channels-last memory: x / gx are the [b][hw][c] memory of an activation whose
  * tf.layers.flatten (NCHW: column c * hw + p, networks.py:185) feeds the layer, w stays [c * hw][out] as stored.  The flatten is a
  * row-index map inside the kernels -- no NCHW copy of the activation, no copy of its gradient back.  Vector-path shapes only
  * (out % 256 == 0, batch <= 16 for bwd_weight; GS_ERR_UNSUPPORTED otherwise). */
 int gs_dense_fwd_nhwc(const void* x, const float* w, void* y, int b, int c, int hw, int out, float alpha, int dtype,
                       void* ws, size_t ws_bytes, void* stream);
+int gs_dense_fwd_bias_act_nhwc(const void* x, const float* w, const float* bias, void* y, int b, int c, int hw, int out, float alpha,
+                               int act, int dtype, void* ws, size_t ws_bytes, void* stream);
 int gs_dense_bwd_data_nhwc(const void* gy, const float* w, void* gx, int b, int c, int hw, int out, float alpha, int dtype, void* stream);
 int gs_dense_bwd_weight_nhwc(const void* x, const void* gy, float* gw, int b, int c, int hw, int out, float alpha, int accumulate,
                              int dtype, void* stream);

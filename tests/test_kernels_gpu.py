@@ -111,6 +111,26 @@ def test_dense(K, E, b, i, o):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("b,i,o,act", [(8, 8192, 256, 1), (16, 8192, 256, 1), (16, 256, 61, 0), (8, 512, 8192, 1), (5, 100, 70, 2), (24, 8192, 256, 1), (8, 256, 61, 0)])
+def test_dense_with_bias_and_activation_where_the_forward_writes(K, E, b, i, o, act, dtype):
+    """gs_dense_fwd_bias_act (ops.py:183-201: matmul, bias_add, activation as the reference calls them -- the discriminator's dense + leaky_relu
+    and its logits layer): against the oracle-side emulation, and in fp32 bit-identical to the two separate entry points (same operations,
+    same order) on every kernel path (MFMA split-K + finalize, one-launch small layer, wide direct, generic)."""
+    x, w, bias = rnd(b, i, seed=1).to(dtype).float(), rnd(i, o, seed=2), rnd(o, seed=3)
+    alpha = float(np.sqrt(2.0 / i))
+    want = E.bias_act_fwd(E.dense_fwd(x, w, alpha), bias, act)
+    got = K.dense_fwd_bias_act(dev(x, dtype), dev(w), dev(bias), alpha, act)
+    close(got, want, rel=2e-2 if dtype == torch.bfloat16 else 1e-3, name="fused")
+    two = K.bias_act_fwd(K.dense_fwd(dev(x, dtype), dev(w), alpha), dev(bias), act)
+    if dtype == torch.float32:
+        assert torch.equal(got, two)
+    else:   # one rounding instead of two: at least as close to the fp32 evaluation
+        ref = K.bias_act_fwd(K.dense_fwd(dev(x), dev(w), alpha), dev(bias), act).double()
+        assert float((got.double() - ref).pow(2).mean()) <= 1.05 * float((two.double() - ref).pow(2).mean()) + 1e-12
+    assert torch.equal(K.dense_fwd_bias_act(dev(x, dtype), dev(w), None, alpha, 0), K.dense_fwd(dev(x, dtype), dev(w), alpha))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("b,c,h,w,o", [(8, 256, 2, 16, 256), (4, 64, 2, 16, 256), (16, 256, 2, 16, 512)])
 def test_dense_of_a_flattened_channels_last_activation(K, E, b, c, h, w, o, dtype):
     """gs_dense_*_nhwc: dense(tf.layers.flatten(x)) with x left in channels-last memory (the flatten is a row map inside the kernels)
@@ -122,6 +142,9 @@ def test_dense_of_a_flattened_channels_last_activation(K, E, b, c, h, w, o, dtyp
     assert K.dense_nhwc_ok(x_cl, o)
     flat = x4.reshape(b, -1)                   # NCHW flatten: column c * hw + p
     close(K.dense_fwd_nhwc(x_cl, dev(wt), alpha), E.dense_fwd(flat, wt, alpha), rel=2e-2 if dtype == torch.bfloat16 else 1e-3, name="fwd")
+    bias = rnd(o, seed=4)
+    close(K.dense_fwd_bias_act(x_cl, dev(wt), dev(bias), alpha, 1), E.bias_act_fwd(E.dense_fwd(flat, wt, alpha), bias, 1),
+          rel=2e-2 if dtype == torch.bfloat16 else 1e-3, name="fwd + bias + leaky_relu")
     gx = K.dense_bwd_data_nhwc(dev(gy, dtype), dev(wt), (b, c, h, w), alpha)
     assert gx.shape == (b, c, h, w) and gx.is_contiguous(memory_format=torch.channels_last)
     close(gx.float().cpu().reshape(b, -1), E.dense_bwd_data(gy, wt, alpha), rel=2e-2 if dtype == torch.bfloat16 else 1e-3, name="bwd_data")
