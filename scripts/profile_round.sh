@@ -19,6 +19,7 @@ python $R/scripts/pmc_traffic.py $(find /tmp/pf -name "*.db" | head -1) $(find /
 python $R/scripts/pmc_traffic.py $(find /tmp/pf -name "*.db" | head -1) $(find /tmp/pw -name "*.db" | head -1) conv_wgrad $OUT/${TAG}_pmc_wgrad_traffic.json \
   "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) on \`$CMD1\` (bf16, batch 8)"
 cd $R
-python bench.py > $OUT/${TAG}_bf16_bench.json 2> $OUT/${TAG}_bf16_bench.err
-python bench.py --dtype f32 --no-cpu-baseline > $OUT/${TAG}_f32_bench.json 2>> $OUT/${TAG}_bf16_bench.err
+# (the one compact line on stdout; the per-stage table and notes go to the detail file)
+GS_BENCH_DETAIL=gpurun_out/${TAG}_bf16_bench_detail.json python bench.py > $OUT/${TAG}_bf16_bench.json 2> $OUT/${TAG}_bf16_bench.err
+GS_BENCH_DETAIL=gpurun_out/${TAG}_f32_bench_detail.json python bench.py --dtype f32 --no-cpu-baseline > $OUT/${TAG}_f32_bench.json 2>> $OUT/${TAG}_bf16_bench.err
 tail -c 600 $OUT/${TAG}_bf16_bench.json
