@@ -1271,14 +1271,31 @@ def _cat2(a, b):
     """[a; b] along the batch axis, either half absent = zeros."""
     ref = a if a is not None else b
     n = ref.shape[0]
+    cl = ref.dim() == 4
+    if ref.is_cuda and (a is None or b is None or (a.stride() == b.stride() and a.dtype == b.dtype)):
+        # ONE launch (torch.cat keeps the common memory format of its inputs): an absent half is a constant tensor of zeros, made once
+        if a is None or b is None:
+            key = (tuple(ref.shape), tuple(ref.stride()), ref.dtype, str(ref.device))
+            zeros = _ZEROS.get(key)
+            if zeros is None:
+                zeros = torch.zeros_like(ref)
+                if not torch.cuda.is_current_stream_capturing():   # (memory made inside a capture belongs to that graph's pool)
+                    _ZEROS[key] = zeros
+            a, b = (zeros if a is None else a), (zeros if b is None else b)
+        out = torch.cat((a, b), dim=0)
+        if out.is_contiguous(memory_format=torch.channels_last if cl else torch.contiguous_format):
+            return out
     out = torch.empty((2 * n,) + tuple(ref.shape[1:]), dtype=ref.dtype, device=ref.device,
-                      memory_format=torch.channels_last if ref.dim() == 4 else torch.contiguous_format)
+                      memory_format=torch.channels_last if cl else torch.contiguous_format)
     for half, t in ((out[:n], a), (out[n:], b)):
         if t is None:
             half.zero_()
         else:
             half.copy_(t)
     return out
+
+
+_ZEROS = {}
 
 
 class _CatBatch(Function):
