@@ -172,12 +172,15 @@ static __global__ __launch_bounds__(256) void wgrad_reduce_scalar_kernel(const f
 struct ReduceBatch {
     GsWgradReduce e[GS_REDUCE_BATCH];
 };
+// L = 4: block = 64 consecutive element quads (1 KiB per slice row: whole DRAM bursts) x 4 slice lanes; L = 16: 16 quads x 16 slice lanes
+// (the thin top-level layers leave 256 slices of 18 K floats each: with 4 slice lanes that is 72 blocks per entry walking 64 slices per
+// thread, four loads in flight -- 32-37 us for 19 MB; 16 lanes put four times the loads in flight on four times the blocks).  A thread keeps
+// four slice rows in flight.
+template <int L>
 static __global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const ReduceBatch b) {
-    // block = 64 consecutive element quads (1 KiB per slice row: whole DRAM bursts) x 4 slice lanes; a thread keeps four slice
-    // rows in flight
     const GsWgradReduce& d = b.e[blockIdx.y];
     const int nslices = d.nslices, oc = d.oc, ic = d.ic;
-    constexpr int L = 4, EPB = 64;
+    constexpr int EPB = 256 / L;
     __shared__ float4 red[256];
     const long total = (long)d.taps * ic * oc;
     const long pstride = total + (d.gb ? oc : 0);
@@ -209,6 +212,7 @@ static __global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const Re
     __syncthreads();
     if (sl != 0 || e >= pstride) return;
     float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
     for (int j = 0; j < L; ++j) {
         const float4 v = red[threadIdx.x + j * EPB];
         t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;

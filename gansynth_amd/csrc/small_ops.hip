@@ -64,9 +64,13 @@ __global__ __launch_bounds__(256) void dense_fwd_small_kernel(const T* __restric
     const T* xr = x + (long)blockIdx.y * in;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     int i = sub;
-    for (; i + 12 < in; i += 16) {
-        const float w0 = w[(long)i * out + colc], w1 = w[(long)(i + 4) * out + colc], w2 = w[(long)(i + 8) * out + colc], w3 = w[(long)(i + 12) * out + colc];
-        a0 += DT<T>::ld(xr + i) * w0; a1 += DT<T>::ld(xr + i + 4) * w1; a2 += DT<T>::ld(xr + i + 8) * w2; a3 += DT<T>::ld(xr + i + 12) * w3;
+    // 16 weight rows per trip, all 32 loads of the trip in flight together (a chain of 4-row trips was 16 dependent round trips: 10 us)
+    for (; i + 60 < in; i += 64) {
+        float wv[16], xv[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { wv[k] = w[(long)(i + 4 * k) * out + colc]; xv[k] = DT<T>::ld(xr + i + 4 * k); }
+#pragma unroll
+        for (int k = 0; k < 16; k += 4) { a0 += xv[k] * wv[k]; a1 += xv[k + 1] * wv[k + 1]; a2 += xv[k + 2] * wv[k + 2]; a3 += xv[k + 3] * wv[k + 3]; }
     }
     for (; i < in; i += 4) a0 += DT<T>::ld(xr + i) * w[(long)i * out + colc];
     red[sub][c] = (a0 + a1) + (a2 + a3);
@@ -129,7 +133,15 @@ __global__ void dense_bwd_weight_kernel(const T* __restrict__ x, const T* __rest
     const int o = e % out;
     const int i = e / out;
     float s = 0.f;
-    for (int k = 0; k < b; ++k) s += DT<T>::ld(x + (long)k * in + i) * DT<T>::ld(gy + (long)k * out + o);
+    int k = 0;
+    for (; k + 8 <= b; k += 8) {   // eight batch rows per trip, their 16 loads in flight together
+        float xv[8], gv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { xv[j] = DT<T>::ld(x + (long)(k + j) * in + i); gv[j] = DT<T>::ld(gy + (long)(k + j) * out + o); }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += xv[j] * gv[j];
+    }
+    for (; k < b; ++k) s += DT<T>::ld(x + (long)k * in + i) * DT<T>::ld(gy + (long)k * out + o);
     gw[e] = accumulate ? gw[e] + s * alpha : s * alpha;
 }
 
