@@ -18,6 +18,10 @@
 #include "conv_shared.h"
 #include "gs_prof.h"
 
+#ifndef GS_WGRAD_THIN_PREFETCH
+#define GS_WGRAD_THIN_PREFETCH 1   // conv_wgrad_bf16_kernel: loads of the next tile in flight under the MFMAs of this one (A/B: 0)
+#endif
+
 extern "C" int gs_pixel_norm_fwd(const void* x, void* y, int64_t p, int c, float eps, int dtype, void* stream);
 extern "C" int gs_pixel_norm_bwd_fused(const void* g, const void* x, const void* addend, void* gx, int64_t p, int c, float eps, int pre_act, int post_act, int dtype,
                                        void* stream);
@@ -1008,7 +1012,14 @@ __global__ __launch_bounds__(192) void conv_wgrad_bf16_kernel(
 #pragma unroll
     for (int o = 0; o < OT; ++o) accb[o] = 0.f;
 
-    for (int tile = slice; tile < ntiles; tile += nslices) {
+    // Software pipeline over the block's tiles (GS_WGRAD_THIN_PREFETCH, default on): the global loads of tile t + 1 are issued -- into
+    // registers -- BEFORE the MFMAs of tile t and stored to LDS after them, so that a block's memory latency runs under its own MFMAs instead
+    // of only under those of the two other blocks of the CU.  These layers are HBM-bound (32 channels: 144 flop/byte): what counts is bytes in
+    // flight per CU.
+    uint4 xv[XIT], gv[GIT];
+    unsigned int xok = 0, gok = 0;
+    bool bias_fetched = false;
+    auto fetch = [&](int tile) __attribute__((always_inline)) {
         int b = tile;
         const int tile_x = b % tiles_x;
         b /= tiles_x;
@@ -1017,12 +1028,11 @@ __global__ __launch_bounds__(192) void conv_wgrad_bf16_kernel(
         const int src = wgrad_source(srcs, b / tiles_y, n);
         const bf16_t* __restrict__ x = reinterpret_cast<const bf16_t*>(srcs.x[src]);
         const bf16_t* __restrict__ gy = reinterpret_cast<const bf16_t*>(srcs.gy[src]);
-        const bool do_bias = bias_wave && ((srcs.bias_mask >> src) & 1u);
+        bias_fetched = bias_wave && ((srcs.bias_mask >> src) & 1u);
         const int by = tile_y * TH, bx = tile_x * TW;
         const int oy0 = S2 ? 2 * by : by - 1;
         const int ox0 = S2 ? 2 * bx : bx - 1;
-        uint4 xv[XIT], gv[GIT];
-        unsigned int xok = 0, gok = 0;
+        xok = 0; gok = 0;
 #pragma unroll
         for (int it = 0; it < XIT; ++it) {
             const int c = tid + 192 * it;
@@ -1042,6 +1052,10 @@ __global__ __launch_bounds__(192) void conv_wgrad_bf16_kernel(
             gok |= ok ? (1u << it) : 0u;
             gv[it] = *reinterpret_cast<const uint4*>(ok ? gy + (((long)n * Hb + gy_) * Wb + gx_) * OC + oc0 + part4 * 8 : gy);
         }
+    };
+    if (slice < ntiles) fetch(slice);
+    for (int tile = slice; tile < ntiles; tile += nslices) {
+        const bool do_bias = bias_fetched;
         __syncthreads();  // every wave is done reading the previous tile
 #pragma unroll
         for (int it = 0; it < XIT; ++it) {
@@ -1053,6 +1067,7 @@ __global__ __launch_bounds__(192) void conv_wgrad_bf16_kernel(
             const int c = tid + 192 * it;
             if (c < GCH) *reinterpret_cast<uint4*>(lg_ + c * 16) = (gok >> it) & 1u ? gv[it] : make_uint4(0, 0, 0, 0);
         }
+        if (GS_WGRAD_THIN_PREFETCH && tile + nslices < ntiles) fetch(tile + nslices);   // in flight under the MFMAs below
         __syncthreads();
         // ---- MFMAs: this wave's kernel row (ky = wv) over every 16-pixel group of the tile
 #pragma unroll 2
@@ -1091,6 +1106,7 @@ __global__ __launch_bounds__(192) void conv_wgrad_bf16_kernel(
                 }
             }
         }
+        if (!GS_WGRAD_THIN_PREFETCH && tile + nslices < ntiles) fetch(tile + nslices);
     }
     // ---- each wave owns its 3 taps: D[ic i][oc j], lane = (j = l31, i = (r&3) + 8(r>>2) + 4hi)
     const long pstride = 9L * IC * OC + (with_bias ? OC : 0);   // fp32 elements per slice: 9 taps (+ the bias row)
