@@ -179,6 +179,14 @@ def test_batch256_properties():
     assert torch.all(img[:, 1, :3] == 0)
     ref_lm, _ = S.convert_to_spectrogram(w[:2], **P)
     assert np.abs(img[:2, 0].cpu().numpy() - ref_lm).max() < 1e-3
+    # the IF of two rows against the oracle as in test_fused_vs_oracle_and_golden (at this batch a block is one example: twelve runs
+    # exchanging their edge phases inside the block), and the last rows of the batch against the same rows alone
+    st64 = S.convert_to_spectrogram_stages(w[:2], **P, dtype=np.float64)
+    on_cut, branch = if_conditioning(st64)
+    for i in range(2):
+        check_if(img[i, 1].cpu().numpy(), st64["mel_if"][i], on_cut[i], branch[i])
+    tail = G.convert_to_images(x[254:256], **P)
+    assert torch.equal(tail, img[254:256])
 
 
 def test_inverse_batch256_properties():
