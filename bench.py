@@ -246,10 +246,15 @@ def family_roofline(args, launches, conv_ms, conv_flops, conv_bytes, roof_ms, ro
     tflops = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
     gbps = conv_bytes / (conv_ms * 1e-3) / 1e9 if conv_ms > 0 else 0.0
     hbm_share = roof_ms_hbm / roof_ms if roof_ms > 0 else 0.0
-    traffic = None  # HBM bytes per launch of the same kernel from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE)
-    pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_igemm_traffic.json")))   # newest round last
-    if args.dtype == "bf16" and args.batch == 8 and pmcs:
-        traffic = json.load(open(pmcs[-1]))["avg_hbm_bytes_per_launch"]
+    traffic, traffic_source = None, "none"  # HBM bytes per launch of the same kernel (FETCH_SIZE x2 + WRITE_SIZE)
+    if getattr(args, "pmc", False):
+        traffic, info = measure_traffic(args.dtype, args.batch)
+        traffic_source = ("measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over one eager iteration, %d launches" % info) if traffic else "in-run measurement failed (%s)" % info
+    if traffic is None:
+        pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_igemm_traffic.json")))   # newest round last
+        if args.dtype == "bf16" and args.batch == 8 and pmcs:
+            traffic = json.load(open(pmcs[-1]))["avg_hbm_bytes_per_launch"]
+            traffic_source = "committed rocprofv3 PMC passes (%s), not measured in this run" % os.path.basename(pmcs[-1])
     conv_rows = [r for r in stages if not r["stage"].startswith("wgrad")]
     strict_ms = sum(max(r["gflop"] / peak, strict_8d_bytes(r) / HBM_GBPS) * r["launches_per_iteration"] for r in conv_rows)   # ms per iteration
     meas_ms = sum(r["avg_us"] * 1e-3 * r["launches_per_iteration"] for r in conv_rows)
@@ -259,7 +264,7 @@ def family_roofline(args, launches, conv_ms, conv_flops, conv_bytes, roof_ms, ro
          "frac": roof_ms / conv_ms if conv_ms > 0 else 0.0,
          "frac_strict_8d": strict_ms / meas_ms if meas_ms > 0 else 0.0,
          "frac_family_hbm": gbps / HBM_GBPS, "frac_family_mfma": tflops / peak,
-         "traffic": traffic,
+         "traffic": traffic, "traffic_measured_in_run": bool(getattr(args, "pmc", False) and traffic is not None and traffic_source.startswith("measured")),
          "kernel": "conv_igemm_kernel<*>", "launches": launches, "avg_launch_ms": conv_ms / max(launches, 1),
          "algorithmic_bytes_per_launch": conv_bytes / max(launches, 1), "algorithmic_flops_per_launch": conv_flops / max(launches, 1),
          "time_share": (conv_ms / prof_steps) / (elapsed * 1e3 / args.steps),
@@ -268,10 +273,40 @@ def family_roofline(args, launches, conv_ms, conv_flops, conv_bytes, roof_ms, ro
         "frac": "sum over launches of the time the launch's binding roof allows (MFMA peak or 8 TB/s on its algorithmic bytes incl. fused epilogue operands) / measured",
         "frac_strict_8d": "the same with SURVEY.md 8(d) bytes only (input + output + weights; fused epilogue operands count 0)",
         "achieved": "family-wide algorithmic rate against the roof that owns the larger share of the summed roof time (hbm_bound_share_of_roof = %.3f)" % hbm_share,
-        "traffic_source": "committed rocprofv3 PMC passes (profiles/r*_pmc_igemm_traffic.json: FETCH_SIZE x2 + WRITE_SIZE), not measured in this run",
+        "traffic_source": traffic_source,
         "measured_over": "%d eager iterations after the timed region (same build, same inputs); HIP event pairs on the launch stream "
                          "around %d back-to-back launches of each conv (launch-to-launch time, one launch boundary included)" % (prof_steps, PROF_BURST)}
     return r
+
+
+def measure_traffic(dtype, batch):
+    """HBM bytes per conv_igemm_kernel launch measured NOW: two rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE cannot share a pass;
+    counters only with --kernel-trace, as the GPU pool requires) over one eager iteration of this script, corrected as
+    MI355X_MICROARCH.md prescribes (FETCH_SIZE x2 on gfx950, both in KiB).  Returns (bytes per launch, launches) or (None, why)."""
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on PATH"
+    tot = {}
+    for counter, scale in (("FETCH_SIZE", 2048.0), ("WRITE_SIZE", 1024.0)):
+        d = tempfile.mkdtemp(prefix="gs_pmc_", dir="/tmp")
+        cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "1",
+               "--batch", str(batch), "--dtype", dtype, "--no-graphs", "--no-cpu-baseline", "--no-spectral", "--no-launch-count"]
+        res = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=900)
+        dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
+        if res.returncode != 0 or not dbs:
+            return None, "rocprofv3 --pmc %s failed: %s" % (counter, (res.stderr or res.stdout)[-200:])
+        per = {}
+        for k, c, v, disp in sqlite3.connect(dbs[0]).execute("select kernel_name, counter_name, value, dispatch_id from counters_collection"):
+            if c == counter and "conv_igemm_kernel" in k:
+                per[disp] = per.get(disp, 0.0) + v
+        if not per:
+            return None, "no conv_igemm_kernel dispatches in the %s pass" % counter
+        tot[counter] = (sum(per.values()) * scale / len(per), len(per))
+        shutil.rmtree(d, ignore_errors=True)
+    return tot["FETCH_SIZE"][0] + tot["WRITE_SIZE"][0], tot["FETCH_SIZE"][1]
 
 
 def compact_leg(full):
@@ -428,6 +463,9 @@ def main():
     ap.add_argument("--no-spectral", action="store_true", help="skip the configs[3] (waveform -> mel + IF) leg")
     ap.add_argument("--no-launch-count", action="store_true", help="skip the torch.profiler count of kernel launches per iteration")
     ap.add_argument("--spectral-only", action="store_true", help="run only the configs[3] leg and print its object")
+    ap.add_argument("--pmc", action="store_true",
+                    help="also MEASURE roofline.traffic in this run: two extra rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over one eager "
+                         "iteration of this same script (+1-2 minutes); without it the committed PMC passes under profiles/ are quoted")
     ap.add_argument("--launch-check", action="store_true",
                     help="no device work: the ranks only rendezvous (gloo), prove the launch plumbing and print one JSON line (CPU test of the self-launch)")
     args = ap.parse_args()
