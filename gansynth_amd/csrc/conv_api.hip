@@ -971,15 +971,12 @@ extern "C" int gs_wgrad_reduce_batch(const GsWgradReduce* pending, int n, void* 
     hipStream_t st = as_stream(stream);
     ReduceBatch b;
     int cnt = 0;
-    long gx = 0;   // element quads of the largest entry of the batch
-    int max_slices = 0;
+    long gx = 0;   // blocks of the entry that needs most (64 element quads per block with 4 slice lanes, 16 with 16: see the kernel)
     auto flush = [&]() {
         if (cnt == 0) return;
-        if (max_slices > 32) hipLaunchKernelGGL(wgrad_reduce_batch_kernel<16>, dim3((unsigned)((gx + 15) / 16), (unsigned)cnt), dim3(256), 0, st, b);
-        else hipLaunchKernelGGL(wgrad_reduce_batch_kernel<4>, dim3((unsigned)((gx + 63) / 64), (unsigned)cnt), dim3(256), 0, st, b);
+        hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((unsigned)gx, (unsigned)cnt), dim3(256), 0, st, b);
         cnt = 0;
         gx = 0;
-        max_slices = 0;
     };
     for (int i = 0; i < n; ++i) {
         const GsWgradReduce& d = pending[i];
@@ -991,8 +988,9 @@ extern "C" int gs_wgrad_reduce_batch(const GsWgradReduce* pending, int n, void* 
         if (clash) flush();
         b.e[cnt++] = d;
         const long pstride = (long)d.taps * d.ic * d.oc + (d.gb ? d.oc : 0);
-        if (pstride / 4 > gx) gx = pstride / 4;
-        if (d.nslices > max_slices) max_slices = d.nslices;
+        const long epb = d.nslices > 32 ? 16 : 64;
+        const long blocks = (pstride / 4 + epb - 1) / epb;
+        if (blocks > gx) gx = blocks;
     }
     flush();
     GS_CHECK_LAUNCH();

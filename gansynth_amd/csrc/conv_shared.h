@@ -176,11 +176,12 @@ struct ReduceBatch {
 // (the thin top-level layers leave 256 slices of 18 K floats each: with 4 slice lanes that is 72 blocks per entry walking 64 slices per
 // thread, four loads in flight -- 32-37 us for 19 MB; 16 lanes put four times the loads in flight on four times the blocks).  A thread keeps
 // four slice rows in flight.
-template <int L>
+// The lane count is a function of the ENTRY (its slice count), never of what else shares the launch: the association of an entry's sum must
+// not depend on how the caller batches the folds (a bucketed flush batches them differently, and two schedules of one iteration must agree).
 static __global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const ReduceBatch b) {
     const GsWgradReduce& d = b.e[blockIdx.y];
     const int nslices = d.nslices, oc = d.oc, ic = d.ic;
-    constexpr int EPB = 256 / L;
+    const int L = nslices > 32 ? 16 : 4, EPB = 256 / L;
     __shared__ float4 red[256];
     const long total = (long)d.taps * ic * oc;
     const long pstride = total + (d.gb ? oc : 0);
@@ -212,7 +213,6 @@ static __global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const Re
     __syncthreads();
     if (sl != 0 || e >= pstride) return;
     float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
     for (int j = 0; j < L; ++j) {
         const float4 v = red[threadIdx.x + j * EPB];
         t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;

@@ -366,19 +366,13 @@ def _same_up_to_accumulation_order(a, b, what):
     branches in an order given by THREAD-LOCAL node-creation counters (the second-order graphs are created on the engine's
     device thread), so a tensor with three or more gradient contributions -- a multi-consumer activation, the dense weights
     fed by the real pass, the fake pass and the R1 term -- may be summed as (a+b)+c in one run and (a+c)+b in another.  A
-    captured graph freezes one such order; a bucketed flush of the deferred weight gradients groups the layers differently (other
-    stream-K partitions, other fold batches).  Everything else is deterministic.  What a last-bit difference in a gradient can do
-    downstream is bounded by TF-Adam's first steps, which are sign-like (m / sqrt(v) = +-1 while v holds one or two gradients): an
-    element whose gradient is itself rounding noise may step +lr in one schedule and -lr in the other.  Hence: parameters agree to a
-    few ulps on all but a vanishing fraction of their elements, and nowhere by more than a few learning-rate steps; losses computed
-    AFTER such steps agree to 1e-4 (measured: 2e-5 on the third iteration of the 16 KiB-bucket schedule), not to the ulp."""
+    captured graph freezes one such order.  Everything else is deterministic -- in particular the folds of the deferred weight gradients
+    associate an entry's sum by the ENTRY's own shape, never by what else shares the launch (a bucketed flush batches them differently) --
+    hence a few-ulp tolerance rather than equality."""
     if isinstance(a, float):
-        assert abs(a - b) <= 1e-4 * max(1.0, abs(a)), (what, a, b)
+        assert abs(a - b) <= 1e-5 * max(1.0, abs(a)), (what, a, b)
     else:
-        d = (a - b).abs()
-        far = d > 1e-5 * float(a.abs().max())
-        assert float(far.float().mean()) <= 2e-4, (what, float(far.float().mean()), float(d.max()))
-        assert float(d.max()) <= 1e-2, (what, float(d.max()))   # (<= 2 lr per optimizer step, a handful of steps at lr = 8e-4)
+        assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max()), (what, float((a - b).abs().max()), float(a.abs().max()))
 
 
 def test_hipgraph_replay_equals_eager(gpu_store):
