@@ -142,21 +142,21 @@ class HipKernels(object):
     def refresh_weights(self, flat=None):
         """Rebuild, in ONE launch, every stale prepared operand of the parameters living in `flat` (all registered
         buffers when None) -- called after an optimizer step instead of letting each conv re-lay its weight."""
-        if self._derived and not getattr(self, "_in_derived_refresh", False):   # slices of parameters first, then their operands
+        extra = []   # registered ranges of the derived slices refreshed here: their operands join the ONE launch below
+        if self._derived:   # slices of parameters first (a copy each), then their operands together with everything else
             lo_, hi_ = (None, None) if flat is None else (flat.data_ptr(), flat.data_ptr() + flat.numel() * flat.element_size())
-            self._in_derived_refresh = True
-            try:
-                with torch.no_grad():
-                    for ent in self._derived.values():
-                        w = ent[2]
-                        if (lo_ is None or lo_ <= w.data_ptr() < hi_) and ent[1] != self._stamp(w):
-                            self._refresh_derived(ent, w)
-                            self.refresh_weights(ent[0])
-            finally:
-                self._in_derived_refresh = False
+            with torch.no_grad():
+                for ent in self._derived.values():
+                    w = ent[2]
+                    if (lo_ is None or lo_ <= w.data_ptr() < hi_) and ent[1] != self._stamp(w):
+                        self._refresh_derived(ent, w)
+                        extra.append(ent[0].data_ptr())
         ptr = None if flat is None else flat.data_ptr()
-        stale = [k for k, e in self._wcache.items()
-                 if e[3] is not None and (ptr is None or e[4][0] <= ptr < e[4][0] + e[4][1]) and e[1] != (e[4][2], e[2]._version)]
+
+        def wanted(rng):
+            return ptr is None or rng[0] <= ptr < rng[0] + rng[1] or any(rng[0] <= q < rng[0] + rng[1] for q in extra)
+
+        stale = [k for k, e in self._wcache.items() if e[3] is not None and wanted(e[4]) and e[1] != (e[4][2], e[2]._version)]
         if not stale:
             return 0
         tkey = tuple(stale)
