@@ -44,9 +44,11 @@ def _copy_inputs(dsts, srcs):
     pairs = [(d, s) for d, s in zip(dsts, srcs) if d.data_ptr() != s.data_ptr()]
     if not pairs:
         return
-    if len(pairs) > 1 and all(d.is_cuda and s.is_cuda and d.dtype == s.dtype == pairs[0][0].dtype and d.stride() == s.stride() for d, s in pairs):
-        torch._foreach_copy_([d for d, _ in pairs], [s for _, s in pairs])
-        return
+    # (only the SMALL inputs share a launch: the multi-tensor kernel moves a 4 MB image batch on 34 blocks -- 21 us against 5 for its own copy)
+    small = [(d, s) for d, s in pairs if d.numel() * d.element_size() <= (256 << 10)]
+    if len(small) > 1 and all(d.is_cuda and s.is_cuda and d.dtype == s.dtype == small[0][0].dtype and d.stride() == s.stride() for d, s in small):
+        torch._foreach_copy_([d for d, _ in small], [s for _, s in small])
+        pairs = [(d, s) for d, s in pairs if d.numel() * d.element_size() > (256 << 10)]
     for d, s in pairs:
         d.copy_(s)
 
