@@ -37,6 +37,14 @@ _OVERLAP_REDUCE = not __import__("os").environ.get("GS_NO_OVERLAP_REDUCE")   # A
 _GRAPH_ALLREDUCE = not __import__("os").environ.get("GS_NO_GRAPH_ALLREDUCE")   # A/B switch: the gradient all-reduce as a node of the captured graph
 
 
+def _capture_mode(with_collective):
+    """Keyword arguments of torch.cuda.graph for a capture that contains an RCCL collective: the communicator's helper threads may call
+    the HIP runtime while this thread captures (proxy progress, registration), which the default "global" capture mode turns into a capture
+    error on THEIR call -- captures with a collective inside run "thread_local" (only this thread's calls are checked), as captured NCCL
+    work is run elsewhere.  Everything else keeps the strict default."""
+    return {"capture_error_mode": "thread_local"} if with_collective else {}
+
+
 def _copy_inputs(dsts, srcs):
     """A run's inputs into the static buffers its graph reads: ONE multi-tensor launch where the tensors allow it (same device, dtype and
     strides pairwise) instead of a ~5 us copy kernel per input in front of every replay."""
@@ -635,7 +643,7 @@ class GANSynth(object):
                 with_collective = self.distributed and self._comm is not None and self._graph_allreduce
                 error = None
                 try:
-                    with _quiet_gc(), torch.cuda.graph(graph):
+                    with _quiet_gc(), torch.cuda.graph(graph, **_capture_mode(with_collective)):
                         loss = self._forward_backward(which, *static)
                 except RuntimeError as e:
                     if not with_collective:
@@ -748,7 +756,7 @@ class GANSynth(object):
                 params.grad_clean = True
             K.refresh_weights()   # (see _run: the captured graphs hold no re-layout launches)
             ga = torch.cuda.CUDAGraph()
-            with _quiet_gc(), torch.cuda.graph(ga):
+            with _quiet_gc(), torch.cuda.graph(ga, **_capture_mode(reduce_params is not None)):
                 if reduce_params is not None:
                     main = torch.cuda.current_stream()
                     fork = torch.cuda.Stream()
