@@ -88,12 +88,21 @@ def load_state_dict(model, state, strict=True):
                 # reference checkpoint written between the discriminator's and the generator's train op (OutOfRangeError after the
                 # first session.run of models.py:191-192) has t_D = global_step + 1, and optimizers that ran different numbers of
                 # steps stay loadable.  A disagreement with global_step beyond rounding is reported, not refused.
-                t_log = int(round(math.log(p2) / math.log(b2))) - 1
-                if abs(t_log - params.t) > max(1, int(1e-3 * params.t)):
+                # (TF accumulates beta2_power by float32 multiplies of float32(beta2): the log is taken of THAT base; what is left
+                # of the float32 rounding drift is why only the documented one-step disagreement is adopted.)
+                import numpy as np
+                t_log = int(round(math.log(p2) / math.log(float(np.float32(b2))))) - 1
+                if abs(t_log - params.t) <= 1:
+                    params.t = max(t_log, 0)
+                elif abs(t_log - params.t) > max(1, int(1e-3 * params.t)):   # (within 0.1 %: float32 product drift -- global_step stands)
+                    # a gross contradiction (a corrupt file, or a beta2 hyper-parameter that is not the checkpoint's): the Adam
+                    # bias-correction step is not silently reset from it
+                    msg = (f"checkpoint: beta2_power{suffix} = {p2:g} says {t_log} optimizer steps with beta2 = {b2:g}, "
+                           f"global_step says {params.t}")
+                    if strict:
+                        raise ValueError(msg + " (strict=False keeps global_step)")
                     import warnings
-                    warnings.warn(f"checkpoint: beta2_power{suffix} = {p2:g} says {t_log} optimizer steps, global_step says {params.t}; "
-                                  f"using {t_log}")
-                params.t = max(t_log, 0)
+                    warnings.warn(msg + "; keeping global_step")
         else:
             missing.append(key)
     if "global_step" in state:

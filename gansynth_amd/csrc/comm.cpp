@@ -102,8 +102,16 @@ extern "C" int gs_allreduce_sum_f32(gs_comm* c, float* data, int64_t count, void
     GS_CHECK_ARG(c && data && count >= 0, "gs_allreduce_sum_f32: bad arguments");
     if (count == 0) return 0;
     if (c->world == 1) {
-        if (const char* us = getenv("GS_COMM_MARKER_US")) {
-            hipLaunchKernelGGL(comm_marker_kernel, dim3(1), dim3(64), 0, gs::as_stream(stream), data, (long long)(atof(us) * 100.0));
+        // read once; clamped to [0, 10 ms] so that a typo cannot park the stream
+        static const double marker_us = [] {
+            const char* us = getenv("GS_COMM_MARKER_US");
+            if (!us) return -1.0;
+            const double v = atof(us);
+            return v < 0.0 ? 0.0 : (v > 10000.0 ? 10000.0 : v);
+        }();
+        if (marker_us >= 0.0) {
+            hipLaunchKernelGGL(comm_marker_kernel, dim3(1), dim3(64), 0, gs::as_stream(stream), data, (long long)(marker_us * 100.0));
+            GS_CHECK_LAUNCH();
             return 0;
         }
     }

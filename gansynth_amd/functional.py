@@ -1282,9 +1282,12 @@ def _cat2(a, b):
                 if not torch.cuda.is_current_stream_capturing():   # (memory made inside a capture belongs to that graph's pool)
                     _ZEROS[key] = zeros
             a, b = (zeros if a is None else a), (zeros if b is None else b)
-        out = torch.cat((a, b), dim=0)
-        if out.is_contiguous(memory_format=torch.channels_last if cl else torch.contiguous_format):
-            return out
+        # torch.cat keeps the memory format only when both halves already have it: checked BEFORE the launch, so that the result is
+        # never thrown away for the copy path below
+        if a.is_contiguous(memory_format=torch.channels_last if cl else torch.contiguous_format) and a.stride() == b.stride():
+            out = torch.cat((a, b), dim=0)
+            if out.is_contiguous(memory_format=torch.channels_last if cl else torch.contiguous_format):
+                return out
     out = torch.empty((2 * n,) + tuple(ref.shape[1:]), dtype=ref.dtype, device=ref.device,
                       memory_format=torch.channels_last if cl else torch.contiguous_format)
     for half, t in ((out[:n], a), (out[n:], b)):
@@ -1296,6 +1299,19 @@ def _cat2(a, b):
 
 
 _ZEROS = {}
+
+
+def constants_snapshot():
+    """The cached constants (zeros of _cat2) alive right now.  A captured graph that was recorded while they were cached replays
+    reads of their memory: whoever owns the graph keeps this list for as long as the graph lives, and drop_constants() is then safe
+    at any time."""
+    return list(_ZEROS.values())
+
+
+def drop_constants():
+    """Forget the cached activation-sized constants (a new growing regime / batch size has other junction shapes; without this
+    they pile up, one full-size tensor per shape ever seen)."""
+    _ZEROS.clear()
 
 
 class _CatBatch(Function):

@@ -510,7 +510,17 @@ class GANSynth(object):
               "it will run eagerly after each replay" % (which, "ok" if error is None else str(error).splitlines()[0]), file=sys.stderr, flush=True)
         self._graph_allreduce = False
         self._captured_reduce = False
-        if self.world > 1:
+        # Every graph captured so far may replay an ncclAllReduce on the communicator given up here (the OTHER run's graph of the
+        # serial path, the pairs of the pipelined step): all of them go, so that every run is captured again without a collective.
+        torch.cuda.synchronize()
+        self._graphs.clear()
+        if self._pipe is not None:
+            self._pipe.pop("d", None), self._pipe.pop("g", None)
+            self._pipe["key"] = None
+        if self.world > 1 and self._comm is not None:
+            # Not destroyed: ncclCommDestroy on a communicator an aborted capture left half-enqueued may block.  It is retired --
+            # never used again, kept alive until the process ends -- and the eager collectives go through torch.distributed.
+            self._retired_comm = self._comm
             self._comm = None
         self._abandon_capture(which)
 
@@ -604,6 +614,7 @@ class GANSynth(object):
         if self._graph_key != key:   # a new growing regime: different launch sequence
             self._graphs.clear()
             self._graph_key = key
+            F.drop_constants()   # (junction constants of the old regime's shapes; live graphs hold their own references)
         if fade is not None:
             if self._lerp is None:
                 self._lerp = F.DeviceLerp(self.g_params.flat.device)
@@ -659,9 +670,9 @@ class GANSynth(object):
                         loss = self._forward_backward(which, *static)
             finally:
                 owner.fade_weight = None   # (only captured launches use the table; eager callers keep passing the number)
-            entry = (graph, static, loss, self._captured_reduce, self.keep_gradients)
+            entry = (graph, static, loss, self._captured_reduce, self.keep_gradients, F.constants_snapshot())
             self._graphs[which] = entry
-        graph, static, loss, reduced, _ = entry
+        graph, static, loss, reduced = entry[:4]
         if not self.keep_gradients:
             params_ = self.d_params if which == "d" else self.g_params
             if not params_.grad_clean:   # (a replay not preceded by the zeroing update: e.g. a run repeated without its optimizer step)
@@ -705,7 +716,10 @@ class GANSynth(object):
     #   (ii) SIDE STREAM (opt-in, GS_PIPELINE=1 with torch.distributed's collectives): the round-2 form.
     def _join_updates(self):
         """A pipelined step leaves the generator's update pending: apply it (reducing the gradient first when the all-reduce was
-        going to ride in the next discriminator graph)."""
+        going to ride in the next discriminator graph).  Data parallel: with a reduction pending this IS a collective -- every rank
+        must get here at the same point of its launch sequence.  train() therefore joins on EVERY rank before a rank-0 checkpoint
+        and at its end; synchronize(), state_dict / checkpoint.save and generate() called by hand on a distributed model must be
+        called on all ranks (`collective_pending()` tells whether the call would communicate)."""
         if self._pipe is not None and self._pipe.get("g_pending"):
             hp = self.hyper_params
             P = self._pipe
@@ -717,8 +731,14 @@ class GANSynth(object):
                 torch.cuda.current_stream().wait_event(P["g_reduced"])
             self._apply(self.g_params, hp.generator_learning_rate, hp.generator_beta1, hp.generator_beta2, reduced=True)
 
+    def collective_pending(self):
+        """True when the next _join_updates() / synchronize() / generate() / checkpoint would issue a gradient all-reduce (the
+        pipelined data-parallel step leaves the generator's gradient unreduced until the next discriminator graph)."""
+        return bool(self.distributed and self.world > 1 and self._pipe is not None and self._pipe.get("g_pending")
+                    and self._pipe.get("g_unreduced"))
+
     def synchronize(self):
-        """Everything a train_step enqueued (including the pending update) has finished."""
+        """Everything a train_step enqueued (including the pending update) has finished.  Collective when `collective_pending()`."""
         self._join_updates()
         if torch.cuda.is_available():
             torch.cuda.synchronize()
@@ -772,7 +792,8 @@ class GANSynth(object):
         finally:
             self._pipe_capture = False
             owner.fade_weight = None
-        return {"a": ga, "b": gb, "sa": sa, "sb": sb, "loss": loss, "reduces": reduce_params is not None, "keep": self.keep_gradients}
+        return {"a": ga, "b": gb, "sa": sa, "sb": sb, "loss": loss, "reduces": reduce_params is not None, "keep": self.keep_gradients,
+                "consts": F.constants_snapshot()}   # (cached junction constants the graphs read: alive as long as the graphs)
 
     def _pipelined_ok(self):
         if not self._graphable():
@@ -808,6 +829,8 @@ class GANSynth(object):
             self._join_updates()
             self._graphs.clear()
             P.pop("d", None), P.pop("g", None)
+            if P["key"] is not None and P["key"][:2] != key[:2]:
+                F.drop_constants()   # (a new growing regime: see _run)
             error = None
             try:
                 P["d"] = self._capture_pair("d", *d_in, reduce_params=self.g_params if in_graph else None)
@@ -957,9 +980,16 @@ class GANSynth(object):
             if log is not None and self.global_step % log_tensor_steps == 0:
                 log(f"global_step = {self.global_step}, generator_loss = {float(g_loss):.6f}, "
                     f"discriminator_loss = {float(d_loss):.6f}")
-            if model_dir is not None and save and save_checkpoint_steps and self.global_step % save_checkpoint_steps == 0:
-                last_saved = self.global_step
-                checkpoint.save(self, model_dir)
+            if model_dir is not None and save_checkpoint_steps and self.global_step % save_checkpoint_steps == 0:
+                # (global_step is the same on every rank.)  The pending generator update may still need its all-reduce: EVERY rank
+                # joins here, so that the rank-local save below finds nothing left to communicate -- a collective issued by rank 0
+                # alone would pair with its peers' NEXT all-reduce and leave the job one collective out of step for good.
+                self._join_updates()
+                if save:
+                    last_saved = self.global_step
+                    checkpoint.save(self, model_dir)
+        if self.g_params is not None:
+            self._join_updates()   # (every rank: the last generator update, and the final save must not communicate either)
         if model_dir is not None and save and self.g_params is not None and last_saved != self.global_step:
             checkpoint.save(self, model_dir)
 

@@ -209,10 +209,28 @@ def test_checkpoint_round_trip_resumes_bit_identically(cpu_backend, tmp_path):
     ahead = dict(tf_like, beta2_power_1=torch.tensor(0.99 ** 6, dtype=torch.float32))
     assert checkpoint.load_state_dict(third, ahead, strict=True) == []
     assert (third.g_params.t, third.d_params.t, third.global_step) == (4, 5, 4)
-    # ... and one that contradicts global_step outright stays loadable, loudly (beta2_power says 4)
-    with pytest.warns(UserWarning, match="says 4 optimizer steps"):
+    # ... and one that contradicts global_step outright (a corrupt file, a beta2 that is not the checkpoint's: beta2_power says 4) is
+    # refused; strict=False loads it loudly and keeps global_step -- the bias-correction step is never reset from a contradiction
+    with pytest.raises(ValueError, match="says 4 optimizer steps"):
         checkpoint.load_state_dict(third, dict(tf_like, global_step=torch.tensor(400)), strict=True)
-    assert (third.g_params.t, third.d_params.t, third.global_step) == (4, 4, 400)
+    with pytest.warns(UserWarning, match="says 4 optimizer steps"):
+        checkpoint.load_state_dict(third, dict(tf_like, global_step=torch.tensor(400)), strict=False)
+    assert (third.g_params.t, third.d_params.t, third.global_step) == (400, 400, 400)
+    # TF accumulates beta2_power by float32 multiplies of float32(beta2): the recovered count stays within the accepted one step of
+    # global_step far into a run (beta2 = 0.999: the double-precision log of the float32 product drifts past 1 after ~38 k steps)
+    import numpy as np
+    b2, p2 = np.float32(0.999), np.float32(1.0)
+    steps = 30000
+    for _ in range(steps + 1):
+        p2 = np.float32(p2 * b2)
+    old_b2 = (third.hyper_params.generator_beta2, third.hyper_params.discriminator_beta2)
+    third.hyper_params.generator_beta2 = third.hyper_params.discriminator_beta2 = 0.999
+    try:
+        long_run = dict(tf_like, global_step=torch.tensor(steps), beta2_power=torch.tensor(float(p2)), beta2_power_1=torch.tensor(float(p2)))
+        assert checkpoint.load_state_dict(third, long_run, strict=True) == []
+        assert abs(third.g_params.t - steps) <= 1 and abs(third.d_params.t - steps) <= 1 and third.global_step == steps
+    finally:
+        third.hyper_params.generator_beta2, third.hyper_params.discriminator_beta2 = old_b2
     # a torn keep-forever clock file (a job killed mid-write) does not break the next save
     third.global_step = 4
     with open(os.path.join(str(tmp_path), "checkpoints_keep_clock"), "w") as f:

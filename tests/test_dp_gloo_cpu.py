@@ -176,3 +176,56 @@ def test_two_rank_resume_and_uneven_input():
         uneven = _run_train(2, model_dir, 50, [6, 4])
         assert [r["step"] for r in uneven] == [2, 2]
         assert torch.equal(uneven[0]["d"], uneven[1]["d"]) and torch.equal(uneven[0]["g"], uneven[1]["g"])
+
+
+# ---------------------------------------------------------------------------------------------- rank-local paths never communicate
+def _pending_worker(rank, world, port, out_dir, model_dir):
+    """The state machine of the in-graph pipelined step (models.GANSynth._train_step_pipelined: the generator's gradient is left
+    UNREDUCED and its update pending until the next discriminator graph) emulated on CPU: train() with a checkpoint every step.  Every
+    all-reduce a rank issues is logged; the sequences must be identical on the two ranks although only rank 0 saves."""
+    _init(rank, world, port)
+    pg, hyper, GANSynth = _setup(level=lambda: 0.3)
+    gen = torch.Generator().manual_seed(7 + rank)
+
+    class Pipelined(GANSynth):
+        def train_step(self):
+            real_images, labels, d_latents, g_latents, g_labels = self._next_inputs()
+            self._ensure_built(d_latents, labels)
+            d_loss = self.discriminator_step(d_latents, labels, real_images)   # (_run joins the pending generator update first)
+            g_loss = self._run("g", g_latents, g_labels)                        # gradients only: no reduction, no update
+            if self._pipe is None:
+                self._pipe = {"g_pending": False, "g_unreduced": False, "key": None}
+            self._pipe["g_pending"] = self._pipe["g_unreduced"] = True
+            self.global_step += 1
+            return d_loss, g_loss
+
+    calls = []
+    real_all_reduce = torch.distributed.all_reduce
+
+    def logged(tensor, *a, **kw):
+        calls.append(int(tensor.numel()))
+        return real_all_reduce(tensor, *a, **kw)
+
+    torch.distributed.all_reduce = logged
+    model = Pipelined(pg.generator, pg.discriminator, _finite_input(rank, 100), lambda: torch.randn(4, 16, generator=gen), None, hyper,
+                      distributed=True, bucket_bytes=8 << 20)
+    model.train(total_steps=3, log=None, model_dir=model_dir, save_checkpoint_steps=1)
+    assert not model.collective_pending()
+    torch.save({"calls": calls, "g": model.g_params.flat.clone(), "d": model.d_params.flat.clone(), "t": (model.d_params.t, model.g_params.t),
+                "files": sorted(os.listdir(model_dir))}, os.path.join(out_dir, f"rank{rank}.pt"))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_checkpoint_in_mid_training_does_not_communicate_from_rank_0_alone():
+    """with the generator's all-reduce pending, checkpoint.save -> state_dict -> synchronize() on rank 0 alone issued
+    a collective its peers never matched.  train() now joins the pending update on EVERY rank before a rank-local save and at its end."""
+    sys.path.insert(0, ROOT)
+    port = 33500 + (os.getpid() % 2000)
+    with tempfile.TemporaryDirectory() as d, tempfile.TemporaryDirectory() as model_dir:
+        mp.spawn(_pending_worker, args=(2, port, d, model_dir), nprocs=2, join=True)
+        r0, r1 = (torch.load(os.path.join(d, f"rank{r}.pt")) for r in range(2))
+    assert r0["calls"] == r1["calls"] and len(r0["calls"]) >= 6, (r0["calls"], r1["calls"])   # same collectives, same order, both ranks
+    assert torch.equal(r0["g"], r1["g"]) and torch.equal(r0["d"], r1["d"])
+    assert r0["t"] == r1["t"] == (3, 3)                                                        # every pending update was applied
+    assert [f for f in r0["files"] if f.startswith("model.ckpt-")] == ["model.ckpt-1.safetensors", "model.ckpt-2.safetensors", "model.ckpt-3.safetensors"]
