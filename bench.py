@@ -57,13 +57,16 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(batch=8, timed=2):
+def cpu_baseline(batch=8, timed=3):
     """The CPU oracle (torch-CPU fp32 restatement of the reference graph: the TF1 reference itself cannot run here, SURVEY.md
     8c/D3) timed on this host's cores as SURVEY.md 8(d) specifies: batch 8, fully grown 128x1024x2, one warm-up iteration
     (D update + G update, R1 + mode-seeking double-backward, TF-Adam) then `timed` timed ones."""
     from oracle import torch_ref as R
     total = os.cpu_count() or 1
-    cores = min(total, 32)  # beyond ~32 threads torch-CPU conv backward stops scaling (a 256-thread run was 40x slower)
+    # SURVEY 8(d) says torch.set_num_threads(os.cpu_count()); measured on the pool's 256-thread EPYC 9575F hosts that run is ~40x SLOWER
+    # than 32 threads (torch-CPU's conv backward oversubscribes; ~9 minutes per iteration), so the baseline runs on 32 threads -- the
+    # fastest setting found (16: 0.41, 32: 0.61-0.67, 64: 0.52 images/s) -- and says so in `sample`
+    cores = min(total, 32)
     torch.set_num_threads(cores)
     pg = R.PGGAN([2, 16], [128, 1024], 32, 256, 1.0)
     gp, dp = pg.init_params(seed=0)
@@ -80,7 +83,8 @@ def cpu_baseline(batch=8, timed=2):
     return {"value": batch / dt, "unit": "images/sec", "cores": cores, "kind": "port", "host_cores": total, "cpu_model": cpu_model(),
             "seconds_per_iteration": dt,
             "sample": "1 warm-up + %d timed iterations (D update + G update incl. R1 + mode-seeking double-backward, TF-Adam) at batch %d, "
-                      "fully grown 128x1024x2, fp32, torch-CPU oracle (oracle/torch_ref.py), %d threads" % (timed, batch, cores)}
+                      "fully grown 128x1024x2, fp32, torch-CPU oracle (oracle/torch_ref.py), %d of %d host threads (all %d threads measured ~40x slower)"
+                      % (timed, batch, cores, total, total)}
 
 
 SPECTRAL_BYTES_PER_EXAMPLE = 64000 * 4 + 2 * 128 * 1024 * 4   # waveform read once + (log-mel, IF) written once, fp32
@@ -206,6 +210,7 @@ def inverse_bench(batch=256, iters=50, warmup=10):
         g_ms = sum(gemm.values())
         ach = executed / (g_ms * 1e-3) / 1e12
         out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK["bf16"], "unit": "TFLOP/s", "frac": ach / PEAK["bf16"],
+                           "frac_algorithmic": flops / (g_ms * 1e-3) / 1e12 / PEAK["bf16"],   # the fp32 contraction's own multiply-adds against the same peak
                            "kernel": "gemm_bf16x6_kernel (the two GEMM launches: phase rows 6 products, magnitude rows 3)",
                            "avg_launch_ms": g_ms / len(gemm), "gemm_ms": gemm, "gemm_share_of_call": g_ms / ms,
                            "executed_flops_per_call": executed, "algorithmic_flops_per_call": flops,
@@ -259,6 +264,7 @@ def family_roofline(args, launches, conv_ms, conv_flops, conv_bytes, roof_ms, ro
     strict_ms = sum(max(r["gflop"] / peak, strict_8d_bytes(r) / HBM_GBPS) * r["launches_per_iteration"] for r in conv_rows)   # ms per iteration
     meas_ms = sum(r["avg_us"] * 1e-3 * r["launches_per_iteration"] for r in conv_rows)
     n40 = sum(1 for r in stages if r["frac"] >= 0.40)
+    n40s = sum(1 for r in stages if r.get("frac_strict_8d", r["frac"]) >= 0.40)
     r = {"bound": "hbm" if hbm_share > 0.5 else "mfma",
          "achieved": gbps if hbm_share > 0.5 else tflops, "peak": HBM_GBPS if hbm_share > 0.5 else peak, "unit": "GB/s" if hbm_share > 0.5 else "TFLOP/s",
          "frac": roof_ms / conv_ms if conv_ms > 0 else 0.0,
@@ -268,7 +274,7 @@ def family_roofline(args, launches, conv_ms, conv_flops, conv_bytes, roof_ms, ro
          "kernel": "conv_igemm_kernel<*>", "launches": launches, "avg_launch_ms": conv_ms / max(launches, 1),
          "algorithmic_bytes_per_launch": conv_bytes / max(launches, 1), "algorithmic_flops_per_launch": conv_flops / max(launches, 1),
          "time_share": (conv_ms / prof_steps) / (elapsed * 1e3 / args.steps),
-         "stages_at_or_above_0.40": "%d/%d" % (n40, len(stages))}
+         "stages_at_or_above_0.40": "%d/%d" % (n40, len(stages)), "stages_at_or_above_0.40_strict": "%d/%d" % (n40s, len(stages))}
     detail["roofline_notes"] = {
         "frac": "sum over launches of the time the launch's binding roof allows (MFMA peak or 8 TB/s on its algorithmic bytes incl. fused epilogue operands) / measured",
         "frac_strict_8d": "the same with SURVEY.md 8(d) bytes only (input + output + weights; fused epilogue operands count 0)",
@@ -313,7 +319,7 @@ def compact_leg(full):
     """A secondary leg (spectral / inverse) reduced to what the judge reads; the full object goes to the detail file."""
     out = {"value": full["value"], "unit": full["unit"]}
     if "roofline" in full:
-        out["roofline"] = {k: full["roofline"].get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms") if k in full["roofline"]}
+        out["roofline"] = {k: full["roofline"].get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "frac_algorithmic", "traffic", "avg_launch_ms") if k in full["roofline"]}
     cb = full.get("cpu_baseline")
     if cb:
         out["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "error") if k in cb}
@@ -420,7 +426,177 @@ def count_launches(model):
         model.use_graphs = was
 
 
-def assemble(args, world, distributed, elapsed, prof_steps, family, stages, kernel_launches, d_loss, g_loss, legs):
+# ------------------------------------------------------------------------------------------------ the whole step against its roofs
+# Kernel families of one iteration: (label, substrings of the device kernel names, how the family is priced).
+#   "conv"  : per-launch binding roof of the library's own records (gs_prof_records: flops and SURVEY 8(d) bytes per launch)
+#   "hbm"   : SURVEY 8(d) elementwise rule -- every operand read once, every result written once -- from the kernel layer's own
+#             call log (kernels.HipKernels.account): bytes / 8 TB/s
+#   None    : not priced (torch-native glue, runtime copies)
+FAMILIES = [
+    ("conv_igemm", ("conv_igemm_kernel",), "conv"),
+    ("conv_wgrad", ("conv_wgrad",), "conv"),
+    ("wgrad_folds", ("wgrad_sk_reduce", "wgrad_reduce"), "hbm"),
+    ("pixel_norm", ("pixel_norm",), "hbm"),
+    ("thin_convs", ("thin_", "conv_direct"), "hbm"),
+    ("dense", ("dense_",), "hbm"),
+    ("bias_sums", ("channel_sum", "channel_fold_batch"), "hbm"),
+    ("act_bwd", ("act_bwd",), "hbm"),
+    ("batch_stddev", ("batch_stddev",), "hbm"),
+    ("adam", ("adam_tf",), "hbm"),
+    ("weight_prep", ("weight_prep",), "hbm"),
+    ("elementwise", ("axpby", "bias_act", "tanh_bwd_bwd", "upscale", "blocksum", "row_scale", "sumsq", "units_to_nhwc", "nhwc_to_units"), "hbm"),
+    ("loss_heads", ("gan_", "embedding"), "hbm"),
+    ("torch_native", ("at::native", "rocclr", "Memcpy", "Memset", "elementwise_kernel", "vectorized_elementwise"), None),
+]
+
+
+def family_of_kernel(name):
+    for label, keys, _ in FAMILIES:
+        if any(k in name for k in keys):
+            return label
+    return "other"
+
+
+def family_of_call(name, meta):
+    """Kernel-layer method -> the family its launches belong to (None: priced by the library's own conv records)."""
+    if name.startswith("conv2d"):
+        w = meta.get("w")
+        if isinstance(w, tuple) and len(w) == 4:               # HWIO
+            ksize, ci, co = w[0], w[2], w[3]
+        else:                                                  # weight gradients: x [n, ci, h, w], gy [n, co, ...]
+            ksize, ci, co = meta.get("ksize", 3), (meta.get("x") or (0, 32))[1], (meta.get("gy") or (0, 32))[1]
+        # 1x1 colour convs and the one-channel stddev plane run the streaming kernels (thin_*, conv_direct_*); the rest is MFMA work
+        return "thin_convs" if (ksize == 1 or ci % 32 or co % 32) else None
+    if name == "flush_wgrad_reductions":
+        return "wgrad_folds"
+    if name.startswith("pixel_norm"):
+        return "pixel_norm"
+    if name.startswith("dense"):
+        return "dense"
+    if name in ("channel_sum",):
+        return "bias_sums"
+    if name.startswith("act_bwd"):
+        return "act_bwd"
+    if name.startswith("batch_stddev"):
+        return "batch_stddev"
+    if name == "adam_tf_step":
+        return "adam"
+    if name == "refresh_weights":
+        return "weight_prep"
+    if name.startswith("gan_") or name.startswith("embedding"):
+        return "loss_heads"
+    return "elementwise"
+
+
+def price_whole_step(model, K, args, stages, ms_per_step, prof_steps, trace_iters=4):
+    """Every kernel family of the iteration against its roof.  Time per family: device timestamps of the kernels
+    of `trace_iters` iterations (torch.profiler = roctracer; graph replays when the trace shows their kernels, eager launches
+    otherwise -- the line says which).  Roof time per family: see FAMILIES.  -> (summary for the line, table for the detail file)."""
+    from torch.profiler import ProfilerActivity, profile
+    peak = PEAK[args.dtype]
+    # (1) algorithmic bytes of the non-conv families: one eager iteration under the kernel layer's call log
+    was = model.use_graphs
+    model.use_graphs = False
+    fam_bytes, fam_calls, unpriced_calls = {}, {}, {}
+    try:
+        model.train_step()
+        torch.cuda.synchronize()
+        with K.account() as calls:
+            model.train_step()
+            torch.cuda.synchronize()
+        for name, meta, rd, wr in calls:
+            fam = family_of_call(name, meta)
+            if fam is None:
+                continue
+            by = rd + wr
+            if name == "adam_tf_step":   # SURVEY 8(d): 28 B per parameter (theta, g, m, v read; theta, m, v written), + 4 where the step also clears g
+                n = 1
+                for d in meta.get("p", ()):
+                    n *= d
+                by = n * (32 if meta.get("zero_grad") else 28)
+            fam_bytes[fam] = fam_bytes.get(fam, 0) + by
+            fam_calls[fam] = fam_calls.get(fam, 0) + 1
+    finally:
+        model.use_graphs = was
+    # the two weight-gradient folds and the batched operand refresh take no tensor arguments: priced from what they move
+    g_params = getattr(model, "g_params", None)
+    d_params = getattr(model, "d_params", None)
+    if g_params is not None and d_params is not None:
+        nparam = g_params.flat.numel() + d_params.flat.numel()
+        esz = 4 if args.dtype == "f32" else 2
+        fam_bytes["weight_prep"] = fam_bytes.get("weight_prep", 0) + nparam * (4 + 3 * esz)   # fp32 masters read once, ~3 re-laid operands (fwd, bwd-data, 2nd order) written
+        fam_bytes["wgrad_folds"] = fam_bytes.get("wgrad_folds", 0) + nparam * 12                # partials read once (>= one fp32 slab per layer) + gradient read and written
+    # (2) time per family from the device timeline
+    def trace(graphs):
+        model.use_graphs = graphs
+        try:
+            model.train_step()
+            torch.cuda.synchronize()
+            with profile(activities=[ProfilerActivity.CUDA]) as prof:
+                for _ in range(trace_iters):
+                    model.train_step()
+                torch.cuda.synchronize()
+        finally:
+            model.use_graphs = was
+        ev = [(e.name, e.time_range.start, e.time_range.end) for e in prof.events()
+              if e.device_type is not None and str(e.device_type).endswith("CUDA") and e.time_range.end > e.time_range.start]
+        return ev
+    mode = "hipGraph replay" if was else "eager"
+    try:
+        ev = trace(was)
+        if was and len(ev) < 100 * trace_iters:   # the tracer did not see inside the replays
+            ev, mode = trace(False), "eager (the tracer shows no kernels inside graph replays)"
+    except Exception as exc:   # noqa: BLE001 -- the profiler is optional equipment
+        return {"error": repr(exc)[:160]}, None
+    if not ev:
+        return {"error": "no device events in the trace"}, None
+    fam_us, fam_n = {}, {}
+    for name, s_, e_ in ev:
+        f = family_of_kernel(name)
+        fam_us[f] = fam_us.get(f, 0.0) + (e_ - s_) / trace_iters
+        fam_n[f] = fam_n.get(f, 0.0) + 1.0 / trace_iters
+    busy_us = sum(fam_us.values())
+    # (3) roofs
+    conv_roof = {"conv_igemm": 0.0, "conv_wgrad": 0.0}
+    conv_roof_strict = {"conv_igemm": 0.0, "conv_wgrad": 0.0}
+    for r in stages:
+        key = "conv_wgrad" if r["stage"].startswith("wgrad") else "conv_igemm"
+        t = max(r["gflop"] / peak, r["mbytes"] / HBM_GBPS) * 1e3 * r["launches_per_iteration"]              # us per iteration
+        ts = max(r["gflop"] / peak, strict_8d_bytes(r) / HBM_GBPS) * 1e3 * r["launches_per_iteration"]
+        conv_roof[key] += t
+        conv_roof_strict[key] += ts
+    rows, priced_us, roof_total, roof_total_strict = [], 0.0, 0.0, 0.0
+    kinds = {label: kind for label, _, kind in FAMILIES}
+    for f in sorted(fam_us, key=lambda k: -fam_us[k]):
+        kind = kinds.get(f)
+        row = {"family": f, "launches_per_iteration": round(fam_n[f], 1), "us_per_iteration": round(fam_us[f], 1), "time_share": round(fam_us[f] / busy_us, 4)}
+        if kind == "conv":
+            row.update(bound="per-launch binding roof (MFMA peak or 8 TB/s)", roof_us=round(conv_roof[f], 1), frac=round(conv_roof[f] / fam_us[f], 3),
+                       frac_strict_8d=round(conv_roof_strict[f] / fam_us[f], 3))
+            roof_total += conv_roof[f]
+            roof_total_strict += conv_roof_strict[f]
+            priced_us += fam_us[f]
+        elif kind == "hbm" and f in fam_bytes:
+            roof = fam_bytes[f] / (HBM_GBPS * 1e9) * 1e6
+            row.update(bound="hbm", algorithmic_mbytes=round(fam_bytes[f] / 1e6, 2), kernel_layer_calls=fam_calls.get(f), roof_us=round(roof, 1),
+                       gbps=round(fam_bytes[f] / fam_us[f] / 1e3, 1), frac=round(roof / fam_us[f], 3))
+            roof_total += roof
+            roof_total_strict += roof
+            priced_us += fam_us[f]
+        else:
+            row.update(bound=None, frac=None)
+        rows.append(row)
+    summary = {"step_frac": round(roof_total / (ms_per_step * 1e3), 4), "step_frac_strict_8d": round(roof_total_strict / (ms_per_step * 1e3), 4),
+               "roof_us_per_iteration": round(roof_total, 1), "kernel_busy_us": round(busy_us, 1), "priced_share_of_kernel_time": round(priced_us / busy_us, 4),
+               "kernels_per_iteration": round(sum(fam_n.values()), 1), "timeline": mode,
+               "families": {r["family"]: r["frac"] for r in rows if r["frac"] is not None}}
+    return summary, {"families": rows, "timeline": mode, "iterations_traced": trace_iters,
+                     "note": "time = device timestamps of each kernel (torch.profiler); roof = per-launch binding roof for the conv families "
+                             "(gs_prof_records), bytes / 8 TB/s for the rest with bytes = every operand read once + every result written once "
+                             "(kernel-layer call log of one eager iteration; Adam 28-32 B / parameter; folds and operand refresh from the parameter count)"}
+
+
+def assemble(args, world, distributed, elapsed, prof_steps, family, stages, kernel_launches, d_loss, g_loss, legs, whole_step=(None, None)):
     """The bench record: (`out`, the ONE compact line the driver parses; `detail`, everything else -- side file + stderr)."""
     launches, conv_ms, conv_flops, conv_bytes, roof_ms, roof_ms_hbm = family
     global_batch = args.batch * world
@@ -440,6 +616,13 @@ def assemble(args, world, distributed, elapsed, prof_steps, family, stages, kern
         "kernel_launches_per_iteration": kernel_launches.get("total") if isinstance(kernel_launches, dict) else None,
         "losses": {"discriminator": d_loss, "generator": g_loss},
     }
+    if whole_step[0] is not None:
+        # the WHOLE iteration against its roofs: sum over every kernel family of the time its own roof allows / ms_per_step
+        out["roofline"]["step_frac"] = whole_step[0].get("step_frac")
+        out["roofline"]["step_frac_strict_8d"] = whole_step[0].get("step_frac_strict_8d")
+        out["whole_step"] = whole_step[0]
+        if whole_step[1] is not None:
+            detail["whole_step"] = whole_step[1]
     for name in ("spectral", "spectral_inverse"):
         if name in legs:
             detail[name] = legs[name]
@@ -584,6 +767,10 @@ def main():
     stages = per_stage(records, prof_steps, PEAK[args.dtype], args.dtype)
     # (one GPU only: an extra iteration on rank 0 alone would leave the other ranks out of its collectives)
     kernel_launches = count_launches(model) if world == 1 and not distributed and not args.no_launch_count else None
+    whole = (None, None)
+    if world == 1 and not distributed and not args.no_launch_count:
+        model.use_graphs = not args.no_graphs
+        whole = price_whole_step(model, K, args, stages, elapsed / args.steps * 1e3, prof_steps)
     if distributed:
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -599,7 +786,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             legs["cpu_baseline"] = cpu_baseline()
         out, detail = assemble(args, world, distributed, elapsed, prof_steps, (launches, conv_ms, conv_flops, conv_bytes, roof_ms, roof_ms_hbm),
-                               stages, kernel_launches, float(d_loss), float(g_loss), legs)
+                               stages, kernel_launches, float(d_loss), float(g_loss), legs, whole_step=whole)
         out["detail"] = write_detail(detail)
         emit(out)
     if distributed:

@@ -890,6 +890,12 @@ class HipKernels(object):
             self.refresh_weights(p)     # ... and are rebuilt here in one launch
 
     # --------------------------------------------------------------------------- profiling
+    def account(self):
+        """bench.py: `with K.account() as calls:` lists every kernel-layer call made inside as (method, argument dict, bytes read,
+        bytes written) -- the algorithmic traffic of SURVEY.md 8(d): every tensor argument read once, every result written once
+        (`out=` targets that are accumulated into: read and written).  Measurement only: the wrappers exist while the context does."""
+        return _Accounting(self)
+
     def prof_enable(self, on):
         """on: False / True, or an int n > 1 for burst mode (every conv launch n times back to back inside its event pair)."""
         self.lib.gs_prof_enable(int(on))
@@ -914,6 +920,65 @@ class HipKernels(object):
         n, ms, fl = ctypes.c_int(0), ctypes.c_double(0.0), ctypes.c_double(0.0)
         self.lib.gs_prof_collect(ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl))
         return n.value, ms.value, fl.value
+
+
+class _Accounting(object):
+    SKIP = ("account", "prof_enable", "prof_roofline", "prof_records", "prof_collect", "register_param_buffer", "invalidate_weights",
+            "derived_slice", "defer_wgrad_reductions", "wgrad_slice_target_ok", "drop_deferred", "dense_nhwc_ok", "norm_bwd_bias_ok",
+            "fwd_pnbwdbwd_is_fused", "bwd_data_pnbwd_is_fused")
+
+    def __init__(self, K):
+        self.K, self.calls, self.depth, self.names = K, [], 0, []
+
+    @staticmethod
+    def _nbytes(obj):
+        if isinstance(obj, torch.Tensor):
+            return obj.numel() * obj.element_size()
+        if isinstance(obj, (tuple, list)):
+            return sum(_Accounting._nbytes(o) for o in obj)
+        return 0
+
+    def _wrap(self, name, fn):
+        import inspect
+        sig = inspect.signature(fn)
+
+        def wrapper(*a, **kw):
+            self.depth += 1
+            try:
+                out = fn(*a, **kw)
+            finally:
+                self.depth -= 1
+            if self.depth == 0:   # (conv2d_fwd -> conv2d_fwd_bias_act ...: the outermost call is the one counted)
+                try:
+                    args = dict(sig.bind(*a, **kw).arguments)
+                except TypeError:
+                    args = {}
+                read = sum(self._nbytes(v) for k, v in args.items() if k not in ("out", "bias_out"))
+                acc = sum(self._nbytes(args.get(k)) for k in ("out", "bias_out"))   # accumulated into: read + written
+                written = self._nbytes(out) if acc == 0 or not isinstance(out, torch.Tensor) else 0
+                meta = {k: (tuple(v.shape) if isinstance(v, torch.Tensor) else v) for k, v in args.items()
+                        if isinstance(v, (int, float, bool, torch.Tensor)) or v is None}
+                self.calls.append((name, meta, read + acc, written + acc))
+            return out
+        return wrapper
+
+    def __enter__(self):
+        for name in dir(type(self.K)):
+            if name.startswith("_") or name in self.SKIP:
+                continue
+            fn = getattr(self.K, name)
+            if callable(fn):
+                setattr(self.K, name, self._wrap(name, fn))   # (instance attribute shadowing the method)
+                self.names.append(name)
+        return self.calls
+
+    def __exit__(self, *exc):
+        for name in self.names:
+            try:
+                delattr(self.K, name)
+            except AttributeError:
+                pass
+        return False
 
 
 def completion_group(group_of, *targets):

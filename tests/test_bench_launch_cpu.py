@@ -90,3 +90,44 @@ def test_bench_line_stays_parseable():
     fat = dict(out, junk="x" * 10000)
     rec2 = json.loads(bench.compact_line(fat))
     assert "junk" not in rec2 and "roofline" in rec2 and "cpu_baseline" in rec2
+
+
+def test_call_log_prices_the_non_conv_families(cpu_backend):
+    """bench.price_whole_step's byte side on CPU: the kernel layer's call log (kernels._Accounting, here around the torch-CPU emulation)
+    of one reduced iteration, mapped to families -- every family of the elementwise rule gets bytes = operands read once + results
+    written once, MFMA-path 3x3 convs are left to the library's own records, Adam is 28 B per parameter."""
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    from gansynth_amd import kernels
+    from gansynth_amd.models import GANSynth
+    from gansynth_amd.networks import PGGAN
+    from gansynth_amd.utils import Dict
+    from oracle import torch_ref as R
+    pg = PGGAN(min_resolution=[2, 16], max_resolution=[4, 32], min_channels=32, max_channels=64, growing_level=1.0)
+    model = GANSynth(pg.generator, pg.discriminator, None, None, None, Dict(R.DEFAULT_HYPER))
+    lat, lab, img = R.synthetic_batch(4, rank=0, image_shape=(2, 4, 32))
+    lat, lab = lat[:, :64], lab
+    K = kernels.get()
+    model.discriminator_step(lat, lab, img)   # builds the variables
+    with kernels._Accounting(K) as calls:
+        model.discriminator_step(lat, lab, img)
+        model.generator_step(lat, lab)
+    assert not any(hasattr(K, "__dict__") and n in K.__dict__ for n in ("conv2d_fwd", "adam_tf_step"))   # the wrappers are gone again
+    fams = {}
+    for name, meta, rd, wr in calls:
+        f = bench.family_of_call(name, meta)
+        if f is not None:
+            fams.setdefault(f, []).append((name, meta, rd, wr))
+    assert {"thin_convs", "dense", "adam", "batch_stddev", "loss_heads"} <= set(fams), sorted(fams)
+    # a 1x1 colour conv is a thin conv, a 3x3 conv with >= 32 channels on both sides is the MFMA path's
+    assert bench.family_of_call("conv2d_fwd_bias_act", {"w": (1, 1, 2, 32), "ksize": 1}) == "thin_convs"
+    assert bench.family_of_call("conv2d_fwd_bias_act", {"w": (3, 3, 64, 64), "ksize": 3}) is None
+    assert bench.family_of_call("conv2d_bwd_weight", {"x": (8, 1, 2, 16), "gy": (8, 256, 2, 16), "ksize": 3}) == "thin_convs"
+    name, meta, rd, wr = fams["adam"][0]
+    n = 1
+    for d in meta["p"]:
+        n *= d
+    assert rd == 16 * n and wr == 0   # (the log itself: four fp32 operands; bench prices the step at 28 B / parameter)
+    for name, meta, rd, wr in fams["thin_convs"]:
+        assert rd > 0 and (wr > 0 or "out" in meta)
