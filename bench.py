@@ -634,6 +634,138 @@ def assemble(args, world, distributed, elapsed, prof_steps, family, stages, kern
     return out, dict(out, **detail)
 
 
+# ------------------------------------------------------------------------------------------ N > 1: first contact must not hang
+# A data-parallel run has never executed with a peer on this project's hardware (one-GPU boxes only).  Its default mode -- the gradient
+# all-reduce as a forked branch of the other run's captured graph, on the library's own RCCL communicator -- is also its most exotic one,
+# and a rank stuck inside a collective cannot rescue itself.  So for N > 1 every rank process the launcher starts is a SUPERVISOR that
+# never touches the GPU: it starts the real rank as a child (`--worker`, same arguments, LOCAL_RANK pins the GPU), watches the child's
+# progress marks (status pipe) against deadlines, and agrees with its peers over gloo (MIN all-reduce of "my worker got through
+# warm-up") after each attempt.  If ANY worker failed or stalled, EVERY supervisor kills its worker and all of them start the next,
+# tamer mode together on a fresh rendezvous port:
+DP_LADDER = [
+    ("graph-overlapped", {}),                                             # all-reduce beside part A of the other run, inside the graphs
+    ("graph-serial", {"GS_NO_OVERLAP_REDUCE": "1"}),                       # all-reduce as the last node of each run's graph
+    ("eager-same-stream", {"GS_NO_OVERLAP_REDUCE": "1", "GS_NO_GRAPH_ALLREDUCE": "1"}),   # eager all-reduce behind each replay, own communicator
+    ("eager-torch-distributed", {"GS_NO_OVERLAP_REDUCE": "1", "GS_NO_GRAPH_ALLREDUCE": "1", "GS_TORCH_COLLECTIVES": "1"}),   # torch.distributed's communicator
+]
+
+
+def _mark(text):
+    """Worker side: a progress mark for the supervisor (no-op when nobody is watching)."""
+    fd = os.environ.get("GS_STATUS_FD")
+    if fd:
+        try:
+            os.write(int(fd), (text + "\n").encode())
+        except OSError:
+            pass
+
+
+def supervise(args, argv):
+    """Rank process of an N > 1 run (see DP_LADDER).  Returns the exit code; rank 0 forwards its worker's JSON line to stdout."""
+    import signal
+    import socket
+    import subprocess
+    import threading
+    import torch.distributed as dist
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    dist.init_process_group("gloo")   # (the launcher's rendezvous; CPU only)
+    t_import = float(os.environ.get("GS_WATCHDOG_IMPORT_S", "420"))    # interpreter + `import torch` on a fresh box: up to minutes
+    t_warm = float(os.environ.get("GS_WATCHDOG_WARMUP_S", "150"))      # communicator, variables, captures, warm-up iterations
+    t_run = float(os.environ.get("GS_WATCHDOG_RUN_S", "0")) or (120.0 + 0.5 * (args.steps + args.warmup))   # timed region + per-kernel profile pass
+    first = int(os.environ.get("GS_DP_FIRST_MODE", "0"))
+    log = lambda msg: print("bench supervisor %d: %s" % (rank, msg), file=sys.stderr, flush=True)
+    rc, line = 1, None
+    for attempt, (mode, knobs) in enumerate(DP_LADDER):
+        if attempt < first:
+            continue
+        port = torch.zeros(1, dtype=torch.int64)
+        if rank == 0:
+            with socket.socket() as sock:
+                sock.bind(("127.0.0.1", 0))
+                port[0] = sock.getsockname()[1]
+        dist.broadcast(port, 0)   # a fresh rendezvous for the workers of this attempt
+        rd, wr = os.pipe()
+        env = {k: v for k, v in os.environ.items() if k not in ("TORCHELASTIC_USE_AGENT_STORE", "TORCHELASTIC_RUN_ID")}
+        for k in ("GS_NO_OVERLAP_REDUCE", "GS_NO_GRAPH_ALLREDUCE", "GS_TORCH_COLLECTIVES"):
+            env.pop(k, None)
+        env.update(knobs, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(int(port[0])), GS_STATUS_FD=str(wr), GS_DP_MODE=mode,
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        child = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv + ["--worker"], env=env, pass_fds=(wr,),
+                                 stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL, start_new_session=True)
+        os.close(wr)
+        marks, out_lines = [], []
+
+        def read_marks():
+            with os.fdopen(rd, "r") as f:
+                for ln in f:
+                    marks.append((ln.strip(), time.time()))
+
+        def read_out():
+            for ln in child.stdout:
+                out_lines.append(ln.decode(errors="replace"))
+
+        threads = [threading.Thread(target=read_marks, daemon=True)]
+        if rank == 0:
+            threads.append(threading.Thread(target=read_out, daemon=True))
+        for th in threads:
+            th.start()
+
+        def wait_for(mark, budget, since):
+            """True once `mark` arrived; False when the worker died or `budget` seconds passed since `since`."""
+            while True:
+                if any(m == mark for m, _ in marks):
+                    return True
+                if child.poll() is not None:
+                    time.sleep(0.2)
+                    return any(m == mark for m, _ in marks)
+                if time.time() - since > budget:
+                    return False
+                time.sleep(0.1)
+
+        t0 = time.time()
+        ok = wait_for("imported", t_import, t0)
+        ok = ok and wait_for("warm", t_warm, next((t for m, t in marks if m == "imported"), t0))
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)   # did EVERY worker get through its warm-up?
+        if int(flag[0]):
+            done = wait_for("done", t_run, time.time())
+            if done:
+                try:
+                    child.wait(timeout=60)
+                except subprocess.TimeoutExpired:
+                    done = False
+            flag = torch.tensor([1 if (done and child.returncode == 0) else 0], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        good = bool(int(flag[0]))
+        if child.poll() is None:   # stalled, or a peer failed: the whole process group of the worker goes
+            try:
+                os.killpg(child.pid, signal.SIGKILL)
+            except OSError:
+                pass
+            child.wait()
+        for th in threads:
+            th.join(timeout=5)
+        if good:
+            rc = 0
+            if rank == 0:
+                line = next((ln for ln in reversed(out_lines) if ln.startswith("{")), None)
+            break
+        log("mode %r did not get every rank through (%s here, worker rc %s, marks %s); next mode"
+            % (mode, "ok" if ok else "FAILED / stalled", child.returncode, [m for m, _ in marks]))
+    if rank == 0:
+        if rc == 0 and line:
+            sys.stdout.write(line if line.endswith("\n") else line + "\n")
+            sys.stdout.flush()
+        else:
+            rc = rc or 1
+            log("no mode of the ladder completed on every rank")
+    dist.barrier()
+    dist.destroy_process_group()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -649,6 +781,7 @@ def main():
     ap.add_argument("--pmc", action="store_true",
                     help="also MEASURE roofline.traffic in this run: two extra rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over one eager "
                          "iteration of this same script (+1-2 minutes); without it the committed PMC passes under profiles/ are quoted")
+    ap.add_argument("--worker", action="store_true", help="(internal) the GPU-side rank of an N > 1 run, started by its supervisor (see DP_LADDER)")
     ap.add_argument("--launch-check", action="store_true",
                     help="no device work: the ranks only rendezvous (gloo), prove the launch plumbing and print one JSON line (CPU test of the self-launch)")
     args = ap.parse_args()
@@ -668,6 +801,11 @@ def main():
                "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         raise SystemExit(subprocess.call(cmd, env=env))
 
+    if (args.gpus > 1 and not args.worker and "RANK" in os.environ and not os.environ.get("GS_NO_SUPERVISOR")
+            and (not args.launch_check or os.environ.get("GS_LAUNCH_CHECK_LADDER"))):
+        raise SystemExit(supervise(args, [a for a in sys.argv[1:] if a != "--worker"]))
+    _mark("imported")
+
     # rank 0 prints exactly ONE line on stdout: whatever native libraries print there (RCCL's version banner ...) goes to stderr
     sys.stdout.flush()
     json_fd = os.dup(1)
@@ -684,14 +822,20 @@ def main():
             raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
         if world > 1:
             torch.distributed.init_process_group("gloo")
+            stall = os.environ.get("GS_TEST_STALL_IN_MODE")   # (test hook, as in the real run below)
+            if stall and os.environ.get("GS_DP_MODE") in stall.split(",") and rank == int(os.environ.get("GS_TEST_STALL_RANK", "0")):
+                time.sleep(1e6)
             t = torch.tensor([rank, local_rank, 1], dtype=torch.int64)
             torch.distributed.all_reduce(t)
             torch.distributed.barrier()
+            _mark("warm")
             torch.distributed.destroy_process_group()
         else:
             t = torch.tensor([0, 0, 1])
         if rank == 0:
-            emit({"launch_check": True, "n_gpus": world, "ranks_joined": int(t[2]), "rank_sum": int(t[0]), "local_rank_sum": int(t[1])})
+            emit({"launch_check": True, "n_gpus": world, "ranks_joined": int(t[2]), "rank_sum": int(t[0]), "local_rank_sum": int(t[1]),
+                  "dp_mode": os.environ.get("GS_DP_MODE")})
+        _mark("done")
         return
     torch.cuda.set_device(local_rank)
     if args.spectral_only:
@@ -742,9 +886,13 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    stall = os.environ.get("GS_TEST_STALL_IN_MODE")   # (test hook: a worker that never gets through its warm-up in the named mode)
+    if stall and os.environ.get("GS_DP_MODE") in stall.split(",") and rank == int(os.environ.get("GS_TEST_STALL_RANK", "0")):
+        time.sleep(1e6)
     for _ in range(max(args.warmup, 1)):
         model.train_step()
     barrier()
+    _mark("warm")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         d_loss, g_loss = model.train_step()
@@ -788,7 +936,14 @@ def main():
         out, detail = assemble(args, world, distributed, elapsed, prof_steps, (launches, conv_ms, conv_flops, conv_bytes, roof_ms, roof_ms_hbm),
                                stages, kernel_launches, float(d_loss), float(g_loss), legs, whole_step=whole)
         out["detail"] = write_detail(detail)
+        if distributed:
+            comm = getattr(model, "_comm", None)
+            out["rccl_ranks"] = comm.count() if comm is not None else world   # ncclCommCount of the library's own communicator
+            out["config"]["parallelism"] = "dp%d, gradient all-reduce: %s%s" % (
+                world, os.environ.get("GS_DP_MODE") or ("graph-overlapped" if getattr(model, "_overlap_in_graph", lambda: False)() else "see GS_* knobs"),
+                "" if comm is not None else " (torch.distributed communicator)")
         emit(out)
+    _mark("done")
     if distributed:
         torch.distributed.destroy_process_group()
 

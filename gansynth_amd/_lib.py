@@ -30,6 +30,7 @@ SIGNATURES = {
     "gs_comm_unique_id": (I, [P]),
     "gs_comm_init": (I, [POINTER(P), I, I, P]),
     "gs_comm_destroy": (I, [P]),
+    "gs_comm_count": (I, [P, POINTER(I)]),
     "gs_allreduce_sum_f32": (I, [P, P, ctypes.c_int64, P]),
     "gs_broadcast_f32": (I, [P, P, ctypes.c_int64, I, P]),
     "gs_conv2d_workspace_bytes": (Z, [I, I, I, I, I, I, I, I, I]),

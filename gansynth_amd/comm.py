@@ -69,6 +69,12 @@ class RcclComm(object):
         _lib.check(self.lib.gs_broadcast_f32(self.handle, tensor.data_ptr(), tensor.numel(), int(root),
                                              ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "gs_broadcast_f32")
 
+    def count(self):
+        """ncclCommCount of the communicator (what RCCL itself says it spans)."""
+        n = ctypes.c_int(0)
+        _lib.check(self.lib.gs_comm_count(self.handle, ctypes.byref(n)), "gs_comm_count")
+        return int(n.value)
+
     def close(self):
         if self.handle:
             self.lib.gs_comm_destroy(self.handle)

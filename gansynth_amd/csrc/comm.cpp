@@ -17,6 +17,7 @@ struct Rccl {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
@@ -37,6 +38,7 @@ int load_rccl() {
     GS_SYM(GetUniqueId, "ncclGetUniqueId");
     GS_SYM(CommInitRank, "ncclCommInitRank");
     GS_SYM(CommDestroy, "ncclCommDestroy");
+    GS_SYM(CommCount, "ncclCommCount");
     GS_SYM(AllReduce, "ncclAllReduce");
     GS_SYM(Broadcast, "ncclBroadcast");
     GS_SYM(GetErrorString, "ncclGetErrorString");
@@ -81,6 +83,12 @@ extern "C" int gs_comm_init(gs_comm** out, int rank, int world, const void* id12
     return 0;
 }
 
+extern "C" int gs_comm_count(gs_comm* c, int* ranks) {
+    GS_CHECK_ARG(c && ranks, "gs_comm_count: bad arguments");
+    GS_NCCL_OK(g_rccl.CommCount(c->comm, ranks));   // what the communicator itself says, not what the launcher's environment says
+    return 0;
+}
+
 extern "C" int gs_comm_destroy(gs_comm* c) {
     if (!c) return 0;
     if (g_rccl.lib) g_rccl.CommDestroy(c->comm);
@@ -102,13 +110,13 @@ extern "C" int gs_allreduce_sum_f32(gs_comm* c, float* data, int64_t count, void
     GS_CHECK_ARG(c && data && count >= 0, "gs_allreduce_sum_f32: bad arguments");
     if (count == 0) return 0;
     if (c->world == 1) {
-        // read once; clamped to [0, 10 ms] so that a typo cannot park the stream
-        static const double marker_us = [] {
-            const char* us = getenv("GS_COMM_MARKER_US");
-            if (!us) return -1.0;
+        // (a one-rank communicator is never a production configuration: the variable is looked up per call -- tests switch it between
+        //  trainers of one process -- and clamped to [0, 10 ms] so that a typo cannot park the stream)
+        double marker_us = -1.0;
+        if (const char* us = getenv("GS_COMM_MARKER_US")) {
             const double v = atof(us);
-            return v < 0.0 ? 0.0 : (v > 10000.0 ? 10000.0 : v);
-        }();
+            marker_us = v < 0.0 ? 0.0 : (v > 10000.0 ? 10000.0 : v);
+        }
         if (marker_us >= 0.0) {
             hipLaunchKernelGGL(comm_marker_kernel, dim3(1), dim3(64), 0, gs::as_stream(stream), data, (long long)(marker_us * 100.0));
             GS_CHECK_LAUNCH();

@@ -776,23 +776,35 @@ class GANSynth(object):
                 params.grad_clean = True
             K.refresh_weights()   # (see _run: the captured graphs hold no re-layout launches)
             ga = torch.cuda.CUDAGraph()
-            with _quiet_gc(), torch.cuda.graph(ga, **_capture_mode(reduce_params is not None)):
-                if reduce_params is not None:
-                    main = torch.cuda.current_stream()
-                    fork = torch.cuda.Stream()
-                    fork.wait_stream(main)            # fork at the root of the graph ...
-                    with torch.cuda.stream(fork):
-                        self._reduce_in_capture(reduce_params)
-                part_a = self._part_a(which, *sa)
-                if reduce_params is not None:
-                    main.wait_stream(fork)            # ... join at its end: the collective runs beside all of part A
+            import warnings
+            with warnings.catch_warnings(record=True) as caught:
+                warnings.simplefilter("always")
+                with _quiet_gc(), torch.cuda.graph(ga, **_capture_mode(reduce_params is not None)):
+                    if reduce_params is not None:
+                        main = torch.cuda.current_stream()
+                        fork = torch.cuda.Stream()
+                        fork.wait_stream(main)            # fork at the root of the graph ...
+                        with torch.cuda.stream(fork):
+                            self._reduce_in_capture(reduce_params)
+                    part_a = self._part_a(which, *sa)
+                    if reduce_params is not None:
+                        main.wait_stream(fork)            # ... join at its end: the collective runs beside all of part A
+            # Part A may hold NO kernel: a discriminator whose whole depth runs in the batched tail has no trunk of its own (shallow
+            # growing regimes), and on ONE rank RCCL short-cuts the all-reduce to nothing as well.  torch warns about the empty graph;
+            # that is the only way it can be empty -- with peers the collective is a node -- and an empty part A is simply not replayed.
+            a_empty = any("Graph is empty" in str(w.message) for w in caught)
+            for w in caught:
+                if "Graph is empty" not in str(w.message):
+                    warnings.warn_explicit(w.message, w.category, w.filename, w.lineno)
+            if a_empty and reduce_params is not None and self.world > 1:
+                raise RuntimeError("part A of the %s run captured no node although it holds a gradient all-reduce over %d ranks" % (which, self.world))
             gb = torch.cuda.CUDAGraph()
             with _quiet_gc(), torch.cuda.graph(gb, pool=ga.pool()):
                 loss = self._part_b(which, part_a, *sb)
         finally:
             self._pipe_capture = False
             owner.fade_weight = None
-        return {"a": ga, "b": gb, "sa": sa, "sb": sb, "loss": loss, "reduces": reduce_params is not None, "keep": self.keep_gradients,
+        return {"a": ga, "b": gb, "sa": sa, "sb": sb, "loss": loss, "reduces": reduce_params is not None, "keep": self.keep_gradients, "a_empty": a_empty,
                 "consts": F.constants_snapshot()}   # (cached junction constants the graphs read: alive as long as the graphs)
 
     def _pipelined_ok(self):
@@ -864,14 +876,16 @@ class GANSynth(object):
             # D run.  Graph A = {D part A  ||  all-reduce of the generator's pending gradient}; then the generator's update (part B runs
             # the generator), then part B.
             armed(self.d_params)
-            D["a"].replay()
+            if not D["a_empty"]:
+                D["a"].replay()
             if P["g_pending"]:
                 P["g_pending"] = P["g_unreduced"] = False
                 self._apply(self.g_params, hp.generator_learning_rate, hp.generator_beta1, hp.generator_beta2, reduced=True)
             D["b"].replay()
             # G run.  Graph A = {G part A  ||  all-reduce of the discriminator's gradient}; the discriminator's update; part B runs it.
             armed(self.g_params)
-            G["a"].replay()
+            if not G["a_empty"]:
+                G["a"].replay()
             self._apply(self.d_params, hp.discriminator_learning_rate, hp.discriminator_beta1, hp.discriminator_beta2, reduced=True)
             G["b"].replay()
             P["g_pending"] = P["g_unreduced"] = True   # reduced inside the next D graph (or eagerly by _join_updates)
@@ -892,13 +906,15 @@ class GANSynth(object):
 
         # D run.  Part A reads the discriminator only: it runs under the all-reduce of the previous generator gradients.
         armed(self.d_params)
-        D["a"].replay()
+        if not D["a_empty"]:
+            D["a"].replay()
         self._join_updates()                        # the generator's update; part B runs the generator
         D["b"].replay()
         reduce_async(self.d_params, P["d_done"], P["d_reduced"])
         # G run.  Part A reads the generator only: it runs under the all-reduce of the discriminator's gradients.
         armed(self.g_params)
-        G["a"].replay()
+        if not G["a_empty"]:
+            G["a"].replay()
         main.wait_event(P["d_reduced"])
         self._apply(self.d_params, hp.discriminator_learning_rate, hp.discriminator_beta1, hp.discriminator_beta2, reduced=True)
         G["b"].replay()                             # runs the updated discriminator

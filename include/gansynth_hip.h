@@ -76,6 +76,7 @@ int gs_comm_available(void);
 int gs_comm_unique_id(void* id128);
 int gs_comm_init(gs_comm** out, int rank, int world, const void* id128);
 int gs_comm_destroy(gs_comm* comm);
+int gs_comm_count(gs_comm* comm, int* ranks);   /* ncclCommCount: the ranks the communicator was built over (bench.py reports it as rccl_ranks) */
 int gs_allreduce_sum_f32(gs_comm* comm, float* data, int64_t count, void* stream);
 int gs_broadcast_f32(gs_comm* comm, float* data, int64_t count, int root, void* stream);
 

@@ -131,3 +131,25 @@ def test_call_log_prices_the_non_conv_families(cpu_backend):
     assert rd == 16 * n and wr == 0   # (the log itself: four fp32 operands; bench prices the step at 28 B / parameter)
     for name, meta, rd, wr in fams["thin_convs"]:
         assert rd > 0 and (wr > 0 or "out" in meta)
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("stall_in,stall_rank,expect", [(None, 0, "graph-overlapped"), ("graph-overlapped", 1, "graph-serial"),
+                                                        ("graph-overlapped,graph-serial", 0, "eager-same-stream")])
+def test_first_contact_ladder_over_gloo(stall_in, stall_rank, expect):
+    """N > 1 cannot hang.  Every rank process is a supervisor (gloo, no GPU) around a `--worker` child; a worker
+    that stalls before the end of its warm-up (simulated: one rank sleeps in the named modes) is noticed by its supervisor's watchdog,
+    ALL supervisors agree (MIN all-reduce), kill their workers and start the next mode of bench.DP_LADDER together on a fresh
+    rendezvous; rank 0 still prints exactly one JSON line, and it names the mode that ran."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(GS_LAUNCH_CHECK_LADDER="1", GS_WATCHDOG_WARMUP_S="6", GS_WATCHDOG_IMPORT_S="120", GS_TEST_STALL_RANK=str(stall_rank))
+    if stall_in:
+        env["GS_TEST_STALL_IN_MODE"] = stall_in
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"], cwd=ROOT, env=env,
+                         capture_output=True, text=True, timeout=500)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = _json_lines(res.stdout)
+    assert len(lines) == 1, res.stdout
+    assert lines[0]["ranks_joined"] == 2 and lines[0]["dp_mode"] == expect, lines[0]
+    if stall_in:
+        assert "did not get every rank through" in res.stderr
