@@ -488,6 +488,34 @@ def family_of_call(name, meta):
     return "elementwise"
 
 
+def unfused_norm_bytes(K, name, meta, dtype):
+    """An MFMA-path conv whose pixel norm (forward, first- or second-order backward) the library could NOT fuse into the epilogue
+    runs the norm's own kernel inside the same entry point: the bytes of that extra pass (they belong to the pixel-norm family)."""
+    if not (name.startswith("conv2d") and ("norm" in name or "pnbwd" in name)) or not hasattr(K, "fwd_pnbwdbwd_is_fused"):
+        return 0
+    try:
+        xs, w = meta.get("x") or meta.get("gy"), meta.get("w")
+        if not (xs and w):
+            return 0
+        transposed = "transpose" in name
+        stride = 2 if transposed else int(meta.get("stride", 1))
+        dt = torch.float32 if dtype == "f32" else torch.bfloat16
+        esz = 4 if dtype == "f32" else 2
+        if "bwd_data" in name:   # first-order norm backward behind the data-gradient conv: the result has the conv INPUT's shape
+            xshape = tuple(meta.get("x_shape") or (xs[0], w[2], xs[2] * stride, xs[3] * stride))
+            if K.bwd_data_pnbwd_is_fused(xshape, xs[1], w[0], stride, transposed, dt):
+                return 0
+            tensors = 3 + (1 if meta.get("addend") is not None else 0)      # g read, z read, result written (+ addend read)
+            return xshape[0] * xshape[1] * xshape[2] * xshape[3] * esz * tensors
+        co = w[2] if transposed else w[3]
+        if K.fwd_pnbwdbwd_is_fused(xs, co, w[0], stride, transposed, dt):
+            return 0
+        out_elems = xs[0] * co * xs[2] * xs[3] * (4 if transposed else 1) // (1 if transposed else stride * stride)
+        return out_elems * esz * (5 if "pnbwdbwd" in name else 2)           # second order: t, g, z read + two results; forward: z read, y written
+    except Exception:   # noqa: BLE001 -- a refinement of the accounting, never a reason to lose the line
+        return 0
+
+
 def price_whole_step(model, K, args, stages, ms_per_step, prof_steps, trace_iters=4):
     """Every kernel family of the iteration against its roof.  Time per family: device timestamps of the kernels
     of `trace_iters` iterations (torch.profiler = roctracer; graph replays when the trace shows their kernels, eager launches
@@ -507,6 +535,10 @@ def price_whole_step(model, K, args, stages, ms_per_step, prof_steps, trace_iter
         for name, meta, rd, wr in calls:
             fam = family_of_call(name, meta)
             if fam is None:
+                extra = unfused_norm_bytes(K, name, meta, args.dtype)
+                if extra:
+                    fam_bytes["pixel_norm"] = fam_bytes.get("pixel_norm", 0) + extra
+                    fam_calls["pixel_norm"] = fam_calls.get("pixel_norm", 0) + 1
                 continue
             by = rd + wr
             if name == "adam_tf_step":   # 28 B per parameter (theta, g, m, v read; theta, m, v written), + 4 where the step also clears g
@@ -524,7 +556,9 @@ def price_whole_step(model, K, args, stages, ms_per_step, prof_steps, trace_iter
     if g_params is not None and d_params is not None:
         nparam = g_params.flat.numel() + d_params.flat.numel()
         esz = 4 if args.dtype == "f32" else 2
-        fam_bytes["weight_prep"] = fam_bytes.get("weight_prep", 0) + nparam * (4 + 3 * esz)   # fp32 masters read once, ~3 re-laid operands (fwd, bwd-data, 2nd order) written
+        # operand refresh: every cached re-laid operand written once, its fp32 master read once per operand
+        prep = sum(ent[0].numel() + ent[2].numel() * 4 for ent in getattr(K, "_wcache", {}).values() if len(ent) > 3 and ent[3] is not None)
+        fam_bytes["weight_prep"] = fam_bytes.get("weight_prep", 0) + (prep if prep else nparam * (4 + 2 * esz))
         fam_bytes["wgrad_folds"] = fam_bytes.get("wgrad_folds", 0) + nparam * 12                # partials read once (>= one fp32 slab per layer) + gradient read and written
     # (2) time per family from the device timeline
     def trace(graphs):

@@ -956,8 +956,10 @@ class _Accounting(object):
                 read = sum(self._nbytes(v) for k, v in args.items() if k not in ("out", "bias_out"))
                 acc = sum(self._nbytes(args.get(k)) for k in ("out", "bias_out"))   # accumulated into: read + written
                 written = self._nbytes(out) if acc == 0 or not isinstance(out, torch.Tensor) else 0
-                meta = {k: (tuple(v.shape) if isinstance(v, torch.Tensor) else v) for k, v in args.items()
-                        if isinstance(v, (int, float, bool, torch.Tensor)) or v is None}
+                meta = {k: (tuple(v.shape) if isinstance(v, torch.Tensor) else (tuple(v) if isinstance(v, (tuple, list, torch.Size)) else v))
+                        for k, v in args.items()
+                        if isinstance(v, (int, float, bool, torch.Tensor)) or v is None
+                        or (isinstance(v, (tuple, list, torch.Size)) and all(isinstance(e, int) for e in v))}
                 self.calls.append((name, meta, read + acc, written + acc))
             return out
         return wrapper
