@@ -153,6 +153,17 @@ __device__ __forceinline__ void lds_dma16(unsigned lds_addr, unsigned voff, i32x
                  : "s"(lds_addr), "v"(voff), "s"(rs)
                  : "memory");
 }
+// the same with a scalar offset: address = base + voff + soff, and soff takes part in the descriptor's range check (measured,
+// scripts/probe/dma_probe.hip mode 2) -- so the per-piece part of a WEIGHT address that is uniform over the wave stays in an SGPR and the
+// piece costs no VALU instruction at all (a wave issues one instruction per ~4-5 cycles: profiles/r05_c_igemm_mid_timeline.txt prices a
+// DMA piece at ~31 cycles of a stage, i.e. at its instruction count).  Only for offsets that never go negative (weights: yes; the
+// patch origin of a border tile: no -- a 33-bit sum of a negative soff would not wrap back into range).
+__device__ __forceinline__ void lds_dma16_s(unsigned lds_addr, unsigned voff, i32x4 rs, unsigned soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :
+                 : "s"(lds_addr), "v"(voff), "s"(rs), "s"(soff)
+                 : "memory");
+}
 // raw buffer descriptor over [base, base + bytes): stride 0, 32-bit data format (gfx950)
 __device__ __forceinline__ i32x4 make_rsrc(const void* base, unsigned bytes) {
     const unsigned long long b = reinterpret_cast<unsigned long long>(base);
@@ -335,7 +346,9 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void conv_igemm_kernel(const Conv
     };
     auto issue_weight_piece = [&](int k, int tg, int wbase, unsigned dst_base) __attribute__((always_inline)) {
         // (pieces past the end of the stage carry 0x80000000: out of range for any descriptor)
-        lds_dma16(dst_base + a_wave + k * 4096, (unsigned)((w_odd[k] ? w_lane1 : w_lane0) + (w_soff[tg][k] + wbase)), rs_w);
+        // (the lane part is loop-invariant, the rest is wave-uniform and >= 0: scalar offset.  Pieces past the end of the stage carry
+        //  0x80000000 in w_soff: base + 2^31 is out of range for any descriptor, with or without wbase on top)
+        lds_dma16_s(dst_base + a_wave + k * 4096, (unsigned)(w_odd[k] ? w_lane1 : w_lane0), rs_w, (unsigned)(w_soff[tg][k] + wbase));
     };
     constexpr int NPW = RESIDENT ? 0 : WP;
     auto stage_pieces = [](int tg) { return (tg == 0 ? PP : 0) + NPW; };  // DMA pieces a wave issues for a stage

@@ -6,6 +6,8 @@
 #include "../../gansynth_amd/csrc/core.cpp"
 // (the conv TU calls the norm entry point of another TU for its unfused fallback: never reached by the probe)
 extern "C" int gs_pixel_norm_fwd(const void*, void*, int64_t, int, float, int, void*) { return -3; }
+extern "C" int gs_pixel_norm_bwd_fused(const void*, const void*, const void*, void*, int64_t, int, float, int, int, int, void*) { return -3; }
+extern "C" int gs_pixel_norm_bwd_bwd_fused(const void*, const void*, const void*, void*, void*, int64_t, int, float, int, int, void*) { return -3; }
 #include <stdlib.h>
 #include <vector>
 
