@@ -1138,6 +1138,187 @@ __global__ __launch_bounds__(192) void conv_wgrad_bf16_kernel(
     }
 }
 
+// The same contraction for the HBM-bound top of the pyramid (32 input channels: 144 flop / byte), staged by LDS-DMA and wave-specialised.
+// SQ counters of conv_wgrad_bf16_kernel on these layers (profiles/r04_n_step_sq_pmc.txt): ~810 VALU instructions per tile and wave for 48 MFMAs --
+// the per-thread address arithmetic of 14 16-byte loads, their border selects and LDS stores -- waves issuing 47 % of the time, MFMA pipe busy
+// 17 %, 2.9 TB/s over x + gy where a streaming kernel reaches 4.5-6: the kernel is bound by its own instruction stream, not by HBM.  Here
+//   * wave 3 is the LOADER: it owns the tile descriptors and issues every DMA piece of tile t + 1 (1 KiB = 16 pixel rows of 64 bytes each,
+//     plain row-major: exactly the [pixel][32 channels] layout the transposing reads want; rows above / below the image fall outside the
+//     per-image descriptor and arrive as zeros, columns outside are forced out of range) while
+//   * waves 0-2 (wave = kernel row, 3 taps, no cross-wave reduction: as conv_wgrad_bf16_kernel) run the MFMAs of tile t from the other buffer;
+//   * ONE barrier per tile: behind the loader's vmcnt(0).  It publishes tile t and, since the loader issues tile t + 1 only after it, also
+//     says that every compute wave is done with the buffer tile t + 1 goes to.
+// Two blocks per CU (2 x ~77 KiB of LDS): 77 KiB in flight per CU at any time.  TW = 32 only; stride 2 takes 64-pixel tiles (its patch is
+// 4.6x the tile).  Same partial layout as conv_wgrad_bf16_kernel: the fold does not know which kernel ran.
+template <int MODE, int OT>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_thin_dma_kernel(   // (two waves per SIMD: two blocks per CU must fit the register file)
+    const WgradSrcs srcs, float* __restrict__ part,
+    int N, int Hi, int Wi, int IC, int OC, int Hb, int Wb, int tiles_x, int tiles_y, int ntiles, int nslices, int with_bias) {
+    constexpr bool S2 = MODE == MODE_S2;
+    constexpr int TW = 32;
+    constexpr int NP = S2 ? 64 : 256;
+    constexpr int TH = NP / TW;
+    constexpr int PH = patch_dim<MODE>(TH), PW = patch_dim<MODE>(TW);
+    constexpr int S = S2 ? 2 : 1;
+    constexpr int XP = (PH * PW + 15) / 16;     // 1 KiB pieces (16 rows of 64 bytes) of the patch ...
+    constexpr int GP = NP / 16;                 // ... and of one 32-channel plane of the gradient tile
+    constexpr int XB = XP * 1024, GB = NP * 64;
+    constexpr int BUF = XB + OT * GB;           // one staged tile; two of them
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const unsigned a_base = (unsigned)(uintptr_t)lds_raw;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = wv == 3;
+    const int oc0 = blockIdx.x * 32 * OT;       // (IC == 32: one input-channel tile)
+    const int slice = blockIdx.y;
+    const int t_row = (lane & 15) >> 2;
+    const int t_col = (((lane >> 4) & 1) * 16 + (lane & 3) * 4) * 2;
+
+    // ---- loader: piece j of the patch = rows 16 j + (lane >> 2) of its PH x PW pixel rows.  The (patch row, column) of a lane's row is
+    //      walked incrementally from piece to piece (+16 columns, wrapping at PW) instead of being kept in 2 x XP registers: the register
+    //      file is shared with the compute waves' accumulators, and the loader has instruction slots to spare
+    const int x_lx0 = lane >> 2;                                 // row of piece 0: patch row 0, column lane >> 2 (PW > 16)
+    const int x_voff0 = (x_lx0 * IC) * 2 + (lane & 3) * 16;
+    // a gradient piece = 16 consecutive pixels of one tile row: pixel (j >> 1, 16 (j & 1) + (lane >> 2))
+    const int g_lane = ((lane >> 2) * OC) * 2 + (lane & 3) * 16;
+    const unsigned ximg = (unsigned)Hi * Wi * IC * 2, gimg = (unsigned)Hb * Wb * OC * 2;
+
+    f32x16 acc[OT][3];
+#pragma unroll
+    for (int o = 0; o < OT; ++o)
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[o][t][r] = 0.f;
+    const bool bias_wave = with_bias && wv == 0;
+    float accb[OT];
+#pragma unroll
+    for (int o = 0; o < OT; ++o) accb[o] = 0.f;
+
+    auto tile_coords = [&](int tile, int& n, int& by, int& bx) __attribute__((always_inline)) {   // -> source index
+        int b = tile;
+        const int tile_x = b % tiles_x;
+        b /= tiles_x;
+        const int tile_y = b % tiles_y;
+        const int src = wgrad_source(srcs, b / tiles_y, n);
+        by = tile_y * TH;
+        bx = tile_x * TW;
+        return src;
+    };
+    auto issue_tile = [&](int tile, int bufi) __attribute__((always_inline)) {
+        int n, by, bx;
+        const int src = tile_coords(tile, n, by, bx);
+        const int oy0 = S2 ? 2 * by : by - 1, ox0 = S2 ? 2 * bx : bx - 1;
+        const i32x4 rs_x = make_rsrc(reinterpret_cast<const unsigned char*>(srcs.x[src]) + (size_t)n * ximg, ximg);
+        const i32x4 rs_g = make_rsrc(reinterpret_cast<const unsigned char*>(srcs.gy[src]) + (size_t)n * gimg, gimg);
+        const int xorg = ((oy0 * Wi + ox0) * IC) * 2;
+        const unsigned a_x = a_base + bufi * BUF, a_g = a_x + XB;
+        int lx = x_lx0, voff = xorg + x_voff0;
+        asm volatile("" : "+v"(lx));   // (opaque per tile: or the compiler hoists the whole column walk out of the tile loop -- 2 x XP registers again)
+        const int wrap = ((Wi - PW) * IC) * 2;                  // byte step from (ly, lx + PW) to (ly + 1, lx)
+#pragma unroll
+        for (int j = 0; j < XP; ++j) {
+            // (the last piece's rows past the patch: any column outside the image will do -- they are never read)
+            const bool in = (unsigned)(ox0 + lx) < (unsigned)Wi && (j * 16 + 15 < PH * PW || j * 16 + (lane >> 2) < PH * PW);
+            lds_dma16(a_x + j * 1024, in ? (unsigned)voff : 0x80000000u, rs_x);
+            lx += 16;
+            voff += 16 * IC * 2;
+            const bool w = lx >= PW;
+            lx = w ? lx - PW : lx;
+            voff = w ? voff + wrap : voff;
+        }
+        const bool in0 = bx + (lane >> 2) < Wb, in1 = bx + 16 + (lane >> 2) < Wb;
+#pragma unroll
+        for (int o = 0; o < OT; ++o)
+#pragma unroll
+            for (int j = 0; j < GP; ++j) {
+                const int gy_ = by + (j >> 1);                        // (wave-uniform)
+                const int gorg = ((gy_ * Wb + bx + 16 * (j & 1)) * OC + oc0 + 32 * o) * 2;
+                const unsigned v = (gy_ < Hb && ((j & 1) ? in1 : in0)) ? (unsigned)(gorg + g_lane) : 0x80000000u;
+                lds_dma16(a_g + o * GB + j * 1024, v, rs_g);
+            }
+    };
+
+    int buf = 0;
+    if (loader && slice < ntiles) issue_tile(slice, 0);
+    for (int tile = slice; tile < ntiles; tile += nslices) {
+        if (loader) wait_vmcnt(0);   // this tile has landed ...
+        block_barrier();             // ... for everybody; and everybody is done with the other buffer
+        if (loader) {
+            if (tile + nslices < ntiles) issue_tile(tile + nslices, buf ^ 1);
+        } else {
+            bool do_bias = false;
+            if (bias_wave) {
+                int n, by, bx;
+                do_bias = (srcs.bias_mask >> tile_coords(tile, n, by, bx)) & 1u;
+            }
+            const unsigned char* const lx_ = lds_raw + buf * BUF;
+            const unsigned char* const lg_ = lx_ + XB;
+            auto group = [&](int g) __attribute__((always_inline)) {
+                const int ty = (g * 16) / TW, tx0 = (g * 16) % TW + 8 * hi;
+                bf16x8 bfrag[OT];
+#pragma unroll
+                for (int o = 0; o < OT; ++o) {
+                    const unsigned char* gp = lg_ + o * GB + (ty * TW + tx0 + t_row) * 64 + t_col;
+                    const uint2 b0 = lds_tr16(gp), b1 = lds_tr16(gp + 4 * 64);
+                    bfrag[o] = mk_frag(b0.x, b0.y, b1.x, b1.y);
+                    if (do_bias) { add_bf16_pair(accb[o], b0.x); add_bf16_pair(accb[o], b0.y); add_bf16_pair(accb[o], b1.x); add_bf16_pair(accb[o], b1.y); }
+                }
+                const unsigned char* xp = lx_ + (((ty * S + wv) * PW + tx0 * S) + t_row * S) * 64 + t_col;
+                if (!S2) {
+                    const uint2 d0 = lds_tr16(xp), d1 = lds_tr16(xp + 4 * 64), d2 = lds_tr16(xp + 8 * 64);
+                    const bf16x8 a0 = mk_frag(d0.x, d0.y, d1.x, d1.y), a1 = mk_frag(shr16(d0.y, d0.x), shr16(d1.x, d0.y), shr16(d1.y, d1.x), shr16(d2.x, d1.y)),
+                                 a2 = mk_frag(d0.y, d1.x, d1.y, d2.x);
+#pragma unroll
+                    for (int o = 0; o < OT; ++o) {
+                        acc[o][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bfrag[o], acc[o][0], 0, 0, 0);
+                        acc[o][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bfrag[o], acc[o][1], 0, 0, 0);
+                        acc[o][2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, bfrag[o], acc[o][2], 0, 0, 0);
+                    }
+                } else {
+                    // even columns 2(p)+0 / +2 share a 9-pixel window; odd columns 2(p)+1 are their own 8-pixel window
+                    const uint2 e0 = lds_tr16(xp), e1 = lds_tr16(xp + 8 * 64), e2 = lds_tr16(xp + 16 * 64);
+                    const uint2 o0 = lds_tr16(xp + 64), o1 = lds_tr16(xp + 9 * 64);
+                    const bf16x8 a0 = mk_frag(e0.x, e0.y, e1.x, e1.y), a1 = mk_frag(o0.x, o0.y, o1.x, o1.y),
+                                 a2 = mk_frag(shr16(e0.y, e0.x), shr16(e1.x, e0.y), shr16(e1.y, e1.x), shr16(e2.x, e1.y));
+#pragma unroll
+                    for (int o = 0; o < OT; ++o) {
+                        acc[o][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bfrag[o], acc[o][0], 0, 0, 0);
+                        acc[o][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bfrag[o], acc[o][1], 0, 0, 0);
+                        acc[o][2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, bfrag[o], acc[o][2], 0, 0, 0);
+                    }
+                }
+            };
+            if constexpr (OT == 1) {
+#pragma unroll 2
+                for (int g = 0; g < NP / 16; ++g) group(g);
+            } else {   // (two output tiles: 96 accumulators -- one group in flight keeps the wave within 256 registers, i.e. two blocks per CU)
+#pragma unroll 1
+                for (int g = 0; g < NP / 16; ++g) group(g);
+            }
+        }
+        buf ^= 1;
+    }
+    if (loader) return;
+    // ---- each compute wave owns its 3 taps: D[ic i][oc j], lane = (j = l31, i = (r&3) + 8(r>>2) + 4hi)
+    const long pstride = 9L * IC * OC + (with_bias ? OC : 0);   // fp32 elements per slice: 9 taps (+ the bias row)
+#pragma unroll
+    for (int o = 0; o < OT; ++o) {
+        if (bias_wave) {   // the two lane halves hold different pixels of the same channel
+            const float tot = accb[o] + __shfl_xor(accb[o], 32, 64);
+            if (hi == 0) part[(long)slice * pstride + 9L * IC * OC + oc0 + o * 32 + l31] = tot;
+        }
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            float* dst = part + (long)slice * pstride + (((long)wv * 3 + kx) * IC) * OC + oc0 + o * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dst[(long)((r & 3) + 8 * (r >> 2) + 4 * hi) * OC] = acc[o][kx][r];
+        }
+    }
+}
+
 // One 16-pixel group of the 64 x 64-tile weight-gradient kernels: 9 MFMAs (3 kernel rows x 3 taps) against the gradient fragment, with the
 // OTHER work of the wave interleaved between them -- the fragment reads of the next group (2 gradient + 9 / 15 input reads), the
 // v_alignbit windows of the shifted taps, the DMA pieces of the next tile.  A wave issues in order and a 32x32x16 MFMA occupies the
@@ -2044,6 +2225,7 @@ int run_igemm(int mode, int variant, const void* x, const float* w_hwio, void* y
                                                     Wb, alpha, bias, act, w_prepared, ws, ws_bytes, st, mask, mask_act, y2, pn_eps, addend, normbwd)));
 }
 
+static int patch_dim_rt(int mode, int t) { return mode == MODE_S1 ? t + 2 : (mode == MODE_S2 ? 2 * t + 1 : t + 1); }
 // ---- weight gradient (fp32 MFMA path)
 static bool wgrad_2x2(int mode, int dtype, int IC, int OC) { (void)mode; return dtype == GS_BF16 && IC % 64 == 0 && OC % 64 == 0; }
 // thin bf16 layers whose output side has a multiple of 64 channels: 32 x 64 pairs per block (conv_wgrad_bf16_kernel<.., 2>)
@@ -2051,10 +2233,32 @@ static bool wgrad_thin_pairs(int mode, int dtype, int IC, int OC) {
     static const bool off = getenv("GS_NO_THIN_PAIRS") != nullptr;   // measurement knob
     return !off && dtype == GS_BF16 && !wgrad_2x2(mode, dtype, IC, OC) && OC % 64 == 0;
 }
+// the 32-input-channel bf16 layers (HBM-bound top of the pyramid): LDS-DMA staged, wave-specialised kernel (conv_wgrad_bf16_thin_dma_kernel)
+static bool wgrad_thin_dma(int mode, int dtype, int IC, int OC, int Wb) {
+    static const bool off = getenv("GS_NO_THIN_DMA") != nullptr;   // measurement knob: back to conv_wgrad_bf16_kernel
+    (void)mode;
+    return !off && dtype == GS_BF16 && IC == 32 && (OC == 32 || OC == 64) && Wb >= 32;
+}
 static void wgrad_geometry(int mode, int dtype, int N, int Hb, int Wb, int IC, int OC, int* tw, int* tiles_x, int* tiles_y,
                            int* ntiles, int* nslices) {
     int np = (mode == MODE_S2 ? 64 : 128) * (dtype == GS_BF16 ? 2 : 1);
     if (mode == MODE_S2 && wgrad_2x2(mode, dtype, IC, OC)) np = 64;
+    if (wgrad_thin_dma(mode, dtype, IC, OC, Wb)) {   // 256-pixel tiles, 64 at stride 2; two double-buffered blocks per CU
+        np = mode == MODE_S2 ? 64 : 256;
+        *tw = 32;
+        const int th = np / 32;
+        *tiles_x = cdiv(Wb, 32);
+        *tiles_y = cdiv(Hb, th);
+        *ntiles = N * *tiles_x * *tiles_y;
+        const int lds = 2 * (((patch_dim_rt(mode, th) * patch_dim_rt(mode, 32) + 15) / 16) * 1024 + (OC / 32) * np * 64);
+        int per_cu = (160 * 1024) / lds;
+        if (per_cu > 2) per_cu = 2;
+        if (per_cu < 1) per_cu = 1;
+        int ns = per_cu * num_cus();
+        if (ns > *ntiles) ns = *ntiles;
+        *nslices = ns;
+        return;
+    }
     *tw = Wb >= 32 ? 32 : 16;
     const int th = np / *tw;
     *tiles_x = cdiv(Wb, *tw);
@@ -2133,13 +2337,31 @@ int run_wgrad_mfma(int mode, const WgradSrcs& srcs, int nsrc, float* gw, float* 
         hipLaunchKernelGGL(kern_, dim3((IC / 64) * (OC / 64), nslices), dim3(256), lds_, st, srcs,                          \
                            part, N, Hi, Wi, IC, OC, Hb, Wb, tiles_x, tiles_y, ntiles, nslices, with_bias);              \
     } while (0)
-            if (wgrad_2x2(mode, dtype, IC, OC)) {
+#define GS_WGT(M, OTV)                                                                                                  \
+    do {                                                                                                                \
+        constexpr int np_ = (M == MODE_S2 ? 64 : 256), th_ = np_ / 32;                                                  \
+        constexpr int lds_ = 2 * (((patch_dim<M>(th_) * patch_dim<M>(32) + 15) / 16) * 1024 + OTV * np_ * 64);           \
+        auto kern_ = conv_wgrad_bf16_thin_dma_kernel<M, OTV>;                                                           \
+        static bool set_ = false;                                                                                       \
+        if (!set_) {                                                                                                    \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern_), hipFuncAttributeMaxDynamicSharedMemorySize, lds_) != hipSuccess) \
+                return fail(GS_ERR_HIP, "conv wgrad: cannot reserve %d bytes of dynamic LDS", lds_);                    \
+            set_ = true;                                                                                                \
+        }                                                                                                               \
+        hipLaunchKernelGGL(kern_, dim3(1, nslices), dim3(256), lds_, st, srcs,                                          \
+                           part, N, Hi, Wi, IC, OC, Hb, Wb, tiles_x, tiles_y, ntiles, nslices, with_bias);              \
+    } while (0)
+            if (wgrad_thin_dma(mode, dtype, IC, OC, Wb)) {
+                if (mode == MODE_S1) { if (OC == 32) GS_WGT(MODE_S1, 1); else GS_WGT(MODE_S1, 2); }
+                else { if (OC == 32) GS_WGT(MODE_S2, 1); else GS_WGT(MODE_S2, 2); }
+            } else if (wgrad_2x2(mode, dtype, IC, OC)) {
                 if (mode == MODE_S1) { if (tw == 32) GS_WGB2(MODE_S1, 32); else GS_WGB2(MODE_S1, 16); }
                 else { if (tw == 32) GS_WGB2(MODE_S2, 32); else GS_WGB2(MODE_S2, 16); }
             } else {
                 if (mode == MODE_S1) { if (tw == 32) GS_WGB(MODE_S1, 32); else GS_WGB(MODE_S1, 16); }
                 else { if (tw == 32) GS_WGB(MODE_S2, 32); else GS_WGB(MODE_S2, 16); }
             }
+#undef GS_WGT
 #undef GS_WGB2
 #undef GS_WGB
         }

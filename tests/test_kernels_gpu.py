@@ -495,9 +495,11 @@ def test_transposed_conv_is_the_adjoint_of_the_stride2_conv_at_full_size(K, case
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("case", [(1, 64, 64, 6, 40, 3, 1), (1, 64, 128, 12, 72, 3, 2), (3, 128, 64, 5, 33, 3, 1), (1, 32, 32, 1, 7, 3, 1)])
+@pytest.mark.parametrize("case", [(1, 64, 64, 6, 40, 3, 1), (1, 64, 128, 12, 72, 3, 2), (3, 128, 64, 5, 33, 3, 1), (1, 32, 32, 1, 7, 3, 1),
+                                  (3, 32, 32, 11, 45, 3, 1), (2, 32, 64, 10, 70, 3, 2), (1, 32, 64, 6, 64, 3, 1), (2, 32, 32, 18, 66, 3, 2)])
 def test_ragged_and_single_image_shapes(K, E, case, dtype):
-    """Tiles that hang over the image edge, odd widths, batch 1 -- through all three maps (64x64-tile weight gradient included)."""
+    """Tiles that hang over the image edge, odd widths, batch 1 -- through all three maps (64x64-tile weight gradient included; the last four
+    cases: the LDS-DMA weight-gradient kernel of the 32-input-channel layers, conv_wgrad_bf16_thin_dma_kernel, in its four instantiations)."""
     n, ci, co, h, w, ks, st = case
     ho, wo = (h + st - 1) // st if st == 1 else h // st, (w + st - 1) // st if st == 1 else w // st
     x = rnd(n, ci, h, w, seed=1).to(dtype).float()
