@@ -123,18 +123,21 @@ static int launch_direct(const T* x, const float* wp, T* y, int mode, int ks, in
 // The colour blocks (ops.py:237-243 with a [1,1,C,2] / [1,1,2,C] kernel) are pure streaming: 64 bytes in and 4 out per
 // pixel, or the reverse.  One lane per 16 bytes of the wide side keeps every access coalesced; the bias / activation
 // epilogue of the block is applied in the same pass.
-__device__ inline float thin_act(float v, int act) {
-    if (act == GS_ACT_LRELU) return fmaxf(v, 0.2f * v);
-    if (act == GS_ACT_TANH) return tanhf(v);
-    return v;
+// The activation of a streaming kernel is a TEMPLATE parameter: as a run-time argument the three-way choice (tanhf's own branches
+// included) was compiled into the pixel loop once per output VALUE -- ~6 scalar branches per value in thin_expand_kernel's hot loop
+// (hipcc -S), 23 us for the 67 MB of the top-level colour block where the write rate allows ~14.
+template <int ACT> __device__ inline float thin_act(float v) {
+    if constexpr (ACT == GS_ACT_LRELU) return fmaxf(v, 0.2f * v);
+    else if constexpr (ACT == GS_ACT_TANH) return fast_tanh(v);
+    else return v;
 }
 // few -> many channels: y[p][oc] = act(alpha * sum_ic x[p][ic] wp[oc][ic] + bias[oc]),  IC <= 4, OC % Wide::N == 0, 256 % (OC / N) == 0.
 // A thread keeps its Wide::N output channels (weights + bias in registers) and strides over pixels.
-template <typename T, int IC>
-// `mask` (optional, y's shape): y *= mask_act'(.) through that activation output -- the second-order pass of the R1 penalty runs the colour
+template <typename T, int IC, int ACT, bool MASKED>
+// `mask` (MASKED, y's shape): y *= mask_act'(.) through that activation output -- the second-order pass of the R1 penalty runs the colour
 // block forward on a cotangent and the next node's first step is that multiplication (gs_conv2d_fwd_mask)
 __global__ __launch_bounds__(256) void thin_expand_kernel(const T* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
-                                                          T* __restrict__ y, long P, int OC, float alpha, int act,
+                                                          T* __restrict__ y, long P, int OC, float alpha,
                                                           const T* __restrict__ mask = nullptr, int mask_act = 0) {
     constexpr int WN = Wide<T>::N;
     const int groups = OC / WN;
@@ -175,9 +178,9 @@ __global__ __launch_bounds__(256) void thin_expand_kernel(const T* __restrict__ 
             float a = br[v];
 #pragma unroll
             for (int i = 0; i < IC; ++i) a += xv[i] * wr[v][i];
-            o[v] = thin_act(a, act);
+            o[v] = thin_act<ACT>(a);
         }
-        if (mask) {
+        if constexpr (MASKED) {
             float mv[WN];
             ld_wide<T>(mask + px * OC + oc0, mv);
 #pragma unroll
@@ -289,9 +292,9 @@ static int run_thin_expand_pnbwd(const void* x, const float* wp, const void* z, 
 
 // many -> few channels: a pixel is read by L = IC / Wide::N lanes (a power of two <= 64), partial dots are folded with
 // xor-shuffles, lane 0 of the group writes the OC <= 4 results.  Weights stay in registers across the pixel loop.
-template <typename T, int OC>
+template <typename T, int OC, int ACT>
 __global__ __launch_bounds__(256) void thin_reduce_kernel(const T* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
-                                                          T* __restrict__ y, long P, int IC, float alpha, int act) {
+                                                          T* __restrict__ y, long P, int IC, float alpha) {
     constexpr int WN = Wide<T>::N;
     const int L = IC / WN;
     const int l = threadIdx.x % L;
@@ -311,10 +314,10 @@ __global__ __launch_bounds__(256) void thin_reduce_kernel(const T* __restrict__ 
             for (int v = 0; v < OC; ++v) a[v] += __shfl_xor(a[v], o, 64);
         if (pix < P && l == 0) {
             if constexpr (OC == 2 && sizeof(T) == 2) {   // both colour channels of a pixel in one 4-byte store
-                *reinterpret_cast<unsigned*>(y + pix * 2) = pack_bf16x2(thin_act(a[0] + bv[0], act), thin_act(a[1] + bv[1], act));
+                *reinterpret_cast<unsigned*>(y + pix * 2) = pack_bf16x2(thin_act<ACT>(a[0] + bv[0]), thin_act<ACT>(a[1] + bv[1]));
             } else {
 #pragma unroll
-                for (int v = 0; v < OC; ++v) DT<T>::st(y + pix * OC + v, thin_act(a[v] + bv[v], act));
+                for (int v = 0; v < OC; ++v) DT<T>::st(y + pix * OC + v, thin_act<ACT>(a[v] + bv[v]));
             }
         }
     };
@@ -454,10 +457,21 @@ static int run_direct(int mode, int ks, int variant, const void* x, const float*
         static const long te_cap = getenv("GS_THIN_EXPAND_BLOCKS") ? atol(getenv("GS_THIN_EXPAND_BLOCKS")) : 2048;
         if (nb > te_cap) nb = te_cap;
         const unsigned grid = (unsigned)nb;
-#define GS_TE(TT, ICV) hipLaunchKernelGGL((thin_expand_kernel<TT, ICV>), dim3(grid), dim3(256), 0, st, (const TT*)x, wp, bias, (TT*)y, P, OCk, alpha, act, (const TT*)mask, mask_act)
-#define GS_TE_ALL(TT) do { if (ICk == 1) GS_TE(TT, 1); else if (ICk == 2) GS_TE(TT, 2); else if (ICk == 3) GS_TE(TT, 3); else GS_TE(TT, 4); } while (0)
+#define GS_TE(TT, ICV, ACTV, MK) hipLaunchKernelGGL((thin_expand_kernel<TT, ICV, ACTV, MK>), dim3(grid), dim3(256), 0, st, (const TT*)x, wp, bias, (TT*)y, P, OCk, alpha, (const TT*)mask, mask_act)
+#define GS_TE_ACT(TT, ICV)                                                                                               \
+    do {                                                                                                                 \
+        if (mask) {   /* (masked: a forward on a cotangent -- the activation, if any, is applied by the slower generic form) */ \
+            if (act == GS_ACT_NONE) GS_TE(TT, ICV, GS_ACT_NONE, true);                                                   \
+            else if (act == GS_ACT_LRELU) GS_TE(TT, ICV, GS_ACT_LRELU, true);                                            \
+            else GS_TE(TT, ICV, GS_ACT_TANH, true);                                                                      \
+        } else if (act == GS_ACT_LRELU) GS_TE(TT, ICV, GS_ACT_LRELU, false);                                             \
+        else if (act == GS_ACT_TANH) GS_TE(TT, ICV, GS_ACT_TANH, false);                                                 \
+        else GS_TE(TT, ICV, GS_ACT_NONE, false);                                                                         \
+    } while (0)
+#define GS_TE_ALL(TT) do { if (ICk == 1) GS_TE_ACT(TT, 1); else if (ICk == 2) GS_TE_ACT(TT, 2); else if (ICk == 3) GS_TE_ACT(TT, 3); else GS_TE_ACT(TT, 4); } while (0)
         GS_DISPATCH_DTYPE(dtype, GS_TE_ALL(T));
 #undef GS_TE_ALL
+#undef GS_TE_ACT
 #undef GS_TE
         GS_CHECK_LAUNCH();
         if (mask_fused) *mask_fused = mask != nullptr;
@@ -471,10 +485,12 @@ static int run_direct(int mode, int ks, int variant, const void* x, const float*
         static const long tr_cap = getenv("GS_THIN_REDUCE_BLOCKS") ? atol(getenv("GS_THIN_REDUCE_BLOCKS")) : 4096;
         if (nb > tr_cap) nb = tr_cap;
         const unsigned grid = (unsigned)nb;
-#define GS_TR(TT, OCV) hipLaunchKernelGGL((thin_reduce_kernel<TT, OCV>), dim3(grid), dim3(256), 0, st, (const TT*)x, wp, bias, (TT*)y, P, ICk, alpha, act)
-#define GS_TR_ALL(TT) do { if (OCk == 1) GS_TR(TT, 1); else if (OCk == 2) GS_TR(TT, 2); else if (OCk == 3) GS_TR(TT, 3); else GS_TR(TT, 4); } while (0)
+#define GS_TR(TT, OCV, ACTV) hipLaunchKernelGGL((thin_reduce_kernel<TT, OCV, ACTV>), dim3(grid), dim3(256), 0, st, (const TT*)x, wp, bias, (TT*)y, P, ICk, alpha)
+#define GS_TR_ACT(TT, OCV) do { if (act == GS_ACT_LRELU) GS_TR(TT, OCV, GS_ACT_LRELU); else if (act == GS_ACT_TANH) GS_TR(TT, OCV, GS_ACT_TANH); else GS_TR(TT, OCV, GS_ACT_NONE); } while (0)
+#define GS_TR_ALL(TT) do { if (OCk == 1) GS_TR_ACT(TT, 1); else if (OCk == 2) GS_TR_ACT(TT, 2); else if (OCk == 3) GS_TR_ACT(TT, 3); else GS_TR_ACT(TT, 4); } while (0)
         GS_DISPATCH_DTYPE(dtype, GS_TR_ALL(T));
 #undef GS_TR_ALL
+#undef GS_TR_ACT
 #undef GS_TR
         GS_CHECK_LAUNCH();
         if (fused) *fused = true;

@@ -164,6 +164,21 @@ __device__ __forceinline__ void lds_dma16_s(unsigned lds_addr, unsigned voff, i3
                  : "s"(lds_addr), "v"(voff), "s"(rs), "s"(soff)
                  : "memory");
 }
+// streamed-once operands (the weight-gradient inputs of the HBM-bound layers): non-temporal policy -- the lines are not kept in L2 for a
+// second reader that never comes
+#ifndef GS_THIN_DMA_NT
+#define GS_THIN_DMA_NT 0
+#endif
+__device__ __forceinline__ void lds_dma16_stream(unsigned lds_addr, unsigned voff, i32x4 rs) {
+#if GS_THIN_DMA_NT
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen nt lds"
+                 :
+                 : "s"(lds_addr), "v"(voff), "s"(rs)
+                 : "memory");
+#else
+    lds_dma16(lds_addr, voff, rs);
+#endif
+}
 // raw buffer descriptor over [base, base + bytes): stride 0, 32-bit data format (gfx950)
 __device__ __forceinline__ i32x4 make_rsrc(const void* base, unsigned bytes) {
     const unsigned long long b = reinterpret_cast<unsigned long long>(base);
@@ -1222,7 +1237,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_thin_dma_kernel(   // 
         for (int j = 0; j < XP; ++j) {
             // (the last piece's rows past the patch: any column outside the image will do -- they are never read)
             const bool in = (unsigned)(ox0 + lx) < (unsigned)Wi && (j * 16 + 15 < PH * PW || j * 16 + (lane >> 2) < PH * PW);
-            lds_dma16(a_x + j * 1024, in ? (unsigned)voff : 0x80000000u, rs_x);
+            lds_dma16_stream(a_x + j * 1024, in ? (unsigned)voff : 0x80000000u, rs_x);
             lx += 16;
             voff += 16 * IC * 2;
             const bool w = lx >= PW;
@@ -1237,7 +1252,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_thin_dma_kernel(   // 
                 const int gy_ = by + (j >> 1);                        // (wave-uniform)
                 const int gorg = ((gy_ * Wb + bx + 16 * (j & 1)) * OC + oc0 + 32 * o) * 2;
                 const unsigned v = (gy_ < Hb && ((j & 1) ? in1 : in0)) ? (unsigned)(gorg + g_lane) : 0x80000000u;
-                lds_dma16(a_g + o * GB + j * 1024, v, rs_g);
+                lds_dma16_stream(a_g + o * GB + j * 1024, v, rs_g);
             }
     };
 
