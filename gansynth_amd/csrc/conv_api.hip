@@ -173,12 +173,25 @@ __global__ __launch_bounds__(256) void thin_expand_kernel(const T* __restrict__ 
     long pix = (long)blockIdx.x * ppb + threadIdx.x / groups;
     auto one = [&](long px, const float* xv) __attribute__((always_inline)) {
         float o[WN];
+        // two output channels per instruction (v_pk_fma_f32 / v_pk_mul_f32): the kernel's time IS its VALU count -- 50 instructions per 16
+        // bytes stored with scalar arithmetic (hipcc split every multiply-add into a packed multiply and an add), ~30 like this
+        typedef float f2_t __attribute__((ext_vector_type(2)));
 #pragma unroll
-        for (int v = 0; v < WN; ++v) {
-            float a = br[v];
+        for (int v = 0; v < WN; v += 2) {
+            f2_t a = {br[v], br[v + 1]};
 #pragma unroll
-            for (int i = 0; i < IC; ++i) a += xv[i] * wr[v][i];
-            o[v] = thin_act<ACT>(a);
+            for (int i = 0; i < IC; ++i) {
+                const f2_t xx = {xv[i], xv[i]}, ww = {wr[v][i], wr[v + 1][i]};
+                a = __builtin_elementwise_fma(xx, ww, a);
+            }
+            if constexpr (ACT == GS_ACT_LRELU) {
+                const f2_t t = a * 0.2f;
+                o[v] = fmaxf(a.x, t.x);
+                o[v + 1] = fmaxf(a.y, t.y);
+            } else {
+                o[v] = thin_act<ACT>(a.x);
+                o[v + 1] = thin_act<ACT>(a.y);
+            }
         }
         if constexpr (MASKED) {
             float mv[WN];
@@ -292,11 +305,14 @@ static int run_thin_expand_pnbwd(const void* x, const float* wp, const void* z, 
 
 // many -> few channels: a pixel is read by L = IC / Wide::N lanes (a power of two <= 64), partial dots are folded with
 // xor-shuffles, lane 0 of the group writes the OC <= 4 results.  Weights stay in registers across the pixel loop.
-template <typename T, int OC, int ACT>
+// LC: the lanes per pixel as a compile-time constant (4: the 32-channel bf16 colour block; 8: 64 bf16 / 32 fp32 channels; 0: any power of
+// two, run-time) -- with a run-time lane count the folds are loops of ds_bpermute round trips through the LDS pipe, with a constant one
+// they unroll into DPP moves.
+template <typename T, int OC, int ACT, int LC>
 __global__ __launch_bounds__(256) void thin_reduce_kernel(const T* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
                                                           T* __restrict__ y, long P, int IC, float alpha) {
     constexpr int WN = Wide<T>::N;
-    const int L = IC / WN;
+    const int L = LC ? LC : IC / WN;
     const int l = threadIdx.x % L;
     float wr[OC][WN];
 #pragma unroll
@@ -308,10 +324,27 @@ __global__ __launch_bounds__(256) void thin_reduce_kernel(const T* __restrict__ 
     float bv[OC];
 #pragma unroll
     for (int v = 0; v < OC; ++v) bv[v] = bias ? bias[v] : 0.f;
-    auto finish = [&](long pix, float* a) __attribute__((always_inline)) {
-        for (int o = L >> 1; o > 0; o >>= 1)
+    auto fold = [&](float* a) __attribute__((always_inline)) {
+        if constexpr (LC != 0) {
 #pragma unroll
-            for (int v = 0; v < OC; ++v) a[v] += __shfl_xor(a[v], o, 64);
+            for (int o = LC >> 1; o > 2; o >>= 1)
+#pragma unroll
+                for (int v = 0; v < OC; ++v) a[v] += __shfl_xor(a[v], o, 64);
+            // the last two folds stay inside a quad: DPP quad_perm moves ([2,3,0,1] = xor 2, [1,0,3,2] = xor 1), one VALU instruction each
+            // (__shfl_xor is a ds_bpermute whatever its offset)
+#pragma unroll
+            for (int v = 0; v < OC; ++v) {
+                a[v] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a[v]), 0x4E, 0xf, 0xf, false));
+                a[v] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a[v]), 0xB1, 0xf, 0xf, false));
+            }
+        } else {
+            for (int o = L >> 1; o > 0; o >>= 1)
+#pragma unroll
+                for (int v = 0; v < OC; ++v) a[v] += __shfl_xor(a[v], o, 64);
+        }
+    };
+    auto finish = [&](long pix, float* a) __attribute__((always_inline)) {
+        fold(a);
         if (pix < P && l == 0) {
             if constexpr (OC == 2 && sizeof(T) == 2) {   // both colour channels of a pixel in one 4-byte store
                 *reinterpret_cast<unsigned*>(y + pix * 2) = pack_bf16x2(thin_act<ACT>(a[0] + bv[0]), thin_act<ACT>(a[1] + bv[1]));
@@ -330,6 +363,34 @@ __global__ __launch_bounds__(256) void thin_reduce_kernel(const T* __restrict__ 
         for (int u = 0; u < U; ++u) {
             pix[u] = ((k + u) * gridDim.x + blockIdx.x) * ppb + threadIdx.x / L;
             ld_wide<T>(x + (pix[u] < P ? pix[u] : 0) * IC + l * WN, xv[u]);   // (clamped: the loads stay unconditional)
+        }
+        if constexpr (LC == U) {
+            // after the folds each of the pixel's LC lanes holds the sums of all U pixels of the trip: lane l finishes pixel l -- bias,
+            // activation (a tanh on the generator's colour block) and the store run ONCE per lane instead of U times on a quarter of them
+            float mine[OC];
+            long mypix = pix[0];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+#pragma unroll
+                for (int v = 0; v < OC; ++v) {
+                    a[u][v] = 0.f;
+#pragma unroll
+                    for (int i = 0; i < WN; ++i) a[u][v] += xv[u][i] * wr[v][i];
+                }
+                fold(a[u]);
+#pragma unroll
+                for (int v = 0; v < OC; ++v) mine[v] = (u == 0 || l == u) ? a[u][v] : mine[v];
+                mypix = l == u ? pix[u] : mypix;
+            }
+            if (mypix < P) {
+                if constexpr (OC == 2 && sizeof(T) == 2) {
+                    *reinterpret_cast<unsigned*>(y + mypix * 2) = pack_bf16x2(thin_act<ACT>(mine[0] + bv[0]), thin_act<ACT>(mine[1] + bv[1]));
+                } else {
+#pragma unroll
+                    for (int v = 0; v < OC; ++v) DT<T>::st(y + mypix * OC + v, thin_act<ACT>(mine[v] + bv[v]));
+                }
+            }
+            continue;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -485,13 +546,15 @@ static int run_direct(int mode, int ks, int variant, const void* x, const float*
         static const long tr_cap = getenv("GS_THIN_REDUCE_BLOCKS") ? atol(getenv("GS_THIN_REDUCE_BLOCKS")) : 4096;
         if (nb > tr_cap) nb = tr_cap;
         const unsigned grid = (unsigned)nb;
-#define GS_TR(TT, OCV, ACTV) hipLaunchKernelGGL((thin_reduce_kernel<TT, OCV, ACTV>), dim3(grid), dim3(256), 0, st, (const TT*)x, wp, bias, (TT*)y, P, ICk, alpha)
+#define GS_TRL(TT, OCV, ACTV, LV) hipLaunchKernelGGL((thin_reduce_kernel<TT, OCV, ACTV, LV>), dim3(grid), dim3(256), 0, st, (const TT*)x, wp, bias, (TT*)y, P, ICk, alpha)
+#define GS_TR(TT, OCV, ACTV) do { if (lanes == 4) GS_TRL(TT, OCV, ACTV, 4); else if (lanes == 8) GS_TRL(TT, OCV, ACTV, 8); else GS_TRL(TT, OCV, ACTV, 0); } while (0)
 #define GS_TR_ACT(TT, OCV) do { if (act == GS_ACT_LRELU) GS_TR(TT, OCV, GS_ACT_LRELU); else if (act == GS_ACT_TANH) GS_TR(TT, OCV, GS_ACT_TANH); else GS_TR(TT, OCV, GS_ACT_NONE); } while (0)
 #define GS_TR_ALL(TT) do { if (OCk == 1) GS_TR_ACT(TT, 1); else if (OCk == 2) GS_TR_ACT(TT, 2); else if (OCk == 3) GS_TR_ACT(TT, 3); else GS_TR_ACT(TT, 4); } while (0)
         GS_DISPATCH_DTYPE(dtype, GS_TR_ALL(T));
 #undef GS_TR_ALL
 #undef GS_TR_ACT
 #undef GS_TR
+#undef GS_TRL
         GS_CHECK_LAUNCH();
         if (fused) *fused = true;
         return 0;

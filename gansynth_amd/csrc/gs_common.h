@@ -91,7 +91,7 @@ __device__ inline void st4(bf16_t* p, const float (&o)[4]) {
 __device__ inline float fast_tanh(float x) {
     const float ax = fabsf(x);
     const float e = __expf(2.f * ax);
-    const float big = 1.f - 2.f * __frcp_rn(e + 1.f);
+    const float big = 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);   // (v_rcp_f32: 1 ulp; __frcp_rn is a correctly rounded division, ~10 instructions)
     const float x2 = ax * ax;
     const float small = ax * (1.f + x2 * (-0.33333334f + x2 * (0.13333334f + x2 * -0.05396825f)));
     return copysignf(ax < 0.25f ? small : big, x);
