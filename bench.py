@@ -300,7 +300,10 @@ def measure_traffic(dtype, batch):
         d = tempfile.mkdtemp(prefix="gs_pmc_", dir="/tmp")
         cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "1",
                "--batch", str(batch), "--dtype", dtype, "--no-graphs", "--no-cpu-baseline", "--no-spectral", "--no-launch-count"]
-        res = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=900)
+        try:
+            res = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp", GS_BENCH_NO_PMC="1"), capture_output=True, text=True, timeout=300)
+        except subprocess.TimeoutExpired:
+            return None, "rocprofv3 --pmc %s did not finish in 300 s" % counter
         dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
         if res.returncode != 0 or not dbs:
             return None, "rocprofv3 --pmc %s failed: %s" % (counter, (res.stderr or res.stdout)[-200:])
@@ -812,13 +815,18 @@ def main():
     ap.add_argument("--no-spectral", action="store_true", help="skip the configs[3] (waveform -> mel + IF) leg")
     ap.add_argument("--no-launch-count", action="store_true", help="skip the torch.profiler count of kernel launches per iteration")
     ap.add_argument("--spectral-only", action="store_true", help="run only the configs[3] leg and print its object")
-    ap.add_argument("--pmc", action="store_true",
-                    help="also MEASURE roofline.traffic in this run: two extra rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over one eager "
-                         "iteration of this same script (+1-2 minutes); without it the committed PMC passes under profiles/ are quoted")
+    ap.add_argument("--pmc", action="store_true", default=None,
+                    help="MEASURE roofline.traffic in this run: two extra rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; counters only with "
+                         "--kernel-trace) over one eager iteration of this same script (+1-2 minutes).  Default: on for the plain one-GPU run "
+                         "(the configuration the driver times), off for partial runs (--no-spectral / --no-cpu-baseline / --no-launch-count)")
+    ap.add_argument("--no-pmc", dest="pmc", action="store_false", help="quote the committed PMC passes under profiles/ instead")
     ap.add_argument("--worker", action="store_true", help="(internal) the GPU-side rank of an N > 1 run, started by its supervisor (see DP_LADDER)")
     ap.add_argument("--launch-check", action="store_true",
                     help="no device work: the ranks only rendezvous (gloo), prove the launch plumbing and print one JSON line (CPU test of the self-launch)")
     args = ap.parse_args()
+    if args.pmc is None:   # (nested passes run with --no-launch-count etc.: they never measure again)
+        args.pmc = (args.gpus == 1 and not (args.no_spectral or args.no_cpu_baseline or args.no_launch_count or args.no_graphs or args.spectral_only
+                                            or args.launch_check or args.worker) and not os.environ.get("GS_BENCH_NO_PMC"))
 
     if args.gpus > 1 and "RANK" not in os.environ:
         # `python bench.py --gpus N` without a launcher: start the N ranks ourselves -- the same command the driver would use

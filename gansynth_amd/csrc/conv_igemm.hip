@@ -436,10 +436,31 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void conv_igemm_kernel(const Conv
     }
     GS_TR(2);
     for (int c = tid; c < OC; c += (SPEC ? 512 : 256)) lbias[c] = p.bias ? p.bias[c] : 0.f;
+    // Everything the first MFMA needs besides the landed stage is computed HERE, in the shadow of the DMA round trip: left to itself hipcc
+    // sinks the fragment-offset tables and the accumulator clears behind the barrier (their first use) -- ~340 instructions between "stage 0
+    // landed" and the first MFMA of every block of every launch (profiles/r05_c_igemm_rb128_isa_slots.txt, slot 0); pinned here, ~180 of
+    // them run before the barrier.  (Ordering the table arithmetic behind the first DMA statements as well -- opaque lane ids -- costs the
+    // common subexpressions of the tables: +118 instructions, the last piece goes out later; measured in the ISA, not adopted.)
+    zero_acc();
+    if (computer) {
+#pragma unroll
+        for (int b = 0; b < B; ++b)
+#pragma unroll
+            for (int ox = 0; ox < 3; ++ox)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(b_off[b][ox][ks]));
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(a_off[ks]));
+#pragma unroll
+        for (int ph = 0; ph < NPH; ++ph)
+#pragma unroll
+            for (int a = 0; a < A; ++a)
+#pragma unroll
+                for (int b = 0; b < B; ++b) asm volatile("" : "+v"(acc[ph][a][b]));
+    }
     wait_vmcnt(0);
     block_barrier();
     GS_TR(3);
-    zero_acc();
 #ifdef GS_IGEMM_TRACE
     int tr_stage = 0;
 #endif
