@@ -22,6 +22,8 @@ SIGNATURES = {
     "gs_last_error": (c_char_p, []),
     "gs_version": (I, []),
     "gs_init": (I, []),
+    "gs_streams_create": (I, [I, POINTER(P)]),
+    "gs_streams_destroy": (I, [I, POINTER(P)]),
     "gs_prof_enable": (I, [I]),
     "gs_prof_collect": (I, [POINTER(c_int), POINTER(c_double), POINTER(c_double)]),
     "gs_prof_roofline": (I, [ctypes.c_double, ctypes.c_double, P, P, P]),

@@ -268,7 +268,8 @@ __global__ __launch_bounds__(256) void thin_expand_pnbwd_kernel(const T* __restr
             ssq += zv[v] * zv[v];
             szg += zv[v] * a;
         }
-        for (int o = groups >> 1; o > 0; o >>= 1) { ssq += __shfl_xor(ssq, o, 64); szg += __shfl_xor(szg, o, 64); }
+        ssq = group_sum(ssq, groups);
+        szg = group_sum(szg, groups);
         const float r = rsqrtf(ssq * inv_c + eps);
         const float m = szg * inv_c * r * r;
         float out[WN];
@@ -325,23 +326,9 @@ __global__ __launch_bounds__(256) void thin_reduce_kernel(const T* __restrict__ 
 #pragma unroll
     for (int v = 0; v < OC; ++v) bv[v] = bias ? bias[v] : 0.f;
     auto fold = [&](float* a) __attribute__((always_inline)) {
-        if constexpr (LC != 0) {
+        // VALU only (DPP inside a row, permlane swaps across rows; gs_common.h: a __shfl_xor is a ds_bpermute whatever its offset)
 #pragma unroll
-            for (int o = LC >> 1; o > 2; o >>= 1)
-#pragma unroll
-                for (int v = 0; v < OC; ++v) a[v] += __shfl_xor(a[v], o, 64);
-            // the last two folds stay inside a quad: DPP quad_perm moves ([2,3,0,1] = xor 2, [1,0,3,2] = xor 1), one VALU instruction each
-            // (__shfl_xor is a ds_bpermute whatever its offset)
-#pragma unroll
-            for (int v = 0; v < OC; ++v) {
-                a[v] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a[v]), 0x4E, 0xf, 0xf, false));
-                a[v] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a[v]), 0xB1, 0xf, 0xf, false));
-            }
-        } else {
-            for (int o = L >> 1; o > 0; o >>= 1)
-#pragma unroll
-                for (int v = 0; v < OC; ++v) a[v] += __shfl_xor(a[v], o, 64);
-        }
+        for (int v = 0; v < OC; ++v) a[v] = group_sum(a[v], LC != 0 ? LC : L);
     };
     auto finish = [&](long pix, float* a) __attribute__((always_inline)) {
         fold(a);

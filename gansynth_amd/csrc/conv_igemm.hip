@@ -713,8 +713,8 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void conv_igemm_kernel(const Conv
 #pragma unroll
                                         for (int e = 0; e < EV; ++e) { ssq += zv[a][v][e] * zv[a][v][e]; szg += zv[a][v][e] * gv[a][v][e]; }
                                 }
-                                ssq += __shfl_xor(ssq, 32, 64);   // the partner lane of the other half holds the pixel's other channels
-                                szg += __shfl_xor(szg, 32, 64);
+                                ssq = swap32_sum(ssq);   // the partner lane of the other half holds the pixel's other channels
+                                szg = swap32_sum(szg);
                                 const float inv_c = 1.f / (float)(32 * A);
                                 const float r = rsqrtf(ssq * inv_c + p.pn_eps);
                                 const float m = szg * inv_c * r * r;
@@ -806,8 +806,8 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void conv_igemm_kernel(const Conv
                                             ssq += zc * zc; shg += hc * gc; shz += hc * zc; szg += zc * gc;
                                         }
                                 }
-                                ssq += __shfl_xor(ssq, 32, 64); shg += __shfl_xor(shg, 32, 64);
-                                shz += __shfl_xor(shz, 32, 64); szg += __shfl_xor(szg, 32, 64);
+                                ssq = swap32_sum(ssq); shg = swap32_sum(shg);
+                                shz = swap32_sum(shz); szg = swap32_sum(szg);
                                 const float inv_c = 1.f / (float)(32 * A);
                                 const float r = rsqrtf(ssq * inv_c + p.pn_eps);
                                 const float r2 = r * r, r3 = r2 * r;
@@ -847,7 +847,7 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void conv_igemm_kernel(const Conv
 #pragma unroll
                                     for (int k = 0; k < 16; ++k) ssq += o[a][k >> 2][k & 3] * o[a][k >> 2][k & 3];
                                 }
-                                ssq += __shfl_xor(ssq, 32, 64);
+                                ssq = swap32_sum(ssq);
                                 const float r = rsqrtf(ssq * (1.f / (float)(32 * A)) + p.pn_eps);
 #pragma unroll
                                 for (int a = 0; a < A; ++a) {
@@ -1162,7 +1162,7 @@ __global__ __launch_bounds__(192) void conv_wgrad_bf16_kernel(
 #pragma unroll
     for (int o = 0; o < OT; ++o) {
         if (bias_wave) {   // the two lane halves hold different pixels of the same channel
-            const float tot = accb[o] + __shfl_xor(accb[o], 32, 64);
+            const float tot = swap32_sum(accb[o]);
             if (hi == 0) part[(long)slice * pstride + 9L * IC * OC + oc0 + o * 32 + l31] = tot;
         }
 #pragma unroll
@@ -1343,7 +1343,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_thin_dma_kernel(   // 
 #pragma unroll
     for (int o = 0; o < OT; ++o) {
         if (bias_wave) {   // the two lane halves hold different pixels of the same channel
-            const float tot = accb[o] + __shfl_xor(accb[o], 32, 64);
+            const float tot = swap32_sum(accb[o]);
             if (hi == 0) part[(long)slice * pstride + 9L * IC * OC + oc0 + o * 32 + l31] = tot;
         }
 #pragma unroll
@@ -1564,7 +1564,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_2x2_kernel(
     // ---- D[ic i][oc j], lane = (j = l31, i = (r&3) + 8(r>>2) + 4hi)
     const long pstride = 9L * IC * OC + (with_bias ? OC : 0);
     if (bias_wave) {
-        const float tot = accb + __shfl_xor(accb, 32, 64);
+        const float tot = swap32_sum(accb);
         if (hi == 0) part[(long)slice * pstride + 9L * IC * OC + oc0 + ot * 32 + l31] = tot;
     }
 #pragma unroll
@@ -1834,7 +1834,7 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void conv_wgrad_bf16_2x2_sk_kerne
         if (leave && computer) {   // partial (block + run): [tap][ic 64][oc 64] + 64 bias sums; lane = (oc j = l31, ic i = (r&3) + 8(r>>2) + 4hi)
             float* const dst0 = part + (long)(blockIdx.x + run_c) * GS_SK_PSTRIDE;
             if (bias_wave_c) {
-                const float tot = accb + __shfl_xor(accb, 32, 64);
+                const float tot = swap32_sum(accb);
                 if (hi == 0) dst0[9 * 4096 + ot * 32 + l31] = tot;
             }
             accb = 0.f;

@@ -468,7 +468,7 @@ __global__ __launch_bounds__(256) void pixel_norm_kernel(const T* __restrict__ a
             for (int k = 0; k < P; ++k)
 #pragma unroll
                 for (int e = 0; e < E; ++e) s += xv[u][k][e] * xv[u][k][e];
-            for (int o = L >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+            s = group_sum(s, L);
             const float r = rsqrtf(s * invc + eps);
             if (MODE == 0) {
 #pragma unroll
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(256) void pixel_norm_kernel(const T* __restrict__ a
                         av[u][k][e] *= dact(pre, xv[u][k][e]);
                         q += xv[u][k][e] * r * av[u][k][e];
                     }
-                for (int o = L >> 1; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+                q = group_sum(q, L);
                 q *= invc;
 #pragma unroll
                 for (int k = 0; k < P; ++k) {
@@ -515,11 +515,9 @@ __global__ __launch_bounds__(256) void pixel_norm_kernel(const T* __restrict__ a
                         sp += yv * av[u][k][e];
                         sq += yv * bv[u][k][e];
                     }
-                for (int o = L >> 1; o > 0; o >>= 1) {
-                    sa += __shfl_xor(sa, o, 64);
-                    sp += __shfl_xor(sp, o, 64);
-                    sq += __shfl_xor(sq, o, 64);
-                }
+                sa = group_sum(sa, L);
+                sp = group_sum(sp, L);
+                sq = group_sum(sq, L);
                 const float k0 = r * r * invc;
 #pragma unroll
                 for (int k = 0; k < P; ++k) {
@@ -546,9 +544,7 @@ __global__ __launch_bounds__(256) void pixel_norm_kernel(const T* __restrict__ a
         for (int k = 0; k < P; ++k)
 #pragma unroll
             for (int e = 0; e < E; ++e) {
-                float v = bs[k][e];
-                for (int o = L; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);   // the lanes that own the same channels (other rows)
-                bs[k][e] = v;
+                bs[k][e] = residue_sum(bs[k][e], L);   // the lanes that own the same channels (other rows)
             }
         const int wv = threadIdx.x >> 6;
         if (lane < L) {

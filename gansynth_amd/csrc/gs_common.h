@@ -118,11 +118,48 @@ template <> __device__ inline void st_wide<bf16_t>(bf16_t* p, const float* o) {
 }
 
 // ------------------------------------------------------------- wave64 / block reductions
-__device__ inline float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Cross-lane sums on the VALU: DPP moves inside a 16-lane row, v_permlane16_swap / v_permlane32_swap across rows.  (__shfl_xor is a
+// ds_bpermute whatever its offset -- a round trip through the LDS pipe per step.  It also turned out NOT to be safe here: with another
+// kernel's LDS-DMA traffic on the same CU -- a forked branch of the run's hipGraph -- three bpermutes in flight returned wrong sums in the
+// upper half of the wave a few times per thousand rows, with s_waitcnt lgkmcnt(0) in front of every use: profiles/r05_e_bpermute_note.txt.)
+template <int CTRL> __device__ inline float dpp_mov(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false));
+}
+// v_permlane16_swap / v_permlane32_swap on a copy of the value, written out: with the builtin hipcc places the copy two wait states in front
+// of the swap (v_mov, v_mov, v_mov, swap, swap in the NORM == 2 epilogue of conv_igemm) and the bf16 instantiation of that epilogue then
+// summed wrong halves on the hardware (test_data_gradient_continued_through_the_previous_pixel_norm, 40 % of the tensor's scale) while the
+// fp32 one (v_mov, v_mov, s_nop 0, swap, swap) was right -- five idle cycles on either side of the swap and both are.
+__device__ inline float swap16_sum(float v) {   // v[lane] + v[lane ^ 16]
+    float a = v, b;
+    asm volatile("v_mov_b32 %1, %0\n\ts_nop 4\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 4" : "+v"(a), "=&v"(b));
+    return a + b;
+}
+__device__ inline float swap32_sum(float v) {   // v[lane] + v[lane ^ 32]
+    float a = v, b;
+    asm volatile("v_mov_b32 %1, %0\n\ts_nop 4\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 4" : "+v"(a), "=&v"(b));
+    return a + b;
+}
+// Sum over every aligned group of L consecutive lanes (L = 1, 2, 4 ... 64, wave-uniform), result in every lane of the group.
+__device__ inline float group_sum(float v, int L) {
+    if (L > 1) v += dpp_mov<0xB1>(v);     // quad_perm [1,0,3,2]
+    if (L > 2) v += dpp_mov<0x4E>(v);     // quad_perm [2,3,0,1]
+    if (L > 4) v += dpp_mov<0x141>(v);    // row_half_mirror: the other quad of the 8 (every lane of a quad holds the quad's sum by now)
+    if (L > 8) v += dpp_mov<0x140>(v);    // row_mirror: the other half of the row
+    if (L > 16) v = swap16_sum(v);
+    if (L > 32) v = swap32_sum(v);
     return v;
 }
+// Sum over the lanes with the same (lane % L): lane, lane + L, lane + 2L ... (L = 1, 2, 4 ... 64, wave-uniform), result in all of them.
+__device__ inline float residue_sum(float v, int L) {
+    if (L <= 1) v += dpp_mov<0x121>(v);   // row_ror:1 -- rotations inside the 16-lane row keep the residue for every power of two
+    if (L <= 2) v += dpp_mov<0x122>(v);
+    if (L <= 4) v += dpp_mov<0x124>(v);
+    if (L <= 8) v += dpp_mov<0x128>(v);
+    if (L <= 16) v = swap16_sum(v);
+    if (L <= 32) v = swap32_sum(v);
+    return v;
+}
+__device__ inline float wave_sum(float v) { return group_sum(v, 64); }
 // Sum over a block of NT threads (NT multiple of 64, <= 1024); result valid in every thread.
 template <int NT>
 __device__ inline float block_sum(float v, float* smem /* >= NT/64 floats */) {

@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void dense_fwd_fast_kernel(const T* __restrict
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float v = acc[b][e];
-                v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+                v = residue_sum(v, 8);   // lanes l, l + 8 ... l + 56
                 acc[b][e] = v;
             }
         }

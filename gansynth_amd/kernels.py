@@ -80,6 +80,7 @@ class HipKernels(object):
         self._derived = {}        # (parent weight ptr, lo, hi) -> [contiguous slice buffer, stamp, parent, lo, hi] (derived_slice)
         self._folds = None        # deferred bias-gradient folds while deferring: [(partial rows, out, nparts, c)]
         self._pending = None      # deferred weight gradients while deferring: {layer key: {out, bias, [(x, gy, with bias)]}}
+        self._guarding = False    # inside stream_guard(): deferred operands are marked with the stream that finally reads them
 
     # --------------------------------------------------------- prepared-weight workspaces
     def register_param_buffer(self, flat):
@@ -203,6 +204,8 @@ class HipKernels(object):
         folds, self._folds = self._folds, None
         if not folds:
             return
+        if self._guarding:   # (a partial written on a forked branch is read here, on the flushing stream)
+            _StreamGuard._mark([f[0] for f in folds], torch.cuda.current_stream())
         arr = (_lib.GsFoldJob * len(folds))()
         for jb, (part, out, rows, c) in zip(arr, folds):
             jb.part, jb.out, jb.nparts, jb.c, jb.accumulate = part.data_ptr(), out.data_ptr(), rows, c, 1
@@ -257,6 +260,8 @@ class HipKernels(object):
         for key, grp in groups.items():
             kind, ksize, stride, alpha = key[0], key[2], key[3], key[4]
             out, bias, src = grp["out"], grp["bias"], grp["src"]
+            if self._guarding:   # (recorded on whatever stream the backward node ran on, read on the flushing stream)
+                _StreamGuard._mark([(x, gy) for x, gy, _ in src], torch.cuda.current_stream())
             _, ci, h, wd = src[0][0].shape   # (the pairs of a layer may differ in their image counts)
             co = src[0][1].shape[1]
             dt = _dt(src[0][0])
@@ -889,6 +894,15 @@ class HipKernels(object):
             self.invalidate_weights(p)  # parameter values changed: cached kernel operands of that buffer are stale ...
             self.refresh_weights(p)     # ... and are rebuilt here in one launch
 
+    # ------------------------------------------------------------------- more than one stream
+    def stream_guard(self):
+        """`with K.stream_guard():` -- every tensor argument of every kernel-layer call made inside is marked with the stream the call
+        runs on (Tensor.record_stream: a no-op for the stream the tensor was allocated on).  A run captured with forked branches
+        (models.GANSynth._branch) reads tensors on a stream other than their own; torch's caching allocator would otherwise hand a freed
+        block straight back to ITS stream while the other stream's kernel is still reading it.  Inside a stream capture a marked block
+        is not reused until the capture ends.  Costs host time at capture only; the wrappers exist while the context does."""
+        return _StreamGuard(self)
+
     # --------------------------------------------------------------------------- profiling
     def account(self):
         """bench.py: `with K.account() as calls:` lists every kernel-layer call made inside as (method, argument dict, bytes read,
@@ -975,6 +989,70 @@ class _Accounting(object):
         return self.calls
 
     def __exit__(self, *exc):
+        for name in self.names:
+            try:
+                delattr(self.K, name)
+            except AttributeError:
+                pass
+        return False
+
+
+class _StreamGuard(object):
+    SKIP = _Accounting.SKIP + ("stream_guard", "refresh_weights", "flush_wgrad_reductions")
+
+    def __init__(self, K):
+        self.K, self.names = K, []
+
+    @staticmethod
+    def _mark(obj, stream):
+        if isinstance(obj, torch.Tensor):
+            if obj.is_cuda:
+                obj.record_stream(stream)
+        elif isinstance(obj, (tuple, list)):
+            for o in obj:
+                _StreamGuard._mark(o, stream)
+
+    def _wrap(self, fn, name=""):
+        mark = self._mark
+
+        def wrapper(*a, **kw):
+            stream = torch.cuda.current_stream()
+            for v in a:
+                mark(v, stream)
+            for v in kw.values():
+                mark(v, stream)
+            rec = getattr(self.K, "_dbg_record", None)
+            if rec is not None:   # (debugging: copies of every operand and result, captured with the run -- which tensor differs between two replays?)
+                ins = []
+                for i, t in enumerate(list(a) + list(kw.values())):
+                    if isinstance(t, torch.Tensor) and t.is_cuda:
+                        ins.append((i, t.data_ptr(), t.numel() * t.element_size(), t.clone()))
+            out = fn(*a, **kw)
+            keep = getattr(self.K, "_dbg_keep", None)
+            if keep is not None:   # (debugging: nothing a kernel touched is freed, hence no block is reused, before the list is dropped)
+                keep.append((a, kw, out))
+            if rec is not None:
+                outs = []
+                for i, t in enumerate(out if isinstance(out, (tuple, list)) else (out,)):
+                    if isinstance(t, torch.Tensor) and t.is_cuda:
+                        outs.append((i, t.data_ptr(), t.numel() * t.element_size(), t.clone()))
+                rec.append((name, int(stream.cuda_stream), ins, outs))
+            return out
+        return wrapper
+
+    def __enter__(self):
+        for name in dir(type(self.K)):
+            if name.startswith("_") or name in self.SKIP or name in self.K.__dict__:
+                continue
+            fn = getattr(self.K, name)
+            if callable(fn):
+                setattr(self.K, name, self._wrap(fn, name))   # (instance attribute shadowing the method)
+                self.names.append(name)
+        self.K._guarding = True
+        return self
+
+    def __exit__(self, *exc):
+        self.K._guarding = False
         for name in self.names:
             try:
                 delattr(self.K, name)

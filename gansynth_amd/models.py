@@ -35,14 +35,25 @@ _PIPELINE = bool(__import__("os").environ.get("GS_PIPELINE"))   # opt-in, see GA
 _PIPE_SIDE = {"0": False, "1": True}.get(__import__("os").environ.get("GS_PIPE_SIDE", ""))
 _OVERLAP_REDUCE = not __import__("os").environ.get("GS_NO_OVERLAP_REDUCE")   # A/B switch: the all-reduce beside part A of the other run (forked graph branch)
 _GRAPH_ALLREDUCE = not __import__("os").environ.get("GS_NO_GRAPH_ALLREDUCE")   # A/B switch: the gradient all-reduce as a node of the captured graph
+_FORK = not __import__("os").environ.get("GS_NO_FORK")   # A/B switch: independent sub-passes of a run on a forked branch of its hipGraph (GANSynth._branch)
+LEVEL_STREAMS = int(__import__("os").environ.get("GS_LEVEL_STREAMS", "48"))   # see GANSynth._leveled_queues
+_FORK_EAGER = bool(__import__("os").environ.get("GS_FORK_EAGER"))   # tests: the same branches with eager launches (a second stream, event hops)
 
 
-def _capture_mode(with_collective):
+def _capture_mode(with_collective, forked=False):
     """Keyword arguments of torch.cuda.graph for a capture that contains an RCCL collective: the communicator's helper threads may call
     the HIP runtime while this thread captures (proxy progress, registration), which the default "global" capture mode turns into a capture
     error on THEIR call -- captures with a collective inside run "thread_local" (only this thread's calls are checked), as captured NCCL
-    work is run elsewhere.  Everything else keeps the strict default."""
-    return {"capture_error_mode": "thread_local"} if with_collective else {}
+    work is run elsewhere.  With forked branches in the same capture (GANSynth._branch: autograd's device thread then records and waits on
+    events between two captured streams) a thread_local capture replayed into a segmentation fault on this stack (ROCm 7.0.2, RCCL 2.26.6,
+    one rank; "global" and "relaxed" captures of the same run replay fine): those captures are "relaxed" (no thread's calls are checked).
+    Everything else keeps the strict default."""
+    forced = __import__("os").environ.get("GS_CAPTURE_MODE")   # (debugging)
+    if forced:
+        return {"capture_error_mode": forced}
+    if not with_collective:
+        return {}
+    return {"capture_error_mode": "relaxed" if forked else "thread_local"}
 
 
 def _copy_inputs(dsts, srcs):
@@ -203,6 +214,103 @@ class GANSynth(object):
         self.overlap_reduce = _OVERLAP_REDUCE
         self._pipe_capture = False
         self._warming_up = False
+        # Forked branches inside a run's hipGraph (see _branch): a run is a chain of ~370 kernels of which ~150 are few-block launches of
+        # the <= 8x64 levels -- 200 CUs idle while they run -- and it holds sub-passes that do not depend on each other.
+        self.fork = _FORK
+        self.fork_eager = _FORK_EAGER
+        self.fork_marks = not __import__("os").environ.get("GS_NO_FORK_MARKS")   # (debugging: branches start where they are opened)
+        self._side = None
+        self._marks = {}
+        self._serial_run = False
+        self._branched = False
+        self.branches_opened = 0   # (tests / bench: how many branches the last captures opened)
+
+    # ------------------------------------------------------------------------ forked branches
+    # A run holds sub-passes that do not depend on each other:
+    #   G run: D(G(z)) forward                        ||  the mode-seeking first-order pass d sum(G(z)) / dz     (both need G(z) only)
+    #          backward through D down to d L / d G(z) ||  the second-order pass of the mode-seeking term        (both need the loss head only)
+    #   D run: G(z) forward (no grad)                  ||  D's trunk on the real batch
+    # Each side has its own latency-bound stretch (the <= 8x64 levels: 64-block launches of ~10 us on a 256-CU chip) that the other side's
+    # full-chip convs can fill.  Inside a stream capture a second stream is free -- fork and join become edges of the hipGraph, there is no
+    # event hop at replay -- so the second member of each pair runs on a side stream THERE (and only there: between eager launches an event
+    # hop costs more than the overlap gains).  autograd runs a node's backward on the stream its forward ran on and orders the streams with
+    # events (captured as edges too), so putting D's forward on the side stream is what puts D's backward beside the second-order pass.
+    # The host-side launch ORDER is the same with and without branches (the engine's ready queue does not look at streams): the same kernels
+    # on the same operands, hence bit-identical parameters -- tests/test_model_gpu.py::test_forked_branches_change_nothing_but_the_schedule.
+    # Memory: torch's caching allocator hands a freed block back to the stream that allocated it, so a tensor read on the other stream must
+    # not be recycled under that read: kernels.HipKernels.stream_guard() marks every tensor argument of every kernel-layer call with the
+    # stream it is used on (record_stream; inside a capture such a block is simply not reused before the capture ends).
+    @contextlib.contextmanager
+    def _leveled_queues(self):
+        """Around a capture whose graph may hold parallel branches: LEVEL_STREAMS throw-away streams exist while the graph is instantiated
+        (torch does that when the capture ends), so that the streams the HIP runtime makes for the branches land on different hardware
+        queues -- see gs_streams_create in include/gansynth_hip.h for the runtime defect this keeps hipGraphLaunch away from."""
+        # (also without branches of our own: the data-parallel graphs fork for their all-reduce)
+        K = kernels.get() if ((self.fork or self.distributed) and torch.cuda.is_available()) else None
+        if K is None or not hasattr(K, "lib") or LEVEL_STREAMS <= 0:
+            yield
+            return
+        import ctypes
+        from . import _lib
+        handles = (ctypes.c_void_p * LEVEL_STREAMS)()
+        ptr = ctypes.cast(handles, ctypes.POINTER(ctypes.c_void_p))
+        t0 = __import__("time").perf_counter()
+        _lib.check(K.lib.gs_streams_create(LEVEL_STREAMS, ptr), "gs_streams_create")
+        self.level_seconds = getattr(self, "level_seconds", 0.0) + __import__("time").perf_counter() - t0
+        try:
+            yield
+        finally:
+            _lib.check(K.lib.gs_streams_destroy(LEVEL_STREAMS, ptr), "gs_streams_destroy")
+
+    def _forking(self):
+        if not self.fork or not torch.cuda.is_available() or not hasattr(kernels.get(), "stream_guard"):
+            return False
+        return self._capturing() or (self.fork_eager and not self._warming_up)
+
+    def _fork_mark(self, tag):
+        """Remember this point of the current stream: a branch opened later IN THE SAME capture starts from here, not from the stream's end
+        (serial runs only: the two parts of a pipelined run are two graphs, and an event of one capture cannot be waited on in another)."""
+        self._marks.pop(tag, None)
+        if self._serial_run and self._forking() and self.fork_marks:
+            ev = torch.cuda.Event()
+            ev.record()
+            self._marks[tag] = ev
+
+    @contextlib.contextmanager
+    def _branch(self, tag=None):
+        """`with self._branch(tag):` -- the launches inside go on the side stream, which starts at the mark `tag` (or here) and which the
+        current stream waits for at the end of the block.  A no-op outside a capture."""
+        ev = self._marks.pop(tag, None) if tag is not None else None
+        if not self._forking():
+            yield
+            return
+        main = torch.cuda.current_stream()
+        if self._side is None or self._side.device != main.device or self._side.cuda_stream == main.cuda_stream:
+            # torch.cuda.Stream() hands out 32 pooled streams round-robin: after enough captures (every one takes a warm-up stream) the next
+            # one IS the stream being captured -- a branch that waits for itself, and a hipGraph that crashed at replay (seen once the whole
+            # GPU suite ran in one process).  Take the next one that is not.
+            for _ in range(64):
+                self._side = torch.cuda.Stream(device=main.device)
+                if self._side.cuda_stream != main.cuda_stream:
+                    break
+            else:
+                raise RuntimeError("no second stream for the forked branches of a captured run")
+        side = self._side
+        if ev is not None:
+            side.wait_event(ev)
+        else:
+            side.wait_stream(main)
+        self.branches_opened += 1
+        self._branched = True
+        with torch.cuda.stream(side):
+            yield
+        main.wait_stream(side)
+
+    def _stream_guard(self):
+        K = kernels.get()
+        if self.fork and hasattr(K, "stream_guard") and torch.cuda.is_available():
+            return K.stream_guard()
+        return contextlib.nullcontext()
 
     # ----------------------------------------------------------------------------- build
     def _build(self, latents, labels):
@@ -289,6 +397,7 @@ class GANSynth(object):
 
     def _d_losses_a(self, labels, real_images, fused=False):
         hp = self.hyper_params
+        self._fork_mark("d_root")   # (the generator's no-grad forward of part B needs nothing of this part: it branches off here)
         real_images = real_images.detach().requires_grad_(True)
         if self._batched_tail(fused, real_images):   # part A is the real batch's trunk; everything else needs the fake batch beside it
             owner = self.discriminator.__self__
@@ -313,7 +422,7 @@ class GANSynth(object):
             return self._d_losses_b_batched(part_a, latents, labels)
         real_part, penalty = part_a
         fake_weight = hp.get("fake_gradient_penalty_weight", 0.0)
-        with torch.no_grad():  # var_list is the discriminator's only: no generator backward (models.py:86-89)
+        with self._branch("d_root"), torch.no_grad():  # var_list is the discriminator's only: no generator backward (models.py:86-89)
             fake_images = self.generator(latents, labels)
         if fake_weight:   # tf.gradients(fake_logits, [fake_images]) (models.py:51): the images are the point of differentiation
             fake_images = fake_images.detach().requires_grad_(True)
@@ -337,7 +446,7 @@ class GANSynth(object):
         hp = self.hyper_params
         _, real_images, x_real, depth, fresh, real_call = part_a
         owner = self.discriminator.__self__
-        with torch.no_grad():  # var_list is the discriminator's only: no generator backward (models.py:86-89)
+        with self._branch("d_root"), torch.no_grad():  # var_list is the discriminator's only: no generator backward (models.py:86-89); beside part A
             fake_images = self.generator(latents, labels)
         x_fake, depth_f, fresh_f = owner.discriminator_trunk(fake_images, labels.shape[1])
         assert depth_f == depth and fresh_f == fresh
@@ -360,6 +469,7 @@ class GANSynth(object):
         hp = self.hyper_params
         latents = latents.detach().requires_grad_(True)
         fake_images = self.generator(latents, labels)
+        self._fork_mark("g_images")   # (the discriminator's pass over these images in part B does not wait for the first-order pass below)
         mode_seeking = None
         if hp.mode_seeking_loss_weight:
             ones = self._ones_like(fake_images)  # tf.gradients(ys) sums ys
@@ -374,7 +484,8 @@ class GANSynth(object):
     def _g_losses_b(self, part_a, labels, fused=False):
         hp = self.hyper_params
         fake_images, mode_seeking = part_a
-        _, fake_logits = self.discriminator(fake_images, labels)
+        with self._branch("g_images") if mode_seeking is not None else contextlib.nullcontext():
+            _, fake_logits = self.discriminator(fake_images, labels)   # (its backward then runs on the branch too: beside the second-order pass)
         if fused:
             return F.gan_g_loss(fake_logits, labels, mode_seeking, hp.mode_seeking_loss_weight, 1.0e-6)
         fake_logits = self._label_logits(fake_logits, labels)
@@ -449,6 +560,7 @@ class GANSynth(object):
     def _part_b(self, which, part_a, *inputs):
         """The rest of the run: losses, backward into the flat gradient buffer; returns the (detached) mean loss."""
         fused = self._fused_losses()
+        self._branched = False
         losses = self._d_losses_b(part_a, *inputs, fused=fused) if which == "d" else self._g_losses_b(part_a, *inputs, fused=fused)   # (latents, labels) | (labels,)
         loss = losses if losses.dim() == 0 else losses.mean()   # (the fused loss kernels return the mean itself)
         K = kernels.get()
@@ -478,6 +590,9 @@ class GANSynth(object):
                     K.flush_wgrad_reductions()
         if launched:
             self._inflight = (params, launched)
+        if self._branched:   # (every branch was joined where it closed and autograd joins the streams it used; a branch left open would fail the capture)
+            self._branched = False
+            torch.cuda.current_stream().wait_stream(self._side)
         if self.distributed and self._comm is not None and self._graph_allreduce and self._capturing() and not getattr(self, "_pipe_capture", False):
             # Same-stream RCCL is capturable: the all-reduce of this run's flat gradient becomes the LAST NODE of the run's hipGraph, so
             # a replayed run hands over reduced gradients and no eager collective launch sits between the replay and the update.
@@ -578,11 +693,16 @@ class GANSynth(object):
     def _forward_backward(self, which, *inputs):
         """Gradients of one run into the flat gradient buffer; returns the (detached) mean loss.
         inputs: (latents, labels, real_images) for "d", (latents, labels) for "g"."""
-        if which == "d":
-            latents, labels, real_images = inputs
-            return self._part_b("d", self._part_a("d", labels, real_images), latents, labels)
-        latents, labels = inputs
-        return self._part_b("g", self._part_a("g", latents, labels), labels)
+        self._serial_run = True   # (both parts inside one capture: a branch of part B may start at a mark of part A)
+        try:
+            if which == "d":
+                latents, labels, real_images = inputs
+                return self._part_b("d", self._part_a("d", labels, real_images), latents, labels)
+            latents, labels = inputs
+            return self._part_b("g", self._part_a("g", latents, labels), labels)
+        finally:
+            self._serial_run = False
+            self._marks.clear()
 
     def _regime(self):
         """(head depth, fade weight or None) of the networks at the current growing depth; None for foreign network objects."""
@@ -608,7 +728,8 @@ class GANSynth(object):
         self._run_reduced = False
         if not self._graphable():
             self._graphs.clear()
-            return self._forward_backward(which, *inputs)
+            with self._stream_guard() if self.fork_eager else contextlib.nullcontext():
+                return self._forward_backward(which, *inputs)
         head, fade = self._regime()
         key = (head, fade is None)
         if self._graph_key != key:   # a new growing regime: different launch sequence
@@ -654,7 +775,7 @@ class GANSynth(object):
                 with_collective = self.distributed and self._comm is not None and self._graph_allreduce
                 error = None
                 try:
-                    with _quiet_gc(), torch.cuda.graph(graph, **_capture_mode(with_collective)):
+                    with _quiet_gc(), self._leveled_queues(), self._stream_guard(), torch.cuda.graph(graph, **_capture_mode(with_collective, self.fork)):
                         loss = self._forward_backward(which, *static)
                 except RuntimeError as e:
                     if not with_collective:
@@ -666,7 +787,7 @@ class GANSynth(object):
                     # then follows each replay eagerly, as in round 2.
                     self._give_up_graph_collectives(which, error)
                     graph = torch.cuda.CUDAGraph()
-                    with _quiet_gc(), torch.cuda.graph(graph):
+                    with _quiet_gc(), self._leveled_queues(), self._stream_guard(), torch.cuda.graph(graph):
                         loss = self._forward_backward(which, *static)
             finally:
                 owner.fade_weight = None   # (only captured launches use the table; eager callers keep passing the number)
@@ -779,10 +900,12 @@ class GANSynth(object):
             import warnings
             with warnings.catch_warnings(record=True) as caught:
                 warnings.simplefilter("always")
-                with _quiet_gc(), torch.cuda.graph(ga, **_capture_mode(reduce_params is not None)):
+                with _quiet_gc(), self._leveled_queues(), self._stream_guard(), torch.cuda.graph(ga, **_capture_mode(reduce_params is not None, self.fork)):
                     if reduce_params is not None:
                         main = torch.cuda.current_stream()
                         fork = torch.cuda.Stream()
+                        while fork.cuda_stream == main.cuda_stream or (self._side is not None and fork.cuda_stream == self._side.cuda_stream):
+                            fork = torch.cuda.Stream()   # (pooled streams come round-robin: never the capturing one, nor the branches')
                         fork.wait_stream(main)            # fork at the root of the graph ...
                         with torch.cuda.stream(fork):
                             self._reduce_in_capture(reduce_params)
@@ -799,7 +922,7 @@ class GANSynth(object):
             if a_empty and reduce_params is not None and self.world > 1:
                 raise RuntimeError("part A of the %s run captured no node although it holds a gradient all-reduce over %d ranks" % (which, self.world))
             gb = torch.cuda.CUDAGraph()
-            with _quiet_gc(), torch.cuda.graph(gb, pool=ga.pool()):
+            with _quiet_gc(), self._leveled_queues(), self._stream_guard(), torch.cuda.graph(gb, pool=ga.pool()):
                 loss = self._part_b(which, part_a, *sb)
         finally:
             self._pipe_capture = False

@@ -41,6 +41,15 @@ const char* gs_last_error(void);
 int gs_version(void);
 /* number of CUs etc. are queried lazily; this forces it (and checks the device is gfx950) */
 int gs_init(void);
+/* n plain (normal priority, non-blocking) streams, made and destroyed around the instantiation of a hipGraph WITH PARALLEL BRANCHES.
+ * The runtime hands every new stream the least-used of its GPU_MAX_HW_QUEUES hardware queues; ROCm 7.0.2's hip::GraphExec makes one
+ * stream more than the branches need and hip::Graph::UpdateStreams, at every launch, skips those that share the LAUNCH stream's hardware
+ * queue -- without a bounds check: two of them on that queue and hipGraphLaunch reads past the end of the list (segmentation fault,
+ * profiles/r05_e_graph_replay_crash.txt).  Two consecutive new streams only land on one queue when it is at least two users short of
+ * every other one; a few dozen throw-away streams level the pool first (each goes to the least-used queue), so the exec's streams
+ * land on different queues and at most one is skipped.  The reference has no such object (one TF session, models.py:189-194). */
+int gs_streams_create(int n, void** streams);
+int gs_streams_destroy(int n, void** streams);
 
 /* ---------------------------------------------------------------- profiling hooks (bench.py)
  * When enabled, every launch of conv_igemm_kernel (the MFMA implicit-GEMM conv) is bracketed by a pair of

@@ -835,6 +835,49 @@ def test_distributed_step_on_rccl_world_size_1():
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("level,full,dtype", [(1.0, False, torch.float32), (0.6, False, torch.float32), (1.0, True, torch.bfloat16)])
+def test_forked_branches_change_nothing_but_the_schedule(gpu_store, level, full, dtype):
+    """models.GANSynth._branch: inside a run's hipGraph the discriminator's pass over G(z) (forward, and through autograd its backward) runs
+    beside the generator's mode-seeking passes, and the no-grad G(z) of the discriminator run beside the real batch's trunk -- on a forked
+    branch of the graph.  The host-side launch order is the same with and without branches, so losses and parameters after three iterations
+    are the same bit for bit (reduced size fully grown / fade-in, and BASELINE.json configs[1] itself: full size, bf16, batch 8); the same
+    branches with eager launches (two streams, events) agree as well."""
+    from gansynth_amd import variables
+    out = {}
+    n = 8 if full else 4
+    res = (2, 128, 1024) if full else (2, 16, 128)
+    batches = [R.synthetic_batch(n, rank=i, image_shape=res) for i in range(3)]
+    for mode in ("plain", "forked", "forked-eager"):
+        variables.set_default_store(variables.VariableStore(device="cuda"))
+        pg, opg, model = make(level, variables.default_store(), full=full, dtype=dtype)
+        model.use_graphs = mode != "forked-eager"
+        model.fork = mode != "plain"
+        model.fork_eager = mode == "forked-eager"
+        gp, dp = opg.init_params(seed=0, bias_std=0.1)
+        losses = []
+        for step, (lat, lab, real) in enumerate(batches):
+            lat, lab, real = cuda(lat).to(dtype), cuda(lab).to(dtype), cuda(real).to(dtype)
+            if step == 0:
+                model._build(lat, lab)
+                variables.default_store().load_state_dict({**gp, **dp})
+            losses.append(float(model.discriminator_step(lat, lab, real)))
+            losses.append(float(model.generator_step(lat, lab)))
+        torch.cuda.synchronize()
+        out[mode] = (losses, model.d_params.flat.clone(), model.g_params.flat.clone(), model.branches_opened)
+        del model
+    assert out["plain"][3] == 0
+    assert out["forked"][3] == 2, out["forked"][3]           # one branch per captured run
+    assert out["forked-eager"][3] == 2 * len(batches)
+    for mode in ("forked", "forked-eager"):
+        for i, (a, b) in enumerate(zip(out["plain"][0], out[mode][0])):
+            _same_up_to_accumulation_order(a, b, f"{mode}: loss {i}")
+        _same_up_to_accumulation_order(out["plain"][1], out[mode][1], f"{mode}: discriminator parameters")
+        _same_up_to_accumulation_order(out["plain"][2], out[mode][2], f"{mode}: generator parameters")
+    same = [bool(torch.equal(out["plain"][k], out["forked"][k])) for k in (1, 2)]
+    print("forked graphs vs plain graphs bit-identical (D, G):", same, "losses:", out["plain"][0], out["forked"][0])
+    assert all(same), same
+
+
 def _dp_trainer(level, batches, full=False, dtype=torch.float32, distributed=True, graphs=True, keep=True):
     from gansynth_amd import variables
     variables.set_default_store(variables.VariableStore(device="cuda"))
