@@ -52,6 +52,7 @@ SIGNATURES = {
     "gs_conv2d_transpose_s2_bwd_weight_multi": (I, [P, P, P, I, P, I, I, I, I, I, F, I, I, P, Z, P, P]),
     "gs_conv_wgrad_jobs_workspace_bytes": (Z, [P, I]),
     "gs_conv_wgrad_jobs": (I, [P, I, P, Z, P]),
+    "gs_wgrad_cu_cap": (I, [I]),
     "gs_conv2d_transpose_s2_workspace_bytes": (Z, [I, I, I, I, I, I, I]),
     "gs_conv2d_transpose_s2_fwd": (I, [P, P, P, I, I, I, I, I, F, I, I, P, Z, P]),
     "gs_conv2d_transpose_s2_fwd_bias_act": (I, [P, P, P, P, I, I, I, I, I, F, I, I, I, P, Z, P]),

@@ -1935,6 +1935,13 @@ static int num_cus() {
     }
     return g_num_cus;
 }
+// weight-gradient launches sized for fewer CUs than the chip has (0: all): what runs beside a latency-bound chain on a forked branch of
+// the run's hipGraph leaves that chain's few blocks somewhere to land (gs_wgrad_cu_cap; models.GANSynth._early_flush)
+static int g_wgrad_cu_cap = 0;
+static int wgrad_cus() {
+    const int n = num_cus();
+    return g_wgrad_cu_cap > 0 && g_wgrad_cu_cap < n ? g_wgrad_cu_cap : n;
+}
 
 #ifndef GS_MAX_BLOCKS_PER_CU
 #define GS_MAX_BLOCKS_PER_CU 2
@@ -2290,7 +2297,7 @@ static void wgrad_geometry(int mode, int dtype, int N, int Hb, int Wb, int IC, i
         int per_cu = (160 * 1024) / lds;
         if (per_cu > 2) per_cu = 2;
         if (per_cu < 1) per_cu = 1;
-        int ns = per_cu * num_cus();
+        int ns = per_cu * wgrad_cus();
         if (ns > *ntiles) ns = *ntiles;
         *nslices = ns;
         return;
@@ -2446,7 +2453,7 @@ void wgrad_sk_plan(int mode, SkGroup& g) {
     static const int upb2_env = getenv("GS_SK_UNITS_PER_BLOCK_S2") ? atoi(getenv("GS_SK_UNITS_PER_BLOCK_S2")) : 0;
     const int upb = mode == MODE_S2 ? (upb2_env > 0 ? upb2_env : 4) : (upb_env > 0 ? upb_env : 2);
     long nb = units / upb;
-    if (nb > num_cus()) nb = num_cus();
+    if (nb > wgrad_cus()) nb = wgrad_cus();
     if (nb < 1) nb = 1;
     g.nblocks = (int)nb;
 }
@@ -2506,6 +2513,11 @@ int run_wgrad_sk(int mode, int tw, const SkGroup& g, void* ws, size_t ws_bytes, 
 
 }  // namespace gs
 
+extern "C" int gs_wgrad_cu_cap(int cap) {
+    const int was = gs::g_wgrad_cu_cap;
+    gs::g_wgrad_cu_cap = cap < 0 ? 0 : cap;
+    return was;
+}
 extern "C" int gs_prof_enable(int on) {
     gs::g_prof.on = on != 0;
     gs::g_prof.burst = on > 1 ? on : 1;

@@ -81,6 +81,7 @@ class HipKernels(object):
         self._folds = None        # deferred bias-gradient folds while deferring: [(partial rows, out, nparts, c)]
         self._pending = None      # deferred weight gradients while deferring: {layer key: {out, bias, [(x, gy, with bias)]}}
         self._guarding = False    # inside stream_guard(): deferred operands are marked with the stream that finally reads them
+        self._early = None        # (min output pixels of a "large" layer, callback): see early_flush_rule
 
     # --------------------------------------------------------- prepared-weight workspaces
     def register_param_buffer(self, flat):
@@ -223,17 +224,38 @@ class HipKernels(object):
             return True
         return x.dtype == torch.bfloat16 and x.shape[1] % 64 == 0 and co % 64 == 0
 
+    # Large layers first.  A backward pass walks the pyramid top-down (and the second-order passes walk it bottom-up first): by the time it
+    # reaches the few-block levels every (x, gy) pair of the full-chip levels recorded so far is final, and their contraction -- the
+    # HBM-bound part of the weight gradients -- needs nothing the chain below still computes.  Rule: when a SMALL layer is recorded while
+    # LARGE ones are pending, `callback(select)` is called once; the trainer answers with flush_wgrad_reductions(select=select) on a forked
+    # branch of the run's hipGraph (models.GANSynth._early_flush), where it runs beside the latency-bound chain instead of after it.  A layer
+    # whose pairs arrive on both sides of that point (the discriminator's: the R1 pairs early, the real / fake pairs late) is contracted in
+    # two launches that add into the same gradient; the rule depends on the recorded sequence only, never on the stream.
+    def early_flush_rule(self, min_pixels, callback):
+        self._early = None if callback is None else (int(min_pixels), callback)
+
+    @staticmethod
+    def _key_pixels(key):
+        return int(key[6][1]) * int(key[6][2])   # (output positions of the conv whose weight this is)
+
     def _defer_wgrad(self, key, x, gy, out, bias_out):
+        if self._early is not None and self._key_pixels(key) < self._early[0] and self._pending:
+            big = self._early[0]
+            if any(self._key_pixels(k) >= big for k in self._pending):
+                self._early[1](lambda k: self._key_pixels(k) >= big)
         grp = self._pending.setdefault(key, {"out": out, "bias": None, "src": []})
         if bias_out is not None:
             assert grp["bias"] is None or grp["bias"].data_ptr() == bias_out.data_ptr()
             grp["bias"] = bias_out
         grp["src"].append((x, gy, bias_out is not None))
 
-    def flush_wgrad_reductions(self, group_of=None, on_group_done=None):
+    def flush_wgrad_reductions(self, group_of=None, on_group_done=None, select=None):
         """`group_of(out.data_ptr()) -> int | None` orders the layers into groups (the trainer's gradient buckets, in completion
         order); each group is contracted and folded before the next one starts and `on_group_done(group)` is called right after
         its last launch -- the data-parallel trainer puts that bucket's all-reduce on the wire there."""
+        if select is not None:   # (the recorded layers `select(key)` picks, now; everything else -- and the bias folds -- stays pending)
+            picked = {k: self._pending.pop(k) for k in [k for k in self._pending if select(k)]}
+            return self._flush_groups(picked) if picked else 0
         groups, self._pending = self._pending, None
         self._flush_folds()   # (bias gradients first: they belong to the same buckets as the weights folded below)
         if not groups:
@@ -937,7 +959,7 @@ class HipKernels(object):
 
 
 class _Accounting(object):
-    SKIP = ("account", "prof_enable", "prof_roofline", "prof_records", "prof_collect", "register_param_buffer", "invalidate_weights",
+    SKIP = ("account", "prof_enable", "prof_roofline", "prof_records", "prof_collect", "register_param_buffer", "invalidate_weights", "early_flush_rule",
             "derived_slice", "defer_wgrad_reductions", "wgrad_slice_target_ok", "drop_deferred", "dense_nhwc_ok", "norm_bwd_bias_ok",
             "fwd_pnbwdbwd_is_fused", "bwd_data_pnbwd_is_fused")
 

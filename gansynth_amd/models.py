@@ -37,6 +37,8 @@ _OVERLAP_REDUCE = not __import__("os").environ.get("GS_NO_OVERLAP_REDUCE")   # A
 _GRAPH_ALLREDUCE = not __import__("os").environ.get("GS_NO_GRAPH_ALLREDUCE")   # A/B switch: the gradient all-reduce as a node of the captured graph
 _FORK = not __import__("os").environ.get("GS_NO_FORK")   # A/B switch: independent sub-passes of a run on a forked branch of its hipGraph (GANSynth._branch)
 LEVEL_STREAMS = int(__import__("os").environ.get("GS_LEVEL_STREAMS", "48"))   # see GANSynth._leveled_queues
+EARLY_FLUSH_MAX = int(__import__("os").environ.get("GS_EARLY_FLUSH_MAX", "1"))   # early contractions per run
+EARLY_FLUSH_CUS = int(__import__("os").environ.get("GS_EARLY_FLUSH_CUS", "192"))   # see GANSynth._early_flush
 _FORK_EAGER = bool(__import__("os").environ.get("GS_FORK_EAGER"))   # tests: the same branches with eager launches (a second stream, event hops)
 
 
@@ -224,6 +226,10 @@ class GANSynth(object):
         self._serial_run = False
         self._branched = False
         self.branches_opened = 0   # (tests / bench: how many branches the last captures opened)
+        self.early_flush = not __import__("os").environ.get("GS_NO_EARLY_FLUSH")   # A/B switch: see _early_flush
+        self.early_flush_always = False   # (tests: the same flush points without branches -- in place, on the one stream)
+        self.early_flushes = 0
+        self._early_in_run = 0
 
     # ------------------------------------------------------------------------ forked branches
     # A run holds sub-passes that do not depend on each other:
@@ -277,7 +283,7 @@ class GANSynth(object):
             self._marks[tag] = ev
 
     @contextlib.contextmanager
-    def _branch(self, tag=None):
+    def _branch(self, tag=None, join=True):
         """`with self._branch(tag):` -- the launches inside go on the side stream, which starts at the mark `tag` (or here) and which the
         current stream waits for at the end of the block.  A no-op outside a capture."""
         ev = self._marks.pop(tag, None) if tag is not None else None
@@ -304,7 +310,31 @@ class GANSynth(object):
         self._branched = True
         with torch.cuda.stream(side):
             yield
-        main.wait_stream(side)
+        if join:   # (else: at the end of the run, _part_b)
+            main.wait_stream(side)
+
+    def _early_flush(self, select):
+        """kernels.HipKernels.early_flush_rule: the weight gradients of the full-chip levels recorded so far are contracted NOW -- on the
+        branch when the run is being captured (joined at the end of the run), else in place: the same launches on the same operands either
+        way.  (Called from inside a backward node, i.e. on autograd's device thread, under that node's stream.)"""
+        K = kernels.get()
+        self.early_flushes += 1
+        self._early_in_run += 1
+        if self._early_in_run > EARLY_FLUSH_MAX:   # (the pairs stay pending: contracted with everything else at the end of the run)
+            return
+        was = K.lib.gs_wgrad_cu_cap(EARLY_FLUSH_CUS) if hasattr(K, "lib") else 0   # (the chain beside it needs somewhere to land)
+        try:
+            with self._branch(join=False):
+                K.flush_wgrad_reductions(select=select)
+        finally:
+            if hasattr(K, "lib"):
+                K.lib.gs_wgrad_cu_cap(was)
+
+    def _large_layer_pixels(self):
+        owner = getattr(self.generator, "__self__", None)
+        if owner is None or not hasattr(owner, "resolution"):
+            return None
+        return max(1, int(owner.resolution(owner.max_depth).prod()) // 16)   # (the three levels at the top of the pyramid)
 
     def _stream_guard(self):
         K = kernels.get()
@@ -570,6 +600,13 @@ class GANSynth(object):
         params = self.d_params if which == "d" else self.g_params
         overlap = (self.distributed and deferring and len(params.buckets) > 1 and not self._capturing()
                    and not getattr(self, "_warming_up", False))
+        if deferring and self.early_flush and hasattr(K, "early_flush_rule") and (self.fork or self.early_flush_always):
+            # (eager launches follow the same rule, in place: a captured run and an eager one then associate every sum alike -- also the
+            #  data-parallel eager path, whose buckets go on the wire from the flush at the end of the pass, behind every early launch)
+            big = self._large_layer_pixels()
+            if big is not None:
+                self._early_in_run = 0
+                K.early_flush_rule(big, self._early_flush)
         launched = []
         if hasattr(F, "reset_fusion_state"):
             F.reset_fusion_state()   # (side-channel state of cross-node fusions is per backward pass)
@@ -583,6 +620,8 @@ class GANSynth(object):
             if hasattr(F, "reset_fusion_state"):
                 F.reset_fusion_state()   # (the hand-off table holds tensors of this pass -- of a graph's pool while capturing: not beyond it)
             if deferring:
+                if hasattr(K, "early_flush_rule"):
+                    K.early_flush_rule(0, None)
                 if overlap:   # contract the layers bucket by bucket; a finished bucket goes on the wire under the next one's kernels
                     K.flush_wgrad_reductions(group_of=params.bucket_of,
                                              on_group_done=lambda i: launched.append((i, self._launch_reduce(params, i))))

@@ -242,6 +242,10 @@ typedef struct GsWgradJob {
 } GsWgradJob;
 size_t gs_conv_wgrad_jobs_workspace_bytes(const GsWgradJob* jobs, int njobs);
 int gs_conv_wgrad_jobs(const GsWgradJob* jobs, int njobs, void* ws, size_t ws_bytes, void* stream);
+/* Size the weight-gradient launches of the calls that follow for `cap` CUs instead of the whole chip (0: the whole chip); returns the
+ * previous setting.  For a call whose launches run on a forked branch of a hipGraph beside a latency-bound chain of few-block kernels,
+ * which then finds CUs to land on.  Host-side state, read when a launch is planned (workspace query and launch alike). */
+int gs_wgrad_cu_cap(int cap);
 
 /* Refreshing many prepared weight operands in one launch (after an optimizer step: ~60 conv maps, one kernel instead of
  * one re-layout launch in front of each conv).  A descriptor names the fp32 HWIO master weight, the persistent workspace
