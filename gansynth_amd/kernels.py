@@ -81,6 +81,7 @@ class HipKernels(object):
         self._folds = None        # deferred bias-gradient folds while deferring: [(partial rows, out, nparts, c)]
         self._pending = None      # deferred weight gradients while deferring: {layer key: {out, bias, [(x, gy, with bias)]}}
         self._guarding = False    # inside stream_guard(): deferred operands are marked with the stream that finally reads them
+        self._last_writer = {}    # inside stream_guard(): accumulate target -> (stream, event) of the last call that added into it
         self._early = None        # (min output pixels of a "large" layer, callback): see early_flush_rule
 
     # --------------------------------------------------------- prepared-weight workspaces
@@ -1037,12 +1038,22 @@ class _StreamGuard(object):
     def _wrap(self, fn, name=""):
         mark = self._mark
 
+        K = self.K
+
         def wrapper(*a, **kw):
             stream = torch.cuda.current_stream()
             for v in a:
                 mark(v, stream)
             for v in kw.values():
                 mark(v, stream)
+            # `out=` / `bias_out=` are ACCUMULATED into (a variable's gradient): two passes on two streams that add into the same variable
+            # -- the real and the fake pass of a discriminator run -- must not interleave their read-modify-writes: the call waits for the
+            # last one that touched the target from the other stream, and leaves its own mark behind
+            targets = [t for t in (kw.get("out"), kw.get("bias_out")) if isinstance(t, torch.Tensor) and t.is_cuda]
+            for t in targets:
+                prev = K._last_writer.get(t.data_ptr())
+                if prev is not None and prev[0] != stream.cuda_stream:
+                    stream.wait_event(prev[1])
             rec = getattr(self.K, "_dbg_record", None)
             if rec is not None:   # (debugging: copies of every operand and result, captured with the run -- which tensor differs between two replays?)
                 ins = []
@@ -1053,6 +1064,10 @@ class _StreamGuard(object):
             keep = getattr(self.K, "_dbg_keep", None)
             if keep is not None:   # (debugging: nothing a kernel touched is freed, hence no block is reused, before the list is dropped)
                 keep.append((a, kw, out))
+            for t in targets:
+                ev = torch.cuda.Event()
+                ev.record(stream)
+                K._last_writer[t.data_ptr()] = (stream.cuda_stream, ev)
             if rec is not None:
                 outs = []
                 for i, t in enumerate(out if isinstance(out, (tuple, list)) else (out,)):
@@ -1071,10 +1086,12 @@ class _StreamGuard(object):
                 setattr(self.K, name, self._wrap(fn, name))   # (instance attribute shadowing the method)
                 self.names.append(name)
         self.K._guarding = True
+        self.K._last_writer = {}
         return self
 
     def __exit__(self, *exc):
         self.K._guarding = False
+        self.K._last_writer = {}
         for name in self.names:
             try:
                 delattr(self.K, name)

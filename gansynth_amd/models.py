@@ -227,6 +227,7 @@ class GANSynth(object):
         self._branched = False
         self.branches_opened = 0   # (tests / bench: how many branches the last captures opened)
         self.early_flush = not __import__("os").environ.get("GS_NO_EARLY_FLUSH")   # A/B switch: see _early_flush
+        self.batch_d_tail = None   # None: the discriminator's tail over [real; fake] as one batch unless the runs fork (see _batched_tail)
         self.early_flush_always = False   # (tests: the same flush points without branches -- in place, on the one stream)
         self.early_flushes = 0
         self._early_in_run = 0
@@ -323,8 +324,9 @@ class GANSynth(object):
         if self._early_in_run > EARLY_FLUSH_MAX:   # (the pairs stay pending: contracted with everything else at the end of the run)
             return
         was = K.lib.gs_wgrad_cu_cap(EARLY_FLUSH_CUS) if hasattr(K, "lib") else 0   # (the chain beside it needs somewhere to land)
+        on_branch = self._side is not None and torch.cuda.is_available() and torch.cuda.current_stream().cuda_stream == self._side.cuda_stream
         try:
-            with self._branch(join=False):
+            with (contextlib.nullcontext() if on_branch else self._branch(join=False)):   # (a node of the branch itself: in place)
                 K.flush_wgrad_reductions(select=select)
         finally:
             if hasattr(K, "lib"):
@@ -421,7 +423,11 @@ class GANSynth(object):
         real rows only.  Needs the network in two pieces (networks.PGGAN.discriminator_trunk / _tail) and the one-launch loss.  (An
         activation tap still sees two passes: functional.tap_pair.)"""
         owner = getattr(self.discriminator, "__self__", None)
-        return (_BATCH_D_TAIL and fused and images.is_cuda and hasattr(owner, "discriminator_trunk")
+        # With forked branches the two passes stay apart instead: the whole fake pass (G(z), D's trunk AND tail, and through autograd their
+        # backward) runs on the branch beside the real pass with its R1 passes -- twice the few-block launches of the tail, on two streams
+        # that fill each other's gaps: 5.74 -> 5.42 ms against the batched tail (same box).  `batch_d_tail` overrides (tests).
+        want = self.batch_d_tail if self.batch_d_tail is not None else (_BATCH_D_TAIL and not self.fork)
+        return (want and fused and images.is_cuda and hasattr(owner, "discriminator_trunk")
                 and getattr(self.discriminator, "__func__", None) is getattr(type(owner), "discriminator", None)
                 and hasattr(kernels.get(), "lib"))
 
@@ -452,11 +458,12 @@ class GANSynth(object):
             return self._d_losses_b_batched(part_a, latents, labels)
         real_part, penalty = part_a
         fake_weight = hp.get("fake_gradient_penalty_weight", 0.0)
-        with self._branch("d_root"), torch.no_grad():  # var_list is the discriminator's only: no generator backward (models.py:86-89)
-            fake_images = self.generator(latents, labels)
-        if fake_weight:   # tf.gradients(fake_logits, [fake_images]) (models.py:51): the images are the point of differentiation
-            fake_images = fake_images.detach().requires_grad_(True)
-        _, fake_logits = self.discriminator(fake_images, labels)
+        with self._branch("d_root"):   # the whole fake pass beside the real one (its backward then runs on the branch as well)
+            with torch.no_grad():  # var_list is the discriminator's only: no generator backward (models.py:86-89)
+                fake_images = self.generator(latents, labels)
+            if fake_weight:   # tf.gradients(fake_logits, [fake_images]) (models.py:51): the images are the point of differentiation
+                fake_images = fake_images.detach().requires_grad_(True)
+            _, fake_logits = self.discriminator(fake_images, labels)
         if fused:
             return F.gan_d_loss(real_part, fake_logits, labels, penalty, hp.real_gradient_penalty_weight or 1.0)
         fake_logits = self._label_logits(fake_logits, labels)

@@ -29,8 +29,8 @@ for mode in ("plain", "forked", "forked2", "nomark", "nomark2", "eager", "eager2
     torch.cuda.synchronize()
     out[mode] = res
     del model
-for a, b in (("forked", "forked2"), ("plain", "forked"), ("nomark", "nomark2"), ("plain", "nomark"), ("eager", "eager2"), ("plain", "eager")):
-    for run in ("d0", "g0"):
+for a, b in (("forked", "forked2"), ("nomark", "nomark2"), ("forked", "nomark"), ("eager", "eager2"), ("forked", "eager")):
+    for run in ("d0", "g0", "d1", "g1"):
         bad = []
         for k in out[a][run]:
             x, y = out[a][run][k], out[b][run][k]

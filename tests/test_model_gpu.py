@@ -516,13 +516,9 @@ def test_discriminator_tail_over_real_and_fake_as_one_batch(gpu_store, full, dty
         lat, lab, real = R.synthetic_batch(8, rank=0, image_shape=shape)
         c = lambda t: cuda(t).to(dtype)
         model._build(c(lat), c(lab))
-        was = models._BATCH_D_TAIL
-        models._BATCH_D_TAIL = batched
-        try:
-            assert model._batched_tail(True, c(real)) == batched
-            loss = float(model.discriminator_step(c(lat), c(lab), c(real)))
-        finally:
-            models._BATCH_D_TAIL = was
+        model.batch_d_tail = batched   # (default: batched unless the runs fork, models.GANSynth._batched_tail)
+        assert model._batched_tail(True, c(real)) == batched
+        loss = float(model.discriminator_step(c(lat), c(lab), c(real)))
         out[batched] = (loss, {k: p.grad.clone() for k, p in model.d_params.named.items()})
     tol = 1e-5 if dtype == torch.float32 else 2e-2
     assert abs(out[True][0] - out[False][0]) <= (1e-6 if dtype == torch.float32 else 2e-3) * max(1.0, abs(out[False][0])), (out[True][0], out[False][0])
@@ -838,7 +834,7 @@ def test_distributed_step_on_rccl_world_size_1():
 @pytest.mark.parametrize("level,full,dtype", [(1.0, False, torch.float32), (0.6, False, torch.float32), (1.0, True, torch.bfloat16)])
 def test_forked_branches_change_nothing_but_the_schedule(gpu_store, level, full, dtype):
     """models.GANSynth._branch: inside a run's hipGraph the discriminator's pass over G(z) (forward, and through autograd its backward) runs
-    beside the generator's mode-seeking passes, the no-grad G(z) of the discriminator run beside the real batch's trunk, and the weight
+    beside the generator's mode-seeking passes, the whole fake pass of the discriminator run beside the real one with its R1 passes, and the weight
     gradients of the full-chip levels beside the few-block chain of the backward below them (kernels.early_flush_rule) -- on a forked
     branch of the graph.  The host-side launch order is the same with and without branches, so losses and parameters after three iterations
     are the same bit for bit (reduced size fully grown / fade-in, and BASELINE.json configs[1] itself: full size, bf16, batch 8); the same
@@ -855,6 +851,7 @@ def test_forked_branches_change_nothing_but_the_schedule(gpu_store, level, full,
         model.fork = mode != "plain"
         model.fork_eager = mode == "forked-eager"
         model.early_flush_always = True   # (the plain schedule contracts the large layers at the same points of its launch sequence, in place)
+        model.batch_d_tail = False        # (and keeps the real and the fake pass of the discriminator run apart, as the forked one does)
         gp, dp = opg.init_params(seed=0, bias_std=0.1)
         losses = []
         for step, (lat, lab, real) in enumerate(batches):
