@@ -21,6 +21,20 @@ a,b,_=sel[len(sel)//2]
 def short(n):
     n=re.sub(r"^void ","",n); n=re.sub(r"\(.*$","",n)
     return n.replace("gs::","").replace("__hip_bfloat16","bf16")[:100]
+# how much of the iteration runs a few-block kernel with nothing beside it (the gaps a forked branch can fill)
+ev=sorted([(s,1,g//w if w else g) for n,s,e,g,w in rows[a:b]]+[(e,-1,g//w if w else g) for n,s,e,g,w in rows[a:b]])
+alone_small=alone_big=multi=idle=0.0; running=[]; last=ev[0][0]
+for t,kind,blk in ev:
+    dt=(t-last)/1e3
+    if not running: idle+=dt
+    if running:
+        if len(running)==1 and running[0]<256: alone_small+=dt
+        elif len(running)==1: alone_big+=dt
+        else: multi+=dt
+    last=t
+    if kind==1: running.append(blk)
+    else: running.remove(blk)
+print("# kernel time: %.0f us one kernel of < 256 blocks alone, %.0f us one kernel of >= 256 blocks alone, %.0f us two or more kernels, %.0f us idle" % (alone_small, alone_big, multi, idle))
 prev=None; t0=rows[a][1]
 print("# one replayed iteration: %d kernels, %.3f ms" % (b-a,(rows[b][1]-rows[a][1])/1e6))
 for n,s,e,g,w in rows[a:b]:
