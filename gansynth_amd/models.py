@@ -218,7 +218,9 @@ class GANSynth(object):
         self._warming_up = False
         # Forked branches inside a run's hipGraph (see _branch): a run is a chain of ~370 kernels of which ~150 are few-block launches of
         # the <= 8x64 levels -- 200 CUs idle while they run -- and it holds sub-passes that do not depend on each other.
-        self.fork = _FORK
+        # (data parallel: off unless GS_FORK_DIST=1 -- a graph with parallel branches costs the host 1.8 ms per replay instead of 0.06
+        #  (scripts/replay_host_time.py), and the pipelined data-parallel iteration replays FOUR graphs: it would be launch-bound)
+        self.fork = _FORK and (not self.distributed or bool(__import__("os").environ.get("GS_FORK_DIST")))
         self.fork_eager = _FORK_EAGER
         self.fork_marks = not __import__("os").environ.get("GS_NO_FORK_MARKS")   # (debugging: branches start where they are opened)
         self._side = None
