@@ -724,6 +724,75 @@ def test_grouped_weight_gradients_match_oracle(K, E):
             close(gb, rb, rel=1e-4, name=f"grouped wgrad bias layer {li}")
 
 
+def test_large_layers_contracted_early_and_on_fewer_cus(K, E):
+    """kernels.early_flush_rule + flush_wgrad_reductions(select=) + gs_wgrad_cu_cap (what models.GANSynth._early_flush does on the forked branch
+    of a run's hipGraph): a backward pass records the pairs of large layers, then a small layer -- the rule fires ONCE, at that point, with a
+    selector for the large ones; they are contracted then (launches sized for 192 or 64 of the CUs), a second pair of one of them and everything
+    small at the final flush.  Every gradient against the CPU restatement; the cap returns its previous setting and 0 restores the whole chip."""
+    dtype = torch.bfloat16
+    # (kind, images per pair, ci, co, h, w, stride): two 32-input-channel layers (the LDS-DMA kernel), two stream-K group layers, the 1x1 colour conv; then small ones
+    large = [("conv", [8], 32, 32, 64, 256, 1), ("conv", [4, 4], 32, 64, 64, 256, 2), ("conv", [8], 64, 64, 32, 128, 1), ("conv", [4], 64, 128, 32, 128, 2), ("conv1", [8], 2, 32, 64, 256, 1)]
+    small = [("conv", [8], 128, 128, 4, 32, 1), ("conv", [8], 256, 256, 2, 16, 1)]
+    for cap in (192, 64):
+        fired, flushed = [], []
+        K.defer_wgrad_reductions()
+
+        def early(select):
+            fired.append(sorted(K._key_pixels(k) for k in K._pending))
+            was = K.lib.gs_wgrad_cu_cap(cap)
+            assert was == 0
+            flushed.append(K.flush_wgrad_reductions(select=select))
+            assert K.lib.gs_wgrad_cu_cap(0) == cap
+        K.early_flush_rule(32 * 128 // 4, early)
+        want, got = [], []
+
+        def record(li, kind, ns, ci, co, h, w, st, first=0):
+            ks = 1 if kind == "conv1" else 3
+            if first == 0:
+                got.append((torch.full((ks, ks, ci, co), 0.25, device="cuda"), torch.full((co,), -0.5, device="cuda")))
+                want.append([torch.full((ks, ks, ci, co), 0.25), torch.full((co,), -0.5)])
+            gw, gb = got[li]
+            for si, n in enumerate(ns):
+                x = rnd(n, ci, h, w, seed=1000 * cap + 100 * li + si + 7 * first).to(dtype).float()
+                gy = rnd(n, co, h // st, w // st, seed=1000 * cap + 100 * li + 50 + si + 7 * first).to(dtype).float()
+                K.conv2d_bwd_weight(dev(x, dtype), dev(gy, dtype), ks, st, 0.3, out=gw, bias_out=gb if ks == 3 else None)
+                want[li][0] += E.conv2d_bwd_weight(x, gy, ks, st, 0.3)
+                if ks == 3:
+                    want[li][1] += E.channel_sum(gy)
+        for li, l in enumerate(large):
+            record(li, *l)
+        assert not fired
+        for li, l in enumerate(small):
+            record(len(large) + li, *l)
+        assert len(fired) == 1 and flushed == [sum(len(l[1]) for l in large)], (fired, flushed)   # once, at the first small layer: every large pair so far
+        record(1, *large[1], first=1)                     # a late pair of a layer that was already contracted: adds into the same gradient at the end
+        K.early_flush_rule(0, None)
+        assert K.flush_wgrad_reductions() == sum(len(l[1]) for l in small) + len(large[1][1])
+        for li, ((gw, gb), (rw, rb)) in enumerate(zip(got, want)):
+            close(gw, rw, rel=1e-4, name=f"cap {cap}: layer {li}")
+            if gw.shape[0] == 3:
+                close(gb, rb, rel=1e-4, name=f"cap {cap}: bias {li}")
+
+
+def test_throwaway_streams(K):
+    """gs_streams_create / gs_streams_destroy (models.GANSynth._leveled_queues: the HIP runtime's pool of hardware queues is level while a graph
+    with parallel branches is instantiated): n distinct streams that take work, destroyed without error; n = 0 is fine, n < 0 is refused."""
+    import ctypes
+    n = 12
+    h = (ctypes.c_void_p * n)()
+    p = ctypes.cast(h, ctypes.POINTER(ctypes.c_void_p))
+    assert K.lib.gs_streams_create(n, p) == 0
+    assert len({int(v) for v in h}) == n and all(v for v in h)
+    x = torch.ones(1024, device="cuda")
+    with torch.cuda.stream(torch.cuda.ExternalStream(int(h[3]))):
+        y = x * 2
+    torch.cuda.synchronize()
+    assert float(y.sum()) == 2048.0
+    assert K.lib.gs_streams_destroy(n, p) == 0 and all(not v for v in h)
+    assert K.lib.gs_streams_create(0, p) == 0
+    assert K.lib.gs_streams_create(-1, p) != 0
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("case", [("conv", 2, 32, 32, 8, 128), ("conv", 8, 64, 64, 64, 512), ("conv", 2, 64, 64, 8, 64), ("conv", 2, 256, 256, 4, 32),
                                   ("convT", 2, 64, 32, 8, 64), ("convT", 8, 128, 64, 32, 256), ("convT", 2, 256, 256, 4, 32)])
