@@ -224,6 +224,11 @@ class GANSynth(object):
         self.fork_eager = _FORK_EAGER
         self.fork_marks = not __import__("os").environ.get("GS_NO_FORK_MARKS")   # (debugging: branches start where they are opened)
         self._side = None
+        self._side2 = None        # the stream of a whole sub-run beside another run (_train_step_merged)
+        self._nodes_on_side2 = False
+        self._origin = None
+        self.merge_runs = bool(__import__("os").environ.get("GS_MERGED_RUNS"))   # opt-in (measured: no gain), see _train_step_merged
+        self._merged = None
         self._marks = {}
         self._serial_run = False
         self._branched = False
@@ -285,6 +290,21 @@ class GANSynth(object):
             ev.record()
             self._marks[tag] = ev
 
+    def _second_stream(self, which, avoid):
+        """A pooled stream for a branch that is none of `avoid` (torch.cuda.Stream() hands out 32 pooled streams round-robin: after enough
+        captures -- every one takes a warm-up stream -- the next one IS the stream being captured: a branch that waits for itself)."""
+        cur = getattr(self, which)
+        taken = {a.cuda_stream for a in avoid if a is not None}
+        if cur is None or cur.device != avoid[0].device or cur.cuda_stream in taken:
+            for _ in range(64):
+                cur = torch.cuda.Stream(device=avoid[0].device)
+                if cur.cuda_stream not in taken:
+                    break
+            else:
+                raise RuntimeError("no further stream for the forked branches of a captured run")
+            setattr(self, which, cur)
+        return cur
+
     @contextlib.contextmanager
     def _branch(self, tag=None, join=True):
         """`with self._branch(tag):` -- the launches inside go on the side stream, which starts at the mark `tag` (or here) and which the
@@ -294,16 +314,7 @@ class GANSynth(object):
             yield
             return
         main = torch.cuda.current_stream()
-        if self._side is None or self._side.device != main.device or self._side.cuda_stream == main.cuda_stream:
-            # torch.cuda.Stream() hands out 32 pooled streams round-robin: after enough captures (every one takes a warm-up stream) the next
-            # one IS the stream being captured -- a branch that waits for itself, and a hipGraph that crashed at replay (seen once the whole
-            # GPU suite ran in one process).  Take the next one that is not.
-            for _ in range(64):
-                self._side = torch.cuda.Stream(device=main.device)
-                if self._side.cuda_stream != main.cuda_stream:
-                    break
-            else:
-                raise RuntimeError("no second stream for the forked branches of a captured run")
+        self._second_stream("_side", [main, self._side2])
         side = self._side
         if ev is not None:
             side.wait_event(ev)
@@ -326,8 +337,18 @@ class GANSynth(object):
         if self._early_in_run > EARLY_FLUSH_MAX:   # (the pairs stay pending: contracted with everything else at the end of the run)
             return
         was = K.lib.gs_wgrad_cu_cap(EARLY_FLUSH_CUS) if hasattr(K, "lib") else 0   # (the chain beside it needs somewhere to land)
-        on_branch = self._side is not None and torch.cuda.is_available() and torch.cuda.current_stream().cuda_stream == self._side.cuda_stream
+        cur = torch.cuda.current_stream().cuda_stream if torch.cuda.is_available() else None
+        on_branch = self._side is not None and cur == self._side.cuda_stream
+        # A node of the merged iteration's generator part runs on ITS stream: the contraction then goes to the run's own stream (idle while the
+        # backward walks that one), never to the other branch -- two non-origin streams of a capture that wait on each other's events become each
+        # other's parent in hip::Stream's bookkeeping and hip::Stream::EndCapture recurses until the stack runs out (ROCm 7.0.2).
+        on_side2 = self._side2 is not None and cur == self._side2.cuda_stream and self._origin is not None and self._forking()
         try:
+            if on_side2:
+                self._origin.wait_stream(self._side2)
+                with torch.cuda.stream(self._origin):
+                    K.flush_wgrad_reductions(select=select)
+                return
             with (contextlib.nullcontext() if on_branch else self._branch(join=False)):   # (a node of the branch itself: in place)
                 K.flush_wgrad_reductions(select=select)
         finally:
@@ -600,6 +621,7 @@ class GANSynth(object):
         """The rest of the run: losses, backward into the flat gradient buffer; returns the (detached) mean loss."""
         fused = self._fused_losses()
         self._branched = False
+        self._origin = torch.cuda.current_stream() if torch.cuda.is_available() else None   # (the stream this run is issued -- or captured -- on)
         losses = self._d_losses_b(part_a, *inputs, fused=fused) if which == "d" else self._g_losses_b(part_a, *inputs, fused=fused)   # (latents, labels) | (labels,)
         loss = losses if losses.dim() == 0 else losses.mean()   # (the fused loss kernels return the mean itself)
         K = kernels.get()
@@ -641,6 +663,8 @@ class GANSynth(object):
         if self._branched:   # (every branch was joined where it closed and autograd joins the streams it used; a branch left open would fail the capture)
             self._branched = False
             torch.cuda.current_stream().wait_stream(self._side)
+        if self._nodes_on_side2 and self._forking():   # (merged iteration: this run's own-network nodes ran -- and accumulated -- on that stream)
+            torch.cuda.current_stream().wait_stream(self._side2)
         if self.distributed and self._comm is not None and self._graph_allreduce and self._capturing() and not getattr(self, "_pipe_capture", False):
             # Same-stream RCCL is capturable: the all-reduce of this run's flat gradient becomes the LAST NODE of the run's hipGraph, so
             # a replayed run hands over reduced gradients and no eager collective launch sits between the replay and the update.
@@ -1096,6 +1120,107 @@ class GANSynth(object):
         self.discriminator_loss, self.generator_loss = D["loss"], G["loss"]
         return D["loss"], G["loss"]
 
+    # ------------------------------------------------------------------- merged iteration
+    # One GPU, graphs with branches: part A of the GENERATOR run (G(z) and the mode-seeking first-order pass: its own network only, whose
+    # parameters the discriminator run does not touch) is captured INSIDE the discriminator run's graph, on a stream of its own from the
+    # graph's root -- the discriminator run's second half is one stream wide (the fake pass and the early weight gradients are done, the R1
+    # double-backward, the real pass's backward and the final contraction remain), and the generator's few-block levels fill from it and
+    # into it.  Two graphs per iteration as before:   X = { D run  ||  G.A }   update D   Y = { G.B }   update G.
+    # MEASURED AND NOT THE DEFAULT (GS_MERGED_RUNS=1 / merge_runs): 5.19-5.23 against 5.22-5.24 ms on one box -- what part A gains beside the
+    # discriminator run, part B loses: its D(G(z)) forward no longer has the first-order pass beside it.  Kept as a tested schedule.
+    # The generator's own-network nodes were created on that stream, so autograd runs their backward there in Y as well (joined at the
+    # end of the run, _part_b).
+    def _merged_ok(self):
+        return (self.merge_runs and self.fork and self._graphable() and not self.distributed and self._fused_losses()
+                and hasattr(kernels.get(), "lib"))
+
+    def _capture_merged(self, d_inputs, g_inputs):
+        K = kernels.get()
+        owner = getattr(self.generator, "__self__", None)
+        _, fade = self._regime()
+        sd = [t.detach().clone() for t in d_inputs]
+        sg = [t.detach().clone() for t in g_inputs]
+        owner.fade_weight = self._lerp if fade is not None else None   # the networks read the fade weight from the device table
+        try:
+            warm = torch.cuda.Stream()
+            warm.wait_stream(torch.cuda.current_stream())
+            self._warming_up = True
+            try:
+                with torch.cuda.stream(warm):  # one eager pass on a side stream (allocator / lazy-init warm-up)
+                    self._forward_backward("d", *sd)
+                    self._forward_backward("g", *sg)
+            finally:
+                self._warming_up = False
+            torch.cuda.current_stream().wait_stream(warm)
+            if not self.keep_gradients:   # the graphs hold no fill: they rely on the zeroing optimizer steps (see _run)
+                for params in (self.d_params, self.g_params):
+                    params.grad.zero_()
+                    params.grad_clean = True
+            K.refresh_weights()   # (see _run: the captured graphs hold no re-layout launches)
+            gx = torch.cuda.CUDAGraph()
+            with _quiet_gc(), self._leveled_queues(), self._stream_guard(), torch.cuda.graph(gx):
+                main = torch.cuda.current_stream()
+                side2 = self._second_stream("_side2", [main, self._side])
+                side2.wait_stream(main)                      # fork at the root of the graph ...
+                with torch.cuda.stream(side2):
+                    g_part_a = self._part_a("g", *sg)
+                d_loss = self._forward_backward("d", *sd)
+                main.wait_stream(side2)                      # ... join at its end
+            gy = torch.cuda.CUDAGraph()
+            with _quiet_gc(), self._leveled_queues(), self._stream_guard(), torch.cuda.graph(gy, pool=gx.pool()):
+                self.g_params.requires_grad_(True)           # (the discriminator run in between armed the other network)
+                self.d_params.requires_grad_(False)
+                # the generator's nodes will run on their stream again (autograd): it joins THIS capture here, from the root, as a child of the
+                # capturing stream -- joining later through an event of the other branch (the discriminator's gradient arrives from there)
+                # made the two branches each other's parent and hip::Stream::EndCapture recursed until the stack ran out
+                self._side2.wait_stream(torch.cuda.current_stream())
+                self._nodes_on_side2 = True
+                try:
+                    g_loss = self._part_b("g", g_part_a, sg[1])
+                finally:
+                    self._nodes_on_side2 = False
+        finally:
+            owner.fade_weight = None
+        return {"x": gx, "y": gy, "sd": sd, "sg": sg, "d_loss": d_loss, "g_loss": g_loss, "keep": self.keep_gradients,
+                "consts": F.constants_snapshot()}
+
+    def _train_step_merged(self, d_latents, d_labels, real_images, g_latents, g_labels):
+        hp = self.hyper_params
+        self._join_updates()
+        head, fade = self._regime()
+        key = (head, fade is None, self.keep_gradients)
+        if fade is not None:
+            if self._lerp is None:
+                self._lerp = F.DeviceLerp(self.g_params.flat.device)
+            self._lerp.set(fade)   # (stream-ordered before the replays below)
+        d_in, g_in = (d_latents, d_labels, real_images), (g_latents, g_labels)
+        M = self._merged
+        if (M is None or M["key"] != key
+                or any(a.shape != b.shape or a.dtype != b.dtype for a, b in zip(M["sd"] + M["sg"], d_in + g_in))):
+            if M is not None and M["key"][:2] != key[:2]:
+                F.drop_constants()   # (a new growing regime: see _run)
+            self._graphs.clear()
+            self._merged = None
+            M = self._capture_merged(d_in, g_in)
+            M["key"] = key
+            self._merged = M
+        _copy_inputs(M["sd"] + M["sg"], list(d_in) + list(g_in))
+
+        def armed(params):   # a no-fill graph is about to accumulate into this buffer: it must be clean (see _run)
+            if not self.keep_gradients:
+                if not params.grad_clean:
+                    params.grad.zero_()
+                params.grad_clean = False
+        armed(self.d_params)
+        M["x"].replay()
+        self._apply(self.d_params, hp.discriminator_learning_rate, hp.discriminator_beta1, hp.discriminator_beta2)
+        armed(self.g_params)
+        M["y"].replay()
+        self._apply(self.g_params, hp.generator_learning_rate, hp.generator_beta1, hp.generator_beta2)
+        self.global_step += 1  # models.py:84
+        self.discriminator_loss, self.generator_loss = M["d_loss"], M["g_loss"]
+        return M["d_loss"], M["g_loss"]
+
     def _next_inputs(self):
         """One iteration's inputs (models.py:191-192: a fresh batch for each of the two runs).  StopIteration = the input ran dry."""
         if self._peeked is not None:
@@ -1113,6 +1238,8 @@ class GANSynth(object):
         self._ensure_built(d_latents, labels)
         if self._pipelined_ok():
             return self._train_step_pipelined(d_latents, labels, real_images, g_latents, g_labels)
+        if self._merged_ok():
+            return self._train_step_merged(d_latents, labels, real_images, g_latents, g_labels)
         d_loss = self.discriminator_step(d_latents, labels, real_images)
         g_loss = self.generator_step(g_latents, g_labels)
         return d_loss, g_loss

@@ -877,6 +877,53 @@ def test_forked_branches_change_nothing_but_the_schedule(gpu_store, level, full,
     assert all(same), same
 
 
+@pytest.mark.parametrize("level,full,dtype", [(1.0, False, torch.float32), (0.6, False, torch.float32), (1.0, True, torch.bfloat16)])
+def test_generator_part_a_inside_the_discriminator_graph(gpu_store, level, full, dtype):
+    """models.GANSynth._train_step_merged (opt-in: merge_runs / GS_MERGED_RUNS=1): train_step() on one GPU with graphs captures part A of the generator run (G(z) and the mode-seeking
+    first-order pass) inside the discriminator run's graph, on a stream of its own from the graph's root.  Same launches on the same operands as
+    the two runs one after the other: losses and parameters after four iterations agree with the unmerged schedule (to the association of
+    multi-consumer gradient sums, see _same_up_to_accumulation_order; bit-identity is reported), in a fade-in regime and fully grown, reduced
+    size and configs[1] itself."""
+    from gansynth_amd import variables
+    out = {}
+    n = 8 if full else 4
+    res = (2, 128, 1024) if full else (2, 16, 128)
+    batches = [R.synthetic_batch(n, rank=i, image_shape=res) for i in range(4)]
+    for merged in (False, True):
+        variables.set_default_store(variables.VariableStore(device="cuda"))
+        pg, opg, model = make(level, variables.default_store(), full=full, dtype=dtype)
+        model.use_graphs, model.keep_gradients = True, False
+        model.merge_runs = merged
+        cur = [0]
+
+        def real_input_fn():
+            lat, lab, real = batches[cur[0] % len(batches)]
+            return cuda(real).to(dtype), cuda(lab).to(dtype)
+
+        def fake_input_fn():
+            lat, _, _ = batches[cur[0] % len(batches)]
+            cur[0] += 1
+            return cuda(lat).to(dtype)
+        model.real_input_fn, model.fake_input_fn = real_input_fn, fake_input_fn
+        gp, dp = opg.init_params(seed=0, bias_std=0.1)
+        lat, lab, _ = batches[0]
+        model._build(cuda(lat).to(dtype), cuda(lab).to(dtype))
+        variables.default_store().load_state_dict({**gp, **dp})
+        losses = []
+        for _ in range(4):
+            d_loss, g_loss = model.train_step()
+            losses += [float(d_loss), float(g_loss)]
+        torch.cuda.synchronize()
+        assert (model._merged is not None) == merged and model.global_step == 4
+        out[merged] = (losses, model.d_params.flat.clone(), model.g_params.flat.clone())
+        del model
+    for i, (a, b) in enumerate(zip(out[False][0], out[True][0])):
+        _same_up_to_accumulation_order(a, b, f"loss {i}")
+    _same_up_to_accumulation_order(out[False][1], out[True][1], "discriminator parameters")
+    _same_up_to_accumulation_order(out[False][2], out[True][2], "generator parameters")
+    print("merged vs unmerged bit-identical (D, G):", [bool(torch.equal(out[False][k], out[True][k])) for k in (1, 2)])
+
+
 def _dp_trainer(level, batches, full=False, dtype=torch.float32, distributed=True, graphs=True, keep=True):
     from gansynth_amd import variables
     variables.set_default_store(variables.VariableStore(device="cuda"))
