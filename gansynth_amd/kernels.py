@@ -8,6 +8,7 @@ libgansynth_hip.so -- nothing here computes with torch ops.
 The autograd layer (functional.py) talks to the module-level `K` object; tests may swap it for
 an emulation to check the autograd algebra on CPU, the product never does.
 """
+import contextlib
 import ctypes
 import os
 
@@ -177,6 +178,29 @@ class HipKernels(object):
             e = self._wcache[k]
             e[1] = (e[4][2], e[2]._version)
         return len(stale)
+
+    # ------------------------------------------------- accumulate targets on more than one stream
+    @contextlib.contextmanager
+    def _adds_into(self, *targets):
+        """Around a launch that ADDS into `targets` (a variable's gradient) right away.  Inside stream_guard() two passes on two streams may
+        add into the same variable -- the real and the fake pass of a discriminator run: the launch waits for the last one that touched the
+        target from the other stream and leaves its own event behind (the host's issue order, which is also the order the one-stream
+        schedule uses).  Calls that only RECORD a deferred job, or leave partial rows for the batched fold, do not come through here: the
+        R1 double-backward's first recorded layer must not wait for the end of the fake pass's backward."""
+        if not self._guarding:
+            yield
+            return
+        stream = torch.cuda.current_stream()
+        targets = [t for t in targets if isinstance(t, torch.Tensor) and t.is_cuda]
+        for t in targets:
+            prev = self._last_writer.get(t.data_ptr())
+            if prev is not None and prev[0] != stream.cuda_stream:
+                stream.wait_event(prev[1])
+        yield
+        for t in targets:
+            ev = torch.cuda.Event()
+            ev.record(stream)
+            self._last_writer[t.data_ptr()] = (stream.cuda_stream, ev)
 
     # ----------------------------------------------------------- deferred weight gradients
     def defer_wgrad_reductions(self):
@@ -493,9 +517,10 @@ class HipKernels(object):
         assert out is None or out.is_contiguous(), "a channel-slice target needs deferred gradients (wgrad_slice_target_ok)"
         nb = self.lib.gs_conv2d_workspace_bytes(_lib.CONV_BWD_WEIGHT, n, h, wd, ci, co, ksize, stride, _dt(x))
         ws = _ws(nb, x.device)
-        _lib.check(self.lib.gs_conv2d_bwd_weight_bias(x.data_ptr(), gy.data_ptr(), gw.data_ptr(), None if bias_out is None else bias_out.data_ptr(),
-                                                      n, h, wd, ci, co, ksize, stride, float(alpha), 0 if out is None else 1, _dt(x),
-                                                      ws.data_ptr(), ws.numel(), _stream()), "gs_conv2d_bwd_weight_bias")
+        with self._adds_into(out, bias_out):
+            _lib.check(self.lib.gs_conv2d_bwd_weight_bias(x.data_ptr(), gy.data_ptr(), gw.data_ptr(), None if bias_out is None else bias_out.data_ptr(),
+                                                          n, h, wd, ci, co, ksize, stride, float(alpha), 0 if out is None else 1, _dt(x),
+                                                          ws.data_ptr(), ws.numel(), _stream()), "gs_conv2d_bwd_weight_bias")
         return gw
 
     def conv2d_transpose_fwd(self, x, w, alpha):
@@ -539,9 +564,10 @@ class HipKernels(object):
             return gw
         nb = self.lib.gs_conv2d_transpose_s2_workspace_bytes(_lib.CONV_BWD_WEIGHT, n, h, wd, ci, co, _dt(x))
         ws = _ws(nb, x.device)
-        _lib.check(self.lib.gs_conv2d_transpose_s2_bwd_weight(x.data_ptr(), gy.data_ptr(), gw.data_ptr(), n, h, wd, ci, co, float(alpha),
-                                                              0 if out is None else 1, _dt(x), ws.data_ptr(), ws.numel(), _stream()),
-                   "gs_conv2d_transpose_s2_bwd_weight")
+        with self._adds_into(out):
+            _lib.check(self.lib.gs_conv2d_transpose_s2_bwd_weight(x.data_ptr(), gy.data_ptr(), gw.data_ptr(), n, h, wd, ci, co, float(alpha),
+                                                                  0 if out is None else 1, _dt(x), ws.data_ptr(), ws.numel(), _stream()),
+                       "gs_conv2d_transpose_s2_bwd_weight")
         return gw
 
     # ------------------------------------------------------------------------------ dense
@@ -588,8 +614,9 @@ class HipKernels(object):
         b, i = x.shape
         o = gy.shape[1]
         gw = torch.empty((i, o), dtype=torch.float32, device=x.device) if out is None else out
-        _lib.check(self.lib.gs_dense_bwd_weight(x.data_ptr(), gy.data_ptr(), gw.data_ptr(), b, i, o, float(alpha),
-                                                0 if out is None else 1, _dt(x), _stream()), "gs_dense_bwd_weight")
+        with self._adds_into(out):
+            _lib.check(self.lib.gs_dense_bwd_weight(x.data_ptr(), gy.data_ptr(), gw.data_ptr(), b, i, o, float(alpha),
+                                                    0 if out is None else 1, _dt(x), _stream()), "gs_dense_bwd_weight")
         return gw
 
     # the dense layer behind tf.layers.flatten of an NCHW activation (networks.py:185-186), fed with the channels-last activation
@@ -624,8 +651,9 @@ class HipKernels(object):
         b, c, h, wd = x.shape
         o = gy.shape[1]
         gw = torch.empty((c * h * wd, o), dtype=torch.float32, device=x.device) if out is None else out
-        _lib.check(self.lib.gs_dense_bwd_weight_nhwc(x.data_ptr(), gy.data_ptr(), gw.data_ptr(), b, c, h * wd, o, float(alpha),
-                                                     0 if out is None else 1, _dt(x), _stream()), "gs_dense_bwd_weight_nhwc")
+        with self._adds_into(out):
+            _lib.check(self.lib.gs_dense_bwd_weight_nhwc(x.data_ptr(), gy.data_ptr(), gw.data_ptr(), b, c, h * wd, o, float(alpha),
+                                                         0 if out is None else 1, _dt(x), _stream()), "gs_dense_bwd_weight_nhwc")
         return gw
 
     def embedding_fwd(self, idx, w, alpha, dtype):
@@ -713,8 +741,9 @@ class HipKernels(object):
         part = self._partial_rows(_lib.BIAS_FROM_ACT_BWD, p, c, _dt(y), out)
         ws = part if part is not None else _ws(self.lib.gs_channel_sum_workspace_bytes(p, c), y.device)
         flags = (0 if out is None else 1) | (_lib.SUM_PARTIALS if part is not None else 0)
-        _lib.check(self.lib.gs_act_bwd_bias(g.data_ptr(), y.data_ptr(), gx.data_ptr(), gb.data_ptr(), p, c, act, flags,
-                                            _dt(y), ws.data_ptr(), ws.numel() * ws.element_size(), _stream()), "gs_act_bwd_bias")
+        with self._adds_into(out if part is None else None):   # (partial rows left for the batched fold: `out` is not touched now)
+            _lib.check(self.lib.gs_act_bwd_bias(g.data_ptr(), y.data_ptr(), gx.data_ptr(), gb.data_ptr(), p, c, act, flags,
+                                                _dt(y), ws.data_ptr(), ws.numel() * ws.element_size(), _stream()), "gs_act_bwd_bias")
         return gx, gb
 
     def tanh_bwd_bwd(self, gg, g, y):
@@ -732,8 +761,9 @@ class HipKernels(object):
         part = self._partial_rows(_lib.BIAS_FROM_CHANNEL_SUM, p, c, _dt(g), out)
         ws = part if part is not None else _ws(self.lib.gs_channel_sum_workspace_bytes(p, c), g.device)
         flags = (0 if out is None else 1) | (_lib.SUM_PARTIALS if part is not None else 0)
-        _lib.check(self.lib.gs_channel_sum(g.data_ptr(), res.data_ptr(), p, c, flags, _dt(g), ws.data_ptr(), ws.numel() * ws.element_size(),
-                                           _stream()), "gs_channel_sum")
+        with self._adds_into(out if part is None else None):
+            _lib.check(self.lib.gs_channel_sum(g.data_ptr(), res.data_ptr(), p, c, flags, _dt(g), ws.data_ptr(), ws.numel() * ws.element_size(),
+                                               _stream()), "gs_channel_sum")
         return res
 
     def pixel_norm_fwd(self, x, eps):
@@ -765,9 +795,10 @@ class HipKernels(object):
             assert bias_out.dtype == torch.float32 and bias_out.is_contiguous() and bias_out.numel() == c
             part = self._partial_rows(_lib.BIAS_FROM_PIXEL_NORM_BWD, p, c, _dt(x), bias_out)
             ws = part if part is not None else _ws(self.lib.gs_pixel_norm_bwd_bias_workspace_bytes(p, c, _dt(x)), x.device)
-            _lib.check(self.lib.gs_pixel_norm_bwd_fused_bias(g.data_ptr(), x.data_ptr(), ap, gx.data_ptr(), bias_out.data_ptr(), p, c, float(eps), int(pre_act),
-                                                             int(act), 1 | (_lib.SUM_PARTIALS if part is not None else 0), _dt(x), ws.data_ptr(),
-                                                             ws.numel() * ws.element_size(), _stream()), "gs_pixel_norm_bwd_fused_bias")
+            with self._adds_into(bias_out if part is None else None):
+                _lib.check(self.lib.gs_pixel_norm_bwd_fused_bias(g.data_ptr(), x.data_ptr(), ap, gx.data_ptr(), bias_out.data_ptr(), p, c, float(eps), int(pre_act),
+                                                                 int(act), 1 | (_lib.SUM_PARTIALS if part is not None else 0), _dt(x), ws.data_ptr(),
+                                                                 ws.numel() * ws.element_size(), _stream()), "gs_pixel_norm_bwd_fused_bias")
             return gx
         _lib.check(self.lib.gs_pixel_norm_bwd_fused(g.data_ptr(), x.data_ptr(), ap, gx.data_ptr(), p, c, float(eps), int(pre_act), int(act), _dt(x),
                                                     _stream()), "gs_pixel_norm_bwd_fused")
@@ -1038,22 +1069,12 @@ class _StreamGuard(object):
     def _wrap(self, fn, name=""):
         mark = self._mark
 
-        K = self.K
-
         def wrapper(*a, **kw):
             stream = torch.cuda.current_stream()
             for v in a:
                 mark(v, stream)
             for v in kw.values():
                 mark(v, stream)
-            # `out=` / `bias_out=` are ACCUMULATED into (a variable's gradient): two passes on two streams that add into the same variable
-            # -- the real and the fake pass of a discriminator run -- must not interleave their read-modify-writes: the call waits for the
-            # last one that touched the target from the other stream, and leaves its own mark behind
-            targets = [t for t in (kw.get("out"), kw.get("bias_out")) if isinstance(t, torch.Tensor) and t.is_cuda]
-            for t in targets:
-                prev = K._last_writer.get(t.data_ptr())
-                if prev is not None and prev[0] != stream.cuda_stream:
-                    stream.wait_event(prev[1])
             rec = getattr(self.K, "_dbg_record", None)
             if rec is not None:   # (debugging: copies of every operand and result, captured with the run -- which tensor differs between two replays?)
                 ins = []
@@ -1064,10 +1085,6 @@ class _StreamGuard(object):
             keep = getattr(self.K, "_dbg_keep", None)
             if keep is not None:   # (debugging: nothing a kernel touched is freed, hence no block is reused, before the list is dropped)
                 keep.append((a, kw, out))
-            for t in targets:
-                ev = torch.cuda.Event()
-                ev.record(stream)
-                K._last_writer[t.data_ptr()] = (stream.cuda_stream, ev)
             if rec is not None:
                 outs = []
                 for i, t in enumerate(out if isinstance(out, (tuple, list)) else (out,)):
