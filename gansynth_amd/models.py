@@ -227,7 +227,7 @@ class GANSynth(object):
         self._side2 = None        # the stream of a whole sub-run beside another run (_train_step_merged)
         self._nodes_on_side2 = False
         self._origin = None
-        self.merge_runs = bool(__import__("os").environ.get("GS_MERGED_RUNS"))   # opt-in (measured: no gain), see _train_step_merged
+        self.merge_runs = not __import__("os").environ.get("GS_NO_MERGED_RUNS")   # A/B switch: see _train_step_merged
         self._merged = None
         self._marks = {}
         self._serial_run = False
@@ -1126,8 +1126,8 @@ class GANSynth(object):
     # graph's root -- the discriminator run's second half is one stream wide (the fake pass and the early weight gradients are done, the R1
     # double-backward, the real pass's backward and the final contraction remain), and the generator's few-block levels fill from it and
     # into it.  Two graphs per iteration as before:   X = { D run  ||  G.A }   update D   Y = { G.B }   update G.
-    # MEASURED AND NOT THE DEFAULT (GS_MERGED_RUNS=1 / merge_runs): 5.19-5.23 against 5.22-5.24 ms on one box -- what part A gains beside the
-    # discriminator run, part B loses: its D(G(z)) forward no longer has the first-order pass beside it.  Kept as a tested schedule.
+    # 5.13 / 5.07 -> 4.99 / 4.93 ms on one box (first measured neutral, 5.19-5.23 against 5.22-5.24: the two passes of the discriminator
+    # run were still waiting on each other at every accumulate target, kernels._adds_into).
     # The generator's own-network nodes were created on that stream, so autograd runs their backward there in Y as well (joined at the
     # end of the run, _part_b).
     def _merged_ok(self):
