@@ -37,6 +37,7 @@ _OVERLAP_REDUCE = not __import__("os").environ.get("GS_NO_OVERLAP_REDUCE")   # A
 _GRAPH_ALLREDUCE = not __import__("os").environ.get("GS_NO_GRAPH_ALLREDUCE")   # A/B switch: the gradient all-reduce as a node of the captured graph
 _FORK = not __import__("os").environ.get("GS_NO_FORK")   # A/B switch: independent sub-passes of a run on a forked branch of its hipGraph (GANSynth._branch)
 LEVEL_STREAMS = int(__import__("os").environ.get("GS_LEVEL_STREAMS", "48"))   # see GANSynth._leveled_queues
+EARLY_FLUSH_DIV = int(__import__("os").environ.get("GS_EARLY_FLUSH_DIV", "16"))   # a layer is "large" from 1/DIV of the full resolution's pixels
 EARLY_FLUSH_MAX = int(__import__("os").environ.get("GS_EARLY_FLUSH_MAX", "1"))   # early contractions per run
 EARLY_FLUSH_CUS = int(__import__("os").environ.get("GS_EARLY_FLUSH_CUS", "192"))   # see GANSynth._early_flush
 _FORK_EAGER = bool(__import__("os").environ.get("GS_FORK_EAGER"))   # tests: the same branches with eager launches (a second stream, event hops)
@@ -359,7 +360,7 @@ class GANSynth(object):
         owner = getattr(self.generator, "__self__", None)
         if owner is None or not hasattr(owner, "resolution"):
             return None
-        return max(1, int(owner.resolution(owner.max_depth).prod()) // 16)   # (the three levels at the top of the pyramid)
+        return max(1, int(owner.resolution(owner.max_depth).prod()) // EARLY_FLUSH_DIV)   # (16: the three levels at the top of the pyramid)
 
     def _stream_guard(self):
         K = kernels.get()
