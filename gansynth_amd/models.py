@@ -36,7 +36,7 @@ _PIPE_SIDE = {"0": False, "1": True}.get(__import__("os").environ.get("GS_PIPE_S
 _OVERLAP_REDUCE = not __import__("os").environ.get("GS_NO_OVERLAP_REDUCE")   # A/B switch: the all-reduce beside part A of the other run (forked graph branch)
 _GRAPH_ALLREDUCE = not __import__("os").environ.get("GS_NO_GRAPH_ALLREDUCE")   # A/B switch: the gradient all-reduce as a node of the captured graph
 _FORK = not __import__("os").environ.get("GS_NO_FORK")   # A/B switch: independent sub-passes of a run on a forked branch of its hipGraph (GANSynth._branch)
-LEVEL_STREAMS = int(__import__("os").environ.get("GS_LEVEL_STREAMS", "48"))   # see GANSynth._leveled_queues
+LEVEL_STREAMS = int(__import__("os").environ.get("GS_LEVEL_STREAMS", "128"))   # see GANSynth._leveled_queues
 EARLY_FLUSH_DIV = int(__import__("os").environ.get("GS_EARLY_FLUSH_DIV", "16"))   # a layer is "large" from 1/DIV of the full resolution's pixels
 EARLY_FLUSH_MAX = int(__import__("os").environ.get("GS_EARLY_FLUSH_MAX", "1"))   # early contractions per run
 EARLY_FLUSH_CUS = int(__import__("os").environ.get("GS_EARLY_FLUSH_CUS", "192"))   # see GANSynth._early_flush

@@ -46,7 +46,7 @@ int gs_init(void);
  * stream more than the branches need and hip::Graph::UpdateStreams, at every launch, skips those that share the LAUNCH stream's hardware
  * queue -- without a bounds check: two of them on that queue and hipGraphLaunch reads past the end of the list (segmentation fault,
  * profiles/r05_e_graph_replay_crash.txt).  Two consecutive new streams only land on one queue when it is at least two users short of
- * every other one; a few dozen throw-away streams level the pool first (each goes to the least-used queue), so the exec's streams
+ * every other one; a hundred-odd throw-away streams level the pool first (each goes to the least-used queue), so the exec's streams
  * land on different queues and at most one is skipped.  The reference has no such object (one TF session, models.py:189-194). */
 int gs_streams_create(int n, void** streams);
 int gs_streams_destroy(int n, void** streams);
