@@ -33,7 +33,11 @@ _FUSED_LOSSES = not __import__("os").environ.get("GS_NO_FUSED_LOSSES")
 _BATCH_D_TAIL = not __import__("os").environ.get("GS_NO_D_TAIL_BATCH")   # A/B switch: real + fake through the discriminator's tail as one batch
 _PIPELINE = bool(__import__("os").environ.get("GS_PIPELINE"))   # opt-in, see GANSynth.pipeline
 _PIPE_SIDE = {"0": False, "1": True}.get(__import__("os").environ.get("GS_PIPE_SIDE", ""))
-_OVERLAP_REDUCE = not __import__("os").environ.get("GS_NO_OVERLAP_REDUCE")   # A/B switch: the all-reduce beside part A of the other run (forked graph branch)
+# The all-reduce beside part A of the other run (forked graph branch, four graphs per iteration: round 4's default) is opt-in since round 5:
+# the two-graph form with the collective as the LAST node of each run's graph keeps the compute branches of section 6.5 (a four-graph
+# iteration with branches would be launch-bound) -- 5.16 against 5.68 ms at world size 1, i.e. the overlapped form has to hide more than
+# half a millisecond of all-reduce to break even.
+_OVERLAP_REDUCE = bool(__import__("os").environ.get("GS_OVERLAP_REDUCE")) and not __import__("os").environ.get("GS_NO_OVERLAP_REDUCE")
 _GRAPH_ALLREDUCE = not __import__("os").environ.get("GS_NO_GRAPH_ALLREDUCE")   # A/B switch: the gradient all-reduce as a node of the captured graph
 _FORK = not __import__("os").environ.get("GS_NO_FORK")   # A/B switch: independent sub-passes of a run on a forked branch of its hipGraph (GANSynth._branch)
 LEVEL_STREAMS = int(__import__("os").environ.get("GS_LEVEL_STREAMS", "128"))   # see GANSynth._leveled_queues
@@ -219,9 +223,10 @@ class GANSynth(object):
         self._warming_up = False
         # Forked branches inside a run's hipGraph (see _branch): a run is a chain of ~370 kernels of which ~150 are few-block launches of
         # the <= 8x64 levels -- 200 CUs idle while they run -- and it holds sub-passes that do not depend on each other.
-        # (data parallel: off unless GS_FORK_DIST=1 -- a graph with parallel branches costs the host 1.8 ms per replay instead of 0.06
-        #  (scripts/replay_host_time.py), and the pipelined data-parallel iteration replays FOUR graphs: it would be launch-bound)
-        self.fork = _FORK and (not self.distributed or bool(__import__("os").environ.get("GS_FORK_DIST")))
+        # (data parallel: off in the PIPELINED iteration unless GS_FORK_DIST=1 -- a graph with parallel branches costs the host 1.8 ms per
+        #  replay instead of 0.06 (scripts/replay_host_time.py), and that iteration replays FOUR graphs: it would be launch-bound; decided
+        #  in _build, when the transport is known.  The two-graph data-parallel forms keep their branches.)
+        self.fork = _FORK
         self.fork_eager = _FORK_EAGER
         self.fork_marks = not __import__("os").environ.get("GS_NO_FORK_MARKS")   # (debugging: branches start where they are opened)
         self._side = None
@@ -400,6 +405,11 @@ class GANSynth(object):
                 self.bucket_bytes = (64 << 20) if self._comm is not None else (8 << 20)
             self.g_params.make_buckets(self.bucket_bytes // 4, reverse=True)
             self.d_params.make_buckets(self.bucket_bytes // 4, reverse=False)
+            if (self._overlap_in_graph() or self._comm is None) and not __import__("os").environ.get("GS_FORK_DIST"):
+                # the pipelined four-graph iteration (see __init__); and torch.distributed's collectives, which run on THEIR stream beside the
+                # launches that follow them: with the passes apart and the early contraction the world-1 step was no longer bit-identical to
+                # the non-distributed one there (5e-7 on the parameters, cause not found) -- that transport keeps round 4's schedule
+                self.fork = False
         K = kernels.get()
         if hasattr(K, "register_param_buffer"):  # lets the conv kernels keep their re-laid weight operands between calls
             K.register_param_buffer(self.g_params.flat)
