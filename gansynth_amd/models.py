@@ -275,9 +275,9 @@ class GANSynth(object):
         handles = (ctypes.c_void_p * LEVEL_STREAMS)()
         ptr = ctypes.cast(handles, ctypes.POINTER(ctypes.c_void_p))
         t0 = __import__("time").perf_counter()
-        _lib.check(K.lib.gs_streams_create(LEVEL_STREAMS, ptr), "gs_streams_create")
-        self.level_seconds = getattr(self, "level_seconds", 0.0) + __import__("time").perf_counter() - t0
         try:
+            _lib.check(K.lib.gs_streams_create(LEVEL_STREAMS, ptr), "gs_streams_create")   # (on failure the ones made so far are in `handles`)
+            self.level_seconds = getattr(self, "level_seconds", 0.0) + __import__("time").perf_counter() - t0
             yield
         finally:
             _lib.check(K.lib.gs_streams_destroy(LEVEL_STREAMS, ptr), "gs_streams_destroy")
