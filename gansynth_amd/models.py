@@ -712,6 +712,7 @@ class GANSynth(object):
         # serial path, the pairs of the pipelined step): all of them go, so that every run is captured again without a collective.
         torch.cuda.synchronize()
         self._graphs.clear()
+        self._merged = None
         if self._pipe is not None:
             self._pipe.pop("d", None), self._pipe.pop("g", None)
             self._pipe["key"] = None
@@ -1142,8 +1143,10 @@ class GANSynth(object):
     # The generator's own-network nodes were created on that stream, so autograd runs their backward there in Y as well (joined at the
     # end of the run, _part_b).
     def _merged_ok(self):
-        return (self.merge_runs and self.fork and self._graphable() and not self.distributed and self._fused_losses()
-                and hasattr(kernels.get(), "lib"))
+        # (data parallel: with the gradient all-reduce as the last node of each of the two graphs -- own communicator, in-graph collectives
+        #  not refused, not the four-graph overlapped form)
+        dp_ok = not self.distributed or (self._comm is not None and self._graph_allreduce and not self._overlap_in_graph())
+        return (self.merge_runs and self.fork and self._graphable() and dp_ok and self._fused_losses() and hasattr(kernels.get(), "lib"))
 
     def _capture_merged(self, d_inputs, g_inputs):
         K = kernels.get()
@@ -1152,6 +1155,8 @@ class GANSynth(object):
         sd = [t.detach().clone() for t in d_inputs]
         sg = [t.detach().clone() for t in g_inputs]
         owner.fade_weight = self._lerp if fade is not None else None   # the networks read the fade weight from the device table
+        with_collective = self.distributed and self._comm is not None and self._graph_allreduce
+        error, reduced = None, [False, False]
         try:
             warm = torch.cuda.Stream()
             warm.wait_stream(torch.cuda.current_stream())
@@ -1160,6 +1165,9 @@ class GANSynth(object):
                 with torch.cuda.stream(warm):  # one eager pass on a side stream (allocator / lazy-init warm-up)
                     self._forward_backward("d", *sd)
                     self._forward_backward("g", *sg)
+                    if with_collective:   # RCCL sets up its channels on the first collective of a kind: not capturable (dead values here)
+                        self._reduce(self.d_params)
+                        self._reduce(self.g_params)
             finally:
                 self._warming_up = False
             torch.cuda.current_stream().wait_stream(warm)
@@ -1168,31 +1176,46 @@ class GANSynth(object):
                     params.grad.zero_()
                     params.grad_clean = True
             K.refresh_weights()   # (see _run: the captured graphs hold no re-layout launches)
-            gx = torch.cuda.CUDAGraph()
-            with _quiet_gc(), self._leveled_queues(), self._stream_guard(), torch.cuda.graph(gx):
-                main = torch.cuda.current_stream()
-                side2 = self._second_stream("_side2", [main, self._side])
-                side2.wait_stream(main)                      # fork at the root of the graph ...
-                with torch.cuda.stream(side2):
-                    g_part_a = self._part_a("g", *sg)
-                d_loss = self._forward_backward("d", *sd)
-                main.wait_stream(side2)                      # ... join at its end
-            gy = torch.cuda.CUDAGraph()
-            with _quiet_gc(), self._leveled_queues(), self._stream_guard(), torch.cuda.graph(gy, pool=gx.pool()):
-                self.g_params.requires_grad_(True)           # (the discriminator run in between armed the other network)
-                self.d_params.requires_grad_(False)
-                # the generator's nodes will run on their stream again (autograd): it joins THIS capture here, from the root, as a child of the
-                # capturing stream -- joining later through an event of the other branch (the discriminator's gradient arrives from there)
-                # made the two branches each other's parent and hip::Stream::EndCapture recursed until the stack ran out
-                self._side2.wait_stream(torch.cuda.current_stream())
-                self._nodes_on_side2 = True
-                try:
-                    g_loss = self._part_b("g", g_part_a, sg[1])
-                finally:
-                    self._nodes_on_side2 = False
+            try:
+                gx = torch.cuda.CUDAGraph()
+                self._captured_reduce = False
+                with _quiet_gc(), self._leveled_queues(), self._stream_guard(), torch.cuda.graph(gx, **_capture_mode(with_collective, self.fork)):
+                    main = torch.cuda.current_stream()
+                    side2 = self._second_stream("_side2", [main, self._side])
+                    side2.wait_stream(main)                      # fork at the root of the graph ...
+                    with torch.cuda.stream(side2):
+                        g_part_a = self._part_a("g", *sg)
+                    d_loss = self._forward_backward("d", *sd)    # (data parallel: ends with the all-reduce of the discriminator's gradient, _part_b)
+                    main.wait_stream(side2)                      # ... join at its end
+                reduced[0] = self._captured_reduce
+                gy = torch.cuda.CUDAGraph()
+                self._captured_reduce = False
+                with _quiet_gc(), self._leveled_queues(), self._stream_guard(), torch.cuda.graph(gy, pool=gx.pool(), **_capture_mode(with_collective, self.fork)):
+                    self.g_params.requires_grad_(True)           # (the discriminator run in between armed the other network)
+                    self.d_params.requires_grad_(False)
+                    # the generator's nodes will run on their stream again (autograd): it joins THIS capture here, from the root, as a child of
+                    # the capturing stream -- joining later through an event of the other branch (the discriminator's gradient arrives from
+                    # there) made the two branches each other's parent and hip::Stream::EndCapture recursed until the stack ran out
+                    self._side2.wait_stream(torch.cuda.current_stream())
+                    self._nodes_on_side2 = True
+                    try:
+                        g_loss = self._part_b("g", g_part_a, sg[1])
+                    finally:
+                        self._nodes_on_side2 = False
+                reduced[1] = self._captured_reduce
+            except RuntimeError as e:
+                if not with_collective:
+                    raise
+                error = e
+            if with_collective and not self._agree(error is None):
+                # the collective would not go into a graph on SOME rank: every rank (agreed) drops the in-graph form; the iteration then runs as
+                # two plain runs with the all-reduce eagerly behind each replay (_run)
+                self._give_up_graph_collectives("d", error)
+                self._abandon_capture("g")
+                return None
         finally:
             owner.fade_weight = None
-        return {"x": gx, "y": gy, "sd": sd, "sg": sg, "d_loss": d_loss, "g_loss": g_loss, "keep": self.keep_gradients,
+        return {"x": gx, "y": gy, "sd": sd, "sg": sg, "d_loss": d_loss, "g_loss": g_loss, "keep": self.keep_gradients, "reduced": reduced,
                 "consts": F.constants_snapshot()}
 
     def _train_step_merged(self, d_latents, d_labels, real_images, g_latents, g_labels):
@@ -1213,6 +1236,10 @@ class GANSynth(object):
             self._graphs.clear()
             self._merged = None
             M = self._capture_merged(d_in, g_in)
+            if M is None:   # (data parallel: the collectives were refused by the capture on some rank)
+                d_loss = self.discriminator_step(d_latents, d_labels, real_images)
+                g_loss = self.generator_step(g_latents, g_labels)
+                return d_loss, g_loss
             M["key"] = key
             self._merged = M
         _copy_inputs(M["sd"] + M["sg"], list(d_in) + list(g_in))
@@ -1224,10 +1251,10 @@ class GANSynth(object):
                 params.grad_clean = False
         armed(self.d_params)
         M["x"].replay()
-        self._apply(self.d_params, hp.discriminator_learning_rate, hp.discriminator_beta1, hp.discriminator_beta2)
+        self._apply(self.d_params, hp.discriminator_learning_rate, hp.discriminator_beta1, hp.discriminator_beta2, reduced=M["reduced"][0])
         armed(self.g_params)
         M["y"].replay()
-        self._apply(self.g_params, hp.generator_learning_rate, hp.generator_beta1, hp.generator_beta2)
+        self._apply(self.g_params, hp.generator_learning_rate, hp.generator_beta1, hp.generator_beta2, reduced=M["reduced"][1])
         self.global_step += 1  # models.py:84
         self.discriminator_loss, self.generator_loss = M["d_loss"], M["g_loss"]
         return M["d_loss"], M["g_loss"]

@@ -11,8 +11,10 @@ pg, opg, model = make(1.0, variables.default_store(), full=True, dtype=dtype)
 model.use_graphs, model.keep_gradients = True, False
 lat, lab, real = [cuda(t).to(dtype) for t in R.synthetic_batch(8, rank=0, image_shape=(2, 128, 1024))]
 model._build(lat, lab)
+model.real_input_fn, model.fake_input_fn = (lambda: (real, lab)), (lambda: lat)
+step = (lambda: model.train_step()) if os.environ.get("RH_TRAIN_STEP", "1") != "0" else (lambda: (model.discriminator_step(lat, lab, real), model.generator_step(lat, lab)))
 for _ in range(3):
-    model.discriminator_step(lat, lab, real); model.generator_step(lat, lab)
+    step()
 torch.cuda.synchronize()
 orig = torch.cuda.CUDAGraph.replay
 host = []
@@ -22,9 +24,9 @@ torch.cuda.CUDAGraph.replay = timed
 N = 30
 t0 = time.perf_counter()
 for _ in range(N):
-    model.discriminator_step(lat, lab, real); model.generator_step(lat, lab)
+    step()
 t_host = time.perf_counter() - t0
 torch.cuda.synchronize()
 t_all = time.perf_counter() - t0
-print("fork" if model.fork else "plain", ": wall %.3f ms per iteration, host loop %.3f ms per iteration, graph.replay() host time %.3f ms mean (%d calls), max %.3f" %
+print("fork" if model.fork else "plain", "merged" if model._merged is not None else "two runs", ": wall %.3f ms per iteration, host loop %.3f ms per iteration, graph.replay() host time %.3f ms mean (%d calls), max %.3f" %
       (t_all / N * 1e3, t_host / N * 1e3, sum(host) / len(host) * 1e3, len(host), max(host) * 1e3))
