@@ -63,6 +63,24 @@ def _capture_mode(with_collective, forked=False):
     return {"capture_error_mode": "relaxed" if forked else "thread_local"}
 
 
+def _hw_queues_allow_branches():
+    """Graphs with parallel branches need the HIP runtime's default of four hardware queues (GPU_MAX_HW_QUEUES): with two, the streams an
+    executable graph makes for its branches cannot all miss the launch stream's queue and hip::Graph::UpdateStreams walks off its list
+    (see GANSynth._leveled_queues; measured: GPU_MAX_HW_QUEUES=2 crashes at the first replay, =8 runs at 7.8 ms instead of 5.2)."""
+    n = __import__("os").environ.get("GPU_MAX_HW_QUEUES")
+    if n is None:
+        return True
+    try:
+        ok = int(n) == 4
+    except ValueError:
+        ok = False
+    if not ok:
+        import sys
+        print("gansynth_amd.models: GPU_MAX_HW_QUEUES=%s: the runs' graphs are captured without parallel branches (they need the default, 4)" % n,
+              file=sys.stderr, flush=True)
+    return ok
+
+
 def _copy_inputs(dsts, srcs):
     """A run's inputs into the static buffers its graph reads: ONE multi-tensor launch where the tensors allow it (same device, dtype and
     strides pairwise) instead of a ~5 us copy kernel per input in front of every replay."""
@@ -226,7 +244,7 @@ class GANSynth(object):
         # (data parallel: off in the PIPELINED iteration unless GS_FORK_DIST=1 -- a graph with parallel branches costs the host 1.8 ms per
         #  replay instead of 0.06 (scripts/replay_host_time.py), and that iteration replays FOUR graphs: it would be launch-bound; decided
         #  in _build, when the transport is known.  The two-graph data-parallel forms keep their branches.)
-        self.fork = _FORK
+        self.fork = _FORK and _hw_queues_allow_branches()
         self.fork_eager = _FORK_EAGER
         self.fork_marks = not __import__("os").environ.get("GS_NO_FORK_MARKS")   # (debugging: branches start where they are opened)
         self._side = None

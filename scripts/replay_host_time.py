@@ -30,3 +30,4 @@ torch.cuda.synchronize()
 t_all = time.perf_counter() - t0
 print("fork" if model.fork else "plain", "merged" if model._merged is not None else "two runs", ": wall %.3f ms per iteration, host loop %.3f ms per iteration, graph.replay() host time %.3f ms mean (%d calls), max %.3f" %
       (t_all / N * 1e3, t_host / N * 1e3, sum(host) / len(host) * 1e3, len(host), max(host) * 1e3))
+print("device memory: %.1f GB allocated at peak, %.1f GB reserved" % (torch.cuda.max_memory_allocated() / 1e9, torch.cuda.memory_reserved() / 1e9))
