@@ -257,17 +257,24 @@ class HipKernels(object):
     # whose pairs arrive on both sides of that point (the discriminator's: the R1 pairs early, the real / fake pairs late) is contracted in
     # two launches that add into the same gradient; the rule depends on the recorded sequence only, never on the stream.
     def early_flush_rule(self, min_pixels, callback):
-        self._early = None if callback is None else (int(min_pixels), callback)
+        """`min_pixels`: one threshold or several (descending): each fires once per arming, for the layers at or above it."""
+        if callback is None:
+            self._early = None
+            return
+        ts = sorted({int(t) for t in (min_pixels if isinstance(min_pixels, (tuple, list)) else (min_pixels,))}, reverse=True)
+        self._early = (ts, callback, set())
 
     @staticmethod
     def _key_pixels(key):
         return int(key[6][1]) * int(key[6][2])   # (output positions of the conv whose weight this is)
 
     def _defer_wgrad(self, key, x, gy, out, bias_out):
-        if self._early is not None and self._key_pixels(key) < self._early[0] and self._pending:
-            big = self._early[0]
-            if any(self._key_pixels(k) >= big for k in self._pending):
-                self._early[1](lambda k: self._key_pixels(k) >= big)
+        if self._early is not None and self._pending:
+            px = self._key_pixels(key)
+            for big in self._early[0]:
+                if px < big and big not in self._early[2] and any(self._key_pixels(k) >= big for k in self._pending):
+                    self._early[2].add(big)
+                    self._early[1](lambda k, big=big: self._key_pixels(k) >= big)
         grp = self._pending.setdefault(key, {"out": out, "bias": None, "src": []})
         if bias_out is not None:
             assert grp["bias"] is None or grp["bias"].data_ptr() == bias_out.data_ptr()

@@ -41,8 +41,7 @@ _OVERLAP_REDUCE = bool(__import__("os").environ.get("GS_OVERLAP_REDUCE")) and no
 _GRAPH_ALLREDUCE = not __import__("os").environ.get("GS_NO_GRAPH_ALLREDUCE")   # A/B switch: the gradient all-reduce as a node of the captured graph
 _FORK = not __import__("os").environ.get("GS_NO_FORK")   # A/B switch: independent sub-passes of a run on a forked branch of its hipGraph (GANSynth._branch)
 LEVEL_STREAMS = int(__import__("os").environ.get("GS_LEVEL_STREAMS", "128"))   # see GANSynth._leveled_queues
-EARLY_FLUSH_DIV = int(__import__("os").environ.get("GS_EARLY_FLUSH_DIV", "16"))   # a layer is "large" from 1/DIV of the full resolution's pixels
-EARLY_FLUSH_MAX = int(__import__("os").environ.get("GS_EARLY_FLUSH_MAX", "1"))   # early contractions per run
+EARLY_FLUSH_DIVS = [int(d) for d in __import__("os").environ.get("GS_EARLY_FLUSH_DIV", "16").split(",")]   # a layer is "large" from 1/DIV of the full resolution's pixels (several: one early contraction each)
 EARLY_FLUSH_CUS = int(__import__("os").environ.get("GS_EARLY_FLUSH_CUS", "192"))   # see GANSynth._early_flush
 _FORK_EAGER = bool(__import__("os").environ.get("GS_FORK_EAGER"))   # tests: the same branches with eager launches (a second stream, event hops)
 
@@ -357,9 +356,6 @@ class GANSynth(object):
         way.  (Called from inside a backward node, i.e. on autograd's device thread, under that node's stream.)"""
         K = kernels.get()
         self.early_flushes += 1
-        self._early_in_run += 1
-        if self._early_in_run > EARLY_FLUSH_MAX:   # (the pairs stay pending: contracted with everything else at the end of the run)
-            return
         was = K.lib.gs_wgrad_cu_cap(EARLY_FLUSH_CUS) if hasattr(K, "lib") else 0   # (the chain beside it needs somewhere to land)
         cur = torch.cuda.current_stream().cuda_stream if torch.cuda.is_available() else None
         on_branch = self._side is not None and cur == self._side.cuda_stream
@@ -383,7 +379,8 @@ class GANSynth(object):
         owner = getattr(self.generator, "__self__", None)
         if owner is None or not hasattr(owner, "resolution"):
             return None
-        return max(1, int(owner.resolution(owner.max_depth).prod()) // EARLY_FLUSH_DIV)   # (16: the three levels at the top of the pyramid)
+        full = int(owner.resolution(owner.max_depth).prod())
+        return [max(1, full // d) for d in EARLY_FLUSH_DIVS]   # (16: the three levels at the top of the pyramid)
 
     def _stream_guard(self):
         K = kernels.get()
