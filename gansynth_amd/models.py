@@ -43,6 +43,7 @@ _FORK = not __import__("os").environ.get("GS_NO_FORK")   # A/B switch: independe
 LEVEL_STREAMS = int(__import__("os").environ.get("GS_LEVEL_STREAMS", "128"))   # see GANSynth._leveled_queues
 EARLY_FLUSH_DIVS = [int(d) for d in __import__("os").environ.get("GS_EARLY_FLUSH_DIV", "16").split(",")]   # a layer is "large" from 1/DIV of the full resolution's pixels (several: one early contraction each)
 EARLY_FLUSH_CUS = int(__import__("os").environ.get("GS_EARLY_FLUSH_CUS", "192"))   # see GANSynth._early_flush
+_MERGED_AT_ROOT = bool(__import__("os").environ.get("GS_MERGED_AT_ROOT"))   # A/B switch, see _capture_merged
 _FORK_EAGER = bool(__import__("os").environ.get("GS_FORK_EAGER"))   # tests: the same branches with eager launches (a second stream, event hops)
 
 
@@ -250,6 +251,7 @@ class GANSynth(object):
         self._side2 = None        # the stream of a whole sub-run beside another run (_train_step_merged)
         self._nodes_on_side2 = False
         self._origin = None
+        self._after_loss = None
         self.merge_runs = not __import__("os").environ.get("GS_NO_MERGED_RUNS")   # A/B switch: see _train_step_merged
         self._merged = None
         self._marks = {}
@@ -650,6 +652,9 @@ class GANSynth(object):
         self._origin = torch.cuda.current_stream() if torch.cuda.is_available() else None   # (the stream this run is issued -- or captured -- on)
         losses = self._d_losses_b(part_a, *inputs, fused=fused) if which == "d" else self._g_losses_b(part_a, *inputs, fused=fused)   # (latents, labels) | (labels,)
         loss = losses if losses.dim() == 0 else losses.mean()   # (the fused loss kernels return the mean itself)
+        hook, self._after_loss = self._after_loss, None
+        if hook is not None:   # (merged iteration: part A of the other run is issued here, see _capture_merged)
+            hook()
         K = kernels.get()
         deferring = _DEFER_REDUCTIONS and hasattr(K, "defer_wgrad_reductions")   # parameter gradients are only read after the whole backward:
         if deferring:                                        # their ~70 slice reductions are folded in one go at the end
@@ -1197,10 +1202,23 @@ class GANSynth(object):
                 with _quiet_gc(), self._leveled_queues(), self._stream_guard(), torch.cuda.graph(gx, **_capture_mode(with_collective, self.fork)):
                     main = torch.cuda.current_stream()
                     side2 = self._second_stream("_side2", [main, self._side])
-                    side2.wait_stream(main)                      # fork at the root of the graph ...
-                    with torch.cuda.stream(side2):
-                        g_part_a = self._part_a("g", *sg)
+                    box = []
+
+                    def part_a_of_g():
+                        # from the discriminator run's loss on its second half is one stream wide (R1 double-backward, the real pass's backward,
+                        # the final contraction): part A of the generator run goes THERE (GS_MERGED_AT_ROOT=1: from the graph's root, beside
+                        # the two forward passes)
+                        side2.wait_stream(torch.cuda.current_stream())
+                        with torch.cuda.stream(side2):
+                            box.append(self._part_a("g", *sg))
+                        self.g_params.requires_grad_(False)      # (back to the discriminator run's arming for its backward)
+                        self.d_params.requires_grad_(True)
+                    if _MERGED_AT_ROOT:
+                        part_a_of_g()
+                    else:
+                        self._after_loss = part_a_of_g
                     d_loss = self._forward_backward("d", *sd)    # (data parallel: ends with the all-reduce of the discriminator's gradient, _part_b)
+                    g_part_a = box[0]
                     main.wait_stream(side2)                      # ... join at its end
                 reduced[0] = self._captured_reduce
                 gy = torch.cuda.CUDAGraph()
