@@ -36,4 +36,4 @@ for depth in (0.0, 0.5, 1.5, 2.5, 3.5, 4.5, 5.5, 6.5, 7.0):
         model.train_step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n * 1e3
-    print(f"growing_depth {pg.growing_depth:4.2f}: {dt:7.2f} ms per iteration ({8 / dt * 1e3:7.0f} images/s)  graphs: {sorted(model._graphs)}")
+    print(f"growing_depth {pg.growing_depth:4.2f}: {dt:7.2f} ms per iteration ({8 / dt * 1e3:7.0f} images/s)  graphs: {sorted(model._graphs) or ('merged pair' if model._merged is not None else [])}")
