@@ -84,8 +84,14 @@ def main(args):
     holder["model"] = model
 
     if args.train:
-        model.train(total_steps=args.total_steps, log_tensor_steps=args.log_tensor_steps, log=print if rank == 0 else None,
-                    model_dir=args.model_dir, save_checkpoint_steps=args.save_checkpoint_steps)   # every rank restores, rank 0 saves
+        model.train(                                   # gan_synth_main.py:102-109, argument for argument
+            model_dir=args.model_dir,                  # (every rank restores, rank 0 saves)
+            config=None,                               # (the reference's tf.ConfigProto: nothing of it applies here)
+            total_steps=args.total_steps,
+            save_checkpoint_steps=args.save_checkpoint_steps,
+            save_summary_steps=100,
+            log_tensor_steps=args.log_tensor_steps,
+            log=print if rank == 0 else None)
         if rank == 0:
             print(f"stopped at global_step = {model.global_step}")
 

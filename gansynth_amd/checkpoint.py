@@ -19,7 +19,9 @@ import math
 import os
 import re
 import time
+import warnings
 
+import numpy as np
 import torch
 
 try:
@@ -57,7 +59,10 @@ def load_state_dict(model, state, strict=True):
         raise RuntimeError("checkpoint: build the model's variables first (GANSynth._build)")
     if hasattr(model, "synchronize"):
         model.synchronize()
-    missing = []
+    # Two passes: everything that can refuse the file (shapes, missing entries, contradictory step counts) is checked BEFORE the first
+    # byte is copied, so a refused checkpoint leaves the model exactly as it was (not half-restored with one optimizer's slots and the
+    # other's step count).
+    missing, copies, steps = [], [], {}
     for params, suffix in ((model.g_params, ""), (model.d_params, "_1")):
         for name, p in params.named.items():
             n = p.numel()
@@ -67,50 +72,53 @@ def load_state_dict(model, state, strict=True):
                     src = state[key]
                     if tuple(src.shape) != tuple(dst.shape):
                         raise ValueError(f"checkpoint: {key} has shape {tuple(src.shape)}, the variable has {tuple(dst.shape)}")
-                    dst.copy_(src.to(dst.device, dst.dtype))
+                    copies.append((dst, src))
                 else:
                     missing.append(key)
         key = "optimizer_steps" + suffix
         if key in state:
-            params.t = int(state[key])
+            steps[suffix] = int(state[key])
         elif "global_step" in state:
             # a checkpoint converted from a real tf.train.Saver file has only TF's own accumulators.  Both optimizers are applied
             # exactly once per iteration (models.py:81-88, 191-192), so t IS global_step.  beta2_power = beta2^(t+1) (float32)
             # cannot give it back in general: 0.99^(t+1) is denormal past ~8.7 k steps and exactly 0 past ~10.3 k, where a
             # log() recovery would restart the bias correction (a 10x learning-rate dip); it only serves as a cross-check while
             # it is still a normal float.
-            params.t = int(state["global_step"])
+            t = int(state["global_step"])
             hp = model.hyper_params
             b2 = float(hp.generator_beta2 if suffix == "" else hp.discriminator_beta2)
             p2 = float(state.get("beta2_power" + suffix, 0.0))
             if 1.2e-38 < p2 < 1.0 and 0.0 < b2 < 1.0:
                 # While beta2_power is still a normal float it IS the optimizer's own step count (beta2^(t+1)): take t from it -- a
                 # reference checkpoint written between the discriminator's and the generator's train op (OutOfRangeError after the
-                # first session.run of models.py:191-192) has t_D = global_step + 1, and optimizers that ran different numbers of
-                # steps stay loadable.  A disagreement with global_step beyond rounding is reported, not refused.
-                # (TF accumulates beta2_power by float32 multiplies of float32(beta2): the log is taken of THAT base; what is left
-                # of the float32 rounding drift is why only the documented one-step disagreement is adopted.)
-                import numpy as np
+                # first session.run of models.py:191-192) has t_D = global_step + 1.  A disagreement within 0.1 % is float32 product
+                # drift (TF accumulates beta2_power by float32 multiplies of float32(beta2): the log is taken of THAT base) and
+                # global_step stands; a gross one -- a corrupt file, a beta2 hyper-parameter that is not the checkpoint's, or
+                # optimizers that really ran different numbers of steps -- is REFUSED under strict=True (the default of restore()
+                # and train()) and a warning under strict=False: the Adam bias-correction step is not silently reset from it.
                 t_log = int(round(math.log(p2) / math.log(float(np.float32(b2))))) - 1
-                if abs(t_log - params.t) <= 1:
-                    params.t = max(t_log, 0)
-                elif abs(t_log - params.t) > max(1, int(1e-3 * params.t)):   # (within 0.1 %: float32 product drift -- global_step stands)
-                    # a gross contradiction (a corrupt file, or a beta2 hyper-parameter that is not the checkpoint's): the Adam
-                    # bias-correction step is not silently reset from it
+                if abs(t_log - t) <= 1:
+                    t = max(t_log, 0)
+                elif abs(t_log - t) > max(1, int(1e-3 * t)):
                     msg = (f"checkpoint: beta2_power{suffix} = {p2:g} says {t_log} optimizer steps with beta2 = {b2:g}, "
-                           f"global_step says {params.t}")
+                           f"global_step says {t}")
                     if strict:
                         raise ValueError(msg + " (strict=False keeps global_step)")
-                    import warnings
                     warnings.warn(msg + "; keeping global_step")
+            steps[suffix] = t
         else:
             missing.append(key)
-    if "global_step" in state:
-        model.global_step = int(state["global_step"])
-    else:
+    if "global_step" not in state:
         missing.append("global_step")
     if strict and missing:
         raise KeyError(f"checkpoint: {len(missing)} entries missing, e.g. {missing[:4]}")
+    for dst, src in copies:
+        dst.copy_(src.to(dst.device, dst.dtype))
+    for params, suffix in ((model.g_params, ""), (model.d_params, "_1")):
+        if suffix in steps:
+            params.t = steps[suffix]
+    if "global_step" in state:
+        model.global_step = int(state["global_step"])
     from . import kernels
     K = kernels.get()
     if hasattr(K, "invalidate_weights"):   # the conv kernels' re-laid weight operands are stale now; captured graphs expect fresh ones

@@ -1,7 +1,12 @@
 #!/bin/bash
-# Builds libgansynth_hip.so for gfx950 (cross-compiles without a GPU).  Usage: build.sh [outdir]
+# Builds libgansynth_hip.so for gfx950 (cross-compiles without a GPU).  Usage: build.sh [--clean] [outdir]
+#   --clean   drop every object first (obj/ is git-ignored but travels with the tree: without the flag the build is incremental by mtime)
 set -e
 cd "$(dirname "$0")"
+if [ "$1" = "--clean" ]; then
+  rm -rf obj
+  shift
+fi
 OUT=${1:-..}
 mkdir -p obj
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result $GS_EXTRA_FLAGS"

@@ -146,12 +146,12 @@ __device__ __forceinline__ void static_for(F&& f) {
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 // one LDS-DMA piece: 64 lanes x 16 bytes -> LDS[lds_addr + 16*lane].  M0 is written and consumed inside the statement and
-// not restored: nothing else in these kernels uses M0 (gfx9 LDS instructions do not), which the build checks in the ISA.
+// not restored; it is DECLARED as clobbered, so a compiler use of M0 (v_movrel / s_movrel indexing, LDS-direct) can never straddle a piece.
 __device__ __forceinline__ void lds_dma16(unsigned lds_addr, unsigned voff, i32x4 rs) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
                  :
                  : "s"(lds_addr), "v"(voff), "s"(rs)
-                 : "memory");
+                 : "memory", "m0");
 }
 // the same with a scalar offset: address = base + voff + soff, and soff takes part in the descriptor's range check (measured,
 // scripts/probe/dma_probe.hip mode 2) -- so the per-piece part of a WEIGHT address that is uniform over the wave stays in an SGPR and the
@@ -162,7 +162,7 @@ __device__ __forceinline__ void lds_dma16_s(unsigned lds_addr, unsigned voff, i3
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                  :
                  : "s"(lds_addr), "v"(voff), "s"(rs), "s"(soff)
-                 : "memory");
+                 : "memory", "m0");
 }
 // streamed-once operands (the weight-gradient inputs of the HBM-bound layers): non-temporal policy -- the lines are not kept in L2 for a
 // second reader that never comes
@@ -174,7 +174,7 @@ __device__ __forceinline__ void lds_dma16_stream(unsigned lds_addr, unsigned vof
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen nt lds"
                  :
                  : "s"(lds_addr), "v"(voff), "s"(rs)
-                 : "memory");
+                 : "memory", "m0");
 #else
     lds_dma16(lds_addr, voff, rs);
 #endif

@@ -684,6 +684,12 @@ class GANSynth(object):
             if deferring:
                 if hasattr(K, "early_flush_rule"):
                     K.early_flush_rule(0, None)
+                # The final contraction reads the (x, gy) pairs and bias partial rows the branches produced and ADDS into gradients the early
+                # contraction on the branch added into (read-modify-write folds, not atomics): it must sit behind the branches in the
+                # captured graph, not merely behind them in time.  record_stream keeps the allocator honest and orders nothing; autograd's
+                # end-of-backward sync only covers the streams of the leaves it accumulated into.  The join costs nothing: the flush needs
+                # those results anyway.  (advisor, round 5)
+                self._join_branches()
                 if overlap:   # contract the layers bucket by bucket; a finished bucket goes on the wire under the next one's kernels
                     K.flush_wgrad_reductions(group_of=params.bucket_of,
                                              on_group_done=lambda i: launched.append((i, self._launch_reduce(params, i))))
@@ -691,17 +697,23 @@ class GANSynth(object):
                     K.flush_wgrad_reductions()
         if launched:
             self._inflight = (params, launched)
-        if self._branched:   # (every branch was joined where it closed and autograd joins the streams it used; a branch left open would fail the capture)
-            self._branched = False
-            torch.cuda.current_stream().wait_stream(self._side)
-        if self._nodes_on_side2 and self._forking():   # (merged iteration: this run's own-network nodes ran -- and accumulated -- on that stream)
-            torch.cuda.current_stream().wait_stream(self._side2)
+        self._join_branches()   # (a branch opened by the flush itself; a branch left open would fail the capture)
         if self.distributed and self._comm is not None and self._graph_allreduce and self._capturing() and not getattr(self, "_pipe_capture", False):
             # Same-stream RCCL is capturable: the all-reduce of this run's flat gradient becomes the LAST NODE of the run's hipGraph, so
             # a replayed run hands over reduced gradients and no eager collective launch sits between the replay and the update.
             self._reduce_in_capture(params)
             self._captured_reduce = True
         return loss.detach()
+
+    def _join_branches(self):
+        """The current stream waits for every branch this run opened: the side stream (every branch was joined where it closed, except the
+        early contraction's, and autograd joins the streams it used) and, in the merged iteration, the stream this run's own-network nodes
+        ran -- and accumulated -- on."""
+        if self._branched:
+            self._branched = False
+            torch.cuda.current_stream().wait_stream(self._side)
+        if self._nodes_on_side2 and self._forking():
+            torch.cuda.current_stream().wait_stream(self._side2)
 
     def _reduce_in_capture(self, params):
         """The gradient all-reduce issued while the current stream is being captured into a hipGraph (a method of its own so that a
@@ -752,6 +764,8 @@ class GANSynth(object):
             K.drop_deferred()
         F.reset_fusion_state()
         self._inflight = None
+        self._after_loss = None
+        self._marks.clear()
         params = self.d_params if which == "d" else self.g_params
         if not self.keep_gradients:   # (as before the first capture: a graph without a fill must find the buffer the way every replay will)
             params.grad.zero_()
@@ -1248,6 +1262,8 @@ class GANSynth(object):
                 return None
         finally:
             owner.fade_weight = None
+            self._after_loss = None   # (a capture that raised before the discriminator run's loss must not leave the hook armed for an unrelated run)
+            self._nodes_on_side2 = False
         return {"x": gx, "y": gy, "sd": sd, "sg": sg, "d_loss": d_loss, "g_loss": g_loss, "keep": self.keep_gradients, "reduced": reduced,
                 "consts": F.constants_snapshot()}
 
@@ -1327,14 +1343,25 @@ class GANSynth(object):
         torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
         return bool(flag.item())
 
-    def train(self, total_steps, log_tensor_steps=100, log=print, model_dir=None, save_checkpoint_steps=1000, save=None):
-        """models.py:110-194 without the TF summary hooks: resume from the latest checkpoint of `model_dir` (CheckpointSaverHook /
+    def train(self, model_dir=None, config=None, total_steps=None, save_checkpoint_steps=1000, save_summary_steps=None, log_tensor_steps=100,
+              log=print, save=None):
+        """models.py:110 -- `train(model_dir, config, total_steps, save_checkpoint_steps, save_summary_steps, log_tensor_steps)`, the
+        reference's own signature and argument order, so that gan_synth_main.py:102-109 calls it unchanged.  `config` is the reference's
+        tf.ConfigProto (session / GPU-allocator options, gan_synth_main.py:91-98): nothing of it applies to this runtime, it is accepted
+        and ignored.  `save_summary_steps` drives the reference's SummarySaverHook (TensorBoard images / audio, models.py:131-136): out of
+        this path's scope, accepted and ignored.  `log`, `save` are additions (keyword only in practice).
+        models.py:110-194 without the TF summary hooks: resume from the latest checkpoint of `model_dir` (CheckpointSaverHook /
         MonitoredSession semantics), alternate D and G runs until global_step reaches total_steps (StopAtStepHook) or the input
         runs dry (OutOfRangeError, :193), log the two losses every `log_tensor_steps` (LoggingTensorHook), checkpoint every
         `save_checkpoint_steps` and at the end.  Data parallel: EVERY rank passes `model_dir` and restores from the same file
         (weights, Adam slots, optimizer steps, global_step -- so that all ranks resume in the same growing regime); only rank 0
         writes (`save` defaults to rank == 0)."""
         from . import checkpoint
+        if isinstance(model_dir, (int, float)) and not isinstance(model_dir, bool) and total_steps is None:
+            model_dir, total_steps = None, model_dir   # (rounds 1-5 of this tree: train(total_steps, ...) with the count first)
+        if total_steps is None:
+            raise TypeError("train(): total_steps is required (models.py:110)")
+        del config, save_summary_steps
         save = (self.rank == 0) if save is None else bool(save)
         have = True
         if model_dir is not None and self.g_params is None:
@@ -1378,8 +1405,38 @@ class GANSynth(object):
         if model_dir is not None and save and self.g_params is not None and last_saved != self.global_step:
             checkpoint.save(self, model_dir)
 
-    def generate(self, latents, labels):
-        """models.py:232-250: fake waveforms for a batch."""
+    def generate(self, *args, **kwargs):
+        """Two forms.
+        `generate(model_dir, config)` -- the reference's (models.py:232-250, called at gan_synth_main.py:128-131): restores the latest
+        checkpoint of `model_dir` (MonitoredSession semantics: the initial weights when there is none), then YIELDS one numpy batch of
+        fake waveforms [B, waveform_length] per batch of the input functions -- labels of `real_input_fn()`, latents of
+        `fake_input_fn()`, as models.py:22-31 wires `fake_waveforms` -- until the input runs dry (OutOfRangeError, :249).  `config`
+        (tf.ConfigProto) is accepted and ignored.
+        `generate(latents, labels)` -- fake waveforms (a device tensor) for one given batch."""
+        if "model_dir" in kwargs or (args and (args[0] is None or isinstance(args[0], (str, bytes)) or hasattr(args[0], "__fspath__"))):
+            return self._generate_from(*args, **kwargs)
+        return self._generate_batch(*args, **kwargs)
+
+    def _generate_from(self, model_dir, config=None):
+        from . import checkpoint
+        del config
+        restored = False
+        while True:
+            try:
+                _, labels = self.real_input_fn()
+            except StopIteration:
+                return
+            latents = self.fake_input_fn()
+            dev = self.store.device if hasattr(self.store, "device") else labels.device
+            latents, labels = latents.to(dev), labels.to(dev)
+            self._ensure_built(latents.to(self.dtype), labels.to(self.dtype))
+            if not restored:
+                restored = True
+                self.restored_from = checkpoint.restore(self, model_dir) if model_dir is not None else None
+            yield self._generate_batch(latents, labels).float().cpu().numpy()
+
+    def _generate_batch(self, latents, labels):
+        """models.py:22-31 (`fake_waveforms`): fake waveforms for a batch."""
         self._join_updates()
         with torch.no_grad():
             images = self.generator(latents.to(self.dtype), labels.to(self.dtype))

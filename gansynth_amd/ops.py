@@ -22,9 +22,20 @@ from ._lib import ACT_LRELU, ACT_NONE, ACT_TANH
 _ACT = {None: ACT_NONE, "leaky_relu": ACT_LRELU, "tanh": ACT_TANH}
 
 
-def get_weight(shape, variance_scale=2.0, scale_weight=False):
+def _no_weight_normalizers(apply_weight_standardization, apply_spectral_normalization):
+    """ops.py:153-154,168-171: the two weight normalisers every layer function of the reference accepts.  They are accepted here in the
+    same positions so that a reference call site runs unchanged; the GANSynth graph never sets them (networks.py passes neither), the
+    normalisers themselves (ops.py:5-146) are not on this path, and asking for one is refused rather than ignored."""
+    if apply_weight_standardization:
+        raise NotImplementedError("apply_weight_standardization=True (ops.py:5-25) is not on the GANSynth hot path: networks.py never sets it")
+    if apply_spectral_normalization:
+        raise NotImplementedError("apply_spectral_normalization=True (ops.py:28-146) is not on the GANSynth hot path: networks.py never sets it")
+
+
+def get_weight(shape, variance_scale=2.0, scale_weight=False, apply_weight_standardization=False, apply_spectral_normalization=False):
     """ops.py:149-171.  Returns (variable, alpha): alpha = sqrt(variance_scale / prod(shape[:-1]))
     when scale_weight (variable ~ truncN(0,1)), else 1 (variable ~ truncN(0, stddev))."""
+    _no_weight_normalizers(apply_weight_standardization, apply_spectral_normalization)
     stddev = float(np.sqrt(variance_scale / np.prod(shape[:-1])))
     store = variables.default_store()
     if scale_weight:
@@ -37,8 +48,10 @@ def get_bias(shape):
     return variables.default_store().get_variable("bias", shape, variables.zeros())
 
 
-def dense(inputs, units, use_bias=True, variance_scale=2.0, scale_weight=False, activation=None):
+def dense(inputs, units, use_bias=True, variance_scale=2.0, scale_weight=False, apply_weight_standardization=False,
+          apply_spectral_normalization=False, activation=None):
     """ops.py:183-201."""
+    _no_weight_normalizers(apply_weight_standardization, apply_spectral_normalization)
     if inputs.dim() == 4:   # tf.layers.flatten of NCHW (networks.py:185) folded into the layer: no channel-major copy
         weight, alpha = get_weight([inputs.shape[1] * inputs.shape[2] * inputs.shape[3], units], variance_scale, scale_weight)
     else:
@@ -65,13 +78,15 @@ def dense_reshaped(inputs, channels, resolution, use_bias=True, variance_scale=2
     return F.units_bias_act_nhwc(outputs, bias, channels, h, w, _ACT[activation])
 
 
-def embedding(inputs, units, variance_scale=2.0, scale_weight=False):
+def embedding(inputs, units, variance_scale=2.0, scale_weight=False, apply_weight_standardization=False, apply_spectral_normalization=False):
     """ops.py:204-218: row gather by argmax of the (one-hot) inputs."""
+    _no_weight_normalizers(apply_weight_standardization, apply_spectral_normalization)
     weight, alpha = get_weight([inputs.shape[1], units], variance_scale, scale_weight)
     return F.embedding_onehot(inputs, weight, alpha)
 
 
 def conv2d(inputs, filters, kernel_size, strides=[1, 1], use_bias=True, variance_scale=2.0, scale_weight=False,
+           apply_weight_standardization=False, apply_spectral_normalization=False,
            activation=None, input_activation=None, pixel_norm_epsilon=None, input_normed=False):
     """ops.py:221-247 (NCHW, SAME).  `input_normed` (with pixel_norm_epsilon): the caller's promise that `inputs` is the pixel-normalised
     output of such a fused block and feeds nothing but this conv -- its backward may then run that block's norm / activation backward in
@@ -81,6 +96,7 @@ def conv2d(inputs, filters, kernel_size, strides=[1, 1], use_bias=True, variance
     this conv's data-gradient kernel (functional.py, "premasked gradients"); results are unchanged.  "Nothing but" includes
     second-order graphs: a tensor whose consumers' backward is differentiated again (pixel norm under the mode-seeking term)
     receives a second gradient and must not be declared."""
+    _no_weight_normalizers(apply_weight_standardization, apply_spectral_normalization)
     kernel_size, strides = list(kernel_size), list(strides)
     if kernel_size[0] != kernel_size[1] or strides[0] != strides[1]:
         raise ValueError("conv2d: only square kernels / isotropic strides are on the hot path")
@@ -94,8 +110,10 @@ def conv2d(inputs, filters, kernel_size, strides=[1, 1], use_bias=True, variance
 
 
 def conv2d_transpose(inputs, filters, kernel_size, strides=[1, 1], use_bias=True, variance_scale=2.0, scale_weight=False,
+                     apply_weight_standardization=False, apply_spectral_normalization=False,
                      activation=None, pixel_norm_epsilon=None, input_normed=False):
     """ops.py:250-280 (NCHW, SAME, output = input * strides); 3x3 / stride 2 is the hot-path case."""
+    _no_weight_normalizers(apply_weight_standardization, apply_spectral_normalization)
     if list(kernel_size) != [3, 3] or list(strides) != [2, 2]:
         raise ValueError("conv2d_transpose: the hot path is kernel 3x3, strides 2x2 (networks.py:71-79)")
     weight, alpha = get_weight([*kernel_size, inputs.shape[1], filters], variance_scale, scale_weight)
