@@ -947,6 +947,11 @@ def main():
     K = kernels.get()
 
     def barrier():
+        # (model.synchronize(): the one-graph iteration leaves the generator's last optimizer step pending -- it rides at the front of the next
+        #  replay -- so the timed region ends with it applied, and starts with nothing pending: exactly K whole iterations inside.  Data
+        #  parallel that step's all-reduce is a collective: every rank is here at the same point of its launch sequence.)
+        if hasattr(model, "synchronize"):
+            model.synchronize()
         if distributed:
             torch.distributed.barrier()
         torch.cuda.synchronize()

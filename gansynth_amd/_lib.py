@@ -109,6 +109,7 @@ SIGNATURES = {
     "gs_gan_g_loss": (I, [P, P, P, F, F, I, I, P, P, P, I, P]),
     "gs_adam_tf_step": (I, [P, P, P, P, L, F, F, F, F, F, P]),
     "gs_adam_tf_step_zero_grad": (I, [P, P, P, P, L, F, F, F, F, F, P]),
+    "gs_adam_tf_step_dev": (I, [P, P, P, P, L, P, F, F, F, F, I, P]),
     "gs_spectral_plan_create": (I, [POINTER(c_void_p), I, I, I, P, P]),
     "gs_spectral_plan_destroy": (I, [P]),
     "gs_stft_fwd": (I, [P, P, I, I, I, P, P, P]),

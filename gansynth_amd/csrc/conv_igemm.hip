@@ -2549,7 +2549,7 @@ extern "C" int gs_prof_roofline(double peak_tflops, double peak_gbps, double* to
 extern "C" int gs_prof_records(int max_records, int* n, double* ms, double* flops, double* bytes, int* desc) {
     int k = 0;
     for (int i = 0; i < gs::g_prof.used && k < max_records; ++i, ++k) {
-        hipEventSynchronize(gs::g_prof.ev[i][1]);
+        (void)hipEventSynchronize(gs::g_prof.ev[i][1]);
         float t = 0.f;
         if (hipEventElapsedTime(&t, gs::g_prof.ev[i][0], gs::g_prof.ev[i][1]) != hipSuccess) t = 0.f;
         t /= (float)gs::g_prof.lreps[i];
@@ -2566,7 +2566,7 @@ extern "C" int gs_prof_collect(int* launches, double* total_ms, double* total_fl
     for (int i = 0; i < gs::g_prof.used; ++i) {
         if (gs::g_prof.ldesc[i][0] >= 10) continue;
         ++count;
-        hipEventSynchronize(gs::g_prof.ev[i][1]);
+        (void)hipEventSynchronize(gs::g_prof.ev[i][1]);
         float t = 0.f;
         if (hipEventElapsedTime(&t, gs::g_prof.ev[i][0], gs::g_prof.ev[i][1]) == hipSuccess) ms += t / (float)gs::g_prof.lreps[i];
     }

@@ -659,9 +659,16 @@ __global__ void row_scale_kernel(const T* __restrict__ x, const float* __restric
 
 // -------------------------------------------------------------------------------- Adam
 // ZERO: the gradient is cleared behind the update (the trainer's next run accumulates into it from zero: no separate fill pass)
-template <bool ZERO>
+// DEV: the bias-corrected step size is read from device memory (`lr_dev[0]`; a NEGATIVE value means "no step": the launch leaves every
+// buffer untouched) -- the by-value scalar would be frozen into a captured hipGraph, and with the optimizer step inside the iteration's
+// graph there is no eager launch left between two runs.
+template <bool ZERO, bool DEV>
 static __global__ void adam_tf_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                                      long n, float lr_t, float b1, float b2, float eps, float gs) {
+                                      long n, float lr_t, const float* __restrict__ lr_dev, float b1, float b2, float eps, float gs) {
+    if (DEV) {
+        lr_t = __builtin_nontemporal_load(lr_dev);
+        if (lr_t < 0.f) return;
+    }
     const long nvec = n >> 2;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
         float4 pv = reinterpret_cast<float4*>(p)[i];
@@ -1010,8 +1017,8 @@ extern "C" int gs_row_scale(const void* x, const float* s, float alpha, void* ou
 extern "C" int gs_adam_tf_step(float* p, const float* g, float* m, float* v, int64_t numel, float lr_t, float beta1, float beta2,
                                float eps, float grad_scale, void* stream) {
     GS_CHECK_ARG(numel > 0, "adam: bad args");
-    hipLaunchKernelGGL(adam_tf_kernel<false>, dim3(ew_grid((numel >> 2) + 4)), dim3(256), 0, as_stream(stream), p, const_cast<float*>(g), m, v, (long)numel, lr_t,
-                       beta1, beta2, eps, grad_scale);
+    hipLaunchKernelGGL((adam_tf_kernel<false, false>), dim3(ew_grid((numel >> 2) + 4)), dim3(256), 0, as_stream(stream), p, const_cast<float*>(g), m, v,
+                       (long)numel, lr_t, (const float*)nullptr, beta1, beta2, eps, grad_scale);
     GS_CHECK_LAUNCH();
     return 0;
 }
@@ -1019,8 +1026,22 @@ extern "C" int gs_adam_tf_step(float* p, const float* g, float* m, float* v, int
 extern "C" int gs_adam_tf_step_zero_grad(float* p, float* g, float* m, float* v, int64_t numel, float lr_t, float beta1, float beta2,
                                          float eps, float grad_scale, void* stream) {
     GS_CHECK_ARG(numel > 0, "adam: bad args");
-    hipLaunchKernelGGL(adam_tf_kernel<true>, dim3(ew_grid((numel >> 2) + 4)), dim3(256), 0, as_stream(stream), p, g, m, v, (long)numel, lr_t, beta1, beta2, eps,
-                       grad_scale);
+    hipLaunchKernelGGL((adam_tf_kernel<true, false>), dim3(ew_grid((numel >> 2) + 4)), dim3(256), 0, as_stream(stream), p, g, m, v, (long)numel, lr_t,
+                       (const float*)nullptr, beta1, beta2, eps, grad_scale);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gs_adam_tf_step_dev(float* p, float* g, float* m, float* v, int64_t numel, const float* lr_t_dev, float beta1, float beta2,
+                                   float eps, float grad_scale, int zero_grad, void* stream) {
+    GS_CHECK_ARG(numel > 0 && lr_t_dev != nullptr, "adam: bad args");
+    const dim3 grid(ew_grid((numel >> 2) + 4));
+    if (zero_grad)
+        hipLaunchKernelGGL((adam_tf_kernel<true, true>), grid, dim3(256), 0, as_stream(stream), p, g, m, v, (long)numel, 0.f, lr_t_dev, beta1, beta2, eps,
+                           grad_scale);
+    else
+        hipLaunchKernelGGL((adam_tf_kernel<false, true>), grid, dim3(256), 0, as_stream(stream), p, g, m, v, (long)numel, 0.f, lr_t_dev, beta1, beta2, eps,
+                           grad_scale);
     GS_CHECK_LAUNCH();
     return 0;
 }

@@ -35,15 +35,15 @@ struct ProfScope {
         for (int i = 0; i < 8; ++i) g_prof.ldesc[idx][i] = d[i];
         if (kind >= 10) flops = 0.0;   // (the family totals of gs_prof_collect count the implicit-GEMM launches only)
         if (idx >= g_prof.created) {
-            hipEventCreate(&g_prof.ev[idx][0]);
-            hipEventCreate(&g_prof.ev[idx][1]);
+            (void)hipEventCreate(&g_prof.ev[idx][0]);
+            (void)hipEventCreate(&g_prof.ev[idx][1]);
             g_prof.created = idx + 1;
         }
         g_prof.flops += flops;
-        hipEventRecord(g_prof.ev[idx][0], s);
+        (void)hipEventRecord(g_prof.ev[idx][0], s);
     }
     ~ProfScope() {
-        if (idx >= 0) hipEventRecord(g_prof.ev[idx][1], s);
+        if (idx >= 0) (void)hipEventRecord(g_prof.ev[idx][1], s);
     }
 };
 

@@ -619,10 +619,10 @@ extern "C" int gs_spectral_plan_create(gs_spectral_plan** out, int frame_length,
 
 extern "C" int gs_spectral_plan_destroy(gs_spectral_plan* p) {
     if (!p) return 0;
-    hipFree(p->hann); hipFree(p->inv_window); hipFree(p->tw); hipFree(p->twp); hipFree(p->mel_idx); hipFree(p->mel_val);
-    if (p->pinv) hipFree(p->pinv);
-    if (p->pinv_split) hipFree(p->pinv_split);
-    if (p->fast) { hipFree(p->tw1k); hipFree(p->mel_lo); hipFree(p->mel_w); }
+    (void)hipFree(p->hann); (void)hipFree(p->inv_window); (void)hipFree(p->tw); (void)hipFree(p->twp); (void)hipFree(p->mel_idx); (void)hipFree(p->mel_val);
+    if (p->pinv) (void)hipFree(p->pinv);
+    if (p->pinv_split) (void)hipFree(p->pinv_split);
+    if (p->fast) { (void)hipFree(p->tw1k); (void)hipFree(p->mel_lo); (void)hipFree(p->mel_w); }
     delete p;
     return 0;
 }

@@ -1150,6 +1150,41 @@ class DeviceLerp(object):
         return DeviceLerp.Coef(self, 2)
 
 
+class DeviceScalars(object):
+    """A few fp32 scalars a captured hipGraph reads from device memory (the optimizers' bias-corrected step sizes: by-value kernel
+    scalars would be frozen into the graph).  `set(values)` is stream-ordered ahead of the next launch / replay; same pinned ring as
+    DeviceLerp (the host runs replays ahead of the device)."""
+
+    _SLOTS = 4
+
+    def __init__(self, device, n):
+        self.host = torch.zeros(n, dtype=torch.float32)
+        self._cuda = torch.device(device).type == "cuda"
+        self._ring = [self.host.clone().pin_memory() for _ in range(self._SLOTS)] if self._cuda else None
+        self._done = [None] * self._SLOTS
+        self._next = 0
+        self.table = self.host.to(device)
+
+    def set(self, values):
+        for i, v in enumerate(values):
+            self.host[i] = float(v)   # (round-to-nearest fp32: what ctypes.c_float does to a by-value scalar)
+        if not self._cuda:
+            self.table.copy_(self.host)
+            return
+        i = self._next
+        self._next = (i + 1) % self._SLOTS
+        if self._done[i] is not None:
+            self._done[i].synchronize()
+        self._ring[i].copy_(self.host)
+        self.table.copy_(self._ring[i], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._done[i] = ev
+
+    def ptr(self, index):
+        return self.table.data_ptr() + 4 * int(index)
+
+
 def _coef_zero(c):
     """0 in the same representation as coefficient c (a device-table entry stays a device-table entry)."""
     return c.owner.zero() if isinstance(c, DeviceLerp.Coef) else 0.0

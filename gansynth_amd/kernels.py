@@ -955,6 +955,18 @@ class HipKernels(object):
             self.invalidate_weights(p)  # parameter values changed: cached kernel operands of that buffer are stale ...
             self.refresh_weights(p)     # ... and are rebuilt here in one launch
 
+    def adam_tf_step_dev(self, p, g, m, v, lr_t_ptr, beta1, beta2, eps, grad_scale=1.0, refresh=True, zero_grad=False):
+        """adam_tf_step with lr_t read from device memory when the launch EXECUTES (`lr_t_ptr`: address of one fp32; negative = no step):
+        the form a captured graph can hold.  `refresh`: the prepared operands of every weight in `p` are rebuilt behind it, unconditionally
+        -- inside a capture the host-side staleness stamps describe the capture pass, not the replays."""
+        for t in (p, g, m, v):
+            assert t.dtype == torch.float32 and t.is_contiguous()
+        _lib.check(self.lib.gs_adam_tf_step_dev(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), int(lr_t_ptr), float(beta1),
+                                                float(beta2), float(eps), float(grad_scale), 1 if zero_grad else 0, _stream()), "gs_adam_tf_step_dev")
+        if refresh:
+            self.invalidate_weights(p)
+            self.refresh_weights(p)
+
     # ------------------------------------------------------------------- more than one stream
     def stream_guard(self):
         """`with K.stream_guard():` -- every tensor argument of every kernel-layer call made inside is marked with the stream the call
@@ -1061,6 +1073,8 @@ class _Accounting(object):
 class _StreamGuard(object):
     SKIP = _Accounting.SKIP + ("stream_guard", "refresh_weights", "flush_wgrad_reductions")
 
+    hook = None   # class attribute: `hook(wrapper, name) -> wrapper` (debugging scripts only)
+
     def __init__(self, K):
         self.K, self.names = K, []
 
@@ -1075,6 +1089,7 @@ class _StreamGuard(object):
 
     def _wrap(self, fn, name=""):
         mark = self._mark
+        hook = self.hook   # (scripts/dbg_fork2.py: a recording wrapper around every call; None in production)
 
         def wrapper(*a, **kw):
             stream = torch.cuda.current_stream()
@@ -1082,24 +1097,8 @@ class _StreamGuard(object):
                 mark(v, stream)
             for v in kw.values():
                 mark(v, stream)
-            rec = getattr(self.K, "_dbg_record", None)
-            if rec is not None:   # (debugging: copies of every operand and result, captured with the run -- which tensor differs between two replays?)
-                ins = []
-                for i, t in enumerate(list(a) + list(kw.values())):
-                    if isinstance(t, torch.Tensor) and t.is_cuda:
-                        ins.append((i, t.data_ptr(), t.numel() * t.element_size(), t.clone()))
-            out = fn(*a, **kw)
-            keep = getattr(self.K, "_dbg_keep", None)
-            if keep is not None:   # (debugging: nothing a kernel touched is freed, hence no block is reused, before the list is dropped)
-                keep.append((a, kw, out))
-            if rec is not None:
-                outs = []
-                for i, t in enumerate(out if isinstance(out, (tuple, list)) else (out,)):
-                    if isinstance(t, torch.Tensor) and t.is_cuda:
-                        outs.append((i, t.data_ptr(), t.numel() * t.element_size(), t.clone()))
-                rec.append((name, int(stream.cuda_stream), ins, outs))
-            return out
-        return wrapper
+            return fn(*a, **kw)
+        return wrapper if hook is None else hook(wrapper, name)
 
     def __enter__(self):
         for name in dir(type(self.K)):

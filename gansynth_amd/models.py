@@ -254,6 +254,11 @@ class GANSynth(object):
         self._after_loss = None
         self.merge_runs = not __import__("os").environ.get("GS_NO_MERGED_RUNS")   # A/B switch: see _train_step_merged
         self._merged = None
+        # The WHOLE iteration as one hipGraph with both optimizer steps inside (see "one graph per iteration" above _capture_merged)
+        self.fuse_iteration = not __import__("os").environ.get("GS_NO_FUSED_ITERATION")
+        self._opt_scalars = None      # functional.DeviceScalars: [lr_t of the discriminator's step, lr_t of the generator's PENDING step | < 0]
+        self._before_fake = None      # hook: issued on the fake pass's stream right before the generator's forward of a discriminator run
+        self._g_pending = None        # lr_t of a generator step whose gradient is in the flat buffer and whose update has not run yet
         self._marks = {}
         self._serial_run = False
         self._branched = False
@@ -510,6 +515,7 @@ class GANSynth(object):
         real_part, penalty = part_a
         fake_weight = hp.get("fake_gradient_penalty_weight", 0.0)
         with self._branch("d_root"):   # the whole fake pass beside the real one (its backward then runs on the branch as well)
+            self._run_before_fake()
             with torch.no_grad():  # var_list is the discriminator's only: no generator backward (models.py:86-89)
                 fake_images = self.generator(latents, labels)
             if fake_weight:   # tf.gradients(fake_logits, [fake_images]) (models.py:51): the images are the point of differentiation
@@ -535,6 +541,7 @@ class GANSynth(object):
         _, real_images, x_real, depth, fresh, real_call = part_a
         owner = self.discriminator.__self__
         with self._branch("d_root"), torch.no_grad():  # var_list is the discriminator's only: no generator backward (models.py:86-89); beside part A
+            self._run_before_fake()
             fake_images = self.generator(latents, labels)
         x_fake, depth_f, fresh_f = owner.discriminator_trunk(fake_images, labels.shape[1])
         assert depth_f == depth and fresh_f == fresh
@@ -549,6 +556,11 @@ class GANSynth(object):
                 (real_gradients,) = torch.autograd.grad(raw, real_images, grad_outputs=seed, create_graph=True)
             penalty = F.sumsq_rows(real_gradients)
         return F.gan_d_loss_pair(raw, labels, penalty, hp.real_gradient_penalty_weight or 1.0)
+
+    def _run_before_fake(self):
+        hook, self._before_fake = self._before_fake, None
+        if hook is not None:   # (one graph per iteration: the generator's pending update runs HERE, on the fake pass's stream, see _capture_merged)
+            hook()
 
     def discriminator_losses(self, latents, labels, real_images):
         return self._d_losses_b(self._d_losses_a(labels, real_images), latents, labels)
@@ -959,6 +971,15 @@ class GANSynth(object):
         must get here at the same point of its launch sequence.  train() therefore joins on EVERY rank before a rank-0 checkpoint
         and at its end; synchronize(), state_dict / checkpoint.save and generate() called by hand on a distributed model must be
         called on all ranks (`collective_pending()` tells whether the call would communicate)."""
+        if self._g_pending is not None:   # (one graph per iteration: the generator's update rides at the front of the NEXT graph -- or here)
+            lr_t, self._g_pending = self._g_pending, None
+            hp = self.hyper_params
+            if self.distributed:
+                self._reduce(self.g_params)
+            zero = not self.keep_gradients
+            kernels.get().adam_tf_step(self.g_params.flat, self.g_params.grad, self.g_params.m, self.g_params.v, lr_t, hp.generator_beta1,
+                                       hp.generator_beta2, 1.0e-8, 1.0 / self.world, zero_grad=zero)
+            self.g_params.grad_clean = zero
         if self._pipe is not None and self._pipe.get("g_pending"):
             hp = self.hyper_params
             P = self._pipe
@@ -973,6 +994,8 @@ class GANSynth(object):
     def collective_pending(self):
         """True when the next _join_updates() / synchronize() / generate() / checkpoint would issue a gradient all-reduce (the
         pipelined data-parallel step leaves the generator's gradient unreduced until the next discriminator graph)."""
+        if self.distributed and self.world > 1 and self._g_pending is not None:
+            return True
         return bool(self.distributed and self.world > 1 and self._pipe is not None and self._pipe.get("g_pending")
                     and self._pipe.get("g_unreduced"))
 
@@ -1182,7 +1205,34 @@ class GANSynth(object):
         dp_ok = not self.distributed or (self._comm is not None and self._graph_allreduce and not self._overlap_in_graph())
         return (self.merge_runs and self.fork and self._graphable() and dp_ok and self._fused_losses() and hasattr(kernels.get(), "lib"))
 
-    def _capture_merged(self, d_inputs, g_inputs):
+    # One graph per iteration (round 6; `fuse_iteration`, GS_NO_FUSED_ITERATION=1 returns to the pair above).  The two optimizer steps were the
+    # only eager launches left between the graphs -- lr_t is a by-value scalar -- and with them outside, (i) every iteration pays two graph
+    # boundaries, (ii) nothing can run beside an update, and (iii) data parallel, an all-reduce can only be the LAST node of a graph: exposed.
+    # gs_adam_tf_step_dev reads lr_t from device memory, so the whole iteration is ONE graph Z:
+    #     Z_k = { D real pass + R1 first-order pass        ||  [all-reduce G_{k-1}] -> Adam G_{k-1} -> refresh G -> D run's fake pass }
+    #           -> D loss -> { D backward, contraction [all-reduce D_k] -> Adam D_k -> refresh D   ||  G.A_k }  ->  G.B_k
+    # The GENERATOR's update of iteration k - 1 rides at the front of Z_k on the fake pass's branch: the discriminator's real pass and its R1
+    # passes need nothing of the generator, and the fake pass (G fwd + D fwd + D bwd = 4 network passes against ~7 on the real side) has the
+    # slack.  Data parallel this is where the generator's all-reduce hides by construction.  The discriminator's update sits where it always
+    # did -- behind its backward -- but part A of the generator run is still in flight beside it.  After Z_k the generator's gradient is
+    # PENDING (`_g_pending` holds its lr_t): the next replay applies it (lr slot >= 0), anything else that needs the weights -- generate(),
+    # a checkpoint, a run outside this path, a new growing regime -- goes through _join_updates() first.  A freshly captured Z finds no
+    # pending step: its lr slot is negative and the kernel leaves every buffer untouched.
+    def _fused_ok(self):
+        return self.fuse_iteration and hasattr(kernels.get(), "adam_tf_step_dev")
+
+    @staticmethod
+    def _lr_t(lr, beta1, beta2, t):
+        return lr * math.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t)
+
+    def _apply_in_graph(self, params, slot, beta1, beta2, reduce_first=False):
+        """The optimizer step as nodes of the graph being captured: [all-reduce] -> Adam with lr_t from the device table -> operand refresh."""
+        if reduce_first:
+            self._reduce_in_capture(params)
+        kernels.get().adam_tf_step_dev(params.flat, params.grad, params.m, params.v, self._opt_scalars.ptr(slot), beta1, beta2, 1.0e-8,
+                                       1.0 / self.world, zero_grad=not self.keep_gradients)
+
+    def _capture_merged(self, d_inputs, g_inputs, fused=False):
         K = kernels.get()
         owner = getattr(self.generator, "__self__", None)
         _, fade = self._regime()
@@ -1210,6 +1260,14 @@ class GANSynth(object):
                     params.grad.zero_()
                     params.grad_clean = True
             K.refresh_weights()   # (see _run: the captured graphs hold no re-layout launches)
+            hp = self.hyper_params
+            if fused:
+                if self._opt_scalars is None:
+                    self._opt_scalars = F.DeviceScalars(self.g_params.flat.device, 2)
+                # the per-network refresh launches read descriptor tables that are built (host -> device) on first use: not inside a capture
+                for params in (self.d_params, self.g_params):
+                    K.invalidate_weights(params.flat)
+                    K.refresh_weights(params.flat)
             try:
                 gx = torch.cuda.CUDAGraph()
                 self._captured_reduce = False
@@ -1217,6 +1275,11 @@ class GANSynth(object):
                     main = torch.cuda.current_stream()
                     side2 = self._second_stream("_side2", [main, self._side])
                     box = []
+                    if fused:
+                        # the generator's PENDING step at the front of the fake pass's branch (no stream of its own: the branch is its only
+                        # consumer until the join, and a graph one branch wider would need one more of the runtime's four hardware queues)
+                        self._before_fake = lambda: self._apply_in_graph(self.g_params, 1, hp.generator_beta1, hp.generator_beta2,
+                                                                         reduce_first=with_collective)
 
                     def part_a_of_g():
                         # from the discriminator run's loss on its second half is one stream wide (R1 double-backward, the real pass's backward,
@@ -1233,23 +1296,47 @@ class GANSynth(object):
                         self._after_loss = part_a_of_g
                     d_loss = self._forward_backward("d", *sd)    # (data parallel: ends with the all-reduce of the discriminator's gradient, _part_b)
                     g_part_a = box[0]
+                    if fused:
+                        if self._before_fake is not None:
+                            raise RuntimeError("the discriminator run never reached its fake pass: the generator's pending step has no place in the graph")
+                        # the discriminator's step, behind its (all-reduced) gradient; part A of the generator run is still in flight beside it
+                        self._apply_in_graph(self.d_params, 0, hp.discriminator_beta1, hp.discriminator_beta2)
                     main.wait_stream(side2)                      # ... join at its end
-                reduced[0] = self._captured_reduce
-                gy = torch.cuda.CUDAGraph()
+                    if fused:   # part B of the generator run in the same graph (reads the discriminator just updated)
+                        reduced[0] = self._captured_reduce
+                        self.g_params.requires_grad_(True)
+                        self.d_params.requires_grad_(False)
+                        self._side2.wait_stream(main)            # (as in the pair's second graph: the generator's nodes run on their stream again)
+                        self._nodes_on_side2 = True
+                        self._pipe_capture = True                # (no all-reduce at the end of THIS run: it opens the next graph, beside the real pass)
+                        try:
+                            g_loss = self._part_b("g", g_part_a, sg[1])
+                        finally:
+                            self._nodes_on_side2 = False
+                            self._pipe_capture = False
+                        reduced[1] = reduced[0]
+                if not fused:
+                    reduced[0] = self._captured_reduce
+                gy = None if fused else torch.cuda.CUDAGraph()
                 self._captured_reduce = False
-                with _quiet_gc(), self._leveled_queues(), self._stream_guard(), torch.cuda.graph(gy, pool=gx.pool(), **_capture_mode(with_collective, self.fork)):
-                    self.g_params.requires_grad_(True)           # (the discriminator run in between armed the other network)
-                    self.d_params.requires_grad_(False)
-                    # the generator's nodes will run on their stream again (autograd): it joins THIS capture here, from the root, as a child of
-                    # the capturing stream -- joining later through an event of the other branch (the discriminator's gradient arrives from
-                    # there) made the two branches each other's parent and hip::Stream::EndCapture recursed until the stack ran out
-                    self._side2.wait_stream(torch.cuda.current_stream())
-                    self._nodes_on_side2 = True
-                    try:
-                        g_loss = self._part_b("g", g_part_a, sg[1])
-                    finally:
-                        self._nodes_on_side2 = False
-                reduced[1] = self._captured_reduce
+                with (contextlib.nullcontext() if fused else contextlib.ExitStack()) as stack:
+                    if not fused:
+                        for cm in (_quiet_gc(), self._leveled_queues(), self._stream_guard(),
+                                   torch.cuda.graph(gy, pool=gx.pool(), **_capture_mode(with_collective, self.fork))):
+                            stack.enter_context(cm)
+                        self.g_params.requires_grad_(True)           # (the discriminator run in between armed the other network)
+                        self.d_params.requires_grad_(False)
+                        # the generator's nodes will run on their stream again (autograd): it joins THIS capture here, from the root, as a child of
+                        # the capturing stream -- joining later through an event of the other branch (the discriminator's gradient arrives from
+                        # there) made the two branches each other's parent and hip::Stream::EndCapture recursed until the stack ran out
+                        self._side2.wait_stream(torch.cuda.current_stream())
+                        self._nodes_on_side2 = True
+                        try:
+                            g_loss = self._part_b("g", g_part_a, sg[1])
+                        finally:
+                            self._nodes_on_side2 = False
+                if not fused:
+                    reduced[1] = self._captured_reduce
             except RuntimeError as e:
                 if not with_collective:
                     raise
@@ -1263,15 +1350,19 @@ class GANSynth(object):
         finally:
             owner.fade_weight = None
             self._after_loss = None   # (a capture that raised before the discriminator run's loss must not leave the hook armed for an unrelated run)
+            self._before_fake = None
             self._nodes_on_side2 = False
-        return {"x": gx, "y": gy, "sd": sd, "sg": sg, "d_loss": d_loss, "g_loss": g_loss, "keep": self.keep_gradients, "reduced": reduced,
+            self._pipe_capture = False
+        return {"fused": fused, "x": gx, "y": gy, "sd": sd, "sg": sg, "d_loss": d_loss, "g_loss": g_loss, "keep": self.keep_gradients, "reduced": reduced,
                 "consts": F.constants_snapshot()}
 
     def _train_step_merged(self, d_latents, d_labels, real_images, g_latents, g_labels):
         hp = self.hyper_params
-        self._join_updates()
         head, fade = self._regime()
-        key = (head, fade is None, self.keep_gradients)
+        fused = self._fused_ok()
+        key = (head, fade is None, self.keep_gradients, fused)
+        if not (fused and self._merged is not None and self._merged["key"] == key):
+            self._join_updates()   # (the one-graph iteration applies a pending generator step itself, at the front of the replay)
         if fade is not None:
             if self._lerp is None:
                 self._lerp = F.DeviceLerp(self.g_params.flat.device)
@@ -1280,11 +1371,12 @@ class GANSynth(object):
         M = self._merged
         if (M is None or M["key"] != key
                 or any(a.shape != b.shape or a.dtype != b.dtype for a, b in zip(M["sd"] + M["sg"], d_in + g_in))):
+            self._join_updates()   # (a pending generator step belongs to the graph being dropped)
             if M is not None and M["key"][:2] != key[:2]:
                 F.drop_constants()   # (a new growing regime: see _run)
             self._graphs.clear()
             self._merged = None
-            M = self._capture_merged(d_in, g_in)
+            M = self._capture_merged(d_in, g_in, fused=fused)
             if M is None:   # (data parallel: the collectives were refused by the capture on some rank)
                 d_loss = self.discriminator_step(d_latents, d_labels, real_images)
                 g_loss = self.generator_step(g_latents, g_labels)
@@ -1298,6 +1390,23 @@ class GANSynth(object):
                 if not params.grad_clean:
                     params.grad.zero_()
                 params.grad_clean = False
+        if M["fused"]:
+            zero = not self.keep_gradients
+            self.d_params.t += 1
+            self.g_params.t += 1
+            lr_d = self._lr_t(hp.discriminator_learning_rate, hp.discriminator_beta1, hp.discriminator_beta2, self.d_params.t)
+            self._opt_scalars.set([lr_d, -1.0 if self._g_pending is None else self._g_pending])   # (stream-ordered before the replay)
+            armed(self.d_params)
+            if self._g_pending is None:
+                armed(self.g_params)      # (no step at the front of this replay: the buffer must already be clean)
+            self._g_pending = None
+            M["x"].replay()
+            self.d_params.grad_clean = zero
+            self.g_params.grad_clean = False   # (holds the gradient of the step that is now pending)
+            self._g_pending = self._lr_t(hp.generator_learning_rate, hp.generator_beta1, hp.generator_beta2, self.g_params.t)
+            self.global_step += 1  # models.py:84
+            self.discriminator_loss, self.generator_loss = M["d_loss"], M["g_loss"]
+            return M["d_loss"], M["g_loss"]
         armed(self.d_params)
         M["x"].replay()
         self._apply(self.d_params, hp.discriminator_learning_rate, hp.discriminator_beta1, hp.discriminator_beta2, reduced=M["reduced"][0])

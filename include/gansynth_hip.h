@@ -406,6 +406,12 @@ int gs_adam_tf_step(float* p, const float* g, float* m, float* v, int64_t numel,
  * flat gradient buffers are accumulated into across a run, so the update hands the next run a zeroed buffer without a fill pass */
 int gs_adam_tf_step_zero_grad(float* p, float* g, float* m, float* v, int64_t numel, float lr_t, float beta1,
                               float beta2, float eps, float grad_scale, void* stream);
+/* the same step with lr_t READ FROM DEVICE MEMORY at execution time (`lr_t_dev[0]`, written by the caller stream-ordered ahead of the
+ * launch): a by-value scalar would be frozen into a captured hipGraph, and with the optimizer step inside the iteration's graph no eager
+ * launch is left between the two runs of models.py:191-192.  A NEGATIVE value means "no step pending": every buffer is left untouched
+ * (the first replay of a graph that starts with the PREVIOUS iteration's update).  zero_grad != 0: g is cleared behind the update. */
+int gs_adam_tf_step_dev(float* p, float* g, float* m, float* v, int64_t numel, const float* lr_t_dev, float beta1,
+                        float beta2, float eps, float grad_scale, int zero_grad, void* stream);
 
 /* ------------------------------------------------------------------------------ spectral
  * spectral_ops.py:45-94.  Plan = immutable per-device tables (Hann window, twiddles, CSR mel matrix

@@ -1,5 +1,5 @@
 """Replays the forked generator-run graph several times on the same state and lists the kernel-layer operands / results that differ
-between the replays (copies of every tensor argument and result are captured with the run: kernels._StreamGuard, _dbg_record)."""
+between the replays (copies of every tensor argument and result are captured with the run: kernels._StreamGuard.hook)."""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -18,19 +18,38 @@ variables.default_store().load_state_dict({**gp, **dp})
 K = kernels.get()
 which = os.environ.get("DBG_RUN", "g")
 inputs = (lat, lab) if which == "g" else (lat, lab, real)
-K._dbg_record = None
 rec = []
 keepalive = []
+recording = [False]
+
+
+def record_hook(inner, name):
+    """kernels._StreamGuard.hook: copies of every operand and result of every kernel-layer call, captured WITH the run (which tensor differs
+    between two replays?); DBG_KEEP: nothing a kernel touched is freed -- hence no block reused -- before `keepalive` is dropped."""
+    def wrapper(*a, **kw):
+        if not recording[0]:
+            return inner(*a, **kw)
+        stream = torch.cuda.current_stream()
+        ins = [(i, t.data_ptr(), t.numel() * t.element_size(), t.clone()) for i, t in enumerate(list(a) + list(kw.values()))
+               if isinstance(t, torch.Tensor) and t.is_cuda]
+        out = inner(*a, **kw)
+        if os.environ.get("DBG_KEEP"):
+            keepalive.append((a, kw, out))
+        outs = [(i, t.data_ptr(), t.numel() * t.element_size(), t.clone()) for i, t in enumerate(out if isinstance(out, (tuple, list)) else (out,))
+                if isinstance(t, torch.Tensor) and t.is_cuda]
+        rec.append((name, int(stream.cuda_stream), ins, outs))
+        return out
+    return wrapper
+
+
+kernels._StreamGuard.hook = staticmethod(record_hook)
 orig = model._forward_backward
 def fb(w, *a):
-    if torch.cuda.is_current_stream_capturing():
-        K._dbg_record = rec
-        if os.environ.get("DBG_KEEP"):
-            K._dbg_keep = keepalive
+    recording[0] = torch.cuda.is_current_stream_capturing()
     try:
         return orig(w, *a)
     finally:
-        K._dbg_record = None
+        recording[0] = False
 model._forward_backward = fb
 
 def checksum(t):
