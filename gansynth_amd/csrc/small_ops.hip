@@ -651,13 +651,15 @@ __global__ __launch_bounds__(256) void gan_d_loss_kernel(const T* __restrict__ r
         float r = 0.f, f = 0.f;
         for (int k = lane; k < c; k += 64) {
             const float l = DT<T>::ld(lab + (long)i * c + k);
-            r += DT<T>::ld(rl + (long)i * c + k) * l;
-            f += DT<T>::ld(fl + (long)i * c + k) * l;
+            if (rl) r += DT<T>::ld(rl + (long)i * c + k) * l;
+            if (fl) f += DT<T>::ld(fl + (long)i * c + k) * l;
         }
         r = wave_sum(r);
         f = wave_sum(f);
         if (lane == 0) {
-            part += softplus_f(-r) + softplus_f(f) + (pen ? pen_w * pen[i] : 0.f);
+            // (either half of the sum may be absent: the two halves of a discriminator run that keeps its real and its fake pass on two
+            //  streams are two launches, each with its own partial mean -- the gradients are the same numbers either way)
+            part += (rl ? softplus_f(-r) : 0.f) + (fl ? softplus_f(f) : 0.f) + (pen ? pen_w * pen[i] : 0.f);
             if (g_pen) g_pen[i] = pen_w * inv_n;
             sr[i] = -sigmoid_f(-r) * inv_n;   // d mean / d r_i
             sf[i] = sigmoid_f(f) * inv_n;     // d mean / d f_i
@@ -668,8 +670,8 @@ __global__ __launch_bounds__(256) void gan_d_loss_kernel(const T* __restrict__ r
     __syncthreads();
     for (int e = threadIdx.x; e < n * c; e += 256) {
         const float l = DT<T>::ld(lab + e);
-        DT<T>::st(g_real + e, sr[e / c] * l);
-        DT<T>::st(g_fake + e, sf[e / c] * l);
+        if (rl) DT<T>::st(g_real + e, sr[e / c] * l);
+        if (fl) DT<T>::st(g_fake + e, sf[e / c] * l);
     }
 }
 
@@ -685,10 +687,10 @@ __global__ __launch_bounds__(256) void gan_g_loss_kernel(const T* __restrict__ f
     const int lane = threadIdx.x & 63;
     for (int i = threadIdx.x >> 6; i < n; i += 4) {   // a wave per sample (see gan_d_loss_kernel)
         float f = 0.f;
-        for (int k = lane; k < c; k += 64) f += DT<T>::ld(fl + (long)i * c + k) * DT<T>::ld(lab + (long)i * c + k);
+        if (fl) for (int k = lane; k < c; k += 64) f += DT<T>::ld(fl + (long)i * c + k) * DT<T>::ld(lab + (long)i * c + k);
         f = wave_sum(f);
         if (lane == 0) {
-            part += softplus_f(-f);
+            if (fl) part += softplus_f(-f);   // (absent: the mode-seeking half alone, see gan_d_loss_kernel)
             sf[i] = -sigmoid_f(-f) * inv_n;
             if (ssq) {
                 const float d = ssq[i] + eps;
@@ -700,7 +702,7 @@ __global__ __launch_bounds__(256) void gan_g_loss_kernel(const T* __restrict__ f
     const float tot = block_sum<256>(part, red);
     if (threadIdx.x == 0) loss[0] = tot * inv_n;
     __syncthreads();
-    for (int e = threadIdx.x; e < n * c; e += 256) DT<T>::st(g_fake + e, sf[e / c] * DT<T>::ld(lab + e));
+    if (fl) for (int e = threadIdx.x; e < n * c; e += 256) DT<T>::st(g_fake + e, sf[e / c] * DT<T>::ld(lab + e));
 }
 
 }  // namespace gs
@@ -709,7 +711,8 @@ using namespace gs;
 
 extern "C" int gs_gan_d_loss(const void* real_logits, const void* fake_logits, const void* labels, const float* penalty, float penalty_weight, int n, int c,
                              float* loss, void* g_real, void* g_fake, float* g_penalty, int dtype, void* stream) {
-    GS_CHECK_ARG(n > 0 && n <= 1024 && c > 0 && real_logits && fake_logits && labels && loss && g_real && g_fake, "gan_d_loss: bad args (batch %d <= 1024)", n);
+    GS_CHECK_ARG(n > 0 && n <= 1024 && c > 0 && (real_logits || fake_logits) && labels && loss && (!real_logits || g_real) && (!fake_logits || g_fake),
+                 "gan_d_loss: bad args (batch %d <= 1024)", n);
     GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gan_d_loss_kernel<T>), dim3(1), dim3(256), 0, as_stream(stream), (const T*)real_logits, (const T*)fake_logits,
                                                 (const T*)labels, penalty, penalty_weight, n, c, loss, (T*)g_real, (T*)g_fake, penalty ? g_penalty : nullptr));
     GS_CHECK_LAUNCH();
@@ -718,7 +721,8 @@ extern "C" int gs_gan_d_loss(const void* real_logits, const void* fake_logits, c
 
 extern "C" int gs_gan_g_loss(const void* fake_logits, const void* labels, const float* sumsq, float weight, float eps, int n, int c, float* loss,
                              void* g_fake, float* g_sumsq, int dtype, void* stream) {
-    GS_CHECK_ARG(n > 0 && n <= 1024 && c > 0 && fake_logits && labels && loss && g_fake && (!sumsq || g_sumsq), "gan_g_loss: bad args (batch %d <= 1024)", n);
+    GS_CHECK_ARG(n > 0 && n <= 1024 && c > 0 && (fake_logits || sumsq) && (!fake_logits || (labels && g_fake)) && loss && (!sumsq || g_sumsq),
+                 "gan_g_loss: bad args (batch %d <= 1024)", n);
     GS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gan_g_loss_kernel<T>), dim3(1), dim3(256), 0, as_stream(stream), (const T*)fake_logits, (const T*)labels, sumsq,
                                                 weight, eps, n, c, loss, (T*)g_fake, g_sumsq));
     GS_CHECK_LAUNCH();

@@ -1275,6 +1275,75 @@ class _GanGLoss(Function):
         return (g_fake * g.to(g_fake.dtype) if ctx.needs_input_grad[0] else None, None, g_sumsq * g if want_ms else None, None, None)
 
 
+class _GanDLossReal(Function):
+    """The real half of L_D: mean(softplus(-r) + penalty) (models.py:39-49, 65) -- a root of its own, so that the backward of the real pass
+    (with the R1 double-backward, the longest chain of the discriminator run) does not wait for the fake pass's forward."""
+
+    @staticmethod
+    def forward(ctx, real_logits, labels, penalty, penalty_weight):
+        loss, g_real, _, g_pen = _K().gan_d_loss(real_logits, None, labels, penalty, penalty_weight)
+        ctx.has_penalty = penalty is not None
+        ctx.save_for_backward(g_real, g_pen if ctx.has_penalty else g_real)
+        return loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        g_real, g_pen = ctx.saved_tensors
+        want_pen = ctx.has_penalty and ctx.needs_input_grad[2]
+        if _is_unit(g):
+            return g_real if ctx.needs_input_grad[0] else None, None, g_pen if want_pen else None, None
+        return g_real * g.to(g_real.dtype) if ctx.needs_input_grad[0] else None, None, g_pen * g if want_pen else None, None
+
+
+class _GanDLossFake(Function):
+    """The fake half of L_D: mean(softplus(f))."""
+
+    @staticmethod
+    def forward(ctx, fake_logits, labels):
+        loss, _, g_fake, _ = _K().gan_d_loss(None, fake_logits, labels, None, 1.0)
+        ctx.save_for_backward(g_fake)
+        return loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (g_fake,) = ctx.saved_tensors
+        if not ctx.needs_input_grad[0]:
+            return None, None
+        return (g_fake if _is_unit(g) else g_fake * g.to(g_fake.dtype)), None
+
+
+class _GanGLossModeSeeking(Function):
+    """The mode-seeking half of L_G: mean(weight / (sumsq + eps)) (models.py:57-64): needs nothing of the discriminator."""
+
+    @staticmethod
+    def forward(ctx, sumsq, weight, eps):
+        loss, _, g_sumsq = _K().gan_g_loss(None, None, sumsq, weight, eps)
+        ctx.save_for_backward(g_sumsq)
+        return loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (g_sumsq,) = ctx.saved_tensors
+        if not ctx.needs_input_grad[0]:
+            return None, None, None
+        return (g_sumsq if _is_unit(g) else g_sumsq * g), None, None
+
+
+def gan_d_loss_real(real_logits, labels, penalty, penalty_weight=1.0):
+    return _GanDLossReal.apply(real_logits, labels, penalty, float(penalty_weight))
+
+
+def gan_d_loss_fake(fake_logits, labels):
+    return _GanDLossFake.apply(fake_logits, labels)
+
+
+def gan_g_loss_mode_seeking(sumsq, weight, eps):
+    return _GanGLossModeSeeking.apply(sumsq, float(weight), float(eps))
+
+
 class _GanDLossPair(Function):
     """_GanDLoss on ONE logits tensor holding the real batch's rows followed by the fake batch's (the discriminator tail run once over
     both, models.GANSynth._d_losses_b): same kernel, the two gradients written into the halves of one tensor."""

@@ -910,35 +910,48 @@ class HipKernels(object):
         return out
 
     def gan_d_loss(self, real_logits, fake_logits, labels, penalty, penalty_weight=1.0, out=None):
-        """(loss, g_real_logits, g_fake_logits, g_penalty): mean of softplus(-r) + softplus(f) + penalty_weight * penalty and its gradients, one launch."""
-        real_logits, fake_logits = _act(real_logits), _act(fake_logits)
-        labels = _match(labels, real_logits)
-        n, c = real_logits.shape
-        loss = torch.empty((), dtype=torch.float32, device=real_logits.device)
-        g_real, g_fake = (torch.empty_like(real_logits), torch.empty_like(fake_logits)) if out is None else out
+        """(loss, g_real_logits, g_fake_logits, g_penalty): mean of softplus(-r) + softplus(f) + penalty_weight * penalty and its gradients, one launch.
+        Either logits tensor may be None (the other half of the sum is then another launch: see include/gansynth_hip.h)."""
+        real_logits = None if real_logits is None else _act(real_logits)
+        fake_logits = None if fake_logits is None else _act(fake_logits)
+        ref = real_logits if real_logits is not None else fake_logits
+        labels = _match(labels, ref)
+        n, c = ref.shape
+        loss = torch.empty((), dtype=torch.float32, device=ref.device)
+        if out is None:
+            g_real = None if real_logits is None else torch.empty_like(real_logits)
+            g_fake = None if fake_logits is None else torch.empty_like(fake_logits)
+        else:
+            g_real, g_fake = out
         pp = g_pen = None
         if penalty is not None:
             penalty = _f32c(penalty)
             pp = penalty.data_ptr()
-            g_pen = torch.empty((n,), dtype=torch.float32, device=real_logits.device)
-        _lib.check(self.lib.gs_gan_d_loss(real_logits.data_ptr(), fake_logits.data_ptr(), labels.data_ptr(), pp, float(penalty_weight), n, c, loss.data_ptr(),
-                                          g_real.data_ptr(), g_fake.data_ptr(), None if g_pen is None else g_pen.data_ptr(), _dt(real_logits), _stream()),
-                   "gs_gan_d_loss")
+            g_pen = torch.empty((n,), dtype=torch.float32, device=ref.device)
+        ptr = lambda t: None if t is None else t.data_ptr()
+        _lib.check(self.lib.gs_gan_d_loss(ptr(real_logits), ptr(fake_logits), labels.data_ptr(), pp, float(penalty_weight), n, c, loss.data_ptr(),
+                                          ptr(g_real), ptr(g_fake), ptr(g_pen), _dt(ref), _stream()), "gs_gan_d_loss")
         return loss, g_real, g_fake, g_pen
 
     def gan_g_loss(self, fake_logits, labels, sumsq, weight, eps):
-        """(loss, g_fake_logits, g_sumsq): mean of softplus(-f) + weight / (sumsq + eps) and its gradients, one launch."""
-        fake_logits = _act(fake_logits)
-        labels = _match(labels, fake_logits)
-        n, c = fake_logits.shape
-        loss = torch.empty((), dtype=torch.float32, device=fake_logits.device)
-        g_fake = torch.empty_like(fake_logits)
+        """(loss, g_fake_logits, g_sumsq): mean of softplus(-f) + weight / (sumsq + eps) and its gradients, one launch.  `fake_logits` None:
+        the mode-seeking half alone."""
         sp = gp = None
         g_sumsq = None
         if sumsq is not None:
             sumsq = _f32c(sumsq)
             g_sumsq = torch.empty_like(sumsq)
             sp, gp = sumsq.data_ptr(), g_sumsq.data_ptr()
+        if fake_logits is None:
+            loss = torch.empty((), dtype=torch.float32, device=sumsq.device)
+            _lib.check(self.lib.gs_gan_g_loss(None, None, sp, float(weight), float(eps), sumsq.numel(), 1, loss.data_ptr(), None, gp, _lib.GS_F32, _stream()),
+                       "gs_gan_g_loss")
+            return loss, None, g_sumsq
+        fake_logits = _act(fake_logits)
+        labels = _match(labels, fake_logits)
+        n, c = fake_logits.shape
+        loss = torch.empty((), dtype=torch.float32, device=fake_logits.device)
+        g_fake = torch.empty_like(fake_logits)
         _lib.check(self.lib.gs_gan_g_loss(fake_logits.data_ptr(), labels.data_ptr(), sp, float(weight), float(eps), n, c, loss.data_ptr(), g_fake.data_ptr(), gp,
                                           _dt(fake_logits), _stream()), "gs_gan_g_loss")
         return loss, g_fake, g_sumsq

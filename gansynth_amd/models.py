@@ -44,6 +44,9 @@ LEVEL_STREAMS = int(__import__("os").environ.get("GS_LEVEL_STREAMS", "128"))   #
 EARLY_FLUSH_DIVS = [int(d) for d in __import__("os").environ.get("GS_EARLY_FLUSH_DIV", "16").split(",")]   # a layer is "large" from 1/DIV of the full resolution's pixels (several: one early contraction each)
 EARLY_FLUSH_CUS = int(__import__("os").environ.get("GS_EARLY_FLUSH_CUS", "192"))   # see GANSynth._early_flush
 _MERGED_AT_ROOT = bool(__import__("os").environ.get("GS_MERGED_AT_ROOT"))   # A/B switch, see _capture_merged
+_HOOK_BEFORE_BACKWARD = not __import__("os").environ.get("GS_HOOK_AFTER_BACKWARD")   # A/B switch, see _part_b
+_SUB_RUNS = bool(__import__("os").environ.get("GS_SUB_RUNS"))   # opt-in (measured slower, see _d_sub_runs): the discriminator run as two independent sub-runs
+_FAKE_FIRST = bool(__import__("os").environ.get("GS_FAKE_FIRST"))   # opt-in, see _d_fake_first
 _FORK_EAGER = bool(__import__("os").environ.get("GS_FORK_EAGER"))   # tests: the same branches with eager launches (a second stream, event hops)
 
 
@@ -258,6 +261,12 @@ class GANSynth(object):
         self.fuse_iteration = not __import__("os").environ.get("GS_NO_FUSED_ITERATION")
         self._opt_scalars = None      # functional.DeviceScalars: [lr_t of the discriminator's step, lr_t of the generator's PENDING step | < 0]
         self._before_fake = None      # hook: issued on the fake pass's stream right before the generator's forward of a discriminator run
+        self._in_sub_runs = False
+        self._early_on_side2 = False
+        self._fake_logits_early = None
+        self.fake_first = _FAKE_FIRST   # (see _d_fake_first)
+        self._g_ready = None          # event: the generator's weights (and prepared operands) of this iteration are final on the fake pass's stream
+        self.sub_runs = _SUB_RUNS
         self._g_pending = None        # lr_t of a generator step whose gradient is in the flat buffer and whose update has not run yet
         self._marks = {}
         self._serial_run = False
@@ -374,6 +383,18 @@ class GANSynth(object):
             if on_side2:
                 self._origin.wait_stream(self._side2)
                 with torch.cuda.stream(self._origin):
+                    K.flush_wgrad_reductions(select=select)
+                return
+            if self._in_sub_runs and not on_branch and self._forking():
+                # Sub-runs (_d_sub_runs): the side stream belongs to the fake sub-run, which is issued AFTER this backward and must start at
+                # the graph's root, not behind this contraction: the contraction goes to the third stream (part A of the generator run is
+                # issued on it later still; the final contraction waits for it, _join_branches)
+                main = torch.cuda.current_stream()
+                third = self._second_stream("_side2", [main, self._side])
+                third.wait_stream(main)
+                self._early_on_side2 = True
+                self.branches_opened += 1
+                with torch.cuda.stream(third):
                     K.flush_wgrad_reductions(select=select)
                 return
             with (contextlib.nullcontext() if on_branch else self._branch(join=False)):   # (a node of the branch itself: in place)
@@ -514,6 +535,12 @@ class GANSynth(object):
             return self._d_losses_b_batched(part_a, latents, labels)
         real_part, penalty = part_a
         fake_weight = hp.get("fake_gradient_penalty_weight", 0.0)
+        if fused and self._sub_runs_ok():
+            return self._d_sub_runs(real_part, penalty, latents, labels)
+        early, self._fake_logits_early = self._fake_logits_early, None
+        if early is not None and fused:   # (the fake pass was issued in front of the real one, _issue_fake_pass_first: only the join is left)
+            torch.cuda.current_stream().wait_stream(self._side)
+            return F.gan_d_loss(real_part, early, labels, penalty, hp.real_gradient_penalty_weight or 1.0)
         with self._branch("d_root"):   # the whole fake pass beside the real one (its backward then runs on the branch as well)
             self._run_before_fake()
             with torch.no_grad():  # var_list is the discriminator's only: no generator backward (models.py:86-89)
@@ -532,6 +559,53 @@ class GANSynth(object):
                 (fake_gradients,) = torch.autograd.grad(fake_logits.sum(), fake_images, create_graph=True)
             losses = losses + F.sumsq_rows(fake_gradients) * fake_weight
         return losses
+
+    # The discriminator run as TWO INDEPENDENT SUB-RUNS (round 6).  L_D = mean(softplus(-r) + penalty) + mean(softplus(f)): the real pass with
+    # its R1 passes and the fake pass share nothing but the parameters (leaves) -- two disjoint autograd graphs, two backward calls, one sum of
+    # gradients.  With ONE loss node (gs_gan_d_loss over r and f) the real side's backward -- R1 double-backward + the real pass's own, the
+    # longest chain of the run -- waited for the fake pass's forward, and, in a captured graph, hipGraphLaunch submitted it LAST: the runtime
+    # walks a graph with parallel branches chain by chain, depth first, first-captured child first, at ~3-4.5 us per node
+    # (scripts/probe/graph_order.hip, graph_chains.hip; profiles/r06_c_graph_order.txt, r06_d_graph_chains.txt), so the order things are ISSUED in is
+    # the order they reach the GPU.  Here the critical chain is issued first and whole: real forward, first-order pass, its loss, its backward --
+    # one chain on the capturing stream from the graph's root -- then the fake sub-run on the branch (generator step pending from the previous
+    # iteration, G(z), D, its loss, its backward: it has the slack, and data parallel it starts with the generator's all-reduce, beside the real
+    # pass instead of on the critical path), then part A of the generator run (models._capture_merged).  The loss VALUE is the sum of the two
+    # partial means (last-bit association differs from the one-launch form; the gradients are the same numbers).
+    # MEASURED, and OPT-IN (GS_SUB_RUNS=1) because of it: parity and bit-identity tests green, and 5.27 -> 5.98 ms (profiles/r06_e_sub_runs_ab.txt;
+    # 5.46 without the early contraction's extra branch, r06_f_*): in the replay the fake sub-run's first node started when the real sub-run's
+    # LAST node finished (profiles/r06_e_graph_sequence.txt) -- three chains that share nothing ran one after the other.  The runtime maps the
+    # chains it finds (depth first) onto its four hardware queues in discovery order, chains that land on one queue run in submission order
+    # (graph_chains.hip: the fifth of five parallel chains starts when the first ends), and which chain lands where is not ours to choose.
+    # The one-loss form below is what the runtime happens to schedule well: its join at the loss cuts the chains short.
+    def _sub_runs_ok(self):
+        # (also WITHOUT branches -- everything on the one stream, same order: a plain and a forked schedule then issue the same launches in the
+        #  same order and stay bit-identical, tests/test_model_gpu.py::test_forked_branches_change_nothing_but_the_schedule)
+        if self._forking() and not self.fork_marks:
+            return False   # (the fake sub-run must start at the run's root, not behind the real sub-run's backward)
+        return (self.sub_runs and self._serial_run and hasattr(F, "gan_d_loss_real") and hasattr(kernels.get(), "lib")
+                and not self.hyper_params.get("fake_gradient_penalty_weight", 0.0))
+
+    def _d_sub_runs(self, real_logits, penalty, latents, labels):
+        hp = self.hyper_params
+        weight = hp.real_gradient_penalty_weight or 1.0
+        root = self._marks.pop("d_root", None)
+
+        def real_sub_run():
+            return F.gan_d_loss_real(real_logits, labels, penalty, weight)
+
+        def fake_sub_run():
+            self._run_before_fake()
+            with torch.no_grad():  # var_list is the discriminator's only: no generator backward (models.py:86-89)
+                fake_images = self.generator(latents, labels)
+            _, fake_logits = self.discriminator(fake_images, labels)
+            return F.gan_d_loss_fake(fake_logits, labels)
+
+        def on_branch():
+            if root is not None:
+                self._marks["d_root"] = root
+            return self._branch("d_root", join=False)   # (joined at the end of the run, _part_b)
+
+        return [(contextlib.nullcontext, real_sub_run), (on_branch, fake_sub_run)]
 
     def _d_losses_b_batched(self, part_a, latents, labels):
         """models.py:39-54,65 with the two discriminator passes sharing their tail: logits of [real; fake] from one pass, the R1 term
@@ -561,6 +635,9 @@ class GANSynth(object):
         hook, self._before_fake = self._before_fake, None
         if hook is not None:   # (one graph per iteration: the generator's pending update runs HERE, on the fake pass's stream, see _capture_merged)
             hook()
+        if self._forking():
+            self._g_ready = torch.cuda.Event()
+            self._g_ready.record()
 
     def discriminator_losses(self, latents, labels, real_images):
         return self._d_losses_b(self._d_losses_a(labels, real_images), latents, labels)
@@ -663,10 +740,22 @@ class GANSynth(object):
         self._branched = False
         self._origin = torch.cuda.current_stream() if torch.cuda.is_available() else None   # (the stream this run is issued -- or captured -- on)
         losses = self._d_losses_b(part_a, *inputs, fused=fused) if which == "d" else self._g_losses_b(part_a, *inputs, fused=fused)   # (latents, labels) | (labels,)
-        loss = losses if losses.dim() == 0 else losses.mean()   # (the fused loss kernels return the mean itself)
+        sub_runs = losses if isinstance(losses, list) else None   # [(context factory, forward() -> root)]: see _d_sub_runs
+        loss = None if sub_runs is not None else (losses if losses.dim() == 0 else losses.mean())   # (the fused loss kernels return the mean itself)
         hook, self._after_loss = self._after_loss, None
-        if hook is not None:   # (merged iteration: part A of the other run is issued here, see _capture_merged)
-            hook()
+        loss_mark = None
+        if hook is not None and sub_runs is None:   # (merged iteration: part A of the other run forks off HERE, see _capture_merged)
+            if _HOOK_BEFORE_BACKWARD:
+                hook(None)
+                hook = None
+            else:
+                # ... but it is ISSUED behind this run's backward.  hipGraphLaunch submits a graph with parallel branches chain by chain, depth
+                # first, the children of a fork in the order they were captured, at ~3-4.5 us per node (scripts/probe/graph_order.hip,
+                # profiles/r06_c_graph_order.txt): issued in front of the backward, the 130 nodes of the other run's part A were submitted --
+                # and ran, alone on the chip -- before the first kernel of this run's backward, its critical path (0.8 ms late).
+                loss_mark = torch.cuda.Event()
+                loss_mark.record()
+        self._g_ready = None
         K = kernels.get()
         deferring = _DEFER_REDUCTIONS and hasattr(K, "defer_wgrad_reductions")   # parameter gradients are only read after the whole backward:
         if deferring:                                        # their ~70 slice reductions are folded in one go at the end
@@ -684,13 +773,28 @@ class GANSynth(object):
         launched = []
         if hasattr(F, "reset_fusion_state"):
             F.reset_fusion_state()   # (side-channel state of cross-node fusions is per backward pass)
-        try:
+        def backward(root):
             with (F.params_only() if hasattr(F, "params_only") else contextlib.nullcontext()):   # tf.gradients(loss, var_list): leaf activations want no gradient
-                if loss.is_cuda and loss.dim() == 0 and loss.dtype == torch.float32 and not self._capturing_fresh_seed(loss.device):
-                    torch.autograd.backward(loss, grad_tensors=F.unit_seed(loss.device))   # (the loss heads recognise the seed: functional.unit_seed)
+                if root.is_cuda and root.dim() == 0 and root.dtype == torch.float32 and not self._capturing_fresh_seed(root.device):
+                    torch.autograd.backward(root, grad_tensors=F.unit_seed(root.device))   # (the loss heads recognise the seed: functional.unit_seed)
                 else:
-                    loss.backward()
+                    root.backward()
+
+        roots = []
+        self._in_sub_runs = sub_runs is not None
+        try:
+            if sub_runs is None:
+                backward(loss)
+            else:
+                for context, forward in sub_runs:   # each on its own stream, whole: forward (what is left of it), loss, backward
+                    with context():
+                        root = forward()
+                        if hasattr(F, "reset_fusion_state"):
+                            F.reset_fusion_state()
+                        backward(root)
+                        roots.append(root.detach())
         finally:
+            self._in_sub_runs = False
             if hasattr(F, "reset_fusion_state"):
                 F.reset_fusion_state()   # (the hand-off table holds tensors of this pass -- of a graph's pool while capturing: not beyond it)
             if deferring:
@@ -709,7 +813,15 @@ class GANSynth(object):
                     K.flush_wgrad_reductions()
         if launched:
             self._inflight = (params, launched)
+        if hook is not None:   # (sub-runs: part A of the other run is issued last and starts where the generator's weights are final)
+            hook(loss_mark if sub_runs is None else self._g_ready)
         self._join_branches()   # (a branch opened by the flush itself; a branch left open would fail the capture)
+        if sub_runs is not None:
+            loss = roots[0]
+            for r in roots[1:]:
+                if r.is_cuda:
+                    r.record_stream(torch.cuda.current_stream())   # (made on its sub-run's stream, read here)
+                loss = loss + r
         if self.distributed and self._comm is not None and self._graph_allreduce and self._capturing() and not getattr(self, "_pipe_capture", False):
             # Same-stream RCCL is capturable: the all-reduce of this run's flat gradient becomes the LAST NODE of the run's hipGraph, so
             # a replayed run hands over reduced gradients and no eager collective launch sits between the replay and the update.
@@ -724,7 +836,8 @@ class GANSynth(object):
         if self._branched:
             self._branched = False
             torch.cuda.current_stream().wait_stream(self._side)
-        if self._nodes_on_side2 and self._forking():
+        if (self._nodes_on_side2 or self._early_on_side2) and self._forking():
+            self._early_on_side2 = False
             torch.cuda.current_stream().wait_stream(self._side2)
 
     def _reduce_in_capture(self, params):
@@ -827,12 +940,44 @@ class GANSynth(object):
         try:
             if which == "d":
                 latents, labels, real_images = inputs
+                if self._d_fake_first():
+                    self._issue_fake_pass_first(latents, labels)
                 return self._part_b("d", self._part_a("d", labels, real_images), latents, labels)
             latents, labels = inputs
             return self._part_b("g", self._part_a("g", latents, labels), labels)
         finally:
             self._serial_run = False
             self._marks.clear()
+
+    # Data parallel, one graph per iteration: the discriminator run's FAKE pass is issued -- hence submitted by hipGraphLaunch -- before the real
+    # pass.  It starts with the generator's pending step, i.e. with the all-reduce of the generator's gradient, and the loss needs both passes:
+    # with the real pass first (the one-GPU order) the fake pass starts ~0.4 ms into the graph (the runtime submits the real pass's 86 nodes
+    # first, ~4.5 us each) and an all-reduce in front of it lands on the critical path whole; with the fake pass first the collective starts at
+    # the graph's root and it is the REAL pass that starts ~0.5 ms late -- it is the shorter of the two (no generator forward in it) and needs
+    # nothing of the collective: up to ~0.45 ms of all-reduce should disappear behind a delay that is there anyway.  One GPU: the same delay
+    # with nothing to hide costs ~0.04 ms (5.17 -> 5.21).  MEASURED at world size 1 with 300-us stand-ins for the two collectives
+    # (scripts/dp_marker_check.py, profiles/r06_g_dp_markers.txt): the two stand-ins add 0.43 ms with this order against 0.56 real-first and 0.61
+    # in the two-graph form -- but 0.61 against 0.52 inside tests/test_model_gpu.py's process: which chain of a graph shares a hardware queue
+    # with which depends on the stream pool's history in the process, so the gain is not one to build a default on.  OPT-IN (GS_FAKE_FIRST=1 /
+    # `fake_first`).
+    def _d_fake_first(self):
+        if not (self._forking() and self._capturing() and self.fork_marks and self._fused_losses()) or self._sub_runs_ok():
+            return False
+        if self.batch_d_tail:   # (tests: real and fake through the tail as one batch -- there is no separate fake pass then)
+            return False
+        want = self.fake_first
+        return bool(want) and not self.hyper_params.get("fake_gradient_penalty_weight", 0.0)
+
+    def _issue_fake_pass_first(self, latents, labels):
+        self.g_params.requires_grad_(False)   # (what _part_a("d") arms: the discriminator's nodes must be recorded for its backward)
+        self.d_params.requires_grad_(True)
+        self._fork_mark("d_root")
+        with self._branch("d_root", join=False):   # (joined where the loss needs it, _d_losses_b)
+            self._run_before_fake()
+            with torch.no_grad():  # var_list is the discriminator's only: no generator backward (models.py:86-89)
+                fake_images = self.generator(latents, labels)
+            _, fake_logits = self.discriminator(fake_images, labels)
+        self._fake_logits_early = fake_logits
 
     def _regime(self):
         """(head depth, fade weight or None) of the networks at the current growing depth; None for foreign network objects."""
@@ -1281,11 +1426,14 @@ class GANSynth(object):
                         self._before_fake = lambda: self._apply_in_graph(self.g_params, 1, hp.generator_beta1, hp.generator_beta2,
                                                                          reduce_first=with_collective)
 
-                    def part_a_of_g():
+                    def part_a_of_g(mark=None):
                         # from the discriminator run's loss on its second half is one stream wide (R1 double-backward, the real pass's backward,
                         # the final contraction): part A of the generator run goes THERE (GS_MERGED_AT_ROOT=1: from the graph's root, beside
-                        # the two forward passes)
-                        side2.wait_stream(torch.cuda.current_stream())
+                        # the two forward passes).  `mark`: an event recorded at the loss -- the branch starts there although it is issued later.
+                        if mark is not None:
+                            side2.wait_event(mark)
+                        else:
+                            side2.wait_stream(torch.cuda.current_stream())
                         with torch.cuda.stream(side2):
                             box.append(self._part_a("g", *sg))
                         self.g_params.requires_grad_(False)      # (back to the discriminator run's arming for its backward)

@@ -391,7 +391,10 @@ int gs_row_scale(const void* x, const float* s, float alpha, void* out, int rows
  * labels one-hot (real_logit_i = sum_c logits[i][c] * labels[i][c] = tf.gather_nd(logits, tf.where(labels))):
  *   L_D = mean_i [ softplus(-r_i) + softplus(f_i) + penalty_weight penalty_i ]     penalty: optional (R1 term: sum of squared gradients per example), fp32 [n]
  *   L_G = mean_i [ softplus(-f_i) + weight / (sumsq_i + eps) ]       sumsq: optional, sum((d sum(G(z)) / d z_i)^2), fp32 [n]
- * loss: fp32 scalar; g_*: d loss / d logits ([n][c], activation dtype), g_sumsq: d L_G / d sumsq (fp32 [n]); g_penalty: d L_D / d penalty = penalty_weight / n (fp32 [n], written when penalty is given). */
+ * loss: fp32 scalar; g_*: d loss / d logits ([n][c], activation dtype), g_sumsq: d L_G / d sumsq (fp32 [n]); g_penalty: d L_D / d penalty = penalty_weight / n (fp32 [n], written when penalty is given).
+ * Either half of a sum may be ABSENT (real_logits or fake_logits NULL with its g_*; for L_G fake_logits NULL with sumsq given, c = 1): a run that
+ * keeps two independent passes on two streams takes the loss as two launches, each the partial mean over its own terms -- the gradients are the same
+ * numbers, and no pass waits for the other's forward before its backward starts. */
 int gs_gan_d_loss(const void* real_logits, const void* fake_logits, const void* labels, const float* penalty, float penalty_weight, int n, int c,
                   float* loss, void* g_real, void* g_fake, float* g_penalty, int dtype, void* stream);
 int gs_gan_g_loss(const void* fake_logits, const void* labels, const float* sumsq, float weight, float eps, int n, int c, float* loss,

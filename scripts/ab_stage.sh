@@ -4,7 +4,7 @@
 for round in 1 2; do
 for v in "$@"; do
   cp ab/lib_$v.so gansynth_amd/libgansynth_hip.so
-  python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-spectral --no-launch-count 2>/dev/null | python -c "
+  python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-spectral --no-launch-count --no-f32-leg 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.readline())
 small=sum(r['launches_per_iteration']*r['avg_us'] for r in d['stages'] if not r['stage'].startswith('wgrad') and any(('@ %s x' % s) in r['stage'] for s in ('2x16','4x32','8x64')))

@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace -d /tmp/pg -o g -- python $R/bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-spectral --no-launch-count > /tmp/pg.log 2>&1
+rocprofv3 --kernel-trace -d /tmp/pg -o g -- python $R/bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-spectral --no-launch-count --no-f32-leg > /tmp/pg.log 2>&1
 f=$(find /tmp/pg -name "*.db" | head -1)
 python - <<PY
 import sqlite3,re,collections

@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=${1:-$R/gpurun_out/graph_sequence.txt}
 rm -rf /tmp/pgs
-rocprofv3 --kernel-trace -d /tmp/pgs -o g -- python $R/bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-spectral --no-launch-count > /tmp/pgs.log 2>&1
+rocprofv3 --kernel-trace -d /tmp/pgs -o g -- python $R/bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-spectral --no-launch-count --no-f32-leg > /tmp/pgs.log 2>&1
 f=$(find /tmp/pgs -name "*.db" | head -1)
 python - > $OUT <<PY
 import sqlite3,re,collections

@@ -1027,11 +1027,13 @@ def test_gradient_all_reduce_rides_beside_part_a_of_the_other_run():
         # (the real batch's trunk) and of the generator run (forward + mode-seeking first-order pass) are each well over 300 us of kernels
         batches = [R.synthetic_batch(8, rank=i, image_shape=(2, 128, 1024)) for i in range(3)]
         ms = {}
-        for mode in ("serial", "overlapped"):
+        for mode in ("serial", "one graph", "overlapped"):
             for marker in (0, 300):
                 os.environ["GS_COMM_MARKER_US"] = str(marker)
                 model = _dp_trainer(1.0, batches, full=True, dtype=torch.bfloat16, keep=False)
-                model.overlap_reduce = mode != "serial"
+                model.overlap_reduce = mode == "overlapped"
+                model.fuse_iteration = mode == "one graph"   # (round 6: the iteration as ONE graph, the generator's all-reduce at the front of the NEXT
+                                                             #  iteration's fake pass, issued first -- part of it disappears behind the real pass)
                 for _ in range(3):
                     model.train_step()
                 model.synchronize()
@@ -1045,8 +1047,14 @@ def test_gradient_all_reduce_rides_beside_part_a_of_the_other_run():
                 ms[(mode, marker)] = best
                 del model
         print("ms per iteration (mode, marker us):", {k: round(v, 3) for k, v in ms.items()})
-        assert ms[("serial", 300)] - ms[("serial", 0)] > 0.45          # two 300 us stand-ins on the critical path
+        serial = ms[("serial", 300)] - ms[("serial", 0)]
+        assert serial > 0.45                                            # two 300 us stand-ins on the critical path
         assert ms[("overlapped", 300)] - ms[("overlapped", 0)] < 0.2   # beside part A: neither shows
+        # the one-graph iteration keeps its compute branches (the overlapped form has none: four branchy graphs per iteration would be host-bound);
+        # how much of its two collectives the runtime lets run beside compute is reported, not asserted (profiles/r06_g_dp_markers.txt: 0.37-0.61 ms
+        # of the 0.6 ms, depending on which chains of the graph end up sharing a hardware queue)
+        assert ms[("one graph", 0)] < ms[("overlapped", 0)] - 0.2
+        assert ms[("one graph", 300)] - ms[("one graph", 0)] < serial + 0.2
     finally:
         os.environ.pop("GS_COMM_MARKER_US", None)
         dist.destroy_process_group()
