@@ -691,7 +691,7 @@ def assemble(args, world, distributed, elapsed, prof_steps, family, stages, kern
         "config": {"workload": "BASELINE.json configs[1]: fully grown PGGAN 128x1024x2 G+D iteration (D update + G update, "
                                "R1 + mode-seeking), per-GPU batch %d, random-init weights" % args.batch,
                    "global_batch": global_batch, "parallelism": "dp%d" % world,
-                   "launch": "eager" if args.no_graphs else "hipGraph replay"},
+                   "launch": "eager" if args.no_graphs else (os.environ.get("GS_SINGLE_MODE") or "hipGraph replay")},
         "roofline": family_roofline(args, launches, conv_ms, conv_flops, conv_bytes, roof_ms, roof_ms_hbm, stages, prof_steps, elapsed, detail),
         "model_flops_utilization": value * FLOPS_PER_IMAGE / 1e12 / PEAK[args.dtype] / world,
         "kernel_launches_per_iteration": kernel_launches.get("total") if isinstance(kernel_launches, dict) else None,
@@ -849,6 +849,38 @@ def supervise(args, argv):
     return rc
 
 
+# One GPU: the same idea, smaller.  The forked schedule rests on a workaround for a defect of the HIP runtime (hipGraphLaunch of a graph with
+# parallel branches can walk off its stream list: profiles/r05_e_graph_replay_crash.txt; GANSynth._leveled_queues keeps it away) -- if the
+# workaround's assumption fails on another ROCm build the failure is a segmentation fault inside the runtime, not an exception.  The plain
+# `python bench.py` run therefore is a supervisor around a worker process as well: a worker that dies is started again without branches
+# (GS_NO_FORK=1), then without graphs; the line says which mode ran (`config.launch`, `config.forked_branches`).
+SINGLE_LADDER = [
+    ("hipGraph replay, forked branches", {}, []),
+    ("hipGraph replay, no branches (the forked replay died)", {"GS_NO_FORK": "1"}, []),
+    ("eager launches (graph replay died)", {"GS_NO_FORK": "1"}, ["--no-graphs"]),
+]
+
+
+def supervise_single(args, argv):
+    import subprocess
+    budget = float(os.environ.get("GS_WATCHDOG_SINGLE_S", "1500"))
+    for mode, knobs, extra in SINGLE_LADDER:
+        env = dict(os.environ, GS_SINGLE_MODE=mode, **knobs)
+        try:
+            res = subprocess.run([sys.executable, os.path.abspath(__file__)] + argv + extra + ["--worker"], env=env, stdout=subprocess.PIPE, timeout=budget)
+            rc, out = res.returncode, res.stdout.decode(errors="replace")
+        except subprocess.TimeoutExpired as exc:
+            rc, out = -9, (exc.stdout or b"").decode(errors="replace")
+        line = next((ln for ln in reversed(out.splitlines()) if ln.startswith("{")), None)
+        if rc == 0 and line:
+            sys.stdout.write(line + "\n")
+            sys.stdout.flush()
+            return 0
+        print("bench supervisor: mode %r did not finish (worker rc %s%s); next mode" % (mode, rc, "" if line else ", no line"), file=sys.stderr, flush=True)
+    print("bench supervisor: no mode completed", file=sys.stderr, flush=True)
+    return 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -874,7 +906,7 @@ def main():
     args = ap.parse_args()
     if args.pmc is None:   # (nested passes run with --no-launch-count etc.: they never measure again)
         args.pmc = (args.gpus == 1 and not (args.no_spectral or args.no_cpu_baseline or args.no_launch_count or args.no_graphs or args.spectral_only
-                                            or args.launch_check or args.worker) and not os.environ.get("GS_BENCH_NO_PMC"))
+                                            or args.launch_check) and not os.environ.get("GS_BENCH_NO_PMC"))
 
     if args.gpus > 1 and "RANK" not in os.environ:
         # `python bench.py --gpus N` without a launcher: start the N ranks ourselves -- the same command the driver would use
@@ -891,6 +923,11 @@ def main():
                "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         raise SystemExit(subprocess.call(cmd, env=env))
 
+    if (args.gpus == 1 and not args.worker and "RANK" not in os.environ and not os.environ.get("GS_NO_SUPERVISOR") and not args.no_graphs
+            and not (args.no_spectral or args.no_cpu_baseline or args.no_launch_count or args.spectral_only or args.launch_check)
+            and not os.environ.get("GS_BENCH_FORCE_DIST")):
+        # (the plain one-GPU run -- the configuration the driver times; partial runs stay in-process: profilers wrap them)
+        raise SystemExit(supervise_single(args, [a for a in sys.argv[1:] if a != "--worker"]))
     if (args.gpus > 1 and not args.worker and "RANK" in os.environ and not os.environ.get("GS_NO_SUPERVISOR")
             and (not args.launch_check or os.environ.get("GS_LAUNCH_CHECK_LADDER"))):
         raise SystemExit(supervise(args, [a for a in sys.argv[1:] if a != "--worker"]))
@@ -993,6 +1030,7 @@ def main():
         d_loss, g_loss = model.train_step()
     barrier()
     elapsed = time.perf_counter() - t0
+    one_graph = bool((getattr(model, "_merged", None) or {}).get("fused"))   # (the whole iteration ONE hipGraph, optimizer steps inside)
     # per-kernel roofline: the same iteration launched eagerly with a HIP event pair around every
     # conv_igemm_kernel launch on its own stream (events cannot bracket kernels inside a replayed hipGraph)
     prof_steps = min(args.steps, 5)
@@ -1034,6 +1072,8 @@ def main():
         out, detail = assemble(args, world, distributed, elapsed, prof_steps, (launches, conv_ms, conv_flops, conv_bytes, roof_ms, roof_ms_hbm),
                                stages, kernel_launches, float(d_loss), float(g_loss), legs, whole_step=whole)
         out["detail"] = write_detail(detail)
+        out["config"]["forked_branches"] = bool(getattr(model, "fork", False)) and not args.no_graphs
+        out["config"]["graphs_per_iteration"] = (1 if one_graph else 2) if not args.no_graphs else 0
         if distributed:
             comm = getattr(model, "_comm", None)
             out["rccl_ranks"] = comm.count() if comm is not None else world   # ncclCommCount of the library's own communicator

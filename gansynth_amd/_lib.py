@@ -34,6 +34,7 @@ SIGNATURES = {
     "gs_comm_destroy": (I, [P]),
     "gs_comm_count": (I, [P, POINTER(I)]),
     "gs_allreduce_sum_f32": (I, [P, P, ctypes.c_int64, P]),
+    "gs_comm_set_marker_us": (I, [P, ctypes.c_double]),
     "gs_broadcast_f32": (I, [P, P, ctypes.c_int64, I, P]),
     "gs_conv2d_workspace_bytes": (Z, [I, I, I, I, I, I, I, I, I]),
     "gs_conv2d_fwd": (I, [P, P, P, I, I, I, I, I, I, I, F, I, I, P, Z, P]),

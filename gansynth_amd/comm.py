@@ -10,6 +10,7 @@ import ctypes
 import torch
 
 from . import _lib
+from . import config
 from . import kernels
 
 
@@ -57,6 +58,13 @@ class RcclComm(object):
             self.close()
             raise RuntimeError("RCCL communicator of libgansynth_hip.so could not be created on every rank (rank %d: %s)"
                                % (self.rank, error if error is not None else "ok here, failed on a peer"))
+        marker = config.value("GS_COMM_MARKER_US")   # (tests / profiles at world size 1: read ONCE, here -- the all-reduce itself reads no environment)
+        if marker is not None and self.world == 1:
+            self.set_marker_us(float(marker))
+
+    def set_marker_us(self, us):
+        """Tests / profiles, world size 1 only: the all-reduce becomes a one-block kernel holding its stream for `us` microseconds."""
+        _lib.check(self.lib.gs_comm_set_marker_us(self.handle, float(us)), "gs_comm_set_marker_us")
 
     def all_reduce_(self, tensor):
         assert tensor.dtype == torch.float32 and tensor.is_contiguous() and tensor.is_cuda

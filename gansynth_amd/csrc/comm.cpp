@@ -58,6 +58,7 @@ int load_rccl() {
 struct gs_comm {
     ncclComm_t comm;
     int rank, world;
+    double marker_us = -1.0;   // (test hook of ONE-rank communicators, gs_comm_set_marker_us; < 0: off)
 };
 
 extern "C" int gs_comm_available(void) { return load_rccl(); }
@@ -97,31 +98,29 @@ extern "C" int gs_comm_destroy(gs_comm* c) {
 }
 
 // World size 1 is the only one the development box has, and RCCL short-cuts a one-rank in-place all-reduce to nothing -- no node in a
-// captured graph, nothing to see in a timeline.  GS_COMM_MARKER_US=<n> (tests / profiles only) puts a stand-in there: one block that
-// occupies the stream for n microseconds (0: a no-op kernel), so that where the collective sits in a graph -- beside part A of the
-// other run, or on its critical path -- shows up as time.
+// captured graph, nothing to see in a timeline.  gs_comm_set_marker_us (tests / profiles only, refused on a communicator with peers) puts a
+// stand-in there: one block that occupies the stream for n microseconds (0: a no-op kernel), so that where the collective sits in a graph --
+// beside other work, or on the critical path -- shows up as time.  The all-reduce itself reads no environment.
 static __global__ void comm_marker_kernel(const float* data, long long ticks) {
     const long long t0 = wall_clock64();   // (100 MHz constant clock)
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
     if (ticks < 0) const_cast<float*>(data)[0] = 0.f;   // (never: keeps the argument alive)
 }
 
+extern "C" int gs_comm_set_marker_us(gs_comm* c, double us) {
+    GS_CHECK_ARG(c, "gs_comm_set_marker_us: null communicator");
+    GS_CHECK_ARG(c->world == 1 || us < 0.0, "gs_comm_set_marker_us: a stand-in only replaces the all-reduce of a ONE-rank communicator (this one has %d)", c->world);
+    c->marker_us = us < 0.0 ? -1.0 : (us > 10000.0 ? 10000.0 : us);   // (clamped: a typo cannot park the stream)
+    return 0;
+}
+
 extern "C" int gs_allreduce_sum_f32(gs_comm* c, float* data, int64_t count, void* stream) {
     GS_CHECK_ARG(c && data && count >= 0, "gs_allreduce_sum_f32: bad arguments");
     if (count == 0) return 0;
-    if (c->world == 1) {
-        // (a one-rank communicator is never a production configuration: the variable is looked up per call -- tests switch it between
-        //  trainers of one process -- and clamped to [0, 10 ms] so that a typo cannot park the stream)
-        double marker_us = -1.0;
-        if (const char* us = getenv("GS_COMM_MARKER_US")) {
-            const double v = atof(us);
-            marker_us = v < 0.0 ? 0.0 : (v > 10000.0 ? 10000.0 : v);
-        }
-        if (marker_us >= 0.0) {
-            hipLaunchKernelGGL(comm_marker_kernel, dim3(1), dim3(64), 0, gs::as_stream(stream), data, (long long)(marker_us * 100.0));
-            GS_CHECK_LAUNCH();
-            return 0;
-        }
+    if (c->world == 1 && c->marker_us >= 0.0) {
+        hipLaunchKernelGGL(comm_marker_kernel, dim3(1), dim3(64), 0, gs::as_stream(stream), data, (long long)(c->marker_us * 100.0));
+        GS_CHECK_LAUNCH();
+        return 0;
     }
     GS_NCCL_OK(g_rccl.AllReduce(data, data, (size_t)count, ncclFloat32, ncclSum, c->comm, gs::as_stream(stream)));
     return 0;

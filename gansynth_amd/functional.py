@@ -16,6 +16,7 @@ import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
+from . import config
 from . import kernels
 from ._lib import ACT_LRELU, ACT_NONE, ACT_TANH
 
@@ -239,7 +240,7 @@ _PARAMS_ONLY = False
 class params_only(object):
     def __enter__(self):
         global _PARAMS_ONLY
-        self.was, _PARAMS_ONLY = _PARAMS_ONLY, not __import__("os").environ.get("GS_NO_PARAMS_ONLY")
+        self.was, _PARAMS_ONLY = _PARAMS_ONLY, not config.flag("GS_NO_PARAMS_ONLY")
         return self
 
     def __exit__(self, *exc):
@@ -266,7 +267,7 @@ def _accum_target(param):
     return g
 
 
-_DERIVED_SLICES = not __import__("os").environ.get("GS_NO_DERIVED_SLICES")   # A/B switch for measurements
+_DERIVED_SLICES = not config.flag("GS_NO_DERIVED_SLICES")   # A/B switch for measurements
 
 
 class _WeightSlice(Function):
@@ -320,9 +321,9 @@ def _slice_target(wref, x, gy, kind):
 # the multiplication by act'(z) moves into the kernel that produces gz (its input x IS z): one full read-modify-write pass per
 # activation disappears from the plain backward.  The consumer tells the producer through the producer's ctx (= z.grad_fn)
 # which tensor is already masked; under create_graph nothing is fused (the pieces must stay differentiable Functions).
-_NO_PREMASK = bool(__import__("os").environ.get("GS_NO_PREMASK"))   # A/B switches for measurements
-_NO_PREMASK_GRAPH = bool(__import__("os").environ.get("GS_NO_PREMASK_GRAPH"))
-_NO_PREMASK_GRAPH2 = bool(__import__("os").environ.get("GS_NO_PREMASK_GRAPH2"))
+_NO_PREMASK = config.flag("GS_NO_PREMASK")   # A/B switches for measurements
+_NO_PREMASK_GRAPH = config.flag("GS_NO_PREMASK_GRAPH")
+_NO_PREMASK_GRAPH2 = config.flag("GS_NO_PREMASK_GRAPH2")
 
 
 def _premask_producer(x, in_act, differentiable=False):
@@ -623,9 +624,9 @@ class _PnActBwd(Function):
         return g_g, g_z, None, None
 
 
-_FUSE_NORM_EPILOGUE = not __import__("os").environ.get("GS_NO_NORM_EPILOGUE")   # A/B switch for measurements
-_FUSE_NORM_BWD = not __import__("os").environ.get("GS_NO_NORM_BWD_EPILOGUE")  # A/B switch: the previous block's norm backward in the data-gradient epilogue
-_FUSE_NORM_BWD2 = not __import__("os").environ.get("GS_NO_NORM_BWD2_EPILOGUE")  # A/B switch: the norm's second-order kernel in the forward-on-cotangent conv
+_FUSE_NORM_EPILOGUE = not config.flag("GS_NO_NORM_EPILOGUE")   # A/B switch for measurements
+_FUSE_NORM_BWD = not config.flag("GS_NO_NORM_BWD_EPILOGUE")  # A/B switch: the previous block's norm backward in the data-gradient epilogue
+_FUSE_NORM_BWD2 = not config.flag("GS_NO_NORM_BWD2_EPILOGUE")  # A/B switch: the norm's second-order kernel in the forward-on-cotangent conv
 
 # ---- the previous block's (activation -> pixel norm) backward inside the conv that produces its input gradient -----------------------
 # Plain backward of a generator block: g_y -> [pixel_norm_bwd(g_y, z) + g_z] * act'(z) -> data gradient conv -> g_y of the block before.
@@ -652,7 +653,7 @@ def _handoff_broken(what):
 
 
 # GS_CHECK_FUSION=1: every fused cross-node form also runs its unfused definition and the two are compared (debug mode).
-_CHECK_FUSION = bool(__import__("os").environ.get("GS_CHECK_FUSION"))
+_CHECK_FUSION = config.flag("GS_CHECK_FUSION")
 
 
 def _check_fused(what, got, ref):
@@ -665,7 +666,7 @@ def _check_fused(what, got, ref):
         if not err <= tol:
             raise RuntimeError("GS_CHECK_FUSION: %s differs from its unfused definition by %.3e of the tensor's scale" % (what, err))
 
-_NORM_BWD_BIAS = not __import__("os").environ.get("GS_NO_NORM_BWD_BIAS")      # A/B switch: bias sums inside the norm's backward
+_NORM_BWD_BIAS = not config.flag("GS_NO_NORM_BWD_BIAS")      # A/B switch: bias sums inside the norm's backward
 
 
 class _ConvBiasActNorm(Function):
@@ -958,7 +959,7 @@ class _NHWCActBwdToUnits(Function):
 
 
 def units_nhwc_ok():
-    return hasattr(_K(), "units_bias_act_to_nhwc") and not __import__("os").environ.get("GS_NO_UNITS_NHWC")
+    return hasattr(_K(), "units_bias_act_to_nhwc") and not config.flag("GS_NO_UNITS_NHWC")
 
 
 def units_bias_act_nhwc(y, bias, c, h, w, act):

@@ -15,6 +15,7 @@ import os
 import numpy as np
 import torch
 
+from . import config
 from . import _lib
 from ._lib import GS_BF16, GS_F32
 
@@ -51,7 +52,7 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-_POISON = bool(__import__("os").environ.get("GS_DEBUG_POISON_WS"))   # debugging: workspaces start as NaN bit patterns, so that a
+_POISON = config.flag("GS_DEBUG_POISON_WS")   # debugging: workspaces start as NaN bit patterns, so that a
                                                                      # kernel reading workspace it never wrote shows up as NaN
 
 
@@ -192,15 +193,28 @@ class HipKernels(object):
             return
         stream = torch.cuda.current_stream()
         targets = [t for t in targets if isinstance(t, torch.Tensor) and t.is_cuda]
-        for t in targets:
-            prev = self._last_writer.get(t.data_ptr())
-            if prev is not None and prev[0] != stream.cuda_stream:
-                stream.wait_event(prev[1])
+        spans = [self._span(t) for t in targets]
+        for lo, hi in spans:
+            # (by ADDRESS RANGE, not by pointer: a channel slice w.grad[:, :, lo:hi, :] of a wider variable -- wgrad_slice_target_ok -- and its
+            #  parent, or two slices, are the same memory under different pointers)
+            for (plo, phi), (pstream, pev) in self._last_writer.items():
+                if plo < hi and lo < phi and pstream != stream.cuda_stream:
+                    stream.wait_event(pev)
         yield
-        for t in targets:
+        for span in spans:
             ev = torch.cuda.Event()
             ev.record(stream)
-            self._last_writer[t.data_ptr()] = (stream.cuda_stream, ev)
+            for old in [k for k in self._last_writer if k[0] < span[1] and span[0] < k[1] and k != span]:
+                # an overlapping older entry stays only where it reaches beyond the new one (its event still orders that part)
+                if span[0] <= old[0] and old[1] <= span[1]:
+                    del self._last_writer[old]
+            self._last_writer[span] = (stream.cuda_stream, ev)
+
+    @staticmethod
+    def _span(t):
+        """[first byte, one past the last byte) a (possibly strided) tensor touches."""
+        lo = t.data_ptr()
+        return lo, lo + (sum((n - 1) * st for n, st in zip(t.shape, t.stride()) if n > 0) + 1) * t.element_size()
 
     # ----------------------------------------------------------- deferred weight gradients
     def defer_wgrad_reductions(self):
@@ -211,7 +225,7 @@ class HipKernels(object):
         only after the flush; x and gy are kept alive (and must not be written) until then."""
         if self._pending is None:
             self._pending = {}
-            self._folds = None if os.environ.get("GS_NO_DEFERRED_FOLDS") else []
+            self._folds = None if config.value("GS_NO_DEFERRED_FOLDS") else []
 
     def _partial_rows(self, producer, p, c, dt, out):
         """While gradients are deferred: a buffer of its own for the partial rows of a bias gradient that is ADDED into `out` (a
@@ -243,7 +257,7 @@ class HipKernels(object):
         """May a conv weight gradient be added into a CHANNEL SLICE w.grad[:, :, lo:hi, :] of a wider variable (a strided `out`)?
         Only while gradients are deferred, for the layers gs_conv_wgrad_jobs runs grouped (bf16, 3x3, >= 64 channels both sides) and
         for the 1-input-channel plane conv of the direct kernel."""
-        if self._pending is None or os.environ.get("GS_NO_WGRAD_GROUPS") or ksize != 3:
+        if self._pending is None or config.value("GS_NO_WGRAD_GROUPS") or ksize != 3:
             return False
         if x.shape[1] == 1 and stride == 1 and co % 4 == 0:   # the 1-channel direct kernel: its slice reduction stays pending, the batched fold takes the stride
             return True
@@ -630,7 +644,7 @@ class HipKernels(object):
     # itself: x is [n, c, h, w] in channels-last memory, w stays [c * h * w, out] in the reference's row order
     @staticmethod
     def dense_nhwc_ok(x, out, batch_for_weight=None):
-        if os.environ.get("GS_NO_DENSE_NHWC"):   # measurement knob: the flatten copy + the plain kernels
+        if config.value("GS_NO_DENSE_NHWC"):   # measurement knob: the flatten copy + the plain kernels
             return False
         return x.dim() == 4 and x.is_contiguous(memory_format=CL) and out % 256 == 0 and (x.shape[1] * x.shape[2] * x.shape[3]) % 4 == 0 and x.shape[0] <= 16
 

@@ -20,6 +20,7 @@ from collections import OrderedDict
 import torch
 import torch.nn.functional as TF
 
+from . import config
 from . import functional as F
 from . import kernels
 from . import spectral_ops
@@ -28,26 +29,24 @@ from . import variables
 _PAD = 64  # floats; keeps every parameter view 256-byte aligned inside the flat buffer
 
 
-_DEFER_REDUCTIONS = not __import__("os").environ.get("GS_NO_DEFERRED_REDUCE")   # A/B switches for measurements
-_FUSED_LOSSES = not __import__("os").environ.get("GS_NO_FUSED_LOSSES")
-_BATCH_D_TAIL = not __import__("os").environ.get("GS_NO_D_TAIL_BATCH")   # A/B switch: real + fake through the discriminator's tail as one batch
-_PIPELINE = bool(__import__("os").environ.get("GS_PIPELINE"))   # opt-in, see GANSynth.pipeline
-_PIPE_SIDE = {"0": False, "1": True}.get(__import__("os").environ.get("GS_PIPE_SIDE", ""))
+_DEFER_REDUCTIONS = not config.flag("GS_NO_DEFERRED_REDUCE")   # A/B switches for measurements
+_FUSED_LOSSES = not config.flag("GS_NO_FUSED_LOSSES")
+_BATCH_D_TAIL = not config.flag("GS_NO_D_TAIL_BATCH")   # A/B switch: real + fake through the discriminator's tail as one batch
+_PIPELINE = config.flag("GS_PIPELINE")   # opt-in, see GANSynth.pipeline
+_PIPE_SIDE = {"0": False, "1": True}.get(config.value("GS_PIPE_SIDE", ""))
 # The all-reduce beside part A of the other run (forked graph branch, four graphs per iteration: round 4's default) is opt-in since round 5:
 # the two-graph form with the collective as the LAST node of each run's graph keeps the compute branches of section 6.5 (a four-graph
 # iteration with branches would be launch-bound) -- 5.16 against 5.68 ms at world size 1, i.e. the overlapped form has to hide more than
 # half a millisecond of all-reduce to break even.
-_OVERLAP_REDUCE = bool(__import__("os").environ.get("GS_OVERLAP_REDUCE")) and not __import__("os").environ.get("GS_NO_OVERLAP_REDUCE")
-_GRAPH_ALLREDUCE = not __import__("os").environ.get("GS_NO_GRAPH_ALLREDUCE")   # A/B switch: the gradient all-reduce as a node of the captured graph
-_FORK = not __import__("os").environ.get("GS_NO_FORK")   # A/B switch: independent sub-passes of a run on a forked branch of its hipGraph (GANSynth._branch)
-LEVEL_STREAMS = int(__import__("os").environ.get("GS_LEVEL_STREAMS", "128"))   # see GANSynth._leveled_queues
-EARLY_FLUSH_DIVS = [int(d) for d in __import__("os").environ.get("GS_EARLY_FLUSH_DIV", "16").split(",")]   # a layer is "large" from 1/DIV of the full resolution's pixels (several: one early contraction each)
-EARLY_FLUSH_CUS = int(__import__("os").environ.get("GS_EARLY_FLUSH_CUS", "192"))   # see GANSynth._early_flush
-_MERGED_AT_ROOT = bool(__import__("os").environ.get("GS_MERGED_AT_ROOT"))   # A/B switch, see _capture_merged
-_HOOK_BEFORE_BACKWARD = not __import__("os").environ.get("GS_HOOK_AFTER_BACKWARD")   # A/B switch, see _part_b
-_SUB_RUNS = bool(__import__("os").environ.get("GS_SUB_RUNS"))   # opt-in (measured slower, see _d_sub_runs): the discriminator run as two independent sub-runs
-_FAKE_FIRST = bool(__import__("os").environ.get("GS_FAKE_FIRST"))   # opt-in, see _d_fake_first
-_FORK_EAGER = bool(__import__("os").environ.get("GS_FORK_EAGER"))   # tests: the same branches with eager launches (a second stream, event hops)
+_OVERLAP_REDUCE = config.flag("GS_OVERLAP_REDUCE") and not config.flag("GS_NO_OVERLAP_REDUCE")
+_GRAPH_ALLREDUCE = not config.flag("GS_NO_GRAPH_ALLREDUCE")   # A/B switch: the gradient all-reduce as a node of the captured graph
+_FORK = not config.flag("GS_NO_FORK")   # A/B switch: independent sub-passes of a run on a forked branch of its hipGraph (GANSynth._branch)
+LEVEL_STREAMS = int(config.value("GS_LEVEL_STREAMS", "128"))   # see GANSynth._leveled_queues
+EARLY_FLUSH_DIVS = [int(d) for d in config.value("GS_EARLY_FLUSH_DIV", "16").split(",")]   # a layer is "large" from 1/DIV of the full resolution's pixels (several: one early contraction each)
+EARLY_FLUSH_CUS = int(config.value("GS_EARLY_FLUSH_CUS", "192"))   # see GANSynth._early_flush
+_SUB_RUNS = config.flag("GS_SUB_RUNS")   # opt-in (measured slower, see _d_sub_runs): the discriminator run as two independent sub-runs
+_FAKE_FIRST = config.flag("GS_FAKE_FIRST")   # opt-in, see _d_fake_first
+_FORK_EAGER = config.flag("GS_FORK_EAGER")   # tests: the same branches with eager launches (a second stream, event hops)
 
 
 def _capture_mode(with_collective, forked=False):
@@ -58,7 +57,7 @@ def _capture_mode(with_collective, forked=False):
     events between two captured streams) a thread_local capture replayed into a segmentation fault on this stack (ROCm 7.0.2, RCCL 2.26.6,
     one rank; "global" and "relaxed" captures of the same run replay fine): those captures are "relaxed" (no thread's calls are checked).
     Everything else keeps the strict default."""
-    forced = __import__("os").environ.get("GS_CAPTURE_MODE")   # (debugging)
+    forced = config.value("GS_CAPTURE_MODE")   # (debugging)
     if forced:
         return {"capture_error_mode": forced}
     if not with_collective:
@@ -81,6 +80,67 @@ def _hw_queues_allow_branches():
         import sys
         print("gansynth_amd.models: GPU_MAX_HW_QUEUES=%s: the runs' graphs are captured without parallel branches (they need the default, 4)" % n,
               file=sys.stderr, flush=True)
+    return ok
+
+
+# The forked schedule was debugged on ONE build of the HIP runtime (ROCm 7.0.2: the stream-list defect of hipGraphLaunch and the workaround
+# for it, GANSynth._leveled_queues).  On that build the branches are used as they are; on any other the first trainer of a process that is about
+# to capture a forked graph runs a reduced forked iteration in a CHILD process first -- a defect of this kind is a segmentation fault inside
+# the runtime, which no exception handler of this process would see -- and a child that dies switches the branches off for the process (and
+# for its children: GS_FORK_PROBED), with a line on stderr.  GS_FORK_PROBE=always / never overrides.
+_VALIDATED_HIP = ("7.0.51831",)
+_FORK_PROBE_RESULT = []
+_FORK_PROBE = r"""
+import sys, torch
+sys.path.insert(0, %r)
+from gansynth_amd import variables
+from gansynth_amd.models import GANSynth
+from gansynth_amd.networks import PGGAN
+from gansynth_amd.utils import Dict
+variables.set_default_store(variables.VariableStore(device="cuda"))
+pg = PGGAN(min_resolution=[2, 16], max_resolution=[16, 128], min_channels=32, max_channels=64, growing_level=1.0)
+hp = Dict(generator_learning_rate=8e-4, generator_beta1=0.0, generator_beta2=0.99, discriminator_learning_rate=8e-4, discriminator_beta1=0.0,
+          discriminator_beta2=0.99, mode_seeking_loss_weight=0.1, real_gradient_penalty_weight=5.0, fake_gradient_penalty_weight=0.0)
+dt = torch.bfloat16
+lab = torch.nn.functional.one_hot(torch.arange(4) %% 61, 61).to("cuda", dt)
+real = lambda: (torch.randn(4, 2, 16, 128, device="cuda").clamp(-1, 1).contiguous(memory_format=torch.channels_last).to(dt), lab)
+model = GANSynth(pg.generator, pg.discriminator, real, lambda: torch.randn(4, 256, device="cuda", dtype=dt), None, hp, dtype=dt, use_graphs=True)
+assert model.fork
+for _ in range(4):
+    model.train_step()
+model.synchronize()
+assert model.branches_opened > 0 and bool(torch.isfinite(model.g_params.flat).all())
+print("forked replay ok")
+"""
+
+
+def _forked_replay_ok():
+    if _FORK_PROBE_RESULT:
+        return _FORK_PROBE_RESULT[0]
+    import os
+    import sys
+    mode = config.value("GS_FORK_PROBE", "auto")
+    hip = getattr(torch.version, "hip", None) or ""
+    ok = True
+    if config.value("GS_FORK_PROBED") in ("ok", "died"):
+        ok = os.environ["GS_FORK_PROBED"] == "ok"
+    elif mode == "never" or (mode != "always" and any(hip.startswith(v) for v in _VALIDATED_HIP)):
+        ok = True
+    else:
+        import subprocess
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        try:
+            res = subprocess.run([sys.executable, "-c", _FORK_PROBE % root], env=dict(os.environ, GS_FORK_PROBE="never"), capture_output=True, text=True,
+                                 timeout=float(config.value("GS_FORK_PROBE_TIMEOUT_S", "600")))
+            ok = res.returncode == 0 and "forked replay ok" in res.stdout
+            why = "rc %s: %s" % (res.returncode, (res.stderr or res.stdout).strip().splitlines()[-1:] or "")
+        except subprocess.TimeoutExpired:
+            ok, why = False, "no result in time"
+        os.environ["GS_FORK_PROBED"] = "ok" if ok else "died"
+        if not ok:
+            print("gansynth_amd.models: a forked hipGraph replay did not survive its probe on HIP %s (%s): the runs' graphs are captured without "
+                  "parallel branches in this process" % (hip or "?", why), file=sys.stderr, flush=True)
+    _FORK_PROBE_RESULT.append(ok)
     return ok
 
 
@@ -249,16 +309,16 @@ class GANSynth(object):
         #  in _build, when the transport is known.  The two-graph data-parallel forms keep their branches.)
         self.fork = _FORK and _hw_queues_allow_branches()
         self.fork_eager = _FORK_EAGER
-        self.fork_marks = not __import__("os").environ.get("GS_NO_FORK_MARKS")   # (debugging: branches start where they are opened)
+        self.fork_marks = not config.flag("GS_NO_FORK_MARKS")   # (debugging: branches start where they are opened)
         self._side = None
         self._side2 = None        # the stream of a whole sub-run beside another run (_train_step_merged)
         self._nodes_on_side2 = False
         self._origin = None
         self._after_loss = None
-        self.merge_runs = not __import__("os").environ.get("GS_NO_MERGED_RUNS")   # A/B switch: see _train_step_merged
+        self.merge_runs = not config.flag("GS_NO_MERGED_RUNS")   # A/B switch: see _train_step_merged
         self._merged = None
         # The WHOLE iteration as one hipGraph with both optimizer steps inside (see "one graph per iteration" above _capture_merged)
-        self.fuse_iteration = not __import__("os").environ.get("GS_NO_FUSED_ITERATION")
+        self.fuse_iteration = not config.flag("GS_NO_FUSED_ITERATION")
         self._opt_scalars = None      # functional.DeviceScalars: [lr_t of the discriminator's step, lr_t of the generator's PENDING step | < 0]
         self._before_fake = None      # hook: issued on the fake pass's stream right before the generator's forward of a discriminator run
         self._in_sub_runs = False
@@ -272,7 +332,7 @@ class GANSynth(object):
         self._serial_run = False
         self._branched = False
         self.branches_opened = 0   # (tests / bench: how many branches the last captures opened)
-        self.early_flush = not __import__("os").environ.get("GS_NO_EARLY_FLUSH")   # A/B switch: see _early_flush
+        self.early_flush = not config.flag("GS_NO_EARLY_FLUSH")   # A/B switch: see _early_flush
         self.batch_d_tail = None   # None: the discriminator's tail over [real; fake] as one batch unless the runs fork (see _batched_tail)
         self.early_flush_always = False   # (tests: the same flush points without branches -- in place, on the one stream)
         self.early_flushes = 0
@@ -314,6 +374,11 @@ class GANSynth(object):
             yield
         finally:
             _lib.check(K.lib.gs_streams_destroy(LEVEL_STREAMS, ptr), "gs_streams_destroy")
+
+    def _check_fork_runtime(self):
+        """Before the first capture that may hold parallel branches (see _forked_replay_ok)."""
+        if self.fork and torch.cuda.is_available() and not _forked_replay_ok():
+            self.fork = False
 
     def _forking(self):
         if not self.fork or not torch.cuda.is_available() or not hasattr(kernels.get(), "stream_guard"):
@@ -433,7 +498,7 @@ class GANSynth(object):
         self.d_params = _FlatParams(self.store.trainable_variables("discriminator"))
         if self.distributed:  # identical weights on every rank
             from . import comm
-            if self._comm is None and not __import__("os").environ.get("GS_TORCH_COLLECTIVES"):
+            if self._comm is None and not config.flag("GS_TORCH_COLLECTIVES"):
                 self._comm = comm.create(self.g_params.flat.device)   # RCCL on the backward's own stream (None on CPU / gloo)
             if self._comm is not None:
                 self._comm.broadcast_(self.g_params.flat, 0)
@@ -448,7 +513,7 @@ class GANSynth(object):
                 self.bucket_bytes = (64 << 20) if self._comm is not None else (8 << 20)
             self.g_params.make_buckets(self.bucket_bytes // 4, reverse=True)
             self.d_params.make_buckets(self.bucket_bytes // 4, reverse=False)
-            if (self._overlap_in_graph() or self._comm is None) and not __import__("os").environ.get("GS_FORK_DIST"):
+            if (self._overlap_in_graph() or self._comm is None) and not config.flag("GS_FORK_DIST"):
                 # the pipelined four-graph iteration (see __init__); and torch.distributed's collectives, which run on THEIR stream beside the
                 # launches that follow them: with the passes apart and the early contraction the world-1 step was no longer bit-identical to
                 # the non-distributed one there (5e-7 on the parameters, cause not found) -- that transport keeps round 4's schedule
@@ -743,18 +808,13 @@ class GANSynth(object):
         sub_runs = losses if isinstance(losses, list) else None   # [(context factory, forward() -> root)]: see _d_sub_runs
         loss = None if sub_runs is not None else (losses if losses.dim() == 0 else losses.mean())   # (the fused loss kernels return the mean itself)
         hook, self._after_loss = self._after_loss, None
-        loss_mark = None
-        if hook is not None and sub_runs is None:   # (merged iteration: part A of the other run forks off HERE, see _capture_merged)
-            if _HOOK_BEFORE_BACKWARD:
-                hook(None)
-                hook = None
-            else:
-                # ... but it is ISSUED behind this run's backward.  hipGraphLaunch submits a graph with parallel branches chain by chain, depth
-                # first, the children of a fork in the order they were captured, at ~3-4.5 us per node (scripts/probe/graph_order.hip,
-                # profiles/r06_c_graph_order.txt): issued in front of the backward, the 130 nodes of the other run's part A were submitted --
-                # and ran, alone on the chip -- before the first kernel of this run's backward, its critical path (0.8 ms late).
-                loss_mark = torch.cuda.Event()
-                loss_mark.record()
+        if hook is not None and sub_runs is None:
+            # Merged iteration: part A of the other run forks off HERE and is issued here, in front of this run's backward (see _capture_merged).
+            # (Measured round 6, profiles/r06_d_hook_after_backward_ab.txt: issued BEHIND the backward from an event recorded here, the runtime
+            #  submitted -- and ran -- it behind the backward's last node instead of beside it: 5.23 -> 5.29 ms.  hipGraphLaunch walks a graph
+            #  with parallel branches chain by chain, depth first, first-captured child first: scripts/probe/graph_order.hip.)
+            hook(None)
+            hook = None
         self._g_ready = None
         K = kernels.get()
         deferring = _DEFER_REDUCTIONS and hasattr(K, "defer_wgrad_reductions")   # parameter gradients are only read after the whole backward:
@@ -814,7 +874,7 @@ class GANSynth(object):
         if launched:
             self._inflight = (params, launched)
         if hook is not None:   # (sub-runs: part A of the other run is issued last and starts where the generator's weights are final)
-            hook(loss_mark if sub_runs is None else self._g_ready)
+            hook(self._g_ready)
         self._join_branches()   # (a branch opened by the flush itself; a branch left open would fail the capture)
         if sub_runs is not None:
             loss = roots[0]
@@ -1019,6 +1079,7 @@ class GANSynth(object):
         if entry is not None and entry[4] != self.keep_gradients:
             entry = None   # (a graph captured without a gradient fill relies on the zeroing optimizer step behind every replay)
         if entry is None or any(a.shape != b.shape or a.dtype != b.dtype for a, b in zip(entry[1], inputs)):
+            self._check_fork_runtime()
             static = [t.detach().clone() for t in inputs]
             K = kernels.get()
             owner.fade_weight = self._lerp if fade is not None else None   # the networks read the weight from the device table
@@ -1428,8 +1489,8 @@ class GANSynth(object):
 
                     def part_a_of_g(mark=None):
                         # from the discriminator run's loss on its second half is one stream wide (R1 double-backward, the real pass's backward,
-                        # the final contraction): part A of the generator run goes THERE (GS_MERGED_AT_ROOT=1: from the graph's root, beside
-                        # the two forward passes).  `mark`: an event recorded at the loss -- the branch starts there although it is issued later.
+                        # the final contraction): part A of the generator run goes THERE (from the graph's root, beside the two forward passes,
+                        # measured 5.27 -> 5.34 ms in round 5).  `mark`: an event recorded at the loss -- the branch starts there although it is issued later.
                         if mark is not None:
                             side2.wait_event(mark)
                         else:
@@ -1438,10 +1499,7 @@ class GANSynth(object):
                             box.append(self._part_a("g", *sg))
                         self.g_params.requires_grad_(False)      # (back to the discriminator run's arming for its backward)
                         self.d_params.requires_grad_(True)
-                    if _MERGED_AT_ROOT:
-                        part_a_of_g()
-                    else:
-                        self._after_loss = part_a_of_g
+                    self._after_loss = part_a_of_g
                     d_loss = self._forward_backward("d", *sd)    # (data parallel: ends with the all-reduce of the discriminator's gradient, _part_b)
                     g_part_a = box[0]
                     if fused:
@@ -1580,6 +1638,8 @@ class GANSynth(object):
         """models.py:191-192: one discriminator run then one generator run, fresh inputs for each."""
         real_images, labels, d_latents, g_latents, g_labels = self._next_inputs()
         self._ensure_built(d_latents, labels)
+        if self.use_graphs:
+            self._check_fork_runtime()
         if self._pipelined_ok():
             return self._train_step_pipelined(d_latents, labels, real_images, g_latents, g_labels)
         if self._merged_ok():

@@ -11,6 +11,7 @@ names, because the reference's graph owns them from step 0 (zero-gradient Adam u
 import numpy as np
 import torch
 
+from . import config
 from . import functional as F
 from . import ops
 from . import variables
@@ -18,7 +19,7 @@ from .variables import AUTO_REUSE, variable_scope
 
 
 PIXEL_NORM_EPS = 1.0e-12   # ops.pixel_normalization default (ops.py:330)
-_FUSE_NORM = not __import__("os").environ.get("GS_NO_FUSED_NORM")   # A/B switch for measurements
+_FUSE_NORM = not config.flag("GS_NO_FUSED_NORM")   # A/B switch for measurements
 
 
 def _ilog2(ratio):
@@ -214,7 +215,7 @@ class PGGAN(object):
     # Every launch of the tail is latency-bound at batch 8 (a few tens of blocks on 256 CUs), so the trainer runs the tails of the real and
     # of the fake pass of a discriminator run as ONE pass over the concatenated batch (models.GANSynth._d_losses_b): `sub_batches` keeps
     # the minibatch statistic per original batch (ops.py:336-348 on each half).
-    TAIL_LEVELS = int(__import__("os").environ.get("GS_D_TAIL_LEVELS", "3"))   # (measured: see DESIGN.md 6.3)
+    TAIL_LEVELS = int(config.value("GS_D_TAIL_LEVELS", "3"))   # (measured: see DESIGN.md 6.3)
 
     def _tail_top(self, head):
         return max(self.min_depth, min(head - 1, self.min_depth + self.TAIL_LEVELS - 1))

@@ -87,6 +87,9 @@ int gs_comm_init(gs_comm** out, int rank, int world, const void* id128);
 int gs_comm_destroy(gs_comm* comm);
 int gs_comm_count(gs_comm* comm, int* ranks);   /* ncclCommCount: the ranks the communicator was built over (bench.py reports it as rccl_ranks) */
 int gs_allreduce_sum_f32(gs_comm* comm, float* data, int64_t count, void* stream);
+/* test hook, ONE-rank communicators only (RCCL short-cuts their all-reduce to nothing): from now on gs_allreduce_sum_f32 launches a one-block
+ * kernel that holds the stream for `us` microseconds instead (us < 0: off again) -- where a collective sits in a captured graph then shows as time */
+int gs_comm_set_marker_us(gs_comm* comm, double us);
 int gs_broadcast_f32(gs_comm* comm, float* data, int64_t count, int root, void* stream);
 
 /* ------------------------------------------------------------------------------- conv2d
