@@ -258,6 +258,51 @@ def test_adam_tf_step(K, E):
     close(dv, rv, rel=1e-6)
 
 
+@pytest.mark.parametrize("zero_grad", [False, True])
+def test_adam_tf_step_with_lr_from_device_memory(K, E, zero_grad):
+    """gs_adam_tf_step_dev (the optimizer step as a node of the iteration's hipGraph): lr_t is read from device memory WHEN THE LAUNCH RUNS --
+    bit-identical to the by-value entry points for the same fp32 lr_t, against the oracle-side TF-Adam within fp32 round-off, a negative
+    value leaves every buffer untouched, and a value written after capture is the one a replay uses."""
+    from gansynth_amd import functional as F
+    n = 100003
+    p, g = rnd(n, seed=1), rnd(n, seed=2)
+    m, v = rnd(n, seed=3).abs() * 0.1, rnd(n, seed=4).abs() * 0.1
+    lr_t = 8e-4 * np.sqrt(1.0 - 0.99 ** 3) / (1.0 - 0.0 ** 3)
+    rp, rm, rv = p.clone(), m.clone(), v.clone()
+    E.adam_tf_step(rp, g, rm, rv, lr_t, 0.0, 0.99, 1e-8, 0.5)
+    by_value = [t.cuda() for t in (p, g, m, v)]
+    K.adam_tf_step(*by_value, lr_t, 0.0, 0.99, 1e-8, 0.5, refresh=False, zero_grad=zero_grad)
+    table = F.DeviceScalars("cuda", 2)
+    table.set([lr_t, -1.0])
+    dev_ = [t.cuda() for t in (p, g, m, v)]
+    K.adam_tf_step_dev(*dev_, table.ptr(0), 0.0, 0.99, 1e-8, 0.5, refresh=False, zero_grad=zero_grad)
+    for a, b, name in zip(dev_, by_value, "pgmv"):
+        assert torch.equal(a, b), name                      # same arithmetic on the same fp32 scalar
+    close(dev_[0], rp, rel=1e-6)
+    close(dev_[2], rm, rel=1e-6)
+    close(dev_[3], rv, rel=1e-6)
+    assert bool((dev_[1] == 0).all()) == zero_grad
+    skipped = [t.cuda() for t in (p, g, m, v)]
+    K.adam_tf_step_dev(*skipped, table.ptr(1), 0.0, 0.99, 1e-8, 0.5, refresh=False, zero_grad=True)   # negative lr_t: no step pending
+    for a, b in zip(skipped, (p, g, m, v)):
+        assert torch.equal(a.cpu(), b)
+    # inside a captured graph the scalar is read at replay time
+    cap = [t.cuda() for t in (p, g, m, v)]
+    table.set([-1.0, -1.0])
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        K.adam_tf_step_dev(*cap, table.ptr(0), 0.0, 0.99, 1e-8, 0.5, refresh=False, zero_grad=zero_grad)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(cap[0].cpu(), p)                     # captured with "no step": nothing moved
+    table.set([lr_t, -1.0])
+    graph.replay()
+    torch.cuda.synchronize()
+    for a, b, name in zip(cap, by_value, "pgmv"):
+        assert torch.equal(a, b), name
+
+
 @pytest.mark.parametrize("case", [(2, 32, 32, 8, 128, 3, 1), (2, 64, 64, 4, 32, 3, 1), (2, 32, 64, 8, 128, 3, 2), (4, 256, 256, 2, 16, 3, 1)])
 def test_conv2d_bf16_forward_and_data_grad(K, E, case):
     """bf16 storage / fp32 accumulate path of the MFMA kernels against the fp32 reference on bf16-rounded inputs."""
@@ -864,6 +909,19 @@ def test_gan_losses_in_one_launch(K, dtype):
     close(ks, g_ssq, rel=1e-5, name="g loss: d/d sumsq")
     loss, kf, ks = K.gan_g_loss(dev(fake.detach(), dtype), dev(lab, dtype), None, 0.0, 1e-6)
     assert ks is None and abs(float(loss) - float(TF.softplus(-(fake.detach() * lab).sum(1)).mean())) <= 1e-5
+    # either half of a sum as a launch of its own (two passes on two streams: include/gansynth_hip.h): the same gradients bit for bit, and the
+    # two partial means add up to the loss
+    _, kr0, kf0, kp0 = K.gan_d_loss(dev(real.detach(), dtype), dev(fake.detach(), dtype), dev(lab, dtype), pen.detach().cuda(), 5.0)
+    l_real, kr1, none_f, kp1 = K.gan_d_loss(dev(real.detach(), dtype), None, dev(lab, dtype), pen.detach().cuda(), 5.0)
+    l_fake, none_r, kf1, none_p = K.gan_d_loss(None, dev(fake.detach(), dtype), dev(lab, dtype), None, 1.0)
+    assert none_f is None and none_r is None and none_p is None
+    assert torch.equal(kr0, kr1) and torch.equal(kf0, kf1) and torch.equal(kp0, kp1)
+    assert abs(float(l_real) + float(l_fake) - float(ld.detach())) <= 1e-5 * abs(float(ld.detach()))
+    _, kf0, ks0 = K.gan_g_loss(dev(fake.detach(), dtype), dev(lab, dtype), ssq.detach().cuda(), 0.1, 1e-6)
+    l_ms, none_f, ks1 = K.gan_g_loss(None, None, ssq.detach().cuda(), 0.1, 1e-6)
+    l_adv, kf1, none_s = K.gan_g_loss(dev(fake.detach(), dtype), dev(lab, dtype), None, 0.0, 1e-6)
+    assert none_f is None and none_s is None and torch.equal(kf0, kf1) and torch.equal(ks0, ks1)
+    assert abs(float(l_ms) + float(l_adv) - float(lg.detach())) <= 1e-5 * abs(float(lg.detach()))
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

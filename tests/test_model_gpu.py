@@ -952,6 +952,52 @@ def test_generator_part_a_inside_the_discriminator_graph(gpu_store, level, full,
     assert out["pair"][0] == out["one graph"][0] and all(same), (same, out["pair"][0], out["one graph"][0])
 
 
+@pytest.mark.parametrize("level,dtype", [(1.0, torch.float32), (0.6, torch.bfloat16)])
+def test_alternative_issue_orders_of_the_discriminator_run(gpu_store, level, dtype):
+    """The two opt-in schedules of round 6 (gansynth_amd/config.py: GS_SUB_RUNS, GS_FAKE_FIRST; measured slower / not robust): the
+    discriminator run as two independent sub-runs -- two loss launches, two backward calls -- and its fake pass issued in front of the real one.
+    Same arithmetic in another order: losses and parameters after four one-graph iterations agree with the default schedule to the association of
+    multi-consumer gradient sums (autograd orders independent nodes by age, and both schedules change the ages)."""
+    from gansynth_amd import variables
+    out = {}
+    batches = [R.synthetic_batch(4, rank=i, image_shape=(2, 16, 128)) for i in range(4)]
+    for mode in ("default", "sub_runs", "fake_first"):
+        variables.set_default_store(variables.VariableStore(device="cuda"))
+        pg, opg, model = make(level, variables.default_store(), full=False, dtype=dtype)
+        model.use_graphs, model.keep_gradients = True, False
+        model.sub_runs, model.fake_first = mode == "sub_runs", mode == "fake_first"
+        cur = [0]
+
+        def real_input_fn():
+            lat, lab, real = batches[cur[0] % len(batches)]
+            return cuda(real).to(dtype), cuda(lab).to(dtype)
+
+        def fake_input_fn():
+            lat, _, _ = batches[cur[0] % len(batches)]
+            cur[0] += 1
+            return cuda(lat).to(dtype)
+        model.real_input_fn, model.fake_input_fn = real_input_fn, fake_input_fn
+        gp, dp = opg.init_params(seed=0, bias_std=0.1)
+        lat, lab, _ = batches[0]
+        model._build(cuda(lat).to(dtype), cuda(lab).to(dtype))
+        variables.default_store().load_state_dict({**gp, **dp})
+        losses = []
+        for _ in range(4):
+            d_loss, g_loss = model.train_step()
+            losses += [float(d_loss), float(g_loss)]
+        model.synchronize()
+        assert model._merged is not None and model._merged["fused"] and model.global_step == 4
+        out[mode] = (losses, model.d_params.flat.clone(), model.g_params.flat.clone())
+        del model
+    tol = 1e-5 if dtype == torch.float32 else 2e-3   # (bf16: a reassociated fp32 sum can move a bf16 rounding of a downstream activation)
+    for mode in ("sub_runs", "fake_first"):
+        for i, (a, b) in enumerate(zip(out["default"][0], out[mode][0])):
+            assert abs(a - b) <= max(5e-5, 10 * tol) * max(1.0, abs(a)), (mode, i, a, b)
+        for k, what in ((1, "discriminator"), (2, "generator")):
+            err = float((out["default"][k] - out[mode][k]).abs().max()) / float(out["default"][k].abs().max())
+            assert err <= 4 * tol, (mode, what, err)
+
+
 def _dp_trainer(level, batches, full=False, dtype=torch.float32, distributed=True, graphs=True, keep=True):
     from gansynth_amd import variables
     variables.set_default_store(variables.VariableStore(device="cuda"))
