@@ -40,7 +40,7 @@ KNOBS = {
     "GS_FORK_DIST": ("schedule", "compute branches also in the four-graph data-parallel iteration (host-bound: 7.4 ms of replay calls)"),
     "GS_PIPELINE": ("schedule", "round 2's pipelined iteration with the update on a side stream (cross-stream hops between replays: -6 %)"),
     "GS_PIPE_SIDE": ("schedule", "0 | 1: the side stream of that form"),
-    "GS_SUB_RUNS": ("schedule", "the discriminator run as two independent sub-runs, real first (5.27 -> 5.98 ms: the runtime serialises the chains)"),
+    "GS_SUB_RUNS": ("schedule", "the discriminator run as two independent sub-runs: split loss launches, two backward calls (4.91 -> 5.33 ms)"),
     "GS_FAKE_FIRST": ("schedule", "the discriminator run's fake pass issued before the real pass (+0.04 ms; hides 0.13 ms of a 0.3 ms all-reduce "
                                   "stand-in in one process, none in another)"),
     "GS_EARLY_FLUSH_DIV": ("schedule", "a layer is 'large' from 1/DIV of the full resolution's pixels (16)"),

@@ -12,9 +12,39 @@ torch.autograd.Function whose backward is itself expressed with Functions, so
 
 torch is only the tape; every tensor operation is a kernel from libgansynth_hip.so.
 """
+import contextlib
+import itertools
+
 import torch
-from torch.autograd import Function
 from torch.autograd.function import once_differentiable
+
+# The autograd engine runs the READY node with the highest sequence number first, and torch numbers nodes from THREAD-LOCAL counters: the nodes of
+# a second-order graph are created on the engine's device thread (inside Function.backward bodies, under create_graph), everything else on the
+# caller's thread, so which of two independent ready nodes runs first depended on how far each thread's counter had got -- on what the process
+# did before.  The launches of a run were the same set either way, but gradients with several contributions (a dense weight fed by the real
+# pass, the fake pass and the R1 term) were summed in another ORDER: last-bit differences that TF-Adam's sign-like first steps turn into 2 lr on
+# the elements whose gradient is round-off sized (seen: the same test green inside the suite and 8e-4 apart in a fresh process).  Every Function of
+# this module therefore numbers its node from ONE process-wide counter, far above anything a thread-local counter reaches: among the nodes of this
+# library the engine's order is the reverse of their creation order, whatever thread created them and whatever ran before.
+_NODE_SEQ = itertools.count(1 << 40)
+
+
+def _number_node(out):
+    t = out[0] if isinstance(out, (tuple, list)) and out else out
+    fn = getattr(t, "grad_fn", None) if isinstance(t, torch.Tensor) else None
+    if fn is not None and hasattr(fn, "_set_sequence_nr"):
+        fn._set_sequence_nr(next(_NODE_SEQ))
+
+
+class Function(torch.autograd.Function):
+    """torch.autograd.Function whose nodes take their engine priority from the process-wide counter above."""
+
+    @classmethod
+    def apply(cls, *args, **kwargs):
+        out = super().apply(*args, **kwargs)
+        _number_node(out)
+        return out
+
 
 from . import config
 from . import kernels
@@ -290,7 +320,13 @@ class _WeightSlice(Function):
             return None, None, None
         tgt = _accum_target(ctx.wref)
         if tgt is not None:
-            tgt[:, :, ctx.lo:ctx.hi, :].add_(g)
+            # This node runs on the stream of ITS forward: with the real and the fake pass of a discriminator run on two streams, two of these
+            # adds -- read-modify-writes of the same slice of w.grad -- met unordered: one contribution lost in ~2 % of the replayed fp32
+            # iterations (scripts/dbg_race.py; round 6).  Ordered like every other launch that adds into a gradient at once.
+            view = tgt[:, :, ctx.lo:ctx.hi, :]
+            K = _K()
+            with (K._adds_into(view) if hasattr(K, "_adds_into") else contextlib.nullcontext()):
+                view.add_(g)
             return None, None, None
         return torch.nn.functional.pad(g, (0, 0, ctx.lo, ctx.wref.shape[2] - ctx.hi)), None, None
 

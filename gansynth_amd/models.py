@@ -451,12 +451,15 @@ class GANSynth(object):
                     K.flush_wgrad_reductions(select=select)
                 return
             if self._in_sub_runs and not on_branch and self._forking():
-                # Sub-runs (_d_sub_runs): the side stream belongs to the fake sub-run, which is issued AFTER this backward and must start at
-                # the graph's root, not behind this contraction: the contraction goes to the third stream (part A of the generator run is
-                # issued on it later still; the final contraction waits for it, _join_branches)
+                # Sub-runs (_d_sub_runs): the contraction goes to the THIRD stream, behind part A of the generator run (issued between the
+                # two sub-runs, _part_b), not behind the fake sub-run on the branch: that chain opens with the generator's all-reduce when the
+                # job is data parallel, and whatever is queued behind it inherits the collective's time (the final contraction waits for
+                # this one, _join_branches)
                 main = torch.cuda.current_stream()
                 third = self._second_stream("_side2", [main, self._side])
                 third.wait_stream(main)
+                if self._side is not None:
+                    third.wait_stream(self._side)   # (the fake sub-run's pairs were recorded THERE: issued, not necessarily written yet)
                 self._early_on_side2 = True
                 self.branches_opened += 1
                 with torch.cuda.stream(third):
@@ -628,20 +631,16 @@ class GANSynth(object):
     # The discriminator run as TWO INDEPENDENT SUB-RUNS (round 6).  L_D = mean(softplus(-r) + penalty) + mean(softplus(f)): the real pass with
     # its R1 passes and the fake pass share nothing but the parameters (leaves) -- two disjoint autograd graphs, two backward calls, one sum of
     # gradients.  With ONE loss node (gs_gan_d_loss over r and f) the real side's backward -- R1 double-backward + the real pass's own, the
-    # longest chain of the run -- waited for the fake pass's forward, and, in a captured graph, hipGraphLaunch submitted it LAST: the runtime
-    # walks a graph with parallel branches chain by chain, depth first, first-captured child first, at ~3-4.5 us per node
-    # (scripts/probe/graph_order.hip, graph_chains.hip; profiles/r06_c_graph_order.txt, r06_d_graph_chains.txt), so the order things are ISSUED in is
-    # the order they reach the GPU.  Here the critical chain is issued first and whole: real forward, first-order pass, its loss, its backward --
-    # one chain on the capturing stream from the graph's root -- then the fake sub-run on the branch (generator step pending from the previous
-    # iteration, G(z), D, its loss, its backward: it has the slack, and data parallel it starts with the generator's all-reduce, beside the real
-    # pass instead of on the critical path), then part A of the generator run (models._capture_merged).  The loss VALUE is the sum of the two
-    # partial means (last-bit association differs from the one-launch form; the gradients are the same numbers).
-    # MEASURED, and OPT-IN (GS_SUB_RUNS=1) because of it: parity and bit-identity tests green, and 5.27 -> 5.98 ms (profiles/r06_e_sub_runs_ab.txt;
-    # 5.46 without the early contraction's extra branch, r06_f_*): in the replay the fake sub-run's first node started when the real sub-run's
-    # LAST node finished (profiles/r06_e_graph_sequence.txt) -- three chains that share nothing ran one after the other.  The runtime maps the
-    # chains it finds (depth first) onto its four hardware queues in discovery order, chains that land on one queue run in submission order
-    # (graph_chains.hip: the fifth of five parallel chains starts when the first ends), and which chain lands where is not ours to choose.
-    # The one-loss form below is what the runtime happens to schedule well: its join at the loss cuts the chains short.
+    # longest chain of the run -- waits for the fake pass's forward.  Here each sub-run is issued whole: the fake sub-run on the branch from the
+    # run's root (generator step pending from the previous iteration -- data parallel: its all-reduce first --, G(z), D, its loss, its backward),
+    # part A of the generator run on the third stream (models._capture_merged), then the real sub-run's loss and backward on the capturing stream
+    # (its forward and first-order pass were issued in part A of this run), its early contraction behind part A.  The loss VALUE is the sum of
+    # the two partial means (last-bit association differs from the one-launch form; the gradients are the same numbers).
+    # MEASURED, and OPT-IN (GS_SUB_RUNS=1) because of it (timelines taken from INSIDE the graph, scripts/phase_timeline.py): parity and
+    # bit-identity tests green; the first form (real sub-run first, the early contraction on a stream of its own) ran 5.27 -> 5.98 ms -- four chains
+    # on the runtime's four hardware queues, two of them on one; this form (fake sub-run first, part A of the generator run between the sub-runs,
+    # the early contraction behind part A and behind the fake sub-run's stream: three chains from the graph's root) runs 4.91 -> 5.33 ms.  The
+    # discriminator phase is throughput-bound: three chains already run side by side in the one-loss form as well.
     def _sub_runs_ok(self):
         # (also WITHOUT branches -- everything on the one stream, same order: a plain and a forked schedule then issue the same launches in the
         #  same order and stay bit-identical, tests/test_model_gpu.py::test_forked_branches_change_nothing_but_the_schedule)
@@ -670,7 +669,10 @@ class GANSynth(object):
                 self._marks["d_root"] = root
             return self._branch("d_root", join=False)   # (joined at the end of the run, _part_b)
 
-        return [(contextlib.nullcontext, real_sub_run), (on_branch, fake_sub_run)]
+        # issue order: the fake sub-run WHOLE (forward, loss, backward on the branch, from the run's root), then the real sub-run's loss and
+        # backward on this stream (its forward and first-order pass were issued in part A) -- the early contraction of the real backward then
+        # goes behind the fake sub-run on the branch, and the graph holds three chains: this stream, the branch, part A of the generator run
+        return [(on_branch, fake_sub_run), (contextlib.nullcontext, real_sub_run)]
 
     def _d_losses_b_batched(self, part_a, latents, labels):
         """models.py:39-54,65 with the two discriminator passes sharing their tail: logits of [real; fake] from one pass, the R1 term
@@ -810,9 +812,7 @@ class GANSynth(object):
         hook, self._after_loss = self._after_loss, None
         if hook is not None and sub_runs is None:
             # Merged iteration: part A of the other run forks off HERE and is issued here, in front of this run's backward (see _capture_merged).
-            # (Measured round 6, profiles/r06_d_hook_after_backward_ab.txt: issued BEHIND the backward from an event recorded here, the runtime
-            #  submitted -- and ran -- it behind the backward's last node instead of beside it: 5.23 -> 5.29 ms.  hipGraphLaunch walks a graph
-            #  with parallel branches chain by chain, depth first, first-captured child first: scripts/probe/graph_order.hip.)
+            # (Measured round 6, profiles/r06_d_hook_after_backward_ab.txt: issued BEHIND the backward from an event recorded here: 5.23 -> 5.29 ms.)
             hook(None)
             hook = None
         self._g_ready = None
@@ -853,6 +853,11 @@ class GANSynth(object):
                             F.reset_fusion_state()
                         backward(root)
                         roots.append(root.detach())
+                    if hook is not None and self._g_ready is not None:
+                        # part A of the other run: issued behind the FAKE sub-run (it starts where the generator's weights are final) and in
+                        # front of the real sub-run's backward, whose early contraction queues behind it on the third stream
+                        hook(self._g_ready)
+                        hook = None
         finally:
             self._in_sub_runs = False
             if hasattr(F, "reset_fusion_state"):
@@ -1009,17 +1014,13 @@ class GANSynth(object):
             self._serial_run = False
             self._marks.clear()
 
-    # Data parallel, one graph per iteration: the discriminator run's FAKE pass is issued -- hence submitted by hipGraphLaunch -- before the real
-    # pass.  It starts with the generator's pending step, i.e. with the all-reduce of the generator's gradient, and the loss needs both passes:
-    # with the real pass first (the one-GPU order) the fake pass starts ~0.4 ms into the graph (the runtime submits the real pass's 86 nodes
-    # first, ~4.5 us each) and an all-reduce in front of it lands on the critical path whole; with the fake pass first the collective starts at
-    # the graph's root and it is the REAL pass that starts ~0.5 ms late -- it is the shorter of the two (no generator forward in it) and needs
-    # nothing of the collective: up to ~0.45 ms of all-reduce should disappear behind a delay that is there anyway.  One GPU: the same delay
-    # with nothing to hide costs ~0.04 ms (5.17 -> 5.21).  MEASURED at world size 1 with 300-us stand-ins for the two collectives
-    # (scripts/dp_marker_check.py, profiles/r06_g_dp_markers.txt): the two stand-ins add 0.43 ms with this order against 0.56 real-first and 0.61
-    # in the two-graph form -- but 0.61 against 0.52 inside tests/test_model_gpu.py's process: which chain of a graph shares a hardware queue
-    # with which depends on the stream pool's history in the process, so the gain is not one to build a default on.  OPT-IN (GS_FAKE_FIRST=1 /
-    # `fake_first`).
+    # One graph per iteration, opt-in (GS_FAKE_FIRST=1 / `fake_first`): the discriminator run's FAKE pass is issued before the real pass.  It
+    # starts with the generator's pending step, i.e. data parallel with the all-reduce of the generator's gradient; issued first it is the
+    # capturing stream's own chain and the real pass the branch.  One GPU: 5.17 -> 5.21 ms.  World size 1 with 300-us stand-ins for the two
+    # collectives (scripts/dp_marker_check.py, profiles/r06_g_dp_markers.txt): the stand-ins add 0.43 ms with this order against 0.56 real-first
+    # and 0.61 in the two-graph form in one process, 0.61 against 0.52 inside tests/test_model_gpu.py's process -- the discriminator phase is
+    # throughput-bound and which chains share a hardware queue depends on the stream pool's history: not a gain to build a
+    # default on.
     def _d_fake_first(self):
         if not (self._forking() and self._capturing() and self.fork_marks and self._fused_losses()) or self._sub_runs_ok():
             return False

@@ -369,7 +369,7 @@ def test_bf16_path_tracks_fp32(gpu_store):
 
 
 
-def _same_up_to_accumulation_order(a, b, what):
+def _same_up_to_accumulation_order(a, b, what, far_fraction=2e-2):
     """Two schedules of the same iteration agree up to the association of fp32 gradient sums: autograd runs independent
     branches in an order given by THREAD-LOCAL node-creation counters (the second-order graphs are created on the engine's
     device thread), so a tensor with three or more gradient contributions -- a multi-consumer activation, the dense weights
@@ -378,11 +378,22 @@ def _same_up_to_accumulation_order(a, b, what):
     associate an entry's sum by the ENTRY's own shape, never by what else shares the launch (a bucketed flush batches them differently) --
     hence a few-ulp tolerance rather than equality."""
     if isinstance(a, float):
-        # (a loss of a LATER iteration sees the last-bit difference of a sum through TF-Adam's sign-like first steps -- m / sqrt(v) = +-1
-        #  whatever the gradient's size: 2.3e-5 seen on the third iteration's generator loss; the parameters themselves stay within 1e-5)
-        assert abs(a - b) <= 5e-5 * max(1.0, abs(a)), (what, a, b)
+        # (a loss of a LATER iteration sees those steps through the forward pass: 2e-4 ... 2e-3 seen between schedules that associate one sum
+        #  differently, bit-identical when they do not)
+        assert abs(a - b) <= 3e-3 * max(1.0, abs(a)), (what, a, b)
     else:
-        assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max()), (what, float((a - b).abs().max()), float(a.abs().max()))
+        # Parameters after a few TF-Adam steps: with beta1 = 0 the first steps are lr * g / (sqrt(1 - beta2) |g| + eps) ~ lr * sign(g) whatever the
+        # gradient's size, so an element whose gradient is itself of the size of the sum's round-off (a reassociated fp32 sum moves it by ~1e-7 of
+        # the tensor's scale) may step the OTHER way in one schedule: 2 lr = 1.6e-3 apart after one step, and the forward pass then carries the
+        # difference on, so that more elements follow in the next step (0.2-0.3 % of the discriminator's after three iterations, seen).  Everything
+        # else must agree to 1e-5, at most two elements in a hundred may be further apart, and none by more than a few steps' worth.  The sharp
+        # statement -- same arithmetic, another order -- is made where nothing amplifies it: test_alternative_issue_orders_of_the_discriminator_run
+        # compares the schedules with both learning rates at zero, and schedules that issue the same launches in the same order are held to
+        # bit-identity (forked vs plain graphs, one graph vs the pair).
+        diff, scale = (a - b).abs(), float(a.abs().max())
+        far = diff > 1e-5 * scale
+        assert float(far.float().mean()) <= far_fraction, (what, float(far.float().mean()), float(diff.max()), scale)
+        assert float(diff.max()) <= 1e-2 * max(scale, 1.0), (what, float(diff.max()), scale)
 
 
 def test_hipgraph_replay_equals_eager(gpu_store):
@@ -834,8 +845,15 @@ def test_distributed_step_on_rccl_world_size_1():
         for mode in ("dist", "dist+graphs", "dist+graphs, collective refused by the capture", "dist+torch"):   # (two trainers in one process may associate fp32 gradient sums differently, see above)
             for i, (a, b) in enumerate(zip(out["plain"][0], out[mode][0])):
                 _same_up_to_accumulation_order(a, b, f"{mode}: loss {i}")
-            _same_up_to_accumulation_order(out["plain"][1], out[mode][1], f"{mode}: discriminator parameters")
-            _same_up_to_accumulation_order(out["plain"][2], out[mode][2], f"{mode}: generator parameters")
+            # (torch.distributed's transport keeps round 4's schedule -- real and fake batch through the discriminator's tail as ONE batch, no early
+            #  contraction: other launches, other association from the first gradient on (6e-9 of its scale), and after three TF-Adam steps a tenth
+            #  of the generator's elements are more than 1e-5 apart, scripts/dbg_dist_torch.py; the three modes on the library's own communicator
+            #  issue the plain schedule's launches and are BIT-identical to it since the engine's node order is process-wide, functional._NODE_SEQ)
+            far = 0.3 if mode == "dist+torch" else 2e-2
+            _same_up_to_accumulation_order(out["plain"][1], out[mode][1], f"{mode}: discriminator parameters", far_fraction=far)
+            _same_up_to_accumulation_order(out["plain"][2], out[mode][2], f"{mode}: generator parameters", far_fraction=far)
+        for mode in ("dist", "dist+graphs"):
+            assert torch.equal(out["plain"][1], out[mode][1]) and torch.equal(out["plain"][2], out[mode][2]), mode
     finally:
         os.environ.pop("GS_TORCH_COLLECTIVES", None)
         dist.destroy_process_group()
@@ -880,6 +898,9 @@ def test_forked_branches_change_nothing_but_the_schedule(gpu_store, level, full,
     for mode in ("forked", "forked-eager"):
         for i, (a, b) in enumerate(zip(out["plain"][0], out[mode][0])):
             _same_up_to_accumulation_order(a, b, f"{mode}: loss {i}")
+        # (three iterations: an element that stepped the other way in the first one moves every later gradient by ~1e-3 and more elements follow --
+        #  0.3 % of the discriminator's after the third when this test runs alone in a fresh process, none inside the suite; the CAPTURED forked
+        #  schedule is held to bit-identity below)
         _same_up_to_accumulation_order(out["plain"][1], out[mode][1], f"{mode}: discriminator parameters")
         _same_up_to_accumulation_order(out["plain"][2], out[mode][2], f"{mode}: generator parameters")
     same = [bool(torch.equal(out["plain"][k], out["forked"][k])) for k in (1, 2)]
@@ -954,17 +975,22 @@ def test_generator_part_a_inside_the_discriminator_graph(gpu_store, level, full,
 
 @pytest.mark.parametrize("level,dtype", [(1.0, torch.float32), (0.6, torch.bfloat16)])
 def test_alternative_issue_orders_of_the_discriminator_run(gpu_store, level, dtype):
-    """The two opt-in schedules of round 6 (gansynth_amd/config.py: GS_SUB_RUNS, GS_FAKE_FIRST; measured slower / not robust): the
-    discriminator run as two independent sub-runs -- two loss launches, two backward calls -- and its fake pass issued in front of the real one.
-    Same arithmetic in another order: losses and parameters after four one-graph iterations agree with the default schedule to the association of
-    multi-consumer gradient sums (autograd orders independent nodes by age, and both schedules change the ages)."""
+    """The two opt-in schedules of round 6 (gansynth_amd/config.py: GS_SUB_RUNS, GS_FAKE_FIRST): the discriminator run as two
+    independent sub-runs -- two loss launches, two backward calls -- and its fake pass issued in front of the real one.  Same arithmetic in
+    another order.  Both learning rates are ZERO here, so that nothing amplifies a reassociated sum (TF-Adam's first steps are sign-like): the
+    parameters never move, the optimizer steps still run inside the graph, and the losses and BOTH networks' gradients of four one-graph
+    iterations on four different batches must agree with the default schedule to fp32 association (bf16: to a bf16 rounding of a downstream
+    activation)."""
     from gansynth_amd import variables
+    from gansynth_amd.utils import Dict
     out = {}
     batches = [R.synthetic_batch(4, rank=i, image_shape=(2, 16, 128)) for i in range(4)]
+    hyper = Dict(R.DEFAULT_HYPER)
+    hyper.generator_learning_rate = hyper.discriminator_learning_rate = 0.0
     for mode in ("default", "sub_runs", "fake_first"):
         variables.set_default_store(variables.VariableStore(device="cuda"))
-        pg, opg, model = make(level, variables.default_store(), full=False, dtype=dtype)
-        model.use_graphs, model.keep_gradients = True, False
+        pg, opg, model = make(level, variables.default_store(), full=False, dtype=dtype, hyper=hyper)
+        model.use_graphs, model.keep_gradients = True, True
         model.sub_runs, model.fake_first = mode == "sub_runs", mode == "fake_first"
         cur = [0]
 
@@ -981,21 +1007,85 @@ def test_alternative_issue_orders_of_the_discriminator_run(gpu_store, level, dty
         lat, lab, _ = batches[0]
         model._build(cuda(lat).to(dtype), cuda(lab).to(dtype))
         variables.default_store().load_state_dict({**gp, **dp})
-        losses = []
+        before = (model.d_params.flat.clone(), model.g_params.flat.clone())
+        rec = []
         for _ in range(4):
             d_loss, g_loss = model.train_step()
-            losses += [float(d_loss), float(g_loss)]
-        model.synchronize()
+            model.synchronize()
+            rec.append((float(d_loss), float(g_loss), model.d_params.grad.clone(), model.g_params.grad.clone()))
         assert model._merged is not None and model._merged["fused"] and model.global_step == 4
-        out[mode] = (losses, model.d_params.flat.clone(), model.g_params.flat.clone())
+        assert (model.d_params.t, model.g_params.t) == (4, 4)
+        assert torch.equal(model.d_params.flat, before[0]) and torch.equal(model.g_params.flat, before[1])   # lr = 0: the steps ran and moved nothing
+        assert float(model.d_params.v.abs().max()) > 0 and float(model.g_params.v.abs().max()) > 0            # ... but they ran
+        out[mode] = rec
         del model
-    tol = 1e-5 if dtype == torch.float32 else 2e-3   # (bf16: a reassociated fp32 sum can move a bf16 rounding of a downstream activation)
+    tol = 1e-5 if dtype == torch.float32 else 4e-3
     for mode in ("sub_runs", "fake_first"):
-        for i, (a, b) in enumerate(zip(out["default"][0], out[mode][0])):
-            assert abs(a - b) <= max(5e-5, 10 * tol) * max(1.0, abs(a)), (mode, i, a, b)
-        for k, what in ((1, "discriminator"), (2, "generator")):
-            err = float((out["default"][k] - out[mode][k]).abs().max()) / float(out["default"][k].abs().max())
-            assert err <= 4 * tol, (mode, what, err)
+        for i, (ref, got) in enumerate(zip(out["default"], out[mode])):
+            for k, what in ((0, "discriminator loss"), (1, "generator loss")):
+                assert abs(ref[k] - got[k]) <= max(tol, 2e-5) * max(1.0, abs(ref[k])), (mode, i, what, ref[k], got[k])
+            for k, what in ((2, "discriminator gradient"), (3, "generator gradient")):
+                err = float((ref[k] - got[k]).abs().max()) / float(ref[k].abs().max())
+                assert err <= tol, (mode, i, what, err)
+
+
+@pytest.mark.parametrize("full,dtype,iterations", [(False, torch.float32, 240), (False, torch.bfloat16, 240), (True, torch.bfloat16, 45)])
+def test_replayed_iterations_reproduce_the_eager_gradients(gpu_store, full, dtype, iterations):
+    """A missing dependency between two streams of a captured iteration shows as a WRONG NUMBER ONCE IN A WHILE, which comparisons after a few
+    optimizer steps cannot tell from TF-Adam's amplification of round-off.  Here both learning rates are zero: the parameters never move, every
+    replayed iteration must reproduce the eagerly launched, one-stream gradients of its batch (three batches in rotation), and hundreds of
+    replays are checked one by one -- every schedule (one graph, the pair, no branches, the two opt-in issue orders), reduced size fp32 / bf16
+    and configs[1] itself.  (Round 6: this found the real and the fake pass's `_WeightSlice.backward` adding into one slice of w.grad from two
+    streams unordered -- one contribution lost in ~2 % of the fp32 iterations -- and the sub-run schedule's early contraction reading the fake
+    sub-run's pairs without waiting for its stream.)"""
+    from gansynth_amd import variables
+    from gansynth_amd.utils import Dict
+    n, res = (8, (2, 128, 1024)) if full else (4, (2, 16, 128))
+    batches = [R.synthetic_batch(n, rank=i, image_shape=res) for i in range(3)]
+    hyper = Dict(R.DEFAULT_HYPER)
+    hyper.generator_learning_rate = hyper.discriminator_learning_rate = 0.0
+    tol = 1e-5 if dtype == torch.float32 else 1e-3   # (same kernels on the same operands: association of fp32 sums only)
+    ref = None
+    for mode in ("eager", "one graph", "pair", "no branches", "sub_runs", "fake_first"):
+        variables.set_default_store(variables.VariableStore(device="cuda"))
+        pg, opg, model = make(1.0, variables.default_store(), full=full, dtype=dtype, hyper=hyper)
+        model.use_graphs, model.keep_gradients = mode != "eager", True
+        model.fuse_iteration = mode != "pair"
+        model.sub_runs, model.fake_first = mode == "sub_runs", mode == "fake_first"
+        if mode == "no branches":
+            model.fork = False
+        cur = [0]
+
+        def real_input_fn():
+            lat, lab, real = batches[cur[0] % 3]
+            return cuda(real).to(dtype), cuda(lab).to(dtype)
+
+        def fake_input_fn():
+            lat, _, _ = batches[cur[0] % 3]
+            cur[0] += 1
+            return cuda(lat).to(dtype)
+        model.real_input_fn, model.fake_input_fn = real_input_fn, fake_input_fn
+        gp, dp = opg.init_params(seed=0, bias_std=0.1)
+        lat, lab, _ = batches[0]
+        model._build(cuda(lat).to(dtype), cuda(lab).to(dtype))
+        variables.default_store().load_state_dict({**gp, **dp})
+        rec, wrong = [], []
+        for it in range(3 if mode == "eager" else (iterations if mode in ("one graph", "pair") else iterations // 3)):
+            model.train_step()
+            model.synchronize()
+            grads = (model.d_params.grad.clone(), model.g_params.grad.clone())
+            if mode == "eager":
+                rec.append(grads)
+                continue
+            for k, what in ((0, "discriminator"), (1, "generator")):
+                err = float((grads[k] - ref[it % 3][k]).abs().max()) / float(ref[it % 3][k].abs().max())
+                if not err <= tol:
+                    wrong.append((it, what, err))
+        if mode == "eager":
+            ref = rec
+        else:
+            assert not wrong, (mode, len(wrong), wrong[:6])
+        del model
 
 
 def _dp_trainer(level, batches, full=False, dtype=torch.float32, distributed=True, graphs=True, keep=True):
