@@ -327,6 +327,7 @@ class GANSynth(object):
         self.fake_first = _FAKE_FIRST   # (see _d_fake_first)
         self._g_ready = None          # event: the generator's weights (and prepared operands) of this iteration are final on the fake pass's stream
         self.sub_runs = _SUB_RUNS
+        self.split_g_loss = not config.flag("GS_NO_SPLIT_G_LOSS")   # A/B switch, see _g_losses_b
         self._g_pending = None        # lr_t of a generator step whose gradient is in the flat buffer and whose update has not run yet
         self._marks = {}
         self._serial_run = False
@@ -728,6 +729,19 @@ class GANSynth(object):
     def _g_losses_b(self, part_a, labels, fused=False):
         hp = self.hyper_params
         fake_images, mode_seeking = part_a
+        if fused and mode_seeking is not None and self.split_g_loss and self._serial_run_or_merged() and hasattr(F, "gan_g_loss_mode_seeking"):
+            # L_G = mean(softplus(-f)) + mean(w / (s + eps)) as TWO roots of one backward call: the mode-seeking half needs nothing of the
+            # discriminator, so its second-order pass -- the longest chain of this run -- starts at the run's FIRST node, beside the
+            # discriminator's forward over G(z), instead of behind a loss launch that waits for that forward (in a replayed graph a node starts
+            # when its dependencies are done, whatever the order it was issued in: DESIGN.md 6.6).  One launch per half; the gradients are the
+            # same numbers, the loss value is the sum of the two partial means.
+            l_ms = F.gan_g_loss_mode_seeking(mode_seeking, hp.mode_seeking_loss_weight, 1.0e-6)
+            with self._branch("g_images", join=False):   # (joined at the end of the run, _part_b)
+                _, fake_logits = self.discriminator(fake_images, labels)
+                l_adv = F.gan_g_loss(fake_logits, labels, None, 0.0, 1.0e-6)
+            return (l_adv, l_ms)
+        # (the same split of the DISCRIMINATOR's loss -- real half and fake half as two roots of one backward call -- measured 5.15 -> 5.41 ms: the
+        #  fake pass then started 0.9 ms into the graph behind a chain it does not depend on, profiles/r06_p_split_losses_ab.txt; not kept)
         with self._branch("g_images") if mode_seeking is not None else contextlib.nullcontext():
             _, fake_logits = self.discriminator(fake_images, labels)   # (its backward then runs on the branch too: beside the second-order pass)
         if fused:
@@ -737,6 +751,9 @@ class GANSynth(object):
         if mode_seeking is not None:
             losses = losses + mode_seeking * hp.mode_seeking_loss_weight
         return losses
+
+    def _serial_run_or_merged(self):
+        return self._serial_run or self._nodes_on_side2 or self._capturing() or not self._forking()
 
     def generator_losses(self, latents, labels):
         return self._g_losses_b(self._g_losses_a(latents, labels), labels)
@@ -808,7 +825,8 @@ class GANSynth(object):
         self._origin = torch.cuda.current_stream() if torch.cuda.is_available() else None   # (the stream this run is issued -- or captured -- on)
         losses = self._d_losses_b(part_a, *inputs, fused=fused) if which == "d" else self._g_losses_b(part_a, *inputs, fused=fused)   # (latents, labels) | (labels,)
         sub_runs = losses if isinstance(losses, list) else None   # [(context factory, forward() -> root)]: see _d_sub_runs
-        loss = None if sub_runs is not None else (losses if losses.dim() == 0 else losses.mean())   # (the fused loss kernels return the mean itself)
+        multi = losses if isinstance(losses, tuple) else None     # several roots of ONE backward call: see _g_losses_b
+        loss = None if (sub_runs is not None or multi is not None) else (losses if losses.dim() == 0 else losses.mean())   # (the fused loss kernels return the mean itself)
         hook, self._after_loss = self._after_loss, None
         if hook is not None and sub_runs is None:
             # Merged iteration: part A of the other run forks off HERE and is issued here, in front of this run's backward (see _capture_merged).
@@ -835,15 +853,23 @@ class GANSynth(object):
             F.reset_fusion_state()   # (side-channel state of cross-node fusions is per backward pass)
         def backward(root):
             with (F.params_only() if hasattr(F, "params_only") else contextlib.nullcontext()):   # tf.gradients(loss, var_list): leaf activations want no gradient
-                if root.is_cuda and root.dim() == 0 and root.dtype == torch.float32 and not self._capturing_fresh_seed(root.device):
-                    torch.autograd.backward(root, grad_tensors=F.unit_seed(root.device))   # (the loss heads recognise the seed: functional.unit_seed)
+                many = list(root) if isinstance(root, (tuple, list)) else None
+                first = many[0] if many is not None else root
+                if first.is_cuda and first.dim() == 0 and first.dtype == torch.float32 and not self._capturing_fresh_seed(first.device):
+                    seed = F.unit_seed(first.device)   # (the loss heads recognise the seed: functional.unit_seed)
+                    torch.autograd.backward(many if many is not None else root, grad_tensors=[seed] * len(many) if many is not None else seed)
+                elif many is not None:
+                    torch.autograd.backward(many)
                 else:
                     root.backward()
 
         roots = []
         self._in_sub_runs = sub_runs is not None
         try:
-            if sub_runs is None:
+            if multi is not None:
+                backward(multi)
+                roots = [r.detach() for r in multi]
+            elif sub_runs is None:
                 backward(loss)
             else:
                 for context, forward in sub_runs:   # each on its own stream, whole: forward (what is left of it), loss, backward
@@ -881,7 +907,7 @@ class GANSynth(object):
         if hook is not None:   # (sub-runs: part A of the other run is issued last and starts where the generator's weights are final)
             hook(self._g_ready)
         self._join_branches()   # (a branch opened by the flush itself; a branch left open would fail the capture)
-        if sub_runs is not None:
+        if sub_runs is not None or multi is not None:
             loss = roots[0]
             for r in roots[1:]:
                 if r.is_cuda:

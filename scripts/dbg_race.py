@@ -14,19 +14,21 @@ batches = [R.synthetic_batch(n, rank=i, image_shape=res) for i in range(NB)]
 hyper = Dict(R.DEFAULT_HYPER); hyper.generator_learning_rate = hyper.discriminator_learning_rate = 0.0
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 modes = os.environ.get("DBG_MODES", "eager,default,pair,sub_runs,nofork").split(",")
-if any(m.startswith("dist") for m in modes):
+if any(m.startswith("dist") or m == "overlapped" for m in modes):
     import torch.distributed as dist
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % (29400 + os.getpid() % 500), rank=0, world_size=1, device_id=torch.device("cuda", 0))
 ref = None
 for mode in modes:
     variables.set_default_store(variables.VariableStore(device="cuda"))
-    pg, opg, model = make(1.0, variables.default_store(), full=full, dtype=dtype, hyper=hyper)
+    pg, opg, model = make(float(os.environ.get("DBG_LEVEL", "1.0")), variables.default_store(), full=full, dtype=dtype, hyper=hyper)
     model.use_graphs, model.keep_gradients = mode not in ("eager", "sub_runs_eager"), not os.environ.get("DBG_NOKEEP")
     model.sub_runs = mode.startswith("sub_runs")
-    if mode.startswith("dist"):   # dist_eager / dist_torch_eager / dist_graph
+    if mode == "overlapped":
+        mode_ = "dist_graph"; model.overlap_reduce = True
+    if mode.startswith("dist") or mode == "overlapped":   # dist_eager / dist_torch_eager / dist_graph / overlapped
         model.distributed, model.world, model.bucket_bytes = True, 1, 16 << 10
-        model.use_graphs = mode == "dist_graph"
+        model.use_graphs = mode in ("dist_graph", "overlapped")
         if "torch" in mode: os.environ["GS_TORCH_COLLECTIVES"] = "1"
         else: os.environ.pop("GS_TORCH_COLLECTIVES", None)
     if mode == "sub_runs_nofork": model.fork = False
@@ -61,7 +63,11 @@ for mode in modes:
     if mode == "eager":
         ref = rec
         # the input functions advance one batch per iteration with period NB: iteration i of any mode sees what eager iteration i % period saw
-        assert all(float((ref[i][0] - ref[i + NB][0]).abs().max()) == 0 for i in range(NB)), "eager is not periodic"
+        for i in range(NB):
+            for k, nm in ((0, "D"), (1, "G")):
+                d = float((ref[i][k] - ref[i + NB][k]).abs().max())
+                if d != 0:
+                    print("  eager iteration %d vs %d: %s gradient differs by %.3g of %.3g" % (i, i + NB, nm, d, float(ref[i][k].abs().max())))
         ref = ref[:NB]
     else:
         print("%s: %d of %d replayed gradient buffers differ from the eager ones" % (mode, bad, 2 * iters))

