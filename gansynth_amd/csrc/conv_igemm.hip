@@ -574,7 +574,11 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void conv_igemm_kernel(const Conv
                     typedef typename std::conditional<SZ == 4, float4, uint4>::type mvec_t;
                     constexpr int NV = SZ == 4 ? 4 : 2;              // mask vectors per 32-channel tile of a pixel
                     auto mask_fetch = [&](long off, bool inside, mvec_t (&mz)[A][NV]) __attribute__((always_inline)) {
+#ifdef GS_ABL_NOMASKLOAD   // (ablation build only: every mask load hits the same few cache lines -- what would a mask of no bytes be worth?)
+                        const long base = (inside ? off : 0) & 1023;
+#else
                         const long base = inside ? off : 0;          // clamped: the loads stay unconditional
+#endif
 #pragma unroll
                         for (int a = 0; a < A; ++a)
 #pragma unroll
