@@ -52,6 +52,7 @@ KNOBS = {
     "GS_NO_DEFERRED_FOLDS": ("ablation", "bias-gradient partial rows folded by their producers"),
     "GS_NO_WGRAD_GROUPS": ("ablation", "no grouped weight-gradient launches"),
     "GS_NO_SPLIT_G_LOSS": ("ablation", "the generator's loss as one launch over both halves: the mode-seeking second-order pass waits for the discriminator's forward"),
+    "GS_NO_SPLIT_FINAL_FLUSH": ("ablation", "the final weight-gradient contraction of a run on one stream (HBM-bound and MFMA-bound jobs one after the other)"),
     "GS_NO_FUSED_LOSSES": ("ablation", "per-sample loss algebra in torch instead of the one-launch loss heads"),
     "GS_NO_D_TAIL_BATCH": ("ablation", "real and fake pass through the discriminator's tail separately (no-fork schedule)"),
     "GS_NO_FUSED_NORM": ("ablation", "pixel norm as its own node behind every generator conv"),

@@ -295,7 +295,7 @@ class HipKernels(object):
             grp["bias"] = bias_out
         grp["src"].append((x, gy, bias_out is not None))
 
-    def flush_wgrad_reductions(self, group_of=None, on_group_done=None, select=None):
+    def flush_wgrad_reductions(self, group_of=None, on_group_done=None, select=None, split_stream=None):
         """`group_of(out.data_ptr()) -> int | None` orders the layers into groups (the trainer's gradient buckets, in completion
         order); each group is contracted and folded before the next one starts and `on_group_done(group)` is called right after
         its last launch -- the data-parallel trainer puts that bucket's all-reduce on the wire there."""
@@ -319,11 +319,26 @@ class HipKernels(object):
                 if g is not None and on_group_done is not None:
                     on_group_done(g)
             return n
-        return self._flush_groups(groups)
+        return self._flush_groups(groups, split_stream)
 
-    def _flush_groups(self, groups):
+    def _flush_groups(self, groups, split_stream=None):
         """One gs_conv_wgrad_jobs call for every recorded layer of `groups`: the library groups the layers by kernel
-        instantiation (one stream-K launch + one fold per group) and batches the rest."""
+        instantiation (one stream-K launch + one fold per group) and batches the rest.
+        `split_stream` (a captured run's idle branch stream): the HBM-bound jobs -- the <= 32-input-channel layers at the top of the pyramid,
+        streaming kernels -- go THERE, beside the MFMA-bound grouped contractions of the other layers on this stream: the jobs of a flush are
+        independent of each other, one launch after the other on one stream each of them has the chip to itself with half of it idle."""
+        if split_stream is not None and self._guarding and len(groups) > 1:
+            thin = {k: g for k, g in groups.items() if int(k[5][0]) <= 32}
+            rest = {k: g for k, g in groups.items() if int(k[5][0]) > 32}
+            if thin and rest:
+                # (a THIRD stream for the stride-2 / transposed layers' grouped launch beside the stride-1 layers': measured neutral, 5.01 / 5.01 ms)
+                main = torch.cuda.current_stream()
+                split_stream.wait_stream(main)
+                with torch.cuda.stream(split_stream):
+                    n = self._flush_groups(thin)
+                n += self._flush_groups(rest)
+                main.wait_stream(split_stream)
+                return n
         jobs, keep = [], []
         for key, grp in groups.items():
             kind, ksize, stride, alpha = key[0], key[2], key[3], key[4]

@@ -328,6 +328,7 @@ class GANSynth(object):
         self._g_ready = None          # event: the generator's weights (and prepared operands) of this iteration are final on the fake pass's stream
         self.sub_runs = _SUB_RUNS
         self.split_g_loss = not config.flag("GS_NO_SPLIT_G_LOSS")   # A/B switch, see _g_losses_b
+        self.split_final_flush = not config.flag("GS_NO_SPLIT_FINAL_FLUSH")   # A/B switch, see kernels.HipKernels._flush_groups
         self._g_pending = None        # lr_t of a generator step whose gradient is in the flat buffer and whose update has not run yet
         self._marks = {}
         self._serial_run = False
@@ -900,6 +901,8 @@ class GANSynth(object):
                 if overlap:   # contract the layers bucket by bucket; a finished bucket goes on the wire under the next one's kernels
                     K.flush_wgrad_reductions(group_of=params.bucket_of,
                                              on_group_done=lambda i: launched.append((i, self._launch_reduce(params, i))))
+                elif self.split_final_flush and self._forking() and self._side is not None and self._capturing():
+                    K.flush_wgrad_reductions(split_stream=self._side)   # (the branch is idle here: joined above)
                 else:
                     K.flush_wgrad_reductions()
         if launched:
