@@ -129,6 +129,10 @@ template <int CTRL> __device__ inline float dpp_mov(float x) {
 // of the swap (v_mov, v_mov, v_mov, swap, swap in the NORM == 2 epilogue of conv_igemm) and the bf16 instantiation of that epilogue then
 // summed wrong halves on the hardware (test_data_gradient_continued_through_the_previous_pixel_norm, 40 % of the tensor's scale) while the
 // fp32 one (v_mov, v_mov, s_nop 0, swap, swap) was right -- five idle cycles on either side of the swap and both are.
+// (Round 6, advisor: was an undeclared M0 write of the LDS-DMA asm the real cause?  No: with M0 declared clobbered there and the padding
+//  removed here, 10 kernel tests fail again (pixel-norm sums, bias folds) -- the wait states are a data hazard of the swap itself, between the
+//  VALU write of its operands and the swap and between the swap and its consumer, which the compiler's hazard recogniser does not insert
+//  around inline asm.)
 __device__ inline float swap16_sum(float v) {   // v[lane] + v[lane ^ 16]
     float a = v, b;
     asm volatile("v_mov_b32 %1, %0\n\ts_nop 4\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 4" : "+v"(a), "=&v"(b));
