@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libgansynth_hip.so")
 
 GS_F32, GS_BF16 = 0, 1
 ACT_NONE, ACT_LRELU, ACT_TANH = 0, 1, 2
+ACT_LRELU_BITS, ACT_WRITE_BITS = 5, 16   # include/gansynth_hip.h: 1-bit leaky-relu masks
 PREP_CONV_FWD, PREP_CONV_BWD_DATA, PREP_CONVT_FWD, PREP_CONVT_BWD_DATA = 0, 1, 2, 3
 CONV_FWD, CONV_BWD_DATA, CONV_BWD_WEIGHT = 0, 1, 2
 
@@ -111,6 +112,7 @@ SIGNATURES = {
     "gs_adam_tf_step": (I, [P, P, P, P, L, F, F, F, F, F, P]),
     "gs_adam_tf_step_zero_grad": (I, [P, P, P, P, L, F, F, F, F, F, P]),
     "gs_adam_tf_step_dev": (I, [P, P, P, P, L, P, F, F, F, F, I, P]),
+    "gs_pack_act_bits": (I, [P, L, I, I, P]),
     "gs_spectral_plan_create": (I, [POINTER(c_void_p), I, I, I, P, P]),
     "gs_spectral_plan_destroy": (I, [P]),
     "gs_stft_fwd": (I, [P, P, I, I, I, P, P, P]),

@@ -60,6 +60,7 @@ KNOBS = {
     "GS_NO_NORM_BWD_EPILOGUE": ("ablation", "no previous-block norm backward in data-gradient epilogues"),
     "GS_NO_NORM_BWD2_EPILOGUE": ("ablation", "no second-order norm kernel in the forward-on-cotangent conv"),
     "GS_NO_NORM_BWD_BIAS": ("ablation", "bias sums outside the norm's backward"),
+    "GS_NO_MASK_BITS": ("ablation", "leaky-relu masks read as the bf16 activations themselves, not as the sign bits stored behind them"),
     "GS_NO_PREMASK": ("ablation", "activation derivative never folded into the consuming data-gradient kernel"),
     "GS_NO_PREMASK_GRAPH": ("ablation", "... not across autograd nodes"),
     "GS_NO_PREMASK_GRAPH2": ("ablation", "... not in second-order graphs"),

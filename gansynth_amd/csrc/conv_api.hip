@@ -138,7 +138,9 @@ template <typename T, int IC, int ACT, bool MASKED>
 // block forward on a cotangent and the next node's first step is that multiplication (gs_conv2d_fwd_mask)
 __global__ __launch_bounds__(256) void thin_expand_kernel(const T* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
                                                           T* __restrict__ y, long P, int OC, float alpha,
-                                                          const T* __restrict__ mask = nullptr, int mask_act = 0) {
+                                                          const T* __restrict__ mask = nullptr, int mask_act = 0, unsigned* __restrict__ bits = nullptr) {
+    // `bits` (bf16 leaky relu, OC % 32 == 0): the sign words of the result behind it (include/gansynth_hip.h, GS_ACT_WRITE_BITS) -- a lane's 8 channels
+    // are one byte of the pixel's word, the four lanes of a 32-channel tile are a DPP quad
     constexpr int WN = Wide<T>::N;
     const int groups = OC / WN;
     const int oc0 = (threadIdx.x % groups) * WN;
@@ -198,6 +200,21 @@ __global__ __launch_bounds__(256) void thin_expand_kernel(const T* __restrict__ 
             ld_wide<T>(mask + px * OC + oc0, mv);
 #pragma unroll
             for (int v = 0; v < WN; ++v) o[v] *= mask_act == GS_ACT_LRELU ? (mv[v] > 0.f ? 1.f : 0.2f) : (mask_act == GS_ACT_TANH ? 1.f - mv[v] * mv[v] : 1.f);
+        }
+        if constexpr (ACT == GS_ACT_LRELU && !MASKED && sizeof(T) == 2) {
+            if (bits) {
+                uint4 v;
+                v.x = pack_bf16x2(o[0], o[1]); v.y = pack_bf16x2(o[2], o[3]); v.z = pack_bf16x2(o[4], o[5]); v.w = pack_bf16x2(o[6], o[7]);
+                *reinterpret_cast<uint4*>(y + px * OC + oc0) = v;
+                const unsigned b8 = ((int)(v.x << 16) > 0 ? 1u : 0u) | ((int)v.x >= 0x10000 ? 2u : 0u) | ((int)(v.y << 16) > 0 ? 4u : 0u) | ((int)v.y >= 0x10000 ? 8u : 0u) |
+                                    ((int)(v.z << 16) > 0 ? 16u : 0u) | ((int)v.z >= 0x10000 ? 32u : 0u) | ((int)(v.w << 16) > 0 ? 64u : 0u) | ((int)v.w >= 0x10000 ? 128u : 0u);
+                const int piece = (oc0 >> 3) & 3;   // 16-byte piece of the tile: channels 8 piece .. -> byte 2 (piece & 1) + (piece >> 1) of the word
+                unsigned word = b8 << (8 * (2 * (piece & 1) + (piece >> 1)));
+                word |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)word, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+                word |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)word, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
+                if (piece == 0) bits[(px * OC + oc0) >> 5] = word;
+                return;
+            }
         }
         st_wide<T>(y + px * OC + oc0, o);
     };
@@ -488,7 +505,7 @@ __global__ __launch_bounds__(256) void thin_single3_kernel(const T* __restrict__
 static int run_direct(int mode, int ks, int variant, const void* x, const float* w_hwio, void* y, int N, int Hi, int Wi,
                       int ICk, int OCk, int w_ci, int w_co, int Ho, int Wo, float alpha, int dtype, int w_prepared, void* ws,
                       size_t ws_bytes, hipStream_t st, const float* bias = nullptr, int act = GS_ACT_NONE, bool* fused = nullptr,
-                      const void* mask = nullptr, int mask_act = 0, bool* mask_fused = nullptr) {
+                      const void* mask = nullptr, int mask_act = 0, bool* mask_fused = nullptr, unsigned* bits_out = nullptr, bool* bits_done = nullptr) {
     const long total = (long)ks * ks * w_ci * w_co;
     if (ws_bytes < (size_t)total * 4) return fail(GS_ERR_WORKSPACE, "conv direct: workspace %zu < %zu", ws_bytes, (size_t)total * 4);
     float* wp = reinterpret_cast<float*>(ws);
@@ -505,7 +522,9 @@ static int run_direct(int mode, int ks, int variant, const void* x, const float*
         static const long te_cap = getenv("GS_THIN_EXPAND_BLOCKS") ? atol(getenv("GS_THIN_EXPAND_BLOCKS")) : 2048;
         if (nb > te_cap) nb = te_cap;
         const unsigned grid = (unsigned)nb;
-#define GS_TE(TT, ICV, ACTV, MK) hipLaunchKernelGGL((thin_expand_kernel<TT, ICV, ACTV, MK>), dim3(grid), dim3(256), 0, st, (const TT*)x, wp, bias, (TT*)y, P, OCk, alpha, (const TT*)mask, mask_act)
+        unsigned* te_bits = (bits_out && bits_done && !mask && act == GS_ACT_LRELU && dtype == GS_BF16 && OCk % 32 == 0) ? bits_out : nullptr;
+        if (te_bits) *bits_done = true;
+#define GS_TE(TT, ICV, ACTV, MK) hipLaunchKernelGGL((thin_expand_kernel<TT, ICV, ACTV, MK>), dim3(grid), dim3(256), 0, st, (const TT*)x, wp, bias, (TT*)y, P, OCk, alpha, (const TT*)mask, mask_act, te_bits)
 #define GS_TE_ACT(TT, ICV)                                                                                               \
     do {                                                                                                                 \
         if (mask) {   /* (masked: a forward on a cotangent -- the activation, if any, is applied by the slower generic form) */ \
@@ -865,19 +884,29 @@ static int conv2d_fwd_impl(const void* x, const float* w_hwio, const float* bias
                            int stride, float alpha, int dtype, int w_prepared, void* ws, size_t ws_bytes, void* stream, void* y2 = nullptr,
                            float pn_eps = 0.f) {
     if (int e = check_conv_args(n, h, w, ci, co, ksize, stride, dtype)) return e;
+    const bool want_bits = (act & GS_ACT_WRITE_BITS) != 0;   // (the caller's y has room for the sign bits behind it: include/gansynth_hip.h)
+    act &= ~GS_ACT_WRITE_BITS;
     GS_CHECK_ARG(act == GS_ACT_NONE || act == GS_ACT_LRELU || act == GS_ACT_TANH, "conv2d: bad activation %d", act);
+    GS_CHECK_ARG(!want_bits || (act == GS_ACT_LRELU && dtype == GS_BF16 && co % 32 == 0 && y), "conv2d: sign bits go with a bf16 leaky-relu result of 32 k channels");
     GS_CHECK_ARG(y || y2, "conv2d: no output");
     hipStream_t st = as_stream(stream);
     const int hb = h / stride, wb = w / stride;
     const int mode = stride == 2 ? MODE_S2 : MODE_S1;
     if (ksize == 3 && igemm_supported(ci, co, dtype) && act != GS_ACT_TANH)
-        return run_igemm(mode, 0, x, w_hwio, y, n, h, w, ci, co, ci, co, hb, wb, alpha, bias, act, dtype, w_prepared, ws, ws_bytes, st, nullptr, 0, y2, pn_eps);
+        return run_igemm(mode, 0, x, w_hwio, y, n, h, w, ci, co, ci, co, hb, wb, alpha, bias, act | (want_bits ? GS_ACT_WRITE_BITS : 0), dtype, w_prepared, ws,
+                         ws_bytes, st, nullptr, 0, y2, pn_eps);
     void* z = y ? y : y2;
     bool fused = false;
-    if (int e = run_direct(mode, ksize, 0, x, w_hwio, z, n, h, w, ci, co, ci, co, hb, wb, alpha, dtype, w_prepared, ws, ws_bytes, st, bias, act, &fused)) return e;
+    bool bits_done = false;
+    unsigned* bits_out = (want_bits && !y2) ? reinterpret_cast<unsigned*>(reinterpret_cast<unsigned short*>(y) + (size_t)n * hb * wb * co) : nullptr;
+    if (int e = run_direct(mode, ksize, 0, x, w_hwio, z, n, h, w, ci, co, ci, co, hb, wb, alpha, dtype, w_prepared, ws, ws_bytes, st, bias, act, &fused, nullptr, 0, nullptr,
+                           bits_out, &bits_done))
+        return e;
     if (!fused && (bias || act != GS_ACT_NONE))
         if (int e = gs_bias_act_fwd(z, bias, z, (int64_t)n * hb * wb, co, act, dtype, stream)) return e;
-    if (y2) return gs_pixel_norm_fwd(z, y2, (int64_t)n * hb * wb, co, pn_eps, dtype, stream);
+    if (y2)
+        if (int e = gs_pixel_norm_fwd(z, y2, (int64_t)n * hb * wb, co, pn_eps, dtype, stream)) return e;
+    if (want_bits && !bits_done) return gs_pack_act_bits(y, (int64_t)n * hb * wb, co, dtype, stream);   // (direct kernels other than the colour block's)
     return 0;
 }
 
@@ -900,14 +929,16 @@ extern "C" int gs_act_bwd(const void* g, const void* y, void* gx, int64_t numel,
 extern "C" int gs_conv2d_fwd_mask(const void* x, const float* w_hwio, const void* mask, int mask_act, void* y, int n, int h, int w, int ci, int co,
                                   int ksize, int stride, float alpha, int dtype, int w_prepared, void* ws, size_t ws_bytes, void* stream) {
     if (int e = check_conv_args(n, h, w, ci, co, ksize, stride, dtype)) return e;
-    GS_CHECK_ARG(mask == nullptr || mask_act == GS_ACT_LRELU || mask_act == GS_ACT_TANH, "conv2d_fwd_mask: bad activation %d", mask_act);
+    GS_CHECK_ARG(mask == nullptr || mask_act == GS_ACT_LRELU || mask_act == GS_ACT_TANH || mask_act == GS_ACT_LRELU_BITS, "conv2d_fwd_mask: bad activation %d", mask_act);
     hipStream_t st = as_stream(stream);
     const int hb = h / stride, wb = w / stride;
     const int mode = stride == 2 ? MODE_S2 : MODE_S1;
     const bool fused = mask != nullptr && co >= mask_fuse_min_channels() && ksize == 3 && igemm_supported(ci, co, dtype);
     int rc;
+    const int bits_act = mask_act;   // (only the MFMA epilogue reads the sign bits; every other path reads the values they stand behind)
+    if (mask_act == GS_ACT_LRELU_BITS) mask_act = GS_ACT_LRELU;
     if (ksize == 3 && igemm_supported(ci, co, dtype))
-        rc = run_igemm(mode, 0, x, w_hwio, y, n, h, w, ci, co, ci, co, hb, wb, alpha, nullptr, GS_ACT_NONE, dtype, w_prepared, ws, ws_bytes, st, fused ? mask : nullptr, mask_act);
+        rc = run_igemm(mode, 0, x, w_hwio, y, n, h, w, ci, co, ci, co, hb, wb, alpha, nullptr, GS_ACT_NONE, dtype, w_prepared, ws, ws_bytes, st, fused ? mask : nullptr, bits_act);
     else {   // (the colour block's streaming kernel applies the mask itself; the other direct kernels leave it to the pass below)
         bool epi = false, mdone = false;
         rc = run_direct(mode, ksize, 0, x, w_hwio, y, n, h, w, ci, co, ci, co, hb, wb, alpha, dtype, w_prepared, ws, ws_bytes, st, nullptr, GS_ACT_NONE, &epi, mask, mask_act, &mdone);
@@ -930,7 +961,9 @@ extern "C" int gs_act_bwd(const void* g, const void* y, void* gx, int64_t numel,
 extern "C" int gs_conv2d_bwd_data_mask(const void* gy, const float* w_hwio, const void* mask, int mask_act, void* gx, int n, int h, int w, int ci, int co,
                                        int ksize, int stride, float alpha, int dtype, int w_prepared, void* ws, size_t ws_bytes, void* stream) {
     if (int e = check_conv_args(n, h, w, ci, co, ksize, stride, dtype)) return e;
-    GS_CHECK_ARG(mask == nullptr || mask_act == GS_ACT_LRELU || mask_act == GS_ACT_TANH, "conv2d_bwd_data_mask: bad activation %d", mask_act);
+    GS_CHECK_ARG(mask == nullptr || mask_act == GS_ACT_LRELU || mask_act == GS_ACT_TANH || mask_act == GS_ACT_LRELU_BITS, "conv2d_bwd_data_mask: bad activation %d", mask_act);
+    const int bits_act = mask_act;   // (see gs_conv2d_fwd_mask)
+    if (mask_act == GS_ACT_LRELU_BITS) mask_act = GS_ACT_LRELU;
     const float* bias = nullptr;
     const int act = GS_ACT_NONE;
     hipStream_t st = as_stream(stream);
@@ -943,10 +976,10 @@ extern "C" int gs_conv2d_bwd_data_mask(const void* gy, const float* w_hwio, cons
     const void* km = fused ? mask : nullptr;
     if (stride == 1) {  // flipped taps, roles of ci/co swapped
         if (ksize == 3 && igemm_supported(co, ci, dtype))
-            rc = run_igemm(MODE_S1, 1, gy, w_hwio, gx, n, h, w, co, ci, ci, co, h, w, alpha, bias, act, dtype, w_prepared, ws, ws_bytes, st, km, mask_act);
+            rc = run_igemm(MODE_S1, 1, gy, w_hwio, gx, n, h, w, co, ci, ci, co, h, w, alpha, bias, act, dtype, w_prepared, ws, ws_bytes, st, km, bits_act);
         else { rc = run_direct(MODE_S1, ksize, 1, gy, w_hwio, gx, n, h, w, co, ci, ci, co, h, w, alpha, dtype, w_prepared, ws, ws_bytes, st); fused = false; }
     } else if (igemm_supported(co, ci, dtype)) {
-        rc = run_igemm(MODE_T2, 2, gy, w_hwio, gx, n, hb, wb, co, ci, ci, co, hb, wb, alpha, bias, act, dtype, w_prepared, ws, ws_bytes, st, km, mask_act);
+        rc = run_igemm(MODE_T2, 2, gy, w_hwio, gx, n, hb, wb, co, ci, ci, co, hb, wb, alpha, bias, act, dtype, w_prepared, ws, ws_bytes, st, km, bits_act);
     } else {
         rc = run_direct(MODE_T2, 3, 2, gy, w_hwio, gx, n, hb, wb, co, ci, ci, co, h, w, alpha, dtype, w_prepared, ws, ws_bytes, st);
         fused = false;

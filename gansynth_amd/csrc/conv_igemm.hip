@@ -23,6 +23,7 @@
 #endif
 
 extern "C" int gs_pixel_norm_fwd(const void* x, void* y, int64_t p, int c, float eps, int dtype, void* stream);
+extern "C" int gs_pack_act_bits(void* z, int64_t p, int c, int dtype, void* stream);
 extern "C" int gs_pixel_norm_bwd_fused(const void* g, const void* x, const void* addend, void* gx, int64_t p, int c, float eps, int pre_act, int post_act, int dtype,
                                        void* stream);
 extern "C" int gs_pixel_norm_bwd_bwd_fused(const void* gg, const void* g, const void* x, void* out, void* out_g, int64_t p, int c, float eps, int pre_act,
@@ -100,6 +101,12 @@ struct ConvP {
     int act;
     const void* mask;   // optional (data gradients): y *= mask_act'(.) expressed through the activation OUTPUT mask[..] (y's shape)
     int mask_act;
+    // 1-bit leaky-relu masks (bf16, plain epilogues): the sign bits of an activation output, one dword per (pixel, 32-channel tile) -- bit
+    // 8 (2 hi + qp) + k is channel 16 qp + 8 hi + k of the tile, the order the lanes store their 16-byte pieces in -- written by the forward
+    // epilogue BEHIND the activation itself (same allocation: z [numel] then numel / 8 bytes) and read by the masked epilogues instead of z:
+    // 1/16 of the mask bytes of a launch that is HBM-bound at the top of the pyramid.  (gs_common.h: GS_ACT_LRELU_BITS / GS_ACT_WRITE_BITS)
+    const unsigned char* mask_bits;
+    unsigned char* bits_out;
     void* y2;           // optional (NORM == 1 kernels): y2 = pixel_norm(y) over the channels, y itself optional then
     float pn_eps;
     // NORM == 2 kernels (data gradients): the conv result g is the gradient w.r.t. y = pixel_norm(z) of the PREVIOUS block; the epilogue turns it
@@ -161,7 +168,7 @@ __device__ __forceinline__ void lds_dma16(unsigned lds_addr, unsigned voff, i32x
 __device__ __forceinline__ void lds_dma16_s(unsigned lds_addr, unsigned voff, i32x4 rs, unsigned soff) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                  :
-                 : "s"(lds_addr), "v"(voff), "s"(rs), "s"(soff)
+                 : "s"(lds_addr), "v"(voff), "s"(rs), "s"(__builtin_amdgcn_readfirstlane(soff))   // (uniform by construction; the compiler cannot always prove it)
                  : "memory", "m0");
 }
 // streamed-once operands (the weight-gradient inputs of the HBM-bound layers): non-temporal policy -- the lines are not kept in L2 for a
@@ -214,7 +221,10 @@ __device__ __forceinline__ void block_barrier() {
 // ~5 cycles whatever it is (scripts/probe/valu_rate.hip), so in a 4-wave block the ~60 cycles of each DMA piece (offset arithmetic,
 // M0, the load) come ON TOP of the MFMAs of the stage -- measured 2260 ticks per stage for 1152 ticks of MFMA on the few-block layers
 // (scripts/probe/igemm_trace.hip); on their own wave they run under them.
-template <typename T, int MODE, int A, int B, int TW, int TG, bool RESIDENT, int D, int NORM, int RB = 64, bool SPEC = false>
+// BITS (bf16, plain epilogues): the build of the kernel for launches with 1-bit leaky-relu masks -- its mask, if any, is the sign words behind
+// an activation (p.mask_bits), and with p.bits_out it writes the sign words of its own result.  Its own instantiation, not a run-time branch: with
+// both mask forms in one epilogue the compiler keeps 15-25 more VGPRs live and the larger tiles lose a wave of occupancy.
+template <typename T, int MODE, int A, int B, int TW, int TG, bool RESIDENT, int D, int NORM, int RB = 64, bool SPEC = false, bool BITS = false>
 __global__ __launch_bounds__(SPEC ? 512 : 256) void conv_igemm_kernel(const ConvP p) {
     static_assert(NORM >= 0 && NORM <= 3, "NORM: 0 plain, 1 pixel norm of the result (forward blocks), 2 pixel-norm backward of the result (data gradients), "
                                           "3 both gradients of a differentiated norm backward (second-order pass)");
@@ -469,12 +479,35 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void conv_igemm_kernel(const Conv
     while (true) {
         int n, by, bx, oc0;
         item_coords(item, n, by, bx, oc0);
+        // BITS: the sign words of the lane's pixels, fetched at the START of the item's last stage -- one register per (pixel, 32-channel tile), so
+        // they can wait through the MFMAs of the stage, where the 16-byte mask vectors (8-32 registers) cannot: a mask fetched in the epilogue
+        // costs every item one exposed memory round trip (~0.9 us per 256-pixel item on the 32-channel layers: scripts/mask_bits_micro.py).
+        unsigned mbw[BITS ? B * (MODE == MODE_T2 ? 4 : 1) : 1][A];
         for (int ch = 0; ch < NCH; ++ch) {
 #pragma unroll
             for (int tg = 0; tg < NTG; ++tg) {
                 const int itg = (tg + D) % NTG;            // tap group of the stage issued during this one
                 const int npiece = stage_pieces(itg);
                 if (issuer) issue_setup(itg);
+                if constexpr (BITS) {
+                    if (tg == NTG - 1 && ch == NCH - 1 && computer && p.mask_bits) {
+                        constexpr int NPHB = MODE == MODE_T2 ? 4 : 1;
+                        const int Ho = MODE == MODE_T2 ? 2 * Hb : Hb, Wo = MODE == MODE_T2 ? 2 * Wb : Wb;
+#pragma unroll
+                        for (int b = 0; b < B; ++b) {
+                            const int q = (wv * B + b) * 32 + l31;
+                            const int gy = by + q / TW, gx = bx + q % TW;
+#pragma unroll
+                            for (int ph = 0; ph < NPHB; ++ph) {
+                                const int oy = MODE == MODE_T2 ? 2 * gy + (ph >> 1) : gy;
+                                const int ox = MODE == MODE_T2 ? 2 * gx + (ph & 1) : gx;
+                                const long off = (gy < Hb && gx < Wb) ? (((long)n * Ho + oy) * Wo + ox) * OC + oc0 : 0;   // clamped: unconditional loads
+#pragma unroll
+                                for (int a = 0; a < A; ++a) mbw[b * NPHB + ph][a] = *reinterpret_cast<const unsigned*>(p.mask_bits + ((off + a * 32) >> 3));
+                            }
+                        }
+                    }
+                }
                 if (SPEC && loader) {   // the whole stage +D in one go, under the compute waves' MFMAs
 #pragma unroll
                     for (int q = 0; q < npiece; ++q) issue_piece(q, itg);
@@ -573,6 +606,8 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void conv_igemm_kernel(const Conv
                     // round trip (4-8 dependent trips per tile).
                     typedef typename std::conditional<SZ == 4, float4, uint4>::type mvec_t;
                     constexpr int NV = SZ == 4 ? 4 : 2;              // mask vectors per 32-channel tile of a pixel
+                    constexpr bool use_mb = BITS;   // (1-bit masks: bf16, plain epilogues)
+                    const bool emit_bits = BITS && p.bits_out != nullptr;
                     auto mask_fetch = [&](long off, bool inside, mvec_t (&mz)[A][NV]) __attribute__((always_inline)) {
 #ifdef GS_ABL_NOMASKLOAD   // (ablation build only: every mask load hits the same few cache lines -- what would a mask of no bytes be worth?)
                         const long base = (inside ? off : 0) & 1023;
@@ -585,11 +620,12 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void conv_igemm_kernel(const Conv
                             for (int v = 0; v < NV; ++v)
                                 mz[a][v] = *reinterpret_cast<const mvec_t*>(reinterpret_cast<const T*>(p.mask) + base + a * 32 + v * (32 / NV) + hi * (16 / NV));
                     };
-                    auto store = [&](T* dst, long off, int a, float (&o)[4][4], bool inside, const mvec_t* mz) __attribute__((always_inline)) {
+                    auto store = [&](T* dst, long off, int a, float (&o)[4][4], bool inside, const mvec_t* mz, int mkind = 0,
+                                     bool emit = false) __attribute__((always_inline)) {   // mkind: 0 no mask, 1 mask values in mz, 2 mask bits in mz[0].x
                         if constexpr (SZ == 4) {
 #pragma unroll
                             for (int qd = 0; qd < 4; ++qd) {
-                                if (mz) {
+                                if (mkind == 1) {
                                     const float4 zv = mz[qd];
                                     if (p.mask_act == GS_ACT_LRELU) {   // (the common case by itself: compare, scale, select per value)
                                         o[qd][0] = zv.x > 0.f ? o[qd][0] : 0.2f * o[qd][0]; o[qd][1] = zv.y > 0.f ? o[qd][1] : 0.2f * o[qd][1];
@@ -601,6 +637,7 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void conv_igemm_kernel(const Conv
                                 if (inside) st4(reinterpret_cast<float*>(dst) + off + a * 32 + qd * 8 + hi * 4, o[qd]);
                             }
                         } else {
+                            unsigned sign_bytes = 0u;
 #pragma unroll
                             for (int qp = 0; qp < 2; ++qp) {
                                 float lo[4], hi4[4];
@@ -610,7 +647,13 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void conv_igemm_kernel(const Conv
                                     lo[e] = __uint_as_float(r[0]);
                                     hi4[e] = __uint_as_float(r[1]);
                                 }
-                                if (mz) {   // the lane's 8 channels of the mask sit where its 16 bytes go
+                                if (BITS && mkind) {   // 1-bit mask: this lane's byte of the pixel's dword
+                                    const unsigned byte = mz[0].x >> (8 * (2 * hi + qp));
+#define GS_BR(V, K) V = (byte >> (K)) & 1u ? V : 0.2f * V
+                                    GS_BR(lo[0], 0); GS_BR(lo[1], 1); GS_BR(lo[2], 2); GS_BR(lo[3], 3);
+                                    GS_BR(hi4[0], 4); GS_BR(hi4[1], 5); GS_BR(hi4[2], 6); GS_BR(hi4[3], 7);
+#undef GS_BR
+                                } else if (!BITS && mkind) {   // the lane's 8 channels of the mask sit where its 16 bytes go
                                     const uint4 zv = mz[qp];
                                     if (p.mask_act == GS_ACT_LRELU) {
                                         // z > 0 on the packed pair: low half shifted up and compared as an integer, high half in place (>= 0x10000: sign
@@ -632,13 +675,26 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void conv_igemm_kernel(const Conv
                                 v.x = pack_bf16x2(lo[0], lo[1]); v.y = pack_bf16x2(lo[2], lo[3]);
                                 v.z = pack_bf16x2(hi4[0], hi4[1]); v.w = pack_bf16x2(hi4[2], hi4[3]);
                                 if (inside) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(dst) + off + a * 32 + qp * 16 + hi * 8) = v;
+                                if (BITS && emit) {   // sign bits of the STORED values (z > 0 exactly as the masked epilogues test it on the bf16 pair)
+                                    const unsigned b8 = ((int)(v.x << 16) > 0 ? 1u : 0u) | ((int)v.x >= 0x10000 ? 2u : 0u) | ((int)(v.y << 16) > 0 ? 4u : 0u) |
+                                                        ((int)v.y >= 0x10000 ? 8u : 0u) | ((int)(v.z << 16) > 0 ? 16u : 0u) | ((int)v.z >= 0x10000 ? 32u : 0u) |
+                                                        ((int)(v.w << 16) > 0 ? 64u : 0u) | ((int)v.w >= 0x10000 ? 128u : 0u);
+                                    sign_bytes |= b8 << (8 * qp);
+                                }
                             }
+                            if (BITS && emit && inside)   // the lane's two bytes of the pixel's dword: bytes 2 hi, 2 hi + 1
+                                *reinterpret_cast<unsigned short*>(p.bits_out + ((off + a * 32) >> 3) + 2 * hi) = (unsigned short)sign_bytes;
                         }
                     };
                     // all mask vectors of the tile in one go when they fit in 32 registers, else one (pixel group, phase) at a time
-                    constexpr bool MASK_ALL = !NORM && B * NPH * A * NV <= 8;
+                    constexpr bool MASK_ALL = !NORM && (BITS || B * NPH * A * NV <= 8);   // (sign words: one register per (pixel, tile), always ahead)
                     mvec_t mz_all[MASK_ALL ? B * NPH : 1][A][NV];
-                    if constexpr (MASK_ALL) {
+                    if constexpr (BITS) {
+#pragma unroll
+                        for (int i = 0; i < B * NPH; ++i)
+#pragma unroll
+                            for (int a = 0; a < A; ++a) mz_all[i][a][0].x = mbw[i][a];
+                    } else if constexpr (MASK_ALL) {
                         if (p.mask) {
 #pragma unroll
                             for (int b = 0; b < B; ++b) {
@@ -875,7 +931,7 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void conv_igemm_kernel(const Conv
                                     float o[4][4];
                                     finish(ph, a, b, o);
                                     const mvec_t* mz = MASK_ALL ? mz_all[MASK_ALL ? b * NPH + ph : 0][a] : mz_one[a];
-                                    store(y, off, a, o, inside, p.mask ? mz : static_cast<const mvec_t*>(nullptr));
+                                    store(y, off, a, o, inside, mz, p.mask ? (use_mb ? 2 : 1) : 0, emit_bits);
                                 }
                             }
                         }
@@ -1953,8 +2009,11 @@ static int wgrad_cus() {
 #ifndef GS_SMALL_D
 #define GS_SMALL_D 2   // stages in flight for the few-block ("small") configurations
 #endif
-template <typename T, int MODE, int A, int B, int TW, int TG, bool RESIDENT = false, int D = 2, int NORM = 0, int RB = 64, bool SPEC = false>
+template <typename T, int MODE, int A, int B, int TW, int TG, bool RESIDENT = false, int D = 2, int NORM = 0, int RB = 64, bool SPEC = false, bool BITS = false>
 static int launch_igemm(ConvP p, hipStream_t st) {
+    if constexpr (!BITS && sizeof(T) == 2 && NORM == 0) {
+        if (p.mask_bits || p.bits_out) return launch_igemm<T, MODE, A, B, TW, TG, RESIDENT, D, NORM, RB, SPEC, true>(p, st);
+    }
     constexpr int NP = 128 * B;
     constexpr int TH = NP / TW;
     constexpr int PH = patch_dim<MODE>(TH), PW = patch_dim<MODE>(TW);
@@ -1990,10 +2049,12 @@ static int launch_igemm(ConvP p, hipStream_t st) {
                 q.y = const_cast<void*>(adv(p.y, n0 * out_img));
                 q.y2 = const_cast<void*>(adv(p.y2, n0 * out_img));
                 q.mask = adv(p.mask, n0 * out_img);
+                q.mask_bits = reinterpret_cast<const unsigned char*>(adv(p.mask_bits, n0 * out_img / (8 * sizeof(T))));
+                q.bits_out = reinterpret_cast<unsigned char*>(const_cast<void*>(adv(p.bits_out, n0 * out_img / (8 * sizeof(T)))));
                 q.addend = adv(p.addend, n0 * out_img);
                 int pending = 0;
                 if (p.norm_pending) q.norm_pending = &pending;
-                if (int e = launch_igemm<T, MODE, A, B, TW, TG, RESIDENT, D, NORM, RB, SPEC>(q, st)) return e;
+                if (int e = launch_igemm<T, MODE, A, B, TW, TG, RESIDENT, D, NORM, RB, SPEC, BITS>(q, st)) return e;
                 if (p.norm_pending && pending) *p.norm_pending = pending;
             }
             return 0;
@@ -2021,7 +2082,7 @@ static int launch_igemm(ConvP p, hipStream_t st) {
         if (p.norm_pending) *p.norm_pending = 1;
     }
     if (p.IC % BK != 0) return fail(GS_ERR_UNSUPPORTED, "conv igemm: %d input channels with %d-channel chunks", p.IC, BK);
-    auto kern = conv_igemm_kernel<T, MODE, A, B, TW, TG, RESIDENT, D, NORM, RB, SPEC>;
+    auto kern = conv_igemm_kernel<T, MODE, A, B, TW, TG, RESIDENT, D, NORM, RB, SPEC, BITS>;
     static size_t max_set = 0;  // per template instantiation
     if (lds > max_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -2239,6 +2300,19 @@ static int run_igemm_t(int mode, int variant, const void* x, const float* w_hwio
         hipLaunchKernelGGL((weight_prep_kernel<T>), dim3(cdiv(total, 256)), dim3(256), 0, st, w_hwio, wp, 9, w_ci, w_co, variant);
     ConvP p;
     memset(&p, 0, sizeof(p));
+    const size_t out_numel = (size_t)N * Hb * Wb * (mode == MODE_T2 ? 4 : 1) * OCk;
+    const bool plain = y2 == nullptr && !normbwd;   // (the fused-norm epilogues need z itself and write no bits)
+    const bool write_bits = (act & GS_ACT_WRITE_BITS) != 0;
+    act &= ~GS_ACT_WRITE_BITS;
+    if (mask_act == GS_ACT_LRELU_BITS) {   // mask = an activation output with its sign bits behind it
+        mask_act = GS_ACT_LRELU;
+        if (sizeof(T) == 2 && plain && mask && OCk % 32 == 0) p.mask_bits = reinterpret_cast<const unsigned char*>(mask) + out_numel * sizeof(T);
+    }
+    bool bits_pending = write_bits;
+    if (write_bits && sizeof(T) == 2 && plain && y && act == GS_ACT_LRELU && OCk % 32 == 0 && (!mask || p.mask_bits)) {   // (the BITS kernel reads no mask VALUES)
+        p.bits_out = reinterpret_cast<unsigned char*>(y) + out_numel * sizeof(T);
+        bits_pending = false;
+    }
     p.x = x; p.wp = wp; p.y = y; p.bias = bias; p.act = act; p.mask = mask; p.mask_act = mask_act;
     p.N = N; p.Hi = Hi; p.Wi = Wi; p.IC = ICk; p.OC = OCk; p.Hb = Hb; p.Wb = Wb; p.alpha = alpha;
     int pending = 0;
@@ -2260,8 +2334,10 @@ static int run_igemm_t(int mode, int variant, const void* x, const float* w_hwio
     }
     if (pending) {   // y2 = pixel_norm(activation), the activation sitting in y (or in y2 itself when the caller keeps no copy)
         const long px = (long)N * Hb * Wb * (mode == MODE_T2 ? 4 : 1);
-        return gs_pixel_norm_fwd(y ? y : y2, y2, px, OCk, pn_eps, sizeof(T) == 4 ? GS_F32 : GS_BF16, st);
+        if (int e = gs_pixel_norm_fwd(y ? y : y2, y2, px, OCk, pn_eps, sizeof(T) == 4 ? GS_F32 : GS_BF16, st)) return e;
     }
+    if (bits_pending && y)   // (asked for the sign bits where this epilogue does not write them: the packing pass)
+        return gs_pack_act_bits(y, (int64_t)(out_numel / OCk), OCk, sizeof(T) == 4 ? GS_F32 : GS_BF16, st);
     return 0;
 }
 

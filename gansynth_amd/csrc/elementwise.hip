@@ -1014,6 +1014,32 @@ extern "C" int gs_row_scale(const void* x, const float* s, float alpha, void* ou
     return 0;
 }
 
+// sign bits of a bf16 activation in the layout the conv epilogues use (include/gansynth_hip.h): one 32-bit word per (pixel, 32-channel tile),
+// bit 8 (2 h + q) + k = channel 16 q + 8 h + k > 0.  A thread per word: 64 bytes in, 4 bytes out.
+static __global__ void pack_act_bits_kernel(const unsigned short* __restrict__ z, unsigned* __restrict__ bits, long nwords) {
+    const long w = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nwords) return;
+    const uint4* src = reinterpret_cast<const uint4*>(z + w * 32);
+    unsigned word = 0u;
+#pragma unroll
+    for (int piece = 0; piece < 4; ++piece) {   // piece = 16-byte group of 8 channels: channels 8 piece ..: q = piece >> 1, h = piece & 1
+        const uint4 v = src[piece];
+        const unsigned b8 = ((int)(v.x << 16) > 0 ? 1u : 0u) | ((int)v.x >= 0x10000 ? 2u : 0u) | ((int)(v.y << 16) > 0 ? 4u : 0u) | ((int)v.y >= 0x10000 ? 8u : 0u) |
+                            ((int)(v.z << 16) > 0 ? 16u : 0u) | ((int)v.z >= 0x10000 ? 32u : 0u) | ((int)(v.w << 16) > 0 ? 64u : 0u) | ((int)v.w >= 0x10000 ? 128u : 0u);
+        word |= b8 << (8 * (2 * (piece & 1) + (piece >> 1)));
+    }
+    bits[w] = word;
+}
+
+extern "C" int gs_pack_act_bits(void* z, int64_t p, int c, int dtype, void* stream) {
+    GS_CHECK_ARG(z && p > 0 && c > 0 && c % 32 == 0 && dtype == GS_BF16, "pack_act_bits: bf16 activations with a multiple of 32 channels only");
+    const long nwords = (long)p * c / 32;
+    unsigned* bits = reinterpret_cast<unsigned*>(reinterpret_cast<unsigned short*>(z) + (long)p * c);
+    hipLaunchKernelGGL(pack_act_bits_kernel, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0, as_stream(stream), reinterpret_cast<const unsigned short*>(z), bits, nwords);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int gs_adam_tf_step(float* p, const float* g, float* m, float* v, int64_t numel, float lr_t, float beta1, float beta2,
                                float eps, float grad_scale, void* stream) {
     GS_CHECK_ARG(numel > 0, "adam: bad args");

@@ -48,6 +48,32 @@ def _empty_like_act(shape, ref):
     return torch.empty(shape, dtype=ref.dtype, device=ref.device)
 
 
+# 1-bit leaky-relu masks (include/gansynth_hip.h, GS_ACT_WRITE_BITS / GS_ACT_LRELU_BITS): a bf16 leaky-relu conv output that a later masked
+# data-gradient launch will read only for its signs carries those signs behind it in the same allocation -- numel values, then numel / 8 bytes --
+# and the masked launches read 1/16 of the bytes.  A tensor "has bits" when its storage is exactly that long: whoever allocated it here wrote them.
+_MASK_BITS = not config.flag("GS_NO_MASK_BITS")
+
+
+def _empty_act_with_bits(shape, ref):
+    n, c, h, w = shape
+    numel = n * c * h * w
+    flat = torch.empty((numel + numel // 16,), dtype=ref.dtype, device=ref.device)
+    return flat[:numel].view(n, h, w, c).permute(0, 3, 1, 2)
+
+
+def _bits_wanted(ref, co, act):
+    return _MASK_BITS and act == _lib.ACT_LRELU and ref.dtype == torch.bfloat16 and co % 32 == 0
+
+
+def _has_bits(t):
+    return (_MASK_BITS and t.dtype == torch.bfloat16 and t.dim() == 4 and t.shape[1] % 32 == 0 and t.storage_offset() == 0
+            and t.untyped_storage().nbytes() == t.numel() * 2 + t.numel() // 8)
+
+
+def _mask_act(mask, mask_act):
+    return _lib.ACT_LRELU_BITS if (mask_act == _lib.ACT_LRELU and _has_bits(mask)) else int(mask_act)
+
+
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -386,15 +412,17 @@ class HipKernels(object):
         assert mask.shape == y.shape and mask.dtype == y.dtype
         nb = self.lib.gs_conv2d_workspace_bytes(_lib.CONV_FWD, n, h, wd, ci, co, ksize, stride, _dt(x))
         ws, prepared = self._weight_ws(w, ("fwd", ksize, stride, _dt(x)), nb, (_lib.PREP_CONV_FWD, ci, co, ksize, stride, _dt(x)))
-        _lib.check(self.lib.gs_conv2d_fwd_mask(x.data_ptr(), w.data_ptr(), mask.data_ptr(), int(mask_act), y.data_ptr(), n, h, wd, ci, co, ksize, stride,
+        _lib.check(self.lib.gs_conv2d_fwd_mask(x.data_ptr(), w.data_ptr(), mask.data_ptr(), _mask_act(mask, mask_act), y.data_ptr(), n, h, wd, ci, co, ksize, stride,
                                                float(alpha), _dt(x), prepared, ws.data_ptr(), ws.numel(), _stream()), "gs_conv2d_fwd_mask")
         return y
 
-    def conv2d_fwd_bias_act(self, x, w, bias, ksize, stride, alpha, act):
+    def conv2d_fwd_bias_act(self, x, w, bias, ksize, stride, alpha, act, bits=None):
+        """`bits` (default: whenever the result qualifies, 1/16 more bytes written): the leaky-relu result carries its sign bits behind it."""
         x, w = _act(x), _f32c(w)
         n, ci, h, wd = x.shape
         co = w.shape[3]
-        y = _empty_like_act((n, co, h // stride, wd // stride), x)
+        bits = _bits_wanted(x, co, act) and bits is not False
+        y = (_empty_act_with_bits if bits else _empty_like_act)((n, co, h // stride, wd // stride), x)
         nb = self.lib.gs_conv2d_workspace_bytes(_lib.CONV_FWD, n, h, wd, ci, co, ksize, stride, _dt(x))
         ws, prepared = self._weight_ws(w, ("fwd", ksize, stride, _dt(x)), nb, (_lib.PREP_CONV_FWD, ci, co, ksize, stride, _dt(x)))
         bp = None
@@ -402,7 +430,7 @@ class HipKernels(object):
             bias = _f32c(bias)
             bp = bias.data_ptr()
         _lib.check(self.lib.gs_conv2d_fwd_bias_act(x.data_ptr(), w.data_ptr(), bp, y.data_ptr(), n, h, wd, ci, co, ksize, stride,
-                                                   float(alpha), act, _dt(x), prepared, ws.data_ptr(), ws.numel(), _stream()),
+                                                   float(alpha), act | (_lib.ACT_WRITE_BITS if bits else 0), _dt(x), prepared, ws.data_ptr(), ws.numel(), _stream()),
                    "gs_conv2d_fwd_bias_act")
         return y
 
@@ -456,7 +484,7 @@ class HipKernels(object):
             mask = _act(mask)
             assert mask.shape == gx.shape and mask.dtype == gx.dtype
             mp = mask.data_ptr()
-        _lib.check(self.lib.gs_conv2d_bwd_data_mask(gy.data_ptr(), w.data_ptr(), mp, int(mask_act), gx.data_ptr(), n, h, wd, ci, co, ksize, stride,
+        _lib.check(self.lib.gs_conv2d_bwd_data_mask(gy.data_ptr(), w.data_ptr(), mp, _mask_act(mask, mask_act) if mask is not None else 0, gx.data_ptr(), n, h, wd, ci, co, ksize, stride,
                                                     float(alpha), _dt(gy), prepared, ws.data_ptr(), ws.numel(), _stream()), "gs_conv2d_bwd_data_mask")
         return gx
 

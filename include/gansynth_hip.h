@@ -34,6 +34,13 @@ extern "C" {
 enum { GS_F32 = 0, GS_BF16 = 1 };
 enum { GS_OK = 0, GS_ERR_ARG = -1, GS_ERR_HIP = -2, GS_ERR_UNSUPPORTED = -3, GS_ERR_WORKSPACE = -4 };
 enum { GS_ACT_NONE = 0, GS_ACT_LRELU = 1, GS_ACT_TANH = 2 };
+/* 1-bit leaky-relu masks (bf16 activations whose channel count is a multiple of 32).  A forward conv called with `act = GS_ACT_LRELU |
+ * GS_ACT_WRITE_BITS` also leaves the SIGN BITS of its result behind it: the caller's buffer holds the activation (numel values) followed by
+ * numel / 8 bytes, one 32-bit word per (pixel, 32-channel tile), bit 8 (2 h + q) + k = "channel 16 q + 8 h + k of the tile is > 0".  A masked
+ * conv (gs_conv2d_fwd_mask / gs_conv2d_bwd_data_mask) called with `mask_act = GS_ACT_LRELU_BITS` is promised such a buffer as `mask` and reads
+ * the words instead of the values where its epilogue can (1 / 16 of the mask bytes); everywhere else it reads the values as with GS_ACT_LRELU.
+ * gs_pack_act_bits writes the words for an activation that some other kernel produced. */
+enum { GS_ACT_LRELU_BITS = 5, GS_ACT_WRITE_BITS = 16 };
 /* which of the three bilinear conv maps a workspace query is for */
 enum { GS_CONV_FWD = 0, GS_CONV_BWD_DATA = 1, GS_CONV_BWD_WEIGHT = 2 };
 
@@ -137,6 +144,7 @@ int gs_conv2d_bwd_data_mask(const void* gy, const float* w_hwio, const void* mas
                             int ksize, int stride, float alpha, int dtype, int w_prepared, void* ws, size_t ws_bytes, void* stream);
 /* The same on the forward map: y = conv2d(x, w) * act'(.)|mask with mask of y's shape (the second-order pass of a gradient penalty
  * runs the convs forward on cotangents; each result meets the derivative of the activation that follows that conv). */
+int gs_pack_act_bits(void* z, int64_t p, int c, int dtype, void* stream);   /* z: [p][c] values followed by p * c / 8 bytes (written here); c % 32 == 0 */
 int gs_conv2d_fwd_mask(const void* x, const float* w_hwio, const void* mask, int mask_act, void* y, int n, int h, int w, int ci, int co,
                        int ksize, int stride, float alpha, int dtype, int w_prepared, void* ws, size_t ws_bytes, void* stream);
 int gs_conv2d_bwd_weight(const void* x, const void* gy, float* gw_hwio, int n, int h, int w, int ci, int co,

@@ -1051,6 +1051,60 @@ def test_colour_block_forward_with_the_next_node_s_mask(K, shape, dtype):
     close(got, want, rel=1e-6 if dtype == torch.float32 else 1e-2, name="colour block fwd mask")
 
 
+def _sign_words(z):
+    """The 1-bit mask layout of include/gansynth_hip.h restated with torch: one 32-bit word per (pixel, 32-channel tile), bit 8 (2 h + q) + k =
+    channel 16 q + 8 h + k of the tile is > 0."""
+    n, c, h, w = z.shape
+    pos = (z.permute(0, 2, 3, 1).float() > 0).reshape(-1, c // 32, 2, 2, 8).to(torch.int64)   # [pixel, tile, q, h, k]
+    q, hh, k = torch.meshgrid(torch.arange(2), torch.arange(2), torch.arange(8), indexing="ij")
+    shift = (8 * (2 * hh + q) + k).to(z.device)
+    word = (pos << shift).sum(dim=(2, 3, 4))
+    return torch.where(word >= 2 ** 31, word - 2 ** 32, word).to(torch.int32).reshape(-1)
+
+
+def _stored_words(z):
+    return torch.empty(0, dtype=torch.int32, device=z.device).set_(z.untyped_storage(), z.numel() // 2, (z.numel() // 32,))
+
+
+@pytest.mark.parametrize("case", [(2, 32, 32, 16, 128, 3, 1), (2, 64, 64, 8, 64, 3, 1), (2, 32, 64, 8, 128, 3, 2), (3, 128, 128, 8, 32, 3, 1), (2, 256, 256, 4, 16, 3, 1),
+                                  (2, 2, 32, 16, 128, 1, 1), (3, 2, 64, 8, 72, 1, 1), (2, 32, 96, 6, 40, 3, 1)])
+def test_one_bit_leaky_relu_masks(K, case):
+    """GS_ACT_WRITE_BITS / GS_ACT_LRELU_BITS: a bf16 leaky-relu conv result carries its sign bits behind it (written by the MFMA epilogue, or by
+    gs_pack_act_bits after the direct kernels), and the masked launches that read them give bit-identical results to the ones that read the
+    values.  An activation without the bits (a clone) takes the values path."""
+    from gansynth_amd import kernels
+    n, ci, co, h, w, ks, st = case
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    CL = torch.channels_last
+    x = torch.randn(n, ci, h, w, device="cuda", generator=gen).bfloat16().contiguous(memory_format=CL)
+    wt = torch.randn(ks, ks, ci, co, device="cuda", generator=gen)
+    bias = torch.randn(co, device="cuda", generator=gen)
+    z = K.conv2d_fwd_bias_act(x, wt, bias, ks, st, 0.1, 1)
+    plain = K.conv2d_fwd_bias_act(x, wt, bias, ks, st, 0.1, 1, bits=False)
+    assert kernels._has_bits(z) and not kernels._has_bits(plain)
+    assert torch.equal(z, plain)
+    assert torch.equal(_stored_words(z), _sign_words(z)), "sign words"
+    zc = z.clone(memory_format=CL)
+    assert not kernels._has_bits(zc)
+    # z as the mask of a data gradient (the conv whose INPUT z was) and of a forward-on-cotangents conv (whose output has z's shape)
+    for c2 in (co, 64):
+        w2 = torch.randn(3, 3, co, c2, device="cuda", generator=gen)
+        gy = torch.randn(n, c2, z.shape[2], z.shape[3], device="cuda", generator=gen).bfloat16().contiguous(memory_format=CL)
+        a = K.conv2d_bwd_data(gy, w2, tuple(z.shape), 3, 1, 0.07, mask=z, mask_act=1)
+        b = K.conv2d_bwd_data(gy, w2, tuple(z.shape), 3, 1, 0.07, mask=zc, mask_act=1)
+        assert torch.equal(a, b), f"bwd_data mask, {c2} channels"
+        if z.shape[2] % 2 == 0:   # behind a stride-2 conv: the transposed-conv-shaped data gradient
+            gy2 = torch.randn(n, c2, z.shape[2] // 2, z.shape[3] // 2, device="cuda", generator=gen).bfloat16().contiguous(memory_format=CL)
+            a = K.conv2d_bwd_data(gy2, w2, tuple(z.shape), 3, 2, 0.07, mask=z, mask_act=1)
+            b = K.conv2d_bwd_data(gy2, w2, tuple(z.shape), 3, 2, 0.07, mask=zc, mask_act=1)
+            assert torch.equal(a, b), f"stride-2 bwd_data mask, {c2} channels"
+        w3 = torch.randn(3, 3, c2, co, device="cuda", generator=gen)
+        xx = torch.randn(n, c2, z.shape[2], z.shape[3], device="cuda", generator=gen).bfloat16().contiguous(memory_format=CL)
+        a = K.conv2d_fwd_mask(xx, w3, 3, 1, 0.07, z, 1)
+        b = K.conv2d_fwd_mask(xx, w3, 3, 1, 0.07, zc, 1)
+        assert torch.equal(a, b), f"fwd mask, {c2} channels"
+
+
 _CHUNK_CHILD = r"""
 import sys, torch
 sys.path.insert(0, sys.argv[1])
@@ -1064,6 +1118,14 @@ for name, (x, wt, mask, ref_fwd, ref_t, ref_bd) in d.items():
     if not torch.equal(K.conv2d_fwd_bias_act(x, wt, None, 3, 1, 0.05, 1).cpu(), ref_fwd): bad.append(name + " fwd")
     if not torch.equal(K.conv2d_transpose_fwd(x, wt, 0.05).cpu(), ref_t): bad.append(name + " transposed")
     if not torch.equal(K.conv2d_bwd_data(x, wt, tuple(x.shape), 3, 1, 0.05, mask=mask, mask_act=1).cpu(), ref_bd): bad.append(name + " bwd_data+mask")
+    if x.dtype == torch.bfloat16:   # the sign bits behind a leaky-relu result, written and read by chunked launches
+        z = K.conv2d_fwd_bias_act(x, wt, None, 3, 1, 0.05, 1)
+        assert kernels._has_bits(z)
+        zc = z.clone(memory_format=CL)
+        assert not kernels._has_bits(zc)
+        a = K.conv2d_bwd_data(x, wt, tuple(x.shape), 3, 1, 0.05, mask=z, mask_act=1)
+        b = K.conv2d_bwd_data(x, wt, tuple(x.shape), 3, 1, 0.05, mask=zc, mask_act=1)
+        if not torch.equal(a, b): bad.append(name + " bwd_data + 1-bit mask")
 print("BAD", bad) if bad else print("CHUNKED-OK", len(d))
 """
 
