@@ -221,6 +221,9 @@ __device__ __forceinline__ void block_barrier() {
 // ~5 cycles whatever it is (scripts/probe/valu_rate.hip), so in a 4-wave block the ~60 cycles of each DMA piece (offset arithmetic,
 // M0, the load) come ON TOP of the MFMAs of the stage -- measured 2260 ticks per stage for 1152 ticks of MFMA on the few-block layers
 // (scripts/probe/igemm_trace.hip); on their own wave they run under them.
+#ifndef GS_NORM_EPI_PIPELINE
+#define GS_NORM_EPI_PIPELINE 1   // (0: the fused norm-backward epilogues fetch z / addend where they use them -- the build to compare against)
+#endif
 // BITS (bf16, plain epilogues): the build of the kernel for launches with 1-bit leaky-relu masks -- its mask, if any, is the sign words behind
 // an activation (p.mask_bits), and with p.bits_out it writes the sign words of its own result.  Its own instantiation, not a run-time branch: with
 // both mask forms in one epilogue the compiler keeps 15-25 more VGPRs live and the larger tiles lose a wave of occupancy.
@@ -483,12 +486,46 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void conv_igemm_kernel(const Conv
         // they can wait through the MFMAs of the stage, where the 16-byte mask vectors (8-32 registers) cannot: a mask fetched in the epilogue
         // costs every item one exposed memory round trip (~0.9 us per 256-pixel item on the 32-channel layers: scripts/mask_bits_micro.py).
         unsigned mbw[BITS ? B * (MODE == MODE_T2 ? 4 : 1) : 1][A];
+        // NORM 2 / 3 (the fused pixel-norm backward epilogues): the z vectors and the addend / g vectors of the lane's (pixel group, phase) steps, double
+        // buffered -- step 0 is fetched at the start of the item's last stage like the sign words above, step i + 1 while step i is computed: fetched
+        // where they are used, every step pays a memory round trip (1-4 per item).  Free registers: two blocks per CU leave a wave 256 VGPRs.
+        // (not the 2 x 2 tiling: 64 more registers would take it past 256 and to one block per CU)
+        constexpr bool NPIPE = (NORM == 2 || NORM == 3) && A * B <= 2 && GS_NORM_EPI_PIPELINE;
+        typedef typename std::conditional<SZ == 4, float4, uint4>::type nvec_t;
+        constexpr int NNV = SZ == 4 ? 4 : 2;
+        nvec_t nz[NPIPE ? 2 : 1][A][NNV], nx[NPIPE ? 2 : 1][A][NNV];
+        auto norm_fetch = [&](int i, nvec_t (&zq)[A][NNV], nvec_t (&xq)[A][NNV]) __attribute__((always_inline)) {
+            constexpr int NPHB = MODE == MODE_T2 ? 4 : 1;
+            const int b = i / NPHB, ph = i % NPHB;
+            const int Ho = MODE == MODE_T2 ? 2 * Hb : Hb, Wo = MODE == MODE_T2 ? 2 * Wb : Wb;
+            const int q = (wv * B + b) * 32 + l31;
+            const int gy = by + q / TW, gx = bx + q % TW;
+            const int oy = MODE == MODE_T2 ? 2 * gy + (ph >> 1) : gy;
+            const int ox = MODE == MODE_T2 ? 2 * gx + (ph & 1) : gx;
+            const long base = (gy < Hb && gx < Wb) ? (((long)n * Ho + oy) * Wo + ox) * OC + oc0 : 0;   // clamped: the loads stay unconditional
+#ifdef GS_ABL_NOMASKLOAD
+            const long zbase = base & 1023;
+#else
+            const long zbase = base;
+#endif
+#pragma unroll
+            for (int a = 0; a < A; ++a)
+#pragma unroll
+                for (int v = 0; v < NNV; ++v) {
+                    zq[a][v] = *reinterpret_cast<const nvec_t*>(reinterpret_cast<const T*>(p.mask) + zbase + a * 32 + v * (32 / NNV) + hi * (16 / NNV));
+                    if (NORM == 3 || p.addend)
+                        xq[a][v] = *reinterpret_cast<const nvec_t*>(reinterpret_cast<const T*>(p.addend) + base + a * 32 + v * (32 / NNV) + hi * (16 / NNV));
+                }
+        };
         for (int ch = 0; ch < NCH; ++ch) {
 #pragma unroll
             for (int tg = 0; tg < NTG; ++tg) {
                 const int itg = (tg + D) % NTG;            // tap group of the stage issued during this one
                 const int npiece = stage_pieces(itg);
                 if (issuer) issue_setup(itg);
+                if constexpr (NPIPE) {
+                    if (tg == NTG - 1 && ch == NCH - 1 && computer) norm_fetch(0, nz[0], nx[0]);
+                }
                 if constexpr (BITS) {
                     if (tg == NTG - 1 && ch == NCH - 1 && computer && p.mask_bits) {
                         constexpr int NPHB = MODE == MODE_T2 ? 4 : 1;
@@ -729,16 +766,22 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void conv_igemm_kernel(const Conv
                                 // and times act'(z).  Values are brought to the STORE layout first (bf16: the lane-half swap), where the lane's
                                 // 16 channels per 32-channel tile sit exactly like the 16-byte vectors of z / addend it fetches.
                                 constexpr int EV = 16 / NV;                    // values per 16-byte vector: 4 (fp32) or 8 (bf16)
-                                mvec_t zq[A][NV], aq[A][NV];
-                                mask_fetch(off, inside, zq);
-                                if (p.addend) {
-                                    const long base = inside ? off : 0;
+                                const int cur = NPIPE ? ((b * NPH + ph) & 1) : 0;
+                                if constexpr (NPIPE) {   // (this step's vectors are on their way since the last stage / the previous step: fetch the next one's)
+                                    if (b * NPH + ph + 1 < B * NPH) norm_fetch(b * NPH + ph + 1, nz[(b * NPH + ph + 1) & 1], nx[(b * NPH + ph + 1) & 1]);
+                                } else {
+                                    mask_fetch(off, inside, nz[0]);
+                                    if (p.addend) {
+                                        const long base = inside ? off : 0;
 #pragma unroll
-                                    for (int a = 0; a < A; ++a)
+                                        for (int a = 0; a < A; ++a)
 #pragma unroll
-                                        for (int v = 0; v < NV; ++v)
-                                            aq[a][v] = *reinterpret_cast<const mvec_t*>(reinterpret_cast<const T*>(p.addend) + base + a * 32 + v * (32 / NV) + hi * (16 / NV));
+                                            for (int v = 0; v < NV; ++v)
+                                                nx[0][a][v] = *reinterpret_cast<const mvec_t*>(reinterpret_cast<const T*>(p.addend) + base + a * 32 + v * (32 / NV) + hi * (16 / NV));
+                                    }
                                 }
+                                mvec_t (&zq)[A][NV] = nz[cur];
+                                mvec_t (&aq)[A][NV] = nx[cur];
                                 float gv[A][NV][EV], zv[A][NV][EV];
                                 float ssq = 0.f, szg = 0.f;
 #pragma unroll
@@ -814,16 +857,20 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void conv_igemm_kernel(const Conv
                                 //   y  = J h                                   = r (h - z r^2 mean(h z))
                                 //   y2 = d<h, J g>/dz = -r^3 (mean(h g) z + mean(z g) h + mean(h z) g) + 3 r^5 mean(h z) mean(z g) z
                                 constexpr int EV = 16 / NV;
-                                mvec_t zq[A][NV], gq[A][NV];
-                                mask_fetch(off, inside, zq);
-                                {
+                                const int cur = NPIPE ? ((b * NPH + ph) & 1) : 0;
+                                if constexpr (NPIPE) {
+                                    if (b * NPH + ph + 1 < B * NPH) norm_fetch(b * NPH + ph + 1, nz[(b * NPH + ph + 1) & 1], nx[(b * NPH + ph + 1) & 1]);
+                                } else {
+                                    mask_fetch(off, inside, nz[0]);
                                     const long base = inside ? off : 0;
 #pragma unroll
                                     for (int a = 0; a < A; ++a)
 #pragma unroll
                                         for (int v = 0; v < NV; ++v)
-                                            gq[a][v] = *reinterpret_cast<const mvec_t*>(reinterpret_cast<const T*>(p.addend) + base + a * 32 + v * (32 / NV) + hi * (16 / NV));
+                                            nx[0][a][v] = *reinterpret_cast<const mvec_t*>(reinterpret_cast<const T*>(p.addend) + base + a * 32 + v * (32 / NV) + hi * (16 / NV));
                                 }
+                                mvec_t (&zq)[A][NV] = nz[cur];
+                                mvec_t (&gq)[A][NV] = nx[cur];
                                 float hv[A][NV][EV], zv[A][NV][EV], gv[A][NV][EV];
                                 float ssq = 0.f, shg = 0.f, shz = 0.f, szg = 0.f;
 #pragma unroll
