@@ -2146,8 +2146,9 @@ static int launch_igemm(ConvP p, hipStream_t st) {
     if (grid >= 8) grid &= ~7L;
     const double flops = 2.0 * 9.0 * (double)p.N * p.Hb * p.Wb * p.IC * p.OC;
     const double out_px = (double)p.N * p.Hb * p.Wb * (MODE == MODE_T2 ? 4 : 1);
-    // algorithmic bytes: input + output + weights, + the activation mask a masked launch reads, + the second output of a fused norm
-    const double bytes = ((double)p.N * p.Hi * p.Wi * p.IC + out_px * p.OC * (1.0 + (p.mask ? 1.0 : 0.0) + ((NORM == 1 && p.y) ? 1.0 : 0.0) + ((NORM == 2 && p.addend) ? 1.0 : 0.0) + (NORM == 3 ? 2.0 : 0.0)) + 9.0 * p.IC * p.OC) * sizeof(T);
+    // algorithmic bytes: input + output + weights, + the activation mask a masked launch reads (1/16 of it as sign words), + the sign words a
+    // forward launch writes, + the second output of a fused norm
+    const double bytes = ((double)p.N * p.Hi * p.Wi * p.IC + out_px * p.OC * (1.0 + (p.mask ? (p.mask_bits ? 1.0 / 16.0 : 1.0) : 0.0) + (p.bits_out ? 1.0 / 16.0 : 0.0) + ((NORM == 1 && p.y) ? 1.0 : 0.0) + ((NORM == 2 && p.addend) ? 1.0 : 0.0) + (NORM == 3 ? 2.0 : 0.0)) + 9.0 * p.IC * p.OC) * sizeof(T);
     const int reps = prof_reps();   // (1 unless profiling in burst mode: the kernel is a pure function of its inputs)
     ProfScope ps(st, flops, bytes, MODE, p.N, p.Hb, p.Wb, p.IC, p.OC, p.mask ? 1 : 0, NORM ? 1 : 0, reps);
     for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(SPEC ? 512 : 256), lds, st, p);
