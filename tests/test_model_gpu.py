@@ -859,6 +859,49 @@ def test_distributed_step_on_rccl_world_size_1():
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("level,full", [(1.0, False), (0.6, False), (1.0, True)])
+def test_one_bit_masks_change_nothing_in_the_iteration(gpu_store, level, full, monkeypatch):
+    """kernels._MASK_BITS (GS_NO_MASK_BITS): the discriminator's leaky-relu results carry their sign words and the masked launches read them -- or
+    read the values.  Same launches otherwise, same order: losses, gradients and parameters of two bf16 iterations (eager; reduced size fully
+    grown and in a fade-in, and BASELINE.json configs[1] itself) are the same bit for bit, and the sign words really were in play."""
+    from gansynth_amd import kernels, variables
+    dtype = torch.bfloat16
+    n = 8 if full else 4
+    res = (2, 128, 1024) if full else (2, 16, 128)
+    batches = [R.synthetic_batch(n, rank=i, image_shape=res) for i in range(2)]
+    out, used = {}, {}
+    for mode in (True, False):
+        monkeypatch.setattr(kernels, "_MASK_BITS", mode)
+        seen = []
+        real_mask_act = kernels._mask_act
+        monkeypatch.setattr(kernels, "_mask_act", lambda m, a, f=real_mask_act: (seen.append(f(m, a)), seen[-1])[1])
+        variables.set_default_store(variables.VariableStore(device="cuda"))
+        pg, opg, model = make(level, variables.default_store(), full=full, dtype=dtype)
+        model.use_graphs = False
+        gp, dp = opg.init_params(seed=0, bias_std=0.1)
+        rec = []
+        for step, (lat, lab, real) in enumerate(batches):
+            lat, lab, real = cuda(lat).to(dtype), cuda(lab).to(dtype), cuda(real).to(dtype)
+            if step == 0:
+                model._build(lat, lab)
+                variables.default_store().load_state_dict({**gp, **dp})
+            rec.append(model.discriminator_step(lat, lab, real).clone())
+            rec.append(model.d_params.grad.clone())
+            rec.append(model.generator_step(lat, lab).clone())
+            rec.append(model.g_params.grad.clone())
+        torch.cuda.synchronize()
+        rec += [model.d_params.flat.clone(), model.g_params.flat.clone()]
+        out[mode], used[mode] = rec, seen
+        monkeypatch.setattr(kernels, "_mask_act", real_mask_act)
+        del model
+    from gansynth_amd import _lib
+    assert used[True] and all(a == _lib.ACT_LRELU_BITS for a in used[True]), sorted(set(used[True]))
+    assert used[False] and _lib.ACT_LRELU_BITS not in used[False]
+    assert len(used[True]) == len(used[False])
+    for i, (a, b) in enumerate(zip(out[True], out[False])):
+        assert torch.equal(a, b), f"record {i}: sign words and values disagree"
+
+
 @pytest.mark.parametrize("level,full,dtype", [(1.0, False, torch.float32), (0.6, False, torch.float32), (1.0, True, torch.bfloat16)])
 def test_forked_branches_change_nothing_but_the_schedule(gpu_store, level, full, dtype):
     """models.GANSynth._branch: inside a run's hipGraph the discriminator's pass over G(z) (forward, and through autograd its backward) runs
