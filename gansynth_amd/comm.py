@@ -65,9 +65,21 @@ class RcclComm(object):
     def set_marker_us(self, us):
         """Tests / profiles, world size 1 only: the all-reduce becomes a one-block kernel holding its stream for `us` microseconds."""
         _lib.check(self.lib.gs_comm_set_marker_us(self.handle, float(us)), "gs_comm_set_marker_us")
+        self.marker_us = float(us)
 
-    def all_reduce_(self, tensor):
+    def all_reduce_(self, tensor, marker_share=None):
+        """`marker_share` (stand-ins only): this message's share of the bytes the stand-in's time was chosen for -- a gradient sent in two
+        messages must not be priced as two whole ones (15 us: what a message costs however short)."""
         assert tensor.dtype == torch.float32 and tensor.is_contiguous() and tensor.is_cuda
+        full = getattr(self, "marker_us", -1.0)
+        if marker_share is not None and full > 0.0:
+            _lib.check(self.lib.gs_comm_set_marker_us(self.handle, max(15.0, full * float(marker_share))), "gs_comm_set_marker_us")
+            try:
+                _lib.check(self.lib.gs_allreduce_sum_f32(self.handle, tensor.data_ptr(), tensor.numel(),
+                                                         ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "gs_allreduce_sum_f32")
+            finally:
+                _lib.check(self.lib.gs_comm_set_marker_us(self.handle, full), "gs_comm_set_marker_us")
+            return _Done()
         _lib.check(self.lib.gs_allreduce_sum_f32(self.handle, tensor.data_ptr(), tensor.numel(),
                                                  ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "gs_allreduce_sum_f32")
         return _Done()

@@ -111,6 +111,10 @@ class HipKernels(object):
         self._guarding = False    # inside stream_guard(): deferred operands are marked with the stream that finally reads them
         self._last_writer = {}    # inside stream_guard(): accumulate target -> (stream, event) of the last call that added into it
         self._early = None        # (min output pixels of a "large" layer, callback): see early_flush_rule
+        self._seen = None         # while deferring: {layer key: [pairs recorded so far in this pass, out, bias]}
+        self._expected = {}       # pass tag -> {layer key: (pairs of a whole pass, out, bias)}, learned at the final flush of the previous pass
+        self._tag = None          # tag of the pass being deferred (defer_wgrad_reductions)
+        self._complete = None     # (pred, callback, expected): see complete_rule
 
     # --------------------------------------------------------- prepared-weight workspaces
     def register_param_buffer(self, flat):
@@ -243,8 +247,9 @@ class HipKernels(object):
         return lo, lo + (sum((n - 1) * st for n, st in zip(t.shape, t.stride()) if n > 0) + 1) * t.element_size()
 
     # ----------------------------------------------------------- deferred weight gradients
-    def defer_wgrad_reductions(self):
-        """From now on the in-place (`out=`) conv weight gradients are only RECORDED; flush_wgrad_reductions() then runs, per
+    def defer_wgrad_reductions(self, tag=None):
+        """`tag`: names the KIND of pass (the trainer's "d" / "g") -- the pairs each layer receives in a pass are remembered per tag (complete_rule).
+        From now on the in-place (`out=`) conv weight gradients are only RECORDED; flush_wgrad_reductions() then runs, per
         weight, ONE multi-source launch over all recorded (x, gy) pairs of that layer (real + fake discriminator pass, the
         second-order contribution of the penalty terms ...) and folds the slice partials of all layers in a handful of launches.
         A backward pass has ~70 such gradients, each otherwise its own partials + reduction.  The `out` buffers are complete
@@ -252,6 +257,7 @@ class HipKernels(object):
         if self._pending is None:
             self._pending = {}
             self._folds = None if config.value("GS_NO_DEFERRED_FOLDS") else []
+            self._seen, self._tag, self._complete = {}, tag, None
 
     def _partial_rows(self, producer, p, c, dt, out):
         """While gradients are deferred: a buffer of its own for the partial rows of a bias gradient that is ADDED into `out` (a
@@ -296,6 +302,22 @@ class HipKernels(object):
     # branch of the run's hipGraph (models.GANSynth._early_flush), where it runs beside the latency-bound chain instead of after it.  A layer
     # whose pairs arrive on both sides of that point (the discriminator's: the R1 pairs early, the real / fake pairs late) is contracted in
     # two launches that add into the same gradient; the rule depends on the recorded sequence only, never on the stream.
+    # Complete layers early.  The pairs a layer receives in a pass of a given kind are the same every time (the real pass, the fake pass, the
+    # second-order terms): once every layer `pred` picks has received as many as in the previous pass of that kind, their gradients need nothing
+    # the backward still computes -- `callback(select, others)` is called once, from inside the node that recorded the last pair, and the trainer
+    # answers with flush_wgrad_reductions(select=select) and whatever wants COMPLETE gradients early (data parallel: their all-reduce, beside
+    # the rest of the backward).  `others`: [(out, bias)] of every layer of the pass `pred` does not pick -- what is NOT complete then.
+    def complete_rule(self, pred, callback):
+        exp = self._expected.get(self._tag) if self._tag is not None else None
+        self._complete = (pred, callback, exp) if (callback is not None and exp and any(pred(k) for k in exp)) else None
+        return self._complete is not None
+
+    def flush_bias_folds(self):
+        """The bias-gradient folds recorded so far, now (the rest stay deferred to the final flush)."""
+        if self._pending is not None and self._folds:
+            self._flush_folds()
+            self._folds = []
+
     def early_flush_rule(self, min_pixels, callback):
         """`min_pixels`: one threshold or several (descending): each fires once per arming, for the layers at or above it."""
         if callback is None:
@@ -320,8 +342,18 @@ class HipKernels(object):
             assert grp["bias"] is None or grp["bias"].data_ptr() == bias_out.data_ptr()
             grp["bias"] = bias_out
         grp["src"].append((x, gy, bias_out is not None))
+        if self._seen is not None:
+            rec = self._seen.setdefault(key, [0, out, bias_out])
+            rec[0] += 1
+            if bias_out is not None:
+                rec[2] = bias_out
+            if self._complete is not None and self._complete[0](key):
+                pred, callback, exp = self._complete
+                if all(self._seen.get(k, (0,))[0] >= e[0] for k, e in exp.items() if pred(k)):
+                    self._complete = None
+                    callback(pred, [(e[1], e[2]) for k, e in exp.items() if not pred(k)])
 
-    def flush_wgrad_reductions(self, group_of=None, on_group_done=None, select=None, split_stream=None):
+    def flush_wgrad_reductions(self, group_of=None, on_group_done=None, select=None, split_stream=None, on_rest_done=None):
         """`group_of(out.data_ptr()) -> int | None` orders the layers into groups (the trainer's gradient buckets, in completion
         order); each group is contracted and folded before the next one starts and `on_group_done(group)` is called right after
         its last launch -- the data-parallel trainer puts that bucket's all-reduce on the wire there."""
@@ -329,6 +361,9 @@ class HipKernels(object):
             picked = {k: self._pending.pop(k) for k in [k for k in self._pending if select(k)]}
             return self._flush_groups(picked) if picked else 0
         groups, self._pending = self._pending, None
+        if self._seen is not None and self._tag is not None:
+            self._expected[self._tag] = {k: (v[0], v[1], v[2]) for k, v in self._seen.items()}
+        self._seen, self._complete = None, None
         self._flush_folds()   # (bias gradients first: they belong to the same buckets as the weights folded below)
         if not groups:
             return 0
@@ -345,9 +380,9 @@ class HipKernels(object):
                 if g is not None and on_group_done is not None:
                     on_group_done(g)
             return n
-        return self._flush_groups(groups, split_stream)
+        return self._flush_groups(groups, split_stream, on_rest_done)
 
-    def _flush_groups(self, groups, split_stream=None):
+    def _flush_groups(self, groups, split_stream=None, on_rest_done=None):
         """One gs_conv_wgrad_jobs call for every recorded layer of `groups`: the library groups the layers by kernel
         instantiation (one stream-K launch + one fold per group) and batches the rest.
         `split_stream` (a captured run's idle branch stream): the HBM-bound jobs -- the <= 32-input-channel layers at the top of the pyramid,
@@ -356,6 +391,18 @@ class HipKernels(object):
         if split_stream is not None and self._guarding and len(groups) > 1:
             thin = {k: g for k, g in groups.items() if int(k[5][0]) <= 32}
             rest = {k: g for k, g in groups.items() if int(k[5][0]) > 32}
+            if thin and rest and on_rest_done is not None:
+                # data parallel: the grouped contractions FIRST -- they complete every gradient in front of the thin layers' in the flat buffer,
+                # i.e. nearly all of its bytes -- then `on_rest_done(thin)` puts that part on the wire on this stream while the thin layers are
+                # contracted beside it on the branch (which starts behind the grouped launches, not beside them: the collective takes their place)
+                main = torch.cuda.current_stream()
+                n = self._flush_groups(rest)
+                split_stream.wait_stream(main)
+                on_rest_done(thin)
+                with torch.cuda.stream(split_stream):
+                    n += self._flush_groups(thin)
+                main.wait_stream(split_stream)
+                return n
             if thin and rest:
                 # (a THIRD stream for the stride-2 / transposed layers' grouped launch beside the stride-1 layers': measured neutral, 5.01 / 5.01 ms)
                 main = torch.cuda.current_stream()
@@ -676,6 +723,7 @@ class HipKernels(object):
     def drop_deferred(self):
         """Forget every deferred job (a backward pass that raised in the middle of a capture: models.GANSynth._abandon_capture)."""
         self._pending, self._folds = None, None
+        self._seen, self._complete = None, None
 
     # (dense weight gradients deferred to the final contraction like the convs' -- off the backward's chain, beside the MFMA-bound jobs: measured
     #  neutral, 5.083 -> 5.09 ms, round 6; they are launched where autograd produces them)

@@ -312,6 +312,11 @@ class GANSynth(object):
         self.fork_marks = not config.flag("GS_NO_FORK_MARKS")   # (debugging: branches start where they are opened)
         self._side = None
         self._side2 = None        # the stream of a whole sub-run beside another run (_train_step_merged)
+        self.bucket_d_reduce = not config.flag("GS_NO_DP_BUCKET_D")   # (data parallel, captured discriminator run: _arm_first_bucket)
+        self.first_bucket = None  # (the range of the flat gradient the first message of the last captured discriminator run covers)
+        self._split_at = None     # (see _arm_first_bucket)
+        self._first_bucket_stream = None
+        self._side3 = None
         self._nodes_on_side2 = False
         self._origin = None
         self._after_loss = None
@@ -433,7 +438,7 @@ class GANSynth(object):
         if join:   # (else: at the end of the run, _part_b)
             main.wait_stream(side)
 
-    def _early_flush(self, select):
+    def _early_flush(self, select, then=None):
         """kernels.HipKernels.early_flush_rule: the weight gradients of the full-chip levels recorded so far are contracted NOW -- on the
         branch when the run is being captured (joined at the end of the run), else in place: the same launches on the same operands either
         way.  (Called from inside a backward node, i.e. on autograd's device thread, under that node's stream.)"""
@@ -451,6 +456,8 @@ class GANSynth(object):
                 self._origin.wait_stream(self._side2)
                 with torch.cuda.stream(self._origin):
                     K.flush_wgrad_reductions(select=select)
+                    if then is not None:
+                        then()
                 return
             if self._in_sub_runs and not on_branch and self._forking():
                 # Sub-runs (_d_sub_runs): the contraction goes to the THIRD stream, behind part A of the generator run (issued between the
@@ -466,9 +473,13 @@ class GANSynth(object):
                 self.branches_opened += 1
                 with torch.cuda.stream(third):
                     K.flush_wgrad_reductions(select=select)
+                    if then is not None:
+                        then()
                 return
             with (contextlib.nullcontext() if on_branch else self._branch(join=False)):   # (a node of the branch itself: in place)
                 K.flush_wgrad_reductions(select=select)
+                if then is not None:
+                    then()
         finally:
             if hasattr(K, "lib"):
                 K.lib.gs_wgrad_cu_cap(was)
@@ -838,7 +849,10 @@ class GANSynth(object):
         K = kernels.get()
         deferring = _DEFER_REDUCTIONS and hasattr(K, "defer_wgrad_reductions")   # parameter gradients are only read after the whole backward:
         if deferring:                                        # their ~70 slice reductions are folded in one go at the end
-            K.defer_wgrad_reductions()
+            if hasattr(K, "complete_rule"):
+                K.defer_wgrad_reductions(tag=which)
+            else:
+                K.defer_wgrad_reductions()
         params = self.d_params if which == "d" else self.g_params
         overlap = (self.distributed and deferring and len(params.buckets) > 1 and not self._capturing()
                    and not getattr(self, "_warming_up", False))
@@ -849,6 +863,8 @@ class GANSynth(object):
             if big is not None:
                 self._early_in_run = 0
                 K.early_flush_rule(big, self._early_flush)
+        if deferring and which == "d":
+            self._arm_first_bucket(K, params)
         launched = []
         if hasattr(F, "reset_fusion_state"):
             F.reset_fusion_state()   # (side-channel state of cross-node fusions is per backward pass)
@@ -919,9 +935,71 @@ class GANSynth(object):
         if self.distributed and self._comm is not None and self._graph_allreduce and self._capturing() and not getattr(self, "_pipe_capture", False):
             # Same-stream RCCL is capturable: the all-reduce of this run's flat gradient becomes the LAST NODE of the run's hipGraph, so
             # a replayed run hands over reduced gradients and no eager collective launch sits between the replay and the update.
-            self._reduce_in_capture(params)
+            split, self._split_at = self._split_at, None
+            if self._first_bucket_stream is not None:
+                torch.cuda.current_stream().wait_stream(self._first_bucket_stream)
+                self._first_bucket_stream = None
+            if split:   # (the middle of the buffer went out behind the grouped contractions, _first_bucket_behind_groups: its two ends now)
+                for a, b in ((0, split[0]), (split[1], params.grad.numel())):
+                    if b > a:
+                        self._comm.all_reduce_(params.grad[a:b], marker_share=(b - a) / params.grad.numel())
+            else:
+                self._reduce_in_capture(params)
             self._captured_reduce = True
         return loss.detach()
+
+    def _arm_first_bucket(self, K, params):
+        """Data parallel, captured discriminator run (`bucket_d_reduce`; GS_NO_DP_BUCKET_D=1: one message): the all-reduce of the gradient in two steps.
+        The layers with >= 128 input channels (and the one-channel slice of the last block's conv) hold ~90 % of the bytes and sit at the BOTTOM of
+        the pyramid: every pass of the backward is done with them long before it ends.  kernels.complete_rule tells when the last of their pairs
+        is recorded; their contraction then runs on the branch (as the early contraction of the large layers does), and behind it, on the branch
+        as well, the all-reduce of the largest range of the flat buffer that holds none of the OTHER layers' gradients -- beside the rest of the
+        backward and the final contraction.  What is left on either side of that range follows where the one message went."""
+        self._split_at, self._first_bucket_stream = None, None
+        if not (self.bucket_d_reduce and self.distributed and self._comm is not None and self._graph_allreduce and self._capturing()
+                and not self._pipe_capture and hasattr(K, "complete_rule")):
+            return
+        pred = lambda key: int(key[5][0]) >= 128 or int(key[5][0]) == 1   # (key: kernels._defer_wgrad; [5] = the conv input's (channels, h, w))
+        named = list(params.named.items())
+        sibling = {}   # weight gradient -> its bias gradient (a layer's bias follows its weight; it is complete when the layer is)
+        for (name, p), (name2, p2) in zip(named, named[1:]):
+            if name.endswith("/weight") and name2 == name[:-len("weight")] + "bias":
+                sibling[p.grad.data_ptr()] = p2.grad
+        base, size, total = params.grad.data_ptr(), params.grad.element_size(), params.grad.numel()
+
+        def on_complete(select, others):
+            def then():
+                K.flush_bias_folds()
+                spans = []
+                for out, bias in others:
+                    for t in (out, bias, sibling.get(out.data_ptr())):
+                        if t is not None:
+                            a, b = K._span(t)
+                            spans.append(((a - base) // size, (b - base + size - 1) // size))
+                if any(not (0 <= a < b <= total) for a, b in spans):
+                    return   # (a gradient outside the flat buffer: the one message at the end)
+                edges, at = [], 0
+                for a, b in sorted(spans):
+                    edges.append((at, max(at, a)))
+                    at = max(at, b)
+                edges.append((at, total))
+                first = max(edges, key=lambda e: e[1] - e[0])
+                if first[1] - first[0] > 0:
+                    self._split_at = self.first_bucket = first
+                    if config.flag("GS_DEBUG_DP_BUCKET"):
+                        print("first bucket", first, "of", total, "behind", sum(1 for _ in others), "other layers", flush=True)
+                    # on a stream of its own, behind the contraction just issued: the branch goes on to the final contraction's thin layers, and
+                    # nothing of this run waits for the message before the messages at the end do (_part_b)
+                    done = torch.cuda.Event()
+                    done.record()
+                    cur = torch.cuda.current_stream()
+                    third = self._second_stream("_side3", [cur, self._origin, self._side, self._side2])
+                    third.wait_event(done)
+                    with torch.cuda.stream(third):
+                        self._comm.all_reduce_(params.grad[first[0]:first[1]], marker_share=(first[1] - first[0]) / total)
+                    self._first_bucket_stream = third
+            self._early_flush(select, then=then)
+        K.complete_rule(pred, on_complete)
 
     def _join_branches(self):
         """The current stream waits for every branch this run opened: the side stream (every branch was joined where it closed, except the

@@ -798,6 +798,71 @@ def test_hipgraph_replay_in_a_fade_in_regime(gpu_store):
     _same_up_to_accumulation_order(out[False][2], out[True][2], "generator parameters")
 
 
+def test_discriminator_gradient_all_reduced_in_two_steps():
+    """models.GANSynth._arm_first_bucket (data parallel, one graph per iteration; world size 1 on the library's RCCL communicator): the layers of the
+    lower pyramid are complete long before the backward ends (kernels.complete_rule counts their pairs against the previous pass), their
+    contraction runs on the branch and the part of the flat gradient that holds none of the other layers' gradients -- 98 % of it at
+    BASELINE.json configs[1] -- goes on the wire behind it, beside the rest of the backward; the two ends follow behind the final contraction.
+    Same gradients as the one-message form up to the association of the regrouped contractions (both learning rates at zero, so that nothing
+    amplifies a last bit: the gradient buffers of three iterations), the first message covers the range it should, and with 300-us stand-ins
+    for the collectives the iteration is shorter than with one message."""
+    import time
+    import torch.distributed as dist
+    from gansynth_amd.utils import Dict
+    hyper = Dict(R.DEFAULT_HYPER)
+    hyper.generator_learning_rate = hyper.discriminator_learning_rate = 0.0
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % (29400 + os.getpid() % 500), rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        batches = [R.synthetic_batch(8, rank=i, image_shape=(2, 128, 1024)) for i in range(2)]
+        out, ms = {}, {}
+        for two_step in (True, False):
+            model = _dp_trainer(1.0, batches, full=True, dtype=torch.bfloat16, keep=True, hyper=hyper)
+            model.bucket_d_reduce = two_step
+            losses, grads = [], []
+            for _ in range(3):
+                losses.append(tuple(float(x) for x in model.train_step()))
+                model.synchronize()
+                grads.append((model.d_params.grad.clone(), model.g_params.grad.clone()))
+            out[two_step] = (losses, grads, None, model.first_bucket, bool(model._merged and model._merged.get("fused")))
+            total = model.d_params.grad.numel()
+            names = list(model.d_params.named.items())
+            if two_step:
+                lo, hi = model.first_bucket
+                base = model.d_params.grad.data_ptr()
+                inside = [n for n, p in names if lo <= (p.grad.data_ptr() - base) // 4 and (p.grad.data_ptr() - base) // 4 + p.numel() <= hi]
+            model._comm.set_marker_us(300.0)   # (stand-ins are read when a launch is captured: new graphs)
+            model._merged = None
+            model._graphs.clear()
+            for _ in range(3):
+                model.train_step()
+            model.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                model.train_step()
+            model.synchronize()
+            ms[two_step] = (time.perf_counter() - t0) / 20 * 1e3
+            model._comm.set_marker_us(-1.0)
+            del model
+        assert out[True][4] and out[False][4], "one graph per iteration expected"
+        assert out[False][3] is None
+        lo, hi = out[True][3]
+        assert hi - lo > 0.9 * total, (lo, hi, total)
+        assert any("conv_block_2x16/dense/weight" in n for n in inside) and any("conv_block_16x128/conv/weight" in n for n in inside)
+        assert not any(("128x1024" in n or "conv_block_64x512" in n) for n in inside), inside
+        assert out[True][0] == out[False][0], (out[True][0], out[False][0])   # (the weights never move: the forward passes are the same launches)
+        for it, (ga, gb) in enumerate(zip(out[True][1], out[False][1])):
+            for k, name in ((0, "discriminator"), (1, "generator")):
+                err = float((ga[k] - gb[k]).abs().max()) / float(gb[k].abs().max())
+                assert err <= 2e-5, (it, name, err)   # (fp32 sums of the same bf16 products, grouped differently)
+            assert torch.equal(ga[1], gb[1]), "the generator run's launches do not change"
+        print("ms per iteration with 300-us stand-ins: two steps %.3f, one message %.3f" % (ms[True], ms[False]))
+        assert ms[True] < ms[False] - 0.05, ms
+    finally:
+        dist.destroy_process_group()
+
+
 def test_distributed_step_on_rccl_world_size_1():
     """The data-parallel path on the real collective backend: torch.distributed backend "nccl" (= RCCL on ROCm) with ONE rank --
     the only world size this box has.  Bucketed gradient all-reduce (16 KiB buckets: many collectives per run, launched from the
@@ -1131,10 +1196,10 @@ def test_replayed_iterations_reproduce_the_eager_gradients(gpu_store, full, dtyp
         del model
 
 
-def _dp_trainer(level, batches, full=False, dtype=torch.float32, distributed=True, graphs=True, keep=True):
+def _dp_trainer(level, batches, full=False, dtype=torch.float32, distributed=True, graphs=True, keep=True, hyper=None):
     from gansynth_amd import variables
     variables.set_default_store(variables.VariableStore(device="cuda"))
-    pg, opg, model = make(level, variables.default_store(), full=full, dtype=dtype)
+    pg, opg, model = make(level, variables.default_store(), full=full, dtype=dtype, hyper=hyper)
     model.keep_gradients = keep
     model.distributed, model.world, model.use_graphs = distributed, 1, graphs
     cur = [0]
@@ -1211,6 +1276,7 @@ def test_gradient_all_reduce_rides_beside_part_a_of_the_other_run():
                 os.environ["GS_COMM_MARKER_US"] = str(marker)
                 model = _dp_trainer(1.0, batches, full=True, dtype=torch.bfloat16, keep=False)
                 model.overlap_reduce = mode == "overlapped"
+                model.bucket_d_reduce = False               # (one message per gradient: what this test prices; the two-step form has its own test)
                 model.fuse_iteration = mode == "one graph"   # (round 6: the iteration as ONE graph, the generator's all-reduce at the front of the NEXT
                                                              #  iteration's fake pass, issued first -- part of it disappears behind the real pass)
                 for _ in range(3):
