@@ -726,10 +726,9 @@ def assemble(args, world, distributed, elapsed, prof_steps, family, stages, kern
 # warm-up") after each attempt.  If ANY worker failed or stalled, EVERY supervisor kills its worker and all of them start the next,
 # tamer mode together on a fresh rendezvous port:
 DP_LADDER = [
-    ("graph-one", {}),                                                    # ONE graph per iteration, optimizer steps inside; D's all-reduce in two steps (most of it beside the end of its backward), G's at the front of the next fake pass (round 6 default)
-    ("graph-one-single-message", {"GS_NO_DP_BUCKET_D": "1"}),             # the same with D's all-reduce as one message behind its backward
-    ("graph-serial", {"GS_NO_FUSED_ITERATION": "1", "GS_NO_DP_BUCKET_D": "1"}),   # two graphs, each all-reduce the last node of its run's graph; compute branches inside (round 5 default)
-    ("graph-overlapped", {"GS_OVERLAP_REDUCE": "1", "GS_NO_DP_BUCKET_D": "1"}),   # all-reduce beside part A of the other run, four graphs, no compute branches (round 4 default)
+    ("graph-one", {}),                                                    # ONE graph per iteration, optimizer steps inside; D's all-reduce behind its backward, G's at the front of the next fake pass (round 6 default)
+    ("graph-serial", {"GS_NO_FUSED_ITERATION": "1"}),                      # two graphs, each all-reduce the last node of its run's graph; compute branches inside (round 5 default)
+    ("graph-overlapped", {"GS_OVERLAP_REDUCE": "1"}),                      # all-reduce beside part A of the other run, four graphs, no compute branches (round 4 default)
     ("eager-same-stream", {"GS_NO_GRAPH_ALLREDUCE": "1"}),                 # eager all-reduce behind each replay, own communicator
     ("eager-torch-distributed", {"GS_NO_GRAPH_ALLREDUCE": "1", "GS_TORCH_COLLECTIVES": "1"}),   # torch.distributed's communicator
 ]
@@ -773,7 +772,7 @@ def supervise(args, argv):
         dist.broadcast(port, 0)   # a fresh rendezvous for the workers of this attempt
         rd, wr = os.pipe()
         env = {k: v for k, v in os.environ.items() if k not in ("TORCHELASTIC_USE_AGENT_STORE", "TORCHELASTIC_RUN_ID")}
-        for k in ("GS_OVERLAP_REDUCE", "GS_NO_OVERLAP_REDUCE", "GS_NO_GRAPH_ALLREDUCE", "GS_TORCH_COLLECTIVES", "GS_NO_FUSED_ITERATION", "GS_NO_DP_BUCKET_D"):
+        for k in ("GS_OVERLAP_REDUCE", "GS_NO_OVERLAP_REDUCE", "GS_NO_GRAPH_ALLREDUCE", "GS_TORCH_COLLECTIVES", "GS_NO_FUSED_ITERATION", "GS_DP_BUCKET_D"):
             env.pop(k, None)
         env.update(knobs, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(int(port[0])), GS_STATUS_FD=str(wr), GS_DP_MODE=mode,
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))

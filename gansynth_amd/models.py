@@ -312,7 +312,7 @@ class GANSynth(object):
         self.fork_marks = not config.flag("GS_NO_FORK_MARKS")   # (debugging: branches start where they are opened)
         self._side = None
         self._side2 = None        # the stream of a whole sub-run beside another run (_train_step_merged)
-        self.bucket_d_reduce = not config.flag("GS_NO_DP_BUCKET_D")   # (data parallel, captured discriminator run: _arm_first_bucket)
+        self.bucket_d_reduce = config.flag("GS_DP_BUCKET_D")   # (data parallel, captured discriminator run, opt-in: _arm_first_bucket)
         self.first_bucket = None  # (the range of the flat gradient the first message of the last captured discriminator run covers)
         self._split_at = None     # (see _arm_first_bucket)
         self._first_bucket_stream = None
@@ -949,7 +949,9 @@ class GANSynth(object):
         return loss.detach()
 
     def _arm_first_bucket(self, K, params):
-        """Data parallel, captured discriminator run (`bucket_d_reduce`; GS_NO_DP_BUCKET_D=1: one message): the all-reduce of the gradient in two steps.
+        """Data parallel, captured discriminator run, OPT-IN (`bucket_d_reduce`, GS_DP_BUCKET_D=1): the all-reduce of the gradient in two steps.
+        (Opt-in because of what it measured, DESIGN.md 7: with 300-us stand-ins for the collectives -0.09 ... -0.14 ms fully grown, +0.15 ms in a
+        fade-in regime, +0.03 with 150-us ones.)
         The layers with >= 128 input channels (and the one-channel slice of the last block's conv) hold ~90 % of the bytes and sit at the BOTTOM of
         the pyramid: every pass of the backward is done with them long before it ends.  kernels.complete_rule tells when the last of their pairs
         is recorded; their contraction then runs on the branch (as the early contraction of the large layers does), and behind it, on the branch

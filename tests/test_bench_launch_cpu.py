@@ -134,8 +134,8 @@ def test_call_log_prices_the_non_conv_families(cpu_backend):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("stall_in,stall_rank,expect", [(None, 0, "graph-one"), ("graph-one", 1, "graph-one-single-message"),
-                                                        ("graph-one,graph-one-single-message,graph-serial,graph-overlapped", 0, "eager-same-stream")])
+@pytest.mark.parametrize("stall_in,stall_rank,expect", [(None, 0, "graph-one"), ("graph-one", 1, "graph-serial"),
+                                                        ("graph-one,graph-serial,graph-overlapped", 0, "eager-same-stream")])
 def test_first_contact_ladder_over_gloo(stall_in, stall_rank, expect):
     """N > 1 cannot hang.  Every rank process is a supervisor (gloo, no GPU) around a `--worker` child; a worker
     that stalls before the end of its warm-up (simulated: one rank sleeps in the named modes) is noticed by its supervisor's watchdog,

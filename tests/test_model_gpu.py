@@ -863,9 +863,9 @@ def test_discriminator_gradient_all_reduced_in_two_steps(level):
             assert torch.equal(ga[1], gb[1]), "the generator run's launches do not change"
         print("level %s: first message %s of %d floats; ms per iteration with 300-us stand-ins: two steps %.3f, one message %.3f"
               % (level, out[True][3], total, ms[True], ms[False]))
-        # (what the stand-ins cost is REPORTED: 5.92 against 6.05 ms in one process, 5.87 against 5.89 in another -- which chains of a replayed graph
-        #  share a hardware queue depends on the stream pool's history; never slower with 300-us stand-ins)
-        assert ms[True] < ms[False] + 0.1, ms
+        # (what the stand-ins cost is REPORTED, not asserted: fully grown 5.92 against 6.05 ms in one process, 5.87 against 5.89 in another -- which
+        #  chains of a replayed graph share a hardware queue depends on the stream pool's history -- and in the fade-in regime 6.24 against 6.09:
+        #  the form is opt-in)
     finally:
         dist.destroy_process_group()
 
@@ -1283,7 +1283,6 @@ def test_gradient_all_reduce_rides_beside_part_a_of_the_other_run():
                 os.environ["GS_COMM_MARKER_US"] = str(marker)
                 model = _dp_trainer(1.0, batches, full=True, dtype=torch.bfloat16, keep=False)
                 model.overlap_reduce = mode == "overlapped"
-                model.bucket_d_reduce = False               # (one message per gradient: what this test prices; the two-step form has its own test)
                 model.fuse_iteration = mode == "one graph"   # (round 6: the iteration as ONE graph, the generator's all-reduce at the front of the NEXT
                                                              #  iteration's fake pass, issued first -- part of it disappears behind the real pass)
                 for _ in range(3):
