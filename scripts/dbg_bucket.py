@@ -1,5 +1,7 @@
+"""Data parallel at world size 1 (the library's RCCL communicator): a few full-size iterations with the discriminator's all-reduce in two steps
+(GS_DP_BUCKET_D=1); GS_DEBUG_DP_BUCKET=1 prints the range the first message covers.  usage: GS_DP_BUCKET_D=1 GS_DEBUG_DP_BUCKET=1 python scripts/dbg_bucket.py"""
 import os, sys
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, torch.distributed as dist
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29477", rank=0, world_size=1, device_id=torch.device("cuda", 0))
